@@ -1,0 +1,268 @@
+"""Generate tests/golden/* by running the REAL reference (build container only).
+
+    python oracle/make_golden.py [--curve]     # --curve adds the 100-step loss curve (~8 min CPU)
+
+Each fixture stores inputs (or the recipe that regenerates them) and the reference's outputs.
+Nothing of the reference's source travels; the vectors are data.  See SURVEY.md section 8c (F1-F6).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shim                      # noqa: E402
+import recipes                       # noqa: E402
+import sarssl_oracle as orc          # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def manifest_of(module):
+    return {k: list(v.shape) for k, v in module.state_dict().items()}
+
+
+def load_recipe(module, seed):
+    man = manifest_of(module)
+    sd = recipes.recipe_state_dict(man, seed)
+    module.load_state_dict(sd)
+    return man
+
+
+def set_dropout(module, p):
+    for m in module.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = p
+
+
+def grads_of(module):
+    return {k: p.grad.detach().clone() for k, p in module.named_parameters()}
+
+
+def sample_idx(numel, n, seed):
+    g = np.random.default_rng(seed)
+    return np.sort(g.choice(numel, size=min(n, numel), replace=False)).astype(np.int64)
+
+
+def f_manifest(ref_model):
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    ds = ref_model.SARSSL(sig_shape=(256, 64, 2, 2), pretrain=False, device="cpu", downstream_token="all",
+                          downstream_head="mlp", downstream_embed="spat", downstream_dlabel=1)
+    out = {"pretrain": manifest_of(net), "downstream": manifest_of(ds),
+           "nparams_pretrain": int(sum(p.numel() for p in net.parameters()))}
+    with open(os.path.join(GOLD, "state_dict_manifest.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    return net
+
+
+def f1_frontend(ref_learner, ref_model):
+    dummy = torch.nn.Linear(1, 1)
+    lrn = ref_learner.STFTLearner(dummy, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1,
+                                  fs=16000, task=None, ch_mode="M")
+    lrn.device = "cpu"
+    small = recipes.recipe_signal(2, 2048, 2, seed=1)
+    out_small, = lrn.data_preprocess(small, None)
+    small4 = recipes.recipe_signal(2, 1536, 4, seed=2)
+    out_small4, = lrn.data_preprocess(small4, None)
+    full = recipes.recipe_signal(2, 65792, 2, seed=3)
+    out_full, = lrn.data_preprocess(full, None)
+    idx = sample_idx(out_full.numel(), 4096, 11)
+    stft_raw = lrn.stft(signal=small)     # (B, 257, nt, nch) complex
+    np.savez_compressed(
+        os.path.join(GOLD, "f1_frontend.npz"),
+        small_out=out_small.numpy(), small4_out=out_small4.numpy(),
+        small_stft_re=stft_raw.real.numpy(), small_stft_im=stft_raw.imag.numpy(),
+        full_idx=idx, full_vals=out_full.reshape(-1)[idx].numpy(),
+        full_sum=np.float64(out_full.double().sum()), full_sumsq=np.float64((out_full.double() ** 2).sum()),
+        full_shape=np.array(out_full.shape))
+
+
+def f2_blocks(ref_model):
+    sys.path.insert(0, ref_shim.REF_CODE)
+    from common.conformer.feed_forward import FeedForwardModule
+    from common.conformer.attention import MultiHeadedSelfAttentionModule, RelativeMultiHeadAttention
+    from common.conformer.convolution import ConformerConvModule
+    from common.Conformer import ConformerBlock, ConformerEncoder
+    store = {}
+    meta = {}
+
+    def run(name, module, x, seed, fwd=None):
+        man = load_recipe(module, seed)
+        meta[name] = man
+        set_dropout(module, 0.0)
+        for mode in ("eval", "train"):
+            module.train(mode == "train")
+            module.load_state_dict(recipes.recipe_state_dict(man, seed))
+            xi = x.clone().requires_grad_(True)
+            module.zero_grad()
+            y = fwd(module, xi) if fwd else module(xi)
+            gy = torch.from_numpy(np.random.default_rng(seed + 77).standard_normal(tuple(y.shape)).astype(np.float32))
+            (y * gy).sum().backward()
+            store["%s.%s.y" % (name, mode)] = y.detach().numpy()
+            store["%s.%s.dx" % (name, mode)] = xi.grad.numpy()
+            for k, g in grads_of(module).items():
+                store["%s.%s.grad.%s" % (name, mode, k)] = g.numpy()
+            if mode == "train":
+                for k, v in module.state_dict().items():
+                    if k.endswith(("running_mean", "running_var")):
+                        store["%s.train.after.%s" % (name, k)] = v.detach().clone().numpy()
+        store["%s.x" % name] = x.numpy()
+        store["%s.gy" % name] = gy.numpy()
+
+    g = np.random.default_rng(5)
+    d, T, B = 32, 16, 3
+    x = torch.from_numpy(g.standard_normal((B, T, d)).astype(np.float32))
+    run("ffn", FeedForwardModule(encoder_dim=d, expansion_factor=4, dropout_p=0.1), x, 21)
+    run("mhsa", MultiHeadedSelfAttentionModule(d_model=d, num_heads=4, dropout_p=0.1), x, 22)
+    run("convmod", ConformerConvModule(in_channels=d, kernel_size=31, expansion_factor=2, dropout_p=0.1), x, 23)
+    run("block", ConformerBlock(encoder_dim=d, num_attention_heads=4), x, 24)
+    run("encoder2", ConformerEncoder(encoder_dim=d, num_layers=2, num_attention_heads=4), x, 25,
+        fwd=lambda m, xi: m(xi, False))
+    # T longer than the depthwise kernel so both conv borders and the interior are exercised
+    x40 = torch.from_numpy(g.standard_normal((2, 40, d)).astype(np.float32))
+    run("block_T40", ConformerBlock(encoder_dim=d, num_attention_heads=4), x40, 26)
+    # EmbedEncoder at reduced size: F=16, T=8
+    Fq, Tq = 16, 8
+    enc = ref_model.EmbedEncoder(sig_shape=[Fq, Tq, 2, 2], patch_shape=(Fq, 1), dembed=32,
+                                 model=["cnn", "conformer"], mode="spat", device="cpu")
+    xe = torch.from_numpy(g.standard_normal((B, Tq, Fq * 4)).astype(np.float32))
+    run("embed_encoder", enc, xe, 27, fwd=lambda m, xi: m.forward(xi))
+    dec = ref_model.EmbedDecoder(sig_shape=[Fq, Tq, 2, 2], patch_shape=(Fq, 1), dembed=48, model=["", "fc"])
+    xd = torch.from_numpy(g.standard_normal((B, Tq, 48)).astype(np.float32))
+    run("embed_decoder", dec, xd, 28, fwd=lambda m, xi: m.forward(xi))
+    # relative-shift tables
+    rel = RelativeMultiHeadAttention(d_model=8, num_heads=2)
+    for T_ in (4, 5, 7):
+        ps = torch.arange(T_ * T_, dtype=torch.float32).reshape(1, 1, T_, T_)
+        store["relshift.T%d" % T_] = rel._relative_shift(ps)[0, 0].numpy()
+    store["meta_json"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(GOLD, "f2_blocks.npz"), **store)
+
+
+def f3_fullsize(ref_model, ref_learner):
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    man = load_recipe(net, 0)
+    set_dropout(net, 0.0)
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1,
+                                  fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    sig = recipes.recipe_signal(2, 65792, 2, seed=3)
+    x, = lrn.data_preprocess(sig, None)
+    store = {}
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        net.load_state_dict(recipes.recipe_state_dict(man, 0))
+        net.zero_grad()
+        random.seed(4321)
+        idx, ch = orc.gen_masks(2, 256, 128, 2, random)     # same call order as PatchMask.forward
+        random.seed(4321)
+        loss, diff, vis = net(x)
+        loss.backward()
+        pred_patch = vis["pred"].permute(0, 2, 1, 3, 4).contiguous()     # (B,T,F,reim,mic)
+        sidx = sample_idx(pred_patch.numel(), 2048, 13)
+        store["%s.loss" % mode] = np.float64(loss.item())
+        store["%s.diff" % mode] = np.float64(diff.item())
+        store["%s.pred_idx" % mode] = sidx
+        store["%s.pred_vals" % mode] = pred_patch.reshape(-1)[sidx].numpy()
+        store["%s.pred_absmax" % mode] = np.float64(pred_patch.abs().max())
+        # the dense mask of the reference tells us which channel/frames it masked: check vs oracle masks
+        m = vis["mask"]                                                   # (B,F,T,mic), 0 = masked
+        masked_ch = (m[:, 0].sum(dim=1)).argmin(dim=1)                    # (B,)
+        assert torch.equal(masked_ch, ch), "mask channel order mismatch"
+        mf = [(m[b, 0, :, int(ch[b])] == 0).nonzero().flatten() for b in range(2)]
+        for b in range(2):
+            assert torch.equal(mf[b], torch.sort(idx[b]).values), "mask frame set mismatch"
+        gn = {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}
+        store["%s.gradnorm_json" % mode] = np.array(json.dumps(gn))
+        if mode == "train":
+            for k in ("spec_encoder.patch_embed.4.running_mean", "spec_encoder.patch_embed.4.running_var",
+                      "spat_encoder.embed.layers.1.sequential.2.module.sequential.5.running_var"):
+                store["train.after." + k] = net.state_dict()[k].numpy().copy()
+    store["mask_idx"] = idx.numpy()
+    store["mask_ch"] = ch.numpy()
+    np.savez_compressed(os.path.join(GOLD, "f3_fullsize.npz"), **store)
+
+
+def f4_masks(ref_um):
+    store = {}
+    for seed in (0, 7, 123456):
+        pm = ref_um.PatchMask(patch_mode="T", nmasked_patch=128, npatch_shape=[1, 256], device="cpu")
+        random.seed(seed)
+        _, _, _, idx, ch = pm.forward((4, 256, 256, 2, 2))
+        store["seed%d.idx" % seed] = idx.numpy()
+        store["seed%d.ch" % seed] = ch.numpy()
+    np.savez_compressed(os.path.join(GOLD, "f4_masks.npz"), **store)
+
+
+def f7_downstream(ref_model):
+    ds = ref_model.SARSSL(sig_shape=(256, 64, 2, 2), pretrain=False, device="cpu", downstream_token="all",
+                          downstream_head="mlp", downstream_embed="spat", downstream_dlabel=1)
+    load_recipe(ds, 5)
+    ds.eval()
+    g = np.random.default_rng(99)
+    x = torch.from_numpy(g.standard_normal((2, 2, 256, 64, 2)).astype(np.float32))
+    with torch.no_grad():
+        pred, emb = ds(x)
+    np.savez_compressed(os.path.join(GOLD, "f7_downstream.npz"), pred=pred.numpy(), embed=emb.numpy())
+
+
+def f8_schedule():
+    sys.path.insert(0, ref_shim.REF_CODE)
+    from common.utils import create_learning_rate_schedule
+    fn = create_learning_rate_schedule(total_steps=30, base=0.001, decay_type="cosine", warmup_steps=1, linear_end=1e-6)
+    lrs = np.array([float(fn(e)) for e in range(1, 31)], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "f8_schedule.npz"), lr=lrs)
+
+
+def f5_curve(ref_model, ref_learner, nstep=100, B=8):
+    from sar_ssl_amd import synth
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    load_recipe(net, 0)
+    set_dropout(net, 0.0)
+    net.train()
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1,
+                                  fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    pool = torch.from_numpy(synth.make_batch(0, 64))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0)   # learner.py:83
+    losses, diffs = [], []
+    for s in range(nstep):
+        sig = pool[(s * B) % 64:(s * B) % 64 + B]
+        x, = lrn.data_preprocess(sig, None)
+        random.seed(9000 + s)
+        loss, diff, _ = net(x)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item()); diffs.append(diff.item())
+        print("step", s, losses[-1], diffs[-1], flush=True)
+        np.savez_compressed(os.path.join(GOLD, "f5_curve.npz"), loss=np.array(losses), diff=np.array(diffs),
+                            B=B, lr=1e-3, mask_seed_base=9000, pool=64, weight_seed=0)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--curve", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(GOLD, exist_ok=True)
+    ref_model, ref_learner, ref_um = ref_shim.load()
+    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8"]
+    if "manifest" in todo: f_manifest(ref_model)
+    if "f1" in todo: f1_frontend(ref_learner, ref_model)
+    if "f2" in todo: f2_blocks(ref_model)
+    if "f3" in todo: f3_fullsize(ref_model, ref_learner)
+    if "f4" in todo: f4_masks(ref_um)
+    if "f7" in todo: f7_downstream(ref_model)
+    if "f8" in todo: f8_schedule()
+    if a.curve: f5_curve(ref_model, ref_learner)
+    print("golden vectors written to", GOLD)

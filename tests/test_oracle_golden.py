@@ -1,0 +1,159 @@
+"""CPU: the oracle restatement (oracle/sarssl_oracle.py) against golden vectors produced by the
+REAL reference (oracle/make_golden.py).  fp32 on both sides -> tight tolerances."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import recipes
+import sarssl_oracle as orc
+from conftest import GOLD
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    tol = atol + rtol * b.abs().max().item()
+    assert err <= tol, "max err %.3e > tol %.3e" % (err, tol)
+
+
+def test_f1_frontend_small_and_multichannel():
+    z = _npz("f1_frontend.npz")
+    small = recipes.recipe_signal(2, 2048, 2, seed=1)
+    X = orc.stft(small)
+    _close(X.real, z["small_stft_re"], 1e-5, 1e-5)
+    _close(X.imag, z["small_stft_im"], 1e-5, 1e-5)
+    _close(orc.data_preprocess(small), z["small_out"], 1e-5, 1e-6)
+    small4 = recipes.recipe_signal(2, 1536, 4, seed=2)
+    out4 = orc.data_preprocess(small4)
+    assert out4.shape[0] == 2 * 3
+    _close(out4, z["small4_out"], 1e-5, 1e-6)
+
+
+def test_f1_frontend_fullsize_samples():
+    z = _npz("f1_frontend.npz")
+    out = orc.data_preprocess(recipes.recipe_signal(2, 65792, 2, seed=3))
+    assert list(out.shape) == list(z["full_shape"]) == [2, 2, 256, 256, 2]
+    _close(out.reshape(-1)[torch.from_numpy(z["full_idx"])], z["full_vals"], 1e-5, 1e-6)
+    assert abs(out.double().sum().item() - float(z["full_sum"])) < 1e-2
+    assert abs((out.double() ** 2).sum().item() / float(z["full_sumsq"]) - 1) < 1e-5
+
+
+def test_relative_shift_tables():
+    z = _npz("f2_blocks.npz")
+    for T in (4, 5, 7):
+        ps = torch.arange(T * T, dtype=torch.float32).reshape(1, 1, T, T)
+        assert torch.equal(orc.relative_shift(ps)[0, 0], torch.from_numpy(z["relshift.T%d" % T]))
+    assert orc.relative_shift(torch.arange(16.).reshape(4, 4)).tolist() == \
+        [[3, 0, 4, 5], [6, 7, 0, 8], [9, 10, 11, 0], [12, 13, 14, 15]]
+
+
+def _run_block(name, fn, seed):
+    z = _npz("f2_blocks.npz")
+    meta = json.loads(str(z["meta_json"]))[name]
+    x0 = torch.from_numpy(z[name + ".x"])
+    gy = torch.from_numpy(z[name + ".gy"])
+    for mode in ("eval", "train"):
+        sd = recipes.recipe_state_dict(meta, seed)
+        params = {k: v.requires_grad_(True) for k, v in sd.items() if orc.is_param(k)}
+        x = x0.clone().requires_grad_(True)
+        y = fn(x, sd, mode == "train")
+        (y * gy).sum().backward()
+        _close(y.detach(), z["%s.%s.y" % (name, mode)], 2e-4, 2e-5)
+        _close(x.grad, z["%s.%s.dx" % (name, mode)], 5e-4, 1e-5)
+        for k, p in params.items():
+            _close(p.grad, z["%s.%s.grad.%s" % (name, mode, k)], 1e-3, 2e-5)
+        if mode == "train":
+            for k in meta:
+                if k.endswith(("running_mean", "running_var")):
+                    _close(sd[k], z["%s.train.after.%s" % (name, k)], 1e-4, 1e-6)
+
+
+def test_f2_ffn():
+    _run_block("ffn", lambda x, sd, tr: orc.feed_forward(x, sd, "sequential.", 0.0, tr), 21)
+
+
+def test_f2_mhsa():
+    _run_block("mhsa", lambda x, sd, tr: orc.mhsa(x, sd, "", 4, 0.0, tr), 22)
+
+
+def test_f2_conv_module():
+    _run_block("convmod", lambda x, sd, tr: orc.conv_module(x, sd, "sequential.", 0.0, tr), 23)
+
+
+def test_f2_block():
+    _run_block("block", lambda x, sd, tr: orc.conformer_block(x, sd, "", 4, 0.0, tr), 24)
+    _run_block("block_T40", lambda x, sd, tr: orc.conformer_block(x, sd, "", 4, 0.0, tr), 26)
+
+
+def test_f2_encoder2():
+    _run_block("encoder2", lambda x, sd, tr: orc.conformer_encoder(x, sd, "", 2, 4, 0.0, tr), 25)
+
+
+def test_f2_embed_encoder_and_decoder():
+    def enc(x, sd, tr):
+        B, T, _ = x.shape
+        return orc.embed_encoder(x.reshape(B, T, 16, 2, 2), sd, "", 3, tr, 0.0)
+    _run_block("embed_encoder", enc, 27)
+    _run_block("embed_decoder", lambda x, sd, tr: orc.decoder(x, sd, "proj."), 28)
+
+
+def test_f4_mask_rng_order():
+    z = _npz("f4_masks.npz")
+    for seed in (0, 7, 123456):
+        random.seed(seed)
+        idx, ch = orc.gen_masks(4, 256, 128, 2, random)
+        assert np.array_equal(idx.numpy(), z["seed%d.idx" % seed])
+        assert np.array_equal(ch.numpy(), z["seed%d.ch" % seed][:, 0])
+
+
+def test_f8_lr_schedule():
+    z = _npz("f8_schedule.npz")
+    got = [orc.cosine_lr(e, 30, 1e-3, 1) for e in range(1, 31)]
+    np.testing.assert_allclose(got, z["lr"], rtol=1e-6)
+    assert abs(got[0] - 1e-3) < 1e-9
+
+
+def test_f7_downstream():
+    z = _npz("f7_downstream.npz")
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["downstream"]
+    sd = recipes.recipe_state_dict(man, 5)
+    x = torch.from_numpy(np.random.default_rng(99).standard_normal((2, 2, 256, 64, 2)).astype(np.float32))
+    with torch.no_grad():
+        pred, emb = orc.sarssl_downstream_forward(x, sd, "spat", train=False)
+    _close(pred, z["pred"], 5e-4, 1e-5)
+    _close(emb, z["embed"], 5e-4, 1e-5)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_f3_fullsize_loss_pred_grads(mode):
+    z = _npz("f3_fullsize.npz")
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    sd = recipes.recipe_state_dict(man, 0)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if orc.is_param(k)}
+    assert sum(p.numel() for p in params.values()) == 17534224
+    x = orc.data_preprocess(recipes.recipe_signal(2, 65792, 2, seed=3))
+    idx, ch = torch.from_numpy(z["mask_idx"]), torch.from_numpy(z["mask_ch"])
+    loss, diff, aux = orc.sarssl_pretrain_forward(x, sd, idx, ch, train=(mode == "train"), p_drop=0.0)
+    loss.backward()
+    assert abs(loss.item() / float(z[mode + ".loss"]) - 1) < 1e-4          # north_star tolerance is 1e-3
+    assert abs(diff.item() / float(z[mode + ".diff"]) - 1) < 1e-5
+    pv = aux["pred"].detach().reshape(-1)[torch.from_numpy(z[mode + ".pred_idx"])]
+    _close(pv, z[mode + ".pred_vals"], 1e-4 * 0 + 2e-4, 1e-5)
+    gn = json.loads(str(z[mode + ".gradnorm_json"]))
+    for k, p in params.items():
+        ref = gn[k]
+        assert abs(p.grad.double().norm().item() - ref) <= 2e-3 * ref + 1e-7, k
+    if mode == "train":
+        for k in ("spec_encoder.patch_embed.4.running_mean", "spec_encoder.patch_embed.4.running_var",
+                  "spat_encoder.embed.layers.1.sequential.2.module.sequential.5.running_var"):
+            _close(sd[k], z["train.after." + k], 1e-4, 1e-6)
