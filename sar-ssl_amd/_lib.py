@@ -1,0 +1,41 @@
+"""ctypes binding of the C-ABI library (include/sarssl_hip.h).
+
+The HIP library is the product: there is no CPU/PyTorch fallback.  Importing this module never
+touches the GPU; calling any kernel without the built library (or on CPU tensors) raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsarssl_hip.so")
+_lib = None
+
+
+class SarsslHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SarsslHipError(
+                "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the product path)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.sarssl_last_error.restype = ctypes.c_char_p
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise SarsslHipError("%s failed (rc=%d): %s" % (what, rc, lib().sarssl_last_error().decode()))
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    check(fn(*args), name)
+
+
+c_void_p, c_int, c_long, c_float, c_ulonglong, c_double = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_ulonglong, ctypes.c_double)

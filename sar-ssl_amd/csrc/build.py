@@ -1,0 +1,58 @@
+"""Builds libsarssl_hip.so (gfx950) in-tree with hipcc.  No torch headers: the library is a plain
+C-ABI shared object (include/sarssl_hip.h) loaded through ctypes."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["api.hip", "gemm.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip"]
+LIB = os.path.join(HERE, "libsarssl_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    objs = []
+    jobs = []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(HERE, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-6000:]))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for w in ex.map(run, jobs):
+            if verbose and w.strip():
+                print(w[-3000:])
+    if force or jobs or _stale(LIB, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

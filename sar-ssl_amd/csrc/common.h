@@ -1,0 +1,127 @@
+// Shared device helpers for the SAR-SSL gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2 };
+
+// error plumbing (api.cpp owns the storage)
+extern "C" const char* sarssl_last_error();
+void sarssl_set_error(const char* fmt, ...);
+#define SARSSL_CHECK_LAUNCH(name)                                          \
+    do {                                                                   \
+        hipError_t e__ = hipGetLastError();                                \
+        if (e__ != hipSuccess) {                                           \
+            sarssl_set_error("%s: %s", name, hipGetErrorString(e__));      \
+            return -2;                                                     \
+        }                                                                  \
+    } while (0)
+#define SARSSL_REQUIRE(cond, name)                                         \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            sarssl_set_error("%s: requirement failed: %s", name, #cond);   \
+            return -1;                                                     \
+        }                                                                  \
+    } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    // round-to-nearest-even (NaN not special-cased: never produced on this path)
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float ld_f(const float* p) { return *p; }
+__device__ __forceinline__ float ld_f(const bf16* p) { return bf16_bits_to_f32(*(const uint16_t*)p); }
+__device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_f(bf16* p, float v) { *(uint16_t*)p = (uint16_t)f32_to_bf16_bits(v); }
+
+// 4-wide vector access (address must be 4-element aligned)
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 ld4(const bf16* p) {
+    uint2 u = *(const uint2*)p;
+    return make_float4(bf16_bits_to_f32(u.x & 0xffffu), __uint_as_float(u.x & 0xffff0000u),
+                       bf16_bits_to_f32(u.y & 0xffffu), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
+__device__ __forceinline__ void st4(bf16* p, float4 v) {
+    uint2 u;
+    u.x = f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16);
+    u.y = f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16);
+    *(uint2*)p = u;
+}
+// 8-wide
+struct f8 { float v[8]; };
+__device__ __forceinline__ f8 ld8(const float* p) {
+    f8 r; float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ f8 ld8(const bf16* p) {
+    uint4 u = *(const uint4*)p; f8 r;
+    r.v[0] = bf16_bits_to_f32(u.x & 0xffffu); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = bf16_bits_to_f32(u.y & 0xffffu); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = bf16_bits_to_f32(u.z & 0xffffu); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = bf16_bits_to_f32(u.w & 0xffffu); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st8(float* p, const f8& r) {
+    *(float4*)p = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    *(float4*)(p + 4) = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+__device__ __forceinline__ void st8(bf16* p, const f8& r) {
+    uint4 u;
+    u.x = f32_to_bf16_bits(r.v[0]) | (f32_to_bf16_bits(r.v[1]) << 16);
+    u.y = f32_to_bf16_bits(r.v[2]) | (f32_to_bf16_bits(r.v[3]) << 16);
+    u.z = f32_to_bf16_bits(r.v[4]) | (f32_to_bf16_bits(r.v[5]) << 16);
+    u.w = f32_to_bf16_bits(r.v[6]) | (f32_to_bf16_bits(r.v[7]) << 16);
+    *(uint4*)p = u;
+}
+
+// Split-bf16 ("precise") operand parts: x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi).
+// part 0 -> hi, part 1 -> lo.  For bf16 sources lo is exactly 0 and never requested.
+__device__ __forceinline__ uint32_t bf16_part_bits(float x, int part) {
+    uint32_t hi = f32_to_bf16_bits(x);
+    if (part == 0) return hi;
+    return f32_to_bf16_bits(x - bf16_bits_to_f32(hi));
+}
+
+// pack 8 floats -> 8 bf16 (uint4), selecting the hi or lo part
+__device__ __forceinline__ uint4 pack8_part(const f8& r, int part) {
+    uint4 u;
+    u.x = bf16_part_bits(r.v[0], part) | (bf16_part_bits(r.v[1], part) << 16);
+    u.y = bf16_part_bits(r.v[2], part) | (bf16_part_bits(r.v[3], part) << 16);
+    u.z = bf16_part_bits(r.v[4], part) | (bf16_part_bits(r.v[5], part) << 16);
+    u.w = bf16_part_bits(r.v[6], part) | (bf16_part_bits(r.v[7], part) << 16);
+    return u;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// counter-based dropout RNG: keep-decision for element `idx` of stream `seed`
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
+    uint32_t h = hash_u32((uint32_t)idx ^ hash_u32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9e3779b9u);
+    float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return (u >= p_drop) ? inv_keep : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

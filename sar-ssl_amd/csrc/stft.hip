@@ -1,0 +1,212 @@
+// Fused 2-channel real STFT front-end for gfx950.
+//
+// Replaces STFT.forward (code/common/utils_module.py:49-72) and the normalise / mic-pair /
+// drop-DC steps of STFTLearner.data_preprocess (code/learner.py:525-553).
+//
+// Two real channels are transformed by ONE complex FFT-512 (z = ch_a + i*ch_b, periodic Hann,
+// hop 256, center=False) and separated with the conjugate-symmetry identities.  One wave (64
+// lanes x 8 points) owns one frame: three radix-8 passes with two in-LDS exchanges
+// (n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3).  A 1024-thread workgroup = 16 consecutive
+// frames, so every (channel, bin) row is written as one 128-byte line.  HBM-bound: reads each
+// sample ~2x (50 % frame overlap, served from L2), writes 257 bins x 8 B per frame per channel.
+#include "common.h"
+
+#define NFFT 512
+#define HOP 256
+#define NBIN 257
+#define FR_PER_BLOCK 16
+#define ZSTRIDE 513   // float2 elements per wave buffer (padded)
+
+struct cpx { float x, y; };
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cpx mul_mi(cpx a) { return {a.y, -a.x}; }   // a * (-i)
+
+__device__ __forceinline__ void dft8(cpx* x) {
+    cpx a0 = cadd(x[0], x[4]), a4 = csub(x[0], x[4]), a2 = cadd(x[2], x[6]), a6 = mul_mi(csub(x[2], x[6]));
+    cpx a1 = cadd(x[1], x[5]), a5 = csub(x[1], x[5]), a3 = cadd(x[3], x[7]), a7 = mul_mi(csub(x[3], x[7]));
+    cpx b0 = cadd(a0, a2), b2 = csub(a0, a2), b4 = cadd(a4, a6), b6 = csub(a4, a6);
+    cpx b1 = cadd(a1, a3), b3 = mul_mi(csub(a1, a3)), b5 = cadd(a5, a7), b7 = csub(a5, a7);
+    const float s = 0.70710678118654752440f;
+    b5 = cmul(b5, cpx{s, -s});
+    b7 = cmul(b7, cpx{-s, -s});
+    x[0] = cadd(b0, b1); x[1] = cadd(b4, b5); x[2] = cadd(b2, b3); x[3] = cadd(b6, b7);
+    x[4] = csub(b0, b1); x[5] = csub(b4, b5); x[6] = csub(b2, b3); x[7] = csub(b6, b7);
+}
+// exp(-2*pi*i * num / den), den a power of two
+__device__ __forceinline__ cpx twiddle(int num, int den) {
+    float s, c;
+    sincospif(-2.0f * (float)(num & (den - 1)) / (float)den, &s, &c);
+    return {c, s};
+}
+__device__ __forceinline__ float ld_sample(const float* p) { return *p; }
+__device__ __forceinline__ float ld_sample(const int16_t* p) { return (float)(*p) * (1.0f / 32768.0f); }
+
+// U: (B, nch, 257, nt, 2) f32 unnormalised spectrum; magsum[b] += sum |X_ch0| over 257 bins x nt frames
+template <typename TIn>
+__global__ __launch_bounds__(1024) void stft_pair_kernel(const TIn* __restrict__ sig, long nsample, int nch, int nt,
+                                                         float* __restrict__ U, double* __restrict__ magsum) {
+    __shared__ float2 Z[FR_PER_BLOCK * ZSTRIDE];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x * FR_PER_BLOCK + wave;
+    const int pair = blockIdx.y, b = blockIdx.z;
+    const int c0 = pair * 2, c1 = pair * 2 + 1;
+    float2* zb = Z + wave * ZSTRIDE;
+    const bool live = t < nt;
+
+    cpx v[8];
+    if (live) {
+        const TIn* base = sig + ((long)b * nsample + (long)t * HOP) * nch;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = lane + 64 * j;
+            const float w = 0.5f - 0.5f * cospif((float)n * (1.0f / 256.0f));     // periodic Hann, N = 512
+            const float re = ld_sample(base + (long)n * nch + c0);
+            const float im = (c1 < nch) ? ld_sample(base + (long)n * nch + c1) : 0.f;
+            v[j] = {re * w, im * w};
+        }
+        dft8(v);                                                                   // over n1
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) {
+            cpx y = cmul(v[k1], twiddle(lane * k1, 512));
+            zb[k1 * 64 + lane] = make_float2(y.x, y.y);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int k1 = lane >> 3, n3 = lane & 7;
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) { float2 q = zb[k1 * 64 + n2 * 8 + n3]; v[n2] = {q.x, q.y}; }
+        dft8(v);                                                                   // over n2
+    }
+    __syncthreads();
+    if (live) {
+        const int k1 = lane >> 3, n3 = lane & 7;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            cpx y = cmul(v[k2], twiddle(n3 * k2, 64));
+            zb[k1 * 64 + k2 * 8 + n3] = make_float2(y.x, y.y);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int k2 = lane >> 3, k1 = lane & 7;
+#pragma unroll
+        for (int n3 = 0; n3 < 8; ++n3) { float2 q = zb[k1 * 64 + k2 * 8 + n3]; v[n3] = {q.x, q.y}; }
+        dft8(v);                                                                   // over n3
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) zb[lane + 64 * k3] = make_float2(v[k3].x, v[k3].y);
+    }
+    __syncthreads();
+
+    // separate the two real channels and write (c, f, t, reim); 16 frames = one 128-byte line per (c, f)
+    const int tl = tid & 15, fo = tid >> 4;
+    const int tt = blockIdx.x * FR_PER_BLOCK + tl;
+    float local = 0.f;
+    for (int f = fo; f < NBIN; f += 64) {
+        if (tt < nt) {
+            const float2 p = Z[tl * ZSTRIDE + f];
+            const float2 q = Z[tl * ZSTRIDE + ((NFFT - f) & (NFFT - 1))];
+            // X_a = (Z[f] + conj(Z[N-f]))/2 ; X_b = (Z[f] - conj(Z[N-f]))/(2i)
+            const float ar = 0.5f * (p.x + q.x), ai = 0.5f * (p.y - q.y);
+            const float br = 0.5f * (p.y + q.y), bi = -0.5f * (p.x - q.x);
+            float* oa = U + ((((long)b * nch + c0) * NBIN + f) * nt + tt) * 2;
+            *(float2*)oa = make_float2(ar, ai);
+            if (c1 < nch) {
+                float* ob = U + ((((long)b * nch + c1) * NBIN + f) * nt + tt) * 2;
+                *(float2*)ob = make_float2(br, bi);
+            }
+            if (pair == 0) local += sqrtf(ar * ar + ai * ai);
+        }
+    }
+    if (pair == 0) {
+        local = wave_sum(local);
+        if (lane == 0) red[wave] = local;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < 16; ++i) s += (double)red[i];
+            atomicAdd(&magsum[b], s);
+        }
+    }
+}
+
+// out[(b*(nch-1)+p), mic, f(256), t, reim] = U[b, mic ? p+1 : 0, f+1, t, reim] / (mean|X_ch0| + eps)
+__global__ void frontend_pack_kernel(const float* __restrict__ U, const double* __restrict__ magsum, int nb, int nch,
+                                     int nt, float eps, float* __restrict__ out) {
+    const long per_ch = (long)256 * nt;           // float2 elements per (pair, mic)
+    const long total = (long)nb * (nch - 1) * 2 * per_ch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long e = i % per_ch;
+        const long q = i / per_ch;
+        const int mic = (int)(q & 1);
+        const long bp = q >> 1;
+        const int p = (int)(bp % (nch - 1));
+        const int b = (int)(bp / (nch - 1));
+        const int c = mic ? p + 1 : 0;
+        const float scale = 1.0f / ((float)(magsum[b] / ((double)NBIN * nt)) + eps);
+        const float2 x = *(const float2*)(U + ((((long)b * nch + c) * NBIN) * nt + nt + e) * 2);   // skip DC row
+        *(float2*)(out + i * 2) = make_float2(x.x * scale, x.y * scale);
+    }
+}
+
+// complex64 (B, 257, nt, nch) view of U for the STFT.forward drop-in
+__global__ void stft_permute_kernel(const float* __restrict__ U, int nb, int nch, int nt, float* __restrict__ out) {
+    const long total = (long)nb * NBIN * nt * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        long r = i / nch;
+        const int t = (int)(r % nt); r /= nt;
+        const int f = (int)(r % NBIN);
+        const int b = (int)(r / NBIN);
+        const float2 x = *(const float2*)(U + ((((long)b * nch + c) * NBIN + f) * nt + t) * 2);
+        *(float2*)(out + i * 2) = x;
+    }
+}
+
+static int launch_stft(const void* sig, int sig_dtype, int nb, long nsample, int nch, int nt, float* U, double* magsum,
+                       hipStream_t st) {
+    if (hipMemsetAsync(magsum, 0, sizeof(double) * nb, st) != hipSuccess) { sarssl_set_error("stft: memset failed"); return -2; }
+    dim3 grid((nt + FR_PER_BLOCK - 1) / FR_PER_BLOCK, (nch + 1) / 2, nb);
+    if (sig_dtype == SARSSL_F32) stft_pair_kernel<float><<<grid, 1024, 0, st>>>((const float*)sig, nsample, nch, nt, U, magsum);
+    else if (sig_dtype == SARSSL_I16) stft_pair_kernel<int16_t><<<grid, 1024, 0, st>>>((const int16_t*)sig, nsample, nch, nt, U, magsum);
+    else { sarssl_set_error("stft: unsupported signal dtype %d", sig_dtype); return -1; }
+    SARSSL_CHECK_LAUNCH("stft_pair_kernel");
+    return 0;
+}
+
+// sig: (B, nsample, nch) f32 or int16 PCM.  U: workspace (B, nch, 257, nt, 2) f32.  magsum: (B) f64 workspace.
+// out: (B*(nch-1), 2, 256, nt, 2) f32 = data_preprocess output for ch_mode 'M'.
+extern "C" int sarssl_stft_frontend(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop,
+                                    int nfft, int nt, float eps, float* U, double* magsum, float* out, void* stream) {
+    SARSSL_REQUIRE(win_len == NFFT && nfft == NFFT && hop == HOP, "sarssl_stft_frontend(only win=nfft=512, hop=256)");
+    SARSSL_REQUIRE(nch >= 2 && nb > 0 && nt > 0 && (long)(nt - 1) * HOP + NFFT <= nsample, "sarssl_stft_frontend");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_stft(sig, sig_dtype, nb, nsample, nch, nt, U, magsum, st);
+    if (rc) return rc;
+    const long total = (long)nb * (nch - 1) * 2 * 256 * nt;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    frontend_pack_kernel<<<blocks, 256, 0, st>>>(U, magsum, nb, nch, nt, eps, out);
+    SARSSL_CHECK_LAUNCH("frontend_pack_kernel");
+    return 0;
+}
+
+// out: complex64 (B, 257, nt, nch) as interleaved f32 pairs.
+extern "C" int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop,
+                               int nfft, int nt, float* U, double* magsum, float* out, void* stream) {
+    SARSSL_REQUIRE(win_len == NFFT && nfft == NFFT && hop == HOP, "sarssl_stft_raw(only win=nfft=512, hop=256)");
+    SARSSL_REQUIRE(nch >= 1 && nb > 0 && nt > 0 && (long)(nt - 1) * HOP + NFFT <= nsample, "sarssl_stft_raw");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_stft(sig, sig_dtype, nb, nsample, nch, nt, U, magsum, st);
+    if (rc) return rc;
+    const long total = (long)nb * NBIN * nt * nch;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    stft_permute_kernel<<<blocks, 256, 0, st>>>(U, nb, nch, nt, out);
+    SARSSL_CHECK_LAUNCH("stft_permute_kernel");
+    return 0;
+}
