@@ -1,0 +1,394 @@
+// 3x3 / stride 1 / pad 1, 64 -> 64 channel convolution of the MC-Conformer CNN stem
+// (code/model.py:54-59) as implicit GEMM on bf16 MFMA, channels-last activations (B, F, T, 64).
+//
+//   conv3x3_fwd   : out[p][co] = sum_{tap,ci} W[tap][co][ci] * z[p + tap][ci],  z = prologue(in)
+//                   prologue = identity, or relu(in*scale[ci] + shift[ci]) (the previous
+//                   BatchNorm2d + ReLU applied while the tile is staged - they never cost an HBM
+//                   round trip).  The same kernel is the data-gradient with flipped/transposed
+//                   weights.
+//   conv3x3_wgrad : dW[tap][co][ci] = sum_p dy[p][co] * z[p + tap][ci]   (contraction over
+//                   pixels: both MFMA operands come from [pixel][channel] LDS tiles through the
+//                   gfx950 transpose read ds_read_b64_tr_b16).
+//
+// Persistent workgroups (one per CU, 8 waves): the 9x64x64 bf16 weight tensor (72 KiB) stays in
+// LDS for the whole launch next to an (8+2)x(64+2)-pixel input tile (82.5 KiB); tile t+1 is
+// prefetched into registers while tile t is on the matrix cores.  LDS tiles are [pixel][64 ch]
+// with the 16-byte chunk index XOR-swizzled by (pixel>>1)&7 so that the 16-lane groups of
+// ds_read_b128 / tr reads touch 16 distinct 16-byte slots.
+//
+// f32 ("precise") storage: operands are split hi/lo to bf16 at staging time and the host runs
+// three accumulating passes (see gemm.hip).
+#include "common.h"
+
+#define TR 8
+#define TCOL 64
+#define HR (TR + 2)
+#define HC (TCOL + 2)
+#define NPIX_H (HR * HC)            // 660 halo pixels
+#define NCHUNK_H (NPIX_H * 8)       // 5280 16-byte chunks
+#define X_ITERS 11                  // ceil(5280 / 512)
+#define W_ELEMS (9 * 64 * 64)
+#define X_ELEMS (NPIX_H * 64)
+#define Y_ELEMS (TR * TCOL * 64)
+
+struct ConvArgs {
+    const void* in; const void* w; void* out;
+    float* acc_ws; int acc_in, acc_out;
+    const float* scale; const float* shift; int prologue;
+    int nb, F, T;
+    int part_in, part_w;
+};
+
+__device__ __forceinline__ int swz(int p, int chunk) { return (p * 8 + (chunk ^ ((p >> 1) & 7))) * 8; }
+
+// raw chunk in registers: 8 channels of one pixel
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16> { uint4 u; };
+template <> struct Chunk<float> { f8 v; };
+
+template <typename T>
+__device__ __forceinline__ Chunk<T> load_chunk(const T* p, bool valid) {
+    Chunk<T> c;
+    if constexpr (sizeof(T) == 2) c.u = valid ? *(const uint4*)p : make_uint4(0, 0, 0, 0);
+    else {
+        if (valid) c.v = ld8(p);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c.v.v[e] = 0.f;
+        }
+    }
+    return c;
+}
+
+// prologue + (split) conversion to 8 bf16
+template <typename T>
+__device__ __forceinline__ uint4 xform_chunk(const Chunk<T>& c, bool valid, int prologue, const float* sc, const float* sh, int part) {
+    if (!valid) return make_uint4(0, 0, 0, 0);
+    if constexpr (sizeof(T) == 2) {
+        if (!prologue) return c.u;
+        f8 v;
+        v.v[0] = bf16_bits_to_f32(c.u.x & 0xffffu); v.v[1] = __uint_as_float(c.u.x & 0xffff0000u);
+        v.v[2] = bf16_bits_to_f32(c.u.y & 0xffffu); v.v[3] = __uint_as_float(c.u.y & 0xffff0000u);
+        v.v[4] = bf16_bits_to_f32(c.u.z & 0xffffu); v.v[5] = __uint_as_float(c.u.z & 0xffff0000u);
+        v.v[6] = bf16_bits_to_f32(c.u.w & 0xffffu); v.v[7] = __uint_as_float(c.u.w & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
+        return pack8_part(v, 0);
+    } else {
+        f8 v = c.v;
+        if (prologue) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
+        }
+        return pack8_part(v, part);
+    }
+}
+
+// halo-tile geometry helper: chunk q -> (pixel p, image coords, validity, global offset)
+struct TileCoord { int b, f0, t0; };
+__device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_f, int tiles_t) {
+    TileCoord c;
+    c.t0 = (tile % tiles_t) * TCOL; tile /= tiles_t;
+    c.f0 = (tile % tiles_f) * TR;
+    c.b = tile / tiles_f;
+    return c;
+}
+
+template <typename T, typename TW>
+__global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
+    __shared__ __attribute__((aligned(16))) uint16_t sX[X_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int F = a.F, Tn = a.T;
+    const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + TCOL - 1) / TCOL;
+    const int ntiles = a.nb * tiles_f * tiles_t;
+    const T* in = (const T*)a.in;
+    const int cch = tid & 7;                        // this thread's 8-channel chunk (fixed: 512 % 8 == 0)
+
+    // weights -> LDS once ([tap][co][ci], ci contiguous)
+    {
+        const TW* w = (const TW*)a.w;
+        for (int q = tid; q < 9 * 64 * 8; q += 512) {
+            const int p = q >> 3, c = q & 7;
+            uint4 u;
+            if constexpr (sizeof(TW) == 2) u = *(const uint4*)(w + (long)p * 64 + c * 8);
+            else { f8 v = ld8(w + (long)p * 64 + c * 8); u = pack8_part(v, a.part_w); }
+            *(uint4*)&sW[swz(p, c)] = u;
+        }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+
+    Chunk<T> regs[X_ITERS];
+    auto issue_loads = [&](int tile) {
+        const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            const int q = tid + i * 512;
+            const int p = q >> 3;
+            const int hr = p / HC, hc = p - hr * HC;
+            const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
+            const bool valid = (q < NCHUNK_H) && f >= 0 && f < F && t >= 0 && t < Tn;
+            regs[i] = load_chunk<T>(in + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
+        }
+    };
+    auto write_tile = [&](int tile) {
+        const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            const int q = tid + i * 512;
+            if (q < NCHUNK_H) {
+                const int p = q >> 3;
+                const int hr = p / HC, hc = p - hr * HC;
+                const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
+                const bool valid = f >= 0 && f < F && t >= 0 && t < Tn;
+                *(uint4*)&sX[swz(p, cch)] = xform_chunk<T>(regs[i], valid, a.prologue, sc, sh, a.part_in);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue_loads(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        write_tile(tile);
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) issue_loads(next);
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int chunk = kc * 2 + (lane >> 5);
+                bf16x8 wf[2], xf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) wf[i] = *(const bf16x8*)&sW[swz(tap * 64 + i * 32 + (lane & 31), chunk)];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xf[j] = *(const bf16x8*)&sX[swz((wave + kh) * HC + j * 32 + (lane & 31) + kw, chunk)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+
+        // epilogue: lane = pixel (col j*32 + lane&31 of tile row `wave`), 4 consecutive co per register group
+        const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
+        const int f = tc.f0 + wave;
+        if (f < F) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t = tc.t0 + j * 32 + (lane & 31);
+                if (t < Tn) {
+                    const long pix = (((long)tc.b * F + f) * Tn + t) * 64;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = i * 32 + 8 * g + 4 * (lane >> 5);
+                            float4 v = make_float4(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                            if (a.acc_in) {
+                                const float4 w4 = *(const float4*)(a.acc_ws + pix + co);
+                                v.x += w4.x; v.y += w4.y; v.z += w4.z; v.w += w4.w;
+                            }
+                            if (a.acc_out) *(float4*)(a.acc_ws + pix + co) = v;
+                            else st4((T*)a.out + pix + co, v);
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ wgrad
+struct WgradArgs {
+    const void* dy;       // (B,F,T,64) gradient w.r.t. the conv output
+    const void* zin;      // (B,F,T,64) conv input before prologue
+    const float* scale; const float* shift; int prologue;
+    float* partial;       // [gridDim.x * 2][9][64][64] f32
+    int nb, F, T;
+    int part_dy, part_z;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int pix_base, int ch_base, int lane) {
+    // rows = pixels (contraction), cols = channels: lane gets channel ch_base + (lane&31), 8 consecutive pixels
+    // starting at pix_base + (lane>>5)*8.  Two transpose reads of 4 pixels each.
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const int col = ch_base + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    const int chunk = col >> 3, within = col & 7;
+    bf16x8 out;
+    s16x4 q[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = pix_base + (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
+        const uint16_t* addr = s + swz(p, chunk) + within;
+        q[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)addr);
+    }
+    union { s16x4 v[2]; bf16x8 b; } u;
+    u.v[0] = q[0]; u.v[1] = q[1];
+    out = u.b;
+    return out;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t sY[Y_ELEMS];     // dy tile  [8*64 px][64 co]
+    __shared__ __attribute__((aligned(16))) uint16_t sX[X_ELEMS];     // z halo tile [660 px][64 ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = (wave >> 1) & 1, wk = wave >> 2;     // co half, ci half, pixel-row half
+    const int F = a.F, Tn = a.T;
+    const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + TCOL - 1) / TCOL;
+    const int ntiles = a.nb * tiles_f * tiles_t;
+    const T* zin = (const T*)a.zin;
+    const T* dy = (const T*)a.dy;
+    const int cch = tid & 7;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t9][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
+        // stage z (with halo, prologue) and dy (no halo)
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            const int q = tid + i * 512;
+            if (q < NCHUNK_H) {
+                const int p = q >> 3;
+                const int hr = p / HC, hc = p - hr * HC;
+                const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
+                const bool valid = f >= 0 && f < F && t >= 0 && t < Tn;
+                Chunk<T> c = load_chunk<T>(zin + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
+                *(uint4*)&sX[swz(p, cch)] = xform_chunk<T>(c, valid, a.prologue, sc, sh, a.part_z);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = tid + i * 512;                   // 4096 chunks
+            const int p = q >> 3;
+            const int r = p >> 6, cc = p & 63;
+            const int f = tc.f0 + r, t = tc.t0 + cc;
+            const bool valid = f < F && t < Tn;
+            Chunk<T> c = load_chunk<T>(dy + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
+            *(uint4*)&sY[swz(p, cch)] = xform_chunk<T>(c, valid, 0, sc, sh, a.part_dy);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wk * 4 + rr;
+#pragma unroll 1
+            for (int cb = 0; cb < 4; ++cb) {
+                const int c0 = cb * 16;
+                const bf16x8 fa = tr_frag(sY, r * 64 + c0, wi * 32, lane);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap - kh * 3;
+                    const bf16x8 fb = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D[co][ci]: lane: ci = lane&31, co = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* P = a.partial + ((long)blockIdx.x * 2 + wk) * W_ELEMS;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int ci = wj * 32 + (lane & 31);
+            P[(tap * 64 + co) * 64 + ci] = acc[tap][r];
+        }
+}
+
+// dW[e] (+)= sum_p partial[p][e]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW, int accumulate) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= W_ELEMS) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(long)p * W_ELEMS + e];
+    dW[e] = accumulate ? dW[e] + s : s;
+}
+
+static int conv_grid(int nb, int F, int T) {
+    int ntiles = nb * ((F + TR - 1) / TR) * ((T + TCOL - 1) / TCOL);
+    return ntiles < 256 ? ntiles : 256;
+}
+
+// in/out: (B,F,T,64) channels-last, dtype 0 f32 / 1 bf16 (same for both).  w: [9][64][64] ([tap][co][ci]) of
+// dtype w_dtype.  scale/shift: f32[64] prologue affine (+ReLU) or null for identity.
+// precise (f32 only): 3-pass split with ws = f32 (B,F,T,64).
+extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
+                                  const float* scale, const float* shift, int precise, float* ws, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_fwd");
+    ConvArgs a;
+    a.in = in; a.w = w; a.out = out; a.acc_ws = nullptr; a.acc_in = 0; a.acc_out = 0;
+    a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
+    a.nb = nb; a.F = F; a.T = T; a.part_in = 0; a.part_w = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = conv_grid(nb, F, T);
+    if (dtype == SARSSL_BF16 && w_dtype == SARSSL_BF16) {
+        conv3x3_fwd_kernel<bf16, bf16><<<grid, 512, 0, st>>>(a);
+    } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
+        if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);
+        else {
+            SARSSL_REQUIRE(ws != nullptr, "sarssl_conv3x3_fwd(precise needs workspace)");
+            a.acc_ws = ws;
+            ConvArgs p = a;
+            p.part_in = 0; p.part_w = 1; p.acc_in = 0; p.acc_out = 1; conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(p);
+            p.part_in = 1; p.part_w = 0; p.acc_in = 1; p.acc_out = 1; conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(p);
+            p.part_in = 0; p.part_w = 0; p.acc_in = 1; p.acc_out = 0; conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(p);
+        }
+    } else { sarssl_set_error("sarssl_conv3x3_fwd: unsupported dtypes (%d,%d)", dtype, w_dtype); return -1; }
+    SARSSL_CHECK_LAUNCH("conv3x3_fwd_kernel");
+    return 0;
+}
+
+extern "C" long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T) {
+    return (long)conv_grid(nb, F, T) * 2 * W_ELEMS * sizeof(float);
+}
+
+// dW: f32 [9][64][64] ([tap][co][ci]).  partial: workspace of sarssl_conv3x3_wgrad_workspace_bytes.
+extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T,
+                                    const float* scale, const float* shift, float* dW, float* partial, int precise,
+                                    void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_wgrad");
+    WgradArgs a;
+    a.dy = dy; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
+    a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = conv_grid(nb, F, T);
+    const int rblocks = (W_ELEMS + 255) / 256;
+    if (dtype == SARSSL_BF16) {
+        conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
+        wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid * 2, dW, 0);
+    } else if (dtype == SARSSL_F32) {
+        const int npass = precise ? 3 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            WgradArgs p = a;
+            if (precise) { p.part_dy = (pass == 1); p.part_z = (pass == 0); }     // hi*lo, lo*hi, hi*hi
+            conv3x3_wgrad_kernel<float><<<grid, 512, 0, st>>>(p);
+            wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid * 2, dW, pass > 0);
+        }
+    } else { sarssl_set_error("sarssl_conv3x3_wgrad: unsupported dtype %d", dtype); return -1; }
+    SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel");
+    return 0;
+}

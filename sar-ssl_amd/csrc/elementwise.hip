@@ -1,0 +1,594 @@
+// HBM-bound row / elementwise kernels of the Conformer blocks, decoder loss and optimiser.
+//   layernorm fwd/bwd (wave per row, f32 statistics)            code/common/conformer/*.py LayerNorm uses
+//   glu fwd/bwd                                                  conformer/activation.py:31-42
+//   depthwise conv k=31 fwd / dgrad (flipped) / wgrad            conformer/convolution.py:140
+//   relative-shift softmax fwd/bwd + shift-gather                conformer/attention.py:87-113
+//   bias2 add (q+u, q+v), axpby, column sums (bias grads), act-backward with dropout mask
+//   masked-channel MSE loss fwd/bwd                              code/model.py:585-592, 721-747
+//   fused Adam over a flat parameter buffer (+ bf16 shadow)      code/learner.py:83
+#include "common.h"
+
+#define ST ((hipStream_t)stream)
+#define DISPATCH_T(dtype, CALL)                                                             \
+    if (dtype == SARSSL_BF16) { typedef bf16 T; CALL; }                                     \
+    else if (dtype == SARSSL_F32) { typedef float T; CALL; }                                \
+    else { sarssl_set_error("unsupported dtype %d", dtype); return -1; }
+static inline int nblocks_for(long work, int per_block, int cap = 4096) {
+    long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm
+#define LN_MAXV 4      // up to 4 float4 per lane -> d <= 1024
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long ldx, long M, int d,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, T* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;                                  // float4 per row
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        float4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) { v[i] = ld4(x + row * ldx + c4 * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+        }
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) {
+                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, e = v[i].w - mu;
+                q += a * a + b * b + c * c + e * e;
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) {
+                const float4 g = *(const float4*)(gamma + c4 * 4), bb = *(const float4*)(beta + c4 * 4);
+                st4(y + row * ldy + c4 * 4, make_float4((v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y,
+                                                        (v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w));
+            }
+        }
+        if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ resid);  dgamma += sum dy*xhat, dbeta += sum dy
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
+                                                            long M, int d, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const T* __restrict__ resid, long ldr, T* __restrict__ dx, long lddx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float4 sg[4][64 * LN_MAXV];
+    __shared__ float4 sb[4][64 * LN_MAXV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;
+    float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 g[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) {
+                const float4 dyv = ld4(dy + row * lddy + c4 * 4), xv = ld4(x + row * ldx + c4 * 4);
+                const float4 gm = *(const float4*)(gamma + c4 * 4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[i] = make_float4(dyv.x * gm.x, dyv.y * gm.y, dyv.z * gm.z, dyv.w * gm.w);
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+                ag[i].x += dyv.x * xh[i].x; ag[i].y += dyv.y * xh[i].y; ag[i].z += dyv.z * xh[i].z; ag[i].w += dyv.w * xh[i].w;
+                ab[i].x += dyv.x; ab[i].y += dyv.y; ab[i].z += dyv.z; ab[i].w += dyv.w;
+            }
+        }
+        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) {
+                float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
+                                       rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+                if (resid) { const float4 r = ld4(resid + row * ldr + c4 * 4); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+                st4(dx + row * lddx + c4 * 4, o);
+            }
+        }
+    }
+    if (dgamma) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) { sg[wave][lane + i * 64] = ag[i]; sb[wave][lane + i * 64] = ab[i]; }
+        __syncthreads();
+        for (int c4 = threadIdx.x; c4 < nv; c4 += 256) {
+            float4 a = sg[0][c4], b = sb[0][c4];
+            for (int w = 1; w < 4; ++w) {
+                const float4 a2 = sg[w][c4], b2 = sb[w][c4];
+                a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+            }
+            atomicAdd(&dgamma[c4 * 4 + 0], a.x); atomicAdd(&dgamma[c4 * 4 + 1], a.y);
+            atomicAdd(&dgamma[c4 * 4 + 2], a.z); atomicAdd(&dgamma[c4 * 4 + 3], a.w);
+            atomicAdd(&dbeta[c4 * 4 + 0], b.x); atomicAdd(&dbeta[c4 * 4 + 1], b.y);
+            atomicAdd(&dbeta[c4 * 4 + 2], b.z); atomicAdd(&dbeta[c4 * 4 + 3], b.w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ GLU
+template <typename T>
+__global__ void glu_fwd_kernel(const T* __restrict__ h, long M, int d, T* __restrict__ g) {
+    const long total4 = M * (d >> 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / (d >> 2); const int c = (int)(i % (d >> 2)) * 4;
+        const float4 a = ld4(h + row * 2 * d + c), b = ld4(h + row * 2 * d + d + c);
+        st4(g + row * d + c, make_float4(a.x * sigmoidf_(b.x), a.y * sigmoidf_(b.y), a.z * sigmoidf_(b.z), a.w * sigmoidf_(b.w)));
+    }
+}
+template <typename T>
+__global__ void glu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ h, long M, int d, T* __restrict__ dh) {
+    const long total4 = M * (d >> 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / (d >> 2); const int c = (int)(i % (d >> 2)) * 4;
+        const float4 a = ld4(h + row * 2 * d + c), b = ld4(h + row * 2 * d + d + c), g = ld4(dg + row * d + c);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, gv[4] = {g.x, g.y, g.z, g.w};
+        float da[4], db[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float s = sigmoidf_(bv[e]); da[e] = gv[e] * s; db[e] = gv[e] * av[e] * s * (1.f - s); }
+        st4(dh + row * 2 * d + c, make_float4(da[0], da[1], da[2], da[3]));
+        st4(dh + row * 2 * d + d + c, make_float4(db[0], db[1], db[2], db[3]));
+    }
+}
+
+// ------------------------------------------------------------------------------------ depthwise conv, K = 31
+#define DWK 31
+#define DWT 32      // outputs per thread per tile
+// y[b][t][c] = sum_k w[c][flip ? K-1-k : k] * x[b][t + k - 15][c];  thread = channel, lanes = consecutive channels
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, int nb, int Tn, int d,
+                                                         int flip, T* __restrict__ y) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float wk[DWK];
+#pragma unroll
+    for (int k = 0; k < DWK; ++k) wk[k] = w[(long)c * DWK + (flip ? DWK - 1 - k : k)];
+    const int ntile = (Tn + DWT - 1) / DWT;
+    for (int tile = blockIdx.y; tile < nb * ntile; tile += gridDim.y) {
+        const int b = tile / ntile, t0 = (tile % ntile) * DWT;
+        float win[DWT + DWK - 1];
+#pragma unroll
+        for (int i = 0; i < DWT + DWK - 1; ++i) {
+            const int t = t0 - 15 + i;
+            win[i] = (t >= 0 && t < Tn) ? ld_f(x + ((long)b * Tn + t) * d + c) : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < DWT; ++o) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) acc += wk[k] * win[o + k];
+            if (t0 + o < Tn) st_f(y + ((long)b * Tn + t0 + o) * d + c, acc);
+        }
+    }
+}
+// dw[c][k] += sum_{b,t} dy[b][t][c] * x[b][t + k - 15][c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, int nb, int Tn, int d,
+                                                           float* __restrict__ dw) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float acc[DWK];
+#pragma unroll
+    for (int k = 0; k < DWK; ++k) acc[k] = 0.f;
+    const int ntile = (Tn + DWT - 1) / DWT;
+    for (int tile = blockIdx.y; tile < nb * ntile; tile += gridDim.y) {
+        const int b = tile / ntile, t0 = (tile % ntile) * DWT;
+        float win[DWT + DWK - 1];
+#pragma unroll
+        for (int i = 0; i < DWT + DWK - 1; ++i) {
+            const int t = t0 - 15 + i;
+            win[i] = (t >= 0 && t < Tn) ? ld_f(x + ((long)b * Tn + t) * d + c) : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < DWT; ++o) {
+            const float g = (t0 + o < Tn) ? ld_f(dy + ((long)b * Tn + t0 + o) * d + c) : 0.f;
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) acc[k] += g * win[o + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DWK; ++k) atomicAdd(&dw[(long)c * DWK + k], acc[k]);
+}
+
+// ------------------------------------------------------------------------------------ attention softmax
+// score[i][j] = (content[i][j] + shift(pos)[i][j]) * scale,  shift per conformer/attention.py:105-113:
+//   j <= i   : pos[i][T-1-i+j]      j == i+1 : 0      j >= i+2 : pos[i+1][j-i-2]
+// p = softmax_j(score) (saved for backward);  pd = p * dropout mask (GEMM operand), pd == p when p_drop == 0.
+#define SM_MAXV 16      // T <= 1024
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_relshift_fwd_kernel(const float* __restrict__ content, const float* __restrict__ pos,
+                                                                   long nrows_total, int Tn, float scale, T* __restrict__ p,
+                                                                   T* __restrict__ pd, float p_drop, unsigned long long seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < nrows_total; row += (long)gridDim.x * 4) {
+        const int i = (int)(row % Tn);
+        const long mat = row / Tn;                       // (b*H + h)
+        const float* cr = content + row * Tn;
+        const float* pm = pos + mat * Tn * Tn;
+        float v[SM_MAXV];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < SM_MAXV; ++k) {
+            const int j = lane + k * 64;
+            if (j < Tn) {
+                float ps;
+                if (j <= i) ps = pm[(long)i * Tn + (Tn - 1 - i + j)];
+                else if (j == i + 1) ps = 0.f;
+                else ps = pm[(long)(i + 1) * Tn + (j - i - 2)];
+                v[k] = (cr[j] + ps) * scale;
+                mx = fmaxf(mx, v[k]);
+            }
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < SM_MAXV; ++k) {
+            const int j = lane + k * 64;
+            if (j < Tn) { v[k] = __expf(v[k] - mx); s += v[k]; }
+        }
+        const float inv = 1.f / wave_sum(s);
+#pragma unroll
+        for (int k = 0; k < SM_MAXV; ++k) {
+            const int j = lane + k * 64;
+            if (j < Tn) {
+                const float pr = v[k] * inv;
+                st_f(p + row * Tn + j, pr);
+                if (pd != p) st_f(pd + row * Tn + j, pr * dropout_scale(seed, (unsigned long long)(row * Tn + j), p_drop, inv_keep));
+            }
+        }
+    }
+}
+// dscore = scale * p * (dp - sum_j dp*p),  dp = dpd * dropout mask
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dpd, const T* __restrict__ p, long nrows_total,
+                                                          int Tn, float scale, float p_drop, unsigned long long seed,
+                                                          T* __restrict__ dscore) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < nrows_total; row += (long)gridDim.x * 4) {
+        float dp[SM_MAXV], pr[SM_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < SM_MAXV; ++k) {
+            const int j = lane + k * 64;
+            if (j < Tn) {
+                pr[k] = ld_f(p + row * Tn + j);
+                dp[k] = dpd[row * Tn + j];
+                if (p_drop > 0.f) dp[k] *= dropout_scale(seed, (unsigned long long)(row * Tn + j), p_drop, inv_keep);
+                s += dp[k] * pr[k];
+            }
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int k = 0; k < SM_MAXV; ++k) {
+            const int j = lane + k * 64;
+            if (j < Tn) st_f(dscore + row * Tn + j, scale * pr[k] * (dp[k] - s));
+        }
+    }
+}
+// dpos[r][m] gathered from dscore through the inverse of the relative shift
+template <typename T>
+__global__ void relshift_bwd_kernel(const T* __restrict__ dscore, long nmat, int Tn, T* __restrict__ dpos) {
+    const long total = nmat * Tn * Tn;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx % Tn);
+        const long rr = idx / Tn;
+        const int r = (int)(rr % Tn);
+        const long mat = rr / Tn;
+        float v = 0.f;
+        if (m >= Tn - 1 - r) v = ld_f(dscore + (mat * Tn + r) * Tn + (m - Tn + 1 + r));
+        else if (r >= 1 && m <= Tn - 2 - r) v = ld_f(dscore + (mat * Tn + r - 1) * Tn + (m + r + 1));
+        st_f(dpos + idx, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------ small elementwise
+// qu = q + u[col], qv = q + v[col]   (q has row stride ldq; outputs dense [M][d])
+template <typename T>
+__global__ void bias2_kernel(const T* __restrict__ q, long ldq, long M, int d, const float* __restrict__ u,
+                             const float* __restrict__ v, T* __restrict__ qu, T* __restrict__ qv) {
+    const long total4 = M * (d >> 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / (d >> 2); const int c = (int)(i % (d >> 2)) * 4;
+        const float4 a = ld4(q + row * ldq + c);
+        const float4 uu = *(const float4*)(u + c), vv = *(const float4*)(v + c);
+        st4(qu + i * 4, make_float4(a.x + uu.x, a.y + uu.y, a.z + uu.z, a.w + uu.w));
+        st4(qv + i * 4, make_float4(a.x + vv.x, a.y + vv.y, a.z + vv.z, a.w + vv.w));
+    }
+}
+// out = a*x + b*y  (y may be null)
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, float a, float b, long n4, T* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 xv = ld4(x + i * 4);
+        float4 o = make_float4(a * xv.x, a * xv.y, a * xv.z, a * xv.w);
+        if (y) { const float4 yv = ld4(y + i * 4); o.x += b * yv.x; o.y += b * yv.y; o.z += b * yv.z; o.w += b * yv.w; }
+        st4(out + i * 4, o);
+    }
+}
+// out[n] += sum_m x[m][n]    (column tiles of 64, f32 atomics: bias / u,v-bias gradients)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, long ldx, long M, int N, float* __restrict__ out) {
+    __shared__ float sred[256][5];
+    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * 64, col = col0 + cgp * 4;
+    float s[4] = {0, 0, 0, 0};
+    if (col < N) {
+        for (long m = (long)blockIdx.y * 16 + rslot; m < M; m += (long)gridDim.y * 16) {
+            const float4 v = ld4(x + m * ldx + col);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sred[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && col0 + threadIdx.x < N) {
+        const int c = threadIdx.x;
+        float acc = 0.f;
+        for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][c & 3];
+        atomicAdd(&out[col0 + c], acc);
+    }
+}
+// dh = dz * act'(h) * dropout_mask(seed, idx) * gscale
+//   act 1: relu, h_is_post = 1 means h holds relu output;  act 2: swish with h = pre-activation;  act 0: none
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ h, long n, int act, float p_drop,
+                               unsigned long long seed, float gscale, T* __restrict__ dh) {
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += (long)gridDim.x * blockDim.x) {
+        const float4 d = ld4(dz + i * 4);
+        float dv[4] = {d.x, d.y, d.z, d.w}, hv[4] = {0, 0, 0, 0};
+        if (act) { const float4 hh = ld4(h + i * 4); hv[0] = hh.x; hv[1] = hh.y; hv[2] = hh.z; hv[3] = hh.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float g = dv[e] * gscale;
+            if (p_drop > 0.f) g *= dropout_scale(seed, (unsigned long long)(i * 4 + e), p_drop, inv_keep);
+            if (act == 1) g = hv[e] > 0.f ? g : 0.f;
+            else if (act == 2) { const float s = sigmoidf_(hv[e]); g *= s * (1.f + hv[e] * (1.f - s)); }
+            dv[e] = g;
+        }
+        st4(dh + i * 4, make_float4(dv[0], dv[1], dv[2], dv[3]));
+    }
+}
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, long n, TD* __restrict__ d) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) st_f(d + i, ld_f(s + i));
+}
+__global__ void f64_accum_kernel(const double* __restrict__ s, float* __restrict__ d, int n, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] += (float)(s[i]) * scale;
+}
+
+// ------------------------------------------------------------------------------------ loss
+// pred: (B, T, F, 2, 2) [f][reim][mic];  x: (B, 2, F, T, 2) f32;  idx: (B, nm) int32 masked frames; mch: (B) int32
+// sums[0] += sum (pred_mch - x_mch)^2 ; sums[1] += sum (x_mch - x_other)^2   over masked frames
+template <typename T>
+__global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ x,
+                                                             const int* __restrict__ idx, const int* __restrict__ mch, int nb,
+                                                             int F, int Tn, int nm, double* __restrict__ sums) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x / nm, k = blockIdx.x % nm;
+    const int t = idx[(long)b * nm + k], mc = mch[b];
+    float l = 0.f, dsum = 0.f;
+    for (int e = threadIdx.x; e < F * 2; e += 256) {
+        const int f = e >> 1, r = e & 1;
+        const float pv = ld_f(pred + ((((long)b * Tn + t) * F + f) * 2 + r) * 2 + mc);
+        const float tar = x[((((long)b * 2 + mc) * F + f) * Tn + t) * 2 + r];
+        const float oth = x[((((long)b * 2 + (1 - mc)) * F + f) * Tn + t) * 2 + r];
+        l += (pv - tar) * (pv - tar);
+        dsum += (tar - oth) * (tar - oth);
+    }
+    l = wave_sum(l); dsum = wave_sum(dsum);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = l; red[1][wave] = dsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+        atomicAdd(&sums[1], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+    }
+}
+__global__ void loss_finalize_kernel(const double* __restrict__ sums, double count, float* __restrict__ out) {
+    if (threadIdx.x == 0) { out[0] = (float)(sums[0] / count); out[1] = (float)(sums[1] / count); }
+}
+// dpred = gscale * 2 (pred - tar) / count on (masked frame, masked channel) entries, 0 elsewhere
+template <typename T>
+__global__ void masked_mse_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ x, const uint8_t* __restrict__ mp,
+                                      const int* __restrict__ mch, int nb, int F, int Tn, float coef, T* __restrict__ dpred) {
+    const long total = (long)nb * Tn * F * 2;          // one thread per (b,t,f,reim): 2 mics = 2 consecutive outputs
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i & 1);
+        long q = i >> 1;
+        const int f = (int)(q % F); q /= F;
+        const int t = (int)(q % Tn);
+        const int b = (int)(q / Tn);
+        float g0 = 0.f, g1 = 0.f;
+        if (!mp[(long)b * Tn + t]) {
+            const int mc = mch[b];
+            const float pv = ld_f(pred + i * 2 + mc);
+            const float tar = x[((((long)b * 2 + mc) * F + f) * Tn + t) * 2 + r];
+            const float g = coef * (pv - tar);
+            if (mc == 0) g0 = g; else g1 = g;
+        }
+        st_f(dpred + i * 2, g0); st_f(dpred + i * 2 + 1, g1);
+    }
+}
+
+// ------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam (no amsgrad, no weight decay) on a flat f32 buffer; also refreshes the bf16 shadow copy.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            bf16* __restrict__ p16, long n, float gscale, float beta1, float beta2, float step_size,
+                            float inv_bc2_sqrt, float eps) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        const float pi = p[i] - step_size * mi / denom;
+        p[i] = pi;
+        if (p16) st_f(p16 + i, pi);
+    }
+}
+
+// ================================================================================================ C ABI
+extern "C" int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps,
+                                    void* y, long ldy, float* mean, float* rstd, int dtype, void* stream) {
+    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0, "sarssl_layernorm_fwd");
+    const int nblk = nblocks_for(M, 4, 4096);
+    DISPATCH_T(dtype, (layernorm_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)x, ldx, M, d, gamma, beta, eps, (T*)y, ldy, mean, rstd)));
+    SARSSL_CHECK_LAUNCH("layernorm_fwd_kernel");
+    return 0;
+}
+// dgamma/dbeta accumulate (f32 atomics) - pass null to skip
+extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
+                                    const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
+                                    float* dgamma, float* dbeta, int dtype, void* stream) {
+    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024, "sarssl_layernorm_bwd");
+    const int nblk = nblocks_for(M, 4 * 8, 1024);
+    DISPATCH_T(dtype, (layernorm_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd,
+                                                                    (const T*)resid, ldr, (T*)dx, lddx, dgamma, dbeta)));
+    SARSSL_CHECK_LAUNCH("layernorm_bwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_glu_fwd(const void* h, long M, int d, void* g, int dtype, void* stream) {
+    SARSSL_REQUIRE((d & 3) == 0, "sarssl_glu_fwd");
+    DISPATCH_T(dtype, (glu_fwd_kernel<T><<<nblocks_for(M * (d >> 2), 256), 256, 0, ST>>>((const T*)h, M, d, (T*)g)));
+    SARSSL_CHECK_LAUNCH("glu_fwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_glu_bwd(const void* dg, const void* h, long M, int d, void* dh, int dtype, void* stream) {
+    SARSSL_REQUIRE((d & 3) == 0, "sarssl_glu_bwd");
+    DISPATCH_T(dtype, (glu_bwd_kernel<T><<<nblocks_for(M * (d >> 2), 256), 256, 0, ST>>>((const T*)dg, (const T*)h, M, d, (T*)dh)));
+    SARSSL_CHECK_LAUNCH("glu_bwd_kernel");
+    return 0;
+}
+// w: f32 [d][31].  flip = 0 forward, flip = 1 data gradient.
+extern "C" int sarssl_dwconv_fwd(const void* x, const float* w, int nb, int Tn, int d, int ksize, int flip, void* y, int dtype,
+                                 void* stream) {
+    SARSSL_REQUIRE(ksize == DWK, "sarssl_dwconv_fwd(kernel size must be 31)");
+    const int ntile = nb * ((Tn + DWT - 1) / DWT);
+    dim3 grid((d + 255) / 256, ntile > 4096 ? 4096 : ntile);
+    DISPATCH_T(dtype, (dwconv_fwd_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, w, nb, Tn, d, flip, (T*)y)));
+    SARSSL_CHECK_LAUNCH("dwconv_fwd_kernel");
+    return 0;
+}
+// dw: f32 [d][31], accumulated (atomics)
+extern "C" int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn, int d, int ksize, float* dw, int dtype,
+                                   void* stream) {
+    SARSSL_REQUIRE(ksize == DWK, "sarssl_dwconv_wgrad(kernel size must be 31)");
+    const int ntile = nb * ((Tn + DWT - 1) / DWT);
+    dim3 grid((d + 255) / 256, ntile > 64 ? 64 : ntile);
+    DISPATCH_T(dtype, (dwconv_wgrad_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, (const T*)x, nb, Tn, d, dw)));
+    SARSSL_CHECK_LAUNCH("dwconv_wgrad_kernel");
+    return 0;
+}
+// content/pos: f32 (nmat, T, T).  p, pd: dtype (nmat, T, T); pass pd == p when p_drop == 0.
+extern "C" int sarssl_softmax_relshift_fwd(const float* content, const float* pos, long nmat, int Tn, float scale, void* p,
+                                           void* pd, float p_drop, unsigned long long seed, int dtype, void* stream) {
+    SARSSL_REQUIRE(Tn > 0 && Tn <= 64 * SM_MAXV, "sarssl_softmax_relshift_fwd(T <= 1024)");
+    const int nblk = nblocks_for(nmat * Tn, 4, 8192);
+    DISPATCH_T(dtype, (softmax_relshift_fwd_kernel<T><<<nblk, 256, 0, ST>>>(content, pos, nmat * Tn, Tn, scale, (T*)p, (T*)pd, p_drop, seed)));
+    SARSSL_CHECK_LAUNCH("softmax_relshift_fwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_softmax_bwd(const float* dpd, const void* p, long nmat, int Tn, float scale, float p_drop,
+                                  unsigned long long seed, void* dscore, int dtype, void* stream) {
+    SARSSL_REQUIRE(Tn > 0 && Tn <= 64 * SM_MAXV, "sarssl_softmax_bwd(T <= 1024)");
+    const int nblk = nblocks_for(nmat * Tn, 4, 8192);
+    DISPATCH_T(dtype, (softmax_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dpd, (const T*)p, nmat * Tn, Tn, scale, p_drop, seed, (T*)dscore)));
+    SARSSL_CHECK_LAUNCH("softmax_bwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_relshift_bwd(const void* dscore, long nmat, int Tn, void* dpos, int dtype, void* stream) {
+    DISPATCH_T(dtype, (relshift_bwd_kernel<T><<<nblocks_for(nmat * Tn * Tn, 256, 8192), 256, 0, ST>>>((const T*)dscore, nmat, Tn, (T*)dpos)));
+    SARSSL_CHECK_LAUNCH("relshift_bwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_bias2(const void* q, long ldq, long M, int d, const float* u, const float* v, void* qu, void* qv, int dtype,
+                            void* stream) {
+    SARSSL_REQUIRE((d & 3) == 0 && (ldq & 3) == 0, "sarssl_bias2");
+    DISPATCH_T(dtype, (bias2_kernel<T><<<nblocks_for(M * (d >> 2), 256), 256, 0, ST>>>((const T*)q, ldq, M, d, u, v, (T*)qu, (T*)qv)));
+    SARSSL_CHECK_LAUNCH("bias2_kernel");
+    return 0;
+}
+extern "C" int sarssl_axpby(const void* x, const void* y, float a, float b, long n, void* out, int dtype, void* stream) {
+    SARSSL_REQUIRE((n & 3) == 0, "sarssl_axpby(n % 4)");
+    DISPATCH_T(dtype, (axpby_kernel<T><<<nblocks_for(n >> 2, 256), 256, 0, ST>>>((const T*)x, (const T*)y, a, b, n >> 2, (T*)out)));
+    SARSSL_CHECK_LAUNCH("axpby_kernel");
+    return 0;
+}
+extern "C" int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream) {
+    SARSSL_REQUIRE((N & 3) == 0 && (ldx & 3) == 0 && M > 0, "sarssl_colsum");
+    int gx = (N + 63) / 64;
+    long gy = (M + 255) / 256; if (gy < 1) gy = 1;
+    long cap = 1024 / gx; if (cap < 1) cap = 1;
+    if (gy > cap) gy = cap;
+    DISPATCH_T(dtype, (colsum_kernel<T><<<dim3(gx, (unsigned)gy), 256, 0, ST>>>((const T*)x, ldx, M, N, out)));
+    SARSSL_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+extern "C" int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,
+                              void* dh, int dtype, void* stream) {
+    SARSSL_REQUIRE((n & 3) == 0, "sarssl_act_bwd(n % 4)");
+    DISPATCH_T(dtype, (act_bwd_kernel<T><<<nblocks_for(n >> 2, 256), 256, 0, ST>>>((const T*)dz, (const T*)h, n, act, p_drop, seed, gscale, (T*)dh)));
+    SARSSL_CHECK_LAUNCH("act_bwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream) {
+    const int nblk = nblocks_for(n, 256);
+    if (src_dtype == SARSSL_F32 && dst_dtype == SARSSL_BF16) cast_kernel<float, bf16><<<nblk, 256, 0, ST>>>((const float*)src, n, (bf16*)dst);
+    else if (src_dtype == SARSSL_BF16 && dst_dtype == SARSSL_F32) cast_kernel<bf16, float><<<nblk, 256, 0, ST>>>((const bf16*)src, n, (float*)dst);
+    else if (src_dtype == SARSSL_F32 && dst_dtype == SARSSL_F32) cast_kernel<float, float><<<nblk, 256, 0, ST>>>((const float*)src, n, (float*)dst);
+    else { sarssl_set_error("sarssl_cast: unsupported (%d -> %d)", src_dtype, dst_dtype); return -1; }
+    SARSSL_CHECK_LAUNCH("cast_kernel");
+    return 0;
+}
+extern "C" int sarssl_f64_accum(const double* src, float* dst, int n, float scale, void* stream) {
+    f64_accum_kernel<<<(n + 255) / 256, 256, 0, ST>>>(src, dst, n, scale);
+    SARSSL_CHECK_LAUNCH("f64_accum_kernel");
+    return 0;
+}
+// out: f32[2] = (loss, diff).  sums: f64[2] workspace (zeroed here).
+extern "C" int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
+                                     int nm, double* sums, float* out, int dtype, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && nm > 0, "sarssl_masked_mse_fwd");
+    if (hipMemsetAsync(sums, 0, 2 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    DISPATCH_T(dtype, (masked_mse_fwd_kernel<T><<<nb * nm, 256, 0, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
+    loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out);
+    SARSSL_CHECK_LAUNCH("masked_mse_fwd_kernel");
+    return 0;
+}
+// dpred = gscale * dLoss/dpred, loss = mean over nb*nm*F*2 entries
+extern "C" int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F,
+                                     int Tn, int nm, float gscale, void* dpred, int dtype, void* stream) {
+    const float coef = gscale * 2.0f / (float)((double)nb * nm * F * 2);
+    DISPATCH_T(dtype, (masked_mse_bwd_kernel<T><<<nblocks_for((long)nb * Tn * F * 2, 256, 8192), 256, 0, ST>>>((const T*)pred, x, mp, mch, nb, F, Tn, coef, (T*)dpred)));
+    SARSSL_CHECK_LAUNCH("masked_mse_bwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, long n, float gscale, float lr,
+                                float beta1, float beta2, float eps, int step, void* stream) {
+    SARSSL_REQUIRE(n > 0 && step >= 1, "sarssl_adam_step");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    adam_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, n, gscale, beta1, beta2, (float)(lr / bc1),
+                                                           (float)(1.0 / sqrt(bc2)), eps);
+    SARSSL_CHECK_LAUNCH("adam_kernel");
+    return 0;
+}

@@ -1,0 +1,482 @@
+// HBM-bound pieces of the CNN stem (code/model.py:50-64) and generic channels-last ([N rows][C ch])
+// BatchNorm machinery shared with the Conformer conv module's BatchNorm1d:
+//   mask_inputs   : builds the two masked 4-channel stem inputs from the STFT tensor (model.py:533-564)
+//   stem_c1       : 1x1 conv 4 -> 64 (+ weight gradient)
+//   stem_c4       : BN+ReLU prologue, 1x1 conv 64 -> 4 written in (B,T,F,4) order = patch-GEMM A operand
+//   stem_c4_bwd   : dz3 = dy4*W4 masked by ReLU, dW4, and the BatchNorm-backward reductions in one pass
+//   cl_stats / bn_finalize / bn_eval_affine / cl_affine_act / cl_bn_bwd_reduce / cl_bn_bwd_apply
+// All reductions: per-thread partials -> LDS -> one f64 atomicAdd per (block, channel).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// x: (B, 2, F, T, 2) f32 [mic][f][t][reim];  mp: (B, T) u8 (1 = visible frame, 0 = masked);
+// mch: (B) int32 masked channel.  spec/spat: (B, F, T, 4) with c = reim*2 + mic.
+// mode 0: pretrain masks (model.py:541, :563);  mode 1: no masking, both outputs = x (model.py:676).
+template <typename T>
+__global__ void mask_inputs_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mp, const int* __restrict__ mch,
+                                   int nb, int F, int Tn, int mode, T* __restrict__ spec, T* __restrict__ spat) {
+    const long total = (long)nb * F * Tn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % Tn);
+        const long bf = i / Tn;
+        const int f = (int)(bf % F), b = (int)(bf / F);
+        const float2 m0 = *(const float2*)(x + ((((long)b * 2 + 0) * F + f) * Tn + t) * 2);
+        const float2 m1 = *(const float2*)(x + ((((long)b * 2 + 1) * F + f) * Tn + t) * 2);
+        float s0 = 1.f, s1 = 1.f, p = 1.f;
+        if (mode == 0) {
+            p = mp[(long)b * Tn + t] ? 1.f : 0.f;
+            const int mc = mch[b];
+            const float v0 = (mc == 0) ? 0.f : 1.f, v1 = (mc == 1) ? 0.f : 1.f;   // mask_ch_dense per mic
+            s0 = (1.f - p) * v0 + p * (1.f - v0);
+            s1 = (1.f - p) * v1 + p * (1.f - v1);
+        }
+        st4(spec + i * 4, make_float4(m0.x * s0, m1.x * s1, m0.y * s0, m1.y * s1));
+        st4(spat + i * 4, make_float4(m0.x * p, m1.x * p, m0.y * p, m1.y * p));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y1[p][co] = sum_c W1[co][c] a0[p][c]     a0: (N,4), y1: (N,64).  Thread = (pixel, 8-channel group).
+template <typename T>
+__global__ void stem_c1_fwd_kernel(const T* __restrict__ a0, const float* __restrict__ W1, long npix, T* __restrict__ y1) {
+    const int cg = threadIdx.x & 7;
+    float w[8][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[e][c] = W1[(cg * 8 + e) * 4 + c];
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
+        const long p = g >> 3;
+        const float4 a = ld4(a0 + p * 4);
+        f8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = w[e][0] * a.x + w[e][1] * a.y + w[e][2] * a.z + w[e][3] * a.w;
+        st8(y1 + p * 64 + cg * 8, o);
+    }
+}
+
+// dW1[co][c] = sum_p dy1[p][co] a0[p][c]   (double accumulators dW1d[64*4], zeroed by the caller)
+template <typename T>
+__global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const T* __restrict__ a0, long npix, double* __restrict__ dW1d) {
+    __shared__ float red[256][33];
+    const int cg = threadIdx.x & 7;
+    float acc[8][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[e][c] = 0.f;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
+        const long p = g >> 3;
+        const float4 a = ld4(a0 + p * 4);
+        const f8 d = ld8(dy1 + p * 64 + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e][0] += d.v[e] * a.x; acc[e][1] += d.v[e] * a.y; acc[e][2] += d.v[e] * a.z; acc[e][3] += d.v[e] * a.w; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[threadIdx.x][e * 4 + c] = acc[e][c];
+    __syncthreads();
+    // 256 outputs; thread o sums the 32 threads that share its channel group
+    const int o = threadIdx.x;           // o = co*4 + c, co = cg*8 + e
+    const int co = o >> 2, c = o & 3;
+    const int ocg = co >> 3, oe = co & 7;
+    float s = 0.f;
+    for (int k = 0; k < 32; ++k) s += red[k * 8 + ocg][oe * 4 + c];
+    atomicAdd(&dW1d[o], (double)s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// y4[b][t][f][c] = sum_ci W4[c][ci] * relu(y3[b][f][t][ci]*scale[ci] + shift[ci])
+// 8 lanes per pixel (one 16-byte chunk each), shuffle-reduced.
+template <typename T>
+__global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __restrict__ W4, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4) {
+    const int cg = threadIdx.x & 7;
+    float w[4][8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c][e] = W4[c * 64 + cg * 8 + e];
+    }
+    const long npix = (long)nb * F * Tn;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
+        const long p = g >> 3;
+        const f8 v = ld8(y3 + p * 64 + cg * 8);
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float z = fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] += w[c][e] * z;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            o[c] += __shfl_xor(o[c], 1, 64); o[c] += __shfl_xor(o[c], 2, 64); o[c] += __shfl_xor(o[c], 4, 64);
+        }
+        if (cg == 0) {
+            const int t = (int)(p % Tn);
+            const long bf = p / Tn;
+            const int f = (int)(bf % F), b = (int)(bf / F);
+            st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+// Backward of the 64->4 conv + the ReLU mask + BatchNorm(3)-backward reductions, one pass over y3:
+//   g3[p][ci]  = (sum_c dy4[p][c] W4[c][ci]) * [bn3(y3) > 0]           (written, same layout as y3)
+//   dW4[c][ci] = sum_p dy4[p][c] * relu(bn3(y3))[p][ci]
+//   s1[ci] = sum_p g3 ; s2[ci] = sum_p g3 * xhat3                         (BatchNorm backward sums)
+// dy4 is (B,T,F,4); y3/g3 are (B,F,T,64).  red: double [4*64 + 64 + 64], zeroed by the caller.
+template <typename T>
+__global__ void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict__ dy4, const float* __restrict__ W4,
+                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   int nb, int F, int Tn, T* __restrict__ g3, double* __restrict__ red) {
+    __shared__ float sred[256][49];
+    const int cg = threadIdx.x & 7;
+    float w[4][8], sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = cg * 8 + e;
+        sc[e] = scale[ci]; sh[e] = shift[ci]; mu[e] = mean[ci]; rs[e] = rstd[ci];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c][e] = W4[c * 64 + ci];
+    }
+    float aW[4][8], a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) aW[c][e] = 0.f; }
+    const long npix = (long)nb * F * Tn;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
+        const long p = g >> 3;
+        const int t = (int)(p % Tn);
+        const long bf = p / Tn;
+        const int f = (int)(bf % F), b = (int)(bf / F);
+        const float4 d = ld4(dy4 + ((((long)b * Tn + t) * F + f) * 4));
+        const f8 v = ld8(y3 + p * 64 + cg * 8);
+        f8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = fmaf(v.v[e], sc[e], sh[e]);
+            const float z = fmaxf(u, 0.f);
+            float gi = d.x * w[0][e] + d.y * w[1][e] + d.z * w[2][e] + d.w * w[3][e];
+            gi = (u > 0.f) ? gi : 0.f;
+            o.v[e] = gi;
+            aW[0][e] += d.x * z; aW[1][e] += d.y * z; aW[2][e] += d.z * z; aW[3][e] += d.w * z;
+            a1[e] += gi;
+            a2[e] += gi * (v.v[e] - mu[e]) * rs[e];
+        }
+        st8(g3 + p * 64 + cg * 8, o);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sred[threadIdx.x][c * 8 + e] = aW[c][e];
+        sred[threadIdx.x][32 + e] = a1[e];
+        sred[threadIdx.x][40 + e] = a2[e];
+    }
+    __syncthreads();
+    // 384 outputs: [0,256) dW4[c][ci], [256,320) s1[ci], [320,384) s2[ci]
+    for (int o = threadIdx.x; o < 384; o += 256) {
+        int ci, slot;
+        if (o < 256) { const int c = o >> 6; ci = o & 63; slot = c * 8 + (ci & 7); }
+        else if (o < 320) { ci = o - 256; slot = 32 + (ci & 7); }
+        else { ci = o - 320; slot = 40 + (ci & 7); }
+        const int ocg = ci >> 3;
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) s += sred[k * 8 + ocg][slot];
+        atomicAdd(&red[o], (double)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic channels-last helpers on X[N][C], C = 4 * 2^k <= 1024.  Thread = (row slot, 4-channel group).
+
+// Column tiles of 64 channels (16 threads x 4 ch) x 16 row slots.  For C < 64 (64 % C == 0) the tensor is viewed as
+// [N*C/64][64] and the 64 virtual columns fold back onto channel (col % C).
+// sums[c] += sum_n x ; sums[C + c] += sum_n x^2
+template <typename T>
+__global__ void cl_stats_kernel(const T* __restrict__ x, long rows, int L, int C, double* __restrict__ sums) {
+    __shared__ float sred[256][9];
+    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * 64, col = col0 + cgp * 4;
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (col < L) {
+        for (long n = (long)blockIdx.y * 16 + rslot; n < rows; n += (long)gridDim.y * 16) {
+            const float4 v = ld4(x + n * L + col);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][4 + e] = q[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        if (col0 + c < L) {
+            float acc = 0.f;
+            for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][which * 4 + (c & 3)];
+            atomicAdd(&sums[which * C + ((col0 + c) % C)], (double)acc);
+        }
+    }
+}
+
+// training-mode BatchNorm statistics -> affine; updates running stats (nn.BatchNorm defaults: momentum 0.1, unbiased)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, long N, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long* __restrict__ nbt,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                                   float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const double m = sums[c] / (double)N;
+    double var = sums[C + c] / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m; rstd[c] = r;
+    scale[c] = gamma[c] * r;
+    shift[c] = beta[c] - (float)m * gamma[c] * r;
+    if (running_mean) {
+        const double unb = (N > 1) ? var * (double)N / (double)(N - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                                      float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float r = rsqrtf(running_var[c] + eps);
+    mean[c] = running_mean[c]; rstd[c] = r;
+    scale[c] = gamma[c] * r;
+    shift[c] = beta[c] - running_mean[c] * gamma[c] * r;
+}
+
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    return act == 1 ? fmaxf(u, 0.f) : (act == 2 ? u * sigmoidf_(u) : u);
+}
+__device__ __forceinline__ float act_bwd(float u, int act) {   // d act / d u
+    if (act == 1) return u > 0.f ? 1.f : 0.f;
+    if (act == 2) { const float s = sigmoidf_(u); return s * (1.f + u * (1.f - s)); }
+    return 1.f;
+}
+
+// z = act(x*scale[c] + shift[c])
+template <typename T>
+__global__ void cl_affine_act_kernel(const T* __restrict__ x, long N, int C, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, int act, T* __restrict__ z) {
+    const long total4 = N * (C >> 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (C >> 2)) * 4;
+        const float4 v = ld4(x + i * 4);
+        const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+        st4(z + i * 4, make_float4(act_fwd(fmaf(v.x, sc.x, sh.x), act), act_fwd(fmaf(v.y, sc.y, sh.y), act),
+                                   act_fwd(fmaf(v.z, sc.z, sh.z), act), act_fwd(fmaf(v.w, sc.w, sh.w), act)));
+    }
+}
+
+// BatchNorm(+act) backward, pass 1: g = dz * act'(u), u = y*scale+shift; red[c] += sum g, red[C+c] += sum g*xhat
+template <typename T>
+__global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y, long rows, int L, int C,
+                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                        double* __restrict__ red) {
+    __shared__ float sred[256][9];
+    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * 64, col = col0 + cgp * 4;
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (col < L) {
+        const int ch = col % C;
+        const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
+        const float4 mu = *(const float4*)(mean + ch), rs = *(const float4*)(rstd + ch);
+        for (long n = (long)blockIdx.y * 16 + rslot; n < rows; n += (long)gridDim.y * 16) {
+            const float4 d = ld4(dz + n * L + col);
+            const float4 v = ld4(y + n * L + col);
+            const float g0 = d.x * act_bwd(fmaf(v.x, sc.x, sh.x), act), g1 = d.y * act_bwd(fmaf(v.y, sc.y, sh.y), act);
+            const float g2 = d.z * act_bwd(fmaf(v.z, sc.z, sh.z), act), g3 = d.w * act_bwd(fmaf(v.w, sc.w, sh.w), act);
+            s[0] += g0; s[1] += g1; s[2] += g2; s[3] += g3;
+            q[0] += g0 * (v.x - mu.x) * rs.x; q[1] += g1 * (v.y - mu.y) * rs.y;
+            q[2] += g2 * (v.z - mu.z) * rs.z; q[3] += g3 * (v.w - mu.w) * rs.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][4 + e] = q[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        if (col0 + c < L) {
+            float acc = 0.f;
+            for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][which * 4 + (c & 3)];
+            atomicAdd(&red[which * C + ((col0 + c) % C)], (double)acc);
+        }
+    }
+}
+
+// pass 2: dy = gamma*rstd * (g - s1/N - xhat*s2/N)      (train)   or   dy = gamma*rstd * g   (eval: use_stats = 0)
+// g_is_masked = 1 when dz already contains g (act' applied upstream).
+template <typename T>
+__global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, long N, int C,
+                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                       int g_is_masked, int use_stats, const double* __restrict__ red, T* __restrict__ dy) {
+    const long total4 = N * (C >> 2);
+    const float invN = 1.0f / (float)N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (C >> 2)) * 4;
+        const float4 d = ld4(dz + i * 4);
+        const float4 v = ld4(y + i * 4);
+        float dd[4] = {d.x, d.y, d.z, d.w}, vv[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g = g_is_masked ? dd[e] : dd[e] * act_bwd(fmaf(vv[e], scale[c + e], shift[c + e]), act);
+            const float xh = (vv[e] - mean[c + e]) * rstd[c + e];
+            const float k = scale[c + e];                       // gamma * rstd
+            o[e] = use_stats ? k * (g - (float)red[c + e] * invN - xh * (float)red[C + c + e] * invN) : k * g;
+        }
+        st4(dy + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// ================================================================================================ C ABI
+static inline int nblocks_for(long work, int per_block, int cap = 2048) {
+    long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+#define ST ((hipStream_t)stream)
+#define DISPATCH_T(dtype, CALL)                                                             \
+    if (dtype == SARSSL_BF16) { typedef bf16 T; CALL; }                                     \
+    else if (dtype == SARSSL_F32) { typedef float T; CALL; }                                \
+    else { sarssl_set_error("unsupported dtype %d", dtype); return -1; }
+
+extern "C" int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn, int mode,
+                                  void* spec, void* spat, int dtype, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && Tn > 0, "sarssl_mask_inputs");
+    const int nblk = nblocks_for((long)nb * F * Tn, 256, 8192);
+    DISPATCH_T(dtype, (mask_inputs_kernel<T><<<nblk, 256, 0, ST>>>(x, mp, mch, nb, F, Tn, mode, (T*)spec, (T*)spat)));
+    SARSSL_CHECK_LAUNCH("mask_inputs_kernel");
+    return 0;
+}
+
+extern "C" int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, int dtype, void* stream) {
+    const int nblk = nblocks_for(npix * 8, 256, 4096);
+    DISPATCH_T(dtype, (stem_c1_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)a0, W1, npix, (T*)y1)));
+    SARSSL_CHECK_LAUNCH("stem_c1_fwd_kernel");
+    return 0;
+}
+
+// dW1d: f64[256] workspace (zeroed here); result must be read as double
+extern "C" int sarssl_stem_c1_wgrad(const void* dy1, const void* a0, long npix, double* dW1d, int dtype, void* stream) {
+    if (hipMemsetAsync(dW1d, 0, 256 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for(npix * 8, 256, 1024);
+    DISPATCH_T(dtype, (stem_c1_wgrad_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy1, (const T*)a0, npix, dW1d)));
+    SARSSL_CHECK_LAUNCH("stem_c1_wgrad_kernel");
+    return 0;
+}
+
+extern "C" int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F,
+                                  int Tn, void* y4, int dtype, void* stream) {
+    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 4096);
+    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4)));
+    SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel");
+    return 0;
+}
+
+// red: f64[384] (zeroed here): [0,256) dW4[c][ci], [256,320) s1, [320,384) s2
+extern "C" int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, int nb, int F, int Tn, void* g3, double* red,
+                                  int dtype, void* stream) {
+    if (hipMemsetAsync(red, 0, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 1024);
+    DISPATCH_T(dtype, (stem_c4_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
+                                                                  nb, F, Tn, (T*)g3, red)));
+    SARSSL_CHECK_LAUNCH("stem_c4_bwd_kernel");
+    return 0;
+}
+
+// view [N][C] as [rows][L] with L = max(C, 64) (C < 64 needs 64 % C == 0 and N*C % 64 == 0)
+static inline bool cl_view(long N, int C, long* rows, int* L) {
+    if (C <= 0 || (C & 3) || N <= 0) return false;
+    if (C >= 64) { *rows = N; *L = C; return true; }
+    if (64 % C || (N * C) % 64) return false;
+    *rows = N * C / 64; *L = 64; return true;
+}
+static inline dim3 cl_grid(long rows, int L) {
+    int gx = (L + 63) / 64;
+    long gy = (rows + 127) / 128; if (gy < 1) gy = 1;
+    long cap = 2048 / gx; if (cap < 1) cap = 1;
+    if (gy > cap) gy = cap;
+    return dim3(gx, (unsigned)gy, 1);
+}
+
+// sums: f64[2C] (zeroed here)
+extern "C" int sarssl_cl_stats(const void* x, long N, int C, double* sums, int dtype, void* stream) {
+    long rows; int L;
+    SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_stats(C % 4 == 0; C < 64 needs 64 % C == 0 and N*C % 64 == 0)");
+    if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const dim3 grid = cl_grid(rows, L);
+    DISPATCH_T(dtype, (cl_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, rows, L, C, sums)));
+    SARSSL_CHECK_LAUNCH("cl_stats_kernel");
+    return 0;
+}
+
+extern "C" int sarssl_bn_finalize(const double* sums, long N, int C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, long* nbt, float* scale,
+                                  float* shift, float* mean, float* rstd, void* stream) {
+    bn_finalize_kernel<<<(C + 63) / 64, 64, 0, ST>>>(sums, N, C, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                                                     scale, shift, mean, rstd);
+    SARSSL_CHECK_LAUNCH("bn_finalize_kernel");
+    return 0;
+}
+
+extern "C" int sarssl_bn_eval_affine(int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                                     const float* running_var, float* scale, float* shift, float* mean, float* rstd,
+                                     void* stream) {
+    bn_eval_affine_kernel<<<(C + 63) / 64, 64, 0, ST>>>(C, gamma, beta, eps, running_mean, running_var, scale, shift, mean, rstd);
+    SARSSL_CHECK_LAUNCH("bn_eval_affine_kernel");
+    return 0;
+}
+
+extern "C" int sarssl_cl_affine_act(const void* x, long N, int C, const float* scale, const float* shift, int act, void* z,
+                                    int dtype, void* stream) {
+    SARSSL_REQUIRE((C & 3) == 0 && N > 0, "sarssl_cl_affine_act");
+    const int nblk = nblocks_for(N * (C >> 2), 256, 8192);
+    DISPATCH_T(dtype, (cl_affine_act_kernel<T><<<nblk, 256, 0, ST>>>((const T*)x, N, C, scale, shift, act, (T*)z)));
+    SARSSL_CHECK_LAUNCH("cl_affine_act_kernel");
+    return 0;
+}
+
+// red: f64[2C] (zeroed here)
+extern "C" int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
+                                       const float* mean, const float* rstd, int act, double* red, int dtype, void* stream) {
+    long rows; int L;
+    SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_bn_bwd_reduce");
+    if (hipMemsetAsync(red, 0, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const dim3 grid = cl_grid(rows, L);
+    DISPATCH_T(dtype, (cl_bn_bwd_reduce_kernel<T><<<grid, 256, 0, ST>>>((const T*)dz, (const T*)y, rows, L, C, scale, shift,
+                                                                       mean, rstd, act, red)));
+    SARSSL_CHECK_LAUNCH("cl_bn_bwd_reduce_kernel");
+    return 0;
+}
+
+extern "C" int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, int act, int g_is_masked, int use_stats,
+                                      const double* red, void* dy, int dtype, void* stream) {
+    SARSSL_REQUIRE((C & 3) == 0 && N > 0, "sarssl_cl_bn_bwd_apply");
+    const int nblk = nblocks_for(N * (C >> 2), 256, 8192);
+    DISPATCH_T(dtype, (cl_bn_bwd_apply_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dz, (const T*)y, N, C, scale, shift, mean,
+                                                                      rstd, act, g_is_masked, use_stats, red, (T*)dy)));
+    SARSSL_CHECK_LAUNCH("cl_bn_bwd_apply_kernel");
+    return 0;
+}

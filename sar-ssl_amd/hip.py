@@ -94,3 +94,269 @@ def stft_raw(sig, win_len=512, hop=256, nfft=512):
     _lib.call("sarssl_stft_raw", _p(sig), c_int(dt(sig)), c_int(nb), c_long(nsample), c_int(nch), c_int(win_len),
               c_int(hop), c_int(nfft), c_int(nt), _p(U), _p(magsum), _p(out), _stream())
     return torch.view_as_complex(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# conv stem
+def _f32ws(n, device, tag):
+    return workspace(4 * n, device, tag).view(torch.float32)[:n]
+
+
+def _f64ws(n, device, tag):
+    return workspace(8 * n + 8, device, tag)[: 8 * n].view(torch.float64)
+
+
+def mask_inputs(x, mp_u8, mch_i32, mode, dtype):
+    """x (B,2,F,T,2) f32 -> spec_in, spat_in (B,F,T,4) of `dtype` (csrc/stem.hip)."""
+    _need_cuda(x)
+    B, _, F, T, _ = x.shape
+    spec = torch.empty((B, F, T, 4), dtype=dtype, device=x.device)
+    spat = torch.empty((B, F, T, 4), dtype=dtype, device=x.device)
+    _lib.call("sarssl_mask_inputs", _p(x), _p(mp_u8), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(mode), _p(spec), _p(spat),
+              c_int(_DT[dtype]), _stream())
+    return spec, spat
+
+
+def stem_c1_fwd(a0, W1):
+    npix = a0.numel() // 4
+    y = torch.empty(a0.shape[:-1] + (64,), dtype=a0.dtype, device=a0.device)
+    _lib.call("sarssl_stem_c1_fwd", _p(a0), _p(W1), c_long(npix), _p(y), c_int(dt(a0)), _stream())
+    return y
+
+
+def stem_c1_wgrad(dy1, a0, grad_out):
+    """grad_out (64,4,1,1) f32 += dW1."""
+    npix = a0.numel() // 4
+    ws = _f64ws(256, a0.device, "c1w")
+    _lib.call("sarssl_stem_c1_wgrad", _p(dy1), _p(a0), c_long(npix), _p(ws), c_int(dt(a0)), _stream())
+    _lib.call("sarssl_f64_accum", _p(ws), _p(grad_out), c_int(256), c_float(1.0), _stream())
+
+
+def stem_c4_fwd(y3, W4, scale, shift):
+    B, F, T, _ = y3.shape
+    y4 = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)
+    _lib.call("sarssl_stem_c4_fwd", _p(y3), _p(W4), _p(scale), _p(shift), c_int(B), c_int(F), c_int(T), _p(y4), c_int(dt(y3)), _stream())
+    return y4
+
+
+def stem_c4_bwd(y3, dy4, W4, aff):
+    """-> g3 (B,F,T,64), red f64[384] = [dW4 (4x64) | s1 (64) | s2 (64)]."""
+    B, F, T, _ = y3.shape
+    g3 = torch.empty_like(y3)
+    red = torch.empty((384,), dtype=torch.float64, device=y3.device)
+    _lib.call("sarssl_stem_c4_bwd", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
+              c_int(T), _p(g3), _p(red), c_int(dt(y3)), _stream())
+    return g3, red
+
+
+def f64_accum(src, dst, scale=1.0):
+    _lib.call("sarssl_f64_accum", _p(src), _p(dst), c_int(src.numel()), c_float(scale), _stream())
+
+
+def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False):
+    """x (B,F,T,64); w_tap [9][64][64] ([tap][co][ci]) in x.dtype; optional BN+ReLU prologue."""
+    _need_cuda(x, w_tap)
+    B, F, T, C = x.shape
+    assert C == 64 and w_tap.dtype == x.dtype and w_tap.is_contiguous() and x.is_contiguous()
+    out = torch.empty_like(x)
+    ws = _f32ws(x.numel(), x.device, "conv_acc") if (precise and x.dtype == torch.float32) else None
+    _lib.call("sarssl_conv3x3_fwd", _p(x), _p(w_tap), _p(out), c_int(dt(x)), c_int(dt(w_tap)), c_int(B), c_int(F), c_int(T),
+              _p(scale), _p(shift), c_int(1 if ws is not None else 0), _p(ws), _stream())
+    return out
+
+
+def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False):
+    """-> dW f32 [9][64][64] ([tap][co][ci])."""
+    _need_cuda(dy, zin)
+    B, F, T, C = zin.shape
+    nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
+    nbytes.restype = c_long
+    part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), zin.device, "wgrad_part")
+    dW = torch.empty((9, 64, 64), dtype=torch.float32, device=zin.device)
+    _lib.call("sarssl_conv3x3_wgrad", _p(dy), _p(zin), c_int(dt(zin)), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW),
+              _p(part), c_int(1 if (precise and zin.dtype == torch.float32) else 0), _stream())
+    return dW
+
+
+# ------------------------------------------------------------------------------------------------
+# channels-last BatchNorm pieces.  aff = (scale, shift, mean, rstd) f32 [C] each
+def cl_stats(x, C):
+    N = x.numel() // C
+    sums = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+    _lib.call("sarssl_cl_stats", _p(x), c_long(N), c_int(C), _p(sums), c_int(dt(x)), _stream())
+    return sums, N
+
+
+def bn_train_affine(x, C, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
+    sums, N = cl_stats(x, C)
+    aff = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    _lib.call("sarssl_bn_finalize", _p(sums), c_long(N), c_int(C), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
+              _p(running_mean), _p(running_var), _p(nbt), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), _stream())
+    return aff
+
+
+def bn_eval_affine(C, gamma, beta, running_mean, running_var, eps=1e-5):
+    aff = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    _lib.call("sarssl_bn_eval_affine", c_int(C), _p(gamma), _p(beta), c_float(eps), _p(running_mean), _p(running_var),
+              _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), _stream())
+    return aff
+
+
+def cl_affine_act(x, C, aff, act):
+    z = torch.empty_like(x)
+    _lib.call("sarssl_cl_affine_act", _p(x), c_long(x.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), c_int(act), _p(z),
+              c_int(dt(x)), _stream())
+    return z
+
+
+def cl_bn_bwd_reduce(dz, y, C, aff, act):
+    red = torch.empty((2 * C,), dtype=torch.float64, device=y.device)
+    _lib.call("sarssl_cl_bn_bwd_reduce", _p(dz), _p(y), c_long(y.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), _p(aff[2]),
+              _p(aff[3]), c_int(act), _p(red), c_int(dt(y)), _stream())
+    return red
+
+
+def cl_bn_bwd_apply(dz, y, C, aff, act, g_is_masked, use_stats, red, out=None):
+    if out is None:
+        out = torch.empty_like(y)
+    _lib.call("sarssl_cl_bn_bwd_apply", _p(dz), _p(y), c_long(y.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), _p(aff[2]),
+              _p(aff[3]), c_int(act), c_int(1 if g_is_masked else 0), c_int(1 if use_stats else 0), _p(red), _p(out),
+              c_int(dt(y)), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# row / elementwise kernels (csrc/elementwise.hip)
+def layernorm_fwd(x2d, gamma, beta, eps=1e-5, out=None, save=True):
+    M, d = x2d.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+    stats = torch.empty((2, M), dtype=torch.float32, device=x2d.device) if save else None
+    _lib.call("sarssl_layernorm_fwd", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d), _p(gamma), _p(beta), c_float(eps),
+              _p(out), c_long(out.stride(0)), _p(stats[0]) if save else c_void_p(0), _p(stats[1]) if save else c_void_p(0),
+              c_int(dt(x2d)), _stream())
+    return out, stats
+
+
+def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, out=None):
+    M, d = x2d.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+    _lib.call("sarssl_layernorm_bwd", _p(dy2d), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
+              _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out),
+              c_long(out.stride(0)), _p(dgamma), _p(dbeta), c_int(dt(x2d)), _stream())
+    return out
+
+
+def glu_fwd(h):
+    M, d2 = h.shape
+    g = torch.empty((M, d2 // 2), dtype=h.dtype, device=h.device)
+    _lib.call("sarssl_glu_fwd", _p(h), c_long(M), c_int(d2 // 2), _p(g), c_int(dt(h)), _stream())
+    return g
+
+
+def glu_bwd(dg, h):
+    dh = torch.empty_like(h)
+    _lib.call("sarssl_glu_bwd", _p(dg), _p(h), c_long(h.shape[0]), c_int(h.shape[1] // 2), _p(dh), c_int(dt(h)), _stream())
+    return dh
+
+
+def dwconv(x3d, w, flip=False):
+    """x (B,T,d), w f32 (d,31)."""
+    B, T, d = x3d.shape
+    y = torch.empty_like(x3d)
+    _lib.call("sarssl_dwconv_fwd", _p(x3d), _p(w), c_int(B), c_int(T), c_int(d), c_int(w.shape[-1]), c_int(1 if flip else 0), _p(y),
+              c_int(dt(x3d)), _stream())
+    return y
+
+
+def dwconv_wgrad(dy3d, x3d, dw_out):
+    B, T, d = x3d.shape
+    _lib.call("sarssl_dwconv_wgrad", _p(dy3d), _p(x3d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), _p(dw_out),
+              c_int(dt(x3d)), _stream())
+
+
+def softmax_relshift_fwd(content, pos, scale, dtype, p_drop=0.0, seed=0):
+    nmat = content.numel() // (content.shape[-1] ** 2)
+    T = content.shape[-1]
+    p = torch.empty(content.shape, dtype=dtype, device=content.device)
+    pd = torch.empty_like(p) if p_drop > 0 else p
+    _lib.call("sarssl_softmax_relshift_fwd", _p(content), _p(pos), c_long(nmat), c_int(T), c_float(scale), _p(p), _p(pd),
+              c_float(p_drop), c_ulonglong(seed), c_int(_DT[dtype]), _stream())
+    return p, pd
+
+
+def softmax_bwd(dpd, p, scale, p_drop=0.0, seed=0):
+    T = p.shape[-1]
+    nmat = p.numel() // (T * T)
+    ds = torch.empty_like(p)
+    _lib.call("sarssl_softmax_bwd", _p(dpd), _p(p), c_long(nmat), c_int(T), c_float(scale), c_float(p_drop), c_ulonglong(seed),
+              _p(ds), c_int(dt(p)), _stream())
+    return ds
+
+
+def relshift_bwd(dscore):
+    T = dscore.shape[-1]
+    dpos = torch.empty_like(dscore)
+    _lib.call("sarssl_relshift_bwd", _p(dscore), c_long(dscore.numel() // (T * T)), c_int(T), _p(dpos), c_int(dt(dscore)), _stream())
+    return dpos
+
+
+def bias2(q2d, u, v):
+    M, d = q2d.shape
+    qu = torch.empty((M, d), dtype=q2d.dtype, device=q2d.device)
+    qv = torch.empty((M, d), dtype=q2d.dtype, device=q2d.device)
+    _lib.call("sarssl_bias2", _p(q2d), c_long(q2d.stride(0)), c_long(M), c_int(d), _p(u), _p(v), _p(qu), _p(qv), c_int(dt(q2d)), _stream())
+    return qu, qv
+
+
+def axpby(x, y, a=1.0, b=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("sarssl_axpby", _p(x), _p(y), c_float(a), c_float(b), c_long(x.numel()), _p(out), c_int(dt(x)), _stream())
+    return out
+
+
+def colsum(x2d, out_f32):
+    """out_f32[n] += sum_m x2d[m][n]."""
+    M, N = x2d.shape
+    _lib.call("sarssl_colsum", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(N), _p(out_f32), c_int(dt(x2d)), _stream())
+
+
+def act_bwd(dz, h, act, p_drop=0.0, seed=0, gscale=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(dz)
+    _lib.call("sarssl_act_bwd", _p(dz), _p(h), c_long(dz.numel()), c_int(act), c_float(p_drop), c_ulonglong(seed), c_float(gscale),
+              _p(out), c_int(dt(dz)), _stream())
+    return out
+
+
+def cast(src, dtype, out=None):
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _lib.call("sarssl_cast", _p(src), c_int(dt(src)), _p(out), c_int(_DT[dtype]), c_long(src.numel()), _stream())
+    return out
+
+
+def masked_mse_fwd(pred, x, idx_i32, mch_i32):
+    """pred (B,T,F*4) -> f32[2] device tensor (loss, diff)."""
+    B, _, F, T, _ = x.shape
+    nm = idx_i32.shape[1]
+    sums = torch.empty((2,), dtype=torch.float64, device=x.device)
+    out = torch.empty((2,), dtype=torch.float32, device=x.device)
+    _lib.call("sarssl_masked_mse_fwd", _p(pred), _p(x), _p(idx_i32), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm), _p(sums),
+              _p(out), c_int(dt(pred)), _stream())
+    return out
+
+
+def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0):
+    B, _, F, T, _ = x.shape
+    dpred = torch.empty_like(pred)
+    _lib.call("sarssl_masked_mse_bwd", _p(pred), _p(x), _p(mp_u8), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm),
+              c_float(gscale), _p(dpred), c_int(dt(pred)), _stream())
+    return dpred
+
+
+def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    _lib.call("sarssl_adam_step", _p(p), _p(g), _p(m), _p(v), _p(p16), c_long(p.numel()), c_float(gscale), c_float(lr),
+              c_float(betas[0]), c_float(betas[1]), c_float(eps), c_int(step), _stream())

@@ -123,3 +123,271 @@ def test_stft_frontend_vs_golden_and_oracle():
     # odd channel count (3 mics -> 2 pairs), ragged frame count (nt not a multiple of 16)
     s3 = recipes.recipe_signal(1, 512 + 256 * 20, 3, seed=4)
     assert _relerr(hip.stft_frontend(s3.to(dev)), orc.data_preprocess(s3)) < 1e-5
+
+
+# ---------------------------------------------------------------- conv stem kernels
+def _cl(x_nchw):          # (B,C,F,T) -> channels-last (B,F,T,C)
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32_precise"])
+@pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64)])
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv3x3_fwd(mode, B, F, T, prologue):
+    from sar_ssl_amd import hip
+    dev = _dev()
+    dtp = torch.bfloat16 if mode == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(B * 100 + F + T)
+    x = torch.randn((B, 64, F, T), generator=g)
+    W = torch.randn((64, 64, 3, 3), generator=g) * 0.05
+    sc = torch.rand(64, generator=g) + 0.5
+    sh = torch.randn(64, generator=g) * 0.3
+    xq = x.to(dtp).float(); Wq = W.to(dtp).float()
+    z = torch.relu(xq * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if prologue else xq
+    if mode == "bf16" and prologue:
+        z = z.to(dtp).float()            # the kernel rounds the prologue output to bf16 before the MFMA
+    ref = torch.nn.functional.conv2d(z.double(), Wq.double(), padding=1)
+    w_tap = Wq.permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous().to(dtp).to(dev)
+    out = hip.conv3x3_fwd(_cl(xq).to(dtp).to(dev), w_tap, sc.to(dev) if prologue else None, sh.to(dev) if prologue else None,
+                          precise=(mode == "f32_precise"))
+    err = _relerr(out.float().cpu(), _cl(ref))
+    assert err < (1e-2 if mode == "bf16" else 5e-5), err
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32_precise"])
+@pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136)])
+def test_conv3x3_wgrad_and_dgrad(mode, B, F, T):
+    from sar_ssl_amd import hip
+    dev = _dev()
+    dtp = torch.bfloat16 if mode == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(7 + F)
+    yprev = torch.randn((B, 64, F, T), generator=g).to(dtp).float()
+    dy = torch.randn((B, 64, F, T), generator=g).to(dtp).float()
+    W = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).to(dtp).float()
+    sc = torch.rand(64, generator=g) + 0.5
+    sh = torch.randn(64, generator=g) * 0.3
+    z = torch.relu(yprev * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if mode == "bf16":
+        z = z.to(dtp).float()
+    z64 = z.double().requires_grad_(True)
+    W64 = W.double().requires_grad_(True)
+    out = torch.nn.functional.conv2d(z64, W64, padding=1)
+    out.backward(dy.double())
+    dW = hip.conv3x3_wgrad(_cl(dy).to(dtp).to(dev), _cl(yprev).to(dtp).to(dev), sc.to(dev), sh.to(dev), precise=(mode == "f32_precise"))
+    ref_dW = W64.grad.permute(2, 3, 0, 1).reshape(9, 64, 64)
+    assert _relerr(dW, ref_dW) < (1e-2 if mode == "bf16" else 5e-5)
+    # data gradient = forward kernel with flipped / transposed weights
+    w_dgrad = W.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous().to(dtp).to(dev)
+    dz = hip.conv3x3_fwd(_cl(dy).to(dtp).to(dev), w_dgrad, precise=(mode == "f32_precise"))
+    assert _relerr(dz.float().cpu(), _cl(z64.grad)) < (1e-2 if mode == "bf16" else 5e-5)
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+def test_stem_pointwise_and_bn(dtp):
+    from sar_ssl_amd import hip
+    dev = _dev()
+    tol = 1e-5 if dtp == torch.float32 else 2e-2
+    g = torch.Generator().manual_seed(3)
+    B, F, T = 2, 16, 8
+    # mask_inputs vs the oracle's formulas
+    x = torch.randn((B, 2, F, T, 2), generator=g)
+    idx, ch = orc.gen_masks(B, T, T // 2, 2)
+    mp, mc = orc.dense_masks(idx, ch, T, 2)
+    v = x.permute(0, 3, 2, 4, 1)
+    mp5, mc5 = mp.view(B, T, 1, 1, 1), mc.view(B, 1, 1, 1, 2)
+    spec_ref = (v * (1 - mp5) * mc5 + v * mp5 * (1 - mc5)).permute(0, 2, 1, 3, 4).reshape(B, F, T, 4)
+    spat_ref = (v * mp5).permute(0, 2, 1, 3, 4).reshape(B, F, T, 4)
+    spec, spat = hip.mask_inputs(x.to(dev), mp.to(torch.uint8).to(dev), ch.to(torch.int32).to(dev), 0, dtp)
+    assert _relerr(spec.float(), spec_ref) < tol and _relerr(spat.float(), spat_ref) < tol
+    s2, t2 = hip.mask_inputs(x.to(dev), mp.to(torch.uint8).to(dev), ch.to(torch.int32).to(dev), 1, dtp)
+    assert _relerr(s2.float(), v.permute(0, 2, 1, 3, 4).reshape(B, F, T, 4)) < tol and torch.equal(s2, t2)
+    # c1 fwd / wgrad
+    a0 = torch.randn((B, F, T, 4), generator=g).to(dtp)
+    W1 = torch.randn((64, 4), generator=g)
+    y1 = hip.stem_c1_fwd(a0.to(dev), W1.to(dev))
+    assert _relerr(y1.float(), a0.float() @ W1.t()) < tol
+    dy1 = torch.randn((B, F, T, 64), generator=g).to(dtp)
+    gW1 = torch.zeros((64, 4), device=dev)
+    hip.stem_c1_wgrad(dy1.to(dev), a0.to(dev), gW1)
+    assert _relerr(gW1, dy1.float().reshape(-1, 64).t() @ a0.float().reshape(-1, 4)) < 1e-4
+    # batch-norm statistics / finalize / running stats
+    y = (torch.randn((B, F, T, 64), generator=g) * 2 + 0.7).to(dtp)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    rm, rv = torch.zeros(64), torch.ones(64)
+    rm_d, rv_d, nbt = rm.to(dev), rv.to(dev), torch.zeros((), dtype=torch.int64, device=dev)
+    aff = hip.bn_train_affine(y.to(dev), 64, gamma.to(dev), beta.to(dev), rm_d, rv_d, nbt)
+    yf = y.float().reshape(-1, 64).double()
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    assert _relerr(aff[2], mean) < 1e-5 and _relerr(aff[3], (var + 1e-5).rsqrt()) < 1e-5
+    assert _relerr(rm_d, 0.1 * mean) < 1e-5 and _relerr(rv_d, 0.9 + 0.1 * yf.var(0, unbiased=True)) < 1e-5
+    assert int(nbt) == 1
+    z = hip.cl_affine_act(y.to(dev), 64, aff, 1)
+    zref = torch.relu((yf - mean) / (var + 1e-5).sqrt() * gamma.double() + beta.double())
+    assert _relerr(z.float().reshape(-1, 64), zref) < tol
+    # c4 fwd (BN+ReLU prologue, (B,T,F,4) output) and its fused backward
+    W4 = torch.randn((4, 64), generator=g) * 0.2
+    y4 = hip.stem_c4_fwd(y.to(dev), W4.to(dev), aff[0], aff[1])
+    zq = zref.float()
+    y4ref = (zq @ W4.t()).reshape(B, F, T, 4).permute(0, 2, 1, 3)
+    assert _relerr(y4.float(), y4ref) < tol
+    dy4 = torch.randn((B, T, F, 4), generator=g).to(dtp)
+    g3, red = hip.stem_c4_bwd(y.to(dev), dy4.to(dev), W4.to(dev), aff)
+    d4 = dy4.float().permute(0, 2, 1, 3).reshape(-1, 4).double()
+    g3ref = (d4 @ W4.double()) * (zref > 0)
+    assert _relerr(g3.float().reshape(-1, 64), g3ref) < tol
+    assert _relerr(red[:256].reshape(4, 64), d4.t() @ zref) < 1e-4
+    xhat = (yf - mean) / (var + 1e-5).sqrt()
+    assert _relerr(red[256:320], g3ref.sum(0)) < 1e-4 and _relerr(red[320:], (g3ref * xhat).sum(0)) < 1e-4
+    # generic BN backward (relu) against autograd
+    yy = yf.clone().requires_grad_(True)
+    zz = torch.relu(torch.nn.functional.batch_norm(yy, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5))
+    dz = torch.randn((B * F * T, 64), generator=g).to(dtp)
+    zz.backward(dz.double())
+    red2 = hip.cl_bn_bwd_reduce(dz.to(dev), y.to(dev), 64, aff, 1)
+    dyk = hip.cl_bn_bwd_apply(dz.to(dev), y.to(dev), 64, aff, 1, False, True, red2)
+    assert _relerr(dyk.float().reshape(-1, 64), yy.grad) < tol
+    # C = 4 path (folded 64-wide view)
+    y4t = torch.randn((B, T, F, 4), generator=g).to(dtp)
+    sums, N = hip.cl_stats(y4t.to(dev), 4)
+    assert N == B * T * F
+    assert _relerr(sums[:4], y4t.float().reshape(-1, 4).double().sum(0)) < 1e-5
+
+
+# ---------------------------------------------------------------- row / elementwise kernels
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [32, 256, 512])
+def test_layernorm(dtp, d):
+    from sar_ssl_amd import hip
+    dev = _dev()
+    tol = 2e-5 if dtp == torch.float32 else 2e-2
+    g = torch.Generator().manual_seed(d)
+    M = 70
+    x = (torch.randn((M, d), generator=g) * 1.5 + 0.3).to(dtp)
+    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
+    dy = torch.randn((M, d), generator=g).to(dtp)
+    res = torch.randn((M, d), generator=g).to(dtp)
+    x64 = x.double().requires_grad_(True); g64 = gamma.double().requires_grad_(True); b64 = beta.double().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(x64, (d,), g64, b64, 1e-5)
+    yref.backward(dy.double())
+    y, stats = hip.layernorm_fwd(x.to(dev), gamma.to(dev), beta.to(dev))
+    assert _relerr(y.float(), yref.detach()) < tol
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    dx = hip.layernorm_bwd(dy.to(dev), x.to(dev), gamma.to(dev), stats, resid=res.to(dev), dgamma=dg, dbeta=db)
+    assert _relerr(dx.float(), x64.grad + res.double()) < tol
+    assert _relerr(dg, g64.grad) < 1e-4 and _relerr(db, b64.grad) < 1e-4
+    # strided output (writes into a wider concat buffer)
+    wide = torch.zeros((M, d + 64), dtype=dtp, device=dev)
+    hip.layernorm_fwd(x.to(dev), gamma.to(dev), beta.to(dev), out=wide[:, 64:], save=False)
+    assert _relerr(wide[:, 64:].float(), yref.detach()) < tol and float(wide[:, :64].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+def test_glu_dwconv_misc(dtp):
+    from sar_ssl_amd import hip
+    dev = _dev()
+    tol = 2e-5 if dtp == torch.float32 else 2e-2
+    g = torch.Generator().manual_seed(11)
+    B, T, d = 2, 40, 64
+    h = torch.randn((B * T, 2 * d), generator=g).to(dtp)
+    dg = torch.randn((B * T, d), generator=g).to(dtp)
+    h64 = h.double().requires_grad_(True)
+    gref = h64[:, :d] * torch.sigmoid(h64[:, d:])
+    gref.backward(dg.double())
+    assert _relerr(hip.glu_fwd(h.to(dev)).float(), gref.detach()) < tol
+    assert _relerr(hip.glu_bwd(dg.to(dev), h.to(dev)).float(), h64.grad) < tol
+    # depthwise conv k=31 (T both longer and shorter than the kernel)
+    for TT in (40, 16):
+        x = torch.randn((B, TT, d), generator=g).to(dtp)
+        w = torch.randn((d, 31), generator=g) * 0.2
+        dy = torch.randn((B, TT, d), generator=g).to(dtp)
+        x64 = x.double().requires_grad_(True); w64 = w.double().requires_grad_(True)
+        yref = torch.nn.functional.conv1d(x64.transpose(1, 2), w64.unsqueeze(1), None, padding=15, groups=d).transpose(1, 2)
+        yref.backward(dy.double())
+        assert _relerr(hip.dwconv(x.to(dev), w.to(dev)).float(), yref.detach()) < tol
+        assert _relerr(hip.dwconv(dy.to(dev), w.to(dev), flip=True).float(), x64.grad) < tol
+        dw = torch.zeros((d, 31), device=dev)
+        hip.dwconv_wgrad(dy.to(dev), x.to(dev), dw)
+        assert _relerr(dw, w64.grad) < 1e-4
+    # bias2 / axpby / colsum / act_bwd / cast
+    q = torch.randn((50, d), generator=g).to(dtp)
+    u, v = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    qu, qv = hip.bias2(q.to(dev), u.to(dev), v.to(dev))
+    assert _relerr(qu.float(), q.float() + u) < tol and _relerr(qv.float(), q.float() + v) < tol
+    assert _relerr(hip.axpby(q.to(dev), qu, 0.5, 2.0).float(), 0.5 * q.float() + 2 * qu.float().cpu()) < tol
+    cs = torch.zeros(d, device=dev)
+    hip.colsum(q.to(dev), cs)
+    assert _relerr(cs, q.float().sum(0)) < 1e-4
+    hpre = torch.randn((50, d), generator=g).to(dtp)
+    h64 = hpre.double().requires_grad_(True)
+    (h64 * torch.sigmoid(h64)).backward(q.double())
+    assert _relerr(hip.act_bwd(q.to(dev), hpre.to(dev), 2).float(), h64.grad) < tol
+    assert _relerr(hip.act_bwd(q.to(dev), hpre.to(dev), 1, gscale=0.5).float(), 0.5 * q.float() * (hpre.float() > 0)) < tol
+    assert torch.equal(hip.cast(u.to(dev), torch.bfloat16).cpu(), u.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T", [16, 100, 256])
+def test_softmax_relshift(dtp, T):
+    from sar_ssl_amd import hip
+    dev = _dev()
+    tol = 2e-5 if dtp == torch.float32 else 1e-2
+    g = torch.Generator().manual_seed(T)
+    nmat = 6
+    content = torch.randn((nmat, T, T), generator=g) * 3
+    pos = torch.randn((nmat, T, T), generator=g) * 3
+    c64 = content.double().requires_grad_(True); p64 = pos.double().requires_grad_(True)
+    score = (c64 + orc.relative_shift(p64)) * 0.17
+    pref = torch.softmax(score, -1)
+    dpd = torch.randn((nmat, T, T), generator=g)
+    pref.backward(dpd.double())
+    p, pd = hip.softmax_relshift_fwd(content.to(dev), pos.to(dev), 0.17, dtp)
+    assert pd is p and _relerr(p.float(), pref.detach()) < tol
+    ds = hip.softmax_bwd(dpd.to(dev), p, 0.17)
+    assert _relerr(ds.float(), c64.grad) < tol
+    dpos = hip.relshift_bwd(ds)
+    assert _relerr(dpos.float(), p64.grad) < tol
+    # dropout: mask consistent between forward and backward
+    p2, pd2 = hip.softmax_relshift_fwd(content.to(dev), pos.to(dev), 0.17, torch.float32, p_drop=0.1, seed=99)
+    keep = (pd2 != 0)
+    assert 0.85 < keep.float().mean().item() < 0.95
+    assert _relerr(pd2[keep], (p2 / 0.9)[keep]) < 1e-5
+    ds2 = hip.softmax_bwd(dpd.to(dev), p2, 0.17, p_drop=0.1, seed=99)
+    dp = dpd.double() * keep.cpu().double() / 0.9
+    pr = p2.double().cpu()
+    assert _relerr(ds2, 0.17 * pr * (dp - (dp * pr).sum(-1, keepdim=True))) < 1e-4
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+def test_masked_mse_and_adam(dtp):
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, F, T = 3, 16, 8
+    x = torch.randn((B, 2, F, T, 2), generator=g)
+    pred = torch.randn((B, T, F * 4), generator=g).to(dtp)
+    idx, ch = orc.gen_masks(B, T, T // 2, 2)
+    mp, mc = orc.dense_masks(idx, ch, T, 2)
+    v = x.permute(0, 3, 2, 4, 1)
+    mc5 = mc.view(B, 1, 1, 1, 2)
+    p64 = pred.double().reshape(B, T, F, 2, 2).requires_grad_(True)
+    gi = idx.view(B, -1, 1, 1).expand(-1, -1, F, 2)
+    pm = (p64 * (1 - mc5)).sum(-1).gather(1, gi)
+    tm = (v.double() * (1 - mc5)).sum(-1).gather(1, gi)
+    om = (v.double() * mc5).sum(-1).gather(1, gi)
+    loss, diff = ((pm - tm) ** 2).mean(), ((tm - om) ** 2).mean()
+    loss.backward()
+    out = hip.masked_mse_fwd(pred.to(dev), x.to(dev), idx.to(torch.int32).to(dev), ch.to(torch.int32).to(dev))
+    assert abs(out[0].item() / loss.item() - 1) < 1e-5 and abs(out[1].item() / diff.item() - 1) < 1e-5
+    dpred = hip.masked_mse_bwd(pred.to(dev), x.to(dev), mp.to(torch.uint8).to(dev), ch.to(torch.int32).to(dev), T // 2)
+    assert _relerr(dpred.float().reshape(B, T, F, 2, 2), p64.grad) < (1e-5 if dtp == torch.float32 else 1e-2)
+    if dtp == torch.float32:
+        n = 1000
+        p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g)
+        pr = {"w": p.clone()}; st = {}
+        pd_, m, vv = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        p16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        for step in (1, 2, 3):
+            orc.adam_step(pr, {"w": gr}, st, 1e-3)
+            hip.adam_step(pd_, gr.to(dev), m, vv, p16, 1e-3, step)
+        assert _relerr(pd_, pr["w"]) < 1e-6
+        assert torch.equal(p16.cpu(), pd_.cpu().to(torch.bfloat16))
