@@ -1,0 +1,41 @@
+"""Bridge between torch.autograd and the hand-written forward/backward pairs in engine.py.
+
+One autograd node per module call: forward runs the HIP forward and keeps a list of saved tensors, backward
+runs the hand-written HIP backward, which accumulates parameter gradients directly into ``p.grad`` (so the
+parameters are passed to ``apply`` only to make the output require grad; their returned gradients are None).
+"""
+import torch
+
+from . import hip
+from .runtime import RT
+
+
+def _to_rt(x):
+    return x if x.dtype == RT.dtype else hip.cast(x.contiguous(), RT.dtype)
+
+
+class _TapeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fwd, bwd, x, *params):
+        if not x.is_cuda:
+            raise hip._lib.SarsslHipError("sar_ssl_amd modules run on the GPU only (no CPU fallback); got a CPU tensor")
+        saved = []
+        y = fwd(_to_rt(x.detach().contiguous()), saved)
+        ctx.bwd, ctx.saved, ctx.in_dtype, ctx.nparams = bwd, saved, x.dtype, len(params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ctx.bwd(_to_rt(dy.contiguous()), ctx.saved)
+        if dx is not None and dx.dtype != ctx.in_dtype:
+            dx = hip.cast(dx.contiguous(), ctx.in_dtype)
+        return (None, None, dx) + (None,) * ctx.nparams
+
+
+def tape_apply(module, fwd, bwd, x):
+    params = [p for p in module.parameters() if p.requires_grad]
+    if torch.is_grad_enabled() and (x.requires_grad or params):
+        return _TapeFn.apply(fwd, bwd, x, *params)
+    if not x.is_cuda:
+        raise hip._lib.SarsslHipError("sar_ssl_amd modules run on the GPU only (no CPU fallback); got a CPU tensor")
+    return fwd(_to_rt(x.detach().contiguous()), [])

@@ -410,7 +410,9 @@ __global__ void loss_finalize_kernel(const double* __restrict__ sums, double cou
 // dpred = gscale * 2 (pred - tar) / count on (masked frame, masked channel) entries, 0 elsewhere
 template <typename T>
 __global__ void masked_mse_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ x, const uint8_t* __restrict__ mp,
-                                      const int* __restrict__ mch, int nb, int F, int Tn, float coef, T* __restrict__ dpred) {
+                                      const int* __restrict__ mch, int nb, int F, int Tn, float coef0,
+                                      const float* __restrict__ gs_dev, T* __restrict__ dpred) {
+    const float coef = gs_dev ? coef0 * gs_dev[0] : coef0;        // upstream d(loss) kept on the device: no host sync
     const long total = (long)nb * Tn * F * 2;          // one thread per (b,t,f,reim): 2 mics = 2 consecutive outputs
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i & 1);
@@ -577,9 +579,10 @@ extern "C" int sarssl_masked_mse_fwd(const void* pred, const float* x, const int
 }
 // dpred = gscale * dLoss/dpred, loss = mean over nb*nm*F*2 entries
 extern "C" int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F,
-                                     int Tn, int nm, float gscale, void* dpred, int dtype, void* stream) {
+                                     int Tn, int nm, float gscale, const float* gscale_dev, void* dpred, int dtype,
+                                     void* stream) {
     const float coef = gscale * 2.0f / (float)((double)nb * nm * F * 2);
-    DISPATCH_T(dtype, (masked_mse_bwd_kernel<T><<<nblocks_for((long)nb * Tn * F * 2, 256, 8192), 256, 0, ST>>>((const T*)pred, x, mp, mch, nb, F, Tn, coef, (T*)dpred)));
+    DISPATCH_T(dtype, (masked_mse_bwd_kernel<T><<<nblocks_for((long)nb * Tn * F * 2, 256, 8192), 256, 0, ST>>>((const T*)pred, x, mp, mch, nb, F, Tn, coef, gscale_dev, (T*)dpred)));
     SARSSL_CHECK_LAUNCH("masked_mse_bwd_kernel");
     return 0;
 }

@@ -1,0 +1,366 @@
+"""Forward/backward orchestration of the MC-Conformer pretraining path on the HIP kernels.
+
+Every function here takes activations as 2-D ``[M = B*T, d]`` (or channels-last 4-D) tensors in the runtime
+dtype, the owning ``nn.Module`` (for its parameters, which keep the reference's state_dict layout) and a list to
+push saved tensors on; the ``*_bwd`` twin consumes what was saved, accumulates parameter gradients straight into
+``p.grad`` (views of the flat gradient buffer when the model is flattened) and returns the input gradient.
+Reference semantics are cited per function; the math is restated in oracle/sarssl_oracle.py.
+"""
+import math
+
+import torch
+
+from . import hip
+from .runtime import RT, wt, gbuf, weights_version
+
+RELU, SWISH = 1, 2
+
+
+# ------------------------------------------------------------------------------------------------ GEMM helpers
+def mm_nt(x, W, **kw):
+    """x [M,K] @ W[N,K]^T -> [M,N]   (nn.Linear forward)."""
+    M, K = x.shape
+    return hip.gemm(x, W, M=M, N=W.shape[0], K=K, lda=x.stride(0), ldb=W.stride(0), precise=RT.precise, **kw)
+
+
+def mm_nn(dy, W, **kw):
+    """dy [M,N] @ W[N,K] -> [M,K]   (input gradient of nn.Linear)."""
+    M, N = dy.shape
+    return hip.gemm(dy, W, a_kc=True, b_kc=False, M=M, N=W.shape[1], K=N, lda=dy.stride(0), ldb=W.stride(0),
+                    precise=RT.precise, **kw)
+
+
+def mm_tn_acc(dy, x, gW):
+    """gW[N,K] += dy[M,N]^T @ x[M,K]   (weight gradient of nn.Linear, f32 accumulate into the grad buffer)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    g2 = gW.view(N, K)
+    hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), out=g2, ldc=K,
+             resid=g2, ldr=K, res_scale=1.0, precise=RT.precise)
+
+
+def to_rt(x):
+    return x if x.dtype == RT.dtype else hip.cast(x.contiguous(), RT.dtype)
+
+
+def _cached(module, name, builder):
+    """Per-module cache of re-laid-out weights, invalidated whenever parameters change."""
+    key = (weights_version(), RT.dtype)
+    c = module.__dict__.setdefault("_wcache", {})
+    hit = c.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            c[name] = (key, builder())
+    return c[name][1]
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm plumbing
+def bn_affine(x, C, bn, train):
+    """BatchNorm{1,2}d affine for channels-last x: batch statistics (+ running-stat update) in train mode, running
+    statistics in eval mode.  Returns aff = [scale, shift, mean, rstd] (4, C) f32."""
+    if train:
+        return hip.bn_train_affine(x, C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum)
+    return hip.bn_eval_affine(C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, eps=bn.eps)
+
+
+def bn_param_grads(bn, red, C):
+    """red = [sum g | sum g*xhat] (f64, 2C) -> dbeta, dgamma."""
+    hip.f64_accum(red[:C], gbuf(bn.bias))
+    hip.f64_accum(red[C:2 * C], gbuf(bn.weight))
+
+
+# ------------------------------------------------------------------------------------------------ CNN stem
+def _taps(conv):
+    """(co,ci,3,3) -> forward taps [9][co][ci] and data-gradient taps [9][ci][co] (flipped), runtime dtype."""
+    def build():
+        W = conv.weight.data
+        fwd = W.permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous()
+        dgr = W.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous()
+        return to_rt(fwd), to_rt(dgr)
+    return _cached(conv, "taps", build)
+
+
+def _patch_w(conv, F):
+    """(d,4,F,1) -> [d][f*4+c] so the patch conv is a plain GEMM over the (B,T,F,4) tensor."""
+    def build():
+        W = conv.weight.data
+        return to_rt(W[:, :, :, 0].permute(0, 2, 1).reshape(W.shape[0], F * 4).contiguous())
+    return _cached(conv, "patchw", build)
+
+
+def stem_fwd(a0, pe, train, saved):
+    """``patch_embed`` (code/model.py:50-64) on channels-last a0 (B,F,T,4) -> [B*T, d]."""
+    B, F, T, _ = a0.shape
+    y1 = hip.stem_c1_fwd(a0, pe[0].weight.data.view(64, 4))
+    aff1 = bn_affine(y1, 64, pe[1], train)
+    y2 = hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], precise=RT.precise)
+    aff2 = bn_affine(y2, 64, pe[4], train)
+    y3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise)
+    aff3 = bn_affine(y3, 64, pe[7], train)
+    y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])           # (B,T,F,4)
+    aff4 = bn_affine(y4, 4, pe[10], train)
+    z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
+    e = mm_nt(z4, _patch_w(pe[12], F))
+    saved.append((a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
+    return e
+
+
+def stem_bwd(de, pe, saved):
+    a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
+    B, F, T, _ = a0.shape
+    d = de.shape[1]
+    # patch GEMM
+    gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
+    mm_tn_acc(de, z4, gtmp)
+    gbuf(pe[12].weight).add_(gtmp.view(d, F, 4).permute(0, 2, 1).unsqueeze(-1))
+    dz4 = mm_nn(de, _patch_w(pe[12], F))                                                   # (B,T,F,4)
+    red4 = hip.cl_bn_bwd_reduce(dz4, y4, 4, aff4, RELU)
+    dy4 = hip.cl_bn_bwd_apply(dz4, y4, 4, aff4, RELU, False, train, red4)
+    bn_param_grads(pe[10], red4, 4)
+    # 64->4 conv + BN3/ReLU backward reductions in one pass over y3
+    g3, red = hip.stem_c4_bwd(y3, dy4, pe[9].weight.data.view(4, 64), aff3)
+    hip.f64_accum(red[:256], gbuf(pe[9].weight))
+    dy3 = hip.cl_bn_bwd_apply(g3, y3, 64, aff3, RELU, True, train, red[256:], out=g3)
+    bn_param_grads(pe[7], red[256:], 64)
+    # second 3x3 conv
+    dW = hip.conv3x3_wgrad(dy3, y2, aff2[0], aff2[1], precise=RT.precise)
+    gbuf(pe[6].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
+    dz2 = hip.conv3x3_fwd(dy3, _taps(pe[6])[1], precise=RT.precise)
+    red2 = hip.cl_bn_bwd_reduce(dz2, y2, 64, aff2, RELU)
+    dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2)
+    bn_param_grads(pe[4], red2, 64)
+    # first 3x3 conv
+    dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise)
+    gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
+    dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
+    red1 = hip.cl_bn_bwd_reduce(dz1, y1, 64, aff1, RELU)
+    dy1 = hip.cl_bn_bwd_apply(dz1, y1, 64, aff1, RELU, False, train, red1, out=dz1)
+    bn_param_grads(pe[1], red1, 64)
+    hip.stem_c1_wgrad(dy1, a0, gbuf(pe[0].weight))
+    return None        # the stem input is data
+
+
+# ------------------------------------------------------------------------------------------------ Conformer modules
+def _p(drop, train):
+    return float(drop.p) if train else 0.0
+
+
+def ffn_fwd(x, ff, factor, train, saved, out=None):
+    """x + factor * FeedForwardModule(x)  (conformer/feed_forward.py:47-57, Conformer.py:60-67)."""
+    seq = ff.sequential
+    ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+    p1, p2 = _p(seq[3], train), _p(seq[5], train)
+    s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
+    hpre = torch.empty((x.shape[0], seq[1].linear.weight.shape[0]), dtype=x.dtype, device=x.device)
+    a = mm_nt(ln, wt(seq[1].linear.weight), bias=seq[1].linear.bias.data, act=SWISH, preact=hpre, p_drop=p1, seed=s1)
+    y = mm_nt(a, wt(seq[4].linear.weight), bias=seq[4].linear.bias.data, p_drop=p2, seed=s2, out_scale=factor,
+              resid=x, ldr=x.stride(0), res_scale=1.0, out=out, ldc=(out.stride(0) if out is not None else None))
+    saved.append((x, ln, stats, hpre, a, p1, s1, p2, s2, factor))
+    return y
+
+
+def ffn_bwd(dy, ff, saved):
+    x, ln, stats, hpre, a, p1, s1, p2, s2, factor = saved.pop()
+    seq = ff.sequential
+    dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
+    mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
+    hip.colsum(dz2, gbuf(seq[4].linear.bias))
+    da = mm_nn(dz2, wt(seq[4].linear.weight))
+    dh = hip.act_bwd(da, hpre, SWISH, p_drop=p1, seed=s1, out=da)
+    mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight))
+    hip.colsum(dh, gbuf(seq[1].linear.bias))
+    dln = mm_nn(dh, wt(seq[1].linear.weight))
+    return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias))
+
+
+def _pe(mod, T):
+    """First T rows of the sinusoid table in the runtime dtype (persistent buffer 'pe', embedding.py:31-39)."""
+    key = (T, RT.dtype)
+    c = mod.__dict__.setdefault("_pecache", {})
+    if key not in c:
+        c[key] = to_rt(mod.positional_encoding.pe[0, :T].contiguous())
+    return c[key]
+
+
+def mhsa_fwd(x, mod, B, T, train, saved):
+    """x + MultiHeadedSelfAttentionModule(x)  (conformer/attention.py:143-151, 72-113).
+
+    Attention core = batched MFMA GEMMs over (b, head) + one fused scale/relative-shift/softmax/dropout kernel;
+    the positional projection is computed once per call (it is batch-invariant)."""
+    att = mod.attention
+    H, dh, d = att.num_heads, att.d_head, att.d_model
+    M = B * T
+    ln, stats = hip.layernorm_fwd(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps)
+    q = mm_nt(ln, wt(att.query_proj.linear.weight), bias=att.query_proj.linear.bias.data)
+    k = mm_nt(ln, wt(att.key_proj.linear.weight), bias=att.key_proj.linear.bias.data)
+    v = mm_nt(ln, wt(att.value_proj.linear.weight), bias=att.value_proj.linear.bias.data)
+    pe = _pe(mod, T)
+    pos = mm_nt(pe, wt(att.pos_proj.linear.weight))                                          # [T, d]
+    qu, qv = hip.bias2(q, att.u_bias.data.view(-1), att.v_bias.data.view(-1))
+    nbh = B * H
+    content = hip.gemm(qu, k, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * d, dh),
+                       out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
+    pscore = hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh),
+                      out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
+    pa = _p(att.dropout, train)
+    sa = RT.next_seed() if pa > 0 else 0
+    scale = 1.0 / math.sqrt(d)                                                               # 1/sqrt(d_model), attention.py:57
+    p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, pa, sa)
+    del content, pscore
+    ctx = torch.empty((M, d), dtype=RT.dtype, device=x.device)
+    hip.gemm(pd, v, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=ctx, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    po = _p(mod.dropout, train)
+    so = RT.next_seed() if po > 0 else 0
+    y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,
+              resid=x, ldr=x.stride(0), res_scale=1.0)
+    saved.append((x, ln, stats, qu, qv, k, v, pos, pe, p, pd, pa, sa, ctx, po, so, B, T))
+    return y
+
+
+def mhsa_bwd(dy, mod, saved):
+    x, ln, stats, qu, qv, k, v, pos, pe, p, pd, pa, sa, ctx, po, so, B, T = saved.pop()
+    att = mod.attention
+    H, dh, d = att.num_heads, att.d_head, att.d_model
+    M, nbh = B * T, B * H
+    dev = x.device
+    dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
+    mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight))
+    hip.colsum(dout, gbuf(att.out_proj.linear.bias))
+    dctx = mm_nn(dout, wt(att.out_proj.linear.weight))
+    # dP = dctx @ v^T ; dv = P^T @ dctx
+    dpd = hip.gemm(dctx, v, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * d, dh),
+                   out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
+    dv = torch.empty((M, d), dtype=RT.dtype, device=dev)
+    hip.gemm(pd, dctx, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dv, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    scale = 1.0 / math.sqrt(d)
+    ds = hip.softmax_bwd(dpd, p, scale, pa, sa)                                              # d content score
+    del dpd
+    dps = hip.relshift_bwd(ds)                                                               # d (unshifted) pos score
+    dqu = torch.empty((M, d), dtype=RT.dtype, device=dev)
+    hip.gemm(ds, k, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dqu, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    dk = torch.empty((M, d), dtype=RT.dtype, device=dev)
+    hip.gemm(ds, qu, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dk, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    dqv = torch.empty((M, d), dtype=RT.dtype, device=dev)
+    hip.gemm(dps, pos, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(0, dh), out=dqv, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    # d pos (per batch item, then summed over the batch): dpos[b][m][h,:] = sum_i dps[b,h,i,m] * qv[b,i,h,:]
+    dposb = torch.empty((B, T, d), dtype=RT.dtype, device=dev)
+    hip.gemm(dps, qv, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dposb, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
+    hip.colsum(dposb.view(B, T * d), dpos)
+    dpos_rt = to_rt(dpos.view(T, d))
+    mm_tn_acc(dpos_rt, pe, gbuf(att.pos_proj.linear.weight))
+    hip.colsum(dqu, gbuf(att.u_bias).view(-1))
+    hip.colsum(dqv, gbuf(att.v_bias).view(-1))
+    dq = hip.axpby(dqu, dqv, 1.0, 1.0, out=dqu)
+    for proj, g in ((att.query_proj, dq), (att.key_proj, dk), (att.value_proj, dv)):
+        mm_tn_acc(g, ln, gbuf(proj.linear.weight))
+        hip.colsum(g, gbuf(proj.linear.bias))
+    dln = mm_nn(dq, wt(att.query_proj.linear.weight))
+    dln = mm_nn(dk, wt(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
+    dln = mm_nn(dv, wt(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
+    return hip.layernorm_bwd(dln, x, mod.layer_norm.weight.data, stats, resid=dy, dgamma=gbuf(mod.layer_norm.weight),
+                             dbeta=gbuf(mod.layer_norm.bias))
+
+
+def convmod_fwd(x, cm, B, T, train, saved):
+    """x + ConformerConvModule(x)  (conformer/convolution.py:136-149)."""
+    seq = cm.sequential
+    d = x.shape[1]
+    ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+    pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
+    h = mm_nt(ln, wt(pw1.weight).view(2 * d, d), bias=pw1.bias.data)                         # [M, 2d]
+    g = hip.glu_fwd(h)
+    c = hip.dwconv(g.view(B, T, d), dw.weight.data.view(d, -1))
+    aff = bn_affine(c, d, bn, train)
+    s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
+    po = _p(seq[8], train)
+    so = RT.next_seed() if po > 0 else 0
+    y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
+    saved.append((x, ln, stats, h, g, c, aff, s, po, so, B, T, train))
+    return y
+
+
+def convmod_bwd(dy, cm, saved):
+    x, ln, stats, h, g, c, aff, s, po, so, B, T, train = saved.pop()
+    seq = cm.sequential
+    d = x.shape[1]
+    pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
+    dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
+    mm_tn_acc(dout, s, gbuf(pw2.weight))
+    hip.colsum(dout, gbuf(pw2.bias))
+    ds = mm_nn(dout, wt(pw2.weight).view(d, d))
+    red = hip.cl_bn_bwd_reduce(ds, c, d, aff, SWISH)
+    dc = hip.cl_bn_bwd_apply(ds, c, d, aff, SWISH, False, train, red, out=ds).view(B, T, d)
+    bn_param_grads(bn, red, d)
+    dg = hip.dwconv(dc, dw.weight.data.view(d, -1), flip=True)
+    hip.dwconv_wgrad(dc, g.view(B, T, d), gbuf(dw.weight).view(d, -1))
+    dh = hip.glu_bwd(dg.view(B * T, d), h)
+    mm_tn_acc(dh, ln, gbuf(pw1.weight))
+    hip.colsum(dh, gbuf(pw1.bias))
+    dln = mm_nn(dh, wt(pw1.weight).view(2 * d, d))
+    return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias))
+
+
+def block_fwd(x, blk, B, T, train, saved, out=None):
+    """ConformerBlock (code/common/Conformer.py:59-91)."""
+    seq = blk.sequential
+    x = ffn_fwd(x, seq[0].module, seq[0].module_factor, train, saved)
+    x = mhsa_fwd(x, seq[1].module, B, T, train, saved)
+    x = convmod_fwd(x, seq[2].module, B, T, train, saved)
+    x = ffn_fwd(x, seq[3].module, seq[3].module_factor, train, saved)
+    y, stats = hip.layernorm_fwd(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
+    saved.append((x, stats))
+    return y
+
+
+def block_bwd(dy, blk, saved):
+    seq = blk.sequential
+    x, stats = saved.pop()
+    d = hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias))
+    d = ffn_bwd(d, seq[3].module, saved)
+    d = convmod_bwd(d, seq[2].module, saved)
+    d = mhsa_bwd(d, seq[1].module, saved)
+    return ffn_bwd(d, seq[0].module, saved)
+
+
+def encoder_fwd(x, enc, B, T, train, saved, out=None):
+    """ConformerEncoder.forward, add_same_one=False (code/common/Conformer.py:165-195)."""
+    n = len(enc.layers)
+    for i, blk in enumerate(enc.layers):
+        x = block_fwd(x, blk, B, T, train, saved, out=out if i == n - 1 else None)
+    return x
+
+
+def encoder_bwd(dy, enc, saved):
+    for blk in reversed(enc.layers):
+        dy = block_bwd(dy, blk, saved)
+    return dy
+
+
+# ------------------------------------------------------------------------------------------------ decoder + loss
+def decoder_fwd(e, dec, saved):
+    """EmbedDecoder ['','fc'] (code/model.py:295-301, 321-334): Linear -> ReLU -> Linear."""
+    l1, l2 = dec.proj[0], dec.proj[2]
+    h = mm_nt(e, wt(l1.weight), bias=l1.bias.data, act=RELU)
+    pred = mm_nt(h, wt(l2.weight), bias=l2.bias.data)
+    saved.append((e, h))
+    return pred
+
+
+def decoder_bwd(dpred, dec, saved):
+    e, h = saved.pop()
+    l1, l2 = dec.proj[0], dec.proj[2]
+    mm_tn_acc(dpred, h, gbuf(l2.weight))
+    hip.colsum(dpred, gbuf(l2.bias))
+    dh = mm_nn(dpred, wt(l2.weight))
+    dh = hip.act_bwd(dh, h, RELU, out=dh)
+    mm_tn_acc(dh, e, gbuf(l1.weight))
+    hip.colsum(dh, gbuf(l1.bias))
+    return mm_nn(dh, wt(l1.weight))

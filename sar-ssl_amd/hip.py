@@ -349,11 +349,12 @@ def masked_mse_fwd(pred, x, idx_i32, mch_i32):
     return out
 
 
-def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0):
+def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0, gscale_dev=None):
+    """gscale_dev: optional f32 device scalar (the incoming d(loss)); multiplied in-kernel, no host sync."""
     B, _, F, T, _ = x.shape
     dpred = torch.empty_like(pred)
     _lib.call("sarssl_masked_mse_bwd", _p(pred), _p(x), _p(mp_u8), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm),
-              c_float(gscale), _p(dpred), c_int(dt(pred)), _stream())
+              c_float(gscale), _p(gscale_dev), _p(dpred), c_int(dt(pred)), _stream())
     return dpred
 
 

@@ -1,0 +1,313 @@
+"""MC-Conformer models with the reference's constructors, forward signatures and state_dict keys
+(code/model.py: EmbedEncoder :18, EmbedDecoder :264, SARSSL :350, SARSSL_MultiCH :793, MCConformer :824).
+
+Only the architectures on the pretraining path are built (model=['cnn','conformer'] encoders, ['','fc'] decoder,
+frame patches); the ablation backbones of the reference are out of scope and rejected loudly.
+All device work runs through the HIP kernels (engine.py); the whole pretrain forward is one autograd node whose
+backward is the hand-written backward pass.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine, hip
+from .autograd import tape_apply
+from .runtime import RT
+from .common import utils_module as at_module
+from .common.Conformer import ConformerEncoder
+
+
+def _check_cnn_conformer(model):
+    if list(model) != ["cnn", "conformer"]:
+        raise NotImplementedError("only model=['cnn','conformer'] (the MC-Conformer) is implemented, got %r" % (model,))
+
+
+class EmbedEncoder(nn.Module):
+    def __init__(self, sig_shape, patch_shape, dembed, model=["cnn", "conformer"], mode="spat", use_cls=False, device="cpu"):
+        super().__init__()
+        _check_cnn_conformer(model)
+        if use_cls:
+            raise NotImplementedError("use_cls is never enabled on the reference's default path")
+        self.sig_shape, self.patch_shape, self.dembed, self.device = sig_shape, patch_shape, dembed, device
+        self.model, self.use_cls = model, use_cls
+        nf, nt, nreim, nmic = sig_shape
+        nch = nreim * nmic
+        assert nch == 4 and tuple(patch_shape) == (nf, 1), "frame patches of 2 mics x (re, im) only"
+        mhsa_nlayer = 1 if mode == "spec" else 3                                              # code/model.py:38-43
+        conv_chs = 64
+        self.patch_recover = at_module.PatchRecover(output_shape=(nf, nt), patch_shape=self.patch_shape)
+        self.patch_embed = nn.Sequential(
+            nn.Conv2d(nch, conv_chs, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=False),
+            nn.BatchNorm2d(conv_chs),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(conv_chs, conv_chs, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False),
+            nn.BatchNorm2d(conv_chs),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(conv_chs, conv_chs, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False),
+            nn.BatchNorm2d(conv_chs),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(conv_chs, nch, kernel_size=(1, 1), stride=(1, 1), padding=0, bias=False),
+            nn.BatchNorm2d(nch),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(int(nch), dembed, kernel_size=patch_shape, stride=patch_shape, padding=0, bias=False),
+        )
+        self.embed = ConformerEncoder(encoder_dim=self.dembed, num_layers=mhsa_nlayer, num_attention_heads=4,
+                                      feed_forward_expansion_factor=4)
+
+    # ---- channels-last fused path used by SARSSL / MCConformer
+    def _fwd_cl(self, a0, B, T, saved, out=None):
+        e = engine.stem_fwd(a0, self.patch_embed, self.training, saved)
+        return engine.encoder_fwd(e, self.embed, B, T, self.training, saved, out=out)
+
+    def _bwd_cl(self, dy, saved):
+        de = engine.encoder_bwd(dy, self.embed, saved)
+        return engine.stem_bwd(de, self.patch_embed, saved)
+
+    def forward(self, embed, add_same_one=False):
+        """embed: (nbatch, npatch, dpatch*nch) -> (nbatch, npatch, dembed)."""
+        assert not add_same_one
+        B, T, dim = embed.shape
+        F = self.patch_shape[0]
+
+        def fwd(x, saved):
+            a0 = x.view(B, T, F, 4).permute(0, 2, 1, 3).contiguous()                          # (B,F,T,4), model.py:204-206
+            return self._fwd_cl(a0, B, T, saved).view(B, T, self.dembed)
+
+        def bwd(dy, saved):
+            self._bwd_cl(dy.reshape(B * T, self.dembed), saved)
+            return None                                                                       # inputs are data
+        return tape_apply(self, fwd, bwd, embed)
+
+
+class EmbedDecoder(nn.Module):
+    def __init__(self, sig_shape, patch_shape, dembed, model=["", "fc"], use_cls=False):
+        super().__init__()
+        if list(model) != ["", "fc"]:
+            raise NotImplementedError("only the ['', 'fc'] decoder of the pretraining path is implemented")
+        self.model, self.use_cls = model, use_cls
+        nf, nt, nreim, nmic = sig_shape
+        self.dpatch = patch_shape[0] * patch_shape[1]
+        dembed_out = self.dpatch * nreim * nmic
+        dff = dembed_out * 3
+        self.proj = nn.Sequential(nn.Linear(dembed, dff), nn.ReLU(), nn.Linear(dff, dembed_out))
+
+    def forward(self, embed, add_same_one=False):
+        B, T, d = embed.shape
+        return tape_apply(
+            self,
+            lambda x, saved: engine.decoder_fwd(x.view(B * T, d), self, saved).view(B, T, -1),
+            lambda dy, saved: engine.decoder_bwd(dy.reshape(B * T, -1), self, saved).view(B, T, d),
+            embed)
+
+
+class LazyVis(dict):
+    """The reference folds mask / prediction / target to (B,F,T,..) every step (code/model.py:595-599, 776-790) although
+    they are only consumed on plotting epochs.  Same keys, materialised on first access."""
+
+    def __init__(self, pred, x, mp_u8, mch):
+        super().__init__()
+        self._src = (pred, x, mp_u8, mch)
+        for k in ("mask", "pred", "tar"):
+            dict.__setitem__(self, k, None)
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is None:
+            pred, x, mp, mch = self._src
+            B, _, F, T, _ = x.shape
+            if key == "pred":                                  # (B,T,F,2,2) -> (B,F,T,2,2)
+                v = pred.detach().float().view(B, T, F, 2, 2).permute(0, 2, 1, 3, 4)
+            elif key == "tar":                                 # x is (B,mic,F,T,reim) -> (B,F,T,reim,mic)
+                v = x.detach().permute(0, 2, 3, 4, 1)
+            else:                                              # mask (B,F,T,mic): 0 where (masked frame, masked mic)
+                mc = torch.ones((B, 2), device=x.device).scatter_(1, mch.long().view(B, 1), 0.0)
+                m = 1.0 - (1.0 - mp.float()).view(B, 1, T, 1) * (1.0 - mc).view(B, 1, 1, 2)
+                v = m.expand(B, F, T, 2)
+            dict.__setitem__(self, key, v)
+        return v
+
+
+class _PretrainFn(torch.autograd.Function):
+    """Whole pretrain forward (masking -> 2 encoders -> decoder -> masked MSE) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, net, x, idx_i32, ch_i32, mp_u8, *params):
+        B, _, F, T, _ = x.shape
+        saved = []
+        spec_in, spat_in = hip.mask_inputs(x, mp_u8, ch_i32, 0, RT.dtype)
+        ds, dt_ = net.spec_encoder.dembed, net.spat_encoder.dembed
+        ecat = torch.empty((B * T, ds + dt_), dtype=RT.dtype, device=x.device)
+        net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
+        net.spat_encoder._fwd_cl(spat_in, B, T, saved, out=ecat[:, ds:])
+        pred = engine.decoder_fwd(ecat, net.decoder, saved)
+        out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32)
+        ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds)
+        ctx.nparams = len(params)
+        ctx.mark_non_differentiable(out, pred)
+        return out[0].clone(), out, pred
+
+    @staticmethod
+    def backward(ctx, dloss, _dout, _dpred):
+        net, saved = ctx.net, ctx.saved
+        pred, x, mp_u8, ch_i32, nm, ds = ctx.aux
+        dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
+        decat = engine.decoder_bwd(dpred, net.decoder, saved)
+        net._after_backward_stage("decoder")
+        # encoder backward takes column slices of the concatenated decoder-input gradient (row stride 768)
+        net.spat_encoder._bwd_cl(decat[:, ds:], saved)
+        net._after_backward_stage("spat_encoder")
+        net.spec_encoder._bwd_cl(decat[:, :ds], saved)
+        net._after_backward_stage("spec_encoder")
+        return (None,) * (5 + ctx.nparams)
+
+
+class SARSSL(nn.Module):
+    def __init__(self, sig_shape=[256, 256, 2, 2], patch_shape=(256, 1), patch_mode="T", nmasked_patch=128 * 1, pretrain=True,
+                 use_cls=False, downstream_token="all", downstream_head="mlp", downstream_embed="spec_spat",
+                 downstream_dlabel=1, device="cpu", pretrain_frozen_encoder=False):
+        super().__init__()
+        nf, nt, nreim, nmic = sig_shape
+        if tuple(patch_shape) != (nf, 1):
+            patch_shape = (nf, 1)                                                             # frame patches only
+        npatch_shape = [int(nf / patch_shape[0]), int(nt / patch_shape[1])]
+        if nmasked_patch != (npatch_shape[0] * npatch_shape[1] // 2):                         # code/model.py:361-364
+            nmasked_patch = npatch_shape[0] * npatch_shape[1] // 2
+        if use_cls or pretrain_frozen_encoder:
+            raise NotImplementedError("use_cls / pretrain_frozen_encoder are outside the pretraining hot path")
+        self.pretrain, self.pretrain_frozen_encoder, self.device, self.use_cls = pretrain, pretrain_frozen_encoder, device, use_cls
+        self.sig_shape = list(sig_shape)
+        self.patch_split = at_module.PatchSplit(patch_shape=patch_shape, f_first=False)
+        self.patch_recover = at_module.PatchRecover(output_shape=(nf, nt), patch_shape=patch_shape, f_first=False)
+        spec_dembed, spat_dembed = 256 * 2, 256                                               # code/model.py:378-379
+        self.in_ver = "separate"
+        self.embed_use4ds = downstream_embed
+        self.spec_encoder = EmbedEncoder(sig_shape=sig_shape, patch_shape=patch_shape, dembed=spec_dembed,
+                                         model=["cnn", "conformer"], mode="spec", use_cls=use_cls, device=device)
+        self.spat_encoder = EmbedEncoder(sig_shape=sig_shape, patch_shape=patch_shape, dembed=spat_dembed,
+                                         model=["cnn", "conformer"], mode="spat", use_cls=use_cls, device=device)
+        if self.pretrain:
+            self.patch_mask = at_module.PatchMask(patch_mode=patch_mode, nmasked_patch=nmasked_patch,
+                                                  npatch_shape=npatch_shape, device=device)
+            self.decoder = EmbedDecoder(sig_shape=sig_shape, patch_shape=patch_shape, dembed=spec_dembed + spat_dembed,
+                                        model=["", "fc"], use_cls=False)
+        else:
+            dembed_ds = {"spec_spat": spec_dembed + spat_dembed, "spec": spec_dembed, "spat": spat_dembed,
+                         "noinfo": spec_dembed}[downstream_embed]
+            if downstream_head == "mlp":
+                if downstream_dlabel == 1:
+                    self.mlp_head = nn.Sequential(nn.LayerNorm(dembed_ds), nn.Linear(dembed_ds, downstream_dlabel))
+                else:
+                    self.joint_head = nn.Sequential(nn.LayerNorm(dembed_ds), nn.Linear(dembed_ds, dembed_ds), nn.ReLU(),
+                                                    nn.Linear(dembed_ds, downstream_dlabel))
+            self.downstream_head, self.downstream_dlabel, self.ds_token = downstream_head, downstream_dlabel, downstream_token
+        self._stage_hook = None
+        self._param_list = None
+        self._forced_masks = None
+
+    # ---- hooks used by the data-parallel wrapper to start gradient all-reduce while backward continues
+    def set_backward_stage_hook(self, fn):
+        self._stage_hook = fn
+
+    def _after_backward_stage(self, name):
+        if self._stage_hook is not None:
+            self._stage_hook(name)
+
+    def set_masks(self, mask_patch_idx, mask_ch_idx):
+        """Test hook: use explicit masks for the next forward instead of drawing them from python ``random``."""
+        self._forced_masks = (np.asarray(mask_patch_idx, dtype=np.int64), np.asarray(mask_ch_idx, dtype=np.int64).reshape(-1))
+
+    def _masks(self, B, T, dev):
+        if self._forced_masks is not None:
+            idx, ch = self._forced_masks
+            self._forced_masks = None
+        else:
+            idx, ch = self.patch_mask.sample(B, 2)
+        mp = np.ones((B, T), dtype=np.uint8)
+        np.put_along_axis(mp, idx, 0, axis=1)
+        to = lambda a, dt_: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True).to(dt_)
+        return to(idx.astype(np.int32), torch.int32), to(ch.astype(np.int32), torch.int32), to(mp, torch.uint8)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise hip._lib.SarsslHipError("SARSSL runs on the GPU only (no CPU fallback); got a CPU tensor")
+        nbatch, nmic, nf, nt, nreim = x.shape
+        x = x.contiguous().float()
+        if self.pretrain:
+            idx, ch, mp = self._masks(nbatch, nt, x.device)
+            if self._param_list is None:
+                self._param_list = [p for p in self.parameters() if p.requires_grad]
+            if torch.is_grad_enabled() and self._param_list:
+                loss, out, pred = _PretrainFn.apply(self, x, idx, ch, mp, *self._param_list)
+            else:
+                loss, out, pred = _PretrainFn.forward(_NoCtx(), self, x, idx, ch, mp)
+            return loss, out[1], LazyVis(pred, x, mp, ch)
+        # ---- downstream branch (code/model.py:667-719): both encoders on the unmasked input, mean over frames, MLP head
+        B, T, F = nbatch, nt, nf
+        v = x.permute(0, 3, 2, 4, 1).reshape(B, T, F * 4)                                      # (B, npatch, dpatch*nreim*nmic)
+        embed_spec = self.spec_encoder(v)
+        embed_spat = self.spat_encoder(v)
+        if self.embed_use4ds == "spec_spat":
+            embed = torch.cat([embed_spec, embed_spat], dim=2)
+        elif self.embed_use4ds == "spec":
+            embed = embed_spec
+        elif self.embed_use4ds == "spat":
+            embed = embed_spat
+        else:
+            embed = torch.zeros_like(embed_spec)
+        # tiny (B x d) pooling + head: torch ops (a "next" row; not on the pretraining hot path)
+        pooled = embed.float().mean(dim=1)
+        head = self.mlp_head if self.downstream_dlabel == 1 else self.joint_head
+        return head(pooled), pooled
+
+
+class _NoCtx:
+    """Stand-in ctx for running _PretrainFn.forward without autograd (eval / no_grad)."""
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+class MCConformer(nn.Module):
+    """Plain encoder/decoder (code/model.py:824-912): both encoders on the unmasked input, decoder, fold."""
+
+    def __init__(self, sig_shape=[256, 256, 2, 2], patch_shape=(256, 1), spec_model=["cnn", "conformer"],
+                 spat_model=["cnn", "conformer"], dembed={"spec": 512, "spat": 256}, dec_model=["", "fc"], device="cpu"):
+        super().__init__()
+        nf, nt, nreim, nmic = sig_shape
+        self.dembed = dembed
+        self.patch_split = at_module.PatchSplit(patch_shape=patch_shape, f_first=False)
+        self.patch_recover = at_module.PatchRecover(output_shape=(nf, nt), patch_shape=patch_shape, f_first=False)
+        assert dembed["spec"] > 0 and dembed["spat"] > 0
+        self.spec_encoder = EmbedEncoder(sig_shape=sig_shape, patch_shape=patch_shape, dembed=dembed["spec"], model=spec_model,
+                                         mode="spec", use_cls=False, device=device)
+        self.spat_encoder = EmbedEncoder(sig_shape=sig_shape, patch_shape=patch_shape, dembed=dembed["spat"], model=spat_model,
+                                         mode="spat", use_cls=False, device=device)
+        self.decoder = EmbedDecoder(sig_shape=sig_shape, patch_shape=patch_shape, dembed=dembed["spec"] + dembed["spat"],
+                                    model=dec_model, use_cls=False)
+
+    def forward(self, x):
+        B, nmic, F, T, _ = x.shape
+        v = x.permute(0, 3, 2, 4, 1).reshape(B, T, F * 4)
+        embed = torch.cat([self.spec_encoder(v), self.spat_encoder(v)], dim=2)
+        pred = self.decoder(embed).view(B, T, F, 2, nmic)
+        return pred.permute(0, 2, 1, 3, 4)                                                    # (nbatch, nf, nt, nreim, nmic)
+
+
+class SARSSL_MultiCH(nn.Module):
+    """Multi-pair head on top of the single-pair encoder (code/model.py:793-821)."""
+
+    def __init__(self, sig_shape, nmic_pair, task, device):
+        super().__init__()
+        self.model_sch = SARSSL(sig_shape=sig_shape, pretrain=False, device=device, downstream_token="all", downstream_head="",
+                                downstream_embed="spat", downstream_dlabel=1)
+        dembed_ds = 256
+        factor = nmic_pair if task == "TDOA" else 1
+        self.head_mch = nn.Sequential(nn.LayerNorm(dembed_ds * nmic_pair), nn.Linear(dembed_ds * nmic_pair, dembed_ds * nmic_pair),
+                                      nn.ReLU(), nn.Linear(dembed_ds * nmic_pair, factor))
+        self.nmic_pair = nmic_pair
+
+    def forward(self, x):
+        v = x.permute(0, 3, 2, 4, 1).reshape(x.shape[0], x.shape[3], -1)
+        embed_sch = self.model_sch.spat_encoder(v).float().mean(dim=1)
+        embed_sch = embed_sch.reshape(-1, self.nmic_pair * embed_sch.shape[-1])
+        return self.head_mch(embed_sch), embed_sch

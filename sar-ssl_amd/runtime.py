@@ -1,0 +1,158 @@
+"""Runtime configuration and parameter storage for the HIP path.
+
+Two numeric modes, same kernels:
+  * ``bf16``  - activations / GEMM weights stored in bf16, f32 accumulation and statistics (the fast path,
+                what bench.py times);
+  * ``fp32``  - f32 storage, every MFMA contraction done as three split-bf16 passes (hi*hi + hi*lo + lo*hi):
+                ~1e-5 relative error, used for the 1e-3 parity gates against the oracle.
+
+``FlatParams`` re-homes all parameters of a module into one flat f32 buffer (plus a flat gradient buffer and a
+bf16 shadow copy) so that Adam is one kernel launch and data-parallel gradient exchange is a handful of large
+all-reduces over contiguous memory (bucket = slice of the flat gradient buffer).
+"""
+import torch
+
+from . import hip
+
+
+class _RT:
+    dtype = torch.bfloat16
+    precise = False
+    _seed = 0x5A25_5151_0000_0000
+    _ctr = 0
+
+    def next_seed(self):
+        self._ctr += 1
+        return (self._seed + self._ctr * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+    def manual_seed(self, seed):
+        self._seed = (int(seed) * 0x2545F4914F6CDD1D + 0x5A25515100000000) & 0xFFFFFFFFFFFFFFFF
+        self._ctr = 0
+
+
+RT = _RT()
+
+
+def set_precision(mode):
+    """'bf16' (fast path) or 'fp32' (split-bf16 precise path)."""
+    if mode in ("bf16", torch.bfloat16):
+        RT.dtype, RT.precise = torch.bfloat16, False
+    elif mode in ("fp32", "f32", torch.float32):
+        RT.dtype, RT.precise = torch.float32, True
+    else:
+        raise ValueError("precision must be 'bf16' or 'fp32'")
+
+
+def get_precision():
+    return "bf16" if RT.dtype == torch.bfloat16 else "fp32"
+
+
+_GLOBAL_VERSION = [0]
+
+
+def bump_version():
+    _GLOBAL_VERSION[0] += 1
+
+
+def weights_version():
+    return _GLOBAL_VERSION[0]
+
+
+def wt(p):
+    """Tensor to feed a GEMM/conv kernel for parameter ``p`` in the current precision."""
+    if RT.dtype == torch.float32:
+        return p.data
+    flat = getattr(p, "_flat", None)
+    if flat is not None:
+        flat.ensure_shadow()
+        return p._w16
+    cache = getattr(p, "_w16_cache", None)
+    if cache is None or cache[0] != p._version:
+        p._w16_cache = (p._version, hip.cast(p.data.contiguous(), torch.bfloat16))
+    return p._w16_cache[1]
+
+
+def gbuf(p):
+    """Gradient buffer of ``p`` (f32, same shape); created zeroed on first use.  Backward kernels accumulate into it."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data)
+    return p.grad
+
+
+class FlatParams:
+    def __init__(self, module):
+        params, seen = [], set()
+        for p in module.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        assert params and all(p.is_cuda for p in params), "move the model to the GPU before flattening"
+        self.params = params
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8              # keep every view 32-byte aligned
+        self.numel = total
+        self.offsets = offs
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.w16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        for p, o in zip(params, offs):
+            n = p.numel()
+            self.flat[o:o + n].view_as(p.data).copy_(p.data)
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+            p._w16 = self.w16[o:o + n].view(p.shape)
+            p._flat = self
+        self._synced = None
+        self.ensure_shadow()
+
+    def _sig(self):
+        return tuple(p._version for p in self.params)
+
+    def ensure_shadow(self):
+        """Refresh the bf16 shadow if any parameter was modified through torch (load_state_dict, init, ...)."""
+        sig = self._sig()
+        if sig != self._synced:
+            hip.cast(self.flat, torch.bfloat16, out=self.w16)
+            self._synced = sig
+            bump_version()
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def bucket_slices(self, nbuckets):
+        """Contiguous [start, end) slices of the flat buffers, ~equal size, aligned to parameter boundaries."""
+        target = self.numel / float(nbuckets)
+        cuts, acc = [0], 0
+        for p, o in zip(self.params, self.offsets):
+            end = o + (p.numel() + 7) // 8 * 8
+            if end - cuts[-1] >= target and len(cuts) < nbuckets:
+                cuts.append(end)
+        if cuts[-1] != self.numel:
+            cuts.append(self.numel)
+        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, betas=(0.9, 0.999), weight_decay=0) semantics (code/learner.py:83) as one kernel over
+    the flat buffers; also rewrites the bf16 shadow weights."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.flat, self.lr, self.betas, self.eps = flat, lr, betas, eps
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        hip.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.lr, self.step_count,
+                      gscale=grad_scale, betas=self.betas, eps=self.eps)
+        bump_version()

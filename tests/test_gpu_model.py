@@ -1,0 +1,234 @@
+"""GPU parity of the HIP modules / full model against golden vectors from the reference (and the oracle).
+
+Tolerances: 'fp32' = split-bf16 precise path, gated at the north_star's 1e-3 (we assert tighter where the margin
+allows); 'bf16' = the fast path (bf16 storage + MFMA inputs), gated at looser, explicitly stated tolerances.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import recipes
+import sarssl_oracle as orc
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def _relerr(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().float().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _set_dropout(m, p):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = p
+
+
+# bf16 gradient tolerance is wide at these toy sizes (B*T = 48 rows, 384 stem pixels): BatchNorm/LayerNorm backward subtracts
+# batch means of bf16-rounded tensors; the full-size bf16 test below is the meaningful fast-path gate.
+TOL = {"fp32": dict(y=2e-4, dx=5e-4, g=1e-3), "bf16": dict(y=3e-2, dx=6e-2, g=6e-1, gall=1e-1)}
+
+
+def _run_block(name, build, seed, prec, call=None, check_dx=True, residual=False):
+    from sar_ssl_amd import runtime
+    runtime.set_precision(prec)
+    try:
+        dev = _dev()
+        z = _npz("f2_blocks.npz")
+        meta = json.loads(str(z["meta_json"]))[name]
+        tol = TOL[prec]
+        for mode in ("eval", "train"):
+            mod = build()
+            missing = mod.load_state_dict(recipes.recipe_state_dict(meta, seed), strict=True)
+            _set_dropout(mod, 0.0)
+            mod.to(dev).train(mode == "train")
+            x = torch.from_numpy(z[name + ".x"]).to(dev).requires_grad_(True)
+            gy = torch.from_numpy(z[name + ".gy"]).to(dev)
+            y = call(mod, x) if call else mod(x)
+            (y.float() * gy).sum().backward()
+            yref, dxref = z["%s.%s.y" % (name, mode)], z["%s.%s.dx" % (name, mode)]
+            if residual:          # module called in its fused x + f(x) form (what the Conformer block uses)
+                yref, dxref = yref + z[name + ".x"], dxref + z[name + ".gy"]
+            assert _relerr(y, yref) < tol["y"], (name, mode, "y")
+            if check_dx:
+                assert _relerr(x.grad, dxref) < tol["dx"], (name, mode, "dx")
+            num = den = 0.0
+            for k, p in mod.named_parameters():
+                ref = z["%s.%s.grad.%s" % (name, mode, k)]
+                assert p.grad is not None, k
+                e = _relerr(p.grad, ref) if np.abs(ref).max() > 1e-6 else float(p.grad.abs().max())
+                assert e < tol["g"], (name, mode, k, e)
+                num += float(((p.grad.double().cpu() - torch.from_numpy(ref).double()) ** 2).sum())
+                den += float((torch.from_numpy(ref).double() ** 2).sum())
+            if "gall" in tol:     # whole-gradient relative L2 error (bf16: individual cancellation-dominated entries are noisy)
+                assert (num / den) ** 0.5 < tol["gall"], (name, mode, (num / den) ** 0.5)
+            if mode == "train":
+                for k, v in mod.state_dict().items():
+                    if k.endswith(("running_mean", "running_var")):
+                        assert _relerr(v, z["%s.train.after.%s" % (name, k)]) < (1e-4 if prec == "fp32" else 2e-2), k
+    finally:
+        runtime.set_precision("bf16")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ffn_module(prec):
+    from sar_ssl_amd.common.conformer.feed_forward import FeedForwardModule
+    _run_block("ffn", lambda: FeedForwardModule(encoder_dim=32, expansion_factor=4, dropout_p=0.1), 21, prec,
+               call=lambda m, x: m.forward_residual(x, 1.0), residual=True)
+    if prec == "fp32":            # plain (non-residual) reference signature
+        _run_block("ffn", lambda: FeedForwardModule(encoder_dim=32, expansion_factor=4, dropout_p=0.1), 21, prec)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mhsa_module(prec):
+    from sar_ssl_amd.common.conformer.attention import MultiHeadedSelfAttentionModule
+    _run_block("mhsa", lambda: MultiHeadedSelfAttentionModule(d_model=32, num_heads=4, dropout_p=0.1), 22, prec,
+               call=lambda m, x: m.forward_residual(x), residual=True)
+    if prec == "fp32":
+        _run_block("mhsa", lambda: MultiHeadedSelfAttentionModule(d_model=32, num_heads=4, dropout_p=0.1), 22, prec)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv_module(prec):
+    from sar_ssl_amd.common.conformer.convolution import ConformerConvModule
+    mk = lambda: ConformerConvModule(in_channels=32, kernel_size=31, expansion_factor=2, dropout_p=0.1)
+    _run_block("convmod", mk, 23, prec, call=lambda m, x: m.forward_residual(x), residual=True)
+    if prec == "fp32":
+        _run_block("convmod", mk, 23, prec)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conformer_block_and_encoder(prec):
+    from sar_ssl_amd.common.Conformer import ConformerBlock, ConformerEncoder
+    _run_block("block", lambda: ConformerBlock(encoder_dim=32, num_attention_heads=4), 24, prec)
+    _run_block("block_T40", lambda: ConformerBlock(encoder_dim=32, num_attention_heads=4), 26, prec)
+    _run_block("encoder2", lambda: ConformerEncoder(encoder_dim=32, num_layers=2, num_attention_heads=4), 25, prec,
+               call=lambda m, x: m(x, False))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_embed_encoder_decoder(prec):
+    from sar_ssl_amd import model
+    _run_block("embed_encoder", lambda: model.EmbedEncoder(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed=32,
+                                                           model=["cnn", "conformer"], mode="spat", device="cuda"),
+               27, prec, call=lambda m, x: m.forward(x), check_dx=False)
+    _run_block("embed_decoder", lambda: model.EmbedDecoder(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed=48,
+                                                           model=["", "fc"]), 28, prec, call=lambda m, x: m.forward(x))
+
+
+def _check_gradnorms(net, gn, rtol):
+    """Per-parameter gradient L2 norms vs the reference.  Gradients that are analytically zero (e.g. the key-projection
+    bias: softmax is invariant to it) are round-off in the reference too, so they get an absolute bound instead."""
+    top = max(gn.values())
+    report = []
+    for k, p in net.named_parameters():
+        got = p.grad.double().norm().item()
+        if gn[k] < 1e-6 * top:
+            assert got < 1e-4 * top, (k, got, gn[k])
+        else:
+            e = abs(got - gn[k]) / gn[k]
+            report.append((e, k))
+            assert e < rtol, (k, e, got, gn[k])
+    return max(report)
+
+
+def _fullsize(prec, mode):
+    from sar_ssl_amd import model, runtime, hip
+    runtime.set_precision(prec)
+    try:
+        dev = _dev()
+        z = _npz("f3_fullsize.npz")
+        man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+        net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev)
+        net.load_state_dict(recipes.recipe_state_dict(man, 0))
+        _set_dropout(net, 0.0)
+        net.to(dev).train(mode == "train")
+        x = hip.stft_frontend(recipes.recipe_signal(2, 65792, 2, seed=3).to(dev))
+        net.set_masks(z["mask_idx"], z["mask_ch"])
+        loss, diff, vis = net(x)
+        loss.backward()
+        return net, loss, diff, vis, z
+    finally:
+        runtime.set_precision("bf16")
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_fullsize_forward_backward_fp32(mode):
+    """north_star gate: loss and per-bin outputs within 1e-3 relative of the reference CPU path."""
+    net, loss, diff, vis, z = _fullsize("fp32", mode)
+    assert abs(loss.item() / float(z[mode + ".loss"]) - 1) < 1e-3
+    assert abs(diff.item() / float(z[mode + ".diff"]) - 1) < 1e-4
+    pred = vis["pred"].permute(0, 2, 1, 3, 4).reshape(-1).cpu()          # back to (B,T,F,reim,mic) order
+    got = pred[torch.from_numpy(z[mode + ".pred_idx"])]
+    want = torch.from_numpy(z[mode + ".pred_vals"])
+    assert ((got - want).abs().max() / float(z[mode + ".pred_absmax"])).item() < 1e-3
+    gn = json.loads(str(z[mode + ".gradnorm_json"]))
+    _check_gradnorms(net, gn, 5e-3)
+    if mode == "train":
+        sd = net.state_dict()
+        for k in ("spec_encoder.patch_embed.4.running_mean", "spec_encoder.patch_embed.4.running_var",
+                  "spat_encoder.embed.layers.1.sequential.2.module.sequential.5.running_var"):
+            assert _relerr(sd[k], z["train.after." + k]) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_fullsize_forward_backward_bf16(mode):
+    """Fast path tolerance (stated separately): loss within 2e-2 relative, sampled outputs within 5e-2 of
+    the output range, per-parameter gradient norms within 10 %."""
+    net, loss, diff, vis, z = _fullsize("bf16", mode)
+    assert abs(loss.item() / float(z[mode + ".loss"]) - 1) < 2e-2
+    assert abs(diff.item() / float(z[mode + ".diff"]) - 1) < 1e-4          # diff only involves the f32 front-end
+    pred = vis["pred"].permute(0, 2, 1, 3, 4).reshape(-1).cpu()
+    got = pred[torch.from_numpy(z[mode + ".pred_idx"])]
+    want = torch.from_numpy(z[mode + ".pred_vals"])
+    assert ((got - want).abs().max() / float(z[mode + ".pred_absmax"])).item() < 5e-2
+    gn = json.loads(str(z[mode + ".gradnorm_json"]))
+    _check_gradnorms(net, gn, 0.10)
+
+
+def test_lazy_vis_and_eval_nograd():
+    from sar_ssl_amd import model, runtime, hip
+    dev = _dev()
+    net = model.SARSSL(sig_shape=(16, 8, 2, 2), patch_shape=(16, 1), pretrain=True, device=dev).to(dev).eval()
+    x = torch.randn((3, 2, 16, 8, 2), device=dev)
+    with torch.no_grad():
+        loss, diff, vis = net(x)
+    assert set(vis.keys()) == {"mask", "pred", "tar"}
+    assert vis["pred"].shape == (3, 16, 8, 2, 2) and vis["tar"].shape == (3, 16, 8, 2, 2) and vis["mask"].shape == (3, 16, 8, 2)
+    assert torch.isfinite(loss) and float((vis["mask"] == 0).float().mean()) == 0.25
+    with pytest.raises(Exception):
+        net(x.cpu())                       # no CPU fallback
+
+
+def test_downstream_forward():
+    from sar_ssl_amd import model, runtime
+    dev = _dev()
+    runtime.set_precision("fp32")
+    try:
+        z = _npz("f7_downstream.npz")
+        man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["downstream"]
+        ds = model.SARSSL(sig_shape=(256, 64, 2, 2), pretrain=False, device=dev, downstream_token="all", downstream_head="mlp",
+                          downstream_embed="spat", downstream_dlabel=1)
+        ds.load_state_dict(recipes.recipe_state_dict(man, 5))
+        ds.to(dev).eval()
+        x = torch.from_numpy(np.random.default_rng(99).standard_normal((2, 2, 256, 64, 2)).astype(np.float32)).to(dev)
+        with torch.no_grad():
+            pred, emb = ds(x)
+        assert _relerr(pred, z["pred"]) < 1e-3 and _relerr(emb, z["embed"]) < 1e-3
+    finally:
+        runtime.set_precision("bf16")
