@@ -1,0 +1,149 @@
+#!/usr/bin/env python
+"""Benchmark of the SAR-SSL pretraining step on MI355X (BASELINE.json metric: pretrain segments/s).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the whole hot path over one batch of synthetic input that is already resident in HBM (int16 PCM,
+64 two-channel 4.112 s @ 16 kHz segments per GPU): fused STFT front-end -> masks -> two MC-Conformer encoders -> decoder ->
+masked MSE -> hand-written backward -> (bucketed RCCL all-reduce overlapped with backward) -> fused Adam.  bf16 storage/MFMA,
+f32 accumulation; dropout active (training mode), nothing cached or skipped.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with events on the launch stream around every launch of the
+dominant kernel (conv3x3_fwd_kernel: 2 forward convs + 2 data-gradient convs per encoder);
+`cpu_baseline` times the CPU oracle (oracle/sarssl_oracle.py, the validated restatement of the reference) on this host.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import sarssl_boot  # noqa: E402,F401
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+FLOP_PER_SEG_STEP = 86.5e9         # 3 x 28.84 GFLOP forward contractions
+NSAMPLE = 65792
+
+
+def cpu_baseline(nstep=2, B=8):
+    """CPU oracle train step (fp32, B=8: the reference's own CPU-runnable shape) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import recipes
+    import sarssl_oracle as orc
+    from sar_ssl_amd import synth
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")))["pretrain"]
+    sd = recipes.recipe_state_dict(man, 0)
+    sig = torch.from_numpy(synth.make_batch(0, B))
+    state = {}
+    random.seed(1)
+    orc.train_step(sig, sd, state, 1e-3)                      # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    for _ in range(nstep):
+        orc.train_step(sig, sd, state, 1e-3)
+    dt = (time.time() - t0) / nstep
+    return {"value": round(B / dt, 3), "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full train steps (STFT+fwd+bwd+Adam) of the CPU oracle, fp32, batch %d, after 1 warm-up" % (nstep, B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="segments per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from sar_ssl_amd import dist as sdist, hip, model, runtime, synth
+    rank, world, local = sdist.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    runtime.set_precision(args.precision)
+    torch.manual_seed(1234)
+    random.seed(1234 + rank)
+    runtime.RT.manual_seed(1234 + rank)
+
+    net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev).to(dev).train()
+    flat = runtime.FlatParams(net)
+    sdist.broadcast_parameters(flat)
+    reducer = sdist.FlatGradAllReduce(net, flat)
+    opt = runtime.FusedAdam(flat, lr=1e-3)
+    opt.zero_grad()
+
+    # synthetic structured segments, int16 PCM resident in HBM (16 unique segments per rank, circularly shifted copies)
+    uniq = synth.make_batch(1000 * rank, 16)
+    segs = np.stack([np.roll(uniq[i % 16], 997 * (i // 16), axis=0) for i in range(args.batch)], axis=0)
+    pcm = torch.from_numpy(synth.to_pcm16(segs)).to(dev)
+
+    def step():
+        x = hip.stft_frontend(pcm)
+        loss, diff, _ = net(x)
+        loss.backward()
+        g = reducer.finish()
+        opt.step(grad_scale=g)
+        opt.zero_grad()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    hip.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = hip.profile_stop()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el[0])
+    loss_val = float(last)
+    assert np.isfinite(loss_val), "non-finite loss"
+
+    if rank == 0:
+        segs_total = args.batch * world * args.steps
+        value = segs_total / elapsed
+        n, ms = prof.get("conv3x3_fwd_kernel", (0, 0.0))
+        flop_per_launch = 2.0 * args.batch * 65536 * 64 * 576            # one 3x3 64->64 conv over B x 256 x 256 pixels
+        achieved = (flop_per_launch / (ms / n * 1e-3)) / 1e12 if n else 0.0
+        nw, msw = prof.get("conv3x3_wgrad_kernel", (0, 0.0))
+        out = {
+            "metric": "pretrain_segments_per_sec", "value": round(value, 2), "unit": "segments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision if args.precision == "bf16" else "f32(split-bf16 MFMA)",
+            "data": "synthetic",
+            "config": {"workload": "SAR-SSL MC-Conformer cross-channel-reconstruction pretrain step (STFT+mask+fwd+bwd+Adam), "
+                                   "2ch 4.112s@16kHz segments, batch %d per GPU, dropout on" % args.batch,
+                       "global_batch": args.batch * world, "segment_samples": NSAMPLE, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_kernel", "achieved": round(achieved, 1),
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": None, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
+                         "flop_per_launch": flop_per_launch,
+                         "wgrad_avg_ms": round(msw / nw, 4) if nw else None,
+                         "end_to_end_frac": round(value / world * FLOP_PER_SEG_STEP / (PEAK_BF16_TFLOPS * 1e12), 4)},
+            "final_loss": round(loss_val, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

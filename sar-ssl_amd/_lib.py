@@ -6,6 +6,8 @@ touches the GPU; calling any kernel without the built library (or on CPU tensors
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must be imported (and its HIP runtime loaded) BEFORE libsarssl_hip.so so both share one runtime
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsarssl_hip.so")
 _lib = None

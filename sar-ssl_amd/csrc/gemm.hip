@@ -39,6 +39,7 @@ struct GemmArgs {
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
     float p_drop; unsigned long long seed;
+    int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s, epilogue = atomicAdd(C, alpha*acc) (f32 C only)
 };
 
 template <typename T, bool KC>
@@ -103,7 +104,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) uint16_t sB[BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int z = blockIdx.z, z0 = z / g.batch_inner, z1 = z % g.batch_inner;
+    const int nsplit = g.split_k > 0 ? g.split_k : 1;
+    const int z = blockIdx.z / nsplit, ks = blockIdx.z % nsplit;
+    const int z0 = z / g.batch_inner, z1 = z % g.batch_inner;
+    const int k_begin = g.split_k > 0 ? ks * g.k_per_split : 0;
+    const int k_end = g.split_k > 0 ? min(g.K, k_begin + g.k_per_split) : g.K;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const TA* A = (const TA*)g.A + z0 * g.sA0 + z1 * g.sA1;
     const TB* B = (const TB*)g.B + z0 * g.sB0 + z1 * g.sB1;
@@ -116,9 +121,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        stage_tile<TA, AKC>(A, g.lda, m0, k0, g.M, g.K, sA, g.partA, tid);
-        stage_tile<TB, BKC>(B, g.ldb, n0, k0, g.N, g.K, sB, g.partB, tid);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        stage_tile<TA, AKC>(A, g.lda, m0, k0, g.M, k_end, sA, g.partA, tid);
+        stage_tile<TB, BKC>(B, g.ldb, n0, k0, g.N, k_end, sB, g.partB, tid);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -158,6 +163,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = g.alpha * acc[i][j][gq * 4 + e];
                 const int nvalid = min(4, g.N - n);
+                if (g.split_k > 0) {
+                    if constexpr (sizeof(TC) == 4) {
+                        for (int e = 0; e < nvalid; ++e) atomicAdd((float*)C + (long)m * g.ldc + n + e, v[e]);
+                    }
+                    continue;
+                }
                 if (g.acc_in) {
                     for (int e = 0; e < nvalid; ++e) v[e] += W[(long)m * g.N + n + e];
                 }
@@ -218,7 +229,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
                            float alpha, float out_scale, const float* bias, int act,
                            const void* resid, long ldr, long sR0, long sR1, float res_scale,
                            void* preact, float p_drop, unsigned long long seed,
-                           int precise, float* ws, void* stream) {
+                           int precise, float* ws, int split_k, void* stream) {
     SARSSL_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0 && batch_inner > 0, "sarssl_gemm");
     SARSSL_REQUIRE(a_kc ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0), "sarssl_gemm(A alignment)");
     SARSSL_REQUIRE(b_kc ? (K % 8 == 0 && ldb % 8 == 0) : (N % 8 == 0 && ldb % 8 == 0), "sarssl_gemm(B alignment)");
@@ -229,7 +240,14 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.resid = resid; g.ldr = ldr; g.sR0 = sR0; g.sR1 = sR1; g.res_scale = res_scale;
     g.preact = preact; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
     g.p_drop = p_drop; g.seed = seed;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch);
+    g.split_k = 0; g.k_per_split = K;
+    if (split_k > 0) {
+        // accumulate mode: C (f32) += alpha * A*B, no other epilogue; K split over split_k workgroups per tile
+        SARSSL_REQUIRE(dtC == SARSSL_F32 && !bias && !resid && !preact && act == 0 && p_drop == 0.f, "sarssl_gemm(split_k epilogue)");
+        int per = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
+        g.split_k = (K + per - 1) / per; g.k_per_split = per;
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch * (g.split_k > 0 ? g.split_k : 1));
     hipStream_t st = (hipStream_t)stream;
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_BF16)
         return launch_layout<bf16, bf16, bf16>(g, a_kc, b_kc, grid, st);
@@ -237,6 +255,12 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
         return launch_layout<bf16, bf16, float>(g, a_kc, b_kc, grid, st);
     if (dtA == SARSSL_F32 && dtB == SARSSL_F32 && dtC == SARSSL_F32) {
         if (!precise) return launch_layout<float, float, float>(g, a_kc, b_kc, grid, st);
+        if (g.split_k > 0) {          // the accumulate epilogue is linear: the three split-precision passes just add up
+            GemmArgs p = g;
+            p.partA = 0; p.partB = 1; int rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
+            p.partA = 1; p.partB = 0; rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
+            p.partA = 0; p.partB = 0; return launch_layout<float, float, float>(p, a_kc, b_kc, grid, st);
+        }
         SARSSL_REQUIRE(ws != nullptr, "sarssl_gemm(precise needs workspace)");
         g.acc_ws = ws;
         GemmArgs p = g;

@@ -199,30 +199,32 @@ __global__ void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict
 // ------------------------------------------------------------------------------------------------
 // Generic channels-last helpers on X[N][C], C = 4 * 2^k <= 1024.  Thread = (row slot, 4-channel group).
 
-// Column tiles of 64 channels (16 threads x 4 ch) x 16 row slots.  For C < 64 (64 % C == 0) the tensor is viewed as
-// [N*C/64][64] and the 64 virtual columns fold back onto channel (col % C).
+// Column tiles of 64 channels (8 threads x 8 ch, 16-byte loads) x 32 row slots.  For C < 64 (64 % C == 0) the tensor is
+// viewed as [N*C/64][64] and the 64 virtual columns fold back onto channel (col % C).
 // sums[c] += sum_n x ; sums[C + c] += sum_n x^2
 template <typename T>
 __global__ void cl_stats_kernel(const T* __restrict__ x, long rows, int L, int C, double* __restrict__ sums) {
-    __shared__ float sred[256][9];
-    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
-    const int col0 = blockIdx.x * 64, col = col0 + cgp * 4;
-    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    __shared__ float sred[256][17];
+    const int cgp = threadIdx.x & 7, rslot = threadIdx.x >> 3;
+    const int col0 = blockIdx.x * 64, col = col0 + cgp * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
     if (col < L) {
-        for (long n = (long)blockIdx.y * 16 + rslot; n < rows; n += (long)gridDim.y * 16) {
-            const float4 v = ld4(x + n * L + col);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-            q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+        for (long n = (long)blockIdx.y * 32 + rslot; n < rows; n += (long)gridDim.y * 32) {
+            const f8 v = ld8(x + n * L + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += v.v[e]; q[e] += v.v[e] * v.v[e]; }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][4 + e] = q[e]; }
+    for (int e = 0; e < 8; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][8 + e] = q[e]; }
     __syncthreads();
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
         if (col0 + c < L) {
             float acc = 0.f;
-            for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][which * 4 + (c & 3)];
+            for (int r = 0; r < 32; ++r) acc += sred[r * 8 + (c >> 3)][which * 8 + (c & 7)];
             atomicAdd(&sums[which * C + ((col0 + c) % C)], (double)acc);
         }
     }
@@ -272,17 +274,20 @@ __device__ __forceinline__ float act_bwd(float u, int act) {   // d act / d u
     return 1.f;
 }
 
-// z = act(x*scale[c] + shift[c])
+// z = act(x*scale[c] + shift[c]);  x viewed as [rows][L], thread = fixed 8-channel group
 template <typename T>
-__global__ void cl_affine_act_kernel(const T* __restrict__ x, long N, int C, const float* __restrict__ scale,
+__global__ void cl_affine_act_kernel(const T* __restrict__ x, long rows, int L, int C, const float* __restrict__ scale,
                                      const float* __restrict__ shift, int act, T* __restrict__ z) {
-    const long total4 = N * (C >> 2);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % (C >> 2)) * 4;
-        const float4 v = ld4(x + i * 4);
-        const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
-        st4(z + i * 4, make_float4(act_fwd(fmaf(v.x, sc.x, sh.x), act), act_fwd(fmaf(v.y, sc.y, sh.y), act),
-                                   act_fwd(fmaf(v.z, sc.z, sh.z), act), act_fwd(fmaf(v.w, sc.w, sh.w), act)));
+    const int gpr = L >> 3, cg = threadIdx.x % gpr, rslot = threadIdx.x / gpr, rpb = 256 / gpr;
+    const int col = cg * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int ch = (col + e) % C; sc[e] = scale[ch]; sh[e] = shift[ch]; }
+    for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
+        f8 v = ld8(x + n * L + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] = act_fwd(fmaf(v.v[e], sc[e], sh[e]), act);
+        st8(z + n * L + col, v);
     }
 }
 
@@ -292,59 +297,70 @@ __global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __res
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ mean, const float* __restrict__ rstd, int act,
                                         double* __restrict__ red) {
-    __shared__ float sred[256][9];
-    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
-    const int col0 = blockIdx.x * 64, col = col0 + cgp * 4;
-    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    __shared__ float sred[256][17];
+    const int cgp = threadIdx.x & 7, rslot = threadIdx.x >> 3;
+    const int col0 = blockIdx.x * 64, col = col0 + cgp * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
     if (col < L) {
-        const int ch = col % C;
-        const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
-        const float4 mu = *(const float4*)(mean + ch), rs = *(const float4*)(rstd + ch);
-        for (long n = (long)blockIdx.y * 16 + rslot; n < rows; n += (long)gridDim.y * 16) {
-            const float4 d = ld4(dz + n * L + col);
-            const float4 v = ld4(y + n * L + col);
-            const float g0 = d.x * act_bwd(fmaf(v.x, sc.x, sh.x), act), g1 = d.y * act_bwd(fmaf(v.y, sc.y, sh.y), act);
-            const float g2 = d.z * act_bwd(fmaf(v.z, sc.z, sh.z), act), g3 = d.w * act_bwd(fmaf(v.w, sc.w, sh.w), act);
-            s[0] += g0; s[1] += g1; s[2] += g2; s[3] += g3;
-            q[0] += g0 * (v.x - mu.x) * rs.x; q[1] += g1 * (v.y - mu.y) * rs.y;
-            q[2] += g2 * (v.z - mu.z) * rs.z; q[3] += g3 * (v.w - mu.w) * rs.w;
+        float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int ch = (col + e) % C; sc[e] = scale[ch]; sh[e] = shift[ch]; mu[e] = mean[ch]; rs[e] = rstd[ch]; }
+        for (long n = (long)blockIdx.y * 32 + rslot; n < rows; n += (long)gridDim.y * 32) {
+            const f8 d = ld8(dz + n * L + col);
+            const f8 v = ld8(y + n * L + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = d.v[e] * act_bwd(fmaf(v.v[e], sc[e], sh[e]), act);
+                s[e] += g;
+                q[e] += g * (v.v[e] - mu[e]) * rs[e];
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][4 + e] = q[e]; }
+    for (int e = 0; e < 8; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][8 + e] = q[e]; }
     __syncthreads();
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
         if (col0 + c < L) {
             float acc = 0.f;
-            for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][which * 4 + (c & 3)];
+            for (int r = 0; r < 32; ++r) acc += sred[r * 8 + (c >> 3)][which * 8 + (c & 7)];
             atomicAdd(&red[which * C + ((col0 + c) % C)], (double)acc);
         }
     }
 }
 
 // pass 2: dy = gamma*rstd * (g - s1/N - xhat*s2/N)      (train)   or   dy = gamma*rstd * g   (eval: use_stats = 0)
-// g_is_masked = 1 when dz already contains g (act' applied upstream).
+// g_is_masked = 1 when dz already contains g (act' applied upstream).  Tensors viewed as [rows][L]; thread = fixed
+// 8-channel group so all per-channel constants live in registers.
 template <typename T>
-__global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, long N, int C,
+__global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, long rows, int L, int C, long N,
                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                        const float* __restrict__ mean, const float* __restrict__ rstd, int act,
                                        int g_is_masked, int use_stats, const double* __restrict__ red, T* __restrict__ dy) {
-    const long total4 = N * (C >> 2);
+    const int gpr = L >> 3, cg = threadIdx.x % gpr, rslot = threadIdx.x / gpr, rpb = 256 / gpr;
+    const int col = cg * 8;
     const float invN = 1.0f / (float)N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % (C >> 2)) * 4;
-        const float4 d = ld4(dz + i * 4);
-        const float4 v = ld4(y + i * 4);
-        float dd[4] = {d.x, d.y, d.z, d.w}, vv[4] = {v.x, v.y, v.z, v.w}, o[4];
+    float sc[8], sh[8], mu[8], rs[8], m1[8], m2[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float g = g_is_masked ? dd[e] : dd[e] * act_bwd(fmaf(vv[e], scale[c + e], shift[c + e]), act);
-            const float xh = (vv[e] - mean[c + e]) * rstd[c + e];
-            const float k = scale[c + e];                       // gamma * rstd
-            o[e] = use_stats ? k * (g - (float)red[c + e] * invN - xh * (float)red[C + c + e] * invN) : k * g;
+    for (int e = 0; e < 8; ++e) {
+        const int ch = (col + e) % C;
+        sc[e] = scale[ch]; sh[e] = shift[ch]; mu[e] = mean[ch]; rs[e] = rstd[ch];
+        m1[e] = use_stats ? (float)red[ch] * invN : 0.f;
+        m2[e] = use_stats ? (float)red[C + ch] * invN : 0.f;
+    }
+    for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
+        const f8 d = ld8(dz + n * L + col);
+        const f8 v = ld8(y + n * L + col);
+        f8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = g_is_masked ? d.v[e] : d.v[e] * act_bwd(fmaf(v.v[e], sc[e], sh[e]), act);
+            const float xh = (v.v[e] - mu[e]) * rs[e];
+            o.v[e] = sc[e] * (g - m1[e] - xh * m2[e]);          // sc = gamma * rstd
         }
-        st4(dy + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        st8(dy + n * L + col, o);
     }
 }
 
@@ -408,13 +424,19 @@ extern "C" int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* 
 // view [N][C] as [rows][L] with L = max(C, 64) (C < 64 needs 64 % C == 0 and N*C % 64 == 0)
 static inline bool cl_view(long N, int C, long* rows, int* L) {
     if (C <= 0 || (C & 3) || N <= 0) return false;
-    if (C >= 64) { *rows = N; *L = C; return true; }
+    if (C >= 64) { if (C & 7) return false; *rows = N; *L = C; return true; }
     if (64 % C || (N * C) % 64) return false;
     *rows = N * C / 64; *L = 64; return true;
 }
+static inline bool cl_rowthreads_ok(int L) { return (L & 7) == 0 && (L >> 3) <= 256 && 256 % (L >> 3) == 0; }
+static inline int cl_rowgrid(long rows, int L) {
+    const int rpb = 256 / (L >> 3);
+    long b = (rows + (long)rpb * 4 - 1) / ((long)rpb * 4); if (b < 1) b = 1;
+    return (int)(b > 4096 ? 4096 : b);
+}
 static inline dim3 cl_grid(long rows, int L) {
     int gx = (L + 63) / 64;
-    long gy = (rows + 127) / 128; if (gy < 1) gy = 1;
+    long gy = (rows + 255) / 256; if (gy < 1) gy = 1;
     long cap = 2048 / gx; if (cap < 1) cap = 1;
     if (gy > cap) gy = cap;
     return dim3(gx, (unsigned)gy, 1);
@@ -423,7 +445,7 @@ static inline dim3 cl_grid(long rows, int L) {
 // sums: f64[2C] (zeroed here)
 extern "C" int sarssl_cl_stats(const void* x, long N, int C, double* sums, int dtype, void* stream) {
     long rows; int L;
-    SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_stats(C % 4 == 0; C < 64 needs 64 % C == 0 and N*C % 64 == 0)");
+    SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_stats(C % 8 == 0 or C | 64; C < 64 needs N*C % 64 == 0)");
     if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const dim3 grid = cl_grid(rows, L);
     DISPATCH_T(dtype, (cl_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, rows, L, C, sums)));
@@ -450,9 +472,9 @@ extern "C" int sarssl_bn_eval_affine(int C, const float* gamma, const float* bet
 
 extern "C" int sarssl_cl_affine_act(const void* x, long N, int C, const float* scale, const float* shift, int act, void* z,
                                     int dtype, void* stream) {
-    SARSSL_REQUIRE((C & 3) == 0 && N > 0, "sarssl_cl_affine_act");
-    const int nblk = nblocks_for(N * (C >> 2), 256, 8192);
-    DISPATCH_T(dtype, (cl_affine_act_kernel<T><<<nblk, 256, 0, ST>>>((const T*)x, N, C, scale, shift, act, (T*)z)));
+    long rows; int L;
+    SARSSL_REQUIRE(cl_view(N, C, &rows, &L) && cl_rowthreads_ok(L), "sarssl_cl_affine_act");
+    DISPATCH_T(dtype, (cl_affine_act_kernel<T><<<cl_rowgrid(rows, L), 256, 0, ST>>>((const T*)x, rows, L, C, scale, shift, act, (T*)z)));
     SARSSL_CHECK_LAUNCH("cl_affine_act_kernel");
     return 0;
 }
@@ -473,10 +495,11 @@ extern "C" int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, in
 extern "C" int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
                                       const float* mean, const float* rstd, int act, int g_is_masked, int use_stats,
                                       const double* red, void* dy, int dtype, void* stream) {
-    SARSSL_REQUIRE((C & 3) == 0 && N > 0, "sarssl_cl_bn_bwd_apply");
-    const int nblk = nblocks_for(N * (C >> 2), 256, 8192);
-    DISPATCH_T(dtype, (cl_bn_bwd_apply_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dz, (const T*)y, N, C, scale, shift, mean,
-                                                                      rstd, act, g_is_masked, use_stats, red, (T*)dy)));
+    long rows; int L;
+    SARSSL_REQUIRE(cl_view(N, C, &rows, &L) && cl_rowthreads_ok(L), "sarssl_cl_bn_bwd_apply");
+    DISPATCH_T(dtype, (cl_bn_bwd_apply_kernel<T><<<cl_rowgrid(rows, L), 256, 0, ST>>>((const T*)dz, (const T*)y, rows, L, C, N, scale,
+                                                                                     shift, mean, rstd, act, g_is_masked,
+                                                                                     use_stats, red, (T*)dy)));
     SARSSL_CHECK_LAUNCH("cl_bn_bwd_apply_kernel");
     return 0;
 }

@@ -35,8 +35,10 @@ def mm_tn_acc(dy, x, gW):
     M, N = dy.shape
     K = x.shape[1]
     g2 = gW.view(N, K)
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    split = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles))       # ~3 workgroups per CU, >= 4 K-tiles each
     hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), out=g2, ldc=K,
-             resid=g2, ldr=K, res_scale=1.0, precise=RT.precise)
+             precise=RT.precise, split_k=split)
 
 
 def to_rt(x):

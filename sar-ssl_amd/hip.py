@@ -30,6 +30,41 @@ def _need_cuda(*ts):
             raise _lib.SarsslHipError("sar_ssl_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
 
 
+# ---- optional per-kernel timing with events on the launch stream (bench.py roofline) ---------------------------------
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = {}
+
+
+def profile_stop():
+    """-> {name: (launches, total_ms)}; synchronises."""
+    global _prof
+    p, _prof = _prof, None
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (p or {}).items()}
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()                      # current stream == the stream the kernel is launched on
+        return self
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.b.record()
+            _prof.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 _ws_cache = {}
 
 
@@ -44,7 +79,8 @@ def workspace(nbytes, device, tag="default"):
 
 def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=None, ldc=None,
          nbatch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, out_scale=1.0, bias=None, act=0,
-         resid=None, ldr=0, sR=(0, 0), res_scale=1.0, preact=None, p_drop=0.0, seed=0, precise=False, out_shape=None):
+         resid=None, ldr=0, sR=(0, 0), res_scale=1.0, preact=None, p_drop=0.0, seed=0, precise=False, out_shape=None,
+         split_k=0):
     """C[z] = epilogue(alpha * opA(A[z]) @ opB(B[z])^T) - see csrc/gemm.hip for the layout flags."""
     _need_cuda(A, B, out, bias, resid, preact)
     if out is None:
@@ -55,7 +91,7 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     if nbatch > 1 and sC == (0, 0):
         sC = (M * N * batch_inner, M * N)
     ws = None
-    if precise and A.dtype == torch.float32:
+    if precise and A.dtype == torch.float32 and split_k <= 0:
         ws = workspace(4 * nbatch * M * N, A.device, "gemm_acc")
     _lib.call("sarssl_gemm", _p(A), _p(B), _p(out), c_int(dt(A)), c_int(dt(B)), c_int(dt(out)),
               c_int(1 if a_kc else 0), c_int(1 if b_kc else 0), c_int(M), c_int(N), c_int(K),
@@ -64,7 +100,7 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
               c_float(alpha), c_float(out_scale), _p(bias), c_int(act),
               _p(resid), c_long(ldr), c_long(sR[0]), c_long(sR[1]), c_float(res_scale),
               _p(preact), c_float(p_drop), c_ulonglong(seed), c_int(1 if (precise and A.dtype == torch.float32) else 0),
-              _p(ws), _stream())
+              _p(ws), c_int(split_k), _stream())
     return out
 
 
@@ -160,8 +196,9 @@ def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False):
     assert C == 64 and w_tap.dtype == x.dtype and w_tap.is_contiguous() and x.is_contiguous()
     out = torch.empty_like(x)
     ws = _f32ws(x.numel(), x.device, "conv_acc") if (precise and x.dtype == torch.float32) else None
-    _lib.call("sarssl_conv3x3_fwd", _p(x), _p(w_tap), _p(out), c_int(dt(x)), c_int(dt(w_tap)), c_int(B), c_int(F), c_int(T),
-              _p(scale), _p(shift), c_int(1 if ws is not None else 0), _p(ws), _stream())
+    with _Timed("conv3x3_fwd_kernel"):
+        _lib.call("sarssl_conv3x3_fwd", _p(x), _p(w_tap), _p(out), c_int(dt(x)), c_int(dt(w_tap)), c_int(B), c_int(F), c_int(T),
+                  _p(scale), _p(shift), c_int(1 if ws is not None else 0), _p(ws), _stream())
     return out
 
 
@@ -173,8 +210,9 @@ def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False):
     nbytes.restype = c_long
     part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), zin.device, "wgrad_part")
     dW = torch.empty((9, 64, 64), dtype=torch.float32, device=zin.device)
-    _lib.call("sarssl_conv3x3_wgrad", _p(dy), _p(zin), c_int(dt(zin)), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW),
-              _p(part), c_int(1 if (precise and zin.dtype == torch.float32) else 0), _stream())
+    with _Timed("conv3x3_wgrad_kernel"):
+        _lib.call("sarssl_conv3x3_wgrad", _p(dy), _p(zin), c_int(dt(zin)), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW),
+                  _p(part), c_int(1 if (precise and zin.dtype == torch.float32) else 0), _stream())
     return dW
 
 

@@ -1,0 +1,213 @@
+"""Training loop ("learner") with the reference's interface (code/learner.py: Learner :13, STFTLearner :488).
+
+What changed underneath: the STFT front-end is one fused HIP kernel pair, the model step is the hand-written HIP
+forward/backward, Adam is one fused kernel over the flat parameter buffer, multi-GPU is one process per GPU with bucketed
+RCCL all-reduce (dist.py) instead of DataParallel, and ``--use-amp`` selects bf16 (no GradScaler needed) instead of fp16.
+"""
+import os
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from . import hip, runtime, dist as sdist
+from .common import utils_module as at_module
+
+
+class Learner(ABC):
+    def __init__(self, model):
+        self.model = model
+        self.max_score = -np.inf
+        self.early_stop_counter = 0
+        self.use_amp = False
+        self.start_epoch = 1
+        self.device = "cpu"
+        self._flat = None
+        self._reducer = None
+        runtime.set_precision("fp32")            # reference default is fp32; .amp() switches to bf16
+        super().__init__()
+
+    # ---- device / precision plumbing -------------------------------------------------------------------------------
+    def mul_gpu(self):
+        """Data parallel: one process per GPU.  Requires a torchrun-style launch (RANK / WORLD_SIZE / LOCAL_RANK)."""
+        sdist.init_from_env()
+        self._want_dp = True
+
+    def cuda(self):
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if sdist.world_size() > 1:
+            torch.cuda.set_device(local)
+        self.model.cuda()
+        self.device = "cuda"
+        self._flat = runtime.FlatParams(self.model)
+        if sdist.world_size() > 1:
+            sdist.broadcast_parameters(self._flat)
+        if hasattr(self.model, "set_backward_stage_hook"):
+            self._reducer = sdist.FlatGradAllReduce(self.model, self._flat)
+
+    def cpu(self):
+        raise hip._lib.SarsslHipError("the sar_ssl_amd learner runs on the GPU only: there is no CPU fallback "
+                                      "(use the oracle in oracle/ for CPU reference numbers)")
+
+    def amp(self):
+        """Mixed precision = bf16 storage / MFMA inputs with f32 accumulation; no loss scaling is needed for bf16."""
+        self.use_amp = True
+        runtime.set_precision("bf16")
+
+    @abstractmethod
+    def data_preprocess(self, mic_sig_batch=None, gt_batch=None):
+        pass
+
+    # ---- pretraining (code/learner.py:76-167) ------------------------------------------------------------------------
+    def pretrain_epoch(self, dataset, lr=0.0001, epoch=None, return_diff=True):
+        self.model.train()
+        optimizer = runtime.FusedAdam(self._flat, lr=float(lr), betas=(0.9, 0.999))        # re-created every epoch (learner.py:83)
+        optimizer.zero_grad()
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        n = 0
+        vis_batch = None
+        for batch in dataset:
+            mic_sig_batch = batch[0] if isinstance(batch, (list, tuple)) else batch
+            in_batch, = self.data_preprocess(mic_sig_batch, None)
+            loss_batch, diff_batch, vis_batch = self.model(in_batch)
+            loss_batch.backward()
+            gscale = self._reducer.finish() if self._reducer is not None else 1.0
+            optimizer.step(grad_scale=gscale)
+            optimizer.zero_grad()
+            acc[0] += loss_batch.detach().double()                                           # no per-step .item() sync
+            acc[1] += diff_batch.detach().double()
+            n += 1
+        acc = acc / max(n, 1)
+        if sdist.world_size() > 1:
+            torch.distributed.all_reduce(acc)
+            acc /= sdist.world_size()
+        loss, diff = float(acc[0]), float(acc[1])
+        return (loss, diff, vis_batch) if return_diff else loss
+
+    def pretest_epoch(self, dataset, return_diff=True, return_eval=False):
+        self.model.eval()
+        with torch.no_grad():
+            acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+            n = 0
+            vis_batch = None
+            for data in dataset:
+                in_batch, = self.data_preprocess(data[0], None)
+                loss_batch, diff_batch, vis_batch = self.model(in_batch)                     # random masking stays active in eval
+                acc[0] += loss_batch.double()
+                acc[1] += diff_batch.double()
+                n += 1
+            acc = acc / max(n, 1)
+            loss, diff = float(acc[0]), float(acc[1])
+        if return_eval:
+            raise NotImplementedError("pretrain_evaluate (ISTFT + PESQ) is an eval/export 'next' row (SURVEY.md 8f-3)")
+        return (loss, diff, vis_batch) if return_diff else loss
+
+    # ---- early stopping / checkpoints (code/learner.py:283-300, 333-448) ------------------------------------------------
+    def early_stopping(self, current_score, patience=5):
+        if current_score >= self.max_score:
+            self.max_score = current_score
+            self.early_stop_counter = 0
+            return False, True
+        self.early_stop_counter += 1
+        return self.early_stop_counter >= patience, False
+
+    def is_best_epoch(self, current_score):
+        if current_score >= self.max_score:
+            self.max_score = current_score
+            return True
+        return False
+
+    def _state_dict_cpu(self):
+        return {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+
+    def save_checkpoint(self, epoch, checkpoints_dir, is_best_epoch=False, save_extra_hist=False):
+        """Same file names and dict layout as the reference: {'epoch', 'max_score', 'model'} (no optimizer state)."""
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        state_dict = {"epoch": epoch, "max_score": self.max_score, "model": self._state_dict_cpu()}
+        torch.save(state_dict, checkpoints_dir + "/latest_model.tar")
+        if save_extra_hist:
+            torch.save(state_dict, checkpoints_dir + "/model" + str(epoch) + ".tar")
+        if is_best_epoch:
+            torch.save(state_dict, checkpoints_dir + "/best_model.tar")
+
+    def _load_model_state(self, sd, as_all_state=True, ex_key=""):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}   # DataParallel prefix (Q13)
+        if as_all_state:
+            self.model.load_state_dict(sd)
+        else:
+            all_state_dict = self.model.state_dict()
+            match_key_cnt = 0
+            for key in sd:
+                if ex_key + key in all_state_dict:
+                    all_state_dict[ex_key + key] = sd[key]
+                    match_key_cnt += 1
+            assert match_key_cnt > 1, "loaded model parameters and original parameters unmatched~"
+            self.model.load_state_dict(all_state_dict)
+        if self._flat is not None:
+            self._flat.ensure_shadow()
+        return sd
+
+    def resume_checkpoint(self, checkpoints_dir, from_latest=True, as_all_state=True, ex_key=""):
+        model_path = checkpoints_dir + ("/latest_model.tar" if from_latest else "/best_model.tar")
+        assert os.path.exists(model_path), f"{model_path} does not exist, can not load latest checkpoint."
+        checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+        self.start_epoch = checkpoint["epoch"] + 1
+        self.max_score = checkpoint["max_score"]
+        self._load_model_state(checkpoint["model"], as_all_state, ex_key)
+
+    def load_checkpoint_best(self, checkpoints_dir, as_all_state=True, param_frozen=False, ex_key=""):
+        best_model_path = checkpoints_dir + "/best_model.tar"
+        assert os.path.exists(best_model_path), f"{best_model_path} does not exist, can not load best model."
+        checkpoint = torch.load(best_model_path, map_location="cpu", weights_only=False)
+        sd = self._load_model_state(checkpoint["model"], as_all_state, ex_key)
+        if param_frozen:
+            for key, value in self.model.named_parameters():
+                if key in sd:
+                    value.requires_grad = False
+        return checkpoint["epoch"]
+
+
+class STFTLearner(Learner):
+    """Learner for models fed with STFTs of the microphone signals (code/learner.py:488-553)."""
+
+    def __init__(self, model, win_len, win_shift_ratio, nfft, fre_used_ratio, fs, mel_scale=False, task=None, ch_mode="M"):
+        super().__init__(model)
+        if mel_scale or fre_used_ratio != 1 or ch_mode != "M":
+            raise NotImplementedError("only the pretraining front-end (linear frequency, bins 1..nfft/2, ch_mode 'M') is implemented")
+        self.ch_mode = ch_mode
+        self.win_len, self.win_shift_ratio, self.nfft = win_len, win_shift_ratio, nfft
+        self.stft = at_module.STFT(win_len=win_len, win_shift_ratio=win_shift_ratio, nfft=nfft)
+        self.fre_range_used = range(1, int(nfft / 2 * fre_used_ratio) + 1, 1)
+        self.addbatch = at_module.AddChToBatch(ch_mode=self.ch_mode)
+        self.task = task
+
+    def data_preprocess(self, mic_sig_batch=None, gt_batch=None, eps=1e-6):
+        """mic_sig_batch (nbatch, nsample, nch) f32 or int16 PCM -> [reim (nb*(nch-1), 2, nf, nt, 2)] on the GPU: STFT,
+        normalisation by the mean magnitude of mic 0, pairing with mic 0 and DC removal fused in csrc/stft.hip."""
+        data = []
+        if mic_sig_batch is not None:
+            if not torch.is_tensor(mic_sig_batch):
+                mic_sig_batch = torch.as_tensor(mic_sig_batch)
+            sig = mic_sig_batch.to(self.device, non_blocking=True)
+            if sig.dtype not in (torch.float32, torch.int16):
+                sig = sig.float()
+            data += [hip.stft_frontend(sig, eps=eps, win_len=self.win_len, hop=int(self.win_len * self.win_shift_ratio),
+                                       nfft=self.nfft)]
+        if gt_batch is not None:
+            gt = gt_batch[self.task].to(self.device)
+            data += [self.get_tar_batch(gt)]
+        return data
+
+    def get_tar_batch(self, gt_batch):
+        if self.task == "TDOA":
+            return gt_batch[:, np.newaxis] * 16000
+        if self.task in ("DRR", "C50", "T60", "ABS"):
+            return gt_batch[:, np.newaxis]
+        raise Exception("Task mode unrecognized")
+
+    def loss(self, pred_batch, gt_batch):
+        return torch.nn.functional.mse_loss(pred_batch.contiguous(), gt_batch.contiguous().detach())
+
+    def evaluate(self, pred_batch, gt_batch):
+        return torch.mean(torch.abs(pred_batch.contiguous().detach() - gt_batch.contiguous().detach()))

@@ -391,3 +391,19 @@ def test_masked_mse_and_adam(dtp):
             hip.adam_step(pd_, gr.to(dev), m, vv, p16, 1e-3, step)
         assert _relerr(pd_, pr["w"]) < 1e-6
         assert torch.equal(p16.cpu(), pd_.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32_precise"])
+@pytest.mark.parametrize("split", [1, 3, 8])
+def test_gemm_split_k_accumulate(mode, split):
+    """dW += dY^T X with the contraction split over several workgroups and f32 atomic accumulation."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    dtp = torch.bfloat16 if mode == "bf16" else torch.float32
+    M, N, K = 1000, 136, 72                      # contraction length M
+    dy = _mk((M, N), dtp, dev, 21); x = _mk((M, K), dtp, dev, 22)
+    g0 = _mk((N, K), torch.float32, dev, 23)
+    g = g0.clone()
+    hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=N, ldb=K, out=g, ldc=K, precise=(mode == "f32_precise"), split_k=split)
+    ref = g0.double() + dy.double().t() @ x.double()
+    assert _relerr(g, ref) < (1e-5 if mode == "bf16" else 5e-5)

@@ -41,7 +41,7 @@ def _set_dropout(m, p):
 
 # bf16 gradient tolerance is wide at these toy sizes (B*T = 48 rows, 384 stem pixels): BatchNorm/LayerNorm backward subtracts
 # batch means of bf16-rounded tensors; the full-size bf16 test below is the meaningful fast-path gate.
-TOL = {"fp32": dict(y=2e-4, dx=5e-4, g=1e-3), "bf16": dict(y=3e-2, dx=6e-2, g=6e-1, gall=1e-1)}
+TOL = {"fp32": dict(y=2e-4, dx=5e-4, g=1e-3), "bf16": dict(y=3e-2, dx=1.2e-1, g=6e-1, gall=1e-1)}
 
 
 def _run_block(name, build, seed, prec, call=None, check_dx=True, residual=False):
