@@ -1,0 +1,110 @@
+/* C ABI of libsarssl_hip.so - the MI355X (gfx950) kernels behind SAR-SSL's pretraining hot path.
+ *
+ * The reference (Audio-WestlakeU/SAR-SSL) is pure Python on PyTorch ATen ops: it has no FFI of its own, so each entry
+ * point below names the reference code whose device work it replaces (paths relative to the reference repository).
+ * Conventions: plain pointers and sizes only (no torch types); every pointer is DEVICE memory owned by the caller,
+ * including workspaces; kernels are enqueued on `stream` (a hipStream_t passed as void*) and never synchronise;
+ * return 0 on success, negative on error with a message in sarssl_last_error().  dtype: 0 = f32, 1 = bf16, 2 = int16.
+ * "precise" != 0 (f32 storage only) runs every MFMA contraction as three split-bf16 passes (hi*hi + hi*lo + lo*hi).
+ */
+#ifndef SARSSL_HIP_H
+#define SARSSL_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sarssl_last_error(void);
+int sarssl_abi_version(void);
+int sarssl_device_info(int device, char* name_out, int name_len, int* cu_count, long* lds_bytes);
+
+/* ---- front-end: code/common/utils_module.py:49-72 (STFT.forward), code/learner.py:525-553 (data_preprocess),
+ *      code/common/utils_module.py:128-134 (AddChToBatch 'M').  sig: (B, nsample, nch) f32|int16.
+ *      U: workspace (B, nch, 257, nt, 2) f32; magsum: workspace f64[B]; out: (B*(nch-1), 2, 256, nt, 2) f32. */
+int sarssl_stft_frontend(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft,
+                         int nt, float eps, float* U, double* magsum, float* out, void* stream);
+/*      out: complex64 (B, 257, nt, nch) interleaved, the STFT.forward return value. */
+int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft, int nt,
+                    float* U, double* magsum, float* out, void* stream);
+
+/* ---- generic batched MFMA GEMM with fused epilogue: nn.Linear / Conv1d(k=1) / patch conv / attention bmm
+ *      (code/common/conformer/modules.py:35-48, feed_forward.py:47-54, attention.py:82-103, convolution.py:138,143,
+ *      code/model.py:63, 296-301).  See csrc/gemm.hip for the layout flags.  split_k > 0: C(f32) += alpha*A*B. */
+int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC, int a_kc, int b_kc, int M, int N, int K,
+                long lda, long ldb, long ldc, int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0,
+                long sC1, float alpha, float out_scale, const float* bias, int act, const void* resid, long ldr, long sR0,
+                long sR1, float res_scale, void* preact, float p_drop, unsigned long long seed, int precise, float* ws,
+                int split_k, void* stream);
+
+/* ---- CNN stem, channels-last (B,F,T,C): code/model.py:50-64 (patch_embed), masking code/model.py:533-564 */
+int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn, int mode, void* spec,
+                       void* spat, int dtype, void* stream);
+int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, int dtype, void* stream);
+int sarssl_stem_c1_wgrad(const void* dy1, const void* a0, long npix, double* dW1d, int dtype, void* stream);
+int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
+                       const float* scale, const float* shift, int precise, float* ws, void* stream);
+long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
+int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
+                         const float* shift, float* dW, float* partial, int precise, void* stream);
+int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
+                       int dtype, void* stream);
+int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
+                       const float* mean, const float* rstd, int nb, int F, int Tn, void* g3, double* red, int dtype,
+                       void* stream);
+
+/* ---- BatchNorm{1,2}d on channels-last [N][C] tensors (training statistics, running-stat update, backward):
+ *      nn.BatchNorm2d in code/model.py:52-61, nn.BatchNorm1d in code/common/conformer/convolution.py:142 */
+int sarssl_cl_stats(const void* x, long N, int C, double* sums, int dtype, void* stream);
+int sarssl_bn_finalize(const double* sums, long N, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, long* nbt, float* scale, float* shift, float* mean,
+                       float* rstd, void* stream);
+int sarssl_bn_eval_affine(int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                          const float* running_var, float* scale, float* shift, float* mean, float* rstd, void* stream);
+int sarssl_cl_affine_act(const void* x, long N, int C, const float* scale, const float* shift, int act, void* z, int dtype,
+                         void* stream);
+int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
+                            const float* mean, const float* rstd, int act, double* red, int dtype, void* stream);
+int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
+                           const float* mean, const float* rstd, int act, int g_is_masked, int use_stats, const double* red,
+                           void* dy, int dtype, void* stream);
+
+/* ---- Conformer row / elementwise kernels: LayerNorm (feed_forward.py:48, attention.py:139, convolution.py:137,
+ *      Conformer.py:87), GLU (activation.py:31-42), depthwise conv k=31 (convolution.py:140), relative-shift softmax
+ *      (attention.py:87-113), u/v bias add (attention.py:87-88) */
+int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps, void* y,
+                         long ldy, float* mean, float* rstd, int dtype, void* stream);
+int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
+                         const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
+                         float* dgamma, float* dbeta, int dtype, void* stream);
+int sarssl_glu_fwd(const void* h, long M, int d, void* g, int dtype, void* stream);
+int sarssl_glu_bwd(const void* dg, const void* h, long M, int d, void* dh, int dtype, void* stream);
+int sarssl_dwconv_fwd(const void* x, const float* w, int nb, int Tn, int d, int ksize, int flip, void* y, int dtype,
+                      void* stream);
+int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn, int d, int ksize, float* dw, int dtype, void* stream);
+int sarssl_softmax_relshift_fwd(const float* content, const float* pos, long nmat, int Tn, float scale, void* p, void* pd,
+                                float p_drop, unsigned long long seed, int dtype, void* stream);
+int sarssl_softmax_bwd(const float* dpd, const void* p, long nmat, int Tn, float scale, float p_drop, unsigned long long seed,
+                       void* dscore, int dtype, void* stream);
+int sarssl_relshift_bwd(const void* dscore, long nmat, int Tn, void* dpos, int dtype, void* stream);
+int sarssl_bias2(const void* q, long ldq, long M, int d, const float* u, const float* v, void* qu, void* qv, int dtype,
+                 void* stream);
+int sarssl_axpby(const void* x, const void* y, float a, float b, long n, void* out, int dtype, void* stream);
+int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream);
+int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,
+                   void* dh, int dtype, void* stream);
+int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+int sarssl_f64_accum(const double* src, float* dst, int n, float scale, void* stream);
+
+/* ---- loss: code/model.py:585-592 (channel select) + 721-747 (gen_loss) */
+int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
+                          double* sums, float* out, int dtype, void* stream);
+int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn,
+                          int nm, float gscale, const float* gscale_dev, void* dpred, int dtype, void* stream);
+
+/* ---- optimiser: torch.optim.Adam(betas=(0.9,0.999), weight_decay=0) at code/learner.py:83, over one flat buffer */
+int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, long n, float gscale, float lr, float beta1,
+                     float beta2, float eps, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""Pretraining entry point with the reference's command line (code/run_pretrain.py):
+
+    python run_pretrain.py --pretrain --simu-exp --gpu-id 0,                      # one GPU
+    torchrun --nproc-per-node 8 run_pretrain.py --pretrain --simu-exp --gpu-id 0,1,2,3,4,5,6,7 [--use-amp]
+
+Only the ``--pretrain --simu-exp`` branch (fixed pre-generated simulated segments) is implemented - the path BASELINE.json
+names.  Multi-GPU = one process per GPU under torchrun (RCCL), not DataParallel; per-epoch scalars go to a JSONL log
+(tensorboardX is optional and absent here).
+"""
+import json
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+import sarssl_boot  # noqa: E402,F401
+
+
+def main(argv=None):
+    from sar_ssl_amd.opt import opt_pretrain
+    opts = opt_pretrain()
+    args = opts.parse(argv)
+    dirs = opts.dir()
+    if "LOCAL_RANK" not in os.environ:
+        os.environ["HIP_VISIBLE_DEVICES"] = ",".join(g for g in args.gpu_id.split(",") if g != "")
+
+    import torch
+    from sar_ssl_amd import dataset as at_dataset, learner as at_learner, model as at_model, dist as sdist
+    from sar_ssl_amd.common.utils import set_seed, set_random_seed, create_learning_rate_schedule, get_nparams, save_config_to_file
+
+    if args.no_cuda or not torch.cuda.is_available():
+        raise SystemExit("run_pretrain.py (sar_ssl_amd) needs an MI355X GPU: the HIP path has no CPU fallback")
+    if not args.pretrain or not args.simu_exp:
+        raise SystemExit("only `--pretrain --simu-exp` is implemented on this path")
+    rank, world, local = sdist.init_from_env()
+    device = torch.device("cuda", local)
+    set_seed(args.seed)
+    if rank == 0:
+        os.makedirs(dirs["log_pretrain"], exist_ok=True)
+        save_config_to_file([{k: v for k, v in args.__dict__.items()}, dirs], os.path.join(dirs["log_pretrain"], "config.json"))
+
+    fs, T = args.acoustic_setting["fs"], args.acoustic_setting["T"]
+    seeds = {"train": int(args.seed + 4e8), "val": int(args.seed + 1e8), "test": int(args.seed + 1)}
+    win_len, nfft, win_shift_ratio, fre_used_ratio = 512, 512, 0.5, 1                       # code/run_pretrain.py:67-72
+    nf = nfft // 2
+    nt = int((T * fs - win_len * (1 - win_shift_ratio)) / (win_len * win_shift_ratio))
+    net = at_model.SARSSL(sig_shape=(nf, nt, 2, 2), pretrain=True, device=device)
+    nparam, nparam_sum = get_nparams(net, param_key_list=["spec_encoder", "spat_encoder", "decoder"])
+    if rank == 0:
+        print(f"T: {T:.3f}, nt: {nt}, nf: {nf}; # Parameters (M): {nparam_sum:.2f}")
+
+    data_num = {"train": 5120 * 100, "val": 4000 * 2}
+    ds_train = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_pretrain"], load_anno=False, load_dp=False, fs=fs,
+                                           dataset_sz=data_num["train"], transforms=None, raw_pcm=True)
+    ds_val = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_preval"], load_anno=False, load_dp=False, fs=fs,
+                                         dataset_sz=data_num["val"], transforms=None, raw_pcm=True)
+    kwargs = {"num_workers": args.workers, "pin_memory": True}
+    sampler = torch.utils.data.distributed.DistributedSampler(ds_train, num_replicas=world, rank=rank, shuffle=True,
+                                                              seed=args.seed) if world > 1 else None
+    dl_train = torch.utils.data.DataLoader(ds_train, batch_size=args.bs[0], shuffle=(sampler is None), sampler=sampler,
+                                           drop_last=(world > 1), **kwargs)
+    dl_val = torch.utils.data.DataLoader(ds_val, batch_size=args.bs[1], shuffle=False, **kwargs)
+
+    learner = at_learner.STFTLearner(net, win_len=win_len, win_shift_ratio=win_shift_ratio, nfft=nfft,
+                                     fre_used_ratio=fre_used_ratio, fs=fs, task=None, ch_mode="M")
+    if world > 1:
+        learner.mul_gpu()
+    learner.cuda()
+    if args.use_amp:
+        learner.amp()
+    if args.checkpoint_start:
+        learner.resume_checkpoint(checkpoints_dir=dirs["log_pretrain"], from_latest=True, as_all_state=True)
+    lr_schedule = create_learning_rate_schedule(total_steps=args.nepoch, base=args.lr, decay_type="cosine", warmup_steps=1,
+                                                linear_end=1e-6)
+    log = open(os.path.join(dirs["log_pretrain"], "scalars.jsonl"), "a") if rank == 0 else None
+    for epoch in range(learner.start_epoch, args.nepoch + 1):
+        lr = float(lr_schedule(epoch))
+        set_random_seed(seeds["train"] + epoch + 1000003 * rank)                              # per-rank mask / dropout streams
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        loss_train, diff_train, _ = learner.pretrain_epoch(dl_train, lr=lr, epoch=epoch, return_diff=True)
+        set_random_seed(seeds["val"])
+        loss_val, diff_val, _ = learner.pretest_epoch(dl_val, return_diff=True)
+        stop_flag, is_best = learner.early_stopping(current_score=-loss_val, patience=100)
+        learner.save_checkpoint(epoch=epoch, checkpoints_dir=dirs["log_pretrain"], is_best_epoch=is_best, save_extra_hist=True)
+        if rank == 0:
+            rec = {"epoch": epoch, "lr": lr, "loss_train": loss_train, "diff_train": diff_train, "loss_val": loss_val,
+                   "diff_val": diff_val, "nparam_M": nparam_sum}
+            print(json.dumps(rec), flush=True)
+            log.write(json.dumps(rec) + "\n"); log.flush()
+        if stop_flag:
+            break
+    if rank == 0:
+        print("\nPre-Training finished\n")
+
+
+if __name__ == "__main__":
+    main()

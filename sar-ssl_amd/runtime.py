@@ -86,7 +86,8 @@ class FlatParams:
             if id(p) not in seen:
                 seen.add(id(p))
                 params.append(p)
-        assert params and all(p.is_cuda for p in params), "move the model to the GPU before flattening"
+        assert params, "module has no parameters"
+        self.on_gpu = all(p.is_cuda for p in params)       # CPU flattening is allowed for host-logic tests only (no kernels)
         self.params = params
         dev = params[0].device
         offs, total = [], 0
@@ -115,7 +116,8 @@ class FlatParams:
         """Refresh the bf16 shadow if any parameter was modified through torch (load_state_dict, init, ...)."""
         sig = self._sig()
         if sig != self._synced:
-            hip.cast(self.flat, torch.bfloat16, out=self.w16)
+            if self.on_gpu:
+                hip.cast(self.flat, torch.bfloat16, out=self.w16)
             self._synced = sig
             bump_version()
 
