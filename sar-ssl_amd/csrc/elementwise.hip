@@ -463,7 +463,7 @@ extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, lo
                                     const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
                                     float* dgamma, float* dbeta, int dtype, void* stream) {
     SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024, "sarssl_layernorm_bwd");
-    const int nblk = nblocks_for(M, 4 * 8, 1024);
+    const int nblk = nblocks_for(M, 4 * 32, 256);
     DISPATCH_T(dtype, (layernorm_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd,
                                                                     (const T*)resid, ldr, (T*)dx, lddx, dgamma, dbeta)));
     SARSSL_CHECK_LAUNCH("layernorm_bwd_kernel");

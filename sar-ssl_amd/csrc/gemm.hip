@@ -14,8 +14,10 @@
 // on the same matrix cores and the same code path as the fast bf16 mode.
 //
 // Tiling: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA
-// fragments), operands staged through registers into LDS as [row][k] with a 144-byte pitch
-// (conflict-free ds_read_b128 fragment reads).  Operand roles are swapped in the MFMA
+// fragments).  K-contiguous operands are staged through registers into LDS as [row][k] with a 144-byte pitch
+// (conflict-free ds_read_b128 fragment reads); operands whose contraction index is the SLOW memory dimension
+// (weight gradients, dX = dY*W) are staged untransposed as [k][row] (320-byte pitch) and their MFMA fragments are
+// fetched with the gfx950 transpose read ds_read_b64_tr_b16 - no transposition pass, no bank conflicts.  Operand roles are swapped in the MFMA
 // (weights as the "A"/row operand) so each lane ends up with 4 consecutive n for one m and the
 // epilogue stores 8/16-byte vectors.
 #include "common.h"
@@ -24,6 +26,8 @@
 #define BN 128
 #define BK 64
 #define PITCH (BK + 8)
+#define PITCH_T (BM + 32)          // [k][row] tiles: 320-byte pitch -> conflict-free 32-lane transpose reads
+#define TILE_ELEMS (BK * PITCH_T)  // >= BM * PITCH
 
 struct GemmArgs {
     const void* A; const void* B; void* C;
@@ -39,7 +43,7 @@ struct GemmArgs {
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
     float p_drop; unsigned long long seed;
-    int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s, epilogue = atomicAdd(C, alpha*acc) (f32 C only)
+    int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
 };
 
 template <typename T, bool KC>
@@ -65,43 +69,45 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ src, long ld, i
             *(uint4*)&s[row * PITCH + kc * 8] = regs[i];
         }
     } else {
-        // source is [K][R]: each thread takes a 4(k) x 8(r) unit and writes 8 k-quads (8 B each)
-        int kq = tid >> 4, rq = tid & 15;
-        int gc = r0 + rq * 8;
-        uint32_t bits[4][8];
+        // source is [K][R] (R contiguous): copy rows as they are -> LDS [k][r]; fragments use transpose reads
+        uint4 regs[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int gk = k0 + kq * 4 + j;
-            if (gk < K && gc < R) {
-                const T* p = src + (long)gk * ld + gc;
-                if (sizeof(T) == 2) {
-                    uint4 u = *(const uint4*)p;
-                    bits[j][0] = u.x & 0xffffu; bits[j][1] = u.x >> 16; bits[j][2] = u.y & 0xffffu; bits[j][3] = u.y >> 16;
-                    bits[j][4] = u.z & 0xffffu; bits[j][5] = u.z >> 16; bits[j][6] = u.w & 0xffffu; bits[j][7] = u.w >> 16;
-                } else {
-                    f8 v = ld8(p);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bits[j][e] = bf16_part_bits(v.v[e], part);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bits[j][e] = 0;
-            }
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + i * 256;
+            int krow = c >> 4, rc = c & 15;
+            int gk = k0 + krow, gr = r0 + rc * 8;
+            if (gk < K && gr < R) {
+                const T* p = src + (long)gk * ld + gr;
+                if (sizeof(T) == 2) regs[i] = *(const uint4*)p;
+                else { f8 v = ld8(p); regs[i] = pack8_part(v, part); }
+            } else regs[i] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            uint2 w;
-            w.x = bits[0][e] | (bits[1][e] << 16);
-            w.y = bits[2][e] | (bits[3][e] << 16);
-            *(uint2*)&s[(rq * 8 + e) * PITCH + kq * 4] = w;
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + i * 256;
+            int krow = c >> 4, rc = c & 15;
+            *(uint4*)&s[krow * PITCH_T + rc * 8] = regs[i];
         }
     }
 }
 
+// MFMA fragment (8 consecutive k for row r0 + (lane&31)) from a [k][row] tile via two transpose reads
+__device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const int col = r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    union { s16x4 v[2]; bf16x8 b; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = kbase + (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
+        u.v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + k * PITCH_T + col));
+    }
+    return u.b;
+}
+
 template <typename TA, typename TB, typename TC, bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) uint16_t sA[BM * PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t sB[BN * PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t sA[TILE_ELEMS];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[TILE_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nsplit = g.split_k > 0 ? g.split_k : 1;
@@ -130,9 +136,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const int koff = kk * 16 + (lane >> 5) * 8;
             bf16x8 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)&sA[(wm * 64 + i * 32 + (lane & 31)) * PITCH + koff];
+            for (int i = 0; i < 2; ++i) {
+                if (AKC) fa[i] = *(const bf16x8*)&sA[(wm * 64 + i * 32 + (lane & 31)) * PITCH + koff];
+                else fa[i] = frag_tr(sA, kk * 16, wm * 64 + i * 32, lane);
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *(const bf16x8*)&sB[(wn * 64 + j * 32 + (lane & 31)) * PITCH + koff];
+            for (int j = 0; j < 2; ++j) {
+                if (BKC) fb[j] = *(const bf16x8*)&sB[(wn * 64 + j * 32 + (lane & 31)) * PITCH + koff];
+                else fb[j] = frag_tr(sB, kk * 16, wn * 64 + j * 32, lane);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -164,9 +176,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 for (int e = 0; e < 4; ++e) v[e] = g.alpha * acc[i][j][gq * 4 + e];
                 const int nvalid = min(4, g.N - n);
                 if (g.split_k > 0) {
-                    if constexpr (sizeof(TC) == 4) {
-                        for (int e = 0; e < nvalid; ++e) atomicAdd((float*)C + (long)m * g.ldc + n + e, v[e]);
-                    }
+                    float* Wp = g.acc_ws + (((long)z * nsplit + ks) * g.M + m) * g.N + n;
+                    if ((g.N & 3) == 0) *(float4*)Wp = make_float4(v[0], v[1], v[2], v[3]);
+                    else for (int e = 0; e < nvalid; ++e) Wp[e] = v[e];
                     continue;
                 }
                 if (g.acc_in) {
@@ -210,6 +222,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// C[z][m][n] += sum_s ws[z][s][m][n]   (second stage of split-K weight-gradient GEMMs; C is f32)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int M, int N, float* __restrict__ C, long ldc,
+                                     int batch_inner, long sC0, long sC1) {
+    const long mn = (long)M * N;
+    const int z = blockIdx.y;
+    float* Cz = C + (z / batch_inner) * sC0 + (z % batch_inner) * sC1;
+    const float* wz = ws + (long)z * nsplit * mn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += wz[(long)k * mn + i];
+        const long m = i / N, n = i - m * N;
+        Cz[m * ldc + n] += s;
+    }
+}
+
 template <typename TA, typename TB, typename TC>
 static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
     if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true><<<grid, 256, 0, st>>>(g);
@@ -242,25 +269,42 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.p_drop = p_drop; g.seed = seed;
     g.split_k = 0; g.k_per_split = K;
     if (split_k > 0) {
-        // accumulate mode: C (f32) += alpha * A*B, no other epilogue; K split over split_k workgroups per tile
-        SARSSL_REQUIRE(dtC == SARSSL_F32 && !bias && !resid && !preact && act == 0 && p_drop == 0.f, "sarssl_gemm(split_k epilogue)");
+        // accumulate mode: C (f32) += alpha * A*B, no other epilogue; K split over split_k workgroups per tile, partials
+        // go to ws (f32, nbatch*split_k*M*N) and a second kernel folds them into C (deterministic, no atomics)
+        SARSSL_REQUIRE(dtC == SARSSL_F32 && !bias && !resid && !preact && act == 0 && p_drop == 0.f && ws != nullptr,
+                       "sarssl_gemm(split_k epilogue)");
+        g.acc_ws = ws;
         int per = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
         g.split_k = (K + per - 1) / per; g.k_per_split = per;
     }
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch * (g.split_k > 0 ? g.split_k : 1));
     hipStream_t st = (hipStream_t)stream;
+    auto reduce = [&]() -> int {
+        const long mn = (long)M * N;
+        int bx = (int)((mn + 255) / 256); if (bx > 1024) bx = 1024;
+        splitk_reduce_kernel<<<dim3(bx, nbatch), 256, 0, st>>>(ws, g.split_k, M, N, (float*)C, ldc, batch_inner, sC0, sC1);
+        SARSSL_CHECK_LAUNCH("splitk_reduce_kernel");
+        return 0;
+    };
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_BF16)
         return launch_layout<bf16, bf16, bf16>(g, a_kc, b_kc, grid, st);
-    if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_F32)
-        return launch_layout<bf16, bf16, float>(g, a_kc, b_kc, grid, st);
+    if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_F32) {
+        int rc = launch_layout<bf16, bf16, float>(g, a_kc, b_kc, grid, st);
+        if (rc || g.split_k <= 0) return rc;
+        return reduce();
+    }
     if (dtA == SARSSL_F32 && dtB == SARSSL_F32 && dtC == SARSSL_F32) {
-        if (!precise) return launch_layout<float, float, float>(g, a_kc, b_kc, grid, st);
-        if (g.split_k > 0) {          // the accumulate epilogue is linear: the three split-precision passes just add up
+        if (g.split_k > 0) {          // the accumulate epilogue is linear: the split-precision passes just add up
             GemmArgs p = g;
-            p.partA = 0; p.partB = 1; int rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
-            p.partA = 1; p.partB = 0; rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
-            p.partA = 0; p.partB = 0; return launch_layout<float, float, float>(p, a_kc, b_kc, grid, st);
+            const int npass = precise ? 3 : 1;
+            for (int pass = 0; pass < npass; ++pass) {
+                p.partA = precise ? (pass == 1) : 0; p.partB = precise ? (pass == 0) : 0;      // hi*lo, lo*hi, hi*hi
+                int rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
+                rc = reduce(); if (rc) return rc;
+            }
+            return 0;
         }
+        if (!precise) return launch_layout<float, float, float>(g, a_kc, b_kc, grid, st);
         SARSSL_REQUIRE(ws != nullptr, "sarssl_gemm(precise needs workspace)");
         g.acc_ws = ws;
         GemmArgs p = g;

@@ -37,6 +37,7 @@ def mm_tn_acc(dy, x, gW):
     g2 = gW.view(N, K)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     split = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles))       # ~3 workgroups per CU, >= 4 K-tiles each
+    split = max(1, min(split, (1 << 26) // (N * K)))                         # partial-sum workspace <= 256 MB
     hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), out=g2, ldc=K,
              precise=RT.precise, split_k=split)
 

@@ -91,7 +91,9 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     if nbatch > 1 and sC == (0, 0):
         sC = (M * N * batch_inner, M * N)
     ws = None
-    if precise and A.dtype == torch.float32 and split_k <= 0:
+    if split_k > 0:
+        ws = workspace(4 * nbatch * split_k * M * N, A.device, "gemm_split")
+    elif precise and A.dtype == torch.float32:
         ws = workspace(4 * nbatch * M * N, A.device, "gemm_acc")
     _lib.call("sarssl_gemm", _p(A), _p(B), _p(out), c_int(dt(A)), c_int(dt(B)), c_int(dt(out)),
               c_int(1 if a_kc else 0), c_int(1 if b_kc else 0), c_int(M), c_int(N), c_int(K),
