@@ -65,6 +65,7 @@ def main():
     from sar_ssl_amd import dist as sdist, hip, model, runtime, synth
     rank, world, local = sdist.init_from_env()
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    local = local % max(torch.cuda.device_count(), 1)      # (single-GPU functional tests run 2 ranks on one device over gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     runtime.set_precision(args.precision)
@@ -111,7 +112,7 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el[0])
-    loss_val = float(last)
+    loss_val = float(last.detach())
     assert np.isfinite(loss_val), "non-finite loss"
 
     if rank == 0:

@@ -164,22 +164,32 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+        {
+            // 36 k-steps (9 taps x 4 chunks of 16 channels); fragments of step s+1 are fetched before the MFMAs of step s.
+            // LDS addresses are tile-invariant: recomputing them (a few VALU ops hidden under the MFMAs) instead of letting
+            // LICM keep ~40 of them live across the tile loop keeps the kernel well under 256 VGPRs.
+            bf16x8 wf[2][2], xf[2][2];
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            auto fetch = [&](int s, int buf) {
+                const int tap = s >> 2, kc = s & 3;
+                const int kh = tap / 3, kw = tap - kh * 3;
+                const int chunk = kc * 2 + (lane_o >> 5);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
+                for (int i = 0; i < 2; ++i) wf[buf][i] = *(const bf16x8*)&sW[swz(tap * 64 + i * 32 + (lane_o & 31), chunk)];
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const int chunk = kc * 2 + (lane >> 5);
-                bf16x8 wf[2], xf[2];
+                for (int j = 0; j < 2; ++j) xf[buf][j] = *(const bf16x8*)&sX[swz((wave + kh) * HC + j * 32 + (lane_o & 31) + kw, chunk)];
+            };
+            fetch(0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) wf[i] = *(const bf16x8*)&sW[swz(tap * 64 + i * 32 + (lane & 31), chunk)];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) xf[j] = *(const bf16x8*)&sX[swz((wave + kh) * HC + j * 32 + (lane & 31) + kw, chunk)];
+            for (int s = 0; s < 36; ++s) {
+                const int cur = s & 1;
+                if (s + 1 < 36) fetch(s + 1, cur ^ 1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
             }
         }
 

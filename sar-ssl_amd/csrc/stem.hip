@@ -133,11 +133,11 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
 //   s1[ci] = sum_p g3 ; s2[ci] = sum_p g3 * xhat3                         (BatchNorm backward sums)
 // dy4 is (B,T,F,4); y3/g3 are (B,F,T,64).  red: double [4*64 + 64 + 64], zeroed by the caller.
 template <typename T>
-__global__ void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict__ dy4, const float* __restrict__ W4,
+__global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict__ dy4, const float* __restrict__ W4,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                    int nb, int F, int Tn, T* __restrict__ g3, double* __restrict__ red) {
-    __shared__ float sred[256][49];
+    __shared__ float sred[4][8][48];
     const int cg = threadIdx.x & 7;
     float w[4][8], sc[8], sh[8], mu[8], rs[8];
 #pragma unroll
@@ -147,40 +147,55 @@ __global__ void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[c][e] = W4[c * 64 + ci];
     }
-    float aW[4][8], a1[8], a2[8];
+    float acc[48];                               // [0,32) dW4[c][e], [32,40) s1[e], [40,48) s2[e]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) aW[c][e] = 0.f; }
+    for (int i = 0; i < 48; ++i) acc[i] = 0.f;
     const long npix = (long)nb * F * Tn;
     const long nthreads = (long)gridDim.x * blockDim.x;
-    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
-        const long p = g >> 3;
-        const int t = (int)(p % Tn);
-        const long bf = p / Tn;
-        const int f = (int)(bf % F), b = (int)(bf / F);
-        const float4 d = ld4(dy4 + ((((long)b * Tn + t) * F + f) * 4));
-        const f8 v = ld8(y3 + p * 64 + cg * 8);
-        f8 o;
+    constexpr int U = 4;                         // pixels in flight per thread (latency hiding)
+    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads * U) {
+        f8 v[U]; float4 d[U]; bool ok[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float u = fmaf(v.v[e], sc[e], sh[e]);
-            const float z = fmaxf(u, 0.f);
-            float gi = d.x * w[0][e] + d.y * w[1][e] + d.z * w[2][e] + d.w * w[3][e];
-            gi = (u > 0.f) ? gi : 0.f;
-            o.v[e] = gi;
-            aW[0][e] += d.x * z; aW[1][e] += d.y * z; aW[2][e] += d.z * z; aW[3][e] += d.w * z;
-            a1[e] += gi;
-            a2[e] += gi * (v.v[e] - mu[e]) * rs[e];
+        for (int u = 0; u < U; ++u) {
+            const long g = g0 + u * nthreads;
+            ok[u] = g < npix * 8;
+            if (ok[u]) {
+                const long p = g >> 3;
+                const int t = (int)(p % Tn);
+                const long bf = p / Tn;
+                const int f = (int)(bf % F), b = (int)(bf / F);
+                d[u] = ld4(dy4 + ((((long)b * Tn + t) * F + f) * 4));
+                v[u] = ld8(y3 + p * 64 + cg * 8);
+            }
         }
-        st8(g3 + p * 64 + cg * 8, o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const long p = (g0 + u * nthreads) >> 3;
+            f8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float uu = fmaf(v[u].v[e], sc[e], sh[e]);
+                const float z = fmaxf(uu, 0.f);
+                float gi = d[u].x * w[0][e] + d[u].y * w[1][e] + d[u].z * w[2][e] + d[u].w * w[3][e];
+                gi = (uu > 0.f) ? gi : 0.f;
+                o.v[e] = gi;
+                acc[0 * 8 + e] += d[u].x * z; acc[1 * 8 + e] += d[u].y * z; acc[2 * 8 + e] += d[u].z * z; acc[3 * 8 + e] += d[u].w * z;
+                acc[32 + e] += gi;
+                acc[40 + e] += gi * (v[u].v[e] - mu[e]) * rs[e];
+            }
+            st8(g3 + p * 64 + cg * 8, o);
+        }
     }
+    // lanes sharing a channel group are 8 apart: butterfly over lane bits 3..5, then across the 4 waves through LDS
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int i = 0; i < 48; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8, 64); acc[i] += __shfl_xor(acc[i], 16, 64); acc[i] += __shfl_xor(acc[i], 32, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 8) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) sred[threadIdx.x][c * 8 + e] = aW[c][e];
-        sred[threadIdx.x][32 + e] = a1[e];
-        sred[threadIdx.x][40 + e] = a2[e];
+        for (int i = 0; i < 48; ++i) sred[wave][lane][i] = acc[i];
     }
     __syncthreads();
     // 384 outputs: [0,256) dW4[c][ci], [256,320) s1[ci], [320,384) s2[ci]
@@ -190,9 +205,8 @@ __global__ void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict
         else if (o < 320) { ci = o - 256; slot = 32 + (ci & 7); }
         else { ci = o - 320; slot = 40 + (ci & 7); }
         const int ocg = ci >> 3;
-        float s = 0.f;
-        for (int k = 0; k < 32; ++k) s += sred[k * 8 + ocg][slot];
-        atomicAdd(&red[o], (double)s);
+        const float sum = sred[0][ocg][slot] + sred[1][ocg][slot] + sred[2][ocg][slot] + sred[3][ocg][slot];
+        atomicAdd(&red[o], (double)sum);
     }
 }
 
