@@ -69,7 +69,7 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag="default"):
-    key = (tag, device)
+    key = (tag, device, torch.cuda.current_stream().cuda_stream)      # one scratch buffer per stream: no cross-stream reuse
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -137,8 +137,28 @@ class _PretrainFn(torch.autograd.Function):
         spec_in, spat_in = hip.mask_inputs(x, mp_u8, ch_i32, 0, RT.dtype)
         ds, dt_ = net.spec_encoder.dembed, net.spat_encoder.dembed
         ecat = torch.empty((B * T, ds + dt_), dtype=RT.dtype, device=x.device)
-        net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
-        net.spat_encoder._fwd_cl(spat_in, B, T, saved, out=ecat[:, ds:])
+        # The two encoders are independent until the decoder: run them on two HIP streams so one encoder's HBM-bound passes
+        # (BatchNorm statistics / backward, LayerNorm, ...) overlap the other's MFMA-bound convolutions and GEMMs.
+        saved_spat = []
+        side = net._side_stream(x.device)
+        main = torch.cuda.current_stream()
+        if side is not None:
+            flat = getattr(params[0], "_flat", None) if params else None
+            if flat is not None:
+                flat.ensure_shadow()                       # any lazy weight refresh happens before the fork, on the main stream
+            side.wait_stream(main)
+            # tensors allocated on the main stream but consumed on the side stream: tell the caching allocator, otherwise their
+            # memory can be recycled by main-stream allocations while side-stream kernels that read them are still queued
+            spat_in.record_stream(side)
+            ecat.record_stream(side)
+            with torch.cuda.stream(side):
+                net.spat_encoder._fwd_cl(spat_in, B, T, saved_spat, out=ecat[:, ds:])
+            net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
+            main.wait_stream(side)
+        else:
+            net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
+            net.spat_encoder._fwd_cl(spat_in, B, T, saved_spat, out=ecat[:, ds:])
+        saved.append(saved_spat)
         pred = engine.decoder_fwd(ecat, net.decoder, saved)
         out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32)
         ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds)
@@ -153,11 +173,24 @@ class _PretrainFn(torch.autograd.Function):
         dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
         decat = engine.decoder_bwd(dpred, net.decoder, saved)
         net._after_backward_stage("decoder")
+        saved_spat = saved.pop()
         # encoder backward takes column slices of the concatenated decoder-input gradient (row stride 768)
-        net.spat_encoder._bwd_cl(decat[:, ds:], saved)
-        net._after_backward_stage("spat_encoder")
-        net.spec_encoder._bwd_cl(decat[:, :ds], saved)
-        net._after_backward_stage("spec_encoder")
+        side = net._side_stream(x.device)
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
+            decat.record_stream(side)
+            with torch.cuda.stream(side):
+                net.spat_encoder._bwd_cl(decat[:, ds:], saved_spat)
+                net._after_backward_stage("spat_encoder")      # its gradient bucket is reduced behind the side stream
+            net.spec_encoder._bwd_cl(decat[:, :ds], saved)
+            main.wait_stream(side)
+            net._after_backward_stage("spec_encoder")
+        else:
+            net.spat_encoder._bwd_cl(decat[:, ds:], saved_spat)
+            net._after_backward_stage("spat_encoder")
+            net.spec_encoder._bwd_cl(decat[:, :ds], saved)
+            net._after_backward_stage("spec_encoder")
         return (None,) * (5 + ctx.nparams)
 
 
@@ -203,6 +236,16 @@ class SARSSL(nn.Module):
         self._stage_hook = None
         self._param_list = None
         self._forced_masks = None
+
+    def _side_stream(self, device):
+        """Second HIP stream for the spat encoder (None disables the two-stream schedule: SARSSL_TWO_STREAMS=0)."""
+        import os
+        if os.environ.get("SARSSL_TWO_STREAMS", "1") == "0":
+            return None
+        s = self.__dict__.get("_side")
+        if s is None:
+            s = self.__dict__["_side"] = torch.cuda.Stream(device=device)
+        return s
 
     # ---- hooks used by the data-parallel wrapper to start gradient all-reduce while backward continues
     def set_backward_stage_hook(self, fn):
