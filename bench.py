@@ -122,6 +122,10 @@ def main():
         flop_per_launch = 2.0 * args.batch * 65536 * 64 * 576            # one 3x3 64->64 conv over B x 256 x 256 pixels
         achieved = (flop_per_launch / (ms / n * 1e-3)) / 1e12 if n else 0.0
         nw, msw = prof.get("conv3x3_wgrad_kernel", (0, 0.0))
+        traffic = None                       # HBM bytes per launch from the committed PMC passes (same kernel, same shape)
+        pmc = os.path.join(ROOT, "profiles", "r01_conv3x3_fwd_pmc.json")
+        if args.batch == 64 and os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         out = {
             "metric": "pretrain_segments_per_sec", "value": round(value, 2), "unit": "segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -133,7 +137,7 @@ def main():
                        "global_batch": args.batch * world, "segment_samples": NSAMPLE, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_kernel", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": None, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
+                         "traffic": traffic, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
                          "flop_per_launch": flop_per_launch,
                          "wgrad_avg_ms": round(msw / nw, 4) if nw else None,
                          "end_to_end_frac": round(value / world * FLOP_PER_SEG_STEP / (PEAK_BF16_TFLOPS * 1e12), 4)},

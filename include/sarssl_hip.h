@@ -72,14 +72,17 @@ int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const f
  *      (attention.py:87-113), u/v bias add (attention.py:87-88) */
 int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps, void* y,
                          long ldy, float* mean, float* rstd, int dtype, void* stream);
+long sarssl_layernorm_bwd_workspace_bytes(long M, int d);
 int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
                          const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
-                         float* dgamma, float* dbeta, int dtype, void* stream);
+                         float* dgamma, float* dbeta, float* partial, int dtype, void* stream);
 int sarssl_glu_fwd(const void* h, long M, int d, void* g, int dtype, void* stream);
 int sarssl_glu_bwd(const void* dg, const void* h, long M, int d, void* dh, int dtype, void* stream);
 int sarssl_dwconv_fwd(const void* x, const float* w, int nb, int Tn, int d, int ksize, int flip, void* y, int dtype,
                       void* stream);
-int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn, int d, int ksize, float* dw, int dtype, void* stream);
+long sarssl_dwconv_wgrad_workspace_bytes(int nb, int Tn, int d);
+int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn, int d, int ksize, float* dw, float* partial, int dtype,
+                        void* stream);
 int sarssl_softmax_relshift_fwd(const float* content, const float* pos, long nmat, int Tn, float scale, void* p, void* pd,
                                 float p_drop, unsigned long long seed, int dtype, void* stream);
 int sarssl_softmax_bwd(const float* dpd, const void* p, long nmat, int Tn, float scale, float p_drop, unsigned long long seed,

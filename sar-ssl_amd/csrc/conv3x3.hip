@@ -94,6 +94,14 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int tiles_f, int tiles
     return c;
 }
 
+// XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only).  In every
+// round of gridDim.x tiles each XCD gets a CONTIGUOUS run of tiles (neighbouring tiles of one image), so the halo rows /
+// columns shared by adjacent tiles are served by that XCD's L2 instead of being fetched from HBM twice.
+__device__ __forceinline__ int xcd_tile(int it, int bid, int grid) {
+    if ((grid & 7) == 0) return it * grid + (bid & 7) * (grid >> 3) + (bid >> 3);
+    return it * grid + bid;
+}
+
 template <typename T, typename TW>
 __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
@@ -148,12 +156,14 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) issue_loads(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
+    if (xcd_tile(0, blockIdx.x, gridDim.x) < ntiles) issue_loads(xcd_tile(0, blockIdx.x, gridDim.x));
+    for (int it = 0; it < nrounds; ++it) {
+        const int tile = xcd_tile(it, blockIdx.x, gridDim.x);
+        if (tile >= ntiles) break;                 // (whole workgroup takes the same branch)
         write_tile(tile);
         __syncthreads();
-        const int next = tile + gridDim.x;
+        const int next = (it + 1 < nrounds) ? xcd_tile(it + 1, blockIdx.x, gridDim.x) : ntiles;
         if (next < ntiles) issue_loads(next);
 
         f32x16 acc[2][2];
@@ -274,7 +284,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t9][r] = 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
+    for (int it = 0; it < nrounds; ++it) {
+        const int tile = xcd_tile(it, blockIdx.x, gridDim.x);
+        if (tile >= ntiles) break;
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
         // stage z (with halo, prologue) and dy (no halo)
 #pragma unroll
@@ -329,13 +342,25 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
         }
 }
 
-// dW[e] (+)= sum_p partial[p][e]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW, int accumulate) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= W_ELEMS) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(long)p * W_ELEMS + e];
-    dW[e] = accumulate ? dW[e] + s : s;
+// dW[e] (+)= sum_p partial[p][e]; workgroup = 64 elements x 4 part-slots, 4-way unrolled loads
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW,
+                                                           int accumulate) {
+    __shared__ float sred[4][64];
+    const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = slot;
+    for (; p + 12 < nparts; p += 16) {
+        s0 += partial[(long)p * W_ELEMS + e]; s1 += partial[(long)(p + 4) * W_ELEMS + e];
+        s2 += partial[(long)(p + 8) * W_ELEMS + e]; s3 += partial[(long)(p + 12) * W_ELEMS + e];
+    }
+    for (; p < nparts; p += 4) s0 += partial[(long)p * W_ELEMS + e];
+    sred[slot][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slot == 0) {
+        const float t = (sred[0][col] + sred[1][col]) + (sred[2][col] + sred[3][col]);
+        dW[e] = accumulate ? dW[e] + t : t;
+    }
 }
 
 static int conv_grid(int nb, int F, int T) {
@@ -386,7 +411,7 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
     a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
     hipStream_t st = (hipStream_t)stream;
     const int grid = conv_grid(nb, F, T);
-    const int rblocks = (W_ELEMS + 255) / 256;
+    const int rblocks = W_ELEMS / 64;
     if (dtype == SARSSL_BF16) {
         conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
         wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid * 2, dW, 0);

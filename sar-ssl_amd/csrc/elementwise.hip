@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             long M, int d, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const T* __restrict__ resid, long ldr, T* __restrict__ dx, long lddx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ partial /* [gridDim.x][2][d] or null */) {
     __shared__ float4 sg[4][64 * LN_MAXV];
     __shared__ float4 sb[4][64 * LN_MAXV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,22 +104,60 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
-    if (dgamma) {
+    if (partial) {
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) { sg[wave][lane + i * 64] = ag[i]; sb[wave][lane + i * 64] = ab[i]; }
         __syncthreads();
+        float* P = partial + (long)blockIdx.x * 2 * d;
         for (int c4 = threadIdx.x; c4 < nv; c4 += 256) {
             float4 a = sg[0][c4], b = sb[0][c4];
             for (int w = 1; w < 4; ++w) {
                 const float4 a2 = sg[w][c4], b2 = sb[w][c4];
                 a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
             }
-            atomicAdd(&dgamma[c4 * 4 + 0], a.x); atomicAdd(&dgamma[c4 * 4 + 1], a.y);
-            atomicAdd(&dgamma[c4 * 4 + 2], a.z); atomicAdd(&dgamma[c4 * 4 + 3], a.w);
-            atomicAdd(&dbeta[c4 * 4 + 0], b.x); atomicAdd(&dbeta[c4 * 4 + 1], b.y);
-            atomicAdd(&dbeta[c4 * 4 + 2], b.z); atomicAdd(&dbeta[c4 * 4 + 3], b.w);
+            *(float4*)(P + c4 * 4) = a;
+            *(float4*)(P + d + c4 * 4) = b;
         }
     }
+}
+// out[i] += sum_p partial[p][i], i < n.  Workgroup = 64 columns x 4 part-slots (4-way unrolled loads), LDS combine.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int nparts, long n,
+                                                             float* __restrict__ out) {
+    __shared__ float sred[4][64];
+    const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = slot;
+        for (; p + 12 < nparts; p += 16) {
+            s0 += partial[(long)p * n + i]; s1 += partial[(long)(p + 4) * n + i];
+            s2 += partial[(long)(p + 8) * n + i]; s3 += partial[(long)(p + 12) * n + i];
+        }
+        for (; p < nparts; p += 4) s0 += partial[(long)p * n + i];
+    }
+    sred[slot][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slot == 0 && i < n) out[i] += (sred[0][col] + sred[1][col]) + (sred[2][col] + sred[3][col]);
+}
+
+// same with a row pitch: out[i] += sum_p partial[p*pitch + i], i < n
+__global__ __launch_bounds__(256) void partial_reduce_strided_kernel(const float* __restrict__ partial, int nparts, long pitch, long n,
+                                                                     float* __restrict__ out) {
+    __shared__ float sred[4][64];
+    const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = slot;
+        for (; p + 12 < nparts; p += 16) {
+            s0 += partial[(long)p * pitch + i]; s1 += partial[(long)(p + 4) * pitch + i];
+            s2 += partial[(long)(p + 8) * pitch + i]; s3 += partial[(long)(p + 12) * pitch + i];
+        }
+        for (; p < nparts; p += 4) s0 += partial[(long)p * pitch + i];
+    }
+    sred[slot][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slot == 0 && i < n) out[i] += (sred[0][col] + sred[1][col]) + (sred[2][col] + sred[3][col]);
 }
 
 // ------------------------------------------------------------------------------------ GLU
@@ -177,11 +215,11 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
         }
     }
 }
-// dw[c][k] += sum_{b,t} dy[b][t][c] * x[b][t + k - 15][c]
+// partial[by][c][k] = sum over this workgroup's (b, t-tile) share of dy[b][t][c] * x[b][t + k - 15][c]
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, int nb, int Tn, int d,
-                                                           float* __restrict__ dw) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, int nb, int Tn, int d,
+                                                          float* __restrict__ partial) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= d) return;
     float acc[DWK];
 #pragma unroll
@@ -202,8 +240,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
             for (int k = 0; k < DWK; ++k) acc[k] += g * win[o + k];
         }
     }
+    float* P = partial + ((long)blockIdx.y * d + c) * DWK;
 #pragma unroll
-    for (int k = 0; k < DWK; ++k) atomicAdd(&dw[(long)c * DWK + k], acc[k]);
+    for (int k = 0; k < DWK; ++k) P[k] = acc[k];
 }
 
 // ------------------------------------------------------------------------------------ attention softmax
@@ -458,14 +497,24 @@ extern "C" int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, cons
     SARSSL_CHECK_LAUNCH("layernorm_fwd_kernel");
     return 0;
 }
-// dgamma/dbeta accumulate (f32 atomics) - pass null to skip
+static inline int ln_bwd_blocks(long M) { return nblocks_for(M, 4 * 8, 512); }
+extern "C" long sarssl_layernorm_bwd_workspace_bytes(long M, int d) {
+    return (long)ln_bwd_blocks(M) * 2 * d * sizeof(float);
+}
+// dgamma/dbeta accumulate (+=) through per-workgroup partials in `partial` (sarssl_layernorm_bwd_workspace_bytes) and a second
+// reduce kernel; pass dgamma = null to skip the parameter gradients.
 extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
                                     const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
-                                    float* dgamma, float* dbeta, int dtype, void* stream) {
-    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024, "sarssl_layernorm_bwd");
-    const int nblk = nblocks_for(M, 4 * 32, 256);
+                                    float* dgamma, float* dbeta, float* partial, int dtype, void* stream) {
+    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (!dgamma || partial), "sarssl_layernorm_bwd");
+    const int nblk = ln_bwd_blocks(M);
+    float* part = dgamma ? partial : nullptr;
     DISPATCH_T(dtype, (layernorm_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd,
-                                                                    (const T*)resid, ldr, (T*)dx, lddx, dgamma, dbeta)));
+                                                                    (const T*)resid, ldr, (T*)dx, lddx, part)));
+    if (dgamma) {       // partial is [nblk][2][d]: viewed as nblk rows of 2d, column halves go to dgamma / dbeta
+        partial_reduce_strided_kernel<<<(d + 63) / 64, 256, 0, ST>>>(part, nblk, 2L * d, d, dgamma);
+        partial_reduce_strided_kernel<<<(d + 63) / 64, 256, 0, ST>>>(part + d, nblk, 2L * d, d, dbeta);
+    }
     SARSSL_CHECK_LAUNCH("layernorm_bwd_kernel");
     return 0;
 }
@@ -491,13 +540,22 @@ extern "C" int sarssl_dwconv_fwd(const void* x, const float* w, int nb, int Tn, 
     SARSSL_CHECK_LAUNCH("dwconv_fwd_kernel");
     return 0;
 }
-// dw: f32 [d][31], accumulated (atomics)
-extern "C" int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn, int d, int ksize, float* dw, int dtype,
-                                   void* stream) {
-    SARSSL_REQUIRE(ksize == DWK, "sarssl_dwconv_wgrad(kernel size must be 31)");
+static inline int dwconv_wgrad_parts(int nb, int Tn) {
     const int ntile = nb * ((Tn + DWT - 1) / DWT);
-    dim3 grid((d + 255) / 256, ntile > 64 ? 64 : ntile);
-    DISPATCH_T(dtype, (dwconv_wgrad_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, (const T*)x, nb, Tn, d, dw)));
+    return ntile > 128 ? 128 : ntile;
+}
+extern "C" long sarssl_dwconv_wgrad_workspace_bytes(int nb, int Tn, int d) {
+    return (long)dwconv_wgrad_parts(nb, Tn) * d * DWK * sizeof(float);
+}
+// dw: f32 [d][31], accumulated (+=) from per-workgroup partials (workspace of sarssl_dwconv_wgrad_workspace_bytes)
+extern "C" int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn, int d, int ksize, float* dw, float* partial,
+                                   int dtype, void* stream) {
+    SARSSL_REQUIRE(ksize == DWK && partial, "sarssl_dwconv_wgrad(kernel size must be 31)");
+    const int parts = dwconv_wgrad_parts(nb, Tn);
+    dim3 grid((d + 63) / 64, parts);
+    DISPATCH_T(dtype, (dwconv_wgrad_kernel<T><<<grid, 64, 0, ST>>>((const T*)dy, (const T*)x, nb, Tn, d, partial)));
+    const long n = (long)d * DWK;
+    partial_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, ST>>>(partial, parts, n, dw);
     SARSSL_CHECK_LAUNCH("dwconv_wgrad_kernel");
     return 0;
 }

@@ -282,9 +282,14 @@ def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, 
     M, d = x2d.shape
     if out is None:
         out = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+    part = None
+    if dgamma is not None:
+        fn = _lib.lib().sarssl_layernorm_bwd_workspace_bytes
+        fn.restype = c_long
+        part = workspace(fn(c_long(M), c_int(d)), x2d.device, "ln_part")
     _lib.call("sarssl_layernorm_bwd", _p(dy2d), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
               _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out),
-              c_long(out.stride(0)), _p(dgamma), _p(dbeta), c_int(dt(x2d)), _stream())
+              c_long(out.stride(0)), _p(dgamma), _p(dbeta), _p(part), c_int(dt(x2d)), _stream())
     return out
 
 
@@ -312,7 +317,10 @@ def dwconv(x3d, w, flip=False):
 
 def dwconv_wgrad(dy3d, x3d, dw_out):
     B, T, d = x3d.shape
-    _lib.call("sarssl_dwconv_wgrad", _p(dy3d), _p(x3d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), _p(dw_out),
+    fn = _lib.lib().sarssl_dwconv_wgrad_workspace_bytes
+    fn.restype = c_long
+    part = workspace(fn(c_int(B), c_int(T), c_int(d)), x3d.device, "dw_part")
+    _lib.call("sarssl_dwconv_wgrad", _p(dy3d), _p(x3d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), _p(dw_out), _p(part),
               c_int(dt(x3d)), _stream())
 
 
