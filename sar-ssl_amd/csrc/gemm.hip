@@ -21,6 +21,7 @@
 // (weights as the "A"/row operand) so each lane ends up with 4 consecutive n for one m and the
 // epilogue stores 8/16-byte vectors.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -43,6 +44,7 @@ struct GemmArgs {
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
     float p_drop; unsigned long long seed;
+    int dbg;                    // experiments (SARSSL_GEMM_DBG): 1 = stage first K-tile only, 2 = no stores, 4 = no MFMA
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
 };
 
@@ -106,8 +108,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
 
 template <typename TA, typename TB, typename TC, bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) uint16_t sA[TILE_ELEMS];
-    __shared__ __attribute__((aligned(16))) uint16_t sB[TILE_ELEMS];
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TILE_ELEMS];      // 40 KiB: A/B tiles, then the C staging tile
+    uint16_t* sA = smem;
+    uint16_t* sB = smem + TILE_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nsplit = g.split_k > 0 ? g.split_k : 1;
@@ -128,9 +131,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        if (!(g.dbg & 1) || k0 == k_begin) {
         stage_tile<TA, AKC>(A, g.lda, m0, k0, g.M, k_end, sA, g.partA, tid);
         stage_tile<TB, BKC>(B, g.ldb, n0, k0, g.N, k_end, sB, g.partB, tid);
+        }
         __syncthreads();
+        if (!(g.dbg & 4))
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int koff = kk * 16 + (lane >> 5) * 8;
@@ -154,71 +160,103 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3] for m = base + (lane&31), n = base + 8g + 4(lane>>5)
+    if (g.dbg & 2) return;
+    // ---- epilogue.  The MFMA leaves each lane with 4 consecutive n for ONE row m (32 different rows per wave instruction):
+    // storing that directly is store-issue bound (every instruction touches 32 cache lines).  Instead the f32 accumulators are
+    // transposed through LDS, 64 rows at a time, so each thread owns 8 consecutive columns of one row: bias / activation /
+    // dropout / residual are applied on 8-wide vectors and every global access is a full 16/32-byte piece of a contiguous row.
     TC* C = (TC*)g.C + z0 * g.sC0 + z1 * g.sC1;
     const TC* Rz = g.resid ? (const TC*)g.resid + z0 * g.sR0 + z1 * g.sR1 : nullptr;
     TC* P = g.preact ? (TC*)g.preact + z0 * g.sC0 + z1 * g.sC1 : nullptr;
     float* W = g.acc_ws ? g.acc_ws + (long)z * g.M * g.N : nullptr;
-    const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (!g.resid || (g.ldr & 3) == 0);
+    float* Wp = (g.split_k > 0) ? g.acc_ws + ((long)z * nsplit + ks) * g.M * g.N : nullptr;
+    const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
     const float inv_keep = g.p_drop > 0.f ? 1.0f / (1.0f - g.p_drop) : 1.0f;
+    constexpr int PC = BN + 4;                                  // f32 staging pitch (conflict-free 16-byte LDS writes)
+    float* sC = (float*)smem;                                   // 64 x 132 x 4 B = 33 KiB <= 40 KiB
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-        if (m >= g.M) continue;
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * gq + 4 * (lane >> 5);
-                if (n >= g.N) continue;
-                float v[4];
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = g.alpha * acc[i][j][gq * 4 + e];
-                const int nvalid = min(4, g.N - n);
-                if (g.split_k > 0) {
-                    float* Wp = g.acc_ws + (((long)z * nsplit + ks) * g.M + m) * g.N + n;
-                    if ((g.N & 3) == 0) *(float4*)Wp = make_float4(v[0], v[1], v[2], v[3]);
-                    else for (int e = 0; e < nvalid; ++e) Wp[e] = v[e];
-                    continue;
-                }
-                if (g.acc_in) {
-                    for (int e = 0; e < nvalid; ++e) v[e] += W[(long)m * g.N + n + e];
-                }
-                if (g.acc_out) {
-                    for (int e = 0; e < nvalid; ++e) W[(long)m * g.N + n + e] = v[e];
-                    continue;
-                }
-                if (g.bias) {
-                    for (int e = 0; e < nvalid; ++e) v[e] += g.bias[n + e];
-                }
-                if (P) {
-                    if (vec_ok) st4(P + (long)m * g.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
-                    else for (int e = 0; e < nvalid; ++e) st_f(P + (long)m * g.ldc + n + e, v[e]);
-                }
-                if (g.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                } else if (g.act == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sigmoidf_(v[e]);
-                }
-                if (g.p_drop > 0.f) {
-                    const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= dropout_scale(g.seed, base + e, g.p_drop, inv_keep);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= g.out_scale;
-                if (Rz) {
-                    if (vec_ok) {
-                        float4 r = ld4(Rz + (long)m * g.ldr + n);
-                        v[0] += g.res_scale * r.x; v[1] += g.res_scale * r.y; v[2] += g.res_scale * r.z; v[3] += g.res_scale * r.w;
-                    } else for (int e = 0; e < nvalid; ++e) v[e] += g.res_scale * ld_f(Rz + (long)m * g.ldr + n + e);
-                }
-                if (vec_ok) st4(C + (long)m * g.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
-                else for (int e = 0; e < nvalid; ++e) st_f(C + (long)m * g.ldc + n + e, v[e]);
-            }
+                    for (int gq = 0; gq < 4; ++gq)
+                        *(float4*)&sC[(i * 32 + (lane & 31)) * PC + wn * 64 + j * 32 + 8 * gq + 4 * (lane >> 5)] =
+                            make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tid + k * 256;
+            const int r = c >> 4, ch = c & 15;
+            const int m = m0 + half * 64 + r, n = n0 + ch * 8;
+            if (m >= g.M || n >= g.N) continue;
+            const int nvalid = min(8, g.N - n);
+            f8 v;
+            {
+                const float4 a0 = *(const float4*)&sC[r * PC + ch * 8], a1 = *(const float4*)&sC[r * PC + ch * 8 + 4];
+                v.v[0] = g.alpha * a0.x; v.v[1] = g.alpha * a0.y; v.v[2] = g.alpha * a0.z; v.v[3] = g.alpha * a0.w;
+                v.v[4] = g.alpha * a1.x; v.v[5] = g.alpha * a1.y; v.v[6] = g.alpha * a1.z; v.v[7] = g.alpha * a1.w;
+            }
+            if (g.split_k > 0) {                                 // raw partial for the split-K second stage
+                float* q = Wp + (long)m * g.N + n;
+                if ((g.N & 3) == 0) { *(float4*)q = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); *(float4*)(q + 4) = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]); }
+                else {
+_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) q[e] = v.v[e]; }
+                continue;
+            }
+            if (g.acc_in) {
+                const float* q = W + (long)m * g.N + n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += q[e];
+            }
+            if (g.acc_out) {
+                float* q = W + (long)m * g.N + n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < nvalid) q[e] = v.v[e];
+                continue;
+            }
+            if (g.bias) {
+                if (nvalid == 8) {
+                    const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
+                    v.v[0] += b0.x; v.v[1] += b0.y; v.v[2] += b0.z; v.v[3] += b0.w; v.v[4] += b1.x; v.v[5] += b1.y; v.v[6] += b1.z; v.v[7] += b1.w;
+                } else {
+_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += g.bias[n + e]; }
+            }
+            if (P) {
+                if (vec_ok) st8(P + (long)m * g.ldc + n, v);
+                else {
+_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(P + (long)m * g.ldc + n + e, v.v[e]); }
+            }
+            if (g.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+            } else if (g.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * sigmoidf_(v.v[e]);
+            }
+            if (g.p_drop > 0.f) {
+                const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(g.seed, base + e, g.p_drop, inv_keep);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] *= g.out_scale;
+            if (Rz) {
+                if (vec_ok) {
+                    const f8 rr = ld8(Rz + (long)m * g.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] += g.res_scale * rr.v[e];
+                } else {
+_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += g.res_scale * ld_f(Rz + (long)m * g.ldr + n + e); }
+            }
+            if (vec_ok) st8(C + (long)m * g.ldc + n, v);
+            else {
+_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(C + (long)m * g.ldc + n + e, v.v[e]); }
+        }
+        __syncthreads();
     }
 }
 
@@ -267,6 +305,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.resid = resid; g.ldr = ldr; g.sR0 = sR0; g.sR1 = sR1; g.res_scale = res_scale;
     g.preact = preact; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
     g.p_drop = p_drop; g.seed = seed;
+    { const char* e = getenv("SARSSL_GEMM_DBG"); g.dbg = e ? atoi(e) : 0; }
     g.split_k = 0; g.k_per_split = K;
     if (split_k > 0) {
         // accumulate mode: C (f32) += alpha * A*B, no other epilogue; K split over split_k workgroups per tile, partials
