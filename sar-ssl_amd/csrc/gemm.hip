@@ -48,48 +48,31 @@ struct GemmArgs {
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
 };
 
+// Operand staging is split in two halves so the global loads of K-tile t+1 are in flight while tile t is on the matrix
+// cores: tile_load (global -> 4 x 16-byte registers, with the f32 -> bf16 hi/lo split if needed) and tile_store (-> LDS).
 template <typename T, bool KC>
-__device__ __forceinline__ void stage_tile(const T* __restrict__ src, long ld, int r0, int k0, int R, int K,
-                                           uint16_t* __restrict__ s, int part, int tid) {
-    if (KC) {
-        uint4 regs[4];
+__device__ __forceinline__ void tile_load(const T* __restrict__ src, long ld, int r0, int k0, int R, int K, int part, int tid,
+                                          uint4 (&regs)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int c = tid + i * 256;
-            int row = c >> 3, kc = c & 7;
-            int gr = r0 + row, gk = k0 + kc * 8;
-            if (gr < R && gk < K) {
-                const T* p = src + (long)gr * ld + gk;
-                if (sizeof(T) == 2) regs[i] = *(const uint4*)p;
-                else { f8 v = ld8(p); regs[i] = pack8_part(v, part); }
-            } else regs[i] = make_uint4(0, 0, 0, 0);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        int gr, gk;
+        if (KC) { gr = r0 + (c >> 3); gk = k0 + (c & 7) * 8; }          // [row][k]: 8 chunks of 8 k per row
+        else { gk = k0 + (c >> 4); gr = r0 + (c & 15) * 8; }            // [k][row]: 16 chunks of 8 rows per k
+        if (gr < R && gk < K) {
+            const T* p = KC ? src + (long)gr * ld + gk : src + (long)gk * ld + gr;
+            if (sizeof(T) == 2) regs[i] = *(const uint4*)p;
+            else { f8 v = ld8(p); regs[i] = pack8_part(v, part); }
+        } else regs[i] = make_uint4(0, 0, 0, 0);
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void tile_store(uint16_t* __restrict__ s, int tid, const uint4 (&regs)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int c = tid + i * 256;
-            int row = c >> 3, kc = c & 7;
-            *(uint4*)&s[row * PITCH + kc * 8] = regs[i];
-        }
-    } else {
-        // source is [K][R] (R contiguous): copy rows as they are -> LDS [k][r]; fragments use transpose reads
-        uint4 regs[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int c = tid + i * 256;
-            int krow = c >> 4, rc = c & 15;
-            int gk = k0 + krow, gr = r0 + rc * 8;
-            if (gk < K && gr < R) {
-                const T* p = src + (long)gk * ld + gr;
-                if (sizeof(T) == 2) regs[i] = *(const uint4*)p;
-                else { f8 v = ld8(p); regs[i] = pack8_part(v, part); }
-            } else regs[i] = make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int c = tid + i * 256;
-            int krow = c >> 4, rc = c & 15;
-            *(uint4*)&s[krow * PITCH_T + rc * 8] = regs[i];
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        if (KC) *(uint4*)&s[(c >> 3) * PITCH + (c & 7) * 8] = regs[i];
+        else *(uint4*)&s[(c >> 4) * PITCH_T + (c & 15) * 8] = regs[i];
     }
 }
 
@@ -106,7 +89,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
     return u.b;
 }
 
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC>
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, bool PF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TILE_ELEMS];      // 40 KiB: A/B tiles, then the C staging tile
     uint16_t* sA = smem;
@@ -130,12 +113,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // PF (long-K GEMMs): the next K-tile is prefetched into registers behind the MFMAs.  Short-K, wide-N GEMMs are
+    // epilogue/store dominated and prefer the extra occupancy of the 32-VGPR-lighter non-prefetching variant.
+    uint4 ra[4], rb[4];
+    if (PF) {
+        tile_load<TA, AKC>(A, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
+        tile_load<TB, BKC>(B, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
+    }
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         if (!(g.dbg & 1) || k0 == k_begin) {
-        stage_tile<TA, AKC>(A, g.lda, m0, k0, g.M, k_end, sA, g.partA, tid);
-        stage_tile<TB, BKC>(B, g.ldb, n0, k0, g.N, k_end, sB, g.partB, tid);
+            if (!PF) {
+                tile_load<TA, AKC>(A, g.lda, m0, k0, g.M, k_end, g.partA, tid, ra);
+                tile_load<TB, BKC>(B, g.ldb, n0, k0, g.N, k_end, g.partB, tid, rb);
+            }
+            tile_store<AKC>(sA, tid, ra);
+            tile_store<BKC>(sB, tid, rb);
         }
         __syncthreads();
+        if (PF && k0 + BK < k_end && !(g.dbg & 1)) {
+            tile_load<TA, AKC>(A, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
+            tile_load<TB, BKC>(B, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
+        }
         if (!(g.dbg & 4))
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -277,10 +275,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, i
 
 template <typename TA, typename TB, typename TC>
 static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
-    if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true><<<grid, 256, 0, st>>>(g);
-    else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false><<<grid, 256, 0, st>>>(g);
-    else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true><<<grid, 256, 0, st>>>(g);
-    else gemm_kernel<TA, TB, TC, false, false><<<grid, 256, 0, st>>>(g);
+    const bool pf = (g.split_k > 0 ? g.k_per_split : g.K) >= 1024;
+    if (pf) {
+        if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, true><<<grid, 256, 0, st>>>(g);
+        else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, true><<<grid, 256, 0, st>>>(g);
+        else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, true><<<grid, 256, 0, st>>>(g);
+        else gemm_kernel<TA, TB, TC, false, false, true><<<grid, 256, 0, st>>>(g);
+    } else {
+        if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, false><<<grid, 256, 0, st>>>(g);
+        else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, false><<<grid, 256, 0, st>>>(g);
+        else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, false><<<grid, 256, 0, st>>>(g);
+        else gemm_kernel<TA, TB, TC, false, false, false><<<grid, 256, 0, st>>>(g);
+    }
     SARSSL_CHECK_LAUNCH("sarssl_gemm");
     return 0;
 }
