@@ -32,8 +32,8 @@ int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nc
 int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC, int a_kc, int b_kc, int M, int N, int K,
                 long lda, long ldb, long ldc, int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0,
                 long sC1, float alpha, float out_scale, const float* bias, int act, const void* resid, long ldr, long sR0,
-                long sR1, float res_scale, void* preact, float p_drop, unsigned long long seed, int precise, float* ws,
-                int split_k, void* stream);
+                long sR1, float res_scale, void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
+                int precise, float* ws, int split_k, void* stream);
 
 /* ---- CNN stem, channels-last (B,F,T,C): code/model.py:50-64 (patch_embed), masking code/model.py:533-564 */
 int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn, int mode, void* spec,

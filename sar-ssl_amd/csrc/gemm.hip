@@ -41,6 +41,7 @@ struct GemmArgs {
     int act;                    // 0 none, 1 relu, 2 swish
     const void* resid; long ldr; long sR0, sR1; float res_scale;
     void* preact;               // optional (same dtype/ld as C): alpha*acc + bias before activation
+    const void* aux; int aux_act;   // optional (same dtype/ld as C): multiply by act'(aux) (1 relu, 2 swish) - fused activation backward
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
     float p_drop; unsigned long long seed;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     TC* C = (TC*)g.C + z0 * g.sC0 + z1 * g.sC1;
     const TC* Rz = g.resid ? (const TC*)g.resid + z0 * g.sR0 + z1 * g.sR1 : nullptr;
     TC* P = g.preact ? (TC*)g.preact + z0 * g.sC0 + z1 * g.sC1 : nullptr;
+    const TC* Xa = g.aux ? (const TC*)g.aux + z0 * g.sC0 + z1 * g.sC1 : nullptr;
     float* W = g.acc_ws ? g.acc_ws + (long)z * g.M * g.N : nullptr;
     float* Wp = (g.split_k > 0) ? g.acc_ws + ((long)z * nsplit + ks) * g.M * g.N : nullptr;
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
@@ -235,6 +237,19 @@ _Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(P + (long)m *
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * sigmoidf_(v.v[e]);
             }
+            if (Xa) {                                            // dX epilogue: times act'(saved pre-activation)
+                f8 h;
+                if (vec_ok) h = ld8(Xa + (long)m * g.ldc + n);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h.v[e] = (e < nvalid) ? ld_f(Xa + (long)m * g.ldc + n + e) : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (g.aux_act == 1) v.v[e] = h.v[e] > 0.f ? v.v[e] : 0.f;
+                    else { const float sg = sigmoidf_(h.v[e]); v.v[e] *= sg * (1.f + h.v[e] * (1.f - sg)); }
+                }
+            }
             if (g.p_drop > 0.f) {
                 const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
 #pragma unroll
@@ -299,7 +314,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
                            int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
                            float alpha, float out_scale, const float* bias, int act,
                            const void* resid, long ldr, long sR0, long sR1, float res_scale,
-                           void* preact, float p_drop, unsigned long long seed,
+                           void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
                            int precise, float* ws, int split_k, void* stream) {
     SARSSL_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0 && batch_inner > 0, "sarssl_gemm");
     SARSSL_REQUIRE(a_kc ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0), "sarssl_gemm(A alignment)");
@@ -309,14 +324,14 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.batch_inner = batch_inner; g.sA0 = sA0; g.sA1 = sA1; g.sB0 = sB0; g.sB1 = sB1; g.sC0 = sC0; g.sC1 = sC1;
     g.alpha = alpha; g.out_scale = out_scale; g.bias = bias; g.act = act;
     g.resid = resid; g.ldr = ldr; g.sR0 = sR0; g.sR1 = sR1; g.res_scale = res_scale;
-    g.preact = preact; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
+    g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
     g.p_drop = p_drop; g.seed = seed;
     { const char* e = getenv("SARSSL_GEMM_DBG"); g.dbg = e ? atoi(e) : 0; }
     g.split_k = 0; g.k_per_split = K;
     if (split_k > 0) {
         // accumulate mode: C (f32) += alpha * A*B, no other epilogue; K split over split_k workgroups per tile, partials
         // go to ws (f32, nbatch*split_k*M*N) and a second kernel folds them into C (deterministic, no atomics)
-        SARSSL_REQUIRE(dtC == SARSSL_F32 && !bias && !resid && !preact && act == 0 && p_drop == 0.f && ws != nullptr,
+        SARSSL_REQUIRE(dtC == SARSSL_F32 && !bias && !resid && !preact && !aux && act == 0 && p_drop == 0.f && ws != nullptr,
                        "sarssl_gemm(split_k epilogue)");
         g.acc_ws = ws;
         int per = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;

@@ -36,8 +36,8 @@ def mm_tn_acc(dy, x, gW):
     K = x.shape[1]
     g2 = gW.view(N, K)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    split = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles))       # ~3 workgroups per CU, >= 4 K-tiles each
-    split = max(1, min(split, (1 << 26) // (N * K)))                         # partial-sum workspace <= 256 MB
+    split = max(1, min((M + 511) // 512, (512 + tiles - 1) // tiles))       # ~2 workgroups per CU, >= 8 K-tiles each
+    split = max(1, min(split, (1 << 23) // (N * K)))                         # partial-sum workspace <= 32 MB (reduce pass cost)
     hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), out=g2, ldc=K,
              precise=RT.precise, split_k=split)
 
@@ -169,8 +169,8 @@ def ffn_bwd(dy, ff, saved):
     dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
     mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
     hip.colsum(dz2, gbuf(seq[4].linear.bias))
-    da = mm_nn(dz2, wt(seq[4].linear.weight))
-    dh = hip.act_bwd(da, hpre, SWISH, p_drop=p1, seed=s1, out=da)
+    # dh = (dz2 @ W2) * dropout_mask1 * swish'(hpre): activation backward fused into the GEMM epilogue
+    dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
     mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight))
     hip.colsum(dh, gbuf(seq[1].linear.bias))
     dln = mm_nn(dh, wt(seq[1].linear.weight))
@@ -362,8 +362,7 @@ def decoder_bwd(dpred, dec, saved):
     l1, l2 = dec.proj[0], dec.proj[2]
     mm_tn_acc(dpred, h, gbuf(l2.weight))
     hip.colsum(dpred, gbuf(l2.bias))
-    dh = mm_nn(dpred, wt(l2.weight))
-    dh = hip.act_bwd(dh, h, RELU, out=dh)
+    dh = mm_nn(dpred, wt(l2.weight), aux=h, aux_act=RELU)
     mm_tn_acc(dh, e, gbuf(l1.weight))
     hip.colsum(dh, gbuf(l1.bias))
     return mm_nn(dh, wt(l1.weight))

@@ -79,10 +79,10 @@ def workspace(nbytes, device, tag="default"):
 
 def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=None, ldc=None,
          nbatch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, out_scale=1.0, bias=None, act=0,
-         resid=None, ldr=0, sR=(0, 0), res_scale=1.0, preact=None, p_drop=0.0, seed=0, precise=False, out_shape=None,
-         split_k=0):
+         resid=None, ldr=0, sR=(0, 0), res_scale=1.0, preact=None, aux=None, aux_act=0, p_drop=0.0, seed=0, precise=False,
+         out_shape=None, split_k=0):
     """C[z] = epilogue(alpha * opA(A[z]) @ opB(B[z])^T) - see csrc/gemm.hip for the layout flags."""
-    _need_cuda(A, B, out, bias, resid, preact)
+    _need_cuda(A, B, out, bias, resid, preact, aux)
     if out is None:
         out = torch.empty(out_shape if out_shape is not None else (nbatch, M, N) if nbatch > 1 else (M, N),
                           dtype=out_dtype or A.dtype, device=A.device)
@@ -101,7 +101,7 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
               c_long(sA[0]), c_long(sA[1]), c_long(sB[0]), c_long(sB[1]), c_long(sC[0]), c_long(sC[1]),
               c_float(alpha), c_float(out_scale), _p(bias), c_int(act),
               _p(resid), c_long(ldr), c_long(sR[0]), c_long(sR[1]), c_float(res_scale),
-              _p(preact), c_float(p_drop), c_ulonglong(seed), c_int(1 if (precise and A.dtype == torch.float32) else 0),
+              _p(preact), _p(aux), c_int(aux_act), c_float(p_drop), c_ulonglong(seed), c_int(1 if (precise and A.dtype == torch.float32) else 0),
               _p(ws), c_int(split_k), _stream())
     return out
 
