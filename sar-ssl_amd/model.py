@@ -151,9 +151,22 @@ class _PretrainFn(torch.autograd.Function):
             # memory can be recycled by main-stream allocations while side-stream kernels that read them are still queued
             spat_in.record_stream(side)
             ecat.record_stream(side)
+            # the host enqueues the two encoders in alternating chunks so that neither HIP queue sits empty while the other
+            # one is being filled (enqueueing ~300 launches takes the host a few ms)
+            train = net.training
+            spe, spa = net.spec_encoder, net.spat_encoder
             with torch.cuda.stream(side):
-                net.spat_encoder._fwd_cl(spat_in, B, T, saved_spat, out=ecat[:, ds:])
-            net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
+                e_spat = engine.stem_fwd(spat_in, spa.patch_embed, train, saved_spat)
+            e_spec = engine.stem_fwd(spec_in, spe.patch_embed, train, saved)
+            nl = len(spa.embed.layers)
+            with torch.cuda.stream(side):
+                e_spat = engine.block_fwd(e_spat, spa.embed.layers[0], B, T, train, saved_spat, out=ecat[:, ds:] if nl == 1 else None)
+            assert len(spe.embed.layers) == 1
+            engine.block_fwd(e_spec, spe.embed.layers[0], B, T, train, saved, out=ecat[:, :ds])
+            with torch.cuda.stream(side):
+                for li in range(1, nl):
+                    e_spat = engine.block_fwd(e_spat, spa.embed.layers[li], B, T, train, saved_spat,
+                                              out=ecat[:, ds:] if li == nl - 1 else None)
             main.wait_stream(side)
         else:
             net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
@@ -180,10 +193,19 @@ class _PretrainFn(torch.autograd.Function):
         if side is not None:
             side.wait_stream(main)
             decat.record_stream(side)
+            spe, spa = net.spec_encoder, net.spat_encoder
+            nl = len(spa.embed.layers)
+            with torch.cuda.stream(side):                       # alternating enqueue order, see forward
+                d_spat = decat[:, ds:]
+                for li in range(nl - 1, 0, -1):
+                    d_spat = engine.block_bwd(d_spat, spa.embed.layers[li], saved_spat)
+            d_spec = engine.block_bwd(decat[:, :ds], spe.embed.layers[0], saved)
             with torch.cuda.stream(side):
-                net.spat_encoder._bwd_cl(decat[:, ds:], saved_spat)
+                d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat)
+            engine.stem_bwd(d_spec, spe.patch_embed, saved)
+            with torch.cuda.stream(side):
+                engine.stem_bwd(d_spat, spa.patch_embed, saved_spat)
                 net._after_backward_stage("spat_encoder")      # its gradient bucket is reduced behind the side stream
-            net.spec_encoder._bwd_cl(decat[:, :ds], saved)
             main.wait_stream(side)
             net._after_backward_stage("spec_encoder")
         else:
