@@ -91,6 +91,8 @@ int sarssl_relshift_bwd(const void* dscore, long nmat, int Tn, void* dpos, int d
 int sarssl_bias2(const void* q, long ldq, long M, int d, const float* u, const float* v, void* qu, void* qv, int dtype,
                  void* stream);
 int sarssl_axpby(const void* x, const void* y, float a, float b, long n, void* out, int dtype, void* stream);
+int sarssl_axpby2d(const void* x, long ldx, const void* y, long ldy, float a, float b, long M, int N, void* out, long ldo,
+                   int dtype, void* stream);
 int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream);
 int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,
                    void* dh, int dtype, void* stream);

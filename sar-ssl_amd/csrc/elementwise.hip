@@ -362,6 +362,17 @@ __global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, f
         st4(out + i * 4, o);
     }
 }
+// out[m][n] = a*x[m][n] + b*y[m][n] on row-strided [M][N] views
+template <typename T>
+__global__ void axpby2d_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ y, long ldy, float a, float b, long M, int N,
+                               T* __restrict__ out, long ldo) {
+    const long total4 = M * (N >> 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / (N >> 2); const int c = (int)(i % (N >> 2)) * 4;
+        const float4 xv = ld4(x + row * ldx + c), yv = ld4(y + row * ldy + c);
+        st4(out + row * ldo + c, make_float4(a * xv.x + b * yv.x, a * xv.y + b * yv.y, a * xv.z + b * yv.z, a * xv.w + b * yv.w));
+    }
+}
 // out[n] += sum_m x[m][n]    (column tiles of 64, f32 atomics: bias / u,v-bias gradients)
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ x, long ldx, long M, int N, float* __restrict__ out) {
@@ -592,6 +603,13 @@ extern "C" int sarssl_axpby(const void* x, const void* y, float a, float b, long
     SARSSL_REQUIRE((n & 3) == 0, "sarssl_axpby(n % 4)");
     DISPATCH_T(dtype, (axpby_kernel<T><<<nblocks_for(n >> 2, 256), 256, 0, ST>>>((const T*)x, (const T*)y, a, b, n >> 2, (T*)out)));
     SARSSL_CHECK_LAUNCH("axpby_kernel");
+    return 0;
+}
+extern "C" int sarssl_axpby2d(const void* x, long ldx, const void* y, long ldy, float a, float b, long M, int N, void* out, long ldo,
+                              int dtype, void* stream) {
+    SARSSL_REQUIRE((N & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldo & 3) == 0, "sarssl_axpby2d");
+    DISPATCH_T(dtype, (axpby2d_kernel<T><<<nblocks_for(M * (N >> 2), 256), 256, 0, ST>>>((const T*)x, ldx, (const T*)y, ldy, a, b, M, N, (T*)out, ldo)));
+    SARSSL_CHECK_LAUNCH("axpby2d_kernel");
     return 0;
 }
 extern "C" int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream) {

@@ -186,6 +186,28 @@ def _pe(mod, T):
     return c[key]
 
 
+def _adjacent(ts):
+    """Back-to-back views of ONE storage (as laid out by runtime.FlatParams)."""
+    base = ts[0].untyped_storage().data_ptr()
+    return all(t.untyped_storage().data_ptr() == base for t in ts) and \
+        all(ts[i + 1].data_ptr() == ts[i].data_ptr() + ts[i].numel() * ts[i].element_size() for i in range(len(ts) - 1))
+
+
+def _qkv_views(att):
+    """([3d,d] weight view, [3d] bias view, their gradient views) when q/k/v parameters are contiguous in memory
+    (runtime.FlatParams lays them out that way), else None."""
+    projs = (att.query_proj.linear, att.key_proj.linear, att.value_proj.linear)
+    ws = [wt(l.weight) for l in projs]
+    bs = [l.bias.data for l in projs]
+    gw = [gbuf(l.weight) for l in projs]
+    gb = [gbuf(l.bias) for l in projs]
+    if not (_adjacent(ws) and _adjacent(bs) and _adjacent(gw) and _adjacent(gb)):
+        return None
+    d = att.d_model
+    return (torch.as_strided(ws[0], (3 * d, d), (d, 1)), torch.as_strided(bs[0], (3 * d,), (1,)),
+            torch.as_strided(gw[0], (3 * d, d), (d, 1)), torch.as_strided(gb[0], (3 * d,), (1,)))
+
+
 def mhsa_fwd(x, mod, B, T, train, saved):
     """x + MultiHeadedSelfAttentionModule(x)  (conformer/attention.py:143-151, 72-113).
 
@@ -195,14 +217,20 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     H, dh, d = att.num_heads, att.d_head, att.d_model
     M = B * T
     ln, stats = hip.layernorm_fwd(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps)
-    q = mm_nt(ln, wt(att.query_proj.linear.weight), bias=att.query_proj.linear.bias.data)
-    k = mm_nt(ln, wt(att.key_proj.linear.weight), bias=att.key_proj.linear.bias.data)
-    v = mm_nt(ln, wt(att.value_proj.linear.weight), bias=att.value_proj.linear.bias.data)
+    fused = _qkv_views(att)
+    if fused is not None:                       # one [M, 3d] GEMM; q / k / v are column slices (row stride 3d)
+        qkv = mm_nt(ln, fused[0], bias=fused[1])
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    else:
+        q = mm_nt(ln, wt(att.query_proj.linear.weight), bias=att.query_proj.linear.bias.data)
+        k = mm_nt(ln, wt(att.key_proj.linear.weight), bias=att.key_proj.linear.bias.data)
+        v = mm_nt(ln, wt(att.value_proj.linear.weight), bias=att.value_proj.linear.bias.data)
+    ldk = k.stride(0)
     pe = _pe(mod, T)
     pos = mm_nt(pe, wt(att.pos_proj.linear.weight))                                          # [T, d]
     qu, qv = hip.bias2(q, att.u_bias.data.view(-1), att.v_bias.data.view(-1))
     nbh = B * H
-    content = hip.gemm(qu, k, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * d, dh),
+    content = hip.gemm(qu, k, M=T, N=T, K=dh, lda=d, ldb=ldk, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * ldk, dh),
                        out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
     pscore = hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh),
                       out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
@@ -212,8 +240,8 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, pa, sa)
     del content, pscore
     ctx = torch.empty((M, d), dtype=RT.dtype, device=x.device)
-    hip.gemm(pd, v, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
-             sA=(H * T * T, T * T), sB=(T * d, dh), out=ctx, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    hip.gemm(pd, v, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=ldk, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * ldk, dh), out=ctx, ldc=d, sC=(T * d, dh), precise=RT.precise)
     po = _p(mod.dropout, train)
     so = RT.next_seed() if po > 0 else 0
     y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,
@@ -232,22 +260,29 @@ def mhsa_bwd(dy, mod, saved):
     mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight))
     hip.colsum(dout, gbuf(att.out_proj.linear.bias))
     dctx = mm_nn(dout, wt(att.out_proj.linear.weight))
+    fused = _qkv_views(att)
+    ldk = k.stride(0)
+    if fused is not None:                       # dq | dk | dv are written straight into one [M, 3d] buffer
+        dqkv = torch.empty((M, 3 * d), dtype=RT.dtype, device=dev)
+        dqu, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+    else:
+        dqu = torch.empty((M, d), dtype=RT.dtype, device=dev)
+        dk = torch.empty((M, d), dtype=RT.dtype, device=dev)
+        dv = torch.empty((M, d), dtype=RT.dtype, device=dev)
+    ldg = dqu.stride(0)
     # dP = dctx @ v^T ; dv = P^T @ dctx
-    dpd = hip.gemm(dctx, v, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * d, dh),
+    dpd = hip.gemm(dctx, v, M=T, N=T, K=dh, lda=d, ldb=ldk, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * ldk, dh),
                    out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
-    dv = torch.empty((M, d), dtype=RT.dtype, device=dev)
     hip.gemm(pd, dctx, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
-             sA=(H * T * T, T * T), sB=(T * d, dh), out=dv, ldc=d, sC=(T * d, dh), precise=RT.precise)
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dv, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
     scale = 1.0 / math.sqrt(d)
     ds = hip.softmax_bwd(dpd, p, scale, pa, sa)                                              # d content score
     del dpd
     dps = hip.relshift_bwd(ds)                                                               # d (unshifted) pos score
-    dqu = torch.empty((M, d), dtype=RT.dtype, device=dev)
-    hip.gemm(ds, k, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
-             sA=(H * T * T, T * T), sB=(T * d, dh), out=dqu, ldc=d, sC=(T * d, dh), precise=RT.precise)
-    dk = torch.empty((M, d), dtype=RT.dtype, device=dev)
+    hip.gemm(ds, k, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=ldk, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * ldk, dh), out=dqu, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
     hip.gemm(ds, qu, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
-             sA=(H * T * T, T * T), sB=(T * d, dh), out=dk, ldc=d, sC=(T * d, dh), precise=RT.precise)
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dk, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
     dqv = torch.empty((M, d), dtype=RT.dtype, device=dev)
     hip.gemm(dps, pos, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(0, dh), out=dqv, ldc=d, sC=(T * d, dh), precise=RT.precise)
@@ -261,13 +296,18 @@ def mhsa_bwd(dy, mod, saved):
     mm_tn_acc(dpos_rt, pe, gbuf(att.pos_proj.linear.weight))
     hip.colsum(dqu, gbuf(att.u_bias).view(-1))
     hip.colsum(dqv, gbuf(att.v_bias).view(-1))
-    dq = hip.axpby(dqu, dqv, 1.0, 1.0, out=dqu)
-    for proj, g in ((att.query_proj, dq), (att.key_proj, dk), (att.value_proj, dv)):
-        mm_tn_acc(g, ln, gbuf(proj.linear.weight))
-        hip.colsum(g, gbuf(proj.linear.bias))
-    dln = mm_nn(dq, wt(att.query_proj.linear.weight))
-    dln = mm_nn(dk, wt(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
-    dln = mm_nn(dv, wt(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
+    dq = hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dqu)
+    if fused is not None:
+        mm_tn_acc(dqkv, ln, fused[2])
+        hip.colsum(dqkv, fused[3])
+        dln = mm_nn(dqkv, fused[0])
+    else:
+        for proj, g in ((att.query_proj, dq), (att.key_proj, dk), (att.value_proj, dv)):
+            mm_tn_acc(g, ln, gbuf(proj.linear.weight))
+            hip.colsum(g, gbuf(proj.linear.bias))
+        dln = mm_nn(dq, wt(att.query_proj.linear.weight))
+        dln = mm_nn(dk, wt(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
+        dln = mm_nn(dv, wt(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
     return hip.layernorm_bwd(dln, x, mod.layer_norm.weight.data, stats, resid=dy, dgamma=gbuf(mod.layer_norm.weight),
                              dbeta=gbuf(mod.layer_norm.bias))
 

@@ -365,6 +365,16 @@ def axpby(x, y, a=1.0, b=1.0, out=None):
     return out
 
 
+def axpby2d(x2d, y2d, a=1.0, b=1.0, out=None):
+    """out = a*x + b*y on row-strided [M, N] views (out may alias x)."""
+    M, N = x2d.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    _lib.call("sarssl_axpby2d", _p(x2d), c_long(x2d.stride(0)), _p(y2d), c_long(y2d.stride(0)), c_float(a), c_float(b), c_long(M),
+              c_int(N), _p(out), c_long(out.stride(0)), c_int(dt(x2d)), _stream())
+    return out
+
+
 def colsum(x2d, out_f32):
     """out_f32[n] += sum_m x2d[m][n]."""
     M, N = x2d.shape

@@ -79,6 +79,27 @@ def gbuf(p):
     return p.grad
 
 
+def _group_qkv(module, params):
+    """Order parameters so that every attention module's query/key/value weights (and biases) sit back to back in the flat
+    buffers: the three projections then run as ONE [3d, d] GEMM (forward, dX and dW), see engine._qkv_views."""
+    groups = {}
+    for m in module.modules():
+        if all(hasattr(m, n) for n in ("query_proj", "key_proj", "value_proj")):
+            ps = [m.query_proj.linear.weight, m.key_proj.linear.weight, m.value_proj.linear.weight,
+                  m.query_proj.linear.bias, m.key_proj.linear.bias, m.value_proj.linear.bias]
+            if all(p is not None for p in ps):
+                groups[id(ps[0])] = ps
+    member = {id(p) for g in groups.values() for p in g}
+    out = []
+    for p in params:
+        if id(p) in groups:
+            out.extend(groups[id(p)])
+        elif id(p) not in member:
+            out.append(p)
+    assert len(out) == len(params)
+    return out
+
+
 class FlatParams:
     def __init__(self, module):
         params, seen = [], set()
@@ -87,6 +108,7 @@ class FlatParams:
                 seen.add(id(p))
                 params.append(p)
         assert params, "module has no parameters"
+        params = _group_qkv(module, params)
         self.on_gpu = all(p.is_cuda for p in params)       # CPU flattening is allowed for host-logic tests only (no kernels)
         self.params = params
         dev = params[0].device
