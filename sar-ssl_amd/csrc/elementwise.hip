@@ -61,52 +61,82 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ resid);  dgamma += sum dy*xhat, dbeta += sum dy
-template <typename T>
+// Two rows per wave are in flight at a time (loads of both issued before either reduction) to hide HBM latency.
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
                                                             long M, int d, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const T* __restrict__ resid, long ldr, T* __restrict__ dx, long lddx,
                                                             float* __restrict__ partial /* [gridDim.x][2][d] or null */) {
-    __shared__ float4 sg[4][64 * LN_MAXV];
-    __shared__ float4 sb[4][64 * LN_MAXV];
+    __shared__ float4 sg[4][64 * NV];
+    __shared__ float4 sb[4][64 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
-    float4 ag[LN_MAXV], ab[LN_MAXV];
+    constexpr int R = 2;
+    float4 ag[NV], ab[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
-    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float4 g[LN_MAXV], xh[LN_MAXV];
-        float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+        const int c4 = lane + i * 64;
+        gm[i] = (c4 < nv) ? *(const float4*)(gamma + c4 * 4) : make_float4(0, 0, 0, 0);
+    }
+    const long rstride = (long)gridDim.x * 4;
+    for (long row0 = (long)blockIdx.x * 4 + wave; row0 < M; row0 += rstride * R) {
+        float4 dyv[R][NV], xv[R][NV], rv[R][NV];
+        float mu[R], rs[R];
+        bool ok[R];
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c4 = lane + i * 64;
-            if (c4 < nv) {
-                const float4 dyv = ld4(dy + row * lddy + c4 * 4), xv = ld4(x + row * ldx + c4 * 4);
-                const float4 gm = *(const float4*)(gamma + c4 * 4);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                g[i] = make_float4(dyv.x * gm.x, dyv.y * gm.y, dyv.z * gm.z, dyv.w * gm.w);
-                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
-                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
-                ag[i].x += dyv.x * xh[i].x; ag[i].y += dyv.y * xh[i].y; ag[i].z += dyv.z * xh[i].z; ag[i].w += dyv.w * xh[i].w;
-                ab[i].x += dyv.x; ab[i].y += dyv.y; ab[i].z += dyv.z; ab[i].w += dyv.w;
+        for (int u = 0; u < R; ++u) {
+            const long row = row0 + u * rstride;
+            ok[u] = row < M;
+            if (ok[u]) {
+                mu[u] = mean[row]; rs[u] = rstd[row];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c4 = lane + i * 64;
+                    if (c4 < nv) {
+                        dyv[u][i] = ld4(dy + row * lddy + c4 * 4);
+                        xv[u][i] = ld4(x + row * ldx + c4 * 4);
+                        if (resid) rv[u][i] = ld4(resid + row * ldr + c4 * 4);
+                    }
+                }
             }
         }
-        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
-            const int c4 = lane + i * 64;
-            if (c4 < nv) {
-                float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
-                                       rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
-                if (resid) { const float4 r = ld4(resid + row * ldr + c4 * 4); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-                st4(dx + row * lddx + c4 * 4, o);
+        for (int u = 0; u < R; ++u) {
+            if (!ok[u]) continue;
+            const long row = row0 + u * rstride;
+            float4 g[NV], xh[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c4 = lane + i * 64;
+                if (c4 < nv) {
+                    const float4 a = dyv[u][i], xx = xv[u][i];
+                    xh[i] = make_float4((xx.x - mu[u]) * rs[u], (xx.y - mu[u]) * rs[u], (xx.z - mu[u]) * rs[u], (xx.w - mu[u]) * rs[u]);
+                    g[i] = make_float4(a.x * gm[i].x, a.y * gm[i].y, a.z * gm[i].z, a.w * gm[i].w);
+                    s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                    s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+                    ag[i].x += a.x * xh[i].x; ag[i].y += a.y * xh[i].y; ag[i].z += a.z * xh[i].z; ag[i].w += a.w * xh[i].w;
+                    ab[i].x += a.x; ab[i].y += a.y; ab[i].z += a.z; ab[i].w += a.w;
+                }
+            }
+            s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c4 = lane + i * 64;
+                if (c4 < nv) {
+                    float4 o = make_float4(rs[u] * (g[i].x - s1 - xh[i].x * s2), rs[u] * (g[i].y - s1 - xh[i].y * s2),
+                                           rs[u] * (g[i].z - s1 - xh[i].z * s2), rs[u] * (g[i].w - s1 - xh[i].w * s2));
+                    if (resid) { o.x += rv[u][i].x; o.y += rv[u][i].y; o.z += rv[u][i].z; o.w += rv[u][i].w; }
+                    st4(dx + row * lddx + c4 * 4, o);
+                }
             }
         }
     }
     if (partial) {
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) { sg[wave][lane + i * 64] = ag[i]; sb[wave][lane + i * 64] = ab[i]; }
+        for (int i = 0; i < NV; ++i) { sg[wave][lane + i * 64] = ag[i]; sb[wave][lane + i * 64] = ab[i]; }
         __syncthreads();
         float* P = partial + (long)blockIdx.x * 2 * d;
         for (int c4 = threadIdx.x; c4 < nv; c4 += 256) {
@@ -520,8 +550,10 @@ extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, lo
     SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (!dgamma || partial), "sarssl_layernorm_bwd");
     const int nblk = ln_bwd_blocks(M);
     float* part = dgamma ? partial : nullptr;
-    DISPATCH_T(dtype, (layernorm_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd,
-                                                                    (const T*)resid, ldr, (T*)dx, lddx, part)));
+#define LN_BWD_LAUNCH(NVv) layernorm_bwd_kernel<T, NVv><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd, \
+                                                                           (const T*)resid, ldr, (T*)dx, lddx, part)
+    DISPATCH_T(dtype, (d <= 256 ? LN_BWD_LAUNCH(1) : (d <= 512 ? LN_BWD_LAUNCH(2) : LN_BWD_LAUNCH(4))));
+#undef LN_BWD_LAUNCH
     if (dgamma) {       // partial is [nblk][2][d]: viewed as nblk rows of 2d, column halves go to dgamma / dbeta
         partial_reduce_strided_kernel<<<(d + 63) / 64, 256, 0, ST>>>(part, nblk, 2L * d, d, dgamma);
         partial_reduce_strided_kernel<<<(d + 63) / 64, 256, 0, ST>>>(part + d, nblk, 2L * d, d, dbeta);
