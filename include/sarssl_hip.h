@@ -38,10 +38,10 @@ int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC
 /* ---- CNN stem, channels-last (B,F,T,C): code/model.py:50-64 (patch_embed), masking code/model.py:533-564 */
 int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn, int mode, void* spec,
                        void* spat, int dtype, void* stream);
-int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, int dtype, void* stream);
+int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, double* stats, int dtype, void* stream);
 int sarssl_stem_c1_wgrad(const void* dy1, const void* a0, long npix, double* dW1d, int dtype, void* stream);
 int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
-                       const float* scale, const float* shift, int precise, float* ws, void* stream);
+                       const float* scale, const float* shift, int precise, float* ws, double* stats, void* stream);
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
                          const float* shift, float* dW, float* partial, int precise, void* stream);

@@ -37,6 +37,7 @@ struct ConvArgs {
     const float* scale; const float* shift; int prologue;
     int nb, F, T;
     int part_in, part_w;
+    double* stats;      // optional f64[128]: per-channel sum / sum of squares of the (bf16-rounded) output, for the next BatchNorm
 };
 
 __device__ __forceinline__ int swz(int p, int chunk) { return (p * 8 + (chunk ^ ((p >> 1) & 7))) * 8; }
@@ -106,11 +107,13 @@ template <typename T, typename TW>
 __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sX[X_ELEMS];
+    __shared__ float sStats[128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = a.F, Tn = a.T;
     const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + TCOL - 1) / TCOL;
     const int ntiles = a.nb * tiles_f * tiles_t;
     const T* in = (const T*)a.in;
+    if (tid < 128) sStats[tid] = 0.f;
     const int cch = tid & 7;                        // this thread's 8-channel chunk (fixed: 512 % 8 == 0)
 
     // weights -> LDS once ([tap][co][ci], ci contiguous)
@@ -227,13 +230,38 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
                     }
                 }
             __syncthreads();
+            float ssum[8], ssq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
             if (f < F) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int px = (lane >> 3) + 8 * k;
                     const int t = tc.t0 + px;
                     const uint4 o = *(const uint4*)&stg[px * 64 + (((lane & 7) ^ (px & 7)) << 3)];
-                    if (t < Tn) *(uint4*)((uint16_t*)a.out + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8) = o;
+                    if (t < Tn) {
+                        *(uint4*)((uint16_t*)a.out + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8) = o;
+                        if (a.stats) {          // BatchNorm statistics of exactly what was stored (8 channels of this lane's chunk)
+                            const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                                ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
+                            }
+                        }
+                    }
+                }
+            }
+            if (a.stats) {
+                // lanes that share a channel chunk are 8 apart: butterfly over lane bits 3..5, then one LDS atomic per channel
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
+                    ssq[e] += __shfl_xor(ssq[e], 8, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+                }
+                if (lane < 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], ssq[e]); }
                 }
             }
         } else if (f < F) {
@@ -261,6 +289,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
         }
         __syncthreads();
     }
+    if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
 }
 
 // ------------------------------------------------------------------------------------ wgrad
@@ -403,9 +432,12 @@ static int conv_grid(int nb, int F, int T) {
 // dtype w_dtype.  scale/shift: f32[64] prologue affine (+ReLU) or null for identity.
 // precise (f32 only): 3-pass split with ws = f32 (B,F,T,64).
 extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
-                                  const float* scale, const float* shift, int precise, float* ws, void* stream) {
+                                  const float* scale, const float* shift, int precise, float* ws, double* stats, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_fwd");
+    SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16, "sarssl_conv3x3_fwd(fused statistics: bf16 storage only)");
+    if (stats && hipMemsetAsync(stats, 0, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a;
+    a.stats = stats;
     a.in = in; a.w = w; a.out = out; a.acc_ws = nullptr; a.acc_in = 0; a.acc_out = 0;
     a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
     a.nb = nb; a.F = F; a.T = T; a.part_in = 0; a.part_w = 0;

@@ -37,14 +37,20 @@ __global__ void mask_inputs_kernel(const float* __restrict__ x, const uint8_t* _
 
 // ------------------------------------------------------------------------------------------------
 // y1[p][co] = sum_c W1[co][c] a0[p][c]     a0: (N,4), y1: (N,64).  Thread = (pixel, 8-channel group).
+// stats (optional f64[128]): per-channel sum / sum of squares of the stored y1 for the following BatchNorm.
 template <typename T>
-__global__ void stem_c1_fwd_kernel(const T* __restrict__ a0, const float* __restrict__ W1, long npix, T* __restrict__ y1) {
+__global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ a0, const float* __restrict__ W1, long npix,
+                                                          T* __restrict__ y1, double* __restrict__ stats) {
+    __shared__ float sred[4][8][16];
     const int cg = threadIdx.x & 7;
     float w[8][4];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[e][c] = W1[(cg * 8 + e) * 4 + c];
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const long nthreads = (long)gridDim.x * blockDim.x;
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
         const long p = g >> 3;
@@ -53,6 +59,31 @@ __global__ void stem_c1_fwd_kernel(const T* __restrict__ a0, const float* __rest
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.v[e] = w[e][0] * a.x + w[e][1] * a.y + w[e][2] * a.z + w[e][3] * a.w;
         st8(y1 + p * 64 + cg * 8, o);
+        if (stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float r = (sizeof(T) == 2) ? bf16_bits_to_f32(f32_to_bf16_bits(o.v[e])) : o.v[e];   // what was stored
+                acc[e] += r; acc[8 + e] += r * r;
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[i] += __shfl_xor(acc[i], 8, 64); acc[i] += __shfl_xor(acc[i], 16, 64); acc[i] += __shfl_xor(acc[i], 32, 64);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane < 8) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sred[wave][lane][i] = acc[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+            const int g8 = c >> 3, e = c & 7;
+            const float t = sred[0][g8][which * 8 + e] + sred[1][g8][which * 8 + e] + sred[2][g8][which * 8 + e] + sred[3][g8][which * 8 + e];
+            atomicAdd(&stats[threadIdx.x], (double)t);
+        }
     }
 }
 
@@ -399,9 +430,10 @@ extern "C" int sarssl_mask_inputs(const float* x, const unsigned char* mp, const
     return 0;
 }
 
-extern "C" int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, int dtype, void* stream) {
-    const int nblk = nblocks_for(npix * 8, 256, 4096);
-    DISPATCH_T(dtype, (stem_c1_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)a0, W1, npix, (T*)y1)));
+extern "C" int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, double* stats, int dtype, void* stream) {
+    if (stats && hipMemsetAsync(stats, 0, 128 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for(npix * 8, 256, stats ? 1024 : 4096);
+    DISPATCH_T(dtype, (stem_c1_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)a0, W1, npix, (T*)y1, stats)));
     SARSSL_CHECK_LAUNCH("stem_c1_fwd_kernel");
     return 0;
 }

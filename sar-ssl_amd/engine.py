@@ -58,12 +58,13 @@ def _cached(module, name, builder):
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm plumbing
-def bn_affine(x, C, bn, train):
+def bn_affine(x, C, bn, train, sums=None):
     """BatchNorm{1,2}d affine for channels-last x: batch statistics (+ running-stat update) in train mode, running
-    statistics in eval mode.  Returns aff = [scale, shift, mean, rstd] (4, C) f32."""
+    statistics in eval mode.  Returns aff = [scale, shift, mean, rstd] (4, C) f32.  ``sums``: statistics already
+    accumulated by the producing kernel's epilogue (saves one pass over x)."""
     if train:
         return hip.bn_train_affine(x, C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
-                                   bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum)
+                                   bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum, sums=sums)
     return hip.bn_eval_affine(C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, eps=bn.eps)
 
 
@@ -95,12 +96,15 @@ def _patch_w(conv, F):
 def stem_fwd(a0, pe, train, saved):
     """``patch_embed`` (code/model.py:50-64) on channels-last a0 (B,F,T,4) -> [B*T, d]."""
     B, F, T, _ = a0.shape
-    y1 = hip.stem_c1_fwd(a0, pe[0].weight.data.view(64, 4))
-    aff1 = bn_affine(y1, 64, pe[1], train)
-    y2 = hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], precise=RT.precise)
-    aff2 = bn_affine(y2, 64, pe[4], train)
-    y3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise)
-    aff3 = bn_affine(y3, 64, pe[7], train)
+    fuse = train and RT.dtype == torch.bfloat16          # BatchNorm sums come out of the producing kernel's epilogue
+    y1, s1 = hip.stem_c1_fwd(a0, pe[0].weight.data.view(64, 4), want_stats=True) if train else (hip.stem_c1_fwd(a0, pe[0].weight.data.view(64, 4)), None)
+    aff1 = bn_affine(y1, 64, pe[1], train, sums=s1)
+    y2, s2 = hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], want_stats=True) if fuse else \
+        (hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], precise=RT.precise), None)
+    aff2 = bn_affine(y2, 64, pe[4], train, sums=s2)
+    y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
+        (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
+    aff3 = bn_affine(y3, 64, pe[7], train, sums=s3)
     y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])           # (B,T,F,4)
     aff4 = bn_affine(y4, 4, pe[10], train)
     z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)

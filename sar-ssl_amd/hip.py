@@ -155,11 +155,13 @@ def mask_inputs(x, mp_u8, mch_i32, mode, dtype):
     return spec, spat
 
 
-def stem_c1_fwd(a0, W1):
+def stem_c1_fwd(a0, W1, want_stats=False):
+    """-> y1, or (y1, sums f64[128]) with the BatchNorm sums of y1 accumulated in the same pass."""
     npix = a0.numel() // 4
     y = torch.empty(a0.shape[:-1] + (64,), dtype=a0.dtype, device=a0.device)
-    _lib.call("sarssl_stem_c1_fwd", _p(a0), _p(W1), c_long(npix), _p(y), c_int(dt(a0)), _stream())
-    return y
+    sums = torch.empty((128,), dtype=torch.float64, device=a0.device) if want_stats else None
+    _lib.call("sarssl_stem_c1_fwd", _p(a0), _p(W1), c_long(npix), _p(y), _p(sums), c_int(dt(a0)), _stream())
+    return (y, sums) if want_stats else y
 
 
 def stem_c1_wgrad(dy1, a0, grad_out):
@@ -191,17 +193,19 @@ def f64_accum(src, dst, scale=1.0):
     _lib.call("sarssl_f64_accum", _p(src), _p(dst), c_int(src.numel()), c_float(scale), _stream())
 
 
-def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False):
-    """x (B,F,T,64); w_tap [9][64][64] ([tap][co][ci]) in x.dtype; optional BN+ReLU prologue."""
+def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False, want_stats=False):
+    """x (B,F,T,64); w_tap [9][64][64] ([tap][co][ci]) in x.dtype; optional BN+ReLU prologue.
+    want_stats (bf16 only): also returns f64[128] = per-channel sum | sum of squares of the output (fused epilogue)."""
     _need_cuda(x, w_tap)
     B, F, T, C = x.shape
     assert C == 64 and w_tap.dtype == x.dtype and w_tap.is_contiguous() and x.is_contiguous()
     out = torch.empty_like(x)
     ws = _f32ws(x.numel(), x.device, "conv_acc") if (precise and x.dtype == torch.float32) else None
+    sums = torch.empty((128,), dtype=torch.float64, device=x.device) if want_stats else None
     with _Timed("conv3x3_fwd_kernel"):
         _lib.call("sarssl_conv3x3_fwd", _p(x), _p(w_tap), _p(out), c_int(dt(x)), c_int(dt(w_tap)), c_int(B), c_int(F), c_int(T),
-                  _p(scale), _p(shift), c_int(1 if ws is not None else 0), _p(ws), _stream())
-    return out
+                  _p(scale), _p(shift), c_int(1 if ws is not None else 0), _p(ws), _p(sums), _stream())
+    return (out, sums) if want_stats else out
 
 
 def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False):
@@ -227,8 +231,12 @@ def cl_stats(x, C):
     return sums, N
 
 
-def bn_train_affine(x, C, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
-    sums, N = cl_stats(x, C)
+def bn_train_affine(x, C, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, sums=None):
+    """sums: optional precomputed f64[2C] (sum | sum of squares) from a fused producer epilogue."""
+    if sums is None:
+        sums, N = cl_stats(x, C)
+    else:
+        N = x.numel() // C
     aff = torch.empty((4, C), dtype=torch.float32, device=x.device)
     _lib.call("sarssl_bn_finalize", _p(sums), c_long(N), c_int(C), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
               _p(running_mean), _p(running_var), _p(nbt), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), _stream())

@@ -152,6 +152,12 @@ def test_conv3x3_fwd(mode, B, F, T, prologue):
                           precise=(mode == "f32_precise"))
     err = _relerr(out.float().cpu(), _cl(ref))
     assert err < (1e-2 if mode == "bf16" else 5e-5), err
+    if mode == "bf16":            # fused BatchNorm statistics of the stored output
+        out2, sums = hip.conv3x3_fwd(_cl(xq).to(dtp).to(dev), w_tap, sc.to(dev) if prologue else None, sh.to(dev) if prologue else None,
+                                     want_stats=True)
+        assert torch.equal(out2, out)
+        o64 = out.float().reshape(-1, 64).double()
+        assert _relerr(sums[:64], o64.sum(0)) < 1e-5 and _relerr(sums[64:], (o64 ** 2).sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f32_precise"])
@@ -204,7 +210,8 @@ def test_stem_pointwise_and_bn(dtp):
     # c1 fwd / wgrad
     a0 = torch.randn((B, F, T, 4), generator=g).to(dtp)
     W1 = torch.randn((64, 4), generator=g)
-    y1 = hip.stem_c1_fwd(a0.to(dev), W1.to(dev))
+    y1, s1k = hip.stem_c1_fwd(a0.to(dev), W1.to(dev), want_stats=True)
+    assert _relerr(s1k[:64], y1.float().reshape(-1, 64).double().sum(0)) < 1e-5 and _relerr(s1k[64:], (y1.float().reshape(-1, 64).double() ** 2).sum(0)) < 1e-5
     assert _relerr(y1.float(), a0.float() @ W1.t()) < tol
     dy1 = torch.randn((B, F, T, 64), generator=g).to(dtp)
     gW1 = torch.zeros((64, 4), device=dev)
