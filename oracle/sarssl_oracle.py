@@ -157,23 +157,14 @@ def mhsa(x, sd, pre, num_heads, p_drop, train):
 
 
 def batch_norm(x, sd, pre, train, channel_dim=1):
-    """nn.BatchNorm{1,2}d: batch statistics (biased var) in train mode with the running-stat
-    update (momentum 0.1, unbiased var), running statistics in eval mode."""
-    dims = [i for i in range(x.dim()) if i != channel_dim]
-    shape = [1] * x.dim()
-    shape[channel_dim] = -1
+    """nn.BatchNorm{1,2}d (channel dim 1): batch statistics (biased var) in train mode with the running-stat update
+    (momentum 0.1, unbiased var), running statistics in eval mode."""
+    assert channel_dim == 1
     if train:
-        mean = x.mean(dim=dims)
-        var = x.var(dim=dims, unbiased=False)
-        n = x.numel() // x.shape[channel_dim]
         with torch.no_grad():
-            sd[pre + "running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
-            sd[pre + "running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var.detach() * n / max(n - 1, 1))
             sd[pre + "num_batches_tracked"] += 1
-    else:
-        mean, var = sd[pre + "running_mean"], sd[pre + "running_var"]
-    xhat = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + EPS_BN)
-    return xhat * sd[pre + "weight"].view(shape) + sd[pre + "bias"].view(shape)
+    return F.batch_norm(x, sd[pre + "running_mean"], sd[pre + "running_var"], sd[pre + "weight"], sd[pre + "bias"],
+                        training=train, momentum=BN_MOMENTUM, eps=EPS_BN)
 
 
 def conv_module(x, sd, pre, p_drop, train):
