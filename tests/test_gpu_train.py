@@ -132,3 +132,19 @@ def test_run_pretrain_entry_point_on_wav_segments(tmp_path):
     assert rec["epoch"] == 2 and np.isfinite(rec["loss_train"]) and np.isfinite(rec["loss_val"]) and rec["lr"] >= 0
     assert (logd / "latest_model.tar").exists() and (logd / "best_model.tar").exists() and (logd / "model1.tar").exists()
     assert (logd / "config.json").exists()
+
+
+def test_two_rank_bench_path_over_gloo():
+    """The data-parallel step (stage hooks, bucketed all-reduce, max-over-ranks timing) with 2 ranks sharing this GPU over gloo -
+    a functional check of the code path the 8-GPU RCCL run uses (RCCL itself needs one GPU per rank)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SARSSL_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak" and out["value"] > 0
+    assert np.isfinite(out["final_loss"]) and "cpu_baseline" not in out
