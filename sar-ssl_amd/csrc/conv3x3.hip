@@ -198,6 +198,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
             for (int s = 0; s < 36; ++s) {
                 const int cur = s & 1;
                 if (s + 1 < 36) fetch(s + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks
+                                                               // the ds_reads next to their use and waits lgkmcnt(0) every 2 MFMAs)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -380,11 +382,16 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
             for (int cb = 0; cb < 4; ++cb) {
                 const int c0 = cb * 16;
                 const bf16x8 fa = tr_frag(sY, r * 64 + c0, wi * 32, lane);
+                bf16x8 fb[2];
+                fb[0] = tr_frag(sX, r * HC + c0, wj * 32, lane);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int kh = tap / 3, kw = tap - kh * 3;
-                    const bf16x8 fb = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tap], 0, 0, 0);
+                    if (tap + 1 < 9) {
+                        const int kh = (tap + 1) / 3, kw = (tap + 1) - kh * 3;
+                        fb[(tap + 1) & 1] = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // pin the next tap's transpose reads above this MFMA
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tap & 1], acc[tap], 0, 0, 0);
                 }
             }
         }
