@@ -324,12 +324,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int pix_base, int c
     return out;
 }
 
+// 8 waves = (co half) x (ci half) x (tap group: taps 0-4 | taps 5-8).  Every wave walks ALL pixels of the tile, so it only
+// needs 5 (4) accumulator fragments = 80 VGPRs; the registers that frees hold the NEXT tile (z halo + dy, 19 x 16 B per
+// thread) which is fetched from HBM while the current tile is on the matrix cores.
 template <typename T>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t sY[Y_ELEMS];     // dy tile  [8*64 px][64 co]
     __shared__ __attribute__((aligned(16))) uint16_t sX[X_ELEMS];     // z halo tile [660 px][64 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave & 1, wj = (wave >> 1) & 1, wk = wave >> 2;     // co half, ci half, pixel-row half
+    const int wi = wave & 1, wj = (wave >> 1) & 1, wt = wave >> 2;     // co half, ci half, tap group
+    const int tap0 = wt ? 5 : 0, ntap = wt ? 4 : 5;
     const int F = a.F, Tn = a.T;
     const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + TCOL - 1) / TCOL;
     const int ntiles = a.nb * tiles_f * tiles_t;
@@ -340,73 +344,101 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
 
-    f32x16 acc[9];
+    f32x16 acc[5];
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9)
+    for (int t9 = 0; t9 < 5; ++t9)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t9][r] = 0.f;
 
-    const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
-    for (int it = 0; it < nrounds; ++it) {
-        const int tile = xcd_tile(it, blockIdx.x, gridDim.x);
-        if (tile >= ntiles) break;
+    Chunk<T> rz[X_ITERS], ry[8];
+    auto issue_loads = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
-        // stage z (with halo, prologue) and dy (no halo)
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));                        // keep the per-chunk index math out of the loop-invariant set
 #pragma unroll
         for (int i = 0; i < X_ITERS; ++i) {
-            const int q = tid + i * 512;
+            const int q = tid_o + i * 512;
+            const int p = q >> 3;
+            const int hr = p / HC, hc = p - hr * HC;
+            const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
+            const bool valid = (q < NCHUNK_H) && f >= 0 && f < F && t >= 0 && t < Tn;
+            rz[i] = load_chunk<T>(zin + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = (tid_o + i * 512) >> 3;
+            const int f = tc.f0 + (p >> 6), t = tc.t0 + (p & 63);
+            ry[i] = load_chunk<T>(dy + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, f < F && t < Tn);
+        }
+    };
+    auto write_tile = [&](int tile) {
+        const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int i = 0; i < X_ITERS; ++i) {
+            const int q = tid_o + i * 512;
             if (q < NCHUNK_H) {
                 const int p = q >> 3;
                 const int hr = p / HC, hc = p - hr * HC;
                 const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
                 const bool valid = f >= 0 && f < F && t >= 0 && t < Tn;
-                Chunk<T> c = load_chunk<T>(zin + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
-                *(uint4*)&sX[swz(p, cch)] = xform_chunk<T>(c, valid, a.prologue, sc, sh, a.part_z);
+                *(uint4*)&sX[swz(p, cch)] = xform_chunk<T>(rz[i], valid, a.prologue, sc, sh, a.part_z);
             }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int q = tid + i * 512;                   // 4096 chunks
-            const int p = q >> 3;
-            const int r = p >> 6, cc = p & 63;
-            const int f = tc.f0 + r, t = tc.t0 + cc;
-            const bool valid = f < F && t < Tn;
-            Chunk<T> c = load_chunk<T>(dy + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
-            *(uint4*)&sY[swz(p, cch)] = xform_chunk<T>(c, valid, 0, sc, sh, a.part_dy);
+            const int p = (tid_o + i * 512) >> 3;
+            const int f = tc.f0 + (p >> 6), t = tc.t0 + (p & 63);
+            *(uint4*)&sY[swz(p, cch)] = xform_chunk<T>(ry[i], f < F && t < Tn, 0, sc, sh, a.part_dy);
         }
+    };
+
+    const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
+    if (xcd_tile(0, blockIdx.x, gridDim.x) < ntiles) issue_loads(xcd_tile(0, blockIdx.x, gridDim.x));
+    for (int it = 0; it < nrounds; ++it) {
+        const int tile = xcd_tile(it, blockIdx.x, gridDim.x);
+        if (tile >= ntiles) break;
+        write_tile(tile);
         __syncthreads();
+        const int next = (it + 1 < nrounds) ? xcd_tile(it + 1, blockIdx.x, gridDim.x) : ntiles;
+        if (next < ntiles) issue_loads(next);
 #pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = wk * 4 + rr;
+        for (int r = 0; r < TR; ++r) {
 #pragma unroll 1
             for (int cb = 0; cb < 4; ++cb) {
                 const int c0 = cb * 16;
                 const bf16x8 fa = tr_frag(sY, r * 64 + c0, wi * 32, lane);
                 bf16x8 fb[2];
-                fb[0] = tr_frag(sX, r * HC + c0, wj * 32, lane);
+                { const int kh = tap0 / 3, kw = tap0 - kh * 3; fb[0] = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane); }
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    if (tap + 1 < 9) {
-                        const int kh = (tap + 1) / 3, kw = (tap + 1) - kh * 3;
-                        fb[(tap + 1) & 1] = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane);
+                for (int tt = 0; tt < 5; ++tt) {
+                    if (tt + 1 < 5 && tt + 1 < ntap) {
+                        const int tap = tap0 + tt + 1;
+                        const int kh = tap / 3, kw = tap - kh * 3;
+                        fb[(tt + 1) & 1] = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane);
                     }
                     __builtin_amdgcn_sched_barrier(0);         // pin the next tap's transpose reads above this MFMA
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tap & 1], acc[tap], 0, 0, 0);
+                    if (tt < ntap) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tt & 1], acc[tt], 0, 0, 0);
                 }
             }
         }
         __syncthreads();
     }
     // D[co][ci]: lane: ci = lane&31, co = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* P = a.partial + ((long)blockIdx.x * 2 + wk) * W_ELEMS;
+    float* P = a.partial + (long)blockIdx.x * W_ELEMS;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tt = 0; tt < 5; ++tt) {
+        if (tt < ntap) {
+            const int tap = tap0 + tt;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int ci = wj * 32 + (lane & 31);
-            P[(tap * 64 + co) * 64 + ci] = acc[tap][r];
+            for (int r = 0; r < 16; ++r) {
+                const int co = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ci = wj * 32 + (lane & 31);
+                P[(tap * 64 + co) * 64 + ci] = acc[tt][r];
+            }
         }
+    }
 }
 
 // dW[e] (+)= sum_p partial[p][e]; workgroup = 64 elements x 4 part-slots, 4-way unrolled loads
@@ -468,7 +500,7 @@ extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int 
 }
 
 extern "C" long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T) {
-    return (long)conv_grid(nb, F, T) * 2 * W_ELEMS * sizeof(float);
+    return (long)conv_grid(nb, F, T) * W_ELEMS * sizeof(float);
 }
 
 // dW: f32 [9][64][64] ([tap][co][ci]).  partial: workspace of sarssl_conv3x3_wgrad_workspace_bytes.
@@ -484,14 +516,14 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
     const int rblocks = W_ELEMS / 64;
     if (dtype == SARSSL_BF16) {
         conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
-        wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid * 2, dW, 0);
+        wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid, dW, 0);
     } else if (dtype == SARSSL_F32) {
         const int npass = precise ? 3 : 1;
         for (int pass = 0; pass < npass; ++pass) {
             WgradArgs p = a;
             if (precise) { p.part_dy = (pass == 1); p.part_z = (pass == 0); }     // hi*lo, lo*hi, hi*hi
             conv3x3_wgrad_kernel<float><<<grid, 512, 0, st>>>(p);
-            wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid * 2, dW, pass > 0);
+            wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid, dW, pass > 0);
         }
     } else { sarssl_set_error("sarssl_conv3x3_wgrad: unsupported dtype %d", dtype); return -1; }
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel");
