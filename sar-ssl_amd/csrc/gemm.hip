@@ -91,7 +91,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
 }
 
 template <typename TA, typename TB, typename TC, bool AKC, bool BKC, bool PF>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4))) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TILE_ELEMS];      // 40 KiB: A/B tiles, then the C staging tile
     uint16_t* sA = smem;
     uint16_t* sB = smem + TILE_ELEMS;
@@ -290,7 +290,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, i
 
 template <typename TA, typename TB, typename TC>
 static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
-    const bool pf = (g.split_k > 0 ? g.k_per_split : g.K) >= 1024;
+    static const int pf_mink = getenv("SARSSL_GEMM_PF_MINK") ? atoi(getenv("SARSSL_GEMM_PF_MINK")) : 1024;
+    const int k_len = g.split_k > 0 ? g.k_per_split : g.K;
+    const bool pf = k_len >= pf_mink || (k_len >= pf_mink / 2 && g.N <= 512);
     if (pf) {
         if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, true><<<grid, 256, 0, st>>>(g);
         else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, true><<<grid, 256, 0, st>>>(g);
