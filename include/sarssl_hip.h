@@ -99,7 +99,8 @@ int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop,
 int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 int sarssl_f64_accum(const double* src, float* dst, int n, float scale, void* stream);
 
-/* ---- loss: code/model.py:585-592 (channel select) + 721-747 (gen_loss) */
+/* ---- loss: code/model.py:585-592 (channel select) + 721-747 (gen_loss).  fwd: sums = f64[128] scratch, out = f32[2]
+ * (loss, diff); F <= 480. */
 int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
                           double* sums, float* out, int dtype, void* stream);
 int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn,

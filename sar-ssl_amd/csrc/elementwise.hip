@@ -459,33 +459,66 @@ __global__ void f64_accum_kernel(const double* __restrict__ s, float* __restrict
 // ------------------------------------------------------------------------------------ loss
 // pred: (B, T, F, 2, 2) [f][reim][mic];  x: (B, 2, F, T, 2) f32;  idx: (B, nm) int32 masked frames; mch: (B) int32
 // sums[0] += sum (pred_mch - x_mch)^2 ; sums[1] += sum (x_mch - x_other)^2   over masked frames
+// Workgroup = (signal b, 8 consecutive frames).  pred is frame-major ([b][t][f][re/im][mic]) and x is frequency-major
+// ([b][mic][f][t][re/im]): the masked pred rows of the group are staged in LDS (contiguous 16-byte reads), then x is walked in
+// its own order (64 contiguous bytes per f) - both sides coalesced.  Partial sums go to 64 slots x 2 quantities.
+#define MSE_TT 8
+#define MSE_SLOTS 64
 template <typename T>
 __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ x,
                                                              const int* __restrict__ idx, const int* __restrict__ mch, int nb,
                                                              int F, int Tn, int nm, double* __restrict__ sums) {
+    extern __shared__ float sp[];                       // [MSE_TT][F * 4]
+    __shared__ unsigned smask;
     __shared__ float red[2][4];
-    const int b = blockIdx.x / nm, k = blockIdx.x % nm;
-    const int t = idx[(long)b * nm + k], mc = mch[b];
+    const int groups = (Tn + MSE_TT - 1) / MSE_TT;
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int t0 = g * MSE_TT, mc = mch[b];
+    if (threadIdx.x == 0) smask = 0u;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nm; k += 256) {
+        const int t = idx[(long)b * nm + k];
+        if (t >= t0 && t < t0 + MSE_TT) atomicOr(&smask, 1u << (t - t0));
+    }
+    __syncthreads();
+    const unsigned mask = smask;
+    if (mask == 0u) return;
+    const int row = F * 4;
+    for (int tl = 0; tl < MSE_TT; ++tl) {
+        if (!((mask >> tl) & 1u)) continue;
+        const T* src = pred + ((long)b * Tn + t0 + tl) * row;
+        for (int e = threadIdx.x; e < F; e += 256) {
+            *(float4*)&sp[tl * row + e * 4] = ld4(src + e * 4);
+        }
+    }
+    __syncthreads();
     float l = 0.f, dsum = 0.f;
-    for (int e = threadIdx.x; e < F * 2; e += 256) {
-        const int f = e >> 1, r = e & 1;
-        const float pv = ld_f(pred + ((((long)b * Tn + t) * F + f) * 2 + r) * 2 + mc);
-        const float tar = x[((((long)b * 2 + mc) * F + f) * Tn + t) * 2 + r];
-        const float oth = x[((((long)b * 2 + (1 - mc)) * F + f) * Tn + t) * 2 + r];
-        l += (pv - tar) * (pv - tar);
-        dsum += (tar - oth) * (tar - oth);
+    const float* xt = x + (((long)b * 2 + mc) * F) * Tn * 2;
+    const float* xo = x + (((long)b * 2 + (1 - mc)) * F) * Tn * 2;
+    for (int i = threadIdx.x; i < F * MSE_TT; i += 256) {
+        const int tl = i & (MSE_TT - 1), f = i >> 3;
+        if (!((mask >> tl) & 1u)) continue;
+        const long off = ((long)f * Tn + t0 + tl) * 2;
+        const float2 tar = *(const float2*)(xt + off), oth = *(const float2*)(xo + off);
+        const float p0 = sp[tl * row + f * 4 + mc], p1 = sp[tl * row + f * 4 + 2 + mc];
+        l += (p0 - tar.x) * (p0 - tar.x) + (p1 - tar.y) * (p1 - tar.y);
+        dsum += (tar.x - oth.x) * (tar.x - oth.x) + (tar.y - oth.y) * (tar.y - oth.y);
     }
     l = wave_sum(l); dsum = wave_sum(dsum);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[0][wave] = l; red[1][wave] = dsum; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&sums[0], (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
-        atomicAdd(&sums[1], (double)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+    if (threadIdx.x < 2) {
+        const int q = threadIdx.x;
+        atomicAdd(&sums[q * MSE_SLOTS + (blockIdx.x & (MSE_SLOTS - 1))], (double)(red[q][0] + red[q][1] + red[q][2] + red[q][3]));
     }
 }
 __global__ void loss_finalize_kernel(const double* __restrict__ sums, double count, float* __restrict__ out) {
-    if (threadIdx.x == 0) { out[0] = (float)(sums[0] / count); out[1] = (float)(sums[1] / count); }
+    const int lane = threadIdx.x;                        // 64 threads
+    double a = sums[lane], c = sums[MSE_SLOTS + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+    if (lane == 0) { out[0] = (float)(a / count); out[1] = (float)(c / count); }
 }
 // dpred = gscale * 2 (pred - tar) / count on (masked frame, masked channel) entries, 0 elsewhere
 template <typename T>
@@ -675,12 +708,14 @@ extern "C" int sarssl_f64_accum(const double* src, float* dst, int n, float scal
     SARSSL_CHECK_LAUNCH("f64_accum_kernel");
     return 0;
 }
-// out: f32[2] = (loss, diff).  sums: f64[2] workspace (zeroed here).
+// out: f32[2] = (loss, diff).  sums: f64[128] workspace (zeroed here).
 extern "C" int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
                                      int nm, double* sums, float* out, int dtype, void* stream) {
-    SARSSL_REQUIRE(nb > 0 && nm > 0, "sarssl_masked_mse_fwd");
-    if (hipMemsetAsync(sums, 0, 2 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    DISPATCH_T(dtype, (masked_mse_fwd_kernel<T><<<nb * nm, 256, 0, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
+    const size_t lds = (size_t)MSE_TT * F * 4 * sizeof(float);
+    SARSSL_REQUIRE(nb > 0 && nm > 0 && lds <= 60 * 1024, "sarssl_masked_mse_fwd (F <= 480)");
+    const int groups = (Tn + MSE_TT - 1) / MSE_TT;
+    if (hipMemsetAsync(sums, 0, 2 * MSE_SLOTS * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    DISPATCH_T(dtype, (masked_mse_fwd_kernel<T><<<nb * groups, 256, lds, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
     loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out);
     SARSSL_CHECK_LAUNCH("masked_mse_fwd_kernel");
     return 0;

@@ -244,6 +244,29 @@ __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // Generic channels-last helpers on X[N][C], C = 4 * 2^k <= 1024.  Thread = (row slot, 4-channel group).
 
+// Tail of the per-channel reductions: 32 row slots -> one value per (quantity, virtual column); when C < 64 the 64/C
+// virtual columns of a channel are folded in LDS first so a workgroup issues 2C (not 128) same-address f64 atomics.
+__device__ __forceinline__ void cl_fold_atomic(float (&sred)[256][17], int col0, int L, int C, double* __restrict__ out) {
+    __shared__ float sfold[2][64];
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float acc = 0.f;
+        if (col0 + c < L)
+            for (int r = 0; r < 32; ++r) acc += sred[r * 8 + (c >> 3)][which * 8 + (c & 7)];
+        if (C >= 64) { if (col0 + c < L) atomicAdd(&out[which * C + col0 + c], (double)acc); }
+        else sfold[which][c] = acc;
+    }
+    if (C < 64) {
+        __syncthreads();
+        if (threadIdx.x < 2 * C) {
+            const int which = threadIdx.x / C, ch = threadIdx.x % C;
+            float a = 0.f;
+            for (int c = ch; c < 64; c += C) a += sfold[which][c];
+            atomicAdd(&out[which * C + ch], (double)a);
+        }
+    }
+}
+
 // Column tiles of 64 channels (8 threads x 8 ch, 16-byte loads) x 32 row slots.  For C < 64 (64 % C == 0) the tensor is
 // viewed as [N*C/64][64] and the 64 virtual columns fold back onto channel (col % C).
 // sums[c] += sum_n x ; sums[C + c] += sum_n x^2
@@ -265,14 +288,7 @@ __global__ void cl_stats_kernel(const T* __restrict__ x, long rows, int L, int C
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][8 + e] = q[e]; }
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
-        if (col0 + c < L) {
-            float acc = 0.f;
-            for (int r = 0; r < 32; ++r) acc += sred[r * 8 + (c >> 3)][which * 8 + (c & 7)];
-            atomicAdd(&sums[which * C + ((col0 + c) % C)], (double)acc);
-        }
-    }
+    cl_fold_atomic(sred, col0, L, C, sums);
 }
 
 // training-mode BatchNorm statistics -> affine; updates running stats (nn.BatchNorm defaults: momentum 0.1, unbiased)
@@ -366,14 +382,7 @@ __global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sred[threadIdx.x][e] = s[e]; sred[threadIdx.x][8 + e] = q[e]; }
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
-        if (col0 + c < L) {
-            float acc = 0.f;
-            for (int r = 0; r < 32; ++r) acc += sred[r * 8 + (c >> 3)][which * 8 + (c & 7)];
-            atomicAdd(&red[which * C + ((col0 + c) % C)], (double)acc);
-        }
-    }
+    cl_fold_atomic(sred, col0, L, C, red);
 }
 
 // pass 2: dy = gamma*rstd * (g - s1/N - xhat*s2/N)      (train)   or   dy = gamma*rstd * g   (eval: use_stats = 0)
@@ -480,10 +489,10 @@ static inline int cl_rowgrid(long rows, int L) {
     long b = (rows + (long)rpb * 4 - 1) / ((long)rpb * 4); if (b < 1) b = 1;
     return (int)(b > 4096 ? 4096 : b);
 }
-static inline dim3 cl_grid(long rows, int L) {
+static inline dim3 cl_grid(long rows, int L, int C) {
     int gx = (L + 63) / 64;
     long gy = (rows + 255) / 256; if (gy < 1) gy = 1;
-    long cap = 2048 / gx; if (cap < 1) cap = 1;
+    long cap = (C < 64 ? 512 : 2048) / gx; if (cap < 1) cap = 1;   // C < 64: every workgroup hits the same 2C addresses
     if (gy > cap) gy = cap;
     return dim3(gx, (unsigned)gy, 1);
 }
@@ -493,7 +502,7 @@ extern "C" int sarssl_cl_stats(const void* x, long N, int C, double* sums, int d
     long rows; int L;
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_stats(C % 8 == 0 or C | 64; C < 64 needs N*C % 64 == 0)");
     if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    const dim3 grid = cl_grid(rows, L);
+    const dim3 grid = cl_grid(rows, L, C);
     DISPATCH_T(dtype, (cl_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, rows, L, C, sums)));
     SARSSL_CHECK_LAUNCH("cl_stats_kernel");
     return 0;
@@ -531,7 +540,7 @@ extern "C" int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, in
     long rows; int L;
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_bn_bwd_reduce");
     if (hipMemsetAsync(red, 0, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    const dim3 grid = cl_grid(rows, L);
+    const dim3 grid = cl_grid(rows, L, C);
     DISPATCH_T(dtype, (cl_bn_bwd_reduce_kernel<T><<<grid, 256, 0, ST>>>((const T*)dz, (const T*)y, rows, L, C, scale, shift,
                                                                        mean, rstd, act, red)));
     SARSSL_CHECK_LAUNCH("cl_bn_bwd_reduce_kernel");

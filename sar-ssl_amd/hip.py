@@ -408,7 +408,7 @@ def masked_mse_fwd(pred, x, idx_i32, mch_i32):
     """pred (B,T,F*4) -> f32[2] device tensor (loss, diff)."""
     B, _, F, T, _ = x.shape
     nm = idx_i32.shape[1]
-    sums = torch.empty((2,), dtype=torch.float64, device=x.device)
+    sums = torch.empty((128,), dtype=torch.float64, device=x.device)
     out = torch.empty((2,), dtype=torch.float32, device=x.device)
     _lib.call("sarssl_masked_mse_fwd", _p(pred), _p(x), _p(idx_i32), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm), _p(sums),
               _p(out), c_int(dt(pred)), _stream())
