@@ -213,6 +213,56 @@ def f7_downstream(ref_model):
     np.savez_compressed(os.path.join(GOLD, "f7_downstream.npz"), pred=pred.numpy(), embed=emb.numpy())
 
 
+def f9_downstream_train(ref_model, ref_learner, nstep=3, B=4):
+    """TDOA fine-tuning steps of the real reference (code/learner.py:168-222 with code/model.py:667-719): per-step loss /
+    metric / predictions, step-1 gradient norms, for 'finetune' (everything trains) and 'lineareval' (encoders frozen,
+    learner.py:441-444), plus what Learner.train_epoch / test_epoch return over the same three batches."""
+    from sar_ssl_amd import synth
+    pool = torch.from_numpy(synth.make_batch(100, nstep * B))[:, :16640].contiguous()           # T = 1.04 s -> nt = 64
+    tdoa = torch.from_numpy(np.random.default_rng(77).uniform(-0.2 / 343, 0.2 / 343, size=(nstep * B,)).astype(np.float32))
+    store = {"tdoa": tdoa.numpy(), "B": B, "lr": 1e-4, "weight_seed": 5, "sig_seed": 100}
+    for mode in ("finetune", "lineareval"):
+        ds = ref_model.SARSSL(sig_shape=(256, 64, 2, 2), pretrain=False, device="cpu", downstream_token="all",
+                              downstream_head="mlp", downstream_embed="spat", downstream_dlabel=1)
+        load_recipe(ds, 5)
+        set_dropout(ds, 0.0)
+        if mode == "lineareval":
+            for k, v in ds.named_parameters():
+                if k.startswith(("spec_encoder.", "spat_encoder.")):
+                    v.requires_grad = False
+        init = {k: v.clone() for k, v in ds.state_dict().items()}
+        lrn = ref_learner.STFTLearner(ds, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000,
+                                      task="TDOA", ch_mode="M")
+        lrn.cpu()
+        ds.train()
+        opt = torch.optim.Adam(ds.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0)
+        losses, metrics, preds = [], [], []
+        for s in range(nstep):
+            sig, gt = pool[s * B:(s + 1) * B], {"TDOA": tdoa[s * B:(s + 1) * B]}
+            x, tar = lrn.data_preprocess(sig, gt)
+            pred, emb = ds(x)
+            loss = lrn.loss(pred_batch=pred, gt_batch=tar)
+            opt.zero_grad()
+            loss.backward()
+            if s == 0:
+                for k, v in ds.named_parameters():
+                    store["%s.gradnorm.%s" % (mode, k)] = np.float64(v.grad.double().norm().item()) if v.grad is not None else np.float64(-1.0)
+                store[mode + ".embed0"] = emb.detach().numpy()
+            opt.step()
+            losses.append(loss.item()); metrics.append(lrn.evaluate(pred_batch=pred, gt_batch=tar).item()); preds.append(pred.detach().numpy())
+            print(mode, "step", s, losses[-1], metrics[-1], flush=True)
+        store[mode + ".loss"], store[mode + ".metric"], store[mode + ".pred"] = np.array(losses), np.array(metrics), np.stack(preds)
+        # the reference's own epoch drivers on the same batches, from the same initial state
+        ds.load_state_dict(init)
+        loader = [(pool[s * B:(s + 1) * B], {"TDOA": tdoa[s * B:(s + 1) * B]}) for s in range(nstep)]
+        ltr, mtr = lrn.train_epoch(loader, lr=1e-4, epoch=1, return_metric=True)
+        lte, mte = lrn.test_epoch(loader, return_metric=True)
+        store[mode + ".train_epoch"] = np.array([float(ltr), float(mtr)])
+        store[mode + ".test_epoch"] = np.array([float(lte), float(mte)])
+        print(mode, "train_epoch", float(ltr), float(mtr), "test_epoch", float(lte), float(mte), flush=True)
+    np.savez_compressed(os.path.join(GOLD, "f9_downstream_train.npz"), **store)
+
+
 def f8_schedule():
     sys.path.insert(0, ref_shim.REF_CODE)
     from common.utils import create_learning_rate_schedule
@@ -256,7 +306,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_learner, ref_um = ref_shim.load()
-    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8"]
+    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8", "f9"]
     if "manifest" in todo: f_manifest(ref_model)
     if "f1" in todo: f1_frontend(ref_learner, ref_model)
     if "f2" in todo: f2_blocks(ref_model)
@@ -264,5 +314,6 @@ if __name__ == "__main__":
     if "f4" in todo: f4_masks(ref_um)
     if "f7" in todo: f7_downstream(ref_model)
     if "f8" in todo: f8_schedule()
+    if "f9" in todo: f9_downstream_train(ref_model, ref_learner)
     if a.curve: f5_curve(ref_model, ref_learner)
     print("golden vectors written to", GOLD)

@@ -337,3 +337,40 @@ def train_step(mic_sig, sd, opt_state, lr, mask_patch_idx=None, mask_ch_idx=None
         for p in params.values():
             p.grad = None
     return float(loss.detach()), float(diff.detach())
+
+
+def downstream_train_step(mic_sig, tdoa, sd, opt_state, lr, embed_use="spat", p_drop=0.1, frozen=(), fs=16000):
+    """One iteration of ``Learner.train_epoch`` (code/learner.py:186-202) for task 'TDOA': preprocess -> downstream
+    forward in train mode -> ``mse_loss(pred, TDOA*fs)`` (learner.py:620-631, 644-647) -> backward -> Adam over the
+    parameters that are not ``frozen`` (key prefixes; 'lineareval' freezes what came from the pretraining checkpoint,
+    learner.py:441-444).  ``sd`` is updated in place.  Returns (loss, metric, pred, mean_embed)."""
+    x = data_preprocess(mic_sig)
+    tar = tdoa.reshape(-1, 1).float() * fs
+    params = {k: t for k, t in sd.items() if is_param(k) and not k.startswith(tuple(frozen))} if frozen else \
+        {k: t for k, t in sd.items() if is_param(k)}
+    for p in params.values():
+        p.requires_grad_(True)
+        p.grad = None
+    pred, emb = sarssl_downstream_forward(x, sd, embed_use=embed_use, train=True, p_drop=p_drop)
+    loss = F.mse_loss(pred, tar)
+    loss.backward()
+    with torch.no_grad():
+        grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
+        for p in params.values():
+            p.requires_grad_(False)
+        used = {k: p for k, p in params.items() if grads[k] is not None}
+        adam_step(used, grads, opt_state, lr)
+        for p in params.values():
+            p.grad = None
+        metric = (pred.detach() - tar).abs().mean()
+    opt_state["last_grads"] = grads
+    return float(loss.detach()), float(metric), pred.detach(), emb.detach()
+
+
+def downstream_eval_step(mic_sig, tdoa, sd, embed_use="spat", fs=16000):
+    """One iteration of ``Learner.test_epoch`` (code/learner.py:236-246): eval-mode forward, MSE loss and MAE metric."""
+    with torch.no_grad():
+        x = data_preprocess(mic_sig)
+        tar = tdoa.reshape(-1, 1).float() * fs
+        pred, emb = sarssl_downstream_forward(x, sd, embed_use=embed_use, train=False)
+        return float(F.mse_loss(pred, tar)), float((pred - tar).abs().mean()), pred, emb

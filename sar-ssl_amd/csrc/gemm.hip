@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4)
                 tile_load<TA, AKC>(A, g.lda, m0, k0, g.M, k_end, g.partA, tid, ra);
                 tile_load<TB, BKC>(B, g.ldb, n0, k0, g.N, k_end, g.partB, tid, rb);
             }
-            tile_store<AKC>(sA, tid, ra);
-            tile_store<BKC>(sB, tid, rb);
+            if (!(g.dbg & 8) || k0 == k_begin) {
+                tile_store<AKC>(sA, tid, ra);
+                tile_store<BKC>(sB, tid, rb);
+            }
         }
         __syncthreads();
         if (PF && k0 + BK < k_end && !(g.dbg & 1)) {

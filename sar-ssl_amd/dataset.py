@@ -48,6 +48,18 @@ def write_wav_pcm16(path, pcm, fs=16000):
         f.write(hdr + b"data" + struct.pack("<I", len(body)) + body)
 
 
+class Selecting(object):
+    """Keep samples [select_range[0], select_range[1]) of a (nsample, nch) signal (code/dataset.py:386-395)."""
+
+    def __init__(self, select_range):
+        self.select_range = select_range
+
+    def __call__(self, mic_sig):
+        nsample = mic_sig.shape[0]
+        assert self.select_range[-1] <= nsample, f"Selecting range ({self.select_range[-1]}) is larger than signal length ({nsample})~"
+        return mic_sig[self.select_range[0]:self.select_range[1], ...]
+
+
 class FixMicSigDataset(Dataset):
     def __init__(self, data_dir, fs, load_anno, dataset_sz, load_dp=False, transforms=None, raw_pcm=False):
         dirs = data_dir if isinstance(data_dir, list) else [data_dir]

@@ -102,6 +102,93 @@ class Learner(ABC):
             raise NotImplementedError("pretrain_evaluate (ISTFT + PESQ) is an eval/export 'next' row (SURVEY.md 8f-3)")
         return (loss, diff, vis_batch) if return_diff else loss
 
+    # ---- supervised fine-tuning / evaluation (code/learner.py:168-269) ------------------------------------------------
+    def train_epoch(self, dataset, lr=0.0001, epoch=None, return_metric=False):
+        """One epoch of downstream training: Adam re-created per epoch (learner.py:176), per batch preprocess -> model ->
+        ``self.loss`` -> backward -> step.  Loss / metric are accumulated on the device (one sync per epoch, not per step)."""
+        self.model.train()
+        optimizer = runtime.FusedAdam(self._flat, lr=float(lr), betas=(0.9, 0.999))
+        optimizer.zero_grad()
+        frozen = self._flat.frozen_ranges()
+        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        n = 0
+        world = sdist.world_size()
+        for mic_sig_batch, gt_batch in dataset:
+            in_batch, gt_batch = self.data_preprocess(mic_sig_batch, gt_batch)
+            pred_batch, embed_batch = self.model(in_batch)
+            loss_batch = self.loss(pred_batch=pred_batch, gt_batch=gt_batch)
+            loss_batch.backward()
+            if world > 1:
+                torch.distributed.all_reduce(self._flat.grad)
+            self._flat.zero_frozen_grads(frozen)
+            optimizer.step(grad_scale=1.0 / world)
+            optimizer.zero_grad()
+            acc[0] += loss_batch.detach().double()
+            if return_metric:
+                acc[1] += self.evaluate(pred_batch=pred_batch, gt_batch=gt_batch).double()
+            n += 1
+        acc = acc / max(n, 1)
+        if world > 1:
+            torch.distributed.all_reduce(acc)
+            acc /= world
+        loss, metric = float(acc[0]), acc[1].float().cpu()
+        return (loss, metric) if return_metric else loss
+
+    def test_epoch(self, dataset, return_metric=False, return_vis=False):
+        self.model.eval()
+        with torch.no_grad():
+            acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+            embed, gt = [], []
+            n = 0
+            for mic_sig_batch, gt_batch in dataset:
+                in_batch, gt_batch = self.data_preprocess(mic_sig_batch, gt_batch)
+                pred_batch, embed_batch = self.model(in_batch)
+                acc[0] += self.loss(pred_batch=pred_batch, gt_batch=gt_batch).double()
+                if return_metric:
+                    acc[1] += self.evaluate(pred_batch=pred_batch, gt_batch=gt_batch).double()
+                if return_vis:
+                    embed += [embed_batch]
+                    gt += [gt_batch]
+                n += 1
+            acc = acc / max(n, 1)
+            loss, metric = float(acc[0]), acc[1].float().cpu()
+            out = (loss,) + ((metric,) if return_metric else ())
+            if return_vis:
+                out += ({"embed": torch.cat(embed, dim=0), "label": torch.cat(gt, dim=0)},)
+            return out if len(out) > 1 else loss
+
+    def smooth_data(self, data_list, alpha=0.8):
+        """current_smooth = alpha * previous_smooth + (1 - alpha) * current (code/learner.py:271-281)."""
+        out, cur = [data_list[0]], data_list[0]
+        for v in data_list[1:]:
+            cur = alpha * cur + (1 - alpha) * v
+            out.append(cur)
+        return out
+
+    def ensembling(self, checkpoints_dir, epochs):
+        """Average the saved models of ``epochs`` into the live model and write ensemble_model.tar (code/learner.py:302-331)."""
+        avg = {}
+        for i, epoch in enumerate(epochs):
+            path = checkpoints_dir + "/model" + str(epoch) + ".tar"
+            assert os.path.exists(path), f"{path} does not exist, can not load best model."
+            sd = torch.load(path, map_location="cpu", weights_only=False)["model"]
+            for k, v in sd.items():
+                avg[k] = v * 1 / len(epochs) if i == 0 else avg[k] + v * 1 / len(epochs)
+        own = self.model.state_dict()
+        self.model.load_state_dict({k: v.to(own[k].dtype) for k, v in avg.items()})
+        if self._flat is not None:
+            self._flat._synced = None
+            self._flat.ensure_shadow()
+        if int(os.environ.get("RANK", "0")) == 0:
+            torch.save({"epoch": epochs, "model": self._state_dict_cpu()}, checkpoints_dir + "/ensemble_model.tar")
+
+    def remove_checkpoint_epochs(self, checkpoints_dir, epochs):
+        """Remove the per-epoch checkpoints of ``epochs`` (code/learner.py:481-486)."""
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        for epoch in epochs:
+            os.remove(checkpoints_dir + "/model" + str(epoch) + ".tar")
+
     # ---- early stopping / checkpoints (code/learner.py:283-300, 333-448) ------------------------------------------------
     def early_stopping(self, current_score, patience=5):
         if current_score >= self.max_score:

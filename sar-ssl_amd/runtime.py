@@ -149,6 +149,23 @@ class FlatParams:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
+    def frozen_ranges(self):
+        """Merged [start, end) ranges of the flat buffers owned by parameters with requires_grad == False."""
+        out = []
+        for p, o in zip(self.params, self.offsets):
+            if not p.requires_grad:
+                end = o + (p.numel() + 7) // 8 * 8
+                if out and out[-1][1] == o:
+                    out[-1][1] = end
+                else:
+                    out.append([o, end])
+        return [tuple(r) for r in out]
+
+    def zero_frozen_grads(self, ranges=None):
+        """Frozen parameters must not move: the hand-written backward may still have accumulated into their slices."""
+        for s, e in (self.frozen_ranges() if ranges is None else ranges):
+            self.grad[s:e].zero_()
+
     def bucket_slices(self, nbuckets):
         """Contiguous [start, end) slices of the flat buffers, ~equal size, aligned to parameter boundaries."""
         target = self.numel / float(nbuckets)

@@ -1,0 +1,183 @@
+"""GPU: SURVEY.md 8f-1 - TDOA fine-tuning on the (pre-trained) encoders: three Adam iterations of the HIP path against the real
+reference's (fixture F9: per-step loss / metric / predictions, step-1 gradient norms), in 'finetune' and 'lineareval' mode,
+and the learner's train_epoch / test_epoch return values on the same batches."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import recipes
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": dict(loss=1e-3, pred=2e-3, grad=2e-3, epoch=2e-3),        # north_star tolerance on the f32 (split-bf16) path
+       "bf16": dict(loss=8e-2, pred=8e-2, grad=1.5e-1, epoch=1e-1)}      # bf16 storage: informational band
+
+
+def _set_dropout(m, p):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = p
+
+
+def _setup(mode, prec):
+    from sar_ssl_amd import learner, model, runtime, synth
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLD, "f9_downstream_train.npz"))
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["downstream"]
+    ds = model.SARSSL(sig_shape=(256, 64, 2, 2), pretrain=False, device=dev, downstream_token="all", downstream_head="mlp",
+                      downstream_embed="spat", downstream_dlabel=1)
+    ds.load_state_dict(recipes.recipe_state_dict(man, int(z["weight_seed"])))
+    _set_dropout(ds, 0.0)
+    if mode == "lineareval":
+        for k, v in ds.named_parameters():
+            if k.startswith(("spec_encoder.", "spat_encoder.")):
+                v.requires_grad = False
+    lrn = learner.STFTLearner(ds, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task="TDOA", ch_mode="M")
+    lrn.cuda()
+    if prec == "bf16":
+        lrn.amp()
+    else:
+        runtime.set_precision("fp32")
+    B = int(z["B"])
+    n = z[mode + ".loss"].shape[0]
+    pool = torch.from_numpy(synth.make_batch(int(z["sig_seed"]), n * B))[:, :16640].contiguous()
+    tdoa = torch.from_numpy(z["tdoa"])
+    loader = [(pool[s * B:(s + 1) * B], {"TDOA": tdoa[s * B:(s + 1) * B]}) for s in range(n)]
+    return z, ds, lrn, loader
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["finetune", "lineareval"])
+def test_tdoa_training_steps_vs_reference(mode, prec):
+    from sar_ssl_amd import runtime
+    tol = TOL[prec]
+    try:
+        z, ds, lrn, loader = _setup(mode, prec)
+        ds.train()
+        opt = runtime.FusedAdam(lrn._flat, lr=float(z["lr"]))
+        opt.zero_grad()
+        frozen = lrn._flat.frozen_ranges()
+        assert (len(frozen) > 0) == (mode == "lineareval")
+        for s, (sig, gt) in enumerate(loader):
+            x, tar = lrn.data_preprocess(sig, gt)
+            pred, emb = ds(x)
+            loss = lrn.loss(pred_batch=pred, gt_batch=tar)
+            loss.backward()
+            if s == 0:
+                refs = {k: float(z["%s.gradnorm.%s" % (mode, k)]) for k, _ in ds.named_parameters()}
+                top = max(refs.values())
+                for k, v in ds.named_parameters():
+                    ref = refs[k]
+                    if ref < 0:
+                        continue                                  # no gradient in the reference (frozen / unused branch)
+                    got = float(v.grad.double().norm())
+                    if ref < 1e-6 * top:                          # analytically zero (key-projection bias): round-off on both sides
+                        assert got < 1e-4 * top, (k, got, ref)
+                    else:
+                        assert abs(got - ref) <= tol["grad"] * ref, (k, got, ref)
+                e_ref = torch.from_numpy(z[mode + ".embed0"]).to(emb.device)
+                assert (emb.float() - e_ref).abs().max() <= tol["pred"] * e_ref.abs().max()
+            lrn._flat.zero_frozen_grads(frozen)
+            opt.step()
+            opt.zero_grad()
+            lref, mref = float(z[mode + ".loss"][s]), float(z[mode + ".metric"][s])
+            assert abs(float(loss.detach()) - lref) <= tol["loss"] * lref, (s, float(loss.detach()), lref)
+            assert abs(float(lrn.evaluate(pred_batch=pred, gt_batch=tar)) - mref) <= tol["loss"] * mref
+            p_ref = torch.from_numpy(z[mode + ".pred"][s]).to(pred.device)
+            assert (pred.detach() - p_ref).abs().max() <= tol["pred"] * p_ref.abs().max(), (s, pred, p_ref)
+        if mode == "lineareval":                                   # frozen encoders did not move
+            man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["downstream"]
+            init = recipes.recipe_state_dict(man, int(z["weight_seed"]))
+            for k, v in ds.named_parameters():
+                if k.startswith("spat_encoder.") and v.numel() > 4:
+                    assert torch.equal(v.detach().cpu(), init[k]), k
+    finally:
+        runtime.set_precision("bf16")
+
+
+@pytest.mark.parametrize("mode", ["finetune", "lineareval"])
+def test_learner_train_and_test_epoch_vs_reference(mode):
+    from sar_ssl_amd import runtime
+    tol = TOL["fp32"]
+    try:
+        z, ds, lrn, loader = _setup(mode, "fp32")
+        ltr, mtr = lrn.train_epoch(loader, lr=float(z["lr"]), epoch=1, return_metric=True)
+        lte, mte, vis = lrn.test_epoch(loader, return_metric=True, return_vis=True)
+        ref_tr, ref_te = z[mode + ".train_epoch"], z[mode + ".test_epoch"]
+        assert abs(ltr - ref_tr[0]) <= tol["epoch"] * ref_tr[0] and abs(float(mtr) - ref_tr[1]) <= tol["epoch"] * ref_tr[1]
+        assert abs(lte - ref_te[0]) <= tol["epoch"] * ref_te[0] and abs(float(mte) - ref_te[1]) <= tol["epoch"] * ref_te[1]
+        assert vis["embed"].shape == (12, 256) and vis["label"].shape == (12, 1)
+        assert lrn.smooth_data([1.0, 2.0, 3.0], alpha=0.5) == [1.0, 1.5, 2.25]
+    finally:
+        runtime.set_precision("bf16")
+
+
+def test_ensembling_and_lineareval_checkpoint_flow(tmp_path):
+    """save_checkpoint(save_extra_hist) x2 -> ensembling averages them; load_checkpoint_best(param_frozen=True) freezes exactly
+    the loaded keys (code/learner.py:302-331, 414-448)."""
+    from sar_ssl_amd import learner, model, runtime
+    try:
+        z, ds, lrn, loader = _setup("finetune", "fp32")
+        d = str(tmp_path)
+        w0 = ds.mlp_head[1].weight.detach().clone()
+        lrn.save_checkpoint(epoch=1, checkpoints_dir=d, is_best_epoch=True, save_extra_hist=True)
+        lrn.train_epoch(loader[:1], lr=1e-3, epoch=2)
+        w1 = ds.mlp_head[1].weight.detach().clone()
+        lrn.save_checkpoint(epoch=2, checkpoints_dir=d, is_best_epoch=False, save_extra_hist=True)
+        lrn.ensembling(d, [1, 2])
+        assert torch.allclose(ds.mlp_head[1].weight.detach(), 0.5 * (w0 + w1), atol=1e-7)
+        ens = torch.load(os.path.join(d, "ensemble_model.tar"), weights_only=False)
+        assert ens["epoch"] == [1, 2] and "spat_encoder.embed.layers.0.sequential.4.weight" in ens["model"]
+        # a fresh downstream model picks up only matching keys and freezes them
+        ds2 = model.SARSSL(sig_shape=(256, 64, 2, 2), pretrain=False, device="cuda:0", downstream_token="all", downstream_head="mlp",
+                           downstream_embed="spat", downstream_dlabel=1)
+        lrn2 = learner.STFTLearner(ds2, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task="TDOA")
+        lrn2.cuda()
+        lrn2.load_checkpoint_best(d, as_all_state=False, param_frozen=True)
+        assert all(not p.requires_grad for p in ds2.parameters())
+    finally:
+        runtime.set_precision("bf16")
+
+
+def test_run_downstream_entry_point_finetunes_from_a_pretrain_checkpoint(tmp_path):
+    """BASELINE config 4 plumbing: a pretraining checkpoint (reference file layout) -> `run_downstream.py --ds-train --simu-exp
+    --ds-trainmode finetune --ds-task TDOA` on WAV + *_info.npz annotation files -> per-epoch log, ensemble and result .mat."""
+    import subprocess
+    import sys
+    import scipy.io
+    from conftest import ROOT
+    from sar_ssl_amd import dataset, model, synth
+    work = tmp_path / "work"
+    rng = np.random.default_rng(3)
+    for sub, n, base in (("train/R1", 8, 0), ("val", 4, 100), ("test", 4, 200)):
+        d = work / "SAR-SSL" / "data" / "MicSig" / "simu_ds" / sub
+        d.mkdir(parents=True)
+        pcm = synth.to_pcm16(synth.make_batch(base, n))[:, :20000]
+        for i in range(n):
+            dataset.write_wav_pcm16(str(d / ("%d.wav" % i)), pcm[i])
+            np.savez(str(d / ("%d_info.npz" % i)), TDOA=np.float64(rng.uniform(-5e-4, 5e-4)), T60_edc=np.float64(0.5), DRR=np.float64(1.0),
+                     C50=np.float64(2.0), room_sz=np.array([4.0, 5.0, 3.0]))
+    # pretraining checkpoint in the reference's layout (encoders + decoder; the downstream model picks the encoder keys)
+    pre = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    ck = work / "SAR-SSL" / "exp" / "pretrain" / "t1"
+    ck.mkdir(parents=True)
+    torch.save({"epoch": 3, "max_score": -1.0, "model": pre.state_dict()}, str(ck / "best_model.tar"))
+    cmd = [sys.executable, os.path.join(ROOT, "run_downstream.py"), "--ds-train", "--simu-exp", "--ds-trainmode", "finetune", "--ds-task", "TDOA",
+           "--ds-nsimroom", "32", "--gpu-id", "0,", "--work-dir", str(work), "--time", "t1", "--workers", "2", "--ds-nepoch", "2",
+           "--ds-num", "8", "--ds-lr-set", "0.0001", "--ds-bs-set", "4", "--ds-eval-num", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    tdir = work / "SAR-SSL" / "exp" / "TDOA" / "t1"
+    runs = [p for p in tdir.iterdir() if p.is_dir()]
+    assert len(runs) == 1 and runs[0].name == "finetune-all-mlp-8-0.0001-4-0-spat-sim_R32"
+    recs = [json.loads(l) for l in open(runs[0] / "scalars.jsonl").read().strip().splitlines()]
+    assert [r_["epoch"] for r_ in recs] == [1, 2] and all(np.isfinite(r_["loss_val"]) and np.isfinite(r_["metric_test"]) for r_ in recs)
+    assert (runs[0] / "ensemble_model.tar").exists() and (runs[0] / "best_model.tar").exists()
+    mats = [p for p in tdir.iterdir() if p.name.endswith("-lr_bs_tri_result.mat")]
+    assert len(mats) == 1
+    res = scipy.io.loadmat(str(mats[0]))
+    assert res["val_metrics"].shape == (1, 1, 1) and np.isfinite(res["test_metrics"]).all()

@@ -134,6 +134,49 @@ def test_f7_downstream():
     _close(emb, z["embed"], 5e-4, 1e-5)
 
 
+@pytest.mark.parametrize("mode", ["finetune", "lineareval"])
+def test_f9_downstream_training_steps(mode):
+    """Three TDOA fine-tuning iterations of the oracle against the real reference's."""
+    from sar_ssl_amd import synth
+    z = _npz("f9_downstream_train.npz")
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["downstream"]
+    sd = recipes.recipe_state_dict(man, int(z["weight_seed"]))
+    B, lr = int(z["B"]), float(z["lr"])
+    n = z[mode + ".loss"].shape[0]
+    pool = torch.from_numpy(synth.make_batch(int(z["sig_seed"]), n * B))[:, :16640].contiguous()
+    tdoa = torch.from_numpy(z["tdoa"])
+    frozen = ("spec_encoder.", "spat_encoder.") if mode == "lineareval" else ()
+    state = {}
+    for s_ in range(n):
+        loss, metric, pred, emb = orc.downstream_train_step(pool[s_ * B:(s_ + 1) * B], tdoa[s_ * B:(s_ + 1) * B], sd, state, lr,
+                                                            embed_use="spat", p_drop=0.0, frozen=frozen)
+        assert abs(loss - z[mode + ".loss"][s_]) <= 2e-3 * abs(z[mode + ".loss"][s_]), (s_, loss, z[mode + ".loss"][s_])
+        assert abs(metric - z[mode + ".metric"][s_]) <= 2e-3 * abs(z[mode + ".metric"][s_])
+        _close(pred, z[mode + ".pred"][s_], 2e-3, 1e-4)
+        if s_ == 0:
+            _close(emb, z[mode + ".embed0"], 5e-4, 1e-5)
+            g = state["last_grads"]
+            for k in man:
+                key = "%s.gradnorm.%s" % (mode, k)
+                if key not in z.files:
+                    continue
+                ref = float(z[key])
+                if ref < 0:                                        # frozen or unused (spec branch with embed 'spat'): no gradient
+                    assert k not in g or float(g[k].abs().max()) == 0.0
+                else:
+                    got = float(g[k].double().norm())
+                    assert abs(got - ref) <= 2e-3 * ref + 1e-6 * max(1.0, ref) + 2e-4, (k, got, ref)
+    # eval-mode pass over the same batches = what Learner.test_epoch averages (after the three updates above the
+    # reference's test_epoch ran on its own train_epoch result, which took the same three steps)
+    lo = me = 0.0
+    for s_ in range(n):
+        l, m, _, _ = orc.downstream_eval_step(pool[s_ * B:(s_ + 1) * B], tdoa[s_ * B:(s_ + 1) * B], sd, "spat")
+        lo += l / n; me += m / n
+    assert abs(lo - z[mode + ".test_epoch"][0]) <= 3e-3 * z[mode + ".test_epoch"][0]
+    assert abs(me - z[mode + ".test_epoch"][1]) <= 3e-3 * z[mode + ".test_epoch"][1]
+    assert abs(np.mean(z[mode + ".loss"]) - z[mode + ".train_epoch"][0]) <= 1e-3 * z[mode + ".train_epoch"][0]
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_f3_fullsize_loss_pred_grads(mode):
     z = _npz("f3_fullsize.npz")
