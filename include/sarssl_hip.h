@@ -22,6 +22,10 @@ int sarssl_device_info(int device, char* name_out, int name_len, int* cu_count, 
  *      U: workspace (B, nch, 257, nt, 2) f32; magsum: workspace f64[B]; out: (B*(nch-1), 2, 256, nt, 2) f32. */
 int sarssl_stft_frontend(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft,
                          int nt, float eps, float* U, double* magsum, float* out, void* stream);
+/*      pair_mode 0 = AddChToBatch 'M' (as above), 1 = 'MM' (code/common/utils_module.py:136-143): all nch(nch-1)/2 pairs,
+ *      out: (B*npair, 2, 256, nt, 2). */
+int sarssl_stft_frontend_pairs(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft,
+                               int nt, float eps, int pair_mode, float* U, double* magsum, float* out, void* stream);
 /*      out: complex64 (B, 257, nt, nch) interleaved, the STFT.forward return value. */
 int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft, int nt,
                     float* U, double* magsum, float* out, void* stream);

@@ -263,6 +263,51 @@ def f9_downstream_train(ref_model, ref_learner, nstep=3, B=4):
     np.savez_compressed(os.path.join(GOLD, "f9_downstream_train.npz"), **store)
 
 
+def f10_multich(ref_model, ref_learner):
+    """SURVEY.md 8f-2 / BASELINE config 5: (a) ch_mode 'MM' pairing of a 4-mic signal; (b) one 4-mic x 160 000-sample segment
+    -> 3 mic pairs at T = 624 through the pretraining forward/backward (train mode, dropout off, replayed masks);
+    (c) SARSSL_MultiCH (code/model.py:793-821) eval forward on 3 pairs."""
+    store = {}
+    dummy = ref_model.SARSSL(sig_shape=(256, 16, 2, 2), pretrain=True, device="cpu")
+    lrn_mm = ref_learner.STFTLearner(dummy, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="MM")
+    lrn_mm.cpu()
+    small4 = recipes.recipe_signal(2, 1536, 4, seed=2)
+    store["mm_small4_out"] = lrn_mm.data_preprocess(small4, None)[0].numpy()
+    # (b)
+    T = 624
+    net = ref_model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device="cpu")
+    man = load_recipe(net, 0)
+    set_dropout(net, 0.0)
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    sig = recipes.recipe_signal(1, 160000, 4, seed=21)
+    x, = lrn.data_preprocess(sig, None)
+    assert tuple(x.shape) == (3, 2, 256, T, 2), x.shape
+    net.train()
+    net.zero_grad()
+    random.seed(777)
+    idx, ch = orc.gen_masks(3, T, T // 2, 2, random)
+    random.seed(777)
+    loss, diff, vis = net(x)
+    loss.backward()
+    pred_patch = vis["pred"].permute(0, 2, 1, 3, 4).contiguous()
+    sidx = sample_idx(pred_patch.numel(), 2048, 17)
+    store.update({"c5.loss": np.float64(loss.item()), "c5.diff": np.float64(diff.item()), "c5.pred_idx": sidx,
+                  "c5.pred_vals": pred_patch.reshape(-1)[sidx].numpy(), "c5.pred_absmax": np.float64(pred_patch.abs().max()),
+                  "c5.mask_idx": idx.numpy(), "c5.mask_ch": ch.numpy(),
+                  "c5.gradnorm_json": np.array(json.dumps({k: float(p.grad.double().norm()) for k, p in net.named_parameters()}))})
+    print("config5: loss", loss.item(), "diff", diff.item(), flush=True)
+    # (c)
+    mch = ref_model.SARSSL_MultiCH(sig_shape=(256, 32, 2, 2), nmic_pair=3, task="TDOA", device="cpu")
+    man_m = load_recipe(mch, 11)
+    mch.eval()
+    xm = torch.from_numpy(np.random.default_rng(5).standard_normal((6, 2, 256, 32, 2)).astype(np.float32))
+    with torch.no_grad():
+        pred, emb = mch(xm)
+    store.update({"mch.manifest_json": np.array(json.dumps(man_m)), "mch.pred": pred.numpy(), "mch.embed": emb.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "f10_multich.npz"), **store)
+
+
 def f8_schedule():
     sys.path.insert(0, ref_shim.REF_CODE)
     from common.utils import create_learning_rate_schedule
@@ -306,7 +351,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_learner, ref_um = ref_shim.load()
-    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8", "f9"]
+    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8", "f9", "f10"]
     if "manifest" in todo: f_manifest(ref_model)
     if "f1" in todo: f1_frontend(ref_learner, ref_model)
     if "f2" in todo: f2_blocks(ref_model)
@@ -315,5 +360,6 @@ if __name__ == "__main__":
     if "f7" in todo: f7_downstream(ref_model)
     if "f8" in todo: f8_schedule()
     if "f9" in todo: f9_downstream_train(ref_model, ref_learner)
+    if "f10" in todo: f10_multich(ref_model, ref_learner)
     if a.curve: f5_curve(ref_model, ref_learner)
     print("golden vectors written to", GOLD)

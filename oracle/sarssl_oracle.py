@@ -374,3 +374,14 @@ def downstream_eval_step(mic_sig, tdoa, sd, embed_use="spat", fs=16000):
         tar = tdoa.reshape(-1, 1).float() * fs
         pred, emb = sarssl_downstream_forward(x, sd, embed_use=embed_use, train=False)
         return float(F.mse_loss(pred, tar)), float((pred - tar).abs().mean()), pred, emb
+
+
+def sarssl_multich_forward(x, sd, nmic_pair):
+    """``SARSSL_MultiCH.forward`` (code/model.py:808-821), eval mode: spat encoder of the single-pair model on every pair ->
+    mean over frames -> concatenate the pairs of a segment -> LayerNorm, Linear, ReLU, Linear head."""
+    v = x.permute(0, 3, 2, 4, 1)
+    e = embed_encoder(v, sd, "model_sch.spat_encoder.", 3, False).mean(dim=1)
+    e = e.reshape(-1, nmic_pair * e.shape[-1])
+    h = F.layer_norm(e, (e.shape[-1],), sd["head_mch.0.weight"], sd["head_mch.0.bias"], EPS_LN)
+    h = F.relu(F.linear(h, sd["head_mch.1.weight"], sd["head_mch.1.bias"]))
+    return F.linear(h, sd["head_mch.3.weight"], sd["head_mch.3.bias"]), e

@@ -136,19 +136,26 @@ __global__ __launch_bounds__(1024) void stft_pair_kernel(const TIn* __restrict__
     }
 }
 
-// out[(b*(nch-1)+p), mic, f(256), t, reim] = U[b, mic ? p+1 : 0, f+1, t, reim] / (mean|X_ch0| + eps)
+// out[(b*npair+p), mic, f(256), t, reim] = U[b, ch(p, mic), f+1, t, reim] / (mean|X_ch0| + eps)
+// pair_mode 0 ('M'): pair p = (0, p+1); pair_mode 1 ('MM'): all i<j pairs in the order (0,1),(0,2),..,(1,2),..
 __global__ void frontend_pack_kernel(const float* __restrict__ U, const double* __restrict__ magsum, int nb, int nch,
-                                     int nt, float eps, float* __restrict__ out) {
+                                     int nt, float eps, int pair_mode, int npair, float* __restrict__ out) {
     const long per_ch = (long)256 * nt;           // float2 elements per (pair, mic)
-    const long total = (long)nb * (nch - 1) * 2 * per_ch;
+    const long total = (long)nb * npair * 2 * per_ch;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long e = i % per_ch;
         const long q = i / per_ch;
         const int mic = (int)(q & 1);
         const long bp = q >> 1;
-        const int p = (int)(bp % (nch - 1));
-        const int b = (int)(bp / (nch - 1));
-        const int c = mic ? p + 1 : 0;
+        const int p = (int)(bp % npair);
+        const int b = (int)(bp / npair);
+        int c;
+        if (pair_mode == 0) c = mic ? p + 1 : 0;
+        else {
+            int i0 = 0, rem = p;
+            while (rem >= nch - 1 - i0) { rem -= nch - 1 - i0; ++i0; }
+            c = mic ? i0 + 1 + rem : i0;
+        }
         const float scale = 1.0f / ((float)(magsum[b] / ((double)NBIN * nt)) + eps);
         const float2 x = *(const float2*)(U + ((((long)b * nch + c) * NBIN) * nt + nt + e) * 2);   // skip DC row
         *(float2*)(out + i * 2) = make_float2(x.x * scale, x.y * scale);
@@ -181,19 +188,27 @@ static int launch_stft(const void* sig, int sig_dtype, int nb, long nsample, int
 }
 
 // sig: (B, nsample, nch) f32 or int16 PCM.  U: workspace (B, nch, 257, nt, 2) f32.  magsum: (B) f64 workspace.
-// out: (B*(nch-1), 2, 256, nt, 2) f32 = data_preprocess output for ch_mode 'M'.
-extern "C" int sarssl_stft_frontend(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop,
-                                    int nfft, int nt, float eps, float* U, double* magsum, float* out, void* stream) {
+// out: (B*npair, 2, 256, nt, 2) f32 = data_preprocess output; pair_mode 0 = ch_mode 'M' (npair = nch-1: mic 0 with every
+// other mic), 1 = ch_mode 'MM' (npair = nch(nch-1)/2: every mic pair).
+extern "C" int sarssl_stft_frontend_pairs(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop,
+                                          int nfft, int nt, float eps, int pair_mode, float* U, double* magsum, float* out,
+                                          void* stream) {
     SARSSL_REQUIRE(win_len == NFFT && nfft == NFFT && hop == HOP, "sarssl_stft_frontend(only win=nfft=512, hop=256)");
     SARSSL_REQUIRE(nch >= 2 && nb > 0 && nt > 0 && (long)(nt - 1) * HOP + NFFT <= nsample, "sarssl_stft_frontend");
+    SARSSL_REQUIRE(pair_mode == 0 || pair_mode == 1, "sarssl_stft_frontend(pair_mode 0 'M' | 1 'MM')");
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_stft(sig, sig_dtype, nb, nsample, nch, nt, U, magsum, st);
     if (rc) return rc;
-    const long total = (long)nb * (nch - 1) * 2 * 256 * nt;
+    const int npair = pair_mode == 0 ? nch - 1 : nch * (nch - 1) / 2;
+    const long total = (long)nb * npair * 2 * 256 * nt;
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-    frontend_pack_kernel<<<blocks, 256, 0, st>>>(U, magsum, nb, nch, nt, eps, out);
+    frontend_pack_kernel<<<blocks, 256, 0, st>>>(U, magsum, nb, nch, nt, eps, pair_mode, npair, out);
     SARSSL_CHECK_LAUNCH("frontend_pack_kernel");
     return 0;
+}
+extern "C" int sarssl_stft_frontend(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop,
+                                    int nfft, int nt, float eps, float* U, double* magsum, float* out, void* stream) {
+    return sarssl_stft_frontend_pairs(sig, sig_dtype, nb, nsample, nch, win_len, hop, nfft, nt, eps, 0, U, magsum, out, stream);
 }
 
 // out: complex64 (B, 257, nt, nch) as interleaved f32 pairs.

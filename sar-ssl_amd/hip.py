@@ -106,17 +106,20 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     return out
 
 
-def stft_frontend(sig, eps=1e-6, win_len=512, hop=256, nfft=512):
-    """(B, nsample, nch) f32|int16 -> (B*(nch-1), 2, nfft/2, nt, 2) f32 (data_preprocess output, ch_mode 'M')."""
+def stft_frontend(sig, eps=1e-6, win_len=512, hop=256, nfft=512, ch_mode="M"):
+    """(B, nsample, nch) f32|int16 -> (B*npair, 2, nfft/2, nt, 2) f32 (data_preprocess output); ch_mode 'M' pairs mic 0 with
+    every other mic (npair = nch-1), 'MM' takes every mic pair (npair = nch(nch-1)/2)."""
     _need_cuda(sig)
     sig = sig.contiguous()
     nb, nsample, nch = sig.shape
     nt = (nsample - win_len) // hop + 1
+    mode = {"M": 0, "MM": 1}[ch_mode]
+    npair = nch - 1 if mode == 0 else nch * (nch - 1) // 2
     U = torch.empty((nb, nch, nfft // 2 + 1, nt, 2), dtype=torch.float32, device=sig.device)
     magsum = torch.empty((nb,), dtype=torch.float64, device=sig.device)
-    out = torch.empty((nb * (nch - 1), 2, nfft // 2, nt, 2), dtype=torch.float32, device=sig.device)
-    _lib.call("sarssl_stft_frontend", _p(sig), c_int(dt(sig)), c_int(nb), c_long(nsample), c_int(nch), c_int(win_len),
-              c_int(hop), c_int(nfft), c_int(nt), c_float(eps), _p(U), _p(magsum), _p(out), _stream())
+    out = torch.empty((nb * npair, 2, nfft // 2, nt, 2), dtype=torch.float32, device=sig.device)
+    _lib.call("sarssl_stft_frontend_pairs", _p(sig), c_int(dt(sig)), c_int(nb), c_long(nsample), c_int(nch), c_int(win_len),
+              c_int(hop), c_int(nfft), c_int(nt), c_float(eps), c_int(mode), _p(U), _p(magsum), _p(out), _stream())
     return out
 
 

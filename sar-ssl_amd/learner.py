@@ -260,8 +260,8 @@ class STFTLearner(Learner):
 
     def __init__(self, model, win_len, win_shift_ratio, nfft, fre_used_ratio, fs, mel_scale=False, task=None, ch_mode="M"):
         super().__init__(model)
-        if mel_scale or fre_used_ratio != 1 or ch_mode != "M":
-            raise NotImplementedError("only the pretraining front-end (linear frequency, bins 1..nfft/2, ch_mode 'M') is implemented")
+        if mel_scale or fre_used_ratio != 1 or ch_mode not in ("M", "MM"):
+            raise NotImplementedError("only the pretraining front-end (linear frequency, bins 1..nfft/2, ch_mode 'M' | 'MM') is implemented")
         self.ch_mode = ch_mode
         self.win_len, self.win_shift_ratio, self.nfft = win_len, win_shift_ratio, nfft
         self.stft = at_module.STFT(win_len=win_len, win_shift_ratio=win_shift_ratio, nfft=nfft)
@@ -280,7 +280,7 @@ class STFTLearner(Learner):
             if sig.dtype not in (torch.float32, torch.int16):
                 sig = sig.float()
             data += [hip.stft_frontend(sig, eps=eps, win_len=self.win_len, hop=int(self.win_len * self.win_shift_ratio),
-                                       nfft=self.nfft)]
+                                       nfft=self.nfft, ch_mode=self.ch_mode)]
         if gt_batch is not None:
             gt = gt_batch[self.task].to(self.device)
             data += [self.get_tar_batch(gt)]

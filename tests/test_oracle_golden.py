@@ -200,3 +200,29 @@ def test_f3_fullsize_loss_pred_grads(mode):
         for k in ("spec_encoder.patch_embed.4.running_mean", "spec_encoder.patch_embed.4.running_var",
                   "spat_encoder.embed.layers.1.sequential.2.module.sequential.5.running_var"):
             _close(sd[k], z["train.after." + k], 1e-4, 1e-6)
+
+
+def test_f10_multichannel_pairs_config5_and_multich_head():
+    """'MM' pairing, a 4-mic 10 s segment (3 pairs, T = 624) through forward/backward, SARSSL_MultiCH."""
+    z = _npz("f10_multich.npz")
+    _close(orc.data_preprocess(recipes.recipe_signal(2, 1536, 4, seed=2), ch_mode="MM"), z["mm_small4_out"], 1e-5, 1e-6)
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    sd = recipes.recipe_state_dict(man, 0)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if orc.is_param(k)}
+    x = orc.data_preprocess(recipes.recipe_signal(1, 160000, 4, seed=21))
+    assert tuple(x.shape) == (3, 2, 256, 624, 2)
+    loss, diff, aux = orc.sarssl_pretrain_forward(x, sd, torch.from_numpy(z["c5.mask_idx"]), torch.from_numpy(z["c5.mask_ch"]),
+                                                  train=True, p_drop=0.0)
+    loss.backward()
+    assert abs(loss.item() / float(z["c5.loss"]) - 1) < 1e-4 and abs(diff.item() / float(z["c5.diff"]) - 1) < 1e-5
+    _close(aux["pred"].detach().reshape(-1)[torch.from_numpy(z["c5.pred_idx"])], z["c5.pred_vals"], 2e-4, 1e-5)
+    gn = json.loads(str(z["c5.gradnorm_json"]))
+    for k, p in params.items():
+        assert abs(p.grad.double().norm().item() - gn[k]) <= 2e-3 * gn[k] + 1e-7, k
+    man_m = json.loads(str(z["mch.manifest_json"]))
+    sdm = recipes.recipe_state_dict(man_m, 11)
+    xm = torch.from_numpy(np.random.default_rng(5).standard_normal((6, 2, 256, 32, 2)).astype(np.float32))
+    with torch.no_grad():
+        pred, emb = orc.sarssl_multich_forward(xm, sdm, 3)
+    _close(pred, z["mch.pred"], 5e-4, 1e-5)
+    _close(emb, z["mch.embed"], 5e-4, 1e-5)
