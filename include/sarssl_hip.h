@@ -29,6 +29,12 @@ int sarssl_stft_frontend_pairs(const void* sig, int sig_dtype, int nb, long nsam
 /*      out: complex64 (B, 257, nt, nch) interleaved, the STFT.forward return value. */
 int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft, int nt,
                     float* U, double* magsum, float* out, void* stream);
+/* ---- inverse STFT: code/common/utils_module.py:74-113 (ISTFT.forward = torch.istft, rectangular window, center = inv).
+ *      spec: complex64 (B, 257, nt, nch) interleaved; sig: (B, nsample, nch) f32, nsample = (nt+1)*hop (center 0) or
+ *      (nt-1)*hop (center 1); frames_ws: sarssl_istft_workspace_bytes(nb, nch, nt) bytes. */
+long sarssl_istft_workspace_bytes(int nb, int nch, int nt);
+int sarssl_istft(const float* spec, int nb, int nch, int nt, int win_len, int hop, int nfft, int center, float* frames_ws,
+                 float* sig, void* stream);
 
 /* ---- generic batched MFMA GEMM with fused epilogue: nn.Linear / Conv1d(k=1) / patch conv / attention bmm
  *      (code/common/conformer/modules.py:35-48, feed_forward.py:47-54, attention.py:82-103, convolution.py:138,143,

@@ -308,6 +308,36 @@ def f10_multich(ref_model, ref_learner):
     np.savez_compressed(os.path.join(GOLD, "f10_multich.npz"), **store)
 
 
+def f11_eval_export(ref_model, ref_learner, ref_um):
+    """ISTFT (both modes) on random spectra, and pretest_epoch(return_eval=True) -> pretrain_evaluate of the real
+    reference on one eval batch (PESQ replaced by a constant: torchmetrics/pesq are not installed)."""
+    g = np.random.default_rng(31)
+    spec = torch.from_numpy(g.standard_normal((2, 257, 9, 3, 2)).astype(np.float32))
+    spec_c = torch.view_as_complex(spec)
+    store = {"spec": spec.numpy()}
+    for inv in (False, True):
+        m = ref_um.ISTFT(win_len=512, win_shift_ratio=0.5, nfft=512, inv=inv)
+        store["istft_inv%d" % int(inv)] = m(spec_c).numpy()
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    load_recipe(net, 0)
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    ref_learner.perceptual_evaluation_speech_quality = lambda *a, **k: torch.tensor(1.0)
+    sig = recipes.recipe_signal(2, 65792, 2, seed=3)
+    random.seed(2468)
+    idx, ch = orc.gen_masks(2, 256, 128, 2, random)
+    random.seed(2468)
+    loss, diff, vis, res = lrn.pretest_epoch([[sig]], return_diff=True, return_eval=True)
+    sidx = sample_idx(res["sig_pred"].numel(), 4096, 23)
+    store.update({"eval.loss": np.float64(loss), "eval.diff": np.float64(diff), "eval.mask_idx": idx.numpy(), "eval.mask_ch": ch.numpy(),
+                  "eval.sig_idx": sidx, "eval.sig_pred": res["sig_pred"].reshape(-1)[sidx].numpy(),
+                  "eval.sig_tar": res["sig_tar"].reshape(-1)[sidx].numpy(), "eval.sig_shape": np.array(res["sig_pred"].shape),
+                  "eval.mse": np.float64(res["mse"]), "eval.mse_mask": np.float64(res["mse_mask"]),
+                  "eval.mse_mask_ch": np.float64(res["mse_mask_ch"])})
+    print("eval: loss", loss, "mse", float(res["mse"]), "mse_mask", float(res["mse_mask"]), flush=True)
+    np.savez_compressed(os.path.join(GOLD, "f11_eval_export.npz"), **store)
+
+
 def f8_schedule():
     sys.path.insert(0, ref_shim.REF_CODE)
     from common.utils import create_learning_rate_schedule
@@ -351,7 +381,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_learner, ref_um = ref_shim.load()
-    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8", "f9", "f10"]
+    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8", "f9", "f10", "f11"]
     if "manifest" in todo: f_manifest(ref_model)
     if "f1" in todo: f1_frontend(ref_learner, ref_model)
     if "f2" in todo: f2_blocks(ref_model)
@@ -361,5 +391,6 @@ if __name__ == "__main__":
     if "f8" in todo: f8_schedule()
     if "f9" in todo: f9_downstream_train(ref_model, ref_learner)
     if "f10" in todo: f10_multich(ref_model, ref_learner)
+    if "f11" in todo: f11_eval_export(ref_model, ref_learner, ref_um)
     if a.curve: f5_curve(ref_model, ref_learner)
     print("golden vectors written to", GOLD)

@@ -385,3 +385,42 @@ def sarssl_multich_forward(x, sd, nmic_pair):
     h = F.layer_norm(e, (e.shape[-1],), sd["head_mch.0.weight"], sd["head_mch.0.bias"], EPS_LN)
     h = F.relu(F.linear(h, sd["head_mch.1.weight"], sd["head_mch.1.bias"]))
     return F.linear(h, sd["head_mch.3.weight"], sd["head_mch.3.bias"]), e
+
+
+# --------------------------------------------------------------------------------------
+# Eval / export path        (code/common/utils_module.py:74-113, code/learner.py:574-618)
+# --------------------------------------------------------------------------------------
+def istft(spec, win_len=512, win_shift_ratio=0.5, nfft=512, inv=False):
+    """``ISTFT.forward`` (utils_module.py:91-113): per channel ``torch.istft(n_fft, hop, win_length, window=None,
+    center=inv)``.  Restated without torch.istft: irfft of every frame (imaginary parts of the DC / Nyquist bins are
+    ignored by the real inverse transform), overlap-add, division by the rectangular window's envelope (number of
+    frames covering a sample); ``inv`` (center=True) drops nfft/2 samples at both ends.
+    spec complex (B, nfft/2+1, nt, nch) -> (B, nsample, nch) float32."""
+    hop = int(win_len * win_shift_ratio)
+    nb, nf, nt, nch = spec.shape
+    frames = torch.fft.irfft(spec.permute(0, 3, 2, 1).to(torch.complex64), n=nfft, dim=-1)      # (B, nch, nt, nfft)
+    full = nfft + hop * (nt - 1)
+    out = torch.zeros((nb, nch, full), dtype=torch.float32)
+    env = torch.zeros(full, dtype=torch.float32)
+    for t in range(nt):
+        out[:, :, t * hop:t * hop + nfft] += frames[:, :, t]
+        env[t * hop:t * hop + nfft] += 1.0
+    out = out / env
+    if inv:
+        out = out[:, :, nfft // 2: nfft // 2 + (nt - 1) * hop]
+    return out.permute(0, 2, 1).contiguous()
+
+
+def pretrain_evaluate(pred, gt, mask):
+    """``STFTLearner.pretrain_evaluate`` (learner.py:574-618) without the PESQ scores (third-party torchmetrics / pesq,
+    absent here: that part of the path is 'parity unpinned').  pred, gt (nb,nf,nt,nreim,nch); mask (nb,nf,nt,nch), 0 = masked."""
+    def to_sig(v):
+        st = torch.view_as_complex(v.permute(0, 1, 2, 4, 3).contiguous())
+        st = torch.cat((torch.zeros_like(st[:, 0:1]), st), dim=1)
+        sig = istft(st)
+        return sig / torch.max(sig)
+    mask_dense = mask[:, :, :, None, :].tile(1, 1, 1, 2, 1)
+    diff = (pred - gt) ** 2
+    diff_mask = diff * (1 - mask_dense)
+    return {"sig_pred": to_sig(pred), "sig_tar": to_sig(gt), "mse": torch.mean(diff),
+            "mse_mask": torch.sum(diff_mask) / torch.sum(1 - mask_dense), "mse_mask_ch": torch.mean(torch.sum(diff_mask, dim=4))}

@@ -1,5 +1,5 @@
 """Front-end transform and patch/mask plumbing with the reference's interfaces
-(code/common/utils_module.py: STFT :28-72, AddChToBatch :116-148, PatchSplit :175-207, PatchRecover :210-244,
+(code/common/utils_module.py: STFT :28-72, ISTFT :74-113, AddChToBatch :116-148, PatchSplit :175-207, PatchRecover :210-244,
 PatchMask :247-308)."""
 import random
 
@@ -23,6 +23,19 @@ class STFT(nn.Module):
 
     def forward(self, signal):
         return hip.stft_raw(signal, self.win_len, int(self.win_len * self.win_shift_ratio), self.nfft)
+
+
+class ISTFT(nn.Module):
+    """stft complex (nbatch, nf = nfft/2+1, nt, nch) -> signal (nbatch, nsample, nch): ``torch.istft`` with the default
+    rectangular window, center = ``inv`` (code/common/utils_module.py:74-113), computed by the paired inverse FFT + overlap-add
+    kernels in csrc/stft.hip.  nsample = (nt+1)*hop (inv=False) or (nt-1)*hop (inv=True)."""
+
+    def __init__(self, win_len, win_shift_ratio, nfft, inv=False):
+        super().__init__()
+        self.win_len, self.win_shift_ratio, self.nfft, self.inv = win_len, win_shift_ratio, nfft, inv
+
+    def forward(self, stft):
+        return hip.istft(stft, center=self.inv, win_len=self.win_len, hop=int(self.win_len * self.win_shift_ratio), nfft=self.nfft)
 
 
 class AddChToBatch(nn.Module):

@@ -43,30 +43,10 @@ __device__ __forceinline__ cpx twiddle(int num, int den) {
 __device__ __forceinline__ float ld_sample(const float* p) { return *p; }
 __device__ __forceinline__ float ld_sample(const int16_t* p) { return (float)(*p) * (1.0f / 32768.0f); }
 
-// U: (B, nch, 257, nt, 2) f32 unnormalised spectrum; magsum[b] += sum |X_ch0| over 257 bins x nt frames
-template <typename TIn>
-__global__ __launch_bounds__(1024) void stft_pair_kernel(const TIn* __restrict__ sig, long nsample, int nch, int nt,
-                                                         float* __restrict__ U, double* __restrict__ magsum) {
-    __shared__ float2 Z[FR_PER_BLOCK * ZSTRIDE];
-    __shared__ float red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x * FR_PER_BLOCK + wave;
-    const int pair = blockIdx.y, b = blockIdx.z;
-    const int c0 = pair * 2, c1 = pair * 2 + 1;
-    float2* zb = Z + wave * ZSTRIDE;
-    const bool live = t < nt;
-
-    cpx v[8];
+// One wave transforms one 512-point frame: in v[j] = z[lane + 64 j], out zb[k] in natural order.  Three radix-8 passes with
+// two in-LDS exchanges (n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3).  Every thread of the workgroup must call it (barriers).
+__device__ __forceinline__ void fft512_wave(cpx (&v)[8], float2* zb, int lane, bool live) {
     if (live) {
-        const TIn* base = sig + ((long)b * nsample + (long)t * HOP) * nch;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int n = lane + 64 * j;
-            const float w = 0.5f - 0.5f * cospif((float)n * (1.0f / 256.0f));     // periodic Hann, N = 512
-            const float re = ld_sample(base + (long)n * nch + c0);
-            const float im = (c1 < nch) ? ld_sample(base + (long)n * nch + c1) : 0.f;
-            v[j] = {re * w, im * w};
-        }
         dft8(v);                                                                   // over n1
 #pragma unroll
         for (int k1 = 0; k1 < 8; ++k1) {
@@ -103,6 +83,34 @@ __global__ __launch_bounds__(1024) void stft_pair_kernel(const TIn* __restrict__
         for (int k3 = 0; k3 < 8; ++k3) zb[lane + 64 * k3] = make_float2(v[k3].x, v[k3].y);
     }
     __syncthreads();
+}
+
+// U: (B, nch, 257, nt, 2) f32 unnormalised spectrum; magsum[b] += sum |X_ch0| over 257 bins x nt frames
+template <typename TIn>
+__global__ __launch_bounds__(1024) void stft_pair_kernel(const TIn* __restrict__ sig, long nsample, int nch, int nt,
+                                                         float* __restrict__ U, double* __restrict__ magsum) {
+    __shared__ float2 Z[FR_PER_BLOCK * ZSTRIDE];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x * FR_PER_BLOCK + wave;
+    const int pair = blockIdx.y, b = blockIdx.z;
+    const int c0 = pair * 2, c1 = pair * 2 + 1;
+    float2* zb = Z + wave * ZSTRIDE;
+    const bool live = t < nt;
+
+    cpx v[8];
+    if (live) {
+        const TIn* base = sig + ((long)b * nsample + (long)t * HOP) * nch;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = lane + 64 * j;
+            const float w = 0.5f - 0.5f * cospif((float)n * (1.0f / 256.0f));     // periodic Hann, N = 512
+            const float re = ld_sample(base + (long)n * nch + c0);
+            const float im = (c1 < nch) ? ld_sample(base + (long)n * nch + c1) : 0.f;
+            v[j] = {re * w, im * w};
+        }
+    }
+    fft512_wave(v, zb, lane, live);
 
     // separate the two real channels and write (c, f, t, reim); 16 frames = one 128-byte line per (c, f)
     const int tl = tid & 15, fo = tid >> 4;
@@ -223,5 +231,88 @@ extern "C" int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsam
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
     stft_permute_kernel<<<blocks, 256, 0, st>>>(U, nb, nch, nt, out);
     SARSSL_CHECK_LAUNCH("stft_permute_kernel");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ inverse STFT
+// ISTFT.forward (code/common/utils_module.py:91-113) = torch.istft(n_fft=512, hop=256, win_length=512, window=None (ones),
+// center=False | True, onesided): per frame a real inverse FFT-512 (imaginary parts of DC / Nyquist ignored), overlap-add,
+// division by the window envelope (= number of frames covering the sample).  Two channels share one complex FFT:
+// Z = X_a + i X_b (Hermitian-extended), z = IFFT(Z) = conj(FFT(conj(Z)))/N, x_a = Re z, x_b = Im z.
+// spec: (B, 257, nt, nch) complex64 interleaved; frames: workspace (B, nch, nt, 512) f32.
+__global__ __launch_bounds__(1024) void istft_frames_kernel(const float* __restrict__ spec, int nch, int nt,
+                                                            float* __restrict__ frames) {
+    __shared__ float2 Z[FR_PER_BLOCK * ZSTRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x * FR_PER_BLOCK + wave;
+    const int pair = blockIdx.y, b = blockIdx.z;
+    const int c0 = pair * 2, c1 = pair * 2 + 1;
+    float2* zb = Z + wave * ZSTRIDE;
+    const bool live = t < nt;
+    cpx v[8];
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            const int kk = k <= 256 ? k : NFFT - k;
+            const float sgn = k <= 256 ? 1.f : -1.f;                               // X[N-k] = conj(X[k])
+            const float* q = spec + ((((long)b * NBIN + kk) * nt + t) * nch) * 2;
+            float2 a = *(const float2*)(q + c0 * 2);
+            float2 c = (c1 < nch) ? *(const float2*)(q + c1 * 2) : make_float2(0.f, 0.f);
+            if (kk == 0 || kk == 256) { a.y = 0.f; c.y = 0.f; }
+            a.y *= sgn; c.y *= sgn;
+            // Z = a + i c = (a.x - c.y) + i (a.y + c.x); feed conj(Z)
+            v[j] = {a.x - c.y, -(a.y + c.x)};
+        }
+    }
+    fft512_wave(v, zb, lane, live);
+    if (live) {
+        float* o0 = frames + (((long)b * nch + c0) * nt + t) * NFFT;
+        float* o1 = frames + (((long)b * nch + c1) * nt + t) * NFFT;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = lane + 64 * j;
+            const float2 y = zb[n];
+            o0[n] = y.x * (1.0f / NFFT);
+            if (c1 < nch) o1[n] = -y.y * (1.0f / NFFT);
+        }
+    }
+}
+
+// sig[b][n][c] = (sum of the <= 2 frames covering sample n) / (their number); center: drop NFFT/2 samples at both ends
+__global__ void istft_ola_kernel(const float* __restrict__ frames, int nb, int nch, int nt, int center, long nsample,
+                                 float* __restrict__ sig) {
+    const long total = (long)nb * nsample * nch;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const long r = i / nch;
+        const long n = r % nsample;
+        const int b = (int)(r / nsample);
+        const long m = n + (center ? NFFT / 2 : 0);
+        const int t1 = (int)(m / HOP), t0 = t1 - 1;
+        const float* fb = frames + ((long)b * nch + c) * nt * NFFT;
+        float acc = 0.f, cnt = 0.f;
+        if (t1 < nt) { acc += fb[(long)t1 * NFFT + (m - (long)t1 * HOP)]; cnt += 1.f; }
+        if (t0 >= 0 && t0 < nt) { acc += fb[(long)t0 * NFFT + (m - (long)t0 * HOP)]; cnt += 1.f; }
+        sig[i] = cnt > 0.f ? acc / cnt : 0.f;
+    }
+}
+
+extern "C" long sarssl_istft_workspace_bytes(int nb, int nch, int nt) { return (long)nb * nch * nt * NFFT * sizeof(float); }
+
+// spec: (B, 257, nt, nch) complex64; sig: (B, nsample, nch) f32 with nsample = (nt+1)*256 (center = 0) or (nt-1)*256 (center = 1)
+extern "C" int sarssl_istft(const float* spec, int nb, int nch, int nt, int win_len, int hop, int nfft, int center,
+                            float* frames_ws, float* sig, void* stream) {
+    SARSSL_REQUIRE(win_len == NFFT && nfft == NFFT && hop == HOP, "sarssl_istft(only win=nfft=512, hop=256)");
+    SARSSL_REQUIRE(nb > 0 && nch >= 1 && nt >= (center ? 2 : 1), "sarssl_istft");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((nt + FR_PER_BLOCK - 1) / FR_PER_BLOCK, (nch + 1) / 2, nb);
+    istft_frames_kernel<<<grid, 1024, 0, st>>>(spec, nch, nt, frames_ws);
+    SARSSL_CHECK_LAUNCH("istft_frames_kernel");
+    const long nsample = center ? (long)(nt - 1) * HOP : (long)(nt + 1) * HOP;
+    const long total = (long)nb * nsample * nch;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    istft_ola_kernel<<<blocks, 256, 0, st>>>(frames_ws, nb, nch, nt, center, nsample, sig);
+    SARSSL_CHECK_LAUNCH("istft_ola_kernel");
     return 0;
 }

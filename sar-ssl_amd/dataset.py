@@ -73,8 +73,6 @@ class FixMicSigDataset(Dataset):
         self.files = [f for f in files if f not in dp]
         self.dataset_sz = len(self.files) if dataset_sz is None else int(np.min([len(self.files), dataset_sz]))
         self.fs, self.load_anno, self.load_dp, self.transforms, self.raw_pcm = fs, load_anno, load_dp, transforms, raw_pcm
-        if load_dp:
-            raise NotImplementedError("direct-path signals are not used on the pretraining path")
 
     def __len__(self):
         return self.dataset_sz
@@ -100,4 +98,14 @@ class FixMicSigDataset(Dataset):
             return_data += [{"TDOA": info["TDOA"].astype(np.float32), "T60": info["T60_edc"].astype(np.float32),
                              "DRR": info["DRR"].astype(np.float32), "C50": info["C50"].astype(np.float32),
                              "ABS": np.array(0.161 * vol / sur / info["T60_edc"]).astype(np.float32)}]
+        if self.load_dp:
+            dp, fs_dp = read_wav_pcm16(file_name.replace(".wav", "_dp.wav"))
+            dp_sig = dp.astype(np.float32) / 32768.0
+            if self.fs != fs_dp:
+                import scipy.signal
+                dp_sig = scipy.signal.resample_poly(dp_sig, self.fs, fs_dp)
+            if self.transforms is not None:
+                for t in self.transforms:
+                    dp_sig = t(dp_sig)
+            return_data += [dp_sig]
         return return_data

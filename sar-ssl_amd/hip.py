@@ -137,6 +137,20 @@ def stft_raw(sig, win_len=512, hop=256, nfft=512):
     return torch.view_as_complex(out)
 
 
+def istft(spec, center=False, win_len=512, hop=256, nfft=512):
+    """complex64 (B, nfft/2+1, nt, nch) -> (B, nsample, nch) f32 like ISTFT.forward (torch.istft, rectangular window)."""
+    _need_cuda(spec)
+    sp = torch.view_as_real(spec.to(torch.complex64).contiguous())
+    nb, nf, nt, nch, _ = sp.shape
+    assert nf == nfft // 2 + 1
+    nsample = (nt - 1) * hop if center else (nt + 1) * hop
+    ws = _f32ws(nb * nch * nt * nfft, spec.device, "istft")
+    sig = torch.empty((nb, nsample, nch), dtype=torch.float32, device=spec.device)
+    _lib.call("sarssl_istft", _p(sp), c_int(nb), c_int(nch), c_int(nt), c_int(win_len), c_int(hop), c_int(nfft),
+              c_int(1 if center else 0), _p(ws), _p(sig), _stream())
+    return sig
+
+
 # ------------------------------------------------------------------------------------------------
 # conv stem
 def _f32ws(n, device, tag):

@@ -98,8 +98,9 @@ class Learner(ABC):
                 n += 1
             acc = acc / max(n, 1)
             loss, diff = float(acc[0]), float(acc[1])
-        if return_eval:
-            raise NotImplementedError("pretrain_evaluate (ISTFT + PESQ) is an eval/export 'next' row (SURVEY.md 8f-3)")
+        if return_diff and return_eval:                                                          # last batch only, as in the reference
+            result_batch = self.pretrain_evaluate(pred_batch=vis_batch["pred"], gt_batch=vis_batch["tar"], mask_batch=vis_batch["mask"])
+            return loss, diff, vis_batch, result_batch
         return (loss, diff, vis_batch) if return_diff else loss
 
     # ---- supervised fine-tuning / evaluation (code/learner.py:168-269) ------------------------------------------------
@@ -265,6 +266,7 @@ class STFTLearner(Learner):
         self.ch_mode = ch_mode
         self.win_len, self.win_shift_ratio, self.nfft = win_len, win_shift_ratio, nfft
         self.stft = at_module.STFT(win_len=win_len, win_shift_ratio=win_shift_ratio, nfft=nfft)
+        self.istft = at_module.ISTFT(win_len=win_len, win_shift_ratio=win_shift_ratio, nfft=nfft, inv=False)
         self.fre_range_used = range(1, int(nfft / 2 * fre_used_ratio) + 1, 1)
         self.addbatch = at_module.AddChToBatch(ch_mode=self.ch_mode)
         self.task = task
@@ -285,6 +287,38 @@ class STFTLearner(Learner):
             gt = gt_batch[self.task].to(self.device)
             data += [self.get_tar_batch(gt)]
         return data
+
+    def pretrain_evaluate(self, pred_batch, gt_batch, mask_batch):
+        """Reconstruction quality of the pretext task (code/learner.py:574-618).  pred/gt (nb,nf,nt,nreim,nch), mask (nb,nf,nt,nch)
+        -> {'sig_pred','sig_tar','mse','mse_mask','mse_mask_ch','pesq','pesq_mask_ch'}.  The waveforms come from the HIP inverse
+        STFT; PESQ is the third-party ``torchmetrics``/``pesq`` package and is NaN when that package is not installed."""
+        def to_sig(v):
+            st = torch.view_as_complex(v.permute(0, 1, 2, 4, 3).contiguous().float())          # (nb,nf,nt,nch)
+            st = torch.cat((torch.zeros_like(st[:, 0:1]), st), dim=1)                           # DC row back
+            sig = self.istft(st)
+            return sig / torch.max(sig)
+        sig_pred, sig_gt = to_sig(pred_batch), to_sig(gt_batch)
+        mask_dense = mask_batch[:, :, :, np.newaxis, :].tile(1, 1, 1, 2, 1)
+        diff = (pred_batch - gt_batch) ** 2
+        diff_mask = diff * (1 - mask_dense)
+        mse_mask = torch.sum(diff_mask) / torch.sum(1 - mask_dense)
+        mse_mask_ch = torch.mean(torch.sum(diff_mask, dim=4))
+        mse = torch.mean(diff)
+        nb, _, _, nch = mask_batch.shape
+        pesq = torch.full((nb, nch), float("nan"))
+        pesq_mask_ch = torch.full((nb,), float("nan"))
+        try:
+            from torchmetrics.functional.audio.pesq import perceptual_evaluation_speech_quality as _pesq
+        except Exception:
+            _pesq = None
+        if _pesq is not None:
+            for b_idx in range(nb):
+                mask_ch_idx = 0 if mask_batch[b_idx, :, :, 1].sum() > mask_batch[b_idx, :, :, 0].sum() else 1
+                for ch_idx in range(nch):
+                    pesq[b_idx, ch_idx] = _pesq(sig_pred[b_idx, :, ch_idx].cpu(), sig_gt[b_idx, :, ch_idx].cpu(), 16000, "wb")
+                pesq_mask_ch = pesq[:, mask_ch_idx]                                            # (sic) last item's channel, learner.py:614
+        return {"sig_pred": sig_pred, "sig_tar": sig_gt, "mse": mse, "mse_mask": mse_mask, "mse_mask_ch": mse_mask_ch,
+                "pesq": pesq, "pesq_mask_ch": pesq_mask_ch}
 
     def get_tar_batch(self, gt_batch):
         if self.task == "TDOA":

@@ -30,8 +30,8 @@ def main(argv=None):
 
     if args.no_cuda or not torch.cuda.is_available():
         raise SystemExit("run_pretrain.py (sar_ssl_amd) needs an MI355X GPU: the HIP path has no CPU fallback")
-    if not args.pretrain or not args.simu_exp:
-        raise SystemExit("only `--pretrain --simu-exp` is implemented on this path")
+    if not (args.pretrain or args.test) or not args.simu_exp:
+        raise SystemExit("only `--pretrain --simu-exp` and `--test --simu-exp` are implemented on this path")
     rank, world, local = sdist.init_from_env()
     device = torch.device("cuda", local)
     set_seed(args.seed)
@@ -48,6 +48,9 @@ def main(argv=None):
     nparam, nparam_sum = get_nparams(net, param_key_list=["spec_encoder", "spat_encoder", "decoder"])
     if rank == 0:
         print(f"T: {T:.3f}, nt: {nt}, nf: {nf}; # Parameters (M): {nparam_sum:.2f}")
+
+    if args.test:
+        return run_test(args, dirs, net, device, fs, (win_len, win_shift_ratio, nfft, fre_used_ratio))
 
     data_num = {"train": 5120 * 100, "val": 4000 * 2}
     ds_train = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_pretrain"], load_anno=False, load_dp=False, fs=fs,
@@ -92,6 +95,52 @@ def main(argv=None):
             break
     if rank == 0:
         print("\nPre-Training finished\n")
+
+
+def run_test(args, dirs, net, device, fs, stft_cfg):
+    """`--test` (code/run_pretrain.py:405-483): best checkpoint -> loss on the pretest set ('all'), or per-instance export of
+    mask / prediction / target spectrograms (.mat) and reconstructed waveforms (.wav through the HIP inverse STFT) ('ins')."""
+    import numpy as np
+    import scipy.io
+    import torch
+    from sar_ssl_amd import dataset as at_dataset, learner as at_learner
+    from sar_ssl_amd.common.utils import set_seed
+    win_len, win_shift_ratio, nfft, fre_used_ratio = stft_cfg
+    learner = at_learner.STFTLearner(net, win_len=win_len, win_shift_ratio=win_shift_ratio, nfft=nfft, fre_used_ratio=fre_used_ratio,
+                                     fs=fs, task=None, ch_mode="M")
+    learner.cuda()
+    if args.use_amp:
+        learner.amp()
+    epoch = learner.load_checkpoint_best(checkpoints_dir=dirs["log_pretrain"], as_all_state=True)
+    kwargs = {"num_workers": args.workers, "pin_memory": True}
+    if args.test_mode == "all":
+        set_seed(args.seed)
+        ds = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_pretest"], load_anno=False, load_dp=False, fs=fs, dataset_sz=4000,
+                                         transforms=None)
+        dl = torch.utils.data.DataLoader(ds, batch_size=args.bs[2], shuffle=False, **kwargs)
+        loss_test, diff_test, _ = learner.pretest_epoch(dl, return_diff=True)
+        print("Test loss: {:.4f}".format(loss_test))
+        print(json.dumps({"epoch": epoch, "loss_test": loss_test, "diff_test": diff_test}), flush=True)
+        return
+    for dir_pretest in dirs["micsig_simu_pretest_ins"]:
+        set_seed(args.seed)
+        ds = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_pretest_ins"], load_anno=False, load_dp=True, dataset_sz=None, fs=fs,
+                                         transforms=None)
+        dl = torch.utils.data.DataLoader(ds, batch_size=len(ds), shuffle=False, **kwargs)
+        loss_test, diff_test, vis, res = learner.pretest_epoch(dl, return_diff=True, return_eval=True)
+        name = dir_pretest.split("/")[-1]
+        print(name, "Test loss: {:.4f}".format(loss_test))
+        data_path = dirs["log_pretrain"] + "/test_result/"
+        os.makedirs(data_path, exist_ok=True)
+        rt = dir_pretest.split("T")[-1]
+        for ins_idx in range(len(ds)):
+            for key, sig in (("pred", res["sig_pred"]), ("tar", res["sig_tar"])):
+                pcm = (sig[ins_idx].clamp(-1, 1) * 32767.0).round().to(torch.int16).cpu().numpy()
+                at_dataset.write_wav_pcm16(data_path + "rt" + rt + "_ins" + str(ins_idx) + "_epoch" + str(epoch) + "_test_" + key + ".wav", pcm, fs)
+        scipy.io.savemat(data_path + "rt" + rt + "_ins" + "_epoch" + str(epoch) + "_test.mat",
+                         {"mask": vis["mask"].cpu().numpy(), "pred": vis["pred"].cpu().numpy(), "tar": vis["tar"].cpu().numpy(),
+                          "pesq": res["pesq"].cpu().numpy(), "pesq_mask_ch": res["pesq_mask_ch"].cpu().numpy(),
+                          "mse": float(res["mse"]), "mse_mask": float(res["mse_mask"]), "mse_mask_ch": float(res["mse_mask_ch"])})
 
 
 if __name__ == "__main__":

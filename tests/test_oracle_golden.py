@@ -226,3 +226,32 @@ def test_f10_multichannel_pairs_config5_and_multich_head():
         pred, emb = orc.sarssl_multich_forward(xm, sdm, 3)
     _close(pred, z["mch.pred"], 5e-4, 1e-5)
     _close(emb, z["mch.embed"], 5e-4, 1e-5)
+
+
+def test_f11_istft_and_pretrain_evaluate():
+    """inverse STFT (both centre modes) and the eval-export metrics against the real reference."""
+    z = _npz("f11_eval_export.npz")
+    spec = torch.view_as_complex(torch.from_numpy(z["spec"]))
+    _close(orc.istft(spec, inv=False), z["istft_inv0"], 1e-5, 1e-6)
+    _close(orc.istft(spec, inv=True), z["istft_inv1"], 1e-5, 1e-6)
+    assert orc.istft(spec, inv=False).shape == (2, 10 * 256, 3) and orc.istft(spec, inv=True).shape == (2, 8 * 256, 3)
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    sd = recipes.recipe_state_dict(man, 0)
+    x = orc.data_preprocess(recipes.recipe_signal(2, 65792, 2, seed=3))
+    idx, ch = torch.from_numpy(z["eval.mask_idx"]), torch.from_numpy(z["eval.mask_ch"])
+    with torch.no_grad():
+        loss, diff, aux = orc.sarssl_pretrain_forward(x, sd, idx, ch, train=False)
+    assert abs(loss.item() / float(z["eval.loss"]) - 1) < 1e-4 and abs(diff.item() / float(z["eval.diff"]) - 1) < 1e-5
+    B, T = 2, 256
+    pred = aux["pred"].detach().view(B, T, 256, 2, 2).permute(0, 2, 1, 3, 4)               # (nb,nf,nt,nreim,nch)
+    tar = x.permute(0, 2, 3, 4, 1)
+    mask = torch.ones(B, 256, T, 2)
+    for b in range(B):
+        mask[b, :, idx[b], int(ch[b])] = 0.0
+    res = orc.pretrain_evaluate(pred, tar, mask)
+    assert tuple(res["sig_pred"].shape) == tuple(z["eval.sig_shape"])
+    sidx = torch.from_numpy(z["eval.sig_idx"])
+    _close(res["sig_pred"].reshape(-1)[sidx], z["eval.sig_pred"], 5e-4, 1e-5)
+    _close(res["sig_tar"].reshape(-1)[sidx], z["eval.sig_tar"], 1e-4, 1e-6)
+    for k in ("mse", "mse_mask", "mse_mask_ch"):
+        assert abs(float(res[k]) / float(z["eval." + k]) - 1) < 2e-4, k
