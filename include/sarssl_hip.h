@@ -29,6 +29,11 @@ int sarssl_stft_frontend_pairs(const void* sig, int sig_dtype, int nb, long nsam
 /*      out: complex64 (B, 257, nt, nch) interleaved, the STFT.forward return value. */
 int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft, int nt,
                     float* U, double* magsum, float* out, void* stream);
+/* ---- on-disk segments: `{idx}.wav` PCM-16 files read per item by soundfile.read in FixMicSigDataset.__getitem__
+ *      (code/dataset.py:147-151).  Host code only (no GPU work): fills out[n][nsample][nch] int16 (e.g. a pinned batch
+ *      buffer) with samples [offset, offset+nsample) of each file using nthreads positional readers. */
+int sarssl_wav_probe(const char* path, int* nch, int* fs, long* nsample);
+int sarssl_wav_read_batch(const char* const* paths, int n, long nsample, int nch, int fs, long offset, short* out, int nthreads);
 /* ---- inverse STFT: code/common/utils_module.py:74-113 (ISTFT.forward = torch.istft, rectangular window, center = inv).
  *      spec: complex64 (B, 257, nt, nch) interleaved; sig: (B, nsample, nch) f32, nsample = (nt+1)*hop (center 0) or
  *      (nt-1)*hop (center 1); frames_ws: sarssl_istft_workspace_bytes(nb, nch, nt) bytes. */

@@ -6,7 +6,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "wavio.hip"]
 LIB = os.path.join(HERE, "libsarssl_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
             if verbose and w.strip():
                 print(w[-3000:])
     if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
     return LIB
 
 

@@ -4,10 +4,14 @@
 ``soundfile`` is not available here, so RIFF/WAVE PCM-16 is parsed directly with numpy.  ``raw_pcm=True`` returns the
 int16 samples untouched (half the PCIe bytes); the STFT kernel converts on the fly.
 """
+import ctypes
+import queue
 import struct
+import threading
 from pathlib import Path
 
 import numpy as np
+import torch
 from torch.utils.data import Dataset
 
 
@@ -109,3 +113,143 @@ class FixMicSigDataset(Dataset):
                     dp_sig = t(dp_sig)
             return_data += [dp_sig]
         return return_data
+
+
+def read_wav_batch(paths, nsample, nch, fs=0, offset=0, out=None, nthreads=0):
+    """Raw int16 PCM of samples [offset, offset+nsample) of every file -> int16 tensor (len(paths), nsample, nch), filled by the
+    threaded reader of the C-ABI library (csrc/wavio.hip, ``sarssl_wav_read_batch``; the GIL is released during the call)."""
+    from . import _lib
+    n = len(paths)
+    if out is None:
+        out = torch.empty((n, nsample, nch), dtype=torch.int16)
+    assert out.dtype == torch.int16 and out.is_contiguous() and not out.is_cuda and out.numel() >= n * nsample * nch
+    arr = (ctypes.c_char_p * n)(*[str(p).encode() for p in paths])
+    _lib.call("sarssl_wav_read_batch", arr, ctypes.c_int(n), ctypes.c_long(nsample), ctypes.c_int(nch), ctypes.c_int(fs),
+              ctypes.c_long(offset), ctypes.c_void_p(out.data_ptr()), ctypes.c_int(nthreads))
+    return out[:n] if out.shape[0] != n else out
+
+
+def wav_probe(path):
+    """-> (nch, fs, nsample) of a PCM-16 WAV file."""
+    from . import _lib
+    nch, fs, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
+    _lib.call("sarssl_wav_probe", str(path).encode(), ctypes.byref(nch), ctypes.byref(fs), ctypes.byref(ns))
+    return nch.value, fs.value, ns.value
+
+
+class PcmSegmentLoader:
+    """Batch iterator over a FixMicSigDataset-style directory of equal-length PCM-16 segments that replaces
+    ``DataLoader(FixMicSigDataset(...), num_workers=N)`` on the pretraining path (code/run_pretrain.py:160-186): a background
+    thread fills (pinned) int16 batch buffers with the native reader and, when ``device`` is a GPU, uploads them on a copy stream
+    while the previous step computes.  Yields ``[pcm]`` with pcm int16 (B, nsample, nch) - the STFT kernel converts on the fly.
+    Without a device the yielded host tensor is a view of a recycled buffer: valid until the next batch is requested.
+
+    shuffle / rank / world / seed reproduce ``DistributedSampler`` semantics (rank-strided slice of one global permutation per
+    epoch, padded by wrap-around); ``set_epoch`` changes the permutation."""
+
+    def __init__(self, files, batch_size, nsample=None, nch=None, fs=16000, shuffle=False, seed=0, rank=0, world=1, drop_last=False,
+                 device=None, nthreads=8, prefetch=2):
+        self.files = [str(f) for f in files]
+        assert self.files, "no segments"
+        if nsample is None or nch is None:
+            c, _, ns = wav_probe(self.files[0])
+            nch, nsample = nch or c, nsample or ns
+        self.batch_size, self.nsample, self.nch, self.fs = int(batch_size), int(nsample), int(nch), fs
+        self.shuffle, self.seed, self.rank, self.world, self.drop_last = shuffle, seed, rank, world, drop_last
+        self.device = torch.device(device) if device is not None else None
+        self.nthreads, self.prefetch, self.epoch = nthreads, max(1, prefetch), 0
+        self.per_rank = (len(self.files) + world - 1) // world
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.per_rank // self.batch_size if self.drop_last else (self.per_rank + self.batch_size - 1) // self.batch_size
+
+    def _order_all(self, epoch):
+        n = len(self.files)
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + epoch)
+            idx = torch.randperm(n, generator=g).tolist()
+        else:
+            idx = list(range(n))
+        total = self.per_rank * self.world
+        return idx + idx[: total - n]
+
+    def _order_for(self, epoch):
+        return self._order_all(epoch)[self.rank::self.world]
+
+    def _order(self):
+        return self._order_for(self.epoch)
+
+    def __iter__(self):
+        order = self._order()
+        nb = len(self)
+        cuda = self.device is not None and self.device.type == "cuda"
+        pin = cuda and torch.cuda.is_available()
+        bufs = [torch.empty((self.batch_size, self.nsample, self.nch), dtype=torch.int16, pin_memory=pin) for _ in range(self.prefetch + 1)]
+        free, ready = queue.Queue(), queue.Queue(maxsize=self.prefetch)
+        for b in bufs:
+            free.put(b)
+        copy_stream = torch.cuda.Stream(self.device) if cuda else None
+        stop = threading.Event()
+
+        def producer():
+            try:
+                for i in range(nb):
+                    if stop.is_set():
+                        return
+                    ids = order[i * self.batch_size:(i + 1) * self.batch_size]
+                    buf = free.get()
+                    host = read_wav_batch([self.files[j] for j in ids], self.nsample, self.nch, self.fs, 0, out=buf, nthreads=self.nthreads)
+                    if cuda:
+                        with torch.cuda.stream(copy_stream):
+                            dev = host.to(self.device, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(copy_stream)
+                        ready.put((dev, ev, buf))
+                    else:
+                        ready.put((host, None, buf))                            # valid until the consumer asks for the next batch
+                ready.put(None)
+            except BaseException as e:                                              # surface reader errors in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                t, ev, buf = item
+                if ev is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ev)
+                    ev.synchronize()                                                 # the pinned buffer is reusable once the copy is done
+                    t.record_stream(torch.cuda.current_stream(self.device))
+                    free.put(buf)
+                    yield [t]
+                else:
+                    yield [t]
+                    free.put(buf)
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+                free.put(bufs[0])
+            th.join()
+
+
+def segment_files(data_dir):
+    """The ``*.wav`` files FixMicSigDataset would list (code/dataset.py:113-126): recursive, minus ``*_dp.wav``."""
+    dirs = data_dir if isinstance(data_dir, list) else [data_dir]
+    files, dp = [], set()
+    for d in dirs:
+        files += list(Path(d).rglob("*.wav"))
+        dp |= set(Path(d).rglob("*_dp.wav"))
+    return [f for f in files if f not in dp]

@@ -53,16 +53,28 @@ def main(argv=None):
         return run_test(args, dirs, net, device, fs, (win_len, win_shift_ratio, nfft, fre_used_ratio))
 
     data_num = {"train": 5120 * 100, "val": 4000 * 2}
-    ds_train = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_pretrain"], load_anno=False, load_dp=False, fs=fs,
-                                           dataset_sz=data_num["train"], transforms=None, raw_pcm=True)
-    ds_val = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_preval"], load_anno=False, load_dp=False, fs=fs,
-                                         dataset_sz=data_num["val"], transforms=None, raw_pcm=True)
-    kwargs = {"num_workers": args.workers, "pin_memory": True}
-    sampler = torch.utils.data.distributed.DistributedSampler(ds_train, num_replicas=world, rank=rank, shuffle=True,
-                                                              seed=args.seed) if world > 1 else None
-    dl_train = torch.utils.data.DataLoader(ds_train, batch_size=args.bs[0], shuffle=(sampler is None), sampler=sampler,
-                                           drop_last=(world > 1), **kwargs)
-    dl_val = torch.utils.data.DataLoader(ds_val, batch_size=args.bs[1], shuffle=False, **kwargs)
+    native = os.environ.get("SARSSL_NATIVE_LOADER", "1") != "0"
+    sampler = None
+    if native:
+        # threaded int16 reader -> pinned buffers -> copy stream (dataset.PcmSegmentLoader); same file listing, same
+        # rank-strided shuffling as DataLoader + DistributedSampler below
+        nsample = int(T * fs)
+        f_train = at_dataset.segment_files(dirs["micsig_simu_pretrain"])[: data_num["train"]]
+        f_val = at_dataset.segment_files(dirs["micsig_simu_preval"])[: data_num["val"]]
+        dl_train = at_dataset.PcmSegmentLoader(f_train, args.bs[0], nsample, 2, fs=fs, shuffle=True, seed=args.seed, rank=rank, world=world,
+                                               drop_last=(world > 1), device=device, nthreads=max(1, args.workers))
+        dl_val = at_dataset.PcmSegmentLoader(f_val, args.bs[1], nsample, 2, fs=fs, device=device, nthreads=max(1, args.workers))
+    else:
+        ds_train = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_pretrain"], load_anno=False, load_dp=False, fs=fs,
+                                               dataset_sz=data_num["train"], transforms=None, raw_pcm=True)
+        ds_val = at_dataset.FixMicSigDataset(data_dir=dirs["micsig_simu_preval"], load_anno=False, load_dp=False, fs=fs,
+                                             dataset_sz=data_num["val"], transforms=None, raw_pcm=True)
+        kwargs = {"num_workers": args.workers, "pin_memory": True}
+        sampler = torch.utils.data.distributed.DistributedSampler(ds_train, num_replicas=world, rank=rank, shuffle=True,
+                                                                  seed=args.seed) if world > 1 else None
+        dl_train = torch.utils.data.DataLoader(ds_train, batch_size=args.bs[0], shuffle=(sampler is None), sampler=sampler,
+                                               drop_last=(world > 1), **kwargs)
+        dl_val = torch.utils.data.DataLoader(ds_val, batch_size=args.bs[1], shuffle=False, **kwargs)
 
     learner = at_learner.STFTLearner(net, win_len=win_len, win_shift_ratio=win_shift_ratio, nfft=nfft,
                                      fre_used_ratio=fre_used_ratio, fs=fs, task=None, ch_mode="M")
@@ -81,6 +93,8 @@ def main(argv=None):
         set_random_seed(seeds["train"] + epoch + 1000003 * rank)                              # per-rank mask / dropout streams
         if sampler is not None:
             sampler.set_epoch(epoch)
+        if native:
+            dl_train.set_epoch(epoch)
         loss_train, diff_train, _ = learner.pretrain_epoch(dl_train, lr=lr, epoch=epoch, return_diff=True)
         set_random_seed(seeds["val"])
         loss_val, diff_val, _ = learner.pretest_epoch(dl_val, return_diff=True)

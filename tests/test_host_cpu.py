@@ -126,3 +126,68 @@ def test_synth_segments_are_deterministic():
     a, b = synth.make_segment(5, nsample=2048), synth.make_segment(5, nsample=2048)
     assert np.array_equal(a, b) and a.shape == (2048, 2) and abs(np.abs(a).max() - 0.9) < 1e-6
     assert not np.array_equal(a, synth.make_segment(6, nsample=2048))
+
+
+def test_native_wav_batch_reader_and_segment_loader(tmp_path):
+    """the threaded PCM-16 reader of the C-ABI library against the pure-Python parser, its error reporting, and the
+    prefetching segment loader's batching / sharding semantics (host-only code: runs without a GPU)."""
+    from sar_ssl_amd import dataset, _lib
+    rng = np.random.default_rng(0)
+    n, ns, nch = 11, 3000, 2
+    pcm = rng.integers(-32768, 32767, size=(n, ns, nch), dtype=np.int16)
+    for i in range(n):
+        dataset.write_wav_pcm16(str(tmp_path / ("%d.wav" % i)), pcm[i])
+    dataset.write_wav_pcm16(str(tmp_path / "3_dp.wav"), pcm[3])                    # direct-path companions are not segments
+    files = sorted(dataset.segment_files(str(tmp_path)), key=lambda p: int(p.stem))
+    assert len(files) == n and dataset.wav_probe(files[0]) == (nch, 16000, ns)
+    for nthreads in (1, 4):
+        got = dataset.read_wav_batch(files, ns, nch, fs=16000, nthreads=nthreads)
+        assert got.dtype == torch.int16 and np.array_equal(got.numpy(), pcm)
+    part = dataset.read_wav_batch(files[:3], 1000, nch, offset=500)
+    assert np.array_equal(part.numpy(), pcm[:3, 500:1500])
+    ref0, fs0 = dataset.read_wav_pcm16(str(files[5]))
+    assert fs0 == 16000 and np.array_equal(ref0, pcm[5])
+    # WAVE_FORMAT_EXTENSIBLE header + an odd-sized LIST chunk before the data chunk
+    import struct
+    body = pcm[0].tobytes()
+    fmt = struct.pack("<HHIIHHHHIH14s", 0xFFFE, nch, 16000, 16000 * nch * 2, nch * 2, 16, 22, 16, 3, 1, b"\x00" * 14)
+    lst = b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\x00"
+    blob = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + lst + b"data" + struct.pack("<I", len(body)) + body
+    with open(tmp_path / "ext.wav", "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(blob)) + blob)
+    assert np.array_equal(dataset.read_wav_batch([tmp_path / "ext.wav"], ns, nch).numpy()[0], pcm[0])
+    assert np.array_equal(dataset.read_wav_pcm16(str(tmp_path / "ext.wav"))[0], pcm[0])
+    # loud failures: too short, wrong channel count, wrong rate, not a WAV, missing
+    for bad, kw, msg in ((files[:2], dict(nsample=ns + 1), "need"), (files[:2], dict(nch=3), "channels"),
+                         (files[:2], dict(fs=8000), "sample rate"), ([tmp_path / "nope.wav"], {}, "cannot open")):
+        args = dict(nsample=ns, nch=nch, fs=16000)
+        args.update(kw)
+        with pytest.raises(_lib.SarsslHipError, match=msg):
+            dataset.read_wav_batch(bad, args["nsample"], args["nch"], fs=args["fs"])
+    (tmp_path / "junk.wav").write_bytes(b"not a wave file at all")
+    with pytest.raises(_lib.SarsslHipError, match="RIFF"):
+        dataset.read_wav_batch([tmp_path / "junk.wav"], 10, 2)
+    # loader: sequential order, ragged last batch, drop_last, two-rank sharding with wrap-around padding, epoch reshuffle
+    ld = dataset.PcmSegmentLoader(files, batch_size=4, fs=16000, nthreads=2)
+    batches = [b[0].clone() for b in ld]
+    assert len(ld) == 3 and [b.shape[0] for b in batches] == [4, 4, 3]
+    assert np.array_equal(torch.cat(batches).numpy(), pcm)
+    assert len(dataset.PcmSegmentLoader(files, batch_size=4, drop_last=True)) == 2
+    seen = []
+    for rank in range(2):
+        ld = dataset.PcmSegmentLoader(files, batch_size=3, shuffle=True, seed=5, rank=rank, world=2, drop_last=True)
+        ld.set_epoch(1)
+        got = torch.cat([b[0].clone() for b in ld]).numpy()
+        assert got.shape[0] == 6
+        seen += [int(np.where((pcm == g).all(axis=(1, 2)))[0][0]) for g in got]
+    assert len(set(seen)) >= 10                                                    # 12 draws from a wrapped permutation of 11
+    ld1 = dataset.PcmSegmentLoader(files, batch_size=3, shuffle=True, seed=5, rank=0, world=2, drop_last=True)
+    ld1.set_epoch(1)
+    ld2 = dataset.PcmSegmentLoader(files, batch_size=3, shuffle=True, seed=5, rank=0, world=2, drop_last=True)
+    ld2.set_epoch(2)
+    assert ld1._order() != ld2._order() and sorted(ld1._order() + dataset.PcmSegmentLoader(
+        files, batch_size=3, shuffle=True, seed=5, rank=1, world=2)._order_for(1)) == sorted(list(range(n)) + [ld1._order_all(1)[0]])
+    # early break does not hang the producer thread
+    it = iter(dataset.PcmSegmentLoader(files, batch_size=2, nthreads=2))
+    next(it)
+    it.close()
