@@ -31,12 +31,15 @@ void sarssl_set_error(const char* fmt, ...);
     } while (0)
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    // round-to-nearest-even (NaN not special-cased: never produced on this path)
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+// f32 -> bf16, round-to-nearest-even, two values per instruction: gfx950's v_cvt_pk_bf16_f32 (a software RNE costs ~6 VALU ops
+// per element, which made the BatchNorm prologue and the bf16 epilogues of the convolution / GEMM kernels VALU-bound)
+typedef float sarssl_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sarssl_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    sarssl_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sarssl_bf16x2));
 }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) { return pack2_bf16(f, 0.f) & 0xffffu; }
 __device__ __forceinline__ float ld_f(const float* p) { return *p; }
 __device__ __forceinline__ float ld_f(const bf16* p) { return bf16_bits_to_f32(*(const uint16_t*)p); }
 __device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
@@ -52,8 +55,8 @@ __device__ __forceinline__ float4 ld4(const bf16* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
 __device__ __forceinline__ void st4(bf16* p, float4 v) {
     uint2 u;
-    u.x = f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16);
-    u.y = f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16);
+    u.x = pack2_bf16(v.x, v.y);
+    u.y = pack2_bf16(v.z, v.w);
     *(uint2*)p = u;
 }
 // 8-wide
@@ -77,10 +80,10 @@ __device__ __forceinline__ void st8(float* p, const f8& r) {
 }
 __device__ __forceinline__ void st8(bf16* p, const f8& r) {
     uint4 u;
-    u.x = f32_to_bf16_bits(r.v[0]) | (f32_to_bf16_bits(r.v[1]) << 16);
-    u.y = f32_to_bf16_bits(r.v[2]) | (f32_to_bf16_bits(r.v[3]) << 16);
-    u.z = f32_to_bf16_bits(r.v[4]) | (f32_to_bf16_bits(r.v[5]) << 16);
-    u.w = f32_to_bf16_bits(r.v[6]) | (f32_to_bf16_bits(r.v[7]) << 16);
+    u.x = pack2_bf16(r.v[0], r.v[1]);
+    u.y = pack2_bf16(r.v[2], r.v[3]);
+    u.z = pack2_bf16(r.v[4], r.v[5]);
+    u.w = pack2_bf16(r.v[6], r.v[7]);
     *(uint4*)p = u;
 }
 
@@ -95,6 +98,11 @@ __device__ __forceinline__ uint32_t bf16_part_bits(float x, int part) {
 // pack 8 floats -> 8 bf16 (uint4), selecting the hi or lo part
 __device__ __forceinline__ uint4 pack8_part(const f8& r, int part) {
     uint4 u;
+    if (part == 0) {
+        u.x = pack2_bf16(r.v[0], r.v[1]); u.y = pack2_bf16(r.v[2], r.v[3]);
+        u.z = pack2_bf16(r.v[4], r.v[5]); u.w = pack2_bf16(r.v[6], r.v[7]);
+        return u;
+    }
     u.x = bf16_part_bits(r.v[0], part) | (bf16_part_bits(r.v[1], part) << 16);
     u.y = bf16_part_bits(r.v[2], part) | (bf16_part_bits(r.v[3], part) << 16);
     u.z = bf16_part_bits(r.v[4], part) | (bf16_part_bits(r.v[5], part) << 16);

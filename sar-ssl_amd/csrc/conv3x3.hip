@@ -19,6 +19,7 @@
 // f32 ("precise") storage: operands are split hi/lo to bf16 at staging time and the host runs
 // three accumulating passes (see gemm.hip).
 #include "common.h"
+#include <stdlib.h>
 
 #define TR 8
 #define TCOL 64
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
 
     const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
     if (xcd_tile(0, blockIdx.x, gridDim.x) < ntiles) issue_loads(xcd_tile(0, blockIdx.x, gridDim.x));
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): see the note after the MFMA loop (keeps the loop-carried wait state clean)
     for (int it = 0; it < nrounds; ++it) {
         const int tile = xcd_tile(it, blockIdx.x, gridDim.x);
         if (tile >= ntiles) break;                 // (whole workgroup takes the same branch)
@@ -208,6 +210,11 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
             }
         }
 
+        // gfx9 counts loads AND stores in vmcnt and they may complete out of order with respect to each other: once this tile's
+        // output stores are in flight, the first use of the prefetched registers (top of the next iteration) would have to wait
+        // vmcnt(0), i.e. for the stores' HBM round trip.  The prefetch was issued a whole MFMA phase ago - retire it here, before
+        // any store is issued, so the stores drain behind the next tile's staging and matrix work instead.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), expcnt / lgkmcnt untouched
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
         const int f = tc.f0 + wave;
         if constexpr (sizeof(T) == 2) {
@@ -226,8 +233,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
                     for (int g = 0; g < 4; ++g) {
                         const int co = i * 32 + 8 * g + 4 * (lane >> 5);
                         uint2 w2;
-                        w2.x = f32_to_bf16_bits(acc[i][j][g * 4 + 0]) | (f32_to_bf16_bits(acc[i][j][g * 4 + 1]) << 16);
-                        w2.y = f32_to_bf16_bits(acc[i][j][g * 4 + 2]) | (f32_to_bf16_bits(acc[i][j][g * 4 + 3]) << 16);
+                        w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+                        w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
                         *(uint2*)&stg[px * 64 + (((co >> 3) ^ (px & 7)) << 3) + (co & 7)] = w2;
                     }
                 }
