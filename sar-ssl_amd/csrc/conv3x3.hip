@@ -132,31 +132,37 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
 
+    // Halo tile staging.  Thread = (pixel column pc = tid >> 3, 8-channel chunk cch): halo row i of columns 0..63 for i = 0..9, plus
+    // one of the 160 chunks of halo columns 64 / 65 for tid < 160 - no per-chunk division, one pointer bump per row.
     Chunk<T> regs[X_ITERS];
+    const int pc = tid >> 3;
     auto issue_loads = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
+        const int t = tc.t0 - 1 + pc;
+        const bool tv = t >= 0 && t < Tn;
+        const T* base = in + (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
 #pragma unroll
-        for (int i = 0; i < X_ITERS; ++i) {
-            const int q = tid + i * 512;
-            const int p = q >> 3;
-            const int hr = p / HC, hc = p - hr * HC;
-            const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
-            const bool valid = (q < NCHUNK_H) && f >= 0 && f < F && t >= 0 && t < Tn;
-            regs[i] = load_chunk<T>(in + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
+        for (int i = 0; i < HR; ++i) {
+            const int f = tc.f0 - 1 + i;
+            regs[i] = load_chunk<T>(base + (long)i * Tn * 64, tv && f >= 0 && f < F);
+        }
+        {
+            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
+            regs[HR] = load_chunk<T>(in + (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8, tid < 160 && f >= 0 && f < F && te < Tn);
         }
     };
     auto write_tile = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
+        const int t = tc.t0 - 1 + pc;
+        const bool tv = t >= 0 && t < Tn;
 #pragma unroll
-        for (int i = 0; i < X_ITERS; ++i) {
-            const int q = tid + i * 512;
-            if (q < NCHUNK_H) {
-                const int p = q >> 3;
-                const int hr = p / HC, hc = p - hr * HC;
-                const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
-                const bool valid = f >= 0 && f < F && t >= 0 && t < Tn;
-                *(uint4*)&sX[swz(p, cch)] = xform_chunk<T>(regs[i], valid, a.prologue, sc, sh, a.part_in);
-            }
+        for (int i = 0; i < HR; ++i) {
+            const int f = tc.f0 - 1 + i;
+            *(uint4*)&sX[swz(i * HC + pc, cch)] = xform_chunk<T>(regs[i], tv && f >= 0 && f < F, a.prologue, sc, sh, a.part_in);
+        }
+        if (tid < 160) {
+            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
+            *(uint4*)&sX[swz(hr * HC + TCOL + (pc & 1), cch)] = xform_chunk<T>(regs[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_in);
         }
     };
 
@@ -347,9 +353,6 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     const T* zin = (const T*)a.zin;
     const T* dy = (const T*)a.dy;
     const int cch = tid & 7;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
 
     f32x16 acc[5];
 #pragma unroll
@@ -357,48 +360,48 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t9][r] = 0.f;
 
+    // staging as in the forward kernel: thread = (pixel column pc, 8-channel chunk), halo rows 0..9 + one chunk of columns 64/65
     Chunk<T> rz[X_ITERS], ry[8];
+    const int pc = tid >> 3;
     auto issue_loads = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));                        // keep the per-chunk index math out of the loop-invariant set
+        const int t = tc.t0 - 1 + pc;
+        const bool tv = t >= 0 && t < Tn;
+        const T* zb = zin + (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
 #pragma unroll
-        for (int i = 0; i < X_ITERS; ++i) {
-            const int q = tid_o + i * 512;
-            const int p = q >> 3;
-            const int hr = p / HC, hc = p - hr * HC;
-            const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
-            const bool valid = (q < NCHUNK_H) && f >= 0 && f < F && t >= 0 && t < Tn;
-            rz[i] = load_chunk<T>(zin + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, valid);
+        for (int i = 0; i < HR; ++i) {
+            const int f = tc.f0 - 1 + i;
+            rz[i] = load_chunk<T>(zb + (long)i * Tn * 64, tv && f >= 0 && f < F);
         }
+        {
+            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
+            rz[HR] = load_chunk<T>(zin + (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8, tid < 160 && f >= 0 && f < F && te < Tn);
+        }
+        const int ty = tc.t0 + pc;
+        const T* yb = dy + (((long)tc.b * F + tc.f0) * Tn + ty) * 64 + cch * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = (tid_o + i * 512) >> 3;
-            const int f = tc.f0 + (p >> 6), t = tc.t0 + (p & 63);
-            ry[i] = load_chunk<T>(dy + (((long)tc.b * F + f) * Tn + t) * 64 + cch * 8, f < F && t < Tn);
-        }
+        for (int i = 0; i < 8; ++i) ry[i] = load_chunk<T>(yb + (long)i * Tn * 64, tc.f0 + i < F && ty < Tn);
     };
     auto write_tile = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
+        float sc[8], sh[8];                                    // live only while staging
 #pragma unroll
-        for (int i = 0; i < X_ITERS; ++i) {
-            const int q = tid_o + i * 512;
-            if (q < NCHUNK_H) {
-                const int p = q >> 3;
-                const int hr = p / HC, hc = p - hr * HC;
-                const int f = tc.f0 - 1 + hr, t = tc.t0 - 1 + hc;
-                const bool valid = f >= 0 && f < F && t >= 0 && t < Tn;
-                *(uint4*)&sX[swz(p, cch)] = xform_chunk<T>(rz[i], valid, a.prologue, sc, sh, a.part_z);
-            }
-        }
+        for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+        const int t = tc.t0 - 1 + pc;
+        const bool tv = t >= 0 && t < Tn;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = (tid_o + i * 512) >> 3;
-            const int f = tc.f0 + (p >> 6), t = tc.t0 + (p & 63);
-            *(uint4*)&sY[swz(p, cch)] = xform_chunk<T>(ry[i], f < F && t < Tn, 0, sc, sh, a.part_dy);
+        for (int i = 0; i < HR; ++i) {
+            const int f = tc.f0 - 1 + i;
+            *(uint4*)&sX[swz(i * HC + pc, cch)] = xform_chunk<T>(rz[i], tv && f >= 0 && f < F, a.prologue, sc, sh, a.part_z);
         }
+        if (tid < 160) {
+            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
+            *(uint4*)&sX[swz(hr * HC + TCOL + (pc & 1), cch)] = xform_chunk<T>(rz[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_z);
+        }
+        const int ty = tc.t0 + pc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *(uint4*)&sY[swz(i * 64 + pc, cch)] = xform_chunk<T>(ry[i], tc.f0 + i < F && ty < Tn, 0, sc, sh, a.part_dy);
     };
 
     const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
