@@ -117,10 +117,29 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+// One 32-bit hash decides TWO neighbouring elements (16 bits each: keep iff bits >= p * 65536), so an 8-wide epilogue pays
+// four hashes instead of sixteen - the dropout epilogues of the FFN GEMMs were VALU-bound on the per-element double hash.
+// The decision is a pure function of (seed, idx): forward and backward recompute the same mask.
+__device__ __forceinline__ uint32_t dropout_key(uint64_t seed, uint32_t idx_hi) {
+    return hash_u32(idx_hi + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9e3779b9u;
+}
+__device__ __forceinline__ uint32_t dropout_thr16(float p_drop) { return (uint32_t)(p_drop * 65536.0f + 0.5f); }
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
-    uint32_t h = hash_u32((uint32_t)idx ^ hash_u32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9e3779b9u);
-    float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    return (u >= p_drop) ? inv_keep : 0.0f;
+    const uint32_t h = hash_u32((uint32_t)(idx >> 1) ^ dropout_key(seed, (uint32_t)(idx >> 33)));
+    const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+    return bits >= dropout_thr16(p_drop) ? inv_keep : 0.0f;
+}
+// v[e] *= keep(seed, base + e) * inv_keep for e = 0..7; base must be even
+__device__ __forceinline__ void dropout_apply8(float (&v)[8], uint64_t seed, uint64_t base, float p_drop, float inv_keep) {
+    const uint32_t thr = dropout_thr16(p_drop);
+    const uint32_t key = dropout_key(seed, (uint32_t)(base >> 33));
+    const uint32_t pair = (uint32_t)(base >> 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t h = hash_u32((pair + q) ^ key);
+        v[2 * q] *= (h & 0xffffu) >= thr ? inv_keep : 0.0f;
+        v[2 * q + 1] *= (h >> 16) >= thr ? inv_keep : 0.0f;
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

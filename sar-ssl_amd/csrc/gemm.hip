@@ -254,8 +254,11 @@ _Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(P + (long)m *
             }
             if (g.p_drop > 0.f) {
                 const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
+                if ((base & 1ull) == 0 && (((base + 7) >> 33) == (base >> 33))) dropout_apply8(v.v, g.seed, base, g.p_drop, inv_keep);
+                else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(g.seed, base + e, g.p_drop, inv_keep);
+                    for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(g.seed, base + e, g.p_drop, inv_keep);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] *= g.out_scale;

@@ -368,6 +368,30 @@ __global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __res
         float sc[8], sh[8], mu[8], rs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const int ch = (col + e) % C; sc[e] = scale[ch]; sh[e] = shift[ch]; mu[e] = mean[ch]; rs[e] = rstd[ch]; }
+        if (act == 1) {
+            // ReLU: threshold test on y, and sum g*xhat = rs * (sum g*y - mu * sum g) finalised per thread (4 ops / element)
+            float thr[8];
+            unsigned sgn = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = sc[e] != 0.f ? -sh[e] / sc[e] : (sh[e] > 0.f ? -INFINITY : INFINITY);
+                if (sc[e] < 0.f) { t = -t; sgn |= 1u << e; }
+                thr[e] = t;
+            }
+            for (long n = (long)blockIdx.y * 32 + rslot; n < rows; n += (long)gridDim.y * 32) {
+                const f8 d = ld8(dz + n * L + col);
+                const f8 v = ld8(y + n * L + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ys = __uint_as_float(__float_as_uint(v.v[e]) ^ (((sgn >> e) & 1u) << 31));
+                    const float g = ys > thr[e] ? d.v[e] : 0.f;
+                    s[e] += g;
+                    q[e] = fmaf(g, v.v[e] - mu[e], q[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] *= rs[e];
+        } else
         for (long n = (long)blockIdx.y * 32 + rslot; n < rows; n += (long)gridDim.y * 32) {
             const f8 d = ld8(dz + n * L + col);
             const f8 v = ld8(y + n * L + col);
@@ -404,13 +428,42 @@ __global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __rest
         m1[e] = use_stats ? (float)red[ch] * invN : 0.f;
         m2[e] = use_stats ? (float)red[C + ch] * invN : 0.f;
     }
+    if (act == 1 || g_is_masked) {
+        // ReLU (or pre-masked) fast path, 6 VALU ops per element instead of 11 (the pass is otherwise VALU- as much as HBM-bound):
+        //   relu'(y*sc + sh) is a threshold test on y;  sc*(g - m1 - (y-mu)*rs*m2) = A*g + (B*y + C) with per-channel A, B, C
+        float A[8], Bc[8], Cc[8], thr[8];
+        unsigned sgn = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            A[e] = sc[e];
+            Bc[e] = -sc[e] * m2[e] * rs[e];
+            Cc[e] = -sc[e] * m1[e] - Bc[e] * mu[e];
+            float t = sc[e] != 0.f ? -sh[e] / sc[e] : (sh[e] > 0.f ? -INFINITY : INFINITY);
+            if (g_is_masked) t = -INFINITY;
+            else if (sc[e] < 0.f) { t = -t; sgn |= 1u << e; }
+            thr[e] = t;
+        }
+        for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
+            const f8 d = ld8(dz + n * L + col);
+            const f8 v = ld8(y + n * L + col);
+            f8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ys = __uint_as_float(__float_as_uint(v.v[e]) ^ (((sgn >> e) & 1u) << 31));
+                const float g = ys > thr[e] ? d.v[e] : 0.f;
+                o.v[e] = fmaf(A[e], g, fmaf(Bc[e], v.v[e], Cc[e]));
+            }
+            st8(dy + n * L + col, o);
+        }
+        return;
+    }
     for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
         const f8 d = ld8(dz + n * L + col);
         const f8 v = ld8(y + n * L + col);
         f8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float g = g_is_masked ? d.v[e] : d.v[e] * act_bwd(fmaf(v.v[e], sc[e], sh[e]), act);
+            const float g = d.v[e] * act_bwd(fmaf(v.v[e], sc[e], sh[e]), act);
             const float xh = (v.v[e] - mu[e]) * rs[e];
             o.v[e] = sc[e] * (g - m1[e] - xh * m2[e]);          // sc = gamma * rstd
         }
