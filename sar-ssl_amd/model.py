@@ -289,7 +289,14 @@ class SARSSL(nn.Module):
             idx, ch = self.patch_mask.sample(B, 2)
         mp = np.ones((B, T), dtype=np.uint8)
         np.put_along_axis(mp, idx, 0, axis=1)
-        to = lambda a, dt_: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True).to(dt_)
+        # pinned staging: an H2D copy from pageable memory first drains the stream (the host could never run ahead of the GPU
+        # by more than one step); the pinned blocks come from torch's caching host allocator, which keeps them alive until
+        # the asynchronous copy has been consumed
+        def to(a, dt_):
+            h = torch.from_numpy(np.ascontiguousarray(a))
+            if dev.type == "cuda":
+                h = h.pin_memory()
+            return h.to(dev, non_blocking=True).to(dt_)
         return to(idx.astype(np.int32), torch.int32), to(ch.astype(np.int32), torch.int32), to(mp, torch.uint8)
 
     def forward(self, x):
