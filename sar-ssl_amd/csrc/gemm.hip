@@ -102,7 +102,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4)
     const int z0 = z / g.batch_inner, z1 = z % g.batch_inner;
     const int k_begin = g.split_k > 0 ? ks * g.k_per_split : 0;
     const int k_end = g.split_k > 0 ? min(g.K, k_begin + g.k_per_split) : g.K;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with its own L2: in the
+    // natural order the N/128 column tiles of one 128-row A panel land on different XCDs and the panel is fetched from HBM by every
+    // one of them (ffn2: 4 x 67 MB instead of 67 MB).  Remap so that XCD x owns row panels x, x+8, ... and walks all their column
+    // tiles back to back - the A panel is then served by that XCD's L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, j = lin >> 3;
+        by = xcd + 8 * (j / (int)gridDim.x);
+        bx = j % (int)gridDim.x;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const TA* A = (const TA*)g.A + z0 * g.sA0 + z1 * g.sA1;
     const TB* B = (const TB*)g.B + z0 * g.sB0 + z1 * g.sB1;
 
