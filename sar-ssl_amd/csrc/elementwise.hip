@@ -246,33 +246,46 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
     }
 }
 // partial[by][c][k] = sum over this workgroup's (b, t-tile) share of dy[b][t][c] * x[b][t + k - 15][c]
+// Workgroup = 64 channels x 4 waves; the waves take different (b, t-tile)s (4x the loads in flight of the former one-wave
+// workgroups - the kernel is latency-bound on its strided row loads) and are folded through LDS before the partial is written.
 template <typename T>
-__global__ __launch_bounds__(64) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, int nb, int Tn, int d,
-                                                          float* __restrict__ partial) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= d) return;
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, int nb, int Tn, int d,
+                                                           float* __restrict__ partial) {
+    __shared__ float sacc[3][64][DWK + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < d;
     float acc[DWK];
 #pragma unroll
     for (int k = 0; k < DWK; ++k) acc[k] = 0.f;
     const int ntile = (Tn + DWT - 1) / DWT;
-    for (int tile = blockIdx.y; tile < nb * ntile; tile += gridDim.y) {
-        const int b = tile / ntile, t0 = (tile % ntile) * DWT;
-        float win[DWT + DWK - 1];
+    if (live) {
+        for (int tile = blockIdx.y * 4 + wv; tile < nb * ntile; tile += gridDim.y * 4) {
+            const int b = tile / ntile, t0 = (tile % ntile) * DWT;
+            float win[DWT + DWK - 1];
 #pragma unroll
-        for (int i = 0; i < DWT + DWK - 1; ++i) {
-            const int t = t0 - 15 + i;
-            win[i] = (t >= 0 && t < Tn) ? ld_f(x + ((long)b * Tn + t) * d + c) : 0.f;
-        }
+            for (int i = 0; i < DWT + DWK - 1; ++i) {
+                const int t = t0 - 15 + i;
+                win[i] = (t >= 0 && t < Tn) ? ld_f(x + ((long)b * Tn + t) * d + c) : 0.f;
+            }
 #pragma unroll
-        for (int o = 0; o < DWT; ++o) {
-            const float g = (t0 + o < Tn) ? ld_f(dy + ((long)b * Tn + t0 + o) * d + c) : 0.f;
+            for (int o = 0; o < DWT; ++o) {
+                const float g = (t0 + o < Tn) ? ld_f(dy + ((long)b * Tn + t0 + o) * d + c) : 0.f;
 #pragma unroll
-            for (int k = 0; k < DWK; ++k) acc[k] += g * win[o + k];
+                for (int k = 0; k < DWK; ++k) acc[k] += g * win[o + k];
+            }
         }
     }
-    float* P = partial + ((long)blockIdx.y * d + c) * DWK;
+    if (wv > 0) {
 #pragma unroll
-    for (int k = 0; k < DWK; ++k) P[k] = acc[k];
+        for (int k = 0; k < DWK; ++k) sacc[wv - 1][lane][k] = acc[k];
+    }
+    __syncthreads();
+    if (wv == 0 && live) {
+        float* P = partial + ((long)blockIdx.y * d + c) * DWK;
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) P[k] = acc[k] + sacc[0][lane][k] + sacc[1][lane][k] + sacc[2][lane][k];
+    }
 }
 
 // ------------------------------------------------------------------------------------ attention softmax
@@ -629,7 +642,7 @@ extern "C" int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn
     SARSSL_REQUIRE(ksize == DWK && partial, "sarssl_dwconv_wgrad(kernel size must be 31)");
     const int parts = dwconv_wgrad_parts(nb, Tn);
     dim3 grid((d + 63) / 64, parts);
-    DISPATCH_T(dtype, (dwconv_wgrad_kernel<T><<<grid, 64, 0, ST>>>((const T*)dy, (const T*)x, nb, Tn, d, partial)));
+    DISPATCH_T(dtype, (dwconv_wgrad_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, (const T*)x, nb, Tn, d, partial)));
     const long n = (long)d * DWK;
     partial_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, ST>>>(partial, parts, n, dw);
     SARSSL_CHECK_LAUNCH("dwconv_wgrad_kernel");
