@@ -32,9 +32,9 @@ FLOP_PER_SEG_STEP = 86.5e9         # 3 x 28.84 GFLOP forward con
 NSAMPLE = 65792
 
 
-def cpu_baseline(nstep=2, B=8):
+def cpu_baseline(nstep=4, B=8):
     """CPU oracle train step (fp32, B=8: the reference's own CPU-runnable shape) on this host's cores.  Primary figure:
-    8 intra-op threads, the reference's own cap (code/run_pretrain.py:19-24); also reported with all cores."""
+    8 intra-op threads, the reference's own cap (code/run_pretrain.py:19-24)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import recipes
     import sarssl_oracle as orc

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  -- must be imported (and its HIP runtime loaded) BEFORE libsarssl_hip.so so both share one runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsarssl_hip.so")
+LIB_PATH = os.environ.get("SARSSL_HIP_LIB") or os.path.join(_HERE, "csrc", "libsarssl_hip.so")   # override: A/B runs of two builds
 _lib = None
 
 

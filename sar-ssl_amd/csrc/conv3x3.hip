@@ -244,7 +244,9 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
                         *(uint2*)&stg[px * 64 + (((co >> 3) ^ (px & 7)) << 3) + (co & 7)] = w2;
                     }
                 }
-            __syncthreads();
+            // the staging slice is private to this wave: its own LDS writes only have to land (no workgroup barrier)
+            __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
             float ssum[8], ssq[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }

@@ -443,7 +443,24 @@ __global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __rest
             else if (sc[e] < 0.f) { t = -t; sgn |= 1u << e; }
             thr[e] = t;
         }
-        for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
+        const long stride = (long)gridDim.x * rpb;
+        long n = (long)blockIdx.x * rpb + rslot;
+        for (; n + stride < rows; n += 2 * stride) {          // two rows in flight per thread (four 16-byte loads before the first use)
+            const f8 d0 = ld8(dz + n * L + col), v0 = ld8(y + n * L + col);
+            const f8 d1 = ld8(dz + (n + stride) * L + col), v1 = ld8(y + (n + stride) * L + col);
+            f8 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned sb = ((sgn >> e) & 1u) << 31;
+                const float g0 = __uint_as_float(__float_as_uint(v0.v[e]) ^ sb) > thr[e] ? d0.v[e] : 0.f;
+                const float g1 = __uint_as_float(__float_as_uint(v1.v[e]) ^ sb) > thr[e] ? d1.v[e] : 0.f;
+                o0.v[e] = fmaf(A[e], g0, fmaf(Bc[e], v0.v[e], Cc[e]));
+                o1.v[e] = fmaf(A[e], g1, fmaf(Bc[e], v1.v[e], Cc[e]));
+            }
+            st8(dy + n * L + col, o0);
+            st8(dy + (n + stride) * L + col, o1);
+        }
+        for (; n < rows; n += stride) {
             const f8 d = ld8(dz + n * L + col);
             const f8 v = ld8(y + n * L + col);
             f8 o;
