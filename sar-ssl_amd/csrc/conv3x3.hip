@@ -339,6 +339,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int pix_base, int c
     return out;
 }
 
+// Weight-gradient tiles use a column-parity swizzle: 16-byte chunk index XOR 4*((column >> 1) & 1).  A 32-lane transpose read
+// touches 4 consecutive pixels x 4 consecutive chunks; pixels x and x+2 share a bank half, and this flips which four chunks of it
+// they use - conflict-free for every tap (the forward kernel's (pixel>>1)&7 swizzle is 2-way conflicted for these reads), and the
+// XOR term only depends on the column within a 16-pixel block, so fragment addresses are lane constant + affine offset.
+__device__ __forceinline__ int swzc(int p, int col, int chunk) { return (p * 8 + (chunk ^ (((col >> 1) & 1) << 2))) * 8; }
+__device__ __forceinline__ bf16x8 tr_pair(const uint16_t* p0, const uint16_t* p1) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    union { s16x4 v[2]; bf16x8 b; } u;
+    u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    return u.b;
+}
+
 // 8 waves = (co half) x (ci half) x (tap group: taps 0-4 | taps 5-8).  Every wave walks ALL pixels of the tile, so it only
 // needs 5 (4) accumulator fragments = 80 VGPRs; the registers that frees hold the NEXT tile (z halo + dy, 19 x 16 B per
 // thread) which is fetched from HBM while the current tile is on the matrix cores.
@@ -361,6 +374,24 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     for (int t9 = 0; t9 < 5; ++t9)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t9][r] = 0.f;
+
+    // lane-constant parts of the transpose-read addresses (element offsets into sY / sX) for fragment halves h = 0, 1:
+    // A (dy): channels wi*32.., pixels +loff(h);  B (z) for this wave's tap tt: channels wj*32.., pixel (kh, kw + loff(h))
+    int baseA[2], baseB[5][2];
+    {
+        const int chA = wi * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4, chB = wj * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int loff = (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
+            baseA[h] = swzc(loff, loff, chA >> 3) + (chA & 7);
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) {
+                const int tap = tap0 + (tt < ntap ? tt : 0);
+                const int kh = tap / 3, kw = tap - kh * 3;
+                baseB[tt][h] = swzc(kh * HC + kw + loff, kw + loff, chB >> 3) + (chB & 7);
+            }
+        }
+    }
 
     // staging as in the forward kernel: thread = (pixel column pc, 8-channel chunk), halo rows 0..9 + one chunk of columns 64/65
     Chunk<T> rz[X_ITERS], ry[8];
@@ -394,16 +425,16 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int f = tc.f0 - 1 + i;
-            *(uint4*)&sX[swz(i * HC + pc, cch)] = xform_chunk<T>(rz[i], tv && f >= 0 && f < F, a.prologue, sc, sh, a.part_z);
+            *(uint4*)&sX[swzc(i * HC + pc, pc, cch)] = xform_chunk<T>(rz[i], tv && f >= 0 && f < F, a.prologue, sc, sh, a.part_z);
         }
         if (tid < 160) {
             const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
-            *(uint4*)&sX[swz(hr * HC + TCOL + (pc & 1), cch)] = xform_chunk<T>(rz[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_z);
+            *(uint4*)&sX[swzc(hr * HC + TCOL + (pc & 1), TCOL + (pc & 1), cch)] = xform_chunk<T>(rz[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_z);
         }
         const int ty = tc.t0 + pc;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *(uint4*)&sY[swz(i * 64 + pc, cch)] = xform_chunk<T>(ry[i], tc.f0 + i < F && ty < Tn, 0, sc, sh, a.part_dy);
+            *(uint4*)&sY[swzc(i * 64 + pc, pc, cch)] = xform_chunk<T>(ry[i], tc.f0 + i < F && ty < Tn, 0, sc, sh, a.part_dy);
     };
 
     const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -415,21 +446,23 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
         __syncthreads();
         const int next = (it + 1 < nrounds) ? xcd_tile(it + 1, blockIdx.x, gridDim.x) : ntiles;
         if (next < ntiles) issue_loads(next);
+        // Transpose-read addresses are lane constant + (row, column block) offset (see swzc): one VGPR add per fragment half and
+        // row, the column block goes into the instruction's immediate offset.
 #pragma unroll 1
         for (int r = 0; r < TR; ++r) {
-#pragma unroll 1
+            const uint16_t* ya[2] = {sY + baseA[0] + r * (64 * 64), sY + baseA[1] + r * (64 * 64)};
+            const uint16_t* xb[5][2];
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) { xb[tt][0] = sX + baseB[tt][0] + r * (HC * 64); xb[tt][1] = sX + baseB[tt][1] + r * (HC * 64); }
+#pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
-                const int c0 = cb * 16;
-                const bf16x8 fa = tr_frag(sY, r * 64 + c0, wi * 32, lane);
+                const int co_ = cb * 16 * 64;                  // 16 pixels x 64 channels further on
+                const bf16x8 fa = tr_pair(ya[0] + co_, ya[1] + co_);
                 bf16x8 fb[2];
-                { const int kh = tap0 / 3, kw = tap0 - kh * 3; fb[0] = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane); }
+                fb[0] = tr_pair(xb[0][0] + co_, xb[0][1] + co_);
 #pragma unroll
                 for (int tt = 0; tt < 5; ++tt) {
-                    if (tt + 1 < 5 && tt + 1 < ntap) {
-                        const int tap = tap0 + tt + 1;
-                        const int kh = tap / 3, kw = tap - kh * 3;
-                        fb[(tt + 1) & 1] = tr_frag(sX, (r + kh) * HC + c0 + kw, wj * 32, lane);
-                    }
+                    if (tt + 1 < 5 && tt + 1 < ntap) fb[(tt + 1) & 1] = tr_pair(xb[tt + 1][0] + co_, xb[tt + 1][1] + co_);
                     __builtin_amdgcn_sched_barrier(0);         // pin the next tap's transpose reads above this MFMA
                     if (tt < ntap) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tt & 1], acc[tt], 0, 0, 0);
                 }
