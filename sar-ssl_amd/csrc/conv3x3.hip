@@ -42,6 +42,9 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ int swz(int p, int chunk) { return (p * 8 + (chunk ^ ((p >> 1) & 7))) * 8; }
+// input-tile variant: XOR term from the pixel's COLUMN in the halo tile only (same conflict-free ds_read_b128 pattern within a row,
+// and fragment addresses become lane constant + affine offset)
+__device__ __forceinline__ int swzx(int p, int col, int chunk) { return (p * 8 + (chunk ^ ((col >> 1) & 7))) * 8; }
 
 // raw chunk in registers: 8 channels of one pixel
 template <typename T> struct Chunk;
@@ -134,6 +137,18 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
 
     // Halo tile staging.  Thread = (pixel column pc = tid >> 3, 8-channel chunk cch): halo row i of columns 0..63 for i = 0..9, plus
     // one of the 160 chunks of halo columns 64 / 65 for tid < 160 - no per-chunk division, one pointer bump per row.
+    // lane-constant element offsets of the MFMA fragments: W rows (tap*64 + i*32 + lane&31) keep the (row>>1)&7 swizzle, which only
+    // depends on the lane; the input tile uses the column swizzle swzx so that its XOR term only depends on (lane, kw)
+    int laneW[4], laneX[3][4];
+    {
+        const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            laneW[kc] = swz(l31, kc * 2 + hi);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) laneX[kw][kc] = swzx(wave * HC + l31 + kw, l31 + kw, kc * 2 + hi);
+        }
+    }
     Chunk<T> regs[X_ITERS];
     const int pc = tid >> 3;
     auto issue_loads = [&](int tile) {
@@ -158,11 +173,11 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int f = tc.f0 - 1 + i;
-            *(uint4*)&sX[swz(i * HC + pc, cch)] = xform_chunk<T>(regs[i], tv && f >= 0 && f < F, a.prologue, sc, sh, a.part_in);
+            *(uint4*)&sX[swzx(i * HC + pc, pc, cch)] = xform_chunk<T>(regs[i], tv && f >= 0 && f < F, a.prologue, sc, sh, a.part_in);
         }
         if (tid < 160) {
             const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
-            *(uint4*)&sX[swz(hr * HC + TCOL + (pc & 1), cch)] = xform_chunk<T>(regs[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_in);
+            *(uint4*)&sX[swzx(hr * HC + TCOL + (pc & 1), TCOL + (pc & 1), cch)] = xform_chunk<T>(regs[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_in);
         }
     };
 
@@ -189,17 +204,16 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
             // 36 k-steps (9 taps x 4 chunks of 16 channels); fragments of step s+1 are fetched before the MFMAs of step s.
             // LDS addresses are tile-invariant: recomputing them (a few VALU ops hidden under the MFMAs) instead of letting
             // LICM keep ~40 of them live across the tile loop keeps the kernel well under 256 VGPRs.
+            // Fragment addresses = lane constant (laneX[kw][kc], laneW[kc]; computed once per kernel) + compile-time offset of the
+            // (tap, row half): no per-step address arithmetic next to the MFMAs (it cost ~6 VALU ops per MFMA).
             bf16x8 wf[2][2], xf[2][2];
-            int lane_o = lane;
-            asm volatile("" : "+v"(lane_o));
             auto fetch = [&](int s, int buf) {
                 const int tap = s >> 2, kc = s & 3;
                 const int kh = tap / 3, kw = tap - kh * 3;
-                const int chunk = kc * 2 + (lane_o >> 5);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) wf[buf][i] = *(const bf16x8*)&sW[swz(tap * 64 + i * 32 + (lane_o & 31), chunk)];
+                for (int i = 0; i < 2; ++i) wf[buf][i] = *(const bf16x8*)(sW + laneW[kc] + (tap * 64 + i * 32) * 64);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xf[buf][j] = *(const bf16x8*)&sX[swz((wave + kh) * HC + j * 32 + (lane_o & 31) + kw, chunk)];
+                for (int j = 0; j < 2; ++j) xf[buf][j] = *(const bf16x8*)(sX + laneX[kw][kc] + (kh * HC + j * 32) * 64);
             };
             fetch(0, 0);
 #pragma unroll
