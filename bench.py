@@ -124,6 +124,25 @@ def main():
     loss_val = float(last.detach())
     assert np.isfinite(loss_val), "non-finite loss"
 
+    # the same kernel on the same shape with nothing else on the GPU (in the step its launches share the device with the other
+    # encoder's stream, which stretches the event-bracketed durations used for `roofline.achieved`)
+    iso_ms = None
+    if rank == 0 and args.precision == "bf16":
+        xi = torch.randn((args.batch, 256, 256, 64), device=dev).to(torch.bfloat16)
+        wi = (torch.randn((9, 64, 64), device=dev) * 0.05).to(torch.bfloat16)
+        sci, shi = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+        for _ in range(3):
+            hip.conv3x3_fwd(xi, wi, sci, shi)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            hip.conv3x3_fwd(xi, wi, sci, shi)           # BN+ReLU prologue variant (the identity / data-gradient variant is faster)
+        e1.record()
+        torch.cuda.synchronize()
+        iso_ms = e0.elapsed_time(e1) / 10
+        del xi
+
     if rank == 0:
         segs_total = args.batch * world * args.steps
         value = segs_total / elapsed
@@ -149,6 +168,8 @@ def main():
                          "traffic": traffic, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
                          "flop_per_launch": flop_per_launch,
                          "wgrad_avg_ms": round(msw / nw, 4) if nw else None,
+                         "isolated_avg_ms": round(iso_ms, 4) if iso_ms else None,
+                         "isolated_achieved": round(flop_per_launch / (iso_ms * 1e-3) / 1e12, 1) if iso_ms else None,
                          "end_to_end_frac": round(value / world * FLOP_PER_SEG_STEP / (PEAK_BF16_TFLOPS * 1e12), 4)},
             "final_loss": round(loss_val, 5),
         }
