@@ -323,6 +323,207 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
     if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
 }
 
+
+// ------------------------------------------------------------------------------------ forward / dgrad, "ping-pong" variant (bf16)
+// Same arithmetic as conv3x3_fwd_kernel, different schedule.  Per-wave cycle stamps showed that with one 8-wave workgroup per CU the
+// matrix pipe is ~95 % busy during the MFMA phase but that phase is only ~half of a tile: staging, the two workgroup barriers and
+// the output epilogue run with the pipe idle, because all eight waves are always in the same phase.  Here the workgroup is split in
+// two independent halves of four waves (waves w and w+4 share a SIMD, so each half has one wave per SIMD).  Each half owns an
+// (8+2)x(32+2)-pixel input buffer (2 x 42.5 KiB next to the 72 KiB of weights = 157 KiB) and walks its own sequence of 8x32-pixel
+// tiles; the halves only synchronise among their own four waves (an LDS arrival counter - s_barrier would couple all eight).
+// The SIMD arbiter favours the older wave, so the halves drift out of phase by themselves: while one is on the matrix cores the
+// other stages its next tile / drains its outputs.
+#define PTC 32
+#define PHC (PTC + 2)
+#define PX_ELEMS (HR * PHC * 64)                   // 21760 bf16 per half
+
+__device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int lane) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);            // my LDS traffic has landed (lgkmcnt(0))
+    if (lane == 0) atomicAdd(cnt, 1u);
+    epoch += 4;
+    // poll through an LDS-address-space pointer: a generic (flat) load would make every poll wait for the outstanding global
+    // loads / stores as well (flat operations count in vmcnt)
+    volatile __attribute__((address_space(3))) unsigned* c3 = (volatile __attribute__((address_space(3))) unsigned*)cnt;
+    while (*c3 < epoch) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
+    typedef bf16 T;
+    __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
+    __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
+    __shared__ float sStats[128];
+    __shared__ unsigned sSync[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = wave >> 2, hw = wave & 3, htid = tid & 255;
+    const int F = a.F, Tn = a.T;
+    const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + PTC - 1) / PTC;
+    const int ntiles = a.nb * tiles_f * tiles_t;
+    const int npairs = (ntiles + 1) >> 1;
+    const T* in = (const T*)a.in;
+    uint16_t* sX = sXh[half];
+    if (tid < 128) sStats[tid] = 0.f;
+    if (tid < 2) sSync[tid] = 0u;
+    const int cch = tid & 7;
+    {
+        const T* w = (const T*)a.w;
+        for (int q = tid; q < 9 * 64 * 8; q += 512) {
+            const int p = q >> 3, c = q & 7;
+            *(uint4*)&sW[swz(p, c)] = *(const uint4*)(w + (long)p * 64 + c * 8);
+        }
+    }
+    __syncthreads();                                // weights, counters (the only workgroup-wide barrier before the end)
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+
+    // lane-constant fragment addresses; this wave computes rows 2*hw and 2*hw+1 (32 pixels x 64 channels each)
+    int laneW[4], laneX[3][4];
+    {
+        const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            laneW[kc] = swz(l31, kc * 2 + hi);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) laneX[kw][kc] = swzx(2 * hw * PHC + l31 + kw, l31 + kw, kc * 2 + hi);
+        }
+    }
+    auto tile_of = [&](int it) { const int pr = xcd_tile(it, blockIdx.x, gridDim.x); return pr < npairs ? pr * 2 + half : ntiles; };
+    auto coord = [&](int tile) { TileCoord c; c.t0 = (tile % tiles_t) * PTC; tile /= tiles_t; c.f0 = (tile % tiles_f) * TR; c.b = tile / tiles_f; return c; };
+
+    // staging: thread of the half = (pixel column pc = htid >> 3 of 32, chunk): halo rows 0..9 + one chunk of halo columns 32 / 33
+    Chunk<T> regs[X_ITERS];
+    const int pc = htid >> 3;
+    auto issue_loads = [&](int tile) {
+        const TileCoord tc = coord(tile);
+        const int t = tc.t0 - 1 + pc;
+        const bool tv = t >= 0 && t < Tn;
+        const T* base = in + (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            const int f = tc.f0 - 1 + i;
+            regs[i] = load_chunk<T>(base + (long)i * Tn * 64, tv && f >= 0 && f < F);
+        }
+        {
+            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
+            regs[HR] = load_chunk<T>(in + (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8, htid < 160 && f >= 0 && f < F && te < Tn);
+        }
+    };
+    auto write_tile = [&](int tile) {
+        const TileCoord tc = coord(tile);
+        const int t = tc.t0 - 1 + pc;
+        const bool tv = t >= 0 && t < Tn;
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            const int f = tc.f0 - 1 + i;
+            *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = xform_chunk<T>(regs[i], tv && f >= 0 && f < F, a.prologue, sc, sh, 0);
+        }
+        if (htid < 160) {
+            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
+            *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = xform_chunk<T>(regs[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, 0);
+        }
+    };
+
+    unsigned epoch = 0;
+    unsigned* cnt = &sSync[half];
+    const int nrounds = (npairs + gridDim.x - 1) / gridDim.x;
+    if (tile_of(0) < ntiles) issue_loads(tile_of(0));
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0) (see conv3x3_fwd_kernel)
+    for (int it = 0; it < nrounds; ++it) {
+        const int tile = tile_of(it);
+        if (tile >= ntiles) break;                 // (all four waves of the half take the same branch)
+        write_tile(tile);
+        half_barrier(cnt, epoch, lane);
+        const int next = (it + 1 < nrounds) ? tile_of(it + 1) : ntiles;
+        if (next < ntiles) issue_loads(next);
+
+        f32x16 acc[2][2];                          // [co half][row]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        {
+            bf16x8 wf[2][2], xf[2][2];
+            auto fetch = [&](int s, int buf) {
+                const int tap = s >> 2, kc = s & 3;
+                const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) wf[buf][i] = *(const bf16x8*)(sW + laneW[kc] + (tap * 64 + i * 32) * 64);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xf[buf][j] = *(const bf16x8*)(sX + laneX[kw][kc] + ((kh + j) * PHC) * 64);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int s = 0; s < 36; ++s) {
+                const int cur = s & 1;
+                if (s + 1 < 36) fetch(s + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // retire the prefetch before any output store is issued
+        half_barrier(cnt, epoch, lane);                        // the half is done reading its input tile
+        const TileCoord tc = coord(tile);
+        uint16_t* stg = sX + hw * (64 * 64);                   // this wave's [64 px][64 co] slice (px = row * 32 + column)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int px = j * 32 + (lane & 31);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = i * 32 + 8 * g + 4 * (lane >> 5);
+                    uint2 w2;
+                    w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+                    w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                    *(uint2*)&stg[px * 64 + (((co >> 3) ^ (px & 7)) << 3) + (co & 7)] = w2;
+                }
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int px = (lane >> 3) + 8 * k;
+            const int f = tc.f0 + 2 * hw + (px >> 5), t = tc.t0 + (px & 31);
+            const uint4 o = *(const uint4*)&stg[px * 64 + (((lane & 7) ^ (px & 7)) << 3)];
+            if (f < F && t < Tn) {
+                *(uint4*)((uint16_t*)a.out + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8) = o;
+                if (a.stats) {
+                    const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
+                    }
+                }
+            }
+        }
+        if (a.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
+                ssq[e] += __shfl_xor(ssq[e], 8, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], ssq[e]); }
+            }
+        }
+        half_barrier(cnt, epoch, lane);                        // slices drained before the next tile overwrites the buffer
+    }
+    __syncthreads();
+    if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
+}
+
 // ------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const void* dy;       // (B,F,T,64) gradient w.r.t. the conv output
@@ -542,7 +743,11 @@ extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int 
     hipStream_t st = (hipStream_t)stream;
     const int grid = conv_grid(nb, F, T);
     if (dtype == SARSSL_BF16 && w_dtype == SARSSL_BF16) {
-        conv3x3_fwd_kernel<bf16, bf16><<<grid, 512, 0, st>>>(a);
+        static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
+        if (use_pp) {
+            const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
+            conv3x3_fwd_pp_kernel<<<npairs < 256 ? npairs : 256, 512, 0, st>>>(a);
+        } else conv3x3_fwd_kernel<bf16, bf16><<<grid, 512, 0, st>>>(a);
     } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
         if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);
         else {
