@@ -10,7 +10,8 @@ masked MSE -> hand-written backward -> (bucketed RCCL all-reduce overlapped with
 f32 accumulation; dropout active (training mode), nothing cached or skipped.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with events on the launch stream around every launch of the
-dominant kernel (conv3x3_fwd_kernel: 2 forward convs + 2 data-gradient convs per encoder);
+dominant kernel (conv3x3_fwd_pp_kernel, the ping-pong schedule of the 3x3 convolution: 2 forward convs + 2 data-gradient
+convs per encoder);
 `cpu_baseline` times the CPU oracle (oracle/sarssl_oracle.py, the validated restatement of the reference) on this host.
 """
 import argparse
@@ -163,7 +164,7 @@ def main():
             "config": {"workload": "SAR-SSL MC-Conformer cross-channel-reconstruction pretrain step (STFT+mask+fwd+bwd+Adam), "
                                    "2ch 4.112s@16kHz segments, batch %d per GPU, dropout on" % args.batch,
                        "global_batch": args.batch * world, "segment_samples": NSAMPLE, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_kernel", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_pp_kernel", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
                          "flop_per_launch": flop_per_launch,
