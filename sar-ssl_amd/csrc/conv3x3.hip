@@ -474,15 +474,15 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int px = j * 32 + (lane & 31);
+            for (int g = 0; g < 4; ++g) {
+                // chunk (i*4+g) ^ (px & 7) only depends on the lane (px & 7 == lane & 7 for both rows): one address per (i, g)
+                uint16_t* q = stg + (lane & 31) * 64 + ((((i * 4 + g) ^ (lane & 7)) << 3) | (4 * (lane >> 5)));
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = i * 32 + 8 * g + 4 * (lane >> 5);
+                for (int j = 0; j < 2; ++j) {
                     uint2 w2;
                     w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
                     w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-                    *(uint2*)&stg[px * 64 + (((co >> 3) ^ (px & 7)) << 3) + (co & 7)] = w2;
+                    *(uint2*)(q + j * 32 * 64) = w2;
                 }
             }
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -494,7 +494,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         for (int k = 0; k < 8; ++k) {
             const int px = (lane >> 3) + 8 * k;
             const int f = tc.f0 + 2 * hw + (px >> 5), t = tc.t0 + (px & 31);
-            const uint4 o = *(const uint4*)&stg[px * 64 + (((lane & 7) ^ (px & 7)) << 3)];
+            // (px & 7) == (lane >> 3) for every k: lane-constant chunk, k only moves the row offset
+            const uint4 o = *(const uint4*)&stg[px * 64 + (((lane & 7) ^ (lane >> 3)) << 3)];
             if (f < F && t < Tn) {
                 *(uint4*)((uint16_t*)a.out + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8) = o;
                 if (a.stats) {
