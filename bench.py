@@ -178,6 +178,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()                 # rank 0 may still be printing / timing the isolated kernel
         torch.distributed.destroy_process_group()
 
 
