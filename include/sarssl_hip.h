@@ -34,6 +34,10 @@ int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nc
  *      buffer) with samples [offset, offset+nsample) of each file using nthreads positional readers. */
 int sarssl_wav_probe(const char* path, int* nch, int* fs, long* nsample);
 int sarssl_wav_read_batch(const char* const* paths, int n, long nsample, int nch, int fs, long offset, short* out, int nthreads);
+/* ---- host-side mask RNG: PatchMask.forward / gen_mask_idx (code/common/utils_module.py:255-273, 305-308) with Python's own
+ *      MT19937 state (random.getstate()[1]: 624 words + position) - bit-identical index / channel stream, no interpreter loop.
+ *      idx: int64[nbatch][nmasked], ch: int64[nbatch]. */
+int sarssl_mask_sample(unsigned int* mt, int* pos, int nbatch, int npatch, int nmasked, int nmic, long* idx, long* ch);
 /* ---- inverse STFT: code/common/utils_module.py:74-113 (ISTFT.forward = torch.istft, rectangular window, center = inv).
  *      spec: complex64 (B, 257, nt, nch) interleaved; sig: (B, nsample, nch) f32, nsample = (nt+1)*hop (center 0) or
  *      (nt-1)*hop (center 1); frames_ws: sarssl_istft_workspace_bytes(nb, nch, nt) bytes. */

@@ -86,6 +86,53 @@ class PatchRecover(nn.Module):
         return data.transpose(1, 2)
 
 
+def _python_sample(nbatch, npatch, nmasked, nmic):
+    idx = np.empty((nbatch, nmasked), dtype=np.int64)
+    ch = np.empty((nbatch,), dtype=np.int64)
+    for b in range(nbatch):
+        idx[b] = random.sample(range(0, npatch), nmasked)
+        ch[b] = random.randint(0, nmic - 1)
+    return idx, ch
+
+
+def _native_sample(nbatch, npatch, nmasked, nmic):
+    """Same draws from Python's global generator, advanced natively (csrc/wavio.hip: sarssl_mask_sample)."""
+    import ctypes
+    from .. import _lib
+    version, state, gauss = random.getstate()
+    mt = np.array(state[:624], dtype=np.uint32)
+    pos = ctypes.c_int(state[624])
+    idx = np.empty((nbatch, nmasked), dtype=np.int64)
+    ch = np.empty((nbatch,), dtype=np.int64)
+    _lib.call("sarssl_mask_sample", mt.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), ctypes.c_int(nbatch), ctypes.c_int(npatch),
+              ctypes.c_int(nmasked), ctypes.c_int(nmic), idx.ctypes.data_as(ctypes.c_void_p), ch.ctypes.data_as(ctypes.c_void_p))
+    random.setstate((version, tuple(int(v) for v in mt) + (pos.value,), gauss))
+    return idx, ch
+
+
+_NATIVE_OK = None
+
+
+def _native_sampler_ok():
+    """One-time self check: the native sampler must reproduce ``random.sample`` / ``randint`` bit for bit on this interpreter
+    (CPython's algorithm is an implementation detail); otherwise the Python loop is used."""
+    global _NATIVE_OK
+    if _NATIVE_OK is None:
+        saved = random.getstate()
+        try:
+            random.seed(987654321)
+            want = _python_sample(3, 256, 128, 2)
+            after_py = random.getstate()
+            random.seed(987654321)
+            got = _native_sample(3, 256, 128, 2)
+            _NATIVE_OK = bool(np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]) and random.getstate() == after_py)
+        except Exception:
+            _NATIVE_OK = False
+        finally:
+            random.setstate(saved)
+    return _NATIVE_OK
+
+
 class PatchMask(nn.Module):
     """Frame / channel masks.  ``sample`` draws the compact form the kernels use with the reference's exact host RNG
     call order (python ``random``: ``sample(range(npatch), nmasked)`` then ``randint(0, nmic-1)`` per batch item,
@@ -106,12 +153,9 @@ class PatchMask(nn.Module):
 
     def sample(self, nbatch, nmic=2):
         npatch = self.npatch_shape[0] * self.npatch_shape[1]
-        idx = np.empty((nbatch, self.nmasked_patch), dtype=np.int64)
-        ch = np.empty((nbatch,), dtype=np.int64)
-        for b in range(nbatch):
-            idx[b] = random.sample(range(0, npatch), self.nmasked_patch)
-            ch[b] = random.randint(0, nmic - 1)
-        return idx, ch
+        if _native_sampler_ok() and 5 < self.nmasked_patch <= npatch <= 1045 and nmic == 2:
+            return _native_sample(nbatch, npatch, self.nmasked_patch, nmic)
+        return _python_sample(nbatch, npatch, self.nmasked_patch, nmic)
 
     def forward(self, data_shape):
         nbatch, npatch, dpatch, _, nmic = data_shape

@@ -113,3 +113,46 @@ extern "C" int sarssl_wav_read_batch(const char* const* paths, int n, long nsamp
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ mask sampling (host)
+// PatchMask.forward (code/common/utils_module.py:263-267, 305-308) draws, per batch item, random.sample(range(npatch), nmasked)
+// then random.randint(0, nmic-1) from Python's global Mersenne Twister.  64 x sample(256, 128) costs 3.5 ms of interpreter time
+// per step; this restates exactly what CPython does with the generator state (random.getstate() -> 624 words + position):
+//   genrand_uint32 (MT19937), getrandbits(k <= 32) = genrand >> (32 - k), _randbelow(n) = rejection on n.bit_length() bits,
+//   sample(): pool-based selection (n <= setsize: always true for npatch <= 1045 when nmasked > 5), randint(a,b) = a + _randbelow(b-a+1)
+// so the stream of masks is bit-identical to the reference's for the same seed.  mt: 624 state words, *pos in/out.
+static inline uint32_t mt_genrand(uint32_t* mt, int* pos) {
+    if (*pos >= 624) {
+        static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+        int kk; uint32_t y;
+        for (kk = 0; kk < 624 - 397; kk++) { y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1u]; }
+        for (; kk < 623; kk++) { y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1u]; }
+        y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu); mt[623] = mt[396] ^ (y >> 1) ^ mag01[y & 1u];
+        *pos = 0;
+    }
+    uint32_t y = mt[(*pos)++];
+    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+    return y;
+}
+static inline int bit_length(uint32_t n) { int k = 0; while (n) { ++k; n >>= 1; } return k; }
+static inline uint32_t mt_randbelow(uint32_t* mt, int* pos, uint32_t n) {
+    const int k = bit_length(n);
+    uint32_t r = mt_genrand(mt, pos) >> (32 - k);
+    while (r >= n) r = mt_genrand(mt, pos) >> (32 - k);
+    return r;
+}
+extern "C" int sarssl_mask_sample(unsigned int* mt, int* pos, int nbatch, int npatch, int nmasked, int nmic, long* idx, long* ch) {
+    SARSSL_REQUIRE(mt && pos && idx && ch && nbatch >= 0 && npatch > 0 && npatch <= 1045 && nmasked > 5 && nmasked <= npatch && nmic >= 1,
+                   "sarssl_mask_sample(5 < nmasked <= npatch <= 1045)");
+    std::vector<long> pool(npatch);
+    for (int b = 0; b < nbatch; ++b) {
+        for (int i = 0; i < npatch; ++i) pool[i] = i;
+        for (int i = 0; i < nmasked; ++i) {
+            const uint32_t j = mt_randbelow(mt, pos, (uint32_t)(npatch - i));
+            idx[(long)b * nmasked + i] = pool[j];
+            pool[j] = pool[npatch - i - 1];
+        }
+        ch[b] = (long)mt_randbelow(mt, pos, (uint32_t)nmic);          // randint(0, nmic-1) = randrange(0, nmic)
+    }
+    return 0;
+}

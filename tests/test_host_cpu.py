@@ -191,3 +191,28 @@ def test_native_wav_batch_reader_and_segment_loader(tmp_path):
     it = iter(dataset.PcmSegmentLoader(files, batch_size=2, nthreads=2))
     next(it)
     it.close()
+
+
+def test_native_mask_sampler_is_bit_identical_to_python_random():
+    """The C-ABI mask sampler (sarssl_mask_sample) advances Python's own Mersenne Twister: same indices, same channels and the
+    same generator state afterwards as random.sample / random.randint, for the shapes of configs 1-5."""
+    import random
+    from sar_ssl_amd.common import utils_module as um
+    assert um._native_sampler_ok()
+    for seed, (nb, n, k) in enumerate([(64, 256, 128), (8, 256, 128), (3, 624, 312), (5, 64, 32), (2, 16, 8), (1, 1045, 6)]):
+        random.seed(1000 + seed)
+        want = um._python_sample(nb, n, k, 2)
+        state_want = random.getstate()
+        random.seed(1000 + seed)
+        got = um._native_sample(nb, n, k, 2)
+        assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]) and random.getstate() == state_want
+        assert random.random() == (random.setstate(state_want) or random.random())     # the stream continues identically
+    pm = um.PatchMask("T", 128, [1, 256], "cpu")
+    z = np.load(os.path.join(GOLD, "f4_masks.npz"))
+    random.seed(0)
+    idx, ch = pm.sample(4, 2)
+    key = [k for k in z.files if k.endswith(".idx")][0]
+    seed0 = int(key.split(".")[0].replace("seed", ""))
+    random.seed(seed0)
+    idx, ch = pm.sample(4, 2)
+    assert np.array_equal(idx, z["seed%d.idx" % seed0]) and np.array_equal(ch.reshape(-1), z["seed%d.ch" % seed0].reshape(-1))
