@@ -7,7 +7,7 @@ parameters are passed to ``apply`` only to make the output require grad; their r
 import torch
 
 from . import hip
-from .runtime import RT
+from .runtime import RT, begin_forward
 
 
 def _to_rt(x):
@@ -33,6 +33,7 @@ class _TapeFn(torch.autograd.Function):
 
 
 def tape_apply(module, fwd, bwd, x):
+    begin_forward(module.parameters())
     params = [p for p in module.parameters() if p.requires_grad]
     if torch.is_grad_enabled() and (x.requires_grad or params):
         return _TapeFn.apply(fwd, bwd, x, *params)

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import engine, hip
 from .autograd import tape_apply
-from .runtime import RT
+from .runtime import RT, begin_forward as runtime_begin_forward
 from .common import utils_module as at_module
 from .common.Conformer import ConformerEncoder
 
@@ -134,6 +134,7 @@ class _PretrainFn(torch.autograd.Function):
     def forward(ctx, net, x, idx_i32, ch_i32, mp_u8, *params):
         B, _, F, T, _ = x.shape
         saved = []
+        runtime_begin_forward(net.parameters() if not params else params)
         spec_in, spat_in = hip.mask_inputs(x, mp_u8, ch_i32, 0, RT.dtype)
         ds, dt_ = net.spec_encoder.dembed, net.spat_encoder.dembed
         ecat = torch.empty((B * T, ds + dt_), dtype=RT.dtype, device=x.device)
@@ -143,9 +144,7 @@ class _PretrainFn(torch.autograd.Function):
         side = net._side_stream(x.device)
         main = torch.cuda.current_stream()
         if side is not None:
-            flat = getattr(params[0], "_flat", None) if params else None
-            if flat is not None:
-                flat.ensure_shadow()                       # any lazy weight refresh happens before the fork, on the main stream
+            pass                                           # (the lazy weight refresh already happened in begin_forward, on the main stream)
             side.wait_stream(main)
             # tensors allocated on the main stream but consumed on the side stream: tell the caching allocator, otherwise their
             # memory can be recycled by main-stream allocations while side-stream kernels that read them are still queued

@@ -64,12 +64,25 @@ def wt(p):
         return p.data
     flat = getattr(p, "_flat", None)
     if flat is not None:
-        flat.ensure_shadow()
+        if not flat._fresh:                    # one full version scan per top-level forward (begin_forward), not per weight use
+            flat.ensure_shadow()
         return p._w16
     cache = getattr(p, "_w16_cache", None)
     if cache is None or cache[0] != p._version:
         p._w16_cache = (p._version, hip.cast(p.data.contiguous(), torch.bfloat16))
     return p._w16_cache[1]
+
+
+def begin_forward(params):
+    """Called once at every top-level forward entry (the pretraining autograd node, tape_apply): re-validates the bf16 shadow
+    weights of the flat buffer(s) the parameters live in.  ``wt`` then trusts it for the rest of that forward / backward."""
+    seen = None
+    for p in params:
+        flat = getattr(p, "_flat", None)
+        if flat is not None and flat is not seen:
+            flat._fresh = False
+            flat.ensure_shadow()
+            seen = flat
 
 
 def gbuf(p):
@@ -129,6 +142,7 @@ class FlatParams:
             p._w16 = self.w16[o:o + n].view(p.shape)
             p._flat = self
         self._synced = None
+        self._fresh = False
         self.ensure_shadow()
 
     def _sig(self):
@@ -142,6 +156,7 @@ class FlatParams:
                 hip.cast(self.flat, torch.bfloat16, out=self.w16)
             self._synced = sig
             bump_version()
+        self._fresh = True
 
     def zero_grad(self):
         self.grad.zero_()

@@ -24,3 +24,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
