@@ -8,6 +8,8 @@ Reference semantics are cited per function; the math is restated in oracle/sarss
 """
 import math
 
+import os
+
 import torch
 
 from . import hip
@@ -113,6 +115,9 @@ def stem_fwd(a0, pe, train, saved):
     return e
 
 
+_C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
+
+
 def stem_bwd(de, pe, saved):
     a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
     B, F, T, _ = a0.shape
@@ -126,9 +131,13 @@ def stem_bwd(de, pe, saved):
     dy4 = hip.cl_bn_bwd_apply(dz4, y4, 4, aff4, RELU, False, train, red4)
     bn_param_grads(pe[10], red4, 4)
     # 64->4 conv + BN3/ReLU backward reductions in one pass over y3
-    g3, red = hip.stem_c4_bwd(y3, dy4, pe[9].weight.data.view(4, 64), aff3)
-    hip.f64_accum(red[:256], gbuf(pe[9].weight))
-    dy3 = hip.cl_bn_bwd_apply(g3, y3, 64, aff3, RELU, True, train, red[256:], out=g3)
+    if _C4_TWO_PHASE:       # sums pass + direct dy3 pass: 1.7 GB per encoder instead of 2.7 GB (c4_bwd + in-place BatchNorm apply)
+        dy3, red = hip.stem_c4_bwd_two_phase(y3, dy4, pe[9].weight.data.view(4, 64), aff3, train)
+        hip.f64_accum(red[:256], gbuf(pe[9].weight))
+    else:
+        g3, red = hip.stem_c4_bwd(y3, dy4, pe[9].weight.data.view(4, 64), aff3)
+        hip.f64_accum(red[:256], gbuf(pe[9].weight))
+        dy3 = hip.cl_bn_bwd_apply(g3, y3, 64, aff3, RELU, True, train, red[256:], out=g3)
     bn_param_grads(pe[7], red[256:], 64)
     # second 3x3 conv
     dW = hip.conv3x3_wgrad(dy3, y2, aff2[0], aff2[1], precise=RT.precise)

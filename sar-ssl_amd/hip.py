@@ -206,6 +206,19 @@ def stem_c4_bwd(y3, dy4, W4, aff):
     return g3, red
 
 
+def stem_c4_bwd_two_phase(y3, dy4, W4, aff, train):
+    """-> dy3 (B,F,T,64) = gradient w.r.t. the third BatchNorm's input, red f64[384] = [dW4 | s1 | s2]; two kernels, no
+    intermediate 64-channel tensor."""
+    B, F, T, _ = y3.shape
+    red = torch.empty((384,), dtype=torch.float64, device=y3.device)
+    _lib.call("sarssl_stem_c4_bwd_sums", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
+              c_int(T), _p(red), c_int(dt(y3)), _stream())
+    dy3 = torch.empty_like(y3)
+    _lib.call("sarssl_stem_c4_bwd_apply", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
+              c_int(T), _p(red), c_int(1 if train else 0), _p(dy3), c_int(dt(y3)), _stream())
+    return dy3, red
+
+
 def f64_accum(src, dst, scale=1.0):
     _lib.call("sarssl_f64_accum", _p(src), _p(dst), c_int(src.numel()), c_float(scale), _stream())
 

@@ -189,6 +189,26 @@ def test_conv3x3_wgrad_and_dgrad(mode, B, F, T):
 
 
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("train", [True, False])
+def test_stem_c4_backward_two_phase_matches_one_pass_plus_apply(dtp, train):
+    """sums-only pass + direct dy3 pass == (g3 + sums) pass followed by the in-place BatchNorm-backward normalisation."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    B, F, T = 2, 24, 40
+    y3 = torch.randn((B, F, T, 64), generator=g).to(dtp).to(dev)
+    dy4 = torch.randn((B, T, F, 4), generator=g).to(dtp).to(dev)
+    W4 = (torch.randn((4, 64), generator=g) * 0.2).to(dev)
+    aff = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1,
+                       torch.rand(64, generator=g) + 0.5]).contiguous().to(dev)
+    g3, red_ref = hip.stem_c4_bwd(y3, dy4, W4, aff)
+    dy3_ref = hip.cl_bn_bwd_apply(g3, y3, 64, aff, 1, True, train, red_ref[256:])
+    dy3, red = hip.stem_c4_bwd_two_phase(y3, dy4, W4, aff, train)
+    assert _relerr(red, red_ref) < 1e-6
+    assert _relerr(dy3.float(), dy3_ref.float()) < (1e-5 if dtp == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
 def test_stem_pointwise_and_bn(dtp):
     from sar_ssl_amd import hip
     dev = _dev()
