@@ -59,6 +59,9 @@ int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, 
                        void* spat, int dtype, void* stream);
 int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, double* stats, int dtype, void* stream);
 int sarssl_stem_c1_wgrad(const void* dy1, const void* a0, long npix, double* dW1d, int dtype, void* stream);
+/*      same, from (dz1, y1): the first BatchNorm's backward normalisation is applied in registers (dy1 is never stored) */
+int sarssl_stem_c1_wgrad_bn(const void* dz1, const void* y1, const void* a0, long npix, const float* aff, const double* bnred,
+                            int use_stats, double* dW1d, int dtype, void* stream);
 int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                        const float* scale, const float* shift, int precise, float* ws, double* stats, void* stream);
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);

@@ -88,10 +88,29 @@ __global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ 
 }
 
 // dW1[co][c] = sum_p dy1[p][co] a0[p][c]   (double accumulators dW1d[64*4], zeroed by the caller)
-template <typename T>
-__global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const T* __restrict__ a0, long npix, double* __restrict__ dW1d) {
+// BNF = 1: dy1 is not materialised - the kernel reads dz1 (gradient w.r.t. relu(bn1(y1))) and y1 and applies the BatchNorm-backward
+// normalisation dy1 = gamma*rstd*(g - s1/N - xhat*s2/N), g = dz1*relu'(bn1(y1)), on the fly (folded to A*g + B*y + C per channel).
+// The first conv's input is data, so dy1 has no other consumer: this removes one 64-channel write and one read per encoder.
+template <typename T, int BNF>
+__global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const T* __restrict__ a0, long npix, double* __restrict__ dW1d,
+                                     const T* __restrict__ y1, const float* __restrict__ aff, const double* __restrict__ bnred, int use_stats) {
     __shared__ float red[256][33];
     const int cg = threadIdx.x & 7;
+    float cA[8], cB[8], cC[8], thr[8];
+    unsigned sgn = 0u;
+    if (BNF) {
+        const float invN = 1.0f / (float)npix;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = cg * 8 + e;
+            const float sc = aff[ch], sh = aff[64 + ch], mu = aff[128 + ch], rs = aff[192 + ch];
+            const float m1 = use_stats ? (float)bnred[ch] * invN : 0.f, m2 = use_stats ? (float)bnred[64 + ch] * invN : 0.f;
+            cA[e] = sc; cB[e] = -sc * m2 * rs; cC[e] = -sc * m1 - cB[e] * mu;
+            float t = sc != 0.f ? -sh / sc : (sh > 0.f ? -INFINITY : INFINITY);
+            if (sc < 0.f) { t = -t; sgn |= 1u << e; }
+            thr[e] = t;
+        }
+    }
     float acc[8][4];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -101,7 +120,16 @@ __global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const T* __restr
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
         const long p = g >> 3;
         const float4 a = ld4(a0 + p * 4);
-        const f8 d = ld8(dy1 + p * 64 + cg * 8);
+        f8 d = ld8(dy1 + p * 64 + cg * 8);
+        if (BNF) {
+            const f8 v = ld8(y1 + p * 64 + cg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ys = __uint_as_float(__float_as_uint(v.v[e]) ^ (((sgn >> e) & 1u) << 31));
+                const float g = ys > thr[e] ? d.v[e] : 0.f;
+                d.v[e] = fmaf(cA[e], g, fmaf(cB[e], v.v[e], cC[e]));
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { acc[e][0] += d.v[e] * a.x; acc[e][1] += d.v[e] * a.y; acc[e][2] += d.v[e] * a.z; acc[e][3] += d.v[e] * a.w; }
     }
@@ -539,8 +567,18 @@ extern "C" int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, vo
 extern "C" int sarssl_stem_c1_wgrad(const void* dy1, const void* a0, long npix, double* dW1d, int dtype, void* stream) {
     if (hipMemsetAsync(dW1d, 0, 256 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for(npix * 8, 256, 1024);
-    DISPATCH_T(dtype, (stem_c1_wgrad_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dy1, (const T*)a0, npix, dW1d)));
+    DISPATCH_T(dtype, (stem_c1_wgrad_kernel<T, 0><<<nblk, 256, 0, ST>>>((const T*)dy1, (const T*)a0, npix, dW1d, (const T*)nullptr, nullptr, nullptr, 0)));
     SARSSL_CHECK_LAUNCH("stem_c1_wgrad_kernel");
+    return 0;
+}
+// dW1 from (dz1, y1) with the first BatchNorm's backward normalisation applied in registers; aff = [scale|shift|mean|rstd] (4 x 64),
+// bnred = [s1 | s2] f64[128] (cl_bn_bwd_reduce / conv epilogue), use_stats = 0 for eval-mode BatchNorm.
+extern "C" int sarssl_stem_c1_wgrad_bn(const void* dz1, const void* y1, const void* a0, long npix, const float* aff,
+                                       const double* bnred, int use_stats, double* dW1d, int dtype, void* stream) {
+    if (hipMemsetAsync(dW1d, 0, 256 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for(npix * 8, 256, 1024);
+    DISPATCH_T(dtype, (stem_c1_wgrad_kernel<T, 1><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)a0, npix, dW1d, (const T*)y1, aff, bnred, use_stats)));
+    SARSSL_CHECK_LAUNCH("stem_c1_wgrad_kernel<bn>");
     return 0;
 }
 

@@ -116,6 +116,7 @@ def stem_fwd(a0, pe, train, saved):
 
 
 _C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
+_C1_FUSED = os.environ.get("SARSSL_C1_FUSED", "1") != "0"
 
 
 def stem_bwd(de, pe, saved):
@@ -151,9 +152,12 @@ def stem_bwd(de, pe, saved):
     gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
     dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
     red1 = hip.cl_bn_bwd_reduce(dz1, y1, 64, aff1, RELU)
-    dy1 = hip.cl_bn_bwd_apply(dz1, y1, 64, aff1, RELU, False, train, red1, out=dz1)
     bn_param_grads(pe[1], red1, 64)
-    hip.stem_c1_wgrad(dy1, a0, gbuf(pe[0].weight))
+    if _C1_FUSED:           # dy1 feeds nothing but this weight gradient (the stem input is data): normalise it in registers
+        hip.stem_c1_wgrad_bn(dz1, y1, a0, aff1, red1, train, gbuf(pe[0].weight))
+    else:
+        dy1 = hip.cl_bn_bwd_apply(dz1, y1, 64, aff1, RELU, False, train, red1, out=dz1)
+        hip.stem_c1_wgrad(dy1, a0, gbuf(pe[0].weight))
     return None        # the stem input is data
 
 

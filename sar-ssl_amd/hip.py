@@ -189,6 +189,15 @@ def stem_c1_wgrad(dy1, a0, grad_out):
     _lib.call("sarssl_f64_accum", _p(ws), _p(grad_out), c_int(256), c_float(1.0), _stream())
 
 
+def stem_c1_wgrad_bn(dz1, y1, a0, aff, red, train, grad_out):
+    """grad_out (64,4,1,1) f32 += dW1, from the gradient w.r.t. relu(bn1(y1)) - BatchNorm backward folded into the kernel."""
+    npix = a0.numel() // 4
+    ws = _f64ws(256, a0.device, "c1w")
+    _lib.call("sarssl_stem_c1_wgrad_bn", _p(dz1), _p(y1), _p(a0), c_long(npix), _p(aff), _p(red), c_int(1 if train else 0), _p(ws),
+              c_int(dt(a0)), _stream())
+    _lib.call("sarssl_f64_accum", _p(ws), _p(grad_out), c_int(256), c_float(1.0), _stream())
+
+
 def stem_c4_fwd(y3, W4, scale, shift):
     B, F, T, _ = y3.shape
     y4 = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)

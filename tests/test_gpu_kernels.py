@@ -209,6 +209,28 @@ def test_stem_c4_backward_two_phase_matches_one_pass_plus_apply(dtp, train):
 
 
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("train", [True, False])
+def test_stem_c1_wgrad_with_fused_bn_backward(dtp, train):
+    """dW1 from (dz1, y1) with the BatchNorm-backward normalisation in registers == normalise (cl_bn_bwd_apply) then stem_c1_wgrad."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(33)
+    B, F, T = 2, 16, 24
+    dz1 = torch.randn((B, F, T, 64), generator=g).to(dtp).to(dev)
+    y1 = torch.randn((B, F, T, 64), generator=g).to(dtp).to(dev)
+    a0 = torch.randn((B, F, T, 4), generator=g).to(dtp).to(dev)
+    aff = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1,
+                       torch.rand(64, generator=g) + 0.5]).contiguous().to(dev)
+    red = hip.cl_bn_bwd_reduce(dz1, y1, 64, aff, 1)
+    dy1 = hip.cl_bn_bwd_apply(dz1, y1, 64, aff, 1, False, train, red)
+    ref = torch.zeros((64, 4, 1, 1), device=dev)
+    hip.stem_c1_wgrad(dy1, a0, ref)
+    got = torch.zeros((64, 4, 1, 1), device=dev)
+    hip.stem_c1_wgrad_bn(dz1, y1, a0, aff, red, train, got)
+    assert _relerr(got, ref) < (1e-5 if dtp == torch.float32 else 1e-2)      # (bf16: the reference path rounds dy1 to bf16 in between)
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
 def test_stem_pointwise_and_bn(dtp):
     from sar_ssl_amd import hip
     dev = _dev()
