@@ -60,6 +60,10 @@ int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, 
 int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, double* stats, int dtype, void* stream);
 int sarssl_stem_c1_wgrad(const void* dy1, const void* a0, long npix, double* dW1d, int dtype, void* stream);
 /*      same, from (dz1, y1): the first BatchNorm's backward normalisation is applied in registers (dy1 is never stored) */
+/*      the whole backward of the first stem layer (BatchNorm sums, dgamma/dbeta, dW1) in one pass over (dz1, y1, a0): red = f64[644]
+ *      workspace, dW1 (64x4) / dgamma / dbeta (64) are f32 buffers accumulated into */
+int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a0, long npix, const float* aff, int use_stats, double* red,
+                       float* dW1, float* dgamma, float* dbeta, int dtype, void* stream);
 int sarssl_stem_c1_wgrad_bn(const void* dz1, const void* y1, const void* a0, long npix, const float* aff, const double* bnred,
                             int use_stats, double* dW1d, int dtype, void* stream);
 int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,

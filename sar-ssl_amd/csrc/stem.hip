@@ -148,6 +148,82 @@ __global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const T* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole backward of the first stem layer in ONE pass over (dz1, y1, a0).  With g = dz1 * relu'(bn1(y1)), xhat = (y1 - mean) * rstd:
+//   BatchNorm sums   s1[co] = sum_p g,  s2[co] = sum_p g * xhat
+//   dW1[co][c] = sum_p dy1[p][co] a0[p][c],  dy1 = gamma*rstd * (g - s1/N - xhat * s2/N)
+//              = gamma*rstd * ( G[co][c] - (s1/N) * Sa[c] - (s2/N) * X[co][c] ),   G = sum g a0,  X = sum xhat a0,  Sa = sum a0
+// so the gradient never has to be normalised per element: G, X, Sa, s1, s2 are accumulated together and a 256-thread finalize
+// kernel combines them.  Replaces cl_bn_bwd_reduce + cl_bn_bwd_apply + stem_c1_wgrad (6 passes over 64-channel tensors -> 2).
+// red: f64[644] = [G 64x4 | X 64x4 | s1 64 | s2 64 | Sa 4], zeroed by the caller.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_c1_bwd_kernel(const T* __restrict__ dz1, const T* __restrict__ y1, const T* __restrict__ a0,
+                                                          long npix, const float* __restrict__ aff, double* __restrict__ red) {
+    __shared__ float sred[4][8][84];
+    const int cg = threadIdx.x & 7;
+    float mu[8], rs[8], thr[8];
+    unsigned sgn = 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = cg * 8 + e;
+        const float sc = aff[ch], sh = aff[64 + ch];
+        mu[e] = aff[128 + ch]; rs[e] = aff[192 + ch];
+        float t = sc != 0.f ? -sh / sc : (sh > 0.f ? -INFINITY : INFINITY);
+        if (sc < 0.f) { t = -t; sgn |= 1u << e; }
+        thr[e] = t;
+    }
+    float acc[84];                               // [0,32) G[e][c], [32,64) X[e][c], [64,72) s1, [72,80) s2, [80,84) Sa
+#pragma unroll
+    for (int i = 0; i < 84; ++i) acc[i] = 0.f;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads) {
+        const long p = g0 >> 3;
+        const float4 a = ld4(a0 + p * 4);
+        const f8 d = ld8(dz1 + p * 64 + cg * 8);
+        const f8 v = ld8(y1 + p * 64 + cg * 8);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ys = __uint_as_float(__float_as_uint(v.v[e]) ^ (((sgn >> e) & 1u) << 31));
+            const float g = ys > thr[e] ? d.v[e] : 0.f;
+            const float xh = (v.v[e] - mu[e]) * rs[e];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { acc[e * 4 + c] = fmaf(g, av[c], acc[e * 4 + c]); acc[32 + e * 4 + c] = fmaf(xh, av[c], acc[32 + e * 4 + c]); }
+            acc[64 + e] += g;
+            acc[72 + e] = fmaf(g, xh, acc[72 + e]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[80 + c] += av[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 84; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8, 64); acc[i] += __shfl_xor(acc[i], 16, 64); acc[i] += __shfl_xor(acc[i], 32, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 8) {
+#pragma unroll
+        for (int i = 0; i < 84; ++i) sred[wave][lane][i] = acc[i];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 644; o += 256) {
+        int grp, slot;
+        if (o < 512) { const int which = o >> 8, co = (o & 255) >> 2, c = o & 3; grp = co >> 3; slot = which * 32 + (co & 7) * 4 + c; }
+        else if (o < 640) { const int which = (o - 512) >> 6, co = (o - 512) & 63; grp = co >> 3; slot = 64 + which * 8 + (co & 7); }
+        else { grp = 0; slot = 80 + (o - 640); }               // Sa: every channel group saw every pixel once - take group 0's copy
+        atomicAdd(&red[o], (double)(sred[0][grp][slot] + sred[1][grp][slot] + sred[2][grp][slot] + sred[3][grp][slot]));
+    }
+}
+// dW1[co][c] += gamma*rstd * (G - s1/N * Sa - s2/N * X)   (use_stats = 0, eval-mode BatchNorm: gamma*rstd * G);  dgamma += s2, dbeta += s1
+__global__ void stem_c1_bwd_finalize_kernel(const double* __restrict__ red, long npix, const float* __restrict__ aff, int use_stats,
+                                            float* __restrict__ dW1, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int o = threadIdx.x;                                 // co*4 + c
+    const int co = o >> 2, c = o & 3;
+    const double invN = 1.0 / (double)npix;
+    const double m1 = use_stats ? red[512 + co] * invN : 0.0, m2 = use_stats ? red[576 + co] * invN : 0.0;
+    dW1[o] += (float)((double)aff[co] * (red[o] - m1 * red[640 + c] - m2 * red[256 + o]));
+    if (c == 0) { dbeta[co] += (float)red[512 + co]; dgamma[co] += (float)red[576 + co]; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // y4[b][t][f][c] = sum_ci W4[c][ci] * relu(y3[b][f][t][ci]*scale[ci] + shift[ci])
 // 8 lanes per pixel (one 16-byte chunk each), shuffle-reduced.
 template <typename T>
@@ -579,6 +655,19 @@ extern "C" int sarssl_stem_c1_wgrad_bn(const void* dz1, const void* y1, const vo
     const int nblk = nblocks_for(npix * 8, 256, 1024);
     DISPATCH_T(dtype, (stem_c1_wgrad_kernel<T, 1><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)a0, npix, dW1d, (const T*)y1, aff, bnred, use_stats)));
     SARSSL_CHECK_LAUNCH("stem_c1_wgrad_kernel<bn>");
+    return 0;
+}
+
+// One-pass backward of the first stem layer (see stem_c1_bwd_kernel).  red: f64[644] workspace (zeroed here); dW1 (64x4), dgamma, dbeta
+// (64) are f32 gradient buffers that are accumulated into.  aff = [scale|shift|mean|rstd] (4 x 64).
+extern "C" int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a0, long npix, const float* aff, int use_stats,
+                                  double* red, float* dW1, float* dgamma, float* dbeta, int dtype, void* stream) {
+    SARSSL_REQUIRE(npix > 0 && red && dW1 && dgamma && dbeta, "sarssl_stem_c1_bwd");
+    if (hipMemsetAsync(red, 0, 644 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for(npix * 8, 256, 1024);
+    DISPATCH_T(dtype, (stem_c1_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)y1, (const T*)a0, npix, aff, red)));
+    stem_c1_bwd_finalize_kernel<<<1, 256, 0, ST>>>(red, npix, aff, use_stats, dW1, dgamma, dbeta);
+    SARSSL_CHECK_LAUNCH("stem_c1_bwd_kernel");
     return 0;
 }
 

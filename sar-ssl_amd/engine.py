@@ -116,7 +116,7 @@ def stem_fwd(a0, pe, train, saved):
 
 
 _C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
-_C1_FUSED = os.environ.get("SARSSL_C1_FUSED", "1") != "0"
+_C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 
 
 def stem_bwd(de, pe, saved):
@@ -151,6 +151,9 @@ def stem_bwd(de, pe, saved):
     dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise)
     gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
     dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
+    if _C1_FUSED == 2:      # everything the first layer needs from (dz1, y1, a0) in one pass: BN sums, dgamma/dbeta, dW1
+        hip.stem_c1_bwd(dz1, y1, a0, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
+        return None
     red1 = hip.cl_bn_bwd_reduce(dz1, y1, 64, aff1, RELU)
     bn_param_grads(pe[1], red1, 64)
     if _C1_FUSED:           # dy1 feeds nothing but this weight gradient (the stem input is data): normalise it in registers

@@ -198,6 +198,15 @@ def stem_c1_wgrad_bn(dz1, y1, a0, aff, red, train, grad_out):
     _lib.call("sarssl_f64_accum", _p(ws), _p(grad_out), c_int(256), c_float(1.0), _stream())
 
 
+def stem_c1_bwd(dz1, y1, a0, aff, train, dW1, dgamma, dbeta):
+    """One pass: dW1 (64,4,1,1) += ..., dgamma / dbeta (64) += BatchNorm(1) parameter gradients, from the gradient w.r.t.
+    relu(bn1(y1))."""
+    npix = a0.numel() // 4
+    ws = _f64ws(644, a0.device, "c1b")
+    _lib.call("sarssl_stem_c1_bwd", _p(dz1), _p(y1), _p(a0), c_long(npix), _p(aff), c_int(1 if train else 0), _p(ws), _p(dW1),
+              _p(dgamma), _p(dbeta), c_int(dt(a0)), _stream())
+
+
 def stem_c4_fwd(y3, W4, scale, shift):
     B, F, T, _ = y3.shape
     y4 = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)

@@ -231,6 +231,32 @@ def test_stem_c1_wgrad_with_fused_bn_backward(dtp, train):
 
 
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("train", [True, False])
+def test_stem_first_layer_backward_in_one_pass(dtp, train):
+    """stem_c1_bwd (BatchNorm sums, dgamma/dbeta and dW1 from one pass, combined algebraically) == reduce + normalise + weight gradient."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(35)
+    B, F, T = 2, 16, 24
+    dz1 = torch.randn((B, F, T, 64), generator=g).to(dtp).to(dev)
+    y1 = (torch.randn((B, F, T, 64), generator=g) * 0.7 + 0.2).to(dtp).to(dev)
+    a0 = torch.randn((B, F, T, 4), generator=g).to(dtp).to(dev)
+    aff = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1 + 0.2,
+                       torch.rand(64, generator=g) + 0.5]).contiguous().to(dev)
+    aff[0, 5] = -aff[0, 5]                                        # a negative BatchNorm scale flips the ReLU threshold test
+    red = hip.cl_bn_bwd_reduce(dz1, y1, 64, aff, 1)
+    dy1 = hip.cl_bn_bwd_apply(dz1.float(), y1.float(), 64, aff, 1, False, train, red)      # f32 reference normalisation
+    ref = torch.zeros((64, 4, 1, 1), device=dev)
+    hip.stem_c1_wgrad(dy1, a0.float(), ref)
+    dW, dga, dbe = torch.zeros((64, 4, 1, 1), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    hip.stem_c1_bwd(dz1, y1, a0, aff, train, dW, dga, dbe)
+    assert _relerr(dW, ref) < 2e-5
+    assert _relerr(dbe, red[:64].float()) < 1e-5 and _relerr(dga, red[64:].float()) < 1e-5
+    hip.stem_c1_bwd(dz1, y1, a0, aff, train, dW, dga, dbe)          # accumulates
+    assert _relerr(dW, 2 * ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
 def test_stem_pointwise_and_bn(dtp):
     from sar_ssl_amd import hip
     dev = _dev()
