@@ -68,6 +68,11 @@ int sarssl_stem_c1_wgrad_bn(const void* dz1, const void* y1, const void* a0, lon
                             int use_stats, double* dW1d, int dtype, void* stream);
 int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                        const float* scale, const float* shift, int precise, float* ws, double* stats, void* stream);
+/*      data gradient (w = flipped/transposed taps) that also accumulates the BatchNorm-backward sums of the layer in front:
+ *      red = f64[128] = [sum g | sum g*xhat], g = dz * relu'(bn(y)); aff = [scale|shift|mean|rstd] (4 x 64 f32); bf16 only.
+ *      Returns 1 without launching when the ping-pong kernel is disabled (caller falls back to sarssl_cl_bn_bwd_reduce). */
+int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, int F, int T, const void* y, const float* aff,
+                               double* red, void* stream);
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
                          const float* shift, float* dW, float* partial, int precise, void* stream);

@@ -39,6 +39,10 @@ struct ConvArgs {
     int nb, F, T;
     int part_in, part_w;
     double* stats;      // optional f64[128]: per-channel sum / sum of squares of the (bf16-rounded) output, for the next BatchNorm
+    // data-gradient mode of the ping-pong kernel: the output is dz = dL/d relu(bn(y)) of the PREVIOUS layer; with bn_y / bn_aff set,
+    // stats instead receives that BatchNorm's backward sums [sum g | sum g*xhat], g = dz * relu'(bn(y)) (the cl_bn_bwd_reduce pass)
+    const void* bn_y;   // (B,F,T,64) pre-BN activations of the layer whose input gradient this launch produces
+    const float* bn_aff;    // [4][64]: scale, shift, mean, rstd
 };
 
 __device__ __forceinline__ int swz(int p, int chunk) { return (p * 8 + (chunk ^ ((p >> 1) & 7))) * 8; }
@@ -348,11 +352,13 @@ __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int
     asm volatile("" ::: "memory");
 }
 
+template <bool BNRED>
 __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     typedef bf16 T;
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
     __shared__ float sStats[128];
+    __shared__ float sAff[256];
     __shared__ unsigned sSync[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 2, hw = wave & 3, htid = tid & 255;
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     uint16_t* sX = sXh[half];
     if (tid < 128) sStats[tid] = 0.f;
     if (tid < 2) sSync[tid] = 0u;
+    if (BNRED && tid < 256) sAff[tid] = a.bn_aff[tid];
     const int cch = tid & 7;
     {
         const T* w = (const T*)a.w;
@@ -485,8 +492,31 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                     *(uint2*)(q + j * 32 * 64) = w2;
                 }
             }
+        // BatchNorm-backward mode: fetch the matching pre-BN activations now (the accumulator registers are free) and retire the
+        // loads BEFORE the first output store is issued (loads and stores share vmcnt and complete out of order on gfx9)
+        uint4 yv[8];
+        float bthr[8];
+        unsigned bsgn = 0u;
+        if (BNRED) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int px = (lane >> 3) + 8 * k;
+                const int f = tc.f0 + 2 * hw + (px >> 5), t = tc.t0 + (px & 31);
+                yv[k] = (f < F && t < Tn) ? *(const uint4*)((const uint16_t*)a.bn_y + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8)
+                                          : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                       // relu'(y*sc + sh) as a threshold test on y (see cl_bn_bwd_reduce)
+                const int c = (lane & 7) * 8 + e;
+                const float sc_ = sAff[c], sh_ = sAff[64 + c];
+                float thr = sc_ != 0.f ? -sh_ / sc_ : (sh_ > 0.f ? -INFINITY : INFINITY);
+                if (sc_ < 0.f) { thr = -thr; bsgn |= 1u << e; }
+                bthr[e] = thr;
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
+        if (BNRED) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         float ssum[8], ssq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
@@ -498,7 +528,20 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             const uint4 o = *(const uint4*)&stg[px * 64 + (((lane & 7) ^ (lane >> 3)) << 3)];
             if (f < F && t < Tn) {
                 *(uint4*)((uint16_t*)a.out + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8) = o;
-                if (a.stats) {
+                if (BNRED) {            // sums of g and g*y; turned into rstd*(sum g*y - mean*sum g) per tile below
+                    const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+                    const uint32_t yw[4] = {yv[k].x, yv[k].y, yv[k].z, yv[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float d0 = bf16_bits_to_f32(w[q] & 0xffffu), d1 = __uint_as_float(w[q] & 0xffff0000u);
+                        const float y0 = bf16_bits_to_f32(yw[q] & 0xffffu), y1 = __uint_as_float(yw[q] & 0xffff0000u);
+                        const float t0_ = __uint_as_float(__float_as_uint(y0) ^ (((bsgn >> (2 * q)) & 1u) << 31));
+                        const float t1_ = __uint_as_float(__float_as_uint(y1) ^ (((bsgn >> (2 * q + 1)) & 1u) << 31));
+                        const float g0 = t0_ > bthr[2 * q] ? d0 : 0.f, g1 = t1_ > bthr[2 * q + 1] ? d1 : 0.f;
+                        ssum[2 * q] += g0; ssq[2 * q] = fmaf(g0, y0, ssq[2 * q]);
+                        ssum[2 * q + 1] += g1; ssq[2 * q + 1] = fmaf(g1, y1, ssq[2 * q + 1]);
+                    }
+                } else if (a.stats) {
                     const uint32_t w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -508,7 +551,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                 }
             }
         }
-        if (a.stats) {
+        if (BNRED || a.stats) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
@@ -516,7 +559,11 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             }
             if (lane < 8) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], ssq[e]); }
+                for (int e = 0; e < 8; ++e) {
+                    float s2 = ssq[e];
+                    if (BNRED) s2 = sAff[192 + lane * 8 + e] * (s2 - sAff[128 + lane * 8 + e] * ssum[e]);     // rstd * (sum g*y - mean * sum g)
+                    atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], s2);
+                }
             }
         }
         half_barrier(cnt, epoch, lane);                        // slices drained before the next tile overwrites the buffer
@@ -731,12 +778,35 @@ static int conv_grid(int nb, int F, int T) {
 // in/out: (B,F,T,64) channels-last, dtype 0 f32 / 1 bf16 (same for both).  w: [9][64][64] ([tap][co][ci]) of
 // dtype w_dtype.  scale/shift: f32[64] prologue affine (+ReLU) or null for identity.
 // precise (f32 only): 3-pass split with ws = f32 (B,F,T,64).
+static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
+                          const float* scale, const float* shift, int precise, float* ws, double* stats, const void* bn_y,
+                          const float* bn_aff, void* stream);
+
 extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                                   const float* scale, const float* shift, int precise, float* ws, double* stats, void* stream) {
+    return conv3x3_launch(in, w, out, dtype, w_dtype, nb, F, T, scale, shift, precise, ws, stats, nullptr, nullptr, stream);
+}
+
+// Data gradient of a 3x3 convolution (w = flipped / transposed taps, no prologue) that also returns, in red = f64[128], the
+// backward sums [sum g | sum g*xhat] of the BatchNorm + ReLU in front of that convolution (g = dz * relu'(bn(y)), y = its pre-BN
+// activations, aff = [scale | shift | mean | rstd], 4 x 64 f32).  bf16, ping-pong kernel only; returns 1 (and does nothing) when that
+// kernel is disabled so the caller can fall back to the separate reduction pass.
+extern "C" int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, int F, int T, const void* y,
+                                          const float* aff, double* red, void* stream) {
+    SARSSL_REQUIRE(y != nullptr && aff != nullptr && red != nullptr, "sarssl_conv3x3_dgrad_bnred");
+    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
+    if (!use_pp) return 1;
+    return conv3x3_launch(dy, w, dz, SARSSL_BF16, SARSSL_BF16, nb, F, T, nullptr, nullptr, 0, nullptr, red, y, aff, stream);
+}
+
+static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
+                          const float* scale, const float* shift, int precise, float* ws, double* stats, const void* bn_y,
+                          const float* bn_aff, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_fwd");
     SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16, "sarssl_conv3x3_fwd(fused statistics: bf16 storage only)");
     if (stats && hipMemsetAsync(stats, 0, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a;
+    a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
     a.in = in; a.w = w; a.out = out; a.acc_ws = nullptr; a.acc_in = 0; a.acc_out = 0;
     a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
@@ -747,7 +817,8 @@ extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int 
         static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
         if (use_pp) {
             const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-            conv3x3_fwd_pp_kernel<<<npairs < 256 ? npairs : 256, 512, 0, st>>>(a);
+            if (bn_y) conv3x3_fwd_pp_kernel<true><<<npairs < 256 ? npairs : 256, 512, 0, st>>>(a);
+            else conv3x3_fwd_pp_kernel<false><<<npairs < 256 ? npairs : 256, 512, 0, st>>>(a);
         } else conv3x3_fwd_kernel<bf16, bf16><<<grid, 512, 0, st>>>(a);
     } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
         if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);

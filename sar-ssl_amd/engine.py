@@ -116,6 +116,7 @@ def stem_fwd(a0, pe, train, saved):
 
 
 _C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
+_DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 
 
@@ -143,8 +144,13 @@ def stem_bwd(de, pe, saved):
     # second 3x3 conv
     dW = hip.conv3x3_wgrad(dy3, y2, aff2[0], aff2[1], precise=RT.precise)
     gbuf(pe[6].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
-    dz2 = hip.conv3x3_fwd(dy3, _taps(pe[6])[1], precise=RT.precise)
-    red2 = hip.cl_bn_bwd_reduce(dz2, y2, 64, aff2, RELU)
+    red2 = None
+    if _DGRAD_BNRED and RT.dtype == torch.bfloat16:   # BatchNorm-backward sums accumulated in the data-gradient kernel's epilogue
+        dz2, red2 = hip.conv3x3_dgrad_bnred(dy3, _taps(pe[6])[1], y2, aff2)
+    else:
+        dz2 = hip.conv3x3_fwd(dy3, _taps(pe[6])[1], precise=RT.precise)
+    if red2 is None:
+        red2 = hip.cl_bn_bwd_reduce(dz2, y2, 64, aff2, RELU)
     dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2)
     bn_param_grads(pe[4], red2, 64)
     # first 3x3 conv

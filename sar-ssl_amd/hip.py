@@ -256,6 +256,25 @@ def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False, want_stats=Fals
     return (out, sums) if want_stats else out
 
 
+def conv3x3_dgrad_bnred(dy, w_tap_dgrad, y, aff):
+    """dz = conv3x3(dy, flipped taps) and the BatchNorm-backward sums red f64[128] of the BN+ReLU in front (pre-BN activations
+    ``y``, ``aff`` = (4,64) scale|shift|mean|rstd), accumulated in the convolution's epilogue (bf16).  Returns (dz, None) when the
+    fused kernel is disabled - the caller then runs cl_bn_bwd_reduce."""
+    _need_cuda(dy, w_tap_dgrad, y, aff)
+    B, F, T, C = dy.shape
+    assert C == 64 and dy.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.shape == dy.shape
+    assert aff.dtype == torch.float32 and aff.is_contiguous() and aff.numel() == 256 and dy.is_contiguous() and y.is_contiguous()
+    dz = torch.empty_like(dy)
+    red = torch.empty((128,), dtype=torch.float64, device=dy.device)
+    fn = _lib.lib().sarssl_conv3x3_dgrad_bnred
+    with _Timed("conv3x3_fwd_kernel"):
+        rc = fn(_p(dy), _p(w_tap_dgrad), _p(dz), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red), _stream())
+    if rc == 1:
+        return conv3x3_fwd(dy, w_tap_dgrad), None
+    _lib.check(rc, "sarssl_conv3x3_dgrad_bnred")
+    return dz, red
+
+
 def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False):
     """-> dW f32 [9][64][64] ([tap][co][ci])."""
     _need_cuda(dy, zin)

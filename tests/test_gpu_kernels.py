@@ -188,6 +188,27 @@ def test_conv3x3_wgrad_and_dgrad(mode, B, F, T):
     assert _relerr(dz.float().cpu(), _cl(z64.grad)) < (1e-2 if mode == "bf16" else 5e-5)
 
 
+@pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64)])
+def test_conv3x3_dgrad_with_fused_bn_backward_sums(B, F, T):
+    """The data-gradient launch that also accumulates the BatchNorm-backward sums of the layer in front must store exactly the
+    same dz as the plain launch, and its sums must equal the stand-alone cl_bn_bwd_reduce pass over (dz, y)."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(11 * B + T)
+    dy = _cl(torch.randn((B, 64, F, T), generator=g)).to(torch.bfloat16).to(dev)
+    y = _cl(torch.randn((B, 64, F, T), generator=g)).to(torch.bfloat16).to(dev)
+    w = (torch.randn((9, 64, 64), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    aff = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1,
+                       torch.rand(64, generator=g) + 0.5]).contiguous().to(dev)
+    aff[0, 9] = -aff[0, 9]
+    dz_ref = hip.conv3x3_fwd(dy, w)
+    red_ref = hip.cl_bn_bwd_reduce(dz_ref, y, 64, aff, 1)
+    dz, red = hip.conv3x3_dgrad_bnred(dy, w, y, aff)
+    assert torch.equal(dz, dz_ref)
+    if red is not None:                                           # (None: fused kernel disabled by SARSSL_CONV_PP=0)
+        assert _relerr(red[:64], red_ref[:64]) < 1e-5 and _relerr(red[64:], red_ref[64:]) < 2e-5
+
+
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("train", [True, False])
 def test_stem_c4_backward_two_phase_matches_one_pass_plus_apply(dtp, train):
