@@ -164,7 +164,7 @@ def main():
             "config": {"workload": "SAR-SSL MC-Conformer cross-channel-reconstruction pretrain step (STFT+mask+fwd+bwd+Adam), "
                                    "2ch 4.112s@16kHz segments, batch %d per GPU, dropout on" % args.batch,
                        "global_batch": args.batch * world, "segment_samples": NSAMPLE, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_pp_kernel", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_pp_kernel<false>", "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
                          "flop_per_launch": flop_per_launch,

@@ -267,7 +267,7 @@ def conv3x3_dgrad_bnred(dy, w_tap_dgrad, y, aff):
     dz = torch.empty_like(dy)
     red = torch.empty((128,), dtype=torch.float64, device=dy.device)
     fn = _lib.lib().sarssl_conv3x3_dgrad_bnred
-    with _Timed("conv3x3_fwd_kernel"):
+    with _Timed("conv3x3_dgrad_bnred"):          # (its own label: this launch also reads y and reduces)
         rc = fn(_p(dy), _p(w_tap_dgrad), _p(dz), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red), _stream())
     if rc == 1:
         return conv3x3_fwd(dy, w_tap_dgrad), None
