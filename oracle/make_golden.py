@@ -3,7 +3,7 @@
     python oracle/make_golden.py [--curve]     # --curve adds the 100-step loss curve (~8 min CPU)
 
 Each fixture stores inputs (or the recipe that regenerates them) and the reference's outputs.
-Nothing of the reference's source travels; the vectors are data.  See SURVEY.md section 8c (F1-F6).
+Nothing of the reference's source travels; the vectors are data.  See SURVEY.md section 8c (F1-F6); F7-F12 cover the later rows.
 """
 import argparse
 import json
@@ -372,6 +372,67 @@ def f5_curve(ref_model, ref_learner, nstep=100, B=8):
                             B=B, lr=1e-3, mask_seed_base=9000, pool=64, weight_seed=0)
 
 
+def f12_pretrain_epoch(ref_model, ref_learner):
+    """The reference's OWN ``Learner.pretrain_epoch`` (code/learner.py:76-131): two epochs x four batches of four full-size
+    segments, dropout 0, masks from Python's RNG seeded once per epoch, a different learning rate in the second epoch and the
+    optimiser re-created per epoch (Q12).  Stores the returned (loss, diff) per epoch, samples of the returned vis dict and, per
+    parameter, the L2 norm of its total update - the quantity a carried-over Adam state would change."""
+    from sar_ssl_amd import synth
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    load_recipe(net, 0)
+    set_dropout(net, 0.0)
+    init = {k: v.detach().clone() for k, v in net.named_parameters()}
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    B, nb = 4, 4
+    pool = torch.from_numpy(synth.make_batch(2000, B * nb))
+    dataset = [[pool[i * B:(i + 1) * B]] for i in range(nb)]
+    lrs, seeds = [1e-3, 5e-4], [4100, 4101]
+    store = {"B": B, "nbatch": nb, "sig_seed": 2000, "weight_seed": 0, "lr": np.array(lrs), "mask_seed": np.array(seeds)}
+    for e in range(2):
+        random.seed(seeds[e])
+        loss, diff, vis = lrn.pretrain_epoch(dataset, lr=lrs[e], epoch=e + 1)
+        store["epoch%d.loss" % (e + 1)] = np.float64(loss)
+        store["epoch%d.diff" % (e + 1)] = np.float64(diff)
+        pred = vis["pred"].detach()
+        idx = sample_idx(pred.numel(), 1024, 31 + e)
+        store["epoch%d.pred_idx" % (e + 1)] = idx
+        store["epoch%d.pred_vals" % (e + 1)] = pred.reshape(-1)[idx].numpy()
+        store["epoch%d.pred_absmax" % (e + 1)] = np.float64(pred.abs().max())
+        store["epoch%d.pred_shape" % (e + 1)] = np.array(pred.shape)
+        store["epoch%d.mask_zero_frac" % (e + 1)] = np.float64((vis["mask"] == 0).float().mean())
+        print("pretrain_epoch", e + 1, loss, diff, flush=True)
+    store["update_norm_json"] = json.dumps({k: float((p.detach() - init[k]).double().norm()) for k, p in net.named_parameters()})
+    store["training_flag"] = np.int64(net.training)
+    np.savez_compressed(os.path.join(GOLD, "f12_pretrain_epoch.npz"), **store)
+
+
+def f6_checkpoint(ref_model, ref_learner):
+    """A checkpoint FILE written by the reference's ``save_checkpoint`` (code/learner.py:344-374; fp32 layout: epoch, max_score,
+    model) for a reduced-width MCConformer (the full model's file is 121 MB), gzip-compressed, plus what a loader must reproduce:
+    the manifest, the recipe seed of the weights, max_score / epoch and the reference's eval-mode output on a seeded input."""
+    import gzip
+    import shutil
+    import tempfile
+    net = ref_model.MCConformer(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed={"spec": 32, "spat": 32}, device="cpu")
+    man = load_recipe(net, 77)
+    net.eval()
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    assert lrn.is_best_epoch(-0.125)                                      # sets max_score the way run_pretrain.py does
+    x = torch.from_numpy(np.random.default_rng(606).standard_normal((2, 2, 16, 8, 2)).astype(np.float32))
+    with torch.no_grad():
+        y = net(x)
+    with tempfile.TemporaryDirectory() as d:
+        lrn.save_checkpoint(epoch=7, checkpoints_dir=d, is_best_epoch=True, save_extra_hist=False)
+        assert os.path.exists(os.path.join(d, "best_model.tar"))
+        with open(os.path.join(d, "latest_model.tar"), "rb") as fi, gzip.open(os.path.join(GOLD, "f6_checkpoint.tar.gz"), "wb", 9) as fo:
+            shutil.copyfileobj(fi, fo)
+    np.savez_compressed(os.path.join(GOLD, "f6_checkpoint_meta.npz"), manifest_json=json.dumps(man), weight_seed=77, epoch=7,
+                        max_score=np.float64(-0.125), x_seed=606, y=y.numpy())
+    print("f6 checkpoint written", os.path.getsize(os.path.join(GOLD, "f6_checkpoint.tar.gz")), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--curve", action="store_true")
@@ -381,7 +442,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_learner, ref_um = ref_shim.load()
-    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f7", "f8", "f9", "f10", "f11"]
+    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
     if "manifest" in todo: f_manifest(ref_model)
     if "f1" in todo: f1_frontend(ref_learner, ref_model)
     if "f2" in todo: f2_blocks(ref_model)
@@ -392,5 +453,7 @@ if __name__ == "__main__":
     if "f9" in todo: f9_downstream_train(ref_model, ref_learner)
     if "f10" in todo: f10_multich(ref_model, ref_learner)
     if "f11" in todo: f11_eval_export(ref_model, ref_learner, ref_um)
+    if "f12" in todo: f12_pretrain_epoch(ref_model, ref_learner)
+    if "f6" in todo: f6_checkpoint(ref_model, ref_learner)
     if a.curve: f5_curve(ref_model, ref_learner)
     print("golden vectors written to", GOLD)

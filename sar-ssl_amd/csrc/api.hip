@@ -21,3 +21,16 @@ extern "C" int sarssl_device_info(int device, char* name_out, int name_len, int*
     if (lds_bytes) *lds_bytes = (long)p.sharedMemPerBlock;
     return 0;
 }
+
+// Compute-unit count of the current device (cached per device): persistent kernels launch one workgroup per CU.
+int sarssl_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}

@@ -14,6 +14,7 @@ enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2 };
 // error plumbing (api.cpp owns the storage)
 extern "C" const char* sarssl_last_error();
 void sarssl_set_error(const char* fmt, ...);
+int sarssl_cu_count();          // CUs of the current device (api.hip): grid size of the persistent kernels
 #define SARSSL_CHECK_LAUNCH(name)                                          \
     do {                                                                   \
         hipError_t e__ = hipGetLastError();                                \

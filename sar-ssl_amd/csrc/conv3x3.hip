@@ -772,7 +772,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static int conv_grid(int nb, int F, int T) {
     int ntiles = nb * ((F + TR - 1) / TR) * ((T + TCOL - 1) / TCOL);
-    return ntiles < 256 ? ntiles : 256;
+    const int ncu = sarssl_cu_count();              // persistent: one workgroup per CU
+    return ntiles < ncu ? ntiles : ncu;
 }
 
 // in/out: (B,F,T,64) channels-last, dtype 0 f32 / 1 bf16 (same for both).  w: [9][64][64] ([tap][co][ci]) of
@@ -817,8 +818,9 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
         static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
         if (use_pp) {
             const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-            if (bn_y) conv3x3_fwd_pp_kernel<true><<<npairs < 256 ? npairs : 256, 512, 0, st>>>(a);
-            else conv3x3_fwd_pp_kernel<false><<<npairs < 256 ? npairs : 256, 512, 0, st>>>(a);
+            const int ncu = sarssl_cu_count();
+            if (bn_y) conv3x3_fwd_pp_kernel<true><<<npairs < ncu ? npairs : ncu, 512, 0, st>>>(a);
+            else conv3x3_fwd_pp_kernel<false><<<npairs < ncu ? npairs : ncu, 512, 0, st>>>(a);
         } else conv3x3_fwd_kernel<bf16, bf16><<<grid, 512, 0, st>>>(a);
     } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
         if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);

@@ -1,12 +1,13 @@
 """Data-parallel pretraining over the GPUs of one node: one process per GPU, RCCL all-reduce over xGMI.
 
 Replaces the reference's single-process ``torch.nn.DataParallel`` (code/learner.py:25-31).  Gradients live in ONE flat
-f32 buffer (runtime.FlatParams) laid out in module order (spec encoder | spat encoder | decoder).  The hand-written
-backward finishes those three regions in reverse order and calls a stage hook after each, which immediately issues the
-all-reduce of that contiguous slice (22 / 20 / 28 MB) so communication overlaps the remaining backward - above all the long,
-almost parameter-free CNN-stem backward that runs last.  No per-step parameter broadcast, ``pe`` buffers are never
-communicated, BatchNorm statistics stay per rank exactly like the reference's per-replica behaviour.  The 1/world scaling is
-folded into the fused Adam kernel.
+f32 buffer (runtime.FlatParams) laid out by ``SARSSL.flat_param_groups``: stems (0.6 MB) | spec block + patch-GEMM weight (28 MB) |
+spat blocks + patch-GEMM weight (20 MB) | decoder (22 MB).  The hand-written backward calls a stage hook as soon as a group's
+gradients are final - decoder, then the spat blocks, then the spec block, all BEFORE the long, almost parameter-free CNN-stem
+backward starts - and the hook immediately issues the all-reduce of that contiguous slice, so 70 of 70.6 MB are exchanged
+underneath the stem backward; only the 0.6 MB stem bucket is reduced after it.  No per-step parameter broadcast, ``pe`` buffers
+are never communicated, BatchNorm batch statistics stay per rank exactly like the reference's per-replica behaviour.  The 1/world
+scaling is folded into the fused Adam kernel.
 """
 import os
 
@@ -32,8 +33,15 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+STAGES = ("decoder", "spat_encoder", "spec_encoder", "stems")          # order in which backward completes them
+
+
 def stage_slices(net, flat):
-    """[start, end) of each backward stage's parameters inside the flat buffers (decoder / spat_encoder / spec_encoder)."""
+    """[start, end) of each backward stage's parameters inside the flat buffers.  Uses the layout groups of the flat buffer when
+    the model defines them (SARSSL.flat_param_groups); otherwise spans by owning sub-module (spec_encoder / spat_encoder /
+    decoder), anything else under 'other'."""
+    if getattr(flat, "group_spans", None):
+        return dict(flat.group_spans)
     owner = {}
     for name in ("spec_encoder", "spat_encoder", "decoder"):
         mod = getattr(net, name, None)
@@ -60,24 +68,32 @@ class FlatGradAllReduce:
         for (a0, a1), (b0, b1) in zip(covered[:-1], covered[1:]):
             assert a1 == b0, "stage spans must be contiguous"
         self.handles = []
+        self._fired = set()
+        self.order = []                                   # stage names in the order their all-reduce was issued (tests)
         self.world = world_size()
         net.set_backward_stage_hook(self._on_stage)
 
     def _on_stage(self, name):
-        if self.world <= 1 or name not in self.spans:
+        if name not in self.spans or name in self._fired:
             return
+        self.order.append(name)
+        if self.world <= 1:
+            return
+        self._fired.add(name)
         s, e = self.spans[name]
         self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
-        """Wait for all outstanding buckets (also reduces 'other' parameters not owned by a stage).  Returns the gradient
-        scale (1/world) to fold into the optimizer step."""
-        if self.world > 1 and "other" in self.spans:
-            s, e = self.spans["other"]
-            self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        """Wait for all outstanding buckets (also reduces every span no stage hook fired for in this step, e.g. 'other' parameters
+        not owned by a stage).  Returns the gradient scale (1/world) to fold into the optimizer step."""
+        if self.world > 1:
+            for name, (s, e) in sorted(self.spans.items(), key=lambda kv: kv[1]):
+                if name not in self._fired:
+                    self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         for h in self.handles:
             h.wait()
         self.handles = []
+        self._fired = set()
         return 1.0 / self.world
 
 
@@ -87,3 +103,32 @@ def broadcast_parameters(flat, src=0):
         dist.broadcast(flat.flat, src=src)
         flat._synced = None
         flat.ensure_shadow()
+
+
+def broadcast_buffers(module, src=0):
+    """Before validation / checkpointing: every rank takes rank ``src``'s BatchNorm running statistics.  Under the reference's
+    ``nn.DataParallel`` the replicas' buffer updates are discarded and only device 0's survive (torch broadcasts module buffers
+    from device 0 at every forward), so "rank 0's statistics" IS the reference behaviour; without it the ranks would validate
+    different models and could disagree on early stopping."""
+    if world_size() <= 1:
+        return
+    bufs = [b for n, b in module.named_buffers() if n.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    for dtype in (torch.float32, torch.int64):
+        sel = [b for b in bufs if b.dtype == dtype]
+        if not sel:
+            continue
+        flat = torch.cat([b.reshape(-1) for b in sel])
+        dist.broadcast(flat, src=src)
+        o = 0
+        for b in sel:
+            b.copy_(flat[o:o + b.numel()].view_as(b))
+            o += b.numel()
+
+
+def agree(values, src=0, device=None):
+    """Rank ``src``'s python floats on every rank (validation loss -> identical early-stopping / best-epoch decisions)."""
+    if world_size() <= 1:
+        return list(values)
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=src)
+    return [float(v) for v in t.cpu()]

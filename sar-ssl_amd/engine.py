@@ -49,8 +49,11 @@ def to_rt(x):
 
 
 def _cached(module, name, builder):
-    """Per-module cache of re-laid-out weights, invalidated whenever parameters change."""
-    key = (weights_version(), RT.dtype)
+    """Per-module cache of re-laid-out weights, invalidated whenever parameters change: by the fused optimizer / flat-buffer
+    refresh (global version) or through torch itself (load_state_dict, torch.optim, in-place init: the parameter's own version
+    counter and storage address)."""
+    w = module.weight
+    key = (weights_version(), RT.dtype, w._version, w.data_ptr())
     c = module.__dict__.setdefault("_wcache", {})
     hit = c.get(name)
     if hit is None or hit[0] != key:
@@ -120,15 +123,23 @@ _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 
 
-def stem_bwd(de, pe, saved):
-    a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
+def patch_bwd(de, pe, saved):
+    """Backward of the frame-patch convolution (the last layer of ``patch_embed``, a plain GEMM here): accumulates its weight
+    gradient - the stem's only sizeable parameter, so the data-parallel bucket holding it can be reduced before the long
+    parameter-poor remainder of the stem backward - and returns the gradient w.r.t. the (B,T,F,4) activations."""
+    a0, z4 = saved[-1][0], saved[-1][9]
     B, F, T, _ = a0.shape
     d = de.shape[1]
-    # patch GEMM
     gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
     mm_tn_acc(de, z4, gtmp)
     gbuf(pe[12].weight).add_(gtmp.view(d, F, 4).permute(0, 2, 1).unsqueeze(-1))
-    dz4 = mm_nn(de, _patch_w(pe[12], F))                                                   # (B,T,F,4)
+    return mm_nn(de, _patch_w(pe[12], F))                                                  # (B,T,F,4)
+
+
+def stem_bwd(dz4, pe, saved):
+    """Backward of the CNN stem below the patch GEMM (``dz4`` = patch_bwd's result)."""
+    a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
+    B, F, T, _ = a0.shape
     red4 = hip.cl_bn_bwd_reduce(dz4, y4, 4, aff4, RELU)
     dy4 = hip.cl_bn_bwd_apply(dz4, y4, 4, aff4, RELU, False, train, red4)
     bn_param_grads(pe[10], red4, 4)

@@ -25,9 +25,19 @@ def _stream():
 
 
 def _need_cuda(*ts):
+    """Kernels are enqueued on the CURRENT device's current stream: tensors must be GPU tensors of that device (a model built on
+    ``cuda:1`` needs ``torch.cuda.set_device(1)`` / a ``torch.cuda.device`` context, as run_pretrain.py and bench.py do)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.SarsslHipError("sar_ssl_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise _lib.SarsslHipError("tensor lives on cuda:%d but the current device is cuda:%d: call torch.cuda.set_device(%d) "
+                                      "(kernels are launched on the current device's stream)" % (t.device.index, cur, t.device.index))
 
 
 # ---- optional per-kernel timing with events on the launch stream (bench.py roofline) ---------------------------------

@@ -6,6 +6,8 @@ frame patches); the ablation backbones of the reference are out of scope and rej
 All device work runs through the HIP kernels (engine.py); the whole pretrain forward is one autograd node whose
 backward is the hand-written backward pass.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -61,7 +63,7 @@ class EmbedEncoder(nn.Module):
 
     def _bwd_cl(self, dy, saved):
         de = engine.encoder_bwd(dy, self.embed, saved)
-        return engine.stem_bwd(de, self.patch_embed, saved)
+        return engine.stem_bwd(engine.patch_bwd(de, self.patch_embed, saved), self.patch_embed, saved)
 
     def forward(self, embed, add_same_one=False):
         """embed: (nbatch, npatch, dpatch*nch) -> (nbatch, npatch, dembed)."""
@@ -186,32 +188,37 @@ class _PretrainFn(torch.autograd.Function):
         decat = engine.decoder_bwd(dpred, net.decoder, saved)
         net._after_backward_stage("decoder")
         saved_spat = saved.pop()
-        # encoder backward takes column slices of the concatenated decoder-input gradient (row stride 768)
+        # encoder backward takes column slices of the concatenated decoder-input gradient (row stride 768).  Schedule: all
+        # Conformer blocks and the two patch GEMMs first - that completes every sizeable gradient bucket, whose all-reduce then
+        # overlaps the long, nearly parameter-free CNN-stem backward (dist.py) - then the two stems, then the 0.6 MB stem bucket.
         side = net._side_stream(x.device)
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream() if side is not None else None
+        on_side = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         if side is not None:
             side.wait_stream(main)
             decat.record_stream(side)
-            spe, spa = net.spec_encoder, net.spat_encoder
-            nl = len(spa.embed.layers)
-            with torch.cuda.stream(side):                       # alternating enqueue order, see forward
-                d_spat = decat[:, ds:]
-                for li in range(nl - 1, 0, -1):
-                    d_spat = engine.block_bwd(d_spat, spa.embed.layers[li], saved_spat)
-            d_spec = engine.block_bwd(decat[:, :ds], spe.embed.layers[0], saved)
-            with torch.cuda.stream(side):
-                d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat)
-            engine.stem_bwd(d_spec, spe.patch_embed, saved)
-            with torch.cuda.stream(side):
-                engine.stem_bwd(d_spat, spa.patch_embed, saved_spat)
-                net._after_backward_stage("spat_encoder")      # its gradient bucket is reduced behind the side stream
+        spe, spa = net.spec_encoder, net.spat_encoder
+        nl = len(spa.embed.layers)
+        with on_side():                                         # the host enqueues the two streams in alternating chunks, see forward
+            d_spat = decat[:, ds:]
+            for li in range(nl - 1, 0, -1):
+                d_spat = engine.block_bwd(d_spat, spa.embed.layers[li], saved_spat)
+        d_spec = decat[:, :ds]
+        for blk in reversed(spe.embed.layers):
+            d_spec = engine.block_bwd(d_spec, blk, saved)
+        with on_side():
+            d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat)
+            dz_spat = engine.patch_bwd(d_spat, spa.patch_embed, saved_spat)
+            net._after_backward_stage("spat_encoder")          # its bucket is reduced behind the side stream
+        dz_spec = engine.patch_bwd(d_spec, spe.patch_embed, saved)
+        net._after_backward_stage("spec_encoder")
+        net._after_backward_stage("stem_bwd_begin")            # (not a bucket: a marker for tests / tracing)
+        engine.stem_bwd(dz_spec, spe.patch_embed, saved)
+        with on_side():
+            engine.stem_bwd(dz_spat, spa.patch_embed, saved_spat)
+        if side is not None:
             main.wait_stream(side)
-            net._after_backward_stage("spec_encoder")
-        else:
-            net.spat_encoder._bwd_cl(decat[:, ds:], saved_spat)
-            net._after_backward_stage("spat_encoder")
-            net.spec_encoder._bwd_cl(decat[:, :ds], saved)
-            net._after_backward_stage("spec_encoder")
+        net._after_backward_stage("stems")
         return (None,) * (5 + ctx.nparams)
 
 
@@ -257,6 +264,20 @@ class SARSSL(nn.Module):
         self._stage_hook = None
         self._param_list = None
         self._forced_masks = None
+
+    def flat_param_groups(self):
+        """Layout of runtime.FlatParams for this model = the data-parallel gradient buckets in the order backward completes them
+        last-to-first (dist.py): stems | spec block(s) + spec patch GEMM | spat blocks + spat patch GEMM | decoder."""
+        def stem(enc):
+            return [p for i, m in enumerate(enc.patch_embed) if i != 12 for p in m.parameters()]
+
+        def body(enc):
+            return list(enc.patch_embed[12].parameters()) + list(enc.embed.parameters())
+        groups = [("stems", stem(self.spec_encoder) + stem(self.spat_encoder)), ("spec_encoder", body(self.spec_encoder)),
+                  ("spat_encoder", body(self.spat_encoder))]
+        if self.pretrain:
+            groups.append(("decoder", list(self.decoder.parameters())))
+        return groups
 
     def _side_stream(self, device):
         """Second HIP stream for the spat encoder (None disables the two-stream schedule: SARSSL_TWO_STREAMS=0)."""

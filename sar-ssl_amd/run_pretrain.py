@@ -97,7 +97,11 @@ def main(argv=None):
             dl_train.set_epoch(epoch)
         loss_train, diff_train, _ = learner.pretrain_epoch(dl_train, lr=lr, epoch=epoch, return_diff=True)
         set_random_seed(seeds["val"])
+        if world > 1:                                       # all ranks validate (and rank 0 saves) rank 0's BatchNorm statistics
+            sdist.broadcast_buffers(net)
         loss_val, diff_val, _ = learner.pretest_epoch(dl_val, return_diff=True)
+        if world > 1:                                       # one decision for early stopping / best epoch on every rank
+            loss_val, diff_val = sdist.agree([loss_val, diff_val], device=device)
         stop_flag, is_best = learner.early_stopping(current_score=-loss_val, patience=100)
         learner.save_checkpoint(epoch=epoch, checkpoints_dir=dirs["log_pretrain"], is_best_epoch=is_best, save_extra_hist=True)
         if rank == 0:

@@ -114,14 +114,27 @@ def _group_qkv(module, params):
 
 
 class FlatParams:
+    """``module.flat_param_groups()`` (optional) -> [(name, [params])]: the groups are laid out back to back in that order, so every
+    group is one contiguous slice of the flat buffers (``group_spans``) - the data-parallel buckets (dist.py)."""
+
     def __init__(self, module):
         params, seen = [], set()
+        groups = module.flat_param_groups() if hasattr(module, "flat_param_groups") else []
+        group_of = {}
+        for name, ps in groups:
+            for p in ps:
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    params.append(p)
+                    group_of[id(p)] = name
         for p in module.parameters():
             if id(p) not in seen:
                 seen.add(id(p))
                 params.append(p)
+                group_of[id(p)] = "other" if groups else None
         assert params, "module has no parameters"
         params = _group_qkv(module, params)
+        self._group_of = group_of
         self.on_gpu = all(p.is_cuda for p in params)       # CPU flattening is allowed for host-logic tests only (no kernels)
         self.params = params
         dev = params[0].device
@@ -141,6 +154,13 @@ class FlatParams:
             p.grad = self.grad[o:o + n].view(p.shape)
             p._w16 = self.w16[o:o + n].view(p.shape)
             p._flat = self
+        self.group_spans = {}
+        for p, o in zip(params, offs):
+            g = self._group_of.get(id(p))
+            if g is not None:
+                end = o + (p.numel() + 7) // 8 * 8
+                a = self.group_spans.get(g)
+                self.group_spans[g] = (min(a[0], o), max(a[1], end)) if a else (o, end)
         self._synced = None
         self._fresh = False
         self.ensure_shadow()

@@ -19,6 +19,18 @@ class _Net(torch.nn.Module):
         self._hook = fn
 
 
+class _NetGrouped(_Net):
+    """Layout groups like SARSSL.flat_param_groups: stems | spec_encoder | spat_encoder | decoder."""
+
+    def __init__(self):
+        super().__init__()
+        self.stem = torch.nn.Linear(2, 2)
+
+    def flat_param_groups(self):
+        return [("stems", list(self.stem.parameters())), ("spec_encoder", list(self.spec_encoder.parameters())),
+                ("spat_encoder", list(self.spat_encoder.parameters())), ("decoder", list(self.decoder.parameters()))]
+
+
 def _worker(rank, world, port, q):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
                        "LOCAL_RANK": str(rank)})
@@ -41,7 +53,25 @@ def _worker(rank, world, port, q):
     for stage in ("decoder", "spat_encoder", "spec_encoder"):      # backward order
         net._hook(stage)
     scale = red.finish()
-    q.put((rank, ok_bcast, scale, float(flat.grad.min()), float(flat.grad.max()), sorted(spans.items())))
+    # grouped layout: the 'stems' hook never fires in this step -> finish() must still reduce that span; a second step reuses the hooks
+    net2 = _NetGrouped()
+    flat2 = runtime.FlatParams(net2)
+    red2 = sdist.FlatGradAllReduce(net2, flat2)
+    ok2 = list(flat2.group_spans) == ["stems", "spec_encoder", "spat_encoder", "decoder"] and flat2.group_spans["stems"][0] == 0
+    for step in range(2):
+        flat2.grad.fill_(float(rank + 1))
+        for stage in ("decoder", "spat_encoder", "spec_encoder", "stem_bwd_begin"):
+            net2._hook(stage)
+        red2.finish()
+        ok2 = ok2 and float(flat2.grad.min()) == float(flat2.grad.max()) == 3.0
+    ok2 = ok2 and red2.order == ["decoder", "spat_encoder", "spec_encoder"] * 2
+    # BatchNorm buffers / validation scalars follow rank 0 (run_pretrain.py)
+    bn = torch.nn.BatchNorm1d(3)
+    bn.running_mean.fill_(float(rank + 1)); bn.num_batches_tracked.fill_(rank + 5)
+    sdist.broadcast_buffers(bn)
+    vals = sdist.agree([0.25 * (rank + 1), 7.0 + rank])
+    ok3 = float(bn.running_mean[0]) == 1.0 and int(bn.num_batches_tracked) == 5 and vals == [0.25, 7.0]
+    q.put((rank, ok_bcast and ok2 and ok3, scale, float(flat.grad.min()), float(flat.grad.max()), sorted(spans.items())))
     dist.destroy_process_group()
 
 
@@ -63,3 +93,40 @@ def test_flat_grad_allreduce_two_ranks():
     assert set(spans) == {"spec_encoder", "spat_encoder", "decoder"}
     assert spans["spec_encoder"][0] == 0 and spans["spec_encoder"][1] == spans["spat_encoder"][0]
     assert spans["spat_encoder"][1] == spans["decoder"][0]
+
+
+def test_backward_stage_hooks_fire_before_the_stem_backward(monkeypatch):
+    """The real SARSSL backward schedule (model._PretrainFn.backward) with the kernels stubbed out: the decoder, spat and spec
+    gradient buckets are handed to the reducer before the CNN-stem backward starts; only the small stem bucket comes after it.
+    Also pins the flat layout that makes every bucket one contiguous slice."""
+    import types
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import sarssl_boot  # noqa: F401
+    from sar_ssl_amd import dist as sdist, engine, hip, model, runtime
+    net = model.SARSSL(sig_shape=(16, 8, 2, 2), patch_shape=(16, 1), pretrain=True, device="cpu")
+    flat = runtime.FlatParams(net)
+    spans = sdist.stage_slices(net, flat)
+    assert list(spans) == ["stems", "spec_encoder", "spat_encoder", "decoder"]
+    order = sorted(spans.values())
+    assert order[0][0] == 0 and order[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(order[:-1], order[1:]))
+    nbytes = {k: 4 * (e - s) for k, (s, e) in spans.items()}
+    assert nbytes["stems"] < 1e6 and min(nbytes["spec_encoder"], nbytes["spat_encoder"]) > 5e6     # (decoder is tiny at this sig_shape)
+    pw = net.spec_encoder.patch_embed[12].weight                          # patch-GEMM weight lives in the block bucket, not the stem's
+    off = (pw.grad.data_ptr() - flat.grad.data_ptr()) // 4
+    assert spans["spec_encoder"][0] <= off < spans["spec_encoder"][1]
+    log = []
+    monkeypatch.setattr(engine, "block_bwd", lambda d, blk, saved: (log.append("block"), d)[1])
+    monkeypatch.setattr(engine, "patch_bwd", lambda d, pe, saved: (log.append("patch"), d)[1])
+    monkeypatch.setattr(engine, "stem_bwd", lambda d, pe, saved: log.append("stem"))
+    monkeypatch.setattr(engine, "decoder_bwd", lambda d, dec, saved: (log.append("decoder"), torch.zeros(16, 768))[1])
+    monkeypatch.setattr(hip, "masked_mse_bwd", lambda *a, **k: torch.zeros(1))
+    monkeypatch.setattr(net, "_side_stream", lambda dev: None)
+    red = sdist.FlatGradAllReduce(net, flat)
+    inner = net._stage_hook
+    net.set_backward_stage_hook(lambda name: (log.append("hook:" + name), inner(name)))
+    ctx = types.SimpleNamespace(net=net, saved=[[]], aux=(None, torch.zeros(2, 2, 16, 8, 2), None, None, 4, 512), nparams=0)
+    model._PretrainFn.backward(ctx, torch.ones(()), None, None)
+    assert log == ["decoder", "hook:decoder", "block", "block", "block", "block", "patch", "hook:spat_encoder", "patch",
+                   "hook:spec_encoder", "hook:stem_bwd_begin", "stem", "stem", "hook:stems"]
+    assert red.order == ["decoder", "spat_encoder", "spec_encoder", "stems"]

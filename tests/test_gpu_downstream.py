@@ -9,12 +9,12 @@ import pytest
 import torch
 
 import recipes
-from conftest import GOLD
+from conftest import GOLD, check
 
 pytestmark = pytest.mark.gpu
 
 TOL = {"fp32": dict(loss=1e-3, pred=2e-3, grad=2e-3, epoch=2e-3),        # north_star tolerance on the f32 (split-bf16) path
-       "bf16": dict(loss=8e-2, pred=8e-2, grad=1.5e-1, epoch=1e-1)}      # bf16 storage: informational band
+       "bf16": dict(loss=2.5e-2, pred=5e-2, grad=1.2e-1, epoch=5e-2)}    # bf16 storage: 2.5-5x measured (5.1e-3, 1.4e-2, 4.5e-2)
 
 
 def _set_dropout(m, p):
@@ -62,6 +62,7 @@ def test_tdoa_training_steps_vs_reference(mode, prec):
         opt.zero_grad()
         frozen = lrn._flat.frozen_ranges()
         assert (len(frozen) > 0) == (mode == "lineareval")
+        worst = dict(loss=0.0, pred=0.0, grad=0.0)
         for s, (sig, gt) in enumerate(loader):
             x, tar = lrn.data_preprocess(sig, gt)
             pred, emb = ds(x)
@@ -78,17 +79,19 @@ def test_tdoa_training_steps_vs_reference(mode, prec):
                     if ref < 1e-6 * top:                          # analytically zero (key-projection bias): round-off on both sides
                         assert got < 1e-4 * top, (k, got, ref)
                     else:
-                        assert abs(got - ref) <= tol["grad"] * ref, (k, got, ref)
+                        worst["grad"] = max(worst["grad"], abs(got - ref) / ref)
                 e_ref = torch.from_numpy(z[mode + ".embed0"]).to(emb.device)
-                assert (emb.float() - e_ref).abs().max() <= tol["pred"] * e_ref.abs().max()
+                worst["pred"] = max(worst["pred"], float((emb.float() - e_ref).abs().max() / e_ref.abs().max()))
             lrn._flat.zero_frozen_grads(frozen)
             opt.step()
             opt.zero_grad()
             lref, mref = float(z[mode + ".loss"][s]), float(z[mode + ".metric"][s])
-            assert abs(float(loss.detach()) - lref) <= tol["loss"] * lref, (s, float(loss.detach()), lref)
-            assert abs(float(lrn.evaluate(pred_batch=pred, gt_batch=tar)) - mref) <= tol["loss"] * mref
+            worst["loss"] = max(worst["loss"], abs(float(loss.detach()) - lref) / lref,
+                                abs(float(lrn.evaluate(pred_batch=pred, gt_batch=tar)) - mref) / mref)
             p_ref = torch.from_numpy(z[mode + ".pred"][s]).to(pred.device)
-            assert (pred.detach() - p_ref).abs().max() <= tol["pred"] * p_ref.abs().max(), (s, pred, p_ref)
+            worst["pred"] = max(worst["pred"], float((pred.detach() - p_ref).abs().max() / p_ref.abs().max()))
+        for k in ("loss", "pred", "grad"):
+            check("tdoa.%s.%s.%s" % (mode, prec, k), worst[k], tol[k])
         if mode == "lineareval":                                   # frozen encoders did not move
             man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["downstream"]
             init = recipes.recipe_state_dict(man, int(z["weight_seed"]))

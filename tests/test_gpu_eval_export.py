@@ -12,7 +12,7 @@ import torch
 
 import recipes
 import sarssl_oracle as orc
-from conftest import GOLD, ROOT
+from conftest import GOLD, ROOT, check
 from test_gpu_model import _relerr
 
 pytestmark = pytest.mark.gpu
@@ -60,7 +60,7 @@ def test_stft_istft_round_trip_full_size():
 def test_pretest_epoch_with_eval_vs_reference(prec):
     from sar_ssl_amd import learner, model, runtime
     z = _z()
-    tol = {"fp32": (1e-3, 1e-3), "bf16": (2e-2, 5e-2)}[prec]
+    tol = {"fp32": (1e-3, 1e-3), "bf16": (1e-3, 2e-2)}[prec]                    # bf16: 3-5x measured (2.1e-4, 6.3e-3)
     try:
         man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
         net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cuda:0")
@@ -72,14 +72,15 @@ def test_pretest_epoch_with_eval_vs_reference(prec):
         sig = recipes.recipe_signal(2, 65792, 2, seed=3)
         random.seed(2468)                                                          # masks come from Python's RNG, as in the reference
         loss, diff, vis, res = lrn.pretest_epoch([[sig]], return_diff=True, return_eval=True)
-        assert abs(loss / float(z["eval.loss"]) - 1) < tol[0] and abs(diff / float(z["eval.diff"]) - 1) < 1e-4
+        check("pretest.%s.loss" % prec, abs(loss / float(z["eval.loss"]) - 1), tol[0])
+        check("pretest.%s.diff" % prec, abs(diff / float(z["eval.diff"]) - 1), 1e-4)
         assert tuple(res["sig_pred"].shape) == tuple(z["eval.sig_shape"])
         sidx = torch.from_numpy(z["eval.sig_idx"])
         sp, st = res["sig_pred"].reshape(-1).cpu()[sidx], res["sig_tar"].reshape(-1).cpu()[sidx]
-        assert (sp - torch.from_numpy(z["eval.sig_pred"])).abs().max() < tol[1]   # waveforms are normalised to max 1
+        check("pretest.%s.sig_pred" % prec, (sp - torch.from_numpy(z["eval.sig_pred"])).abs().max(), tol[1])   # waveforms are normalised to max 1
         assert (st - torch.from_numpy(z["eval.sig_tar"])).abs().max() < 1e-4
         for k in ("mse", "mse_mask", "mse_mask_ch"):
-            assert abs(float(res[k]) / float(z["eval." + k]) - 1) < tol[0], k
+            check("pretest.%s.%s" % (prec, k), abs(float(res[k]) / float(z["eval." + k]) - 1), tol[0])
         assert tuple(res["pesq"].shape) == (2, 2)
     finally:
         runtime.set_precision("bf16")

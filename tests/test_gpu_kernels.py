@@ -188,6 +188,49 @@ def test_conv3x3_wgrad_and_dgrad(mode, B, F, T):
     assert _relerr(dz.float().cpu(), _cl(z64.grad)) < (1e-2 if mode == "bf16" else 5e-5)
 
 
+def test_conv3x3_full_batch_shape_against_the_precise_f32_kernels():
+    """BASELINE config-2 shape (B = 64, 256 x 256 pixels): the persistent 32-round tile loops with the XCD-aware tile order of the
+    bf16 kernels (forward with BatchNorm prologue + fused statistics, data gradient with fused BatchNorm-backward sums, weight
+    gradient) against the three-pass f32 kernels on the same bf16-representable data - every pixel of four sampled images for the
+    forward / data-gradient launches, the full weight gradient over all 64 images."""
+    from sar_ssl_amd import hip
+    from conftest import check
+    dev = _dev()
+    B, F, T = 64, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(4242)
+    x16 = torch.randn((B, F, T, 64), generator=g, device=dev).to(torch.bfloat16)
+    dy16 = torch.randn((B, F, T, 64), generator=g, device=dev).to(torch.bfloat16)
+    w16 = (torch.randn((9, 64, 64), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    sc = torch.rand(64, generator=g, device=dev) + 0.5
+    sh = torch.randn(64, generator=g, device=dev) * 0.3
+    aff = torch.stack([sc, sh, torch.zeros_like(sc), torch.ones_like(sc)]).contiguous()
+    pick = [0, 21, 42, 63]
+    x32s, dy32s, w32 = x16[pick].float().contiguous(), dy16[pick].float().contiguous(), w16.float()
+    # forward: BN + ReLU prologue, fused output statistics
+    out, sums = hip.conv3x3_fwd(x16, w16, sc, sh, want_stats=True)
+    zs = torch.relu(x32s * sc + sh).to(torch.bfloat16).float()          # the bf16 kernel rounds the prologue output before the MFMA
+    ref = hip.conv3x3_fwd(zs, w32, precise=True)
+    check("conv_full.fwd", _relerr(out[pick].float(), ref.cpu()), 1e-2)
+    o64 = out.float().reshape(-1, 64).double()
+    check("conv_full.fwd_stats", max(_relerr(sums[:64], o64.sum(0).cpu()), _relerr(sums[64:], (o64 ** 2).sum(0).cpu())), 1e-5)
+    # data gradient, plain and with the fused BatchNorm-backward sums
+    dz = hip.conv3x3_fwd(dy16, w16)
+    refd = hip.conv3x3_fwd(dy32s, w32, precise=True)
+    check("conv_full.dgrad", _relerr(dz[pick].float(), refd.cpu()), 1e-2)
+    dz2, red = hip.conv3x3_dgrad_bnred(dy16, w16, x16, aff)
+    assert red is not None and torch.equal(dz2, dz)
+    red_ref = hip.cl_bn_bwd_reduce(dz, x16, 64, aff, 1)
+    check("conv_full.dgrad_bnred_sums", _relerr(red, red_ref.cpu()), 1e-5)
+    # weight gradient over all 64 images (identity prologue: no rounding difference between the two paths)
+    dW = hip.conv3x3_wgrad(dy16, x16)
+    dWref = hip.conv3x3_wgrad(dy16.float(), x16.float(), precise=True)
+    check("conv_full.wgrad", _relerr(dW, dWref.cpu()), 1e-4)
+    dWp = hip.conv3x3_wgrad(dy16, x16, sc, sh)
+    zfull = torch.relu(x16.float() * sc + sh).to(torch.bfloat16).float()
+    dWpref = hip.conv3x3_wgrad(dy16.float(), zfull, precise=True)
+    check("conv_full.wgrad_prologue", _relerr(dWp, dWpref.cpu()), 1e-4)
+
+
 @pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64)])
 def test_conv3x3_dgrad_with_fused_bn_backward_sums(B, F, T):
     """The data-gradient launch that also accumulates the BatchNorm-backward sums of the layer in front must store exactly the

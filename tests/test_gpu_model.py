@@ -12,7 +12,7 @@ import torch
 
 import recipes
 import sarssl_oracle as orc
-from conftest import GOLD
+from conftest import GOLD, check
 
 pytestmark = pytest.mark.gpu
 
@@ -131,7 +131,7 @@ def test_embed_encoder_decoder(prec):
                                                            model=["", "fc"]), 28, prec, call=lambda m, x: m.forward(x))
 
 
-def _check_gradnorms(net, gn, rtol):
+def _check_gradnorms(net, gn, rtol, tag="gradnorm"):
     """Per-parameter gradient L2 norms vs the reference.  Gradients that are analytically zero (e.g. the key-projection
     bias: softmax is invariant to it) are round-off in the reference too, so they get an absolute bound instead."""
     top = max(gn.values())
@@ -141,10 +141,10 @@ def _check_gradnorms(net, gn, rtol):
         if gn[k] < 1e-6 * top:
             assert got < 1e-4 * top, (k, got, gn[k])
         else:
-            e = abs(got - gn[k]) / gn[k]
-            report.append((e, k))
-            assert e < rtol, (k, e, got, gn[k])
-    return max(report)
+            report.append((abs(got - gn[k]) / gn[k], k))
+    worst = max(report)
+    check("%s[worst=%s]" % (tag, worst[1]), worst[0], rtol)
+    return worst
 
 
 def _fullsize(prec, mode):
@@ -167,38 +167,33 @@ def _fullsize(prec, mode):
         runtime.set_precision("bf16")
 
 
+# Full-size tolerances.  fp32 (split-bf16 MFMA) path: the north_star's 1e-3.  bf16 path (what bench.py times): 2.5-5x the deviation
+# measured on MI355X (round 2: loss 3.6e-4, sampled pred 9.6e-3 of range, worst per-parameter gradient norm 2.6e-2, BN running
+# stats 9.6e-4; recorded by conftest.check in gpurun_out/parity_measured.jsonl).
+FULL_TOL = {"fp32": dict(loss=1e-3, pred=1e-3, grad=5e-3, bn=1e-4), "bf16": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3)}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_fullsize_forward_backward_fp32(mode):
-    """north_star gate: loss and per-bin outputs within 1e-3 relative of the reference CPU path."""
-    net, loss, diff, vis, z = _fullsize("fp32", mode)
-    assert abs(loss.item() / float(z[mode + ".loss"]) - 1) < 1e-3
-    assert abs(diff.item() / float(z[mode + ".diff"]) - 1) < 1e-4
+def test_fullsize_forward_backward(mode, prec):
+    """north_star gate: loss and per-bin outputs within 1e-3 relative of the reference CPU path (fp32 mode); the bf16 fast path is
+    gated at a small multiple of its measured deviation."""
+    tol = FULL_TOL[prec]
+    net, loss, diff, vis, z = _fullsize(prec, mode)
+    tag = "fullsize.%s.%s." % (prec, mode)
+    check(tag + "loss", abs(loss.item() / float(z[mode + ".loss"]) - 1), tol["loss"])
+    check(tag + "diff", abs(diff.item() / float(z[mode + ".diff"]) - 1), 1e-4)       # diff only involves the f32 front-end
     pred = vis["pred"].permute(0, 2, 1, 3, 4).reshape(-1).cpu()          # back to (B,T,F,reim,mic) order
     got = pred[torch.from_numpy(z[mode + ".pred_idx"])]
     want = torch.from_numpy(z[mode + ".pred_vals"])
-    assert ((got - want).abs().max() / float(z[mode + ".pred_absmax"])).item() < 1e-3
+    check(tag + "pred", ((got - want).abs().max() / float(z[mode + ".pred_absmax"])).item(), tol["pred"])
     gn = json.loads(str(z[mode + ".gradnorm_json"]))
-    _check_gradnorms(net, gn, 5e-3)
+    _check_gradnorms(net, gn, tol["grad"], tag + "gradnorm")
     if mode == "train":
         sd = net.state_dict()
         for k in ("spec_encoder.patch_embed.4.running_mean", "spec_encoder.patch_embed.4.running_var",
                   "spat_encoder.embed.layers.1.sequential.2.module.sequential.5.running_var"):
-            assert _relerr(sd[k], z["train.after." + k]) < 1e-4
-
-
-@pytest.mark.parametrize("mode", ["eval", "train"])
-def test_fullsize_forward_backward_bf16(mode):
-    """Fast path tolerance (stated separately): loss within 2e-2 relative, sampled outputs within 5e-2 of
-    the output range, per-parameter gradient norms within 10 %."""
-    net, loss, diff, vis, z = _fullsize("bf16", mode)
-    assert abs(loss.item() / float(z[mode + ".loss"]) - 1) < 2e-2
-    assert abs(diff.item() / float(z[mode + ".diff"]) - 1) < 1e-4          # diff only involves the f32 front-end
-    pred = vis["pred"].permute(0, 2, 1, 3, 4).reshape(-1).cpu()
-    got = pred[torch.from_numpy(z[mode + ".pred_idx"])]
-    want = torch.from_numpy(z[mode + ".pred_vals"])
-    assert ((got - want).abs().max() / float(z[mode + ".pred_absmax"])).item() < 5e-2
-    gn = json.loads(str(z[mode + ".gradnorm_json"]))
-    _check_gradnorms(net, gn, 0.10)
+            check(tag + "bn." + k, _relerr(sd[k], z["train.after." + k]), tol["bn"])
 
 
 def test_lazy_vis_and_eval_nograd():
@@ -230,5 +225,38 @@ def test_downstream_forward():
         with torch.no_grad():
             pred, emb = ds(x)
         assert _relerr(pred, z["pred"]) < 1e-3 and _relerr(emb, z["embed"]) < 1e-3
+    finally:
+        runtime.set_precision("bf16")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_reloaded_weights_are_picked_up_without_flat_params(prec):
+    """Re-laid-out weight caches (3x3 taps, patch-GEMM weight, bf16 shadows) must follow ``load_state_dict`` / in-place updates on a
+    model that is NOT flattened: forward -> load_state_dict -> forward equals a fresh model carrying the second weights."""
+    from sar_ssl_amd import model, runtime
+    runtime.set_precision(prec)
+    try:
+        dev = _dev()
+        z = _npz("f2_blocks.npz")
+        meta = json.loads(str(z["meta_json"]))["embed_encoder"]
+        mk = lambda: model.EmbedEncoder(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed=32, model=["cnn", "conformer"], mode="spat",
+                                        device="cuda")
+        x = torch.from_numpy(z["embed_encoder.x"]).to(dev)
+        a = mk(); a.load_state_dict(recipes.recipe_state_dict(meta, 27)); a.to(dev).eval()
+        with torch.no_grad():
+            y_first = a(x).float().clone()
+            a.load_state_dict(recipes.recipe_state_dict(meta, 31))
+            y_second = a(x).float().clone()
+            for p in a.parameters():                              # in-place update through torch (what torch.optim does)
+                p.mul_(1.25)
+            y_third = a(x).float().clone()
+        b = mk(); b.load_state_dict(recipes.recipe_state_dict(meta, 31)); b.to(dev).eval()
+        with torch.no_grad():
+            want_second = b(x).float().clone()
+            for p in b.parameters():
+                p.mul_(1.25)
+            want_third = mk_out = b(x).float().clone()
+        assert not torch.allclose(y_first, y_second)
+        assert torch.equal(y_second, want_second) and torch.equal(y_third, want_third)
     finally:
         runtime.set_precision("bf16")

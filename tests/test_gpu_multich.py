@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import recipes
-from conftest import GOLD
+from conftest import GOLD, check
 from test_gpu_model import _check_gradnorms, _relerr, _set_dropout
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +36,7 @@ def test_config5_ten_second_four_mic_segment(prec):
     """T = 624 is not a multiple of the conv tile (64) or the GEMM tile: ragged tiles everywhere."""
     from sar_ssl_amd import hip, model, runtime
     z = _z()
-    tol = {"fp32": (1e-3, 1e-3, 5e-3), "bf16": (2e-2, 5e-2, 1e-1)}[prec]
+    tol = {"fp32": (1e-3, 1e-3, 5e-3), "bf16": (1e-3, 3e-2, 6e-2)}[prec]       # bf16: 3-5x measured (5.3e-5, 1.0e-2, 1.9e-2)
     runtime.set_precision(prec)
     try:
         man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
@@ -49,12 +49,12 @@ def test_config5_ten_second_four_mic_segment(prec):
         net.set_masks(z["c5.mask_idx"], z["c5.mask_ch"])
         loss, diff, vis = net(x)
         loss.backward()
-        assert abs(loss.item() / float(z["c5.loss"]) - 1) < tol[0]
-        assert abs(diff.item() / float(z["c5.diff"]) - 1) < 1e-4
+        check("config5.%s.loss" % prec, abs(loss.item() / float(z["c5.loss"]) - 1), tol[0])
+        check("config5.%s.diff" % prec, abs(diff.item() / float(z["c5.diff"]) - 1), 1e-4)
         pred = vis["pred"].permute(0, 2, 1, 3, 4).reshape(-1).cpu()
         got, want = pred[torch.from_numpy(z["c5.pred_idx"])], torch.from_numpy(z["c5.pred_vals"])
-        assert ((got - want).abs().max() / float(z["c5.pred_absmax"])).item() < tol[1]
-        _check_gradnorms(net, json.loads(str(z["c5.gradnorm_json"])), tol[2])
+        check("config5.%s.pred" % prec, ((got - want).abs().max() / float(z["c5.pred_absmax"])).item(), tol[1])
+        _check_gradnorms(net, json.loads(str(z["c5.gradnorm_json"])), tol[2], "config5.%s.gradnorm" % prec)
     finally:
         runtime.set_precision("bf16")
 

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import recipes
-from conftest import GOLD, ROOT
+from conftest import GOLD, ROOT, check
 
 pytestmark = pytest.mark.gpu
 
@@ -58,19 +58,97 @@ def test_loss_curve_100_steps_vs_reference_fp32():
     got, gdiff, z = _curve("fp32", 100)
     ref = z["loss"][:100]
     rel = np.abs(got - ref) / ref
-    print("max rel dev over 100 steps: %.3e (first 10: %.3e)" % (rel.max(), rel[:10].max()))
-    assert np.abs(gdiff - z["diff"][:100]).max() / z["diff"].max() < 1e-4       # 'diff' depends on data + masks only
-    assert rel[:10].max() < 1e-3
-    assert rel.max() < 1e-3
+    check("curve100.fp32.diff", np.abs(gdiff - z["diff"][:100]).max() / z["diff"].max(), 1e-4)   # 'diff' depends on data + masks only
+    check("curve100.fp32.first10", rel[:10].max(), 1e-3)
+    check("curve100.fp32.max", rel.max(), 1e-3)
 
 
-def test_loss_curve_bf16_tracks_reference():
-    """Fast path (bf16 storage): stated tolerance 5 % per step over the first 30 steps of the same curve."""
-    got, _, z = _curve("bf16", 30)
-    ref = z["loss"][:30]
+def test_loss_curve_100_steps_bf16_tracks_reference():
+    """Fast path (bf16 storage, what bench.py times): all 100 steps of the same curve at the north_star's 1e-3 (measured on
+    MI355X: max relative deviation 2.1e-4, i.e. ~5x margin)."""
+    got, _, z = _curve("bf16", 100)
+    ref = z["loss"][:100]
     rel = np.abs(got - ref) / ref
-    print("bf16 max rel dev over 30 steps: %.3e" % rel.max())
-    assert rel.max() < 5e-2
+    check("curve100.bf16.first10", rel[:10].max(), 1e-3)
+    check("curve100.bf16.max", rel.max(), 1e-3)
+
+
+def _update_norms(net, init):
+    return {k: float((p.detach().float().cpu().double() - init[k].double()).norm()) for k, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_pretrain_epoch_vs_reference_pretrain_epoch(prec):
+    """``STFTLearner.pretrain_epoch`` against fixture F12, produced by the reference's OWN ``pretrain_epoch``
+    (code/learner.py:76-131): two epochs x four batches, returned (loss, diff, vis) per epoch, a new learning rate and a fresh Adam
+    in the second epoch (Q12), masks from Python's RNG seeded once per epoch.  The per-parameter update norms pin the optimiser
+    reset - carried-over Adam moments would change every one of them."""
+    from sar_ssl_amd import learner as L, model, runtime, synth
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLD, "f12_pretrain_epoch.npz"))
+    tol = {"fp32": dict(loss=1e-3, pred=2e-3, upd=1e-2), "bf16": dict(loss=2e-3, pred=3e-2, upd=1e-1)}[prec]
+    try:
+        man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+        net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev)
+        init = recipes.recipe_state_dict(man, int(z["weight_seed"]))
+        net.load_state_dict(init)
+        _set_dropout(net, 0.0)
+        lrn = L.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+        lrn.cuda()
+        if prec == "bf16":
+            lrn.amp()
+        B, nb = int(z["B"]), int(z["nbatch"])
+        pool = torch.from_numpy(synth.make_batch(int(z["sig_seed"]), B * nb))
+        dataset = [[pool[i * B:(i + 1) * B]] for i in range(nb)]
+        for e in (1, 2):
+            random.seed(int(z["mask_seed"][e - 1]))
+            loss, diff, vis = lrn.pretrain_epoch(dataset, lr=float(z["lr"][e - 1]), epoch=e)
+            assert net.training == bool(z["training_flag"])
+            check("pretrain_epoch.%s.e%d.loss" % (prec, e), abs(loss / float(z["epoch%d.loss" % e]) - 1), tol["loss"])
+            check("pretrain_epoch.%s.e%d.diff" % (prec, e), abs(diff / float(z["epoch%d.diff" % e]) - 1), 1e-4)
+            pred = vis["pred"]
+            assert tuple(pred.shape) == tuple(z["epoch%d.pred_shape" % e])
+            got = pred.reshape(-1).cpu()[torch.from_numpy(z["epoch%d.pred_idx" % e])]
+            want = torch.from_numpy(z["epoch%d.pred_vals" % e])
+            check("pretrain_epoch.%s.e%d.pred" % (prec, e), (got - want).abs().max() / float(z["epoch%d.pred_absmax" % e]), tol["pred"])
+            assert abs(float((vis["mask"] == 0).float().mean()) - float(z["epoch%d.mask_zero_frac" % e])) < 1e-6
+        ref = json.loads(str(z["update_norm_json"]))
+        got = _update_norms(net, init)
+        worst = max((abs(got[k] - ref[k]) / ref[k], k) for k in ref if ref[k] > 1e-3 * max(ref.values()))
+        check("pretrain_epoch.%s.update_norm[worst=%s]" % (prec, worst[1]), worst[0], tol["upd"])
+    finally:
+        runtime.set_precision("bf16")
+
+
+def test_checkpoint_written_by_reference_resumes(tmp_path):
+    """SURVEY fixture F6: a checkpoint FILE written by the reference's ``save_checkpoint`` (code/learner.py:344-374) is loaded by
+    ``resume_checkpoint``; every tensor equals the recipe it was written from and the eval-mode output matches the reference's."""
+    import gzip
+    import shutil
+    from sar_ssl_amd import learner as L, model, runtime
+    meta = np.load(os.path.join(GOLD, "f6_checkpoint_meta.npz"))
+    with gzip.open(os.path.join(GOLD, "f6_checkpoint.tar.gz"), "rb") as fi, open(str(tmp_path / "latest_model.tar"), "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    dev = torch.device("cuda:0")
+    net = model.MCConformer(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed={"spec": 32, "spat": 32}, device=dev)
+    lrn = L.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cuda()                                                    # fp32 mode (the reference default)
+    try:
+        lrn.resume_checkpoint(str(tmp_path), from_latest=True)
+        assert lrn.start_epoch == int(meta["epoch"]) + 1 and lrn.max_score == float(meta["max_score"])
+        want = recipes.recipe_state_dict(json.loads(str(meta["manifest_json"])), int(meta["weight_seed"]))
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(want.keys())
+        for k, v in want.items():
+            assert torch.equal(sd[k].cpu(), v), k
+        net.eval()
+        x = torch.from_numpy(np.random.default_rng(int(meta["x_seed"])).standard_normal((2, 2, 16, 8, 2)).astype(np.float32)).to(dev)
+        with torch.no_grad():
+            y = net(x)
+        yref = torch.from_numpy(meta["y"])
+        check("f6_checkpoint.forward", (y.float().cpu() - yref).abs().max() / yref.abs().max(), 1e-3)
+    finally:
+        runtime.set_precision("bf16")
 
 
 def test_learner_epoch_and_checkpoint_roundtrip(tmp_path):
@@ -148,3 +226,20 @@ def test_two_rank_bench_path_over_gloo():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak" and out["value"] > 0
     assert np.isfinite(out["final_loss"]) and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("two_streams", ["0", "1"])
+def test_two_rank_overlapped_allreduce_equals_full_batch_gradient(two_streams):
+    """The overlapped data-parallel path on the real SARSSL (stage hooks issued from the hand-written backward, side stream on/off,
+    grouped q/k/v layout, 1/world scaling): the averaged 2-rank gradient equals the single-process gradient of the whole batch
+    (tools/dp_grad_check.py; 2 ranks share this GPU over gloo - RCCL needs one GPU per rank)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SARSSL_DIST_BACKEND="gloo", SARSSL_TWO_STREAMS=two_streams)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dp_grad_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["world"] == 2 and out["hook_order"] == ["decoder", "spat_encoder", "spec_encoder", "stems"]
+    check("dp2.grad_vs_full_batch.streams%s" % two_streams, out["max_rel_err"], 2e-5)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import recipes
 from conftest import GOLD, ROOT
 
 
@@ -216,3 +217,23 @@ def test_native_mask_sampler_is_bit_identical_to_python_random():
     random.seed(seed0)
     idx, ch = pm.sample(4, 2)
     assert np.array_equal(idx, z["seed%d.idx" % seed0]) and np.array_equal(ch.reshape(-1), z["seed%d.ch" % seed0].reshape(-1))
+
+
+def test_reference_written_checkpoint_file_matches_our_state_dict_layout():
+    """Fixture F6 on the host: the file the reference's ``save_checkpoint`` wrote (fp32 layout: epoch / max_score / model) loads
+    strictly into this build's MCConformer - same keys, shapes and values (code/learner.py:354-374)."""
+    import gzip
+    import io
+    from sar_ssl_amd import model
+    meta = np.load(os.path.join(GOLD, "f6_checkpoint_meta.npz"))
+    with gzip.open(os.path.join(GOLD, "f6_checkpoint.tar.gz"), "rb") as f:
+        ck = torch.load(io.BytesIO(f.read()), map_location="cpu", weights_only=False)
+    assert set(ck.keys()) == {"epoch", "max_score", "model"} and ck["epoch"] == int(meta["epoch"])
+    assert ck["max_score"] == float(meta["max_score"])
+    net = model.MCConformer(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed={"spec": 32, "spat": 32}, device="cpu")
+    man = json.loads(str(meta["manifest_json"]))
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == man
+    net.load_state_dict(ck["model"], strict=True)
+    want = recipes.recipe_state_dict(man, int(meta["weight_seed"]))
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, want[k]), k

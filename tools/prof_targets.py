@@ -1,0 +1,107 @@
+"""Runs every hot kernel family of the pretraining step at BASELINE config-2 shapes (B = 64), each group preceded by a marker
+launch (tools/prof_marker.hip, grid = tag) - the target of tools/prof_counters.py's rocprofv3 --pmc passes."""
+import ctypes
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import sarssl_boot  # noqa
+import torch
+from sar_ssl_amd import hip
+
+MARK = os.path.join(HERE, "libprofmarker.so")
+if not os.path.exists(MARK) or os.path.getmtime(MARK) < os.path.getmtime(os.path.join(HERE, "prof_marker.hip")):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", MARK,
+                           os.path.join(HERE, "prof_marker.hip")])
+_mk = ctypes.CDLL(MARK)
+dev = torch.device("cuda:0")
+NREP = int(os.environ.get("PROF_NREP", "3"))
+ONLY = set(int(t) for t in os.environ.get("PROF_ONLY", "").split(",") if t)
+
+TAGS = {}          # tag -> (label, algorithmic flop per launch, algorithmic bytes per launch)
+
+
+def group(tag, label, fn, flop=0.0, nbytes=0.0):
+    TAGS[tag] = (label, flop, nbytes)
+    if ONLY and tag not in ONLY:
+        return
+    fn()                                             # warm (allocations)
+    torch.cuda.synchronize()
+    _mk.prof_marker(ctypes.c_int(tag), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for _ in range(NREP):
+        fn()
+    _mk.prof_marker(ctypes.c_int(0x3fff), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))      # closes the group
+    torch.cuda.synchronize()
+
+
+def rnd(*shape, dtype=torch.bfloat16, scale=1.0):
+    return (torch.randn(shape, device=dev) * scale).to(dtype)
+
+
+def gemm_group(tag, label, M, N, K, a_kc=True, b_kc=True, out_dtype=torch.bfloat16, split=0, **kw):
+    A = rnd(*((M, K) if a_kc else (K, M)))
+    B = rnd(*((N, K) if b_kc else (K, N)))
+    out = torch.zeros((M, N), dtype=out_dtype, device=dev)
+    osz = 2 if out_dtype == torch.bfloat16 else 4
+    group(tag, label, lambda: hip.gemm(A, B, a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], out=out,
+                                       split_k=split, **kw), 2.0 * M * N * K, 2.0 * (M * K + N * K) + osz * M * N)
+
+
+def main():
+    Mr = 64 * 256
+    bias = torch.zeros(4096, device=dev)
+    d = 512
+    pre = torch.empty((Mr, 4 * d), dtype=torch.bfloat16, device=dev)
+    gemm_group(1, "gemm ffn1 NT d=512 (+bias,swish,preact,dropout)", Mr, 4 * d, d, bias=bias[:4 * d], act=2, preact=pre, p_drop=0.1, seed=7)
+    res = rnd(Mr, d)
+    gemm_group(2, "gemm ffn2 NT d=512 (+bias,dropout,resid)", Mr, d, 4 * d, bias=bias[:d], p_drop=0.1, seed=9, resid=res, ldr=d, out_scale=0.5)
+    gemm_group(3, "gemm qkv NT d=512 (N=1536)", Mr, 3 * d, d, bias=bias[:3 * d])
+    aux = rnd(Mr, 4 * d)
+    gemm_group(4, "gemm ffn2 dX NN d=512 (+swish' aux)", Mr, 4 * d, d, b_kc=False, aux=aux, aux_act=2)
+    gemm_group(5, "gemm ffn1 dX NN d=512", Mr, d, 4 * d, b_kc=False)
+    gemm_group(6, "gemm ffn dW TN d=512 (split-K)", 4 * d, d, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8)
+    gemm_group(7, "gemm decoder1 NT (768->3072, relu)", Mr, 3072, 768, bias=bias[:3072], act=1)
+    gemm_group(8, "gemm decoder2 NT (3072->1024)", Mr, 1024, 3072, bias=bias[:1024])
+    gemm_group(9, "gemm decoder2 dW TN (split-K)", 1024, 3072, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=2)
+    gemm_group(10, "gemm patch NT (1024->512)", Mr, 512, 1024)
+    gemm_group(11, "gemm ffn1 NT d=256", Mr, 1024, 256, bias=bias[:1024], act=2)
+    gemm_group(12, "gemm ffn2 NT d=256", Mr, 256, 1024, bias=bias[:256])
+    # ---- stem
+    B = 64
+    x = rnd(B, 256, 256, 64)
+    y = rnd(B, 256, 256, 64)
+    w = rnd(9, 64, 64, scale=0.05)
+    sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    aff = torch.stack([sc, sh, sh, sc]).contiguous()
+    cfl = 2.0 * B * 65536 * 64 * 576
+    tb = x.numel() * 2.0
+    group(20, "conv3x3 fwd (BN+ReLU prologue, stats epilogue)", lambda: hip.conv3x3_fwd(x, w, sc, sh, want_stats=True), cfl, 2 * tb)
+    group(21, "conv3x3 dgrad (identity prologue)", lambda: hip.conv3x3_fwd(x, w), cfl, 2 * tb)
+    group(22, "conv3x3 dgrad + BN-backward sums", lambda: hip.conv3x3_dgrad_bnred(x, w, y, aff), cfl, 3 * tb)
+    group(23, "conv3x3 wgrad", lambda: hip.conv3x3_wgrad(x, y, sc, sh), cfl, 2 * tb)
+    a0 = rnd(B, 256, 256, 4)
+    W1 = torch.randn((64, 4), device=dev)
+    W4 = torch.randn((4, 64), device=dev)
+    group(30, "stem_c1_fwd (4->64 + BN sums)", lambda: hip.stem_c1_fwd(a0, W1, want_stats=True), 0, tb + tb / 16)
+    group(31, "stem_c4_fwd (BN+ReLU, 64->4)", lambda: hip.stem_c4_fwd(x, W4, sc, sh), 0, tb + tb / 16)
+    dy4 = rnd(B, 256, 256, 4)
+    group(32, "stem_c4_bwd two-phase (sums + apply)", lambda: hip.stem_c4_bwd_two_phase(x, dy4, W4, aff, True), 0, 3 * tb + 2 * tb / 16)
+    gW, gg, gb = torch.zeros((64, 4), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    group(33, "stem_c1_bwd (one pass)", lambda: hip.stem_c1_bwd(x, y, a0, aff, True, gW, gg, gb), 0, 2 * tb + tb / 16)
+    red = torch.zeros(128, dtype=torch.float64, device=dev)
+    group(34, "cl_bn_bwd_apply C=64 (in place)", lambda: hip.cl_bn_bwd_apply(x, y, 64, aff, 1, False, True, red, out=x), 0, 3 * tb)
+    group(35, "cl_bn_bwd_reduce C=64", lambda: hip.cl_bn_bwd_reduce(x, y, 64, aff, 1), 0, 2 * tb)
+    # ---- attention glue (d = 512: 4 heads, T = 256)
+    T, H = 256, 4
+    content = torch.randn((B, H, T, T), device=dev)
+    pos = torch.randn((B, H, T, T), device=dev)
+    group(40, "softmax_relshift_fwd (B,4,256,256)", lambda: hip.softmax_relshift_fwd(content, pos, 0.044, torch.bfloat16, 0.1, 5), 0,
+          content.numel() * (8.0 + 4.0))
+    import json
+    print("PROF_TAGS " + json.dumps(TAGS))
+
+
+if __name__ == "__main__":
+    main()
