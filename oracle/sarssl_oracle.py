@@ -339,6 +339,29 @@ def train_step(mic_sig, sd, opt_state, lr, mask_patch_idx=None, mask_ch_idx=None
     return float(loss.detach()), float(diff.detach())
 
 
+def pretrain_epoch(batches, sd, lr, p_drop=0.1, rng=random):
+    """``Learner.pretrain_epoch`` (code/learner.py:76-131): train mode, a NEW Adam (zero moments, step count 0) per call, one
+    ``train_step`` per batch, returns (mean loss, mean diff, pred of the LAST batch as computed before its optimiser step - the
+    ``vis_batch`` the reference returns, folded to (B, F, T, reim, mic) like ``vis_results``, code/model.py:776-790)."""
+    opt_state = {}
+    loss_sum = diff_sum = 0.0
+    last = None
+    for mic_sig in batches:
+        x = data_preprocess(mic_sig)
+        B, _, Fq, T, _ = x.shape
+        idx, ch = gen_masks(B, T, T // 2, 2, rng)
+        with torch.no_grad():                                            # the returned vis uses the pre-step weights (train-mode BN)
+            last = (x, idx, ch, {k: v.clone() for k, v in sd.items()})
+        l, d = train_step(mic_sig, sd, opt_state, lr, idx, ch, p_drop=p_drop)
+        loss_sum += l
+        diff_sum += d
+    x, idx, ch, sd_before = last
+    with torch.no_grad():
+        _, _, aux = sarssl_pretrain_forward(x, sd_before, idx, ch, train=True, p_drop=p_drop)
+    n = len(batches)
+    return loss_sum / n, diff_sum / n, aux["pred"].permute(0, 2, 1, 3, 4)
+
+
 def downstream_train_step(mic_sig, tdoa, sd, opt_state, lr, embed_use="spat", p_drop=0.1, frozen=(), fs=16000):
     """One iteration of ``Learner.train_epoch`` (code/learner.py:186-202) for task 'TDOA': preprocess -> downstream
     forward in train mode -> ``mse_loss(pred, TDOA*fs)`` (learner.py:620-631, 644-647) -> backward -> Adam over the

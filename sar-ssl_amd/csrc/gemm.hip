@@ -13,22 +13,25 @@
 // (hi*hi, hi*lo, lo*hi) accumulating in an f32 workspace: ~2^-16 relative error per product,
 // on the same matrix cores and the same code path as the fast bf16 mode.
 //
-// Tiling: 128x128x64 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA
-// fragments).  K-contiguous operands are staged through registers into LDS as [row][k] with a 144-byte pitch
-// (conflict-free ds_read_b128 fragment reads); operands whose contraction index is the SLOW memory dimension
-// (weight gradients, dX = dY*W) are staged untransposed as [k][row] (320-byte pitch) and their MFMA fragments are
-// fetched with the gfx950 transpose read ds_read_b64_tr_b16 - no transposition pass, no bank conflicts.  Operand roles are swapped in the MFMA
-// (weights as the "A"/row operand) so each lane ends up with 4 consecutive n for one m and the
-// epilogue stores 8/16-byte vectors.
+// Tiling: (64*FM) x 128 x 64 per 256-thread workgroup, 4 waves as 2 x 2; each wave owns FM x 2 MFMA fragments of 32 x 32
+// (FM = 4: 256 x 128 tiles, 128 x 64 per wave, 128 accumulator registers; FM = 2: 128 x 128 tiles for grids that would not fill
+// the chip with the large tile).  Round-2 counters (profiles/r02_gemm_before_counters.json) showed the round-1 kernel issue-bound,
+// not LDS- or HBM-bound: per K-tile a wave spent ~400 cycles issuing address arithmetic / bounds checks / staging instructions
+// next to 512 cycles of MFMA, and the fused epilogue another ~14 k cycles per 128 x 128 tile.  Hence: twice the MFMAs per staged
+// byte and per barrier (wave tile 128 x 64), per-thread base pointers advanced by a constant per K-tile, no bounds logic unless the
+// shape is ragged (EDGE instantiation), and an epilogue whose row / column bookkeeping is hoisted out of the element loop.
+// K-contiguous operands are staged through registers into LDS as [row][k] with a 144-byte pitch (conflict-free ds_read_b128
+// fragment reads); operands whose contraction index is the SLOW memory dimension (weight gradients, dX = dY*W) are staged
+// untransposed as [k][row] (pitch rows + 32 elements) and their MFMA fragments are fetched with the gfx950 transpose read
+// ds_read_b64_tr_b16 - no transposition pass, no bank conflicts.  The next K-tile is always prefetched into registers behind the
+// MFMAs.  Operand roles are swapped in the MFMA (weights as the "A"/row operand) so each lane ends up with 4 consecutive n for one
+// m; the epilogue transposes the accumulators through LDS so every thread stores 16-byte pieces of contiguous rows.
 #include "common.h"
 #include <stdlib.h>
 
-#define BM 128
 #define BN 128
 #define BK 64
 #define PITCH (BK + 8)
-#define PITCH_T (BM + 32)          // [k][row] tiles: 320-byte pitch -> conflict-free 32-lane transpose reads
-#define TILE_ELEMS (BK * PITCH_T)  // >= BM * PITCH
 
 struct GemmArgs {
     const void* A; const void* B; void* C;
@@ -45,39 +48,45 @@ struct GemmArgs {
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
     float p_drop; unsigned long long seed;
-    int dbg;                    // experiments (SARSSL_GEMM_DBG): 1 = stage first K-tile only, 2 = no stores, 4 = no MFMA
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
 };
 
-// Operand staging is split in two halves so the global loads of K-tile t+1 are in flight while tile t is on the matrix
-// cores: tile_load (global -> 4 x 16-byte registers, with the f32 -> bf16 hi/lo split if needed) and tile_store (-> LDS).
-template <typename T, bool KC>
-__device__ __forceinline__ void tile_load(const T* __restrict__ src, long ld, int r0, int k0, int R, int K, int part, int tid,
-                                          uint4 (&regs)[4]) {
+template <typename T>
+__device__ __forceinline__ uint4 load_chunk(const T* __restrict__ p, int part) {
+    if constexpr (sizeof(T) == 2) return *(const uint4*)p;
+    else { const f8 v = ld8(p); return pack8_part(v, part); }
+}
+
+// Register-staged operand tile: ROWS x 64 elements, 16-byte chunks, NCH = ROWS / 32 chunks per thread.
+//   KC  ([row][k] in memory):  chunk i of thread t = row (t >> 3) + 32 i, k-chunk t & 7
+//   !KC ([k][row] in memory):  CPR = ROWS / 8 chunks per k-row; chunk i of thread t = k (t / CPR) + i * (256 / CPR), row-chunk t % CPR
+// `p` points at this thread's chunk 0 of the current K-tile; EDGE instantiations zero-fill rows >= R and k >= Kend.
+template <typename T, bool KC, int ROWS, bool EDGE>
+__device__ __forceinline__ void tile_load(const T* __restrict__ p, long ld, int r0, int k0, int R, int Kend, int part, int tid,
+                                          uint4 (&regs)[ROWS / 32]) {
+    constexpr int CPR = ROWS / 8, KPP = 256 / CPR;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * 256;
-        int gr, gk;
-        if (KC) { gr = r0 + (c >> 3); gk = k0 + (c & 7) * 8; }          // [row][k]: 8 chunks of 8 k per row
-        else { gk = k0 + (c >> 4); gr = r0 + (c & 15) * 8; }            // [k][row]: 16 chunks of 8 rows per k
-        if (gr < R && gk < K) {
-            const T* p = KC ? src + (long)gr * ld + gk : src + (long)gk * ld + gr;
-            if (sizeof(T) == 2) regs[i] = *(const uint4*)p;
-            else { f8 v = ld8(p); regs[i] = pack8_part(v, part); }
-        } else regs[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const T* q = KC ? p + (long)(32 * i) * ld : p + (long)(KPP * i) * ld;
+        if constexpr (EDGE) {
+            const int gr = KC ? r0 + (tid >> 3) + 32 * i : r0 + (tid % CPR) * 8;
+            const int gk = KC ? k0 + (tid & 7) * 8 : k0 + tid / CPR + KPP * i;
+            regs[i] = (gr < R && gk < Kend) ? load_chunk(q, part) : make_uint4(0, 0, 0, 0);
+        } else regs[i] = load_chunk(q, part);
     }
 }
-template <bool KC>
-__device__ __forceinline__ void tile_store(uint16_t* __restrict__ s, int tid, const uint4 (&regs)[4]) {
+template <bool KC, int ROWS>
+__device__ __forceinline__ void tile_store(uint16_t* __restrict__ s, int tid, const uint4 (&regs)[ROWS / 32]) {
+    constexpr int CPR = ROWS / 8, KPP = 256 / CPR, PT = ROWS + 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * 256;
-        if (KC) *(uint4*)&s[(c >> 3) * PITCH + (c & 7) * 8] = regs[i];
-        else *(uint4*)&s[(c >> 4) * PITCH_T + (c & 15) * 8] = regs[i];
+    for (int i = 0; i < ROWS / 32; ++i) {
+        if (KC) *(uint4*)&s[((tid >> 3) + 32 * i) * PITCH + (tid & 7) * 8] = regs[i];
+        else *(uint4*)&s[(tid / CPR + KPP * i) * PT + (tid % CPR) * 8] = regs[i];
     }
 }
 
-// MFMA fragment (8 consecutive k for row r0 + (lane&31)) from a [k][row] tile via two transpose reads
+// MFMA fragment (8 consecutive k for row r0 + (lane&31)) from a [k][row] tile (pitch PT) via two transpose reads
+template <int PT>
 __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, int lane) {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     const int col = r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
@@ -85,16 +94,111 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int k = kbase + (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
-        u.v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + k * PITCH_T + col));
+        u.v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + k * PT + col));
     }
     return u.b;
 }
 
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC, bool PF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4))) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TILE_ELEMS];      // 40 KiB: A/B tiles, then the C staging tile
+// ---- fused epilogue on one 8-wide piece of one output row (v = alpha * accumulator) -------------------------------------------------
+template <typename TC, bool EDGE>
+__device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m, int n, TC* __restrict__ C, const TC* __restrict__ Rz,
+                                          TC* __restrict__ P, const TC* __restrict__ Xa, float* __restrict__ W, float* __restrict__ Wp,
+                                          const float (&bias8)[8], bool vec_ok, float inv_keep) {
+    const int nvalid = EDGE ? min(8, g.N - n) : 8;
+    const bool vec = EDGE ? (vec_ok && nvalid == 8) : true;
+    if (g.split_k > 0) {                                 // raw partial for the split-K second stage
+        float* q = Wp + (long)m * g.N + n;
+        if (!EDGE || ((g.N & 3) == 0 && nvalid == 8)) {
+            *(float4*)q = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); *(float4*)(q + 4) = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) q[e] = v.v[e];
+        }
+        return;
+    }
+    if (g.acc_in) {
+        const float* q = W + (long)m * g.N + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += q[e];
+    }
+    if (g.acc_out) {
+        float* q = W + (long)m * g.N + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) q[e] = v.v[e];
+        return;
+    }
+    if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] += bias8[e];
+    }
+    const long co = (long)m * g.ldc + n;
+    if (P) {
+        if (vec) st8(P + co, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(P + co + e, v.v[e]);
+        }
+    }
+    if (g.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
+    } else if (g.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * sigmoidf_(v.v[e]);
+    }
+    if (Xa) {                                            // dX epilogue: times act'(saved pre-activation)
+        f8 h;
+        if (vec) h = ld8(Xa + co);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h.v[e] = (e < nvalid) ? ld_f(Xa + co + e) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (g.aux_act == 1) v.v[e] = h.v[e] > 0.f ? v.v[e] : 0.f;
+            else { const float sg = sigmoidf_(h.v[e]); v.v[e] *= sg * (1.f + h.v[e] * (1.f - sg)); }
+        }
+    }
+    if (g.p_drop > 0.f) {
+        const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
+        if ((base & 1ull) == 0 && (((base + 7) >> 33) == (base >> 33))) dropout_apply8(v.v, g.seed, base, g.p_drop, inv_keep);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(g.seed, base + e, g.p_drop, inv_keep);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.v[e] *= g.out_scale;
+    if (Rz) {
+        const long ro = (long)m * g.ldr + n;
+        if (vec) {
+            const f8 rr = ld8(Rz + ro);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] += g.res_scale * rr.v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += g.res_scale * ld_f(Rz + ro + e);
+        }
+    }
+    if (vec) st8(C + co, v);
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(C + co + e, v.v[e]);
+    }
+}
+
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_kernel(GemmArgs g) {
+    constexpr int BM = 64 * FM;
+    constexpr int PTA = BM + 32, PTB = BN + 32;
+    constexpr int A_ELEMS = AKC ? BM * PITCH : BK * PTA;
+    constexpr int B_ELEMS = BKC ? BN * PITCH : BK * PTB;
+    constexpr int PC = BN + 4;                                  // f32 staging pitch of the epilogue (conflict-free 16-byte LDS writes)
+    constexpr int EPI_ELEMS = 64 * PC * 2;                      // 64 x 132 f32, in 16-bit units
+    constexpr int LDS_ELEMS = (A_ELEMS + B_ELEMS) > EPI_ELEMS ? (A_ELEMS + B_ELEMS) : EPI_ELEMS;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];    // FM = 2: 40 KiB (3-4 workgroups / CU), FM = 4: 56 KiB (2 / CU)
     uint16_t* sA = smem;
-    uint16_t* sB = smem + TILE_ELEMS;
+    uint16_t* sB = smem + A_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nsplit = g.split_k > 0 ? g.split_k : 1;
@@ -103,9 +207,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4)
     const int k_begin = g.split_k > 0 ? ks * g.k_per_split : 0;
     const int k_end = g.split_k > 0 ? min(g.K, k_begin + g.k_per_split) : g.K;
     // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with its own L2: in the
-    // natural order the N/128 column tiles of one 128-row A panel land on different XCDs and the panel is fetched from HBM by every
-    // one of them (ffn2: 4 x 67 MB instead of 67 MB).  Remap so that XCD x owns row panels x, x+8, ... and walks all their column
-    // tiles back to back - the A panel is then served by that XCD's L2.
+    // natural order the column tiles of one A row panel land on different XCDs and the panel is fetched from HBM by every one of
+    // them.  Remap so that XCD x owns row panels x, x+8, ... and walks all their column tiles back to back - the A panel is then
+    // served by that XCD's L2.
     int bx = blockIdx.x, by = blockIdx.y;
     if ((gridDim.y & 7) == 0) {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
@@ -114,57 +218,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4)
         bx = j % (int)gridDim.x;
     }
     const int m0 = by * BM, n0 = bx * BN;
-    const TA* A = (const TA*)g.A + z0 * g.sA0 + z1 * g.sA1;
-    const TB* B = (const TB*)g.B + z0 * g.sB0 + z1 * g.sB1;
+    // this thread's chunk 0 of the first K-tile; advanced by a constant per K-tile
+    constexpr int CPRA = BM / 8, CPRB = BN / 8;
+    const TA* pa = (const TA*)g.A + z0 * g.sA0 + z1 * g.sA1 +
+                   (AKC ? (long)(m0 + (tid >> 3)) * g.lda + k_begin + (tid & 7) * 8 : (long)(k_begin + tid / CPRA) * g.lda + m0 + (tid % CPRA) * 8);
+    const TB* pb = (const TB*)g.B + z0 * g.sB0 + z1 * g.sB1 +
+                   (BKC ? (long)(n0 + (tid >> 3)) * g.ldb + k_begin + (tid & 7) * 8 : (long)(k_begin + tid / CPRB) * g.ldb + n0 + (tid % CPRB) * 8);
+    const long stepA = AKC ? BK : (long)BK * g.lda, stepB = BKC ? BK : (long)BK * g.ldb;
 
-    f32x16 acc[2][2];
+    f32x16 acc[FM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // PF (long-K GEMMs): the next K-tile is prefetched into registers behind the MFMAs.  Short-K, wide-N GEMMs are
-    // epilogue/store dominated and prefer the extra occupancy of the 32-VGPR-lighter non-prefetching variant.
-    uint4 ra[4], rb[4];
-    if (PF) {
-        tile_load<TA, AKC>(A, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
-        tile_load<TB, BKC>(B, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
-    }
+    uint4 ra[BM / 32], rb[BN / 32];
+    tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
+    tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        if (!(g.dbg & 1) || k0 == k_begin) {
-            if (!PF) {
-                tile_load<TA, AKC>(A, g.lda, m0, k0, g.M, k_end, g.partA, tid, ra);
-                tile_load<TB, BKC>(B, g.ldb, n0, k0, g.N, k_end, g.partB, tid, rb);
-            }
-            if (!(g.dbg & 8) || k0 == k_begin) {
-                tile_store<AKC>(sA, tid, ra);
-                tile_store<BKC>(sB, tid, rb);
-            }
-        }
+        tile_store<AKC, BM>(sA, tid, ra);
+        tile_store<BKC, BN>(sB, tid, rb);
         __syncthreads();
-        if (PF && k0 + BK < k_end && !(g.dbg & 1)) {
-            tile_load<TA, AKC>(A, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
-            tile_load<TB, BKC>(B, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
+        if (k0 + BK < k_end) {                           // next K-tile in flight behind the MFMAs
+            pa += stepA; pb += stepB;
+            tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
+            tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
         }
-        if (!(g.dbg & 4))
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int koff = kk * 16 + (lane >> 5) * 8;
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[FM], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (AKC) fa[i] = *(const bf16x8*)&sA[(wm * 64 + i * 32 + (lane & 31)) * PITCH + koff];
-                else fa[i] = frag_tr(sA, kk * 16, wm * 64 + i * 32, lane);
+            for (int i = 0; i < FM; ++i) {
+                if (AKC) fa[i] = *(const bf16x8*)&sA[(wm * (FM * 32) + i * 32 + (lane & 31)) * PITCH + koff];
+                else fa[i] = frag_tr<PTA>(sA, kk * 16, wm * (FM * 32) + i * 32, lane);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (BKC) fb[j] = *(const bf16x8*)&sB[(wn * 64 + j * 32 + (lane & 31)) * PITCH + koff];
-                else fb[j] = frag_tr(sB, kk * 16, wn * 64 + j * 32, lane);
+                else fb[j] = frag_tr<PTB>(sB, kk * 16, wn * 64 + j * 32, lane);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -172,11 +269,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4)
         __syncthreads();
     }
 
-    if (g.dbg & 2) return;
     // ---- epilogue.  The MFMA leaves each lane with 4 consecutive n for ONE row m (32 different rows per wave instruction):
     // storing that directly is store-issue bound (every instruction touches 32 cache lines).  Instead the f32 accumulators are
-    // transposed through LDS, 64 rows at a time, so each thread owns 8 consecutive columns of one row: bias / activation /
-    // dropout / residual are applied on 8-wide vectors and every global access is a full 16/32-byte piece of a contiguous row.
+    // transposed through LDS, 64 rows at a time (fragment row i of both wave rows), so each thread owns 8 consecutive columns of
+    // one row: bias / activation / dropout / residual are applied on 8-wide vectors and every global access is a full 16/32-byte
+    // piece of a contiguous row.  A thread keeps the same 8 columns in every slice, so its bias values are loaded once.
     TC* C = (TC*)g.C + z0 * g.sC0 + z1 * g.sC1;
     const TC* Rz = g.resid ? (const TC*)g.resid + z0 * g.sR0 + z1 * g.sR1 : nullptr;
     TC* P = g.preact ? (TC*)g.preact + z0 * g.sC0 + z1 * g.sC1 : nullptr;
@@ -185,107 +282,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF ? 3 : 4)
     float* Wp = (g.split_k > 0) ? g.acc_ws + ((long)z * nsplit + ks) * g.M * g.N : nullptr;
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
     const float inv_keep = g.p_drop > 0.f ? 1.0f / (1.0f - g.p_drop) : 1.0f;
-    constexpr int PC = BN + 4;                                  // f32 staging pitch (conflict-free 16-byte LDS writes)
-    float* sC = (float*)smem;                                   // 64 x 132 x 4 B = 33 KiB <= 40 KiB
+    float* sC = (float*)smem;
+    const int ch = tid & 15, n = n0 + ch * 8;
+    float bias8[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (wm == half) {
+    for (int e = 0; e < 8; ++e) bias8[e] = (g.bias && (!EDGE || n + e < g.N)) ? g.bias[n + e] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        *(float4*)&sC[(i * 32 + (lane & 31)) * PC + wn * 64 + j * 32 + 8 * gq + 4 * (lane >> 5)] =
-                            make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
-        }
+            for (int gq = 0; gq < 4; ++gq)
+                *(float4*)&sC[(wm * 32 + (lane & 31)) * PC + wn * 64 + j * 32 + 8 * gq + 4 * (lane >> 5)] =
+                    make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = tid + k * 256;
-            const int r = c >> 4, ch = c & 15;
-            const int m = m0 + half * 64 + r, n = n0 + ch * 8;
-            if (m >= g.M || n >= g.N) continue;
-            const int nvalid = min(8, g.N - n);
+            const int r = (tid >> 4) + 16 * k;                   // 0..63: wave row r >> 5, row r & 31 of fragment i
+            const int m = m0 + (r >> 5) * (FM * 32) + i * 32 + (r & 31);
+            if (EDGE && (m >= g.M || n >= g.N)) continue;
             f8 v;
-            {
-                const float4 a0 = *(const float4*)&sC[r * PC + ch * 8], a1 = *(const float4*)&sC[r * PC + ch * 8 + 4];
-                v.v[0] = g.alpha * a0.x; v.v[1] = g.alpha * a0.y; v.v[2] = g.alpha * a0.z; v.v[3] = g.alpha * a0.w;
-                v.v[4] = g.alpha * a1.x; v.v[5] = g.alpha * a1.y; v.v[6] = g.alpha * a1.z; v.v[7] = g.alpha * a1.w;
-            }
-            if (g.split_k > 0) {                                 // raw partial for the split-K second stage
-                float* q = Wp + (long)m * g.N + n;
-                if ((g.N & 3) == 0) { *(float4*)q = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); *(float4*)(q + 4) = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]); }
-                else {
-_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) q[e] = v.v[e]; }
-                continue;
-            }
-            if (g.acc_in) {
-                const float* q = W + (long)m * g.N + n;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += q[e];
-            }
-            if (g.acc_out) {
-                float* q = W + (long)m * g.N + n;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nvalid) q[e] = v.v[e];
-                continue;
-            }
-            if (g.bias) {
-                if (nvalid == 8) {
-                    const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
-                    v.v[0] += b0.x; v.v[1] += b0.y; v.v[2] += b0.z; v.v[3] += b0.w; v.v[4] += b1.x; v.v[5] += b1.y; v.v[6] += b1.z; v.v[7] += b1.w;
-                } else {
-_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += g.bias[n + e]; }
-            }
-            if (P) {
-                if (vec_ok) st8(P + (long)m * g.ldc + n, v);
-                else {
-_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(P + (long)m * g.ldc + n + e, v.v[e]); }
-            }
-            if (g.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
-            } else if (g.act == 2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * sigmoidf_(v.v[e]);
-            }
-            if (Xa) {                                            // dX epilogue: times act'(saved pre-activation)
-                f8 h;
-                if (vec_ok) h = ld8(Xa + (long)m * g.ldc + n);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) h.v[e] = (e < nvalid) ? ld_f(Xa + (long)m * g.ldc + n + e) : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (g.aux_act == 1) v.v[e] = h.v[e] > 0.f ? v.v[e] : 0.f;
-                    else { const float sg = sigmoidf_(h.v[e]); v.v[e] *= sg * (1.f + h.v[e] * (1.f - sg)); }
-                }
-            }
-            if (g.p_drop > 0.f) {
-                const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
-                if ((base & 1ull) == 0 && (((base + 7) >> 33) == (base >> 33))) dropout_apply8(v.v, g.seed, base, g.p_drop, inv_keep);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(g.seed, base + e, g.p_drop, inv_keep);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v.v[e] *= g.out_scale;
-            if (Rz) {
-                if (vec_ok) {
-                    const f8 rr = ld8(Rz + (long)m * g.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] += g.res_scale * rr.v[e];
-                } else {
-_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += g.res_scale * ld_f(Rz + (long)m * g.ldr + n + e); }
-            }
-            if (vec_ok) st8(C + (long)m * g.ldc + n, v);
-            else {
-_Pragma("unroll") for (int e = 0; e < 8; ++e) if (e < nvalid) st_f(C + (long)m * g.ldc + n + e, v.v[e]); }
+            const float4 a0 = *(const float4*)&sC[r * PC + ch * 8], a1 = *(const float4*)&sC[r * PC + ch * 8 + 4];
+            v.v[0] = g.alpha * a0.x; v.v[1] = g.alpha * a0.y; v.v[2] = g.alpha * a0.z; v.v[3] = g.alpha * a0.w;
+            v.v[4] = g.alpha * a1.x; v.v[5] = g.alpha * a1.y; v.v[6] = g.alpha * a1.z; v.v[7] = g.alpha * a1.w;
+            epilogue8<TC, EDGE>(g, v, z, m, n, C, Rz, P, Xa, W, Wp, bias8, vec_ok, inv_keep);
         }
-        __syncthreads();
+        if (i + 1 < FM) __syncthreads();
     }
 }
 
@@ -304,22 +326,43 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, i
     }
 }
 
-template <typename TA, typename TB, typename TC>
-static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
-    static const int pf_mink = getenv("SARSSL_GEMM_PF_MINK") ? atoi(getenv("SARSSL_GEMM_PF_MINK")) : 1024;
+template <typename TA, typename TB, typename TC, int FM, bool EDGE>
+static void launch_fm(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
+    if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, FM, EDGE><<<grid, 256, 0, st>>>(g);
+    else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, FM, EDGE><<<grid, 256, 0, st>>>(g);
+    else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, FM, EDGE><<<grid, 256, 0, st>>>(g);
+    else gemm_kernel<TA, TB, TC, false, false, FM, EDGE><<<grid, 256, 0, st>>>(g);
+}
+
+// Tile choice: 256 x 128 tiles (FM = 4) halve the staged bytes and barriers per MFMA but also the number of workgroups; they are
+// used when the grid still has at least ~one workgroup per CU, otherwise 128 x 128 (FM = 2).  big = allowed for this dtype combo.
+static int pick_fm(const GemmArgs& g, int nbatch, bool big) {
+    static const int force = getenv("SARSSL_GEMM_FM") ? atoi(getenv("SARSSL_GEMM_FM")) : 0;        // A/B experiments only
+    if (!big) return 2;
+    if (force == 2 || force == 4) return force;
+    const long nsplit = g.split_k > 0 ? g.split_k : 1;
+    const long wg4 = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN) * nbatch * nsplit;
+    return (g.M >= 192 && wg4 >= (long)sarssl_cu_count() * 7 / 8) ? 4 : 2;
+}
+
+template <typename TA, typename TB, typename TC, bool BIG>
+static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, int nbatch, hipStream_t st) {
+    const int fm = pick_fm(g, nbatch, BIG);
+    const int bm = 64 * fm;
     const int k_len = g.split_k > 0 ? g.k_per_split : g.K;
-    const bool pf = k_len >= pf_mink || (k_len >= pf_mink / 2 && g.N <= 512);
-    if (pf) {
-        if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, true><<<grid, 256, 0, st>>>(g);
-        else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, true><<<grid, 256, 0, st>>>(g);
-        else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, true><<<grid, 256, 0, st>>>(g);
-        else gemm_kernel<TA, TB, TC, false, false, true><<<grid, 256, 0, st>>>(g);
-    } else {
-        if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, false><<<grid, 256, 0, st>>>(g);
-        else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, false><<<grid, 256, 0, st>>>(g);
-        else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, false><<<grid, 256, 0, st>>>(g);
-        else gemm_kernel<TA, TB, TC, false, false, false><<<grid, 256, 0, st>>>(g);
+    const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
+    const bool edge = (g.M % bm) != 0 || (g.N % BN) != 0 || (k_len % BK) != 0 || (g.K % BK) != 0 || !vec_ok;
+    dim3 grid((g.N + BN - 1) / BN, (g.M + bm - 1) / bm, nbatch * (g.split_k > 0 ? g.split_k : 1));
+    if constexpr (BIG) {
+        if (fm == 4) {
+            if (edge) launch_fm<TA, TB, TC, 4, true>(g, a_kc, b_kc, grid, st);
+            else launch_fm<TA, TB, TC, 4, false>(g, a_kc, b_kc, grid, st);
+            SARSSL_CHECK_LAUNCH("sarssl_gemm");
+            return 0;
+        }
     }
+    if (edge) launch_fm<TA, TB, TC, 2, true>(g, a_kc, b_kc, grid, st);
+    else launch_fm<TA, TB, TC, 2, false>(g, a_kc, b_kc, grid, st);
     SARSSL_CHECK_LAUNCH("sarssl_gemm");
     return 0;
 }
@@ -344,7 +387,6 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.resid = resid; g.ldr = ldr; g.sR0 = sR0; g.sR1 = sR1; g.res_scale = res_scale;
     g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
     g.p_drop = p_drop; g.seed = seed;
-    { const char* e = getenv("SARSSL_GEMM_DBG"); g.dbg = e ? atoi(e) : 0; }
     g.split_k = 0; g.k_per_split = K;
     if (split_k > 0) {
         // accumulate mode: C (f32) += alpha * A*B, no other epilogue; K split over split_k workgroups per tile, partials
@@ -355,7 +397,6 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
         int per = ((K + split_k - 1) / split_k + BK - 1) / BK * BK;
         g.split_k = (K + per - 1) / per; g.k_per_split = per;
     }
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch * (g.split_k > 0 ? g.split_k : 1));
     hipStream_t st = (hipStream_t)stream;
     auto reduce = [&]() -> int {
         const long mn = (long)M * N;
@@ -365,9 +406,9 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
         return 0;
     };
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_BF16)
-        return launch_layout<bf16, bf16, bf16>(g, a_kc, b_kc, grid, st);
+        return launch_layout<bf16, bf16, bf16, true>(g, a_kc, b_kc, nbatch, st);
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_F32) {
-        int rc = launch_layout<bf16, bf16, float>(g, a_kc, b_kc, grid, st);
+        int rc = launch_layout<bf16, bf16, float, true>(g, a_kc, b_kc, nbatch, st);
         if (rc || g.split_k <= 0) return rc;
         return reduce();
     }
@@ -377,21 +418,21 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
             const int npass = precise ? 3 : 1;
             for (int pass = 0; pass < npass; ++pass) {
                 p.partA = precise ? (pass == 1) : 0; p.partB = precise ? (pass == 0) : 0;      // hi*lo, lo*hi, hi*hi
-                int rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
+                int rc = launch_layout<float, float, float, false>(p, a_kc, b_kc, nbatch, st); if (rc) return rc;
                 rc = reduce(); if (rc) return rc;
             }
             return 0;
         }
-        if (!precise) return launch_layout<float, float, float>(g, a_kc, b_kc, grid, st);
+        if (!precise) return launch_layout<float, float, float, false>(g, a_kc, b_kc, nbatch, st);
         SARSSL_REQUIRE(ws != nullptr, "sarssl_gemm(precise needs workspace)");
         g.acc_ws = ws;
         GemmArgs p = g;
         p.partA = 0; p.partB = 1; p.acc_in = 0; p.acc_out = 1;          // hi*lo
-        int rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
+        int rc = launch_layout<float, float, float, false>(p, a_kc, b_kc, nbatch, st); if (rc) return rc;
         p.partA = 1; p.partB = 0; p.acc_in = 1; p.acc_out = 1;          // + lo*hi
-        rc = launch_layout<float, float, float>(p, a_kc, b_kc, grid, st); if (rc) return rc;
+        rc = launch_layout<float, float, float, false>(p, a_kc, b_kc, nbatch, st); if (rc) return rc;
         p.partA = 0; p.partB = 0; p.acc_in = 1; p.acc_out = 0;          // + hi*hi, then epilogue
-        return launch_layout<float, float, float>(p, a_kc, b_kc, grid, st);
+        return launch_layout<float, float, float, false>(p, a_kc, b_kc, nbatch, st);
     }
     sarssl_set_error("sarssl_gemm: unsupported dtype combination (%d,%d,%d)", dtA, dtB, dtC);
     return -1;

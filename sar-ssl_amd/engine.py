@@ -37,7 +37,7 @@ def mm_tn_acc(dy, x, gW):
     M, N = dy.shape
     K = x.shape[1]
     g2 = gW.view(N, K)
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    tiles = ((N + 255) // 256) * ((K + 127) // 128)                          # 256 x 128 output tiles (csrc/gemm.hip)
     split = max(1, min((M + 511) // 512, (512 + tiles - 1) // tiles))       # ~2 workgroups per CU, >= 8 K-tiles each
     split = max(1, min(split, (1 << 23) // (N * K)))                         # partial-sum workspace <= 32 MB (reduce pass cost)
     hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), out=g2, ldc=K,

@@ -56,6 +56,41 @@ def test_gemm_layouts(a_kc, b_kc, mode, M, N, K):
     assert err < tol, (mode, err)
 
 
+@pytest.mark.parametrize("a_kc,b_kc", LAYOUTS)
+@pytest.mark.parametrize("M,N,K,nbatch", [(4096, 1024, 256, 1), (512, 256, 128, 64), (520, 264, 200, 60)])
+def test_gemm_large_tiles_all_epilogues(a_kc, b_kc, M, N, K, nbatch):
+    """Grids large enough for the 256 x 128-tile instantiations (plain and ragged-edge): batched product with bias, Swish,
+    pre-activation side output, dropout, output scale and residual, in bf16 against an f64 reference of the same bf16 operands;
+    and the split-K accumulate path with f32 output."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    A = _mk((nbatch, M, K) if a_kc else (nbatch, K, M), torch.bfloat16, dev, 11)
+    B = _mk((nbatch, N, K) if b_kc else (nbatch, K, N), torch.bfloat16, dev, 12)
+    bias = _mk((N,), torch.float32, dev, 13)
+    R = _mk((nbatch, M, N), torch.bfloat16, dev, 14)
+    pre = torch.empty((nbatch, M, N), dtype=torch.bfloat16, device=dev)
+    kw = dict(a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, lda=A.shape[2], ldb=B.shape[2], nbatch=nbatch, sA=(A.shape[1] * A.shape[2], 0),
+              sB=(B.shape[1] * B.shape[2], 0), sC=(M * N, 0), sR=(M * N, 0))
+    Y = hip.gemm(A, B, bias=bias, act=2, preact=pre, p_drop=0.1, seed=77, out_scale=0.5, resid=R, ldr=N, res_scale=1.0, alpha=0.25,
+                 out_shape=(nbatch, M, N), **kw)
+    Af = A.double() if a_kc else A.double().transpose(1, 2)
+    Bf = B.double() if b_kc else B.double().transpose(1, 2)
+    h = 0.25 * torch.bmm(Af, Bf.transpose(1, 2)) + bias.double()
+    assert _relerr(pre, h) < 1e-2
+    Y0 = hip.gemm(A, B, bias=bias, act=2, out_scale=0.5, resid=R, ldr=N, res_scale=1.0, alpha=0.25, out_shape=(nbatch, M, N), **kw)
+    want0 = R.double() + 0.5 * h * torch.sigmoid(h)
+    assert _relerr(Y0, want0) < 1e-2
+    kept = (Y.float() - R.float()).abs() > 1e-3 * want0.abs().max().item()          # dropped elements are exactly the residual
+    keep = kept.float().mean().item()
+    assert 0.86 < keep < 0.94, keep
+    want = R.double() + 0.5 * (h * torch.sigmoid(h)) / 0.9
+    assert ((Y.double() - want).abs()[kept].max() / want.abs().max()).item() < 1.5e-2
+    if nbatch == 1:                                                    # split-K accumulate (weight-gradient form), f32 output
+        G = torch.ones((M, N), dtype=torch.float32, device=dev)
+        hip.gemm(A[0], B[0], a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, lda=A.shape[2], ldb=B.shape[2], out=G, ldc=N, split_k=3)
+        assert _relerr(G, 1.0 + torch.bmm(Af, Bf.transpose(1, 2))[0]) < 1e-5
+
+
 def test_gemm_epilogues_and_batch():
     from sar_ssl_amd import hip
     dev = _dev()

@@ -255,3 +255,28 @@ def test_f11_istft_and_pretrain_evaluate():
     _close(res["sig_tar"].reshape(-1)[sidx], z["eval.sig_tar"], 1e-4, 1e-6)
     for k in ("mse", "mse_mask", "mse_mask_ch"):
         assert abs(float(res[k]) / float(z["eval." + k]) - 1) < 2e-4, k
+
+
+def test_oracle_pretrain_epoch_vs_reference_pretrain_epoch():
+    """Fixture F12 (the reference's own ``Learner.pretrain_epoch``, two epochs x four batches): the oracle's restatement returns the
+    same per-epoch (loss, diff) and the same total parameter update - which a carried-over Adam state would change by 15 %."""
+    import random
+    from sar_ssl_amd import synth
+    z = np.load(os.path.join(GOLD, "f12_pretrain_epoch.npz"))
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    sd = recipes.recipe_state_dict(man, int(z["weight_seed"]))
+    init = {k: v.clone() for k, v in sd.items()}
+    B, nb = int(z["B"]), int(z["nbatch"])
+    pool = torch.from_numpy(synth.make_batch(int(z["sig_seed"]), B * nb))
+    batches = [pool[i * B:(i + 1) * B] for i in range(nb)]
+    torch.set_num_threads(8)
+    for e in (1, 2):
+        random.seed(int(z["mask_seed"][e - 1]))
+        loss, diff, pred = orc.pretrain_epoch(batches, sd, float(z["lr"][e - 1]), p_drop=0.0)
+        assert abs(loss / float(z["epoch%d.loss" % e]) - 1) < 2e-4, (e, loss)
+        assert abs(diff / float(z["epoch%d.diff" % e]) - 1) < 1e-6
+        assert tuple(pred.shape) == tuple(z["epoch%d.pred_shape" % e])
+    ref = json.loads(str(z["update_norm_json"]))
+    tot_ref = sum(v * v for v in ref.values()) ** 0.5
+    tot = sum(float((sd[k].double() - init[k].double()).norm()) ** 2 for k in ref) ** 0.5
+    assert abs(tot / tot_ref - 1) < 1e-3
