@@ -47,12 +47,28 @@ int sarssl_istft(const float* spec, int nb, int nch, int nt, int win_len, int ho
 
 /* ---- generic batched MFMA GEMM with fused epilogue: nn.Linear / Conv1d(k=1) / patch conv / attention bmm
  *      (code/common/conformer/modules.py:35-48, feed_forward.py:47-54, attention.py:82-103, convolution.py:138,143,
- *      code/model.py:63, 296-301).  See csrc/gemm.hip for the layout flags.  split_k > 0: C(f32) += alpha*A*B. */
+ *      code/model.py:63, 296-301).  See csrc/gemm.hip for the layout flags.  split_k > 0: C(f32) += alpha*A*B.
+ *      c_row_shift != 0 (M == N == ldc): row m of every batch matrix is stored m + 1 - N elements further, i.e. the product is
+ *      written directly in the layout of RelativeMultiHeadAttention._relative_shift (attention.py:105-113). */
 int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC, int a_kc, int b_kc, int M, int N, int K,
                 long lda, long ldb, long ldc, int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0,
                 long sC1, float alpha, float out_scale, const float* bias, int act, const void* resid, long ldr, long sR0,
                 long sR1, float res_scale, void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
-                int precise, float* ws, int split_k, void* stream);
+                int precise, float* ws, int split_k, int c_row_shift, void* stream);
+
+/* ---- fused relative-position attention, bf16 (RelativeMultiHeadAttention.forward, attention.py:87-101, and its backward):
+ *      softmax(((q+u) k^T + bias) * scale) -> dropout -> @ v per (batch, head) without materialising scores / probabilities.
+ *      qu, k, v: bf16 [B*T][ld], head h at column h*dh; bias: bf16 (B,H,T,T) = shifted positional score (a sarssl_gemm with
+ *      c_row_shift), element (i, i+1) ignored; ctx: bf16 [B*T][ldc]; lse: f32 (B,H,T).  sarssl_relpos_attn_supported: shapes the
+ *      fused kernels take (T % 8 == 0, dh in {32, 64, 128}); otherwise use the GEMM + sarssl_softmax_relshift_fwd path.
+ *      Backward: dsum = f32 (B,H,T) workspace; dbias bf16 (B,H,T,T) in the shifted layout (feed sarssl_relshift_bwd). */
+int sarssl_relpos_attn_supported(int T, int dh);
+int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, void* ctx, long ldc,
+                           float* lse, int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed, void* stream);
+int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, const void* ctx,
+                           long ldc, const float* lse, const void* dctx, long lddc, void* dqu, long lddq, void* dk, void* dv,
+                           long lddk, void* dbias, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,
+                           unsigned long long seed, void* stream);
 
 /* ---- CNN stem, channels-last (B,F,T,C): code/model.py:50-64 (patch_embed), masking code/model.py:533-564 */
 int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn, int mode, void* spec,

@@ -1,0 +1,614 @@
+// Fused relative-position multi-head self-attention for gfx950 (bf16 storage, f32 softmax / accumulation).
+//
+// Replaces, per (batch, head), the reference's  score = ((q+u) k^T + shift((q+v) p^T)) / sqrt(d_model);  softmax;  dropout;  @ v
+// (code/common/conformer/attention.py:87-101) without ever writing a (B, H, T, T) score / probability tensor:
+//   * the shifted positional score `bias` (B,H,T,T) is produced by the positional-score GEMM, whose epilogue writes every raw row r
+//     at the constant offset r + 1 - T - the reference's pad-and-reshape trick (attention.py:105-113) is exactly that row-dependent
+//     shift of the flat layout; the element (i, i+1) it leaves unwritten is the zero of the padding column and is masked here;
+//   * forward: flash-style online softmax over 64-key tiles, one workgroup per (batch, head, 128 query rows), one wave per 32
+//     rows.  S^T = K Q^T is computed with the operands swapped so that a lane owns ONE query row (row max / sum are lane-local plus
+//     one exchange with the partner half-wave); P goes back to the matrix cores through v_cvt_pk_bf16_f32 + v_permlane32_swap
+//     (no LDS round trip); V is consumed with the transpose read ds_read_b64_tr_b16;
+//   * backward recomputes the probabilities from the saved log-sum-exp: one kernel per query tile for dQ and d(bias), one per key
+//     tile for dK and dV (no atomics, deterministic).
+// Dropout uses the library's counter hash on the element index ((b*H + h)*T + i)*T + j, recomputed identically in backward.
+#include "common.h"
+
+struct AttnArgs {
+    const bf16* qu; long ldq;          // [B*T][ldq]: q + u_bias, head h at column h*DH
+    const bf16* k; const bf16* v; long ldk;
+    const bf16* bias;                  // (B,H,T,T) shifted positional score (unscaled)
+    bf16* ctx; long ldc;               // [B*T][ldc]
+    float* lse;                        // (B,H,T): log2-domain log-sum-exp of the scaled scores
+    const bf16* dctx; long lddc;       // backward: gradient of ctx
+    bf16* dqu; long lddq;              // backward outputs
+    bf16* dk; bf16* dv; long lddk;
+    bf16* dbias;                       // (B,H,T,T): gradient of the shifted positional score
+    float* dsum;                       // (B,H,T): sum_c dctx * ctx
+    int B, H, T;
+    float scale, p_drop; unsigned long long seed;
+};
+
+#define LOG2E 1.4426950408889634f
+
+template <int PT>
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int kbase, int r0, int lane) {      // as gemm.hip: [k][row] tile
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const int col = r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    union { s16x4 v[2]; bf16x8 b; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = kbase + (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
+        u.v[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + k * PT + col));
+    }
+    return u.b;
+}
+
+// Accumulator fragment (lane = row, 16 values = columns 8g + 4*half + e of a 32-column block) -> the two MFMA operand fragments
+// (8 consecutive columns at offset half*8 of each 16-column step) of the same 32 columns, in bf16.
+__device__ __forceinline__ void acc_to_operand(const f32x16& p, bf16x8 (&out)[2]) {
+    uint32_t w[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        w[g][0] = pack2_bf16(p[4 * g + 0], p[4 * g + 1]);
+        w[g][1] = pack2_bf16(p[4 * g + 2], p[4 * g + 3]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        union { uint32_t u[4]; bf16x8 b; } f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            // upper half-wave of w[2s] <-> lower half-wave of w[2s+1]
+            auto r = __builtin_amdgcn_permlane32_swap(w[2 * s][x], w[2 * s + 1][x], false, false);
+            f.u[x] = r[0];
+            f.u[2 + x] = r[1];
+        }
+        out[s] = f.b;
+    }
+}
+
+__device__ __forceinline__ float half_swap_f(float v) { return __shfl_xor(v, 32, 64); }
+
+// keep-scale of attention probability (bh, i, j)
+__device__ __forceinline__ float attn_keep(const AttnArgs& a, unsigned long long rowbase, int j, float inv_keep) {
+    return dropout_scale(a.seed, rowbase + (unsigned long long)j, a.p_drop, inv_keep);
+}
+
+// ------------------------------------------------------------------------------------------------------------------- forward
+template <int DH>
+__global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(AttnArgs a) {
+    constexpr int TQ = 128, TK = 64;
+    constexpr int PK = DH + 8, PV = DH + 32, PB = TK + 8;
+    constexpr int CPR = DH / 8;                               // 16-byte chunks per K / V row
+    __shared__ __attribute__((aligned(16))) uint16_t smem[TK * PK + TK * PV + TQ * PB];
+    uint16_t* sK = smem;
+    uint16_t* sV = sK + TK * PK;
+    uint16_t* sB = sV + TK * PV;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H, T = a.T;
+    const int i0 = blockIdx.x * TQ;
+    const int i = i0 + wave * 32 + (lane & 31);               // this lane's query row
+    const bool row_ok = i < T;
+    const bf16* K = a.k + (long)b * T * a.ldk + h * DH;
+    const bf16* V = a.v + (long)b * T * a.ldk + h * DH;
+    const bf16* Bi = a.bias + (long)bh * T * T;
+    bf16x8 fq[DH / 16];
+    {
+        const bf16* q = a.qu + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) {
+            uint4 u = row_ok ? *(const uint4*)(q + s * 16) : make_uint4(0, 0, 0, 0);
+            fq[s] = __builtin_bit_cast(bf16x8, u);
+        }
+    }
+    f32x16 o[DH / 32];
+#pragma unroll
+    for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = a.scale * LOG2E;
+    const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned long long)(row_ok ? i : 0)) * (unsigned long long)T;
+
+    // K, V (64 keys x DH) and the bias tile (128 rows x 64 keys) go through registers: the next tile's loads are in flight while
+    // this one is on the matrix cores
+    constexpr int NKV = TK * CPR / 256, NBI = TQ * (TK / 8) / 256;
+    uint4 rk[NKV], rv[NKV], rbi[NBI];
+    auto load_tile = [&](int j0) {
+#pragma unroll
+        for (int c = 0; c < NKV; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            rk[c] = make_uint4(0, 0, 0, 0); rv[c] = rk[c];
+            if (j0 + row < T) {
+                rk[c] = *(const uint4*)(K + (long)(j0 + row) * a.ldk + c8 * 8);
+                rv[c] = *(const uint4*)(V + (long)(j0 + row) * a.ldk + c8 * 8);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NBI; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+            rbi[c] = make_uint4(0, 0, 0, 0);
+            if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
+        }
+    };
+    load_tile(0);
+    for (int j0 = 0; j0 < T; j0 += TK) {
+#pragma unroll
+        for (int c = 0; c < NKV; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            *(uint4*)&sK[row * PK + c8 * 8] = rk[c];
+            *(uint4*)&sV[row * PV + c8 * 8] = rv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NBI; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+            *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
+        }
+        __syncthreads();
+        if (j0 + TK < T) load_tile(j0 + TK);
+        // ---- S^T = K Q^T: lane = query row, registers = keys
+        f32x16 s[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < DH / 16; ++st)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const bf16x8 kf = *(const bf16x8*)&sK[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, fq[st], s[f], 0, 0, 0);
+            }
+        // ---- scores in the log2 domain, masks, running max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jl = f * 32 + 8 * g + 4 * half;
+                const uint2 bu = *(const uint2*)&sB[(wave * 32 + (lane & 31)) * PB + jl];
+                const float bv[4] = {bf16_bits_to_f32(bu.x & 0xffffu), __uint_as_float(bu.x & 0xffff0000u),
+                                     bf16_bits_to_f32(bu.y & 0xffffu), __uint_as_float(bu.y & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = j0 + jl + e;
+                    float x = (s[f][4 * g + e] + (j == i + 1 ? 0.f : bv[e])) * sc2;
+                    x = j < T ? x : -INFINITY;
+                    s[f][4 * g + e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+        mx = fmaxf(mx, half_swap_f(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[f][r] - m_new);
+                rs += p;
+                s[f][r] = p;
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] *= alpha;
+        if (a.p_drop > 0.f) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0 + f * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    s[f][r] *= attn_keep(a, rowbase, j, inv_keep);
+                }
+        }
+        // ---- O^T += V^T P^T: lane = query row, registers = head channels
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            bf16x8 pf[2];
+            acc_to_operand(s[f], pf);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int c = 0; c < DH / 32; ++c) {
+                    const bf16x8 vf = tr_frag<PV>(sV, f * 32 + st * 16, c * 32, lane);
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o[c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    const float l_tot = l_run + half_swap_f(l_run);
+    const float inv_l = 1.0f / l_tot;
+    if (row_ok) {
+        if (half == 0 && a.lse) a.lse[(long)bh * T + i] = m_run + log2f(l_tot);
+        bf16* out = a.ctx + ((long)b * T + i) * a.ldc + h * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = pack2_bf16(o[c][4 * g + 0] * inv_l, o[c][4 * g + 1] * inv_l);
+                u.y = pack2_bf16(o[c][4 * g + 2] * inv_l, o[c][4 * g + 3] * inv_l);
+                *(uint2*)(out + c * 32 + 8 * g + 4 * half) = u;
+            }
+    }
+}
+
+// --------------------------------------------------------------------------------------------- backward, part 0: D_i = dctx_i . ctx_i
+__global__ void relpos_attn_dsum_kernel(AttnArgs a, int dh) {
+    // one wave per (b, i, h) row slice
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);          // over B*T*H
+    const int lane = threadIdx.x & 63;
+    const long nrow = (long)a.B * a.T * a.H;
+    if (row >= nrow) return;
+    const long bt = row / a.H; const int h = (int)(row % a.H);
+    const bf16* x = a.dctx + bt * a.lddc + h * dh;
+    const bf16* y = a.ctx + bt * a.ldc + h * dh;
+    float s = 0.f;
+    for (int c = lane; c < dh; c += 64) s += ld_f(x + c) * ld_f(y + c);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const long b = bt / a.T, i = bt % a.T;
+        a.dsum[(b * a.H + h) * a.T + i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------- backward, part 1: dQ and d(bias), per query tile
+template <int DH>
+__global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(AttnArgs a) {
+    constexpr int TQ = 128, TK = 64;
+    constexpr int PK = DH + 8, PT = DH + 32, PB = TK + 8;
+    constexpr int CPR = DH / 8;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TK * PK + TK * PT + TQ * PB];
+    uint16_t* sK = smem;                 // [key][c]  (b128 fragment reads: S)
+    uint16_t* sV = sK + TK * PK;         // [key][c]  (dP)
+    uint16_t* sKt = sV + TK * PK;        // [key][c] with the transpose-read pitch (dQ += dS K)
+    uint16_t* sB = sKt + TK * PT;        // bias tile in, d(bias) tile out
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H, T = a.T;
+    const int i0 = blockIdx.x * TQ;
+    const int i = i0 + wave * 32 + (lane & 31);
+    const bool row_ok = i < T;
+    const bf16* K = a.k + (long)b * T * a.ldk + h * DH;
+    const bf16* V = a.v + (long)b * T * a.ldk + h * DH;
+    const bf16* Bi = a.bias + (long)bh * T * T;
+    bf16* dBi = a.dbias + (long)bh * T * T;
+    bf16x8 fq[DH / 16], fdo[DH / 16];
+    {
+        const bf16* q = a.qu + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
+        const bf16* d = a.dctx + ((long)b * T + (row_ok ? i : 0)) * a.lddc + h * DH + half * 8;
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) {
+            fq[s] = __builtin_bit_cast(bf16x8, row_ok ? *(const uint4*)(q + s * 16) : make_uint4(0, 0, 0, 0));
+            fdo[s] = __builtin_bit_cast(bf16x8, row_ok ? *(const uint4*)(d + s * 16) : make_uint4(0, 0, 0, 0));
+        }
+    }
+    const float lse = row_ok ? a.lse[(long)bh * T + i] : 0.f;
+    const float dsum = row_ok ? a.dsum[(long)bh * T + i] : 0.f;
+    f32x16 dq[DH / 32];
+#pragma unroll
+    for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[c][r] = 0.f;
+    const float sc2 = a.scale * LOG2E;
+    const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned long long)(row_ok ? i : 0)) * (unsigned long long)T;
+
+    constexpr int NKV = TK * CPR / 256, NBI = TQ * (TK / 8) / 256;
+    uint4 rk[NKV], rv[NKV], rbi[NBI];
+    auto load_tile = [&](int j0) {
+#pragma unroll
+        for (int c = 0; c < NKV; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            rk[c] = make_uint4(0, 0, 0, 0); rv[c] = rk[c];
+            if (j0 + row < T) {
+                rk[c] = *(const uint4*)(K + (long)(j0 + row) * a.ldk + c8 * 8);
+                rv[c] = *(const uint4*)(V + (long)(j0 + row) * a.ldk + c8 * 8);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NBI; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+            rbi[c] = make_uint4(0, 0, 0, 0);
+            if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
+        }
+    };
+    load_tile(0);
+    for (int j0 = 0; j0 < T; j0 += TK) {
+#pragma unroll
+        for (int c = 0; c < NKV; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            *(uint4*)&sK[row * PK + c8 * 8] = rk[c];
+            *(uint4*)&sKt[row * PT + c8 * 8] = rk[c];
+            *(uint4*)&sV[row * PK + c8 * 8] = rv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NBI; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+            *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
+        }
+        __syncthreads();
+        if (j0 + TK < T) load_tile(j0 + TK);
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[f][r] = 0.f; dp[f][r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < DH / 16; ++st)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const bf16x8 kf = *(const bf16x8*)&sK[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                const bf16x8 vf = *(const bf16x8*)&sV[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, fq[st], s[f], 0, 0, 0);
+                dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, fdo[st], dp[f], 0, 0, 0);
+            }
+        // dScore = scale * p * (keep * dP - D)   (lane = query row, registers = keys); staged to LDS as the d(bias) tile
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jl = f * 32 + 8 * g + 4 * half;
+                uint16_t* bp = &sB[(wave * 32 + (lane & 31)) * PB + jl];
+                const uint2 bu = *(const uint2*)bp;
+                const float bv[4] = {bf16_bits_to_f32(bu.x & 0xffffu), __uint_as_float(bu.x & 0xffff0000u),
+                                     bf16_bits_to_f32(bu.y & 0xffffu), __uint_as_float(bu.y & 0xffff0000u)};
+                float ds[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = j0 + jl + e;
+                    const float x = (s[f][4 * g + e] + (j == i + 1 ? 0.f : bv[e])) * sc2;
+                    const float p = j < T ? exp2f(x - lse) : 0.f;
+                    const float keep = a.p_drop > 0.f ? attn_keep(a, rowbase, j, inv_keep) : 1.0f;
+                    ds[e] = a.scale * p * (keep * dp[f][4 * g + e] - dsum);
+                    s[f][4 * g + e] = ds[e];
+                }
+                uint2 ou;
+                ou.x = pack2_bf16(ds[0], ds[1]);
+                ou.y = pack2_bf16(ds[2], ds[3]);
+                *(uint2*)bp = ou;                              // each lane overwrites exactly the 4 bias values it has just read
+            }
+        // dQ^T += K^T dS^T
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            bf16x8 pf[2];
+            acc_to_operand(s[f], pf);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int c = 0; c < DH / 32; ++c) {
+                    const bf16x8 kf = tr_frag<PT>(sKt, f * 32 + st * 16, c * 32, lane);
+                    dq[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, pf[st], dq[c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        // d(bias) tile -> global, 16-byte row pieces (the element (i, i+1) is the padding zero of the shift: its gradient is dropped
+        // by the consumer, which never reads it back through the shifted addressing)
+#pragma unroll
+        for (int c = 0; c < TQ * (TK / 8) / 256; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+            if (i0 + row < T && j0 + c8 * 8 < T) *(uint4*)(dBi + (long)(i0 + row) * T + j0 + c8 * 8) = *(const uint4*)&sB[row * PB + c8 * 8];
+        }
+        __syncthreads();
+    }
+    if (row_ok) {
+        bf16* out = a.dqu + ((long)b * T + i) * a.lddq + h * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = pack2_bf16(dq[c][4 * g + 0], dq[c][4 * g + 1]);
+                u.y = pack2_bf16(dq[c][4 * g + 2], dq[c][4 * g + 3]);
+                *(uint2*)(out + c * 32 + 8 * g + 4 * half) = u;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------- backward, part 2: dK and dV, per key tile
+// One workgroup per (batch, head, 128 keys), one wave per 32 keys; loops over 64-query tiles.  Lane = key row.
+template <int DH>
+__global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
+    constexpr int TKB = 128, TQ = 64;
+    constexpr int PK = DH + 8, PT = DH + 32, PB = TKB + 8;
+    constexpr int CPR = DH / 8;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TQ * PK + 2 * TQ * PT + TQ * PB];
+    __shared__ float sStat[2 * TQ];
+    uint16_t* sQ = smem;                 // [query][c]  b128 reads (S^T)
+    uint16_t* sDO = sQ + TQ * PK;        // [query][c]  b128 reads (dP^T)
+    uint16_t* sQt = sDO + TQ * PK;       // transpose-read copies (dK += dS^T Q, dV += P^T dO)
+    uint16_t* sDOt = sQt + TQ * PT;
+    uint16_t* sB = sDOt + TQ * PT;       // bias tile [query][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H, T = a.T;
+    const int j0 = blockIdx.x * TKB;
+    const int j = j0 + wave * 32 + (lane & 31);                // this lane's key row
+    const bool key_ok = j < T;
+    const bf16* Q = a.qu + (long)b * T * a.ldq + h * DH;
+    const bf16* DO = a.dctx + (long)b * T * a.lddc + h * DH;
+    const bf16* Bi = a.bias + (long)bh * T * T;
+    bf16x8 fk[DH / 16], fv[DH / 16];
+    {
+        const bf16* kp = a.k + ((long)b * T + (key_ok ? j : 0)) * a.ldk + h * DH + half * 8;
+        const bf16* vp = a.v + ((long)b * T + (key_ok ? j : 0)) * a.ldk + h * DH + half * 8;
+#pragma unroll
+        for (int s = 0; s < DH / 16; ++s) {
+            fk[s] = __builtin_bit_cast(bf16x8, key_ok ? *(const uint4*)(kp + s * 16) : make_uint4(0, 0, 0, 0));
+            fv[s] = __builtin_bit_cast(bf16x8, key_ok ? *(const uint4*)(vp + s * 16) : make_uint4(0, 0, 0, 0));
+        }
+    }
+    f32x16 dk[DH / 32], dv[DH / 32];
+#pragma unroll
+    for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[c][r] = 0.f; dv[c][r] = 0.f; }
+    const float sc2 = a.scale * LOG2E;
+    const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+
+    constexpr int NQD = TQ * CPR / 256, NBI = TQ * (TKB / 8) / 256;
+    uint4 rq[NQD], rd[NQD], rbi[NBI];
+    float rstat = 0.f;
+    auto load_tile = [&](int i0) {
+#pragma unroll
+        for (int c = 0; c < NQD; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            rq[c] = make_uint4(0, 0, 0, 0); rd[c] = rq[c];
+            if (i0 + row < T) {
+                rq[c] = *(const uint4*)(Q + (long)(i0 + row) * a.ldq + c8 * 8);
+                rd[c] = *(const uint4*)(DO + (long)(i0 + row) * a.lddc + c8 * 8);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NBI; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 4, c8 = cid & 15;
+            rbi[c] = make_uint4(0, 0, 0, 0);
+            if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
+        }
+        rstat = 0.f;
+        if (tid < 2 * TQ) {
+            const int il = tid & (TQ - 1);
+            if (i0 + il < T) rstat = tid < TQ ? a.lse[(long)bh * T + i0 + il] : a.dsum[(long)bh * T + i0 + il];
+        }
+    };
+    load_tile(0);
+    for (int i0 = 0; i0 < T; i0 += TQ) {
+#pragma unroll
+        for (int c = 0; c < NQD; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            *(uint4*)&sQ[row * PK + c8 * 8] = rq[c];
+            *(uint4*)&sQt[row * PT + c8 * 8] = rq[c];
+            *(uint4*)&sDO[row * PK + c8 * 8] = rd[c];
+            *(uint4*)&sDOt[row * PT + c8 * 8] = rd[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NBI; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 4, c8 = cid & 15;
+            *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
+        }
+        if (tid < 2 * TQ) sStat[tid] = rstat;
+        __syncthreads();
+        if (i0 + TQ < T) load_tile(i0 + TQ);
+        // S = Q K^T and dP = dO V^T with lane = key, registers = queries
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[f][r] = 0.f; dp[f][r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < DH / 16; ++st)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const bf16x8 qf = *(const bf16x8*)&sQ[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                const bf16x8 df = *(const bf16x8*)&sDO[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, fk[st], s[f], 0, 0, 0);
+                dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, fv[st], dp[f], 0, 0, 0);
+            }
+        // P (dropped, for dV) -> dp registers are reused for it after dS has been formed in s
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = f * 32 + 8 * (r >> 2) + 4 * half + (r & 3);     // query row inside the tile
+                const int i = i0 + il;
+                const float bv = bf16_bits_to_f32(sB[il * PB + wave * 32 + (lane & 31)]);
+                const float x = (s[f][r] + (j == i + 1 ? 0.f : bv)) * sc2;
+                const float p = (i < T && key_ok) ? exp2f(x - sStat[il]) : 0.f;
+                float keep = 1.0f;
+                if (a.p_drop > 0.f)
+                    keep = dropout_scale(a.seed, ((unsigned long long)bh * T + (unsigned long long)(i < T ? i : 0)) * (unsigned long long)T + (unsigned long long)(key_ok ? j : 0),
+                                         a.p_drop, inv_keep);
+                s[f][r] = a.scale * p * (keep * dp[f][r] - sStat[TQ + il]);       // dScore^T
+                dp[f][r] = p * keep;                                               // dropped probability
+            }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            bf16x8 sf[2], pf[2];
+            acc_to_operand(s[f], sf);
+            acc_to_operand(dp[f], pf);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int c = 0; c < DH / 32; ++c) {
+                    const bf16x8 qf = tr_frag<PT>(sQt, f * 32 + st * 16, c * 32, lane);
+                    const bf16x8 df = tr_frag<PT>(sDOt, f * 32 + st * 16, c * 32, lane);
+                    dk[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, sf[st], dk[c], 0, 0, 0);
+                    dv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, pf[st], dv[c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    if (key_ok) {
+        bf16* ok_ = a.dk + ((long)b * T + j) * a.lddk + h * DH;
+        bf16* ov_ = a.dv + ((long)b * T + j) * a.lddk + h * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u, w;
+                u.x = pack2_bf16(dk[c][4 * g + 0], dk[c][4 * g + 1]); u.y = pack2_bf16(dk[c][4 * g + 2], dk[c][4 * g + 3]);
+                w.x = pack2_bf16(dv[c][4 * g + 0], dv[c][4 * g + 1]); w.y = pack2_bf16(dv[c][4 * g + 2], dv[c][4 * g + 3]);
+                *(uint2*)(ok_ + c * 32 + 8 * g + 4 * half) = u;
+                *(uint2*)(ov_ + c * 32 + 8 * g + 4 * half) = w;
+            }
+    }
+}
+
+// C ABI ----------------------------------------------------------------------------------------------------------------------
+static int attn_check(int B, int H, int T, int dh, long ldq, long ldk, const char* name) {
+    if (!(B > 0 && H > 0 && T > 0 && (dh == 32 || dh == 64 || dh == 128) && T % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0)) {
+        sarssl_set_error("%s: unsupported shape (B=%d H=%d T=%d dh=%d): needs dh in {32,64,128}, T %% 8 == 0, 16-byte aligned rows",
+                         name, B, H, T, dh);
+        return -1;
+    }
+    return 0;
+}
+
+// 1 when sarssl_relpos_attn_{fwd,bwd} support the shape (the caller otherwise uses the unfused GEMM + softmax path).
+extern "C" int sarssl_relpos_attn_supported(int T, int dh) { return (T > 0 && T % 8 == 0 && (dh == 32 || dh == 64 || dh == 128)) ? 1 : 0; }
+
+// qu, k, v: bf16 [B*T][ld] with head h at column h*dh; bias: bf16 (B,H,T,T) shifted positional scores (unscaled);
+// ctx: bf16 [B*T][ldc]; lse: f32 (B,H,T) (log2 domain, saved for backward).
+extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, void* ctx,
+                                      long ldc, float* lse, int B, int H, int T, int dh, float scale, float p_drop,
+                                      unsigned long long seed, void* stream) {
+    if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_fwd")) return -1;
+    SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr, "sarssl_relpos_attn_fwd");
+    AttnArgs a = {};
+    a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
+    a.ctx = (bf16*)ctx; a.ldc = ldc; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    dim3 grid((T + 127) / 128, B * H);
+    hipStream_t st = (hipStream_t)stream;
+    if (dh == 128) relpos_attn_fwd_kernel<128><<<grid, 256, 0, st>>>(a);
+    else if (dh == 64) relpos_attn_fwd_kernel<64><<<grid, 256, 0, st>>>(a);
+    else relpos_attn_fwd_kernel<32><<<grid, 256, 0, st>>>(a);
+    SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel");
+    return 0;
+}
+
+// Backward of sarssl_relpos_attn_fwd.  dsum: f32 workspace (B,H,T).  Outputs: dqu [B*T][lddq], dk / dv [B*T][lddk] (head h at
+// column h*dh), dbias bf16 (B,H,T,T) = gradient of the shifted positional score (the element (i, i+1) carries no meaning).
+extern "C" int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias,
+                                      const void* ctx, long ldc, const float* lse, const void* dctx, long lddc, void* dqu, long lddq,
+                                      void* dk, void* dv, long lddk, void* dbias, float* dsum, int B, int H, int T, int dh,
+                                      float scale, float p_drop, unsigned long long seed, void* stream) {
+    if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_bwd")) return -1;
+    SARSSL_REQUIRE(lddc % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && dsum != nullptr && lse != nullptr, "sarssl_relpos_attn_bwd");
+    AttnArgs a = {};
+    a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
+    a.ctx = (bf16*)ctx; a.ldc = ldc; a.lse = (float*)lse; a.dctx = (const bf16*)dctx; a.lddc = lddc;
+    a.dqu = (bf16*)dqu; a.lddq = lddq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddk = lddk; a.dbias = (bf16*)dbias; a.dsum = dsum;
+    a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    hipStream_t st = (hipStream_t)stream;
+    const long nrow = (long)B * T * H;
+    relpos_attn_dsum_kernel<<<(unsigned)((nrow + 3) / 4), 256, 0, st>>>(a, dh);
+    dim3 gq((T + 127) / 128, B * H), gk((T + 127) / 128, B * H);
+    if (dh == 128) { relpos_attn_bwd_q_kernel<128><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<128><<<gk, 256, 0, st>>>(a); }
+    else if (dh == 64) { relpos_attn_bwd_q_kernel<64><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<64><<<gk, 256, 0, st>>>(a); }
+    else { relpos_attn_bwd_q_kernel<32><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<32><<<gk, 256, 0, st>>>(a); }
+    SARSSL_CHECK_LAUNCH("relpos_attn_bwd_kernel");
+    return 0;
+}

@@ -49,6 +49,9 @@ struct GemmArgs {
     int partA, partB;
     float p_drop; unsigned long long seed;
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
+    int row_shift;              // != 0 (= T, with M = N = ldc = T): row m of every batch matrix is stored m + 1 - T elements further
+                                // (elements falling before the matrix are dropped): the relative-position shift of the reference
+                                // (attention.py:105-113: pad one zero column, reinterpret (T, T+1) as (T+1, T), drop the first row)
 };
 
 template <typename T>
@@ -103,7 +106,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
 template <typename TC, bool EDGE>
 __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m, int n, TC* __restrict__ C, const TC* __restrict__ Rz,
                                           TC* __restrict__ P, const TC* __restrict__ Xa, float* __restrict__ W, float* __restrict__ Wp,
-                                          const float (&bias8)[8], bool vec_ok, float inv_keep) {
+                                          const float (&bias8)[8], bool vec_ok, float inv_keep, const f8* pre) {
     const int nvalid = EDGE ? min(8, g.N - n) : 8;
     const bool vec = EDGE ? (vec_ok && nvalid == 8) : true;
     if (g.split_k > 0) {                                 // raw partial for the split-K second stage
@@ -148,7 +151,8 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m,
     }
     if (Xa) {                                            // dX epilogue: times act'(saved pre-activation)
         f8 h;
-        if (vec) h = ld8(Xa + co);
+        if (pre) h = *pre;
+        else if (vec) h = ld8(Xa + co);
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) h.v[e] = (e < nvalid) ? ld_f(Xa + co + e) : 0.f;
@@ -172,13 +176,19 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m,
     if (Rz) {
         const long ro = (long)m * g.ldr + n;
         if (vec) {
-            const f8 rr = ld8(Rz + ro);
+            const f8 rr = pre ? *pre : ld8(Rz + ro);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] += g.res_scale * rr.v[e];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (e < nvalid) v.v[e] += g.res_scale * ld_f(Rz + ro + e);
         }
+    }
+    if (EDGE && g.row_shift) {
+        const long d0 = co + (m + 1 - g.row_shift);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid && d0 + e >= 0) st_f(C + d0 + e, v.v[e]);
+        return;
     }
     if (vec) st8(C + co, v);
     else {
@@ -234,6 +244,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // epilogue operands that do not depend on the accumulators are requested early: a thread keeps the same 8 output columns in
+    // every epilogue slice, so its 8 bias values are loaded here, behind the whole K loop
+    const int ch = tid & 15, n = n0 + ch * 8;
+    float bias8[8];
+    if (g.bias && (!EDGE || n + 8 <= g.N)) {
+        const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[e] = (g.bias && n + e < g.N) ? g.bias[n + e] : 0.f;
+    }
+
     uint4 ra[BM / 32], rb[BN / 32];
     tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
     tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
@@ -246,10 +268,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
             tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
             tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
         }
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        // MFMA phase, software-pipelined by hand: the fragments of k-step kk+1 are read from LDS BEFORE the MFMAs of step kk are
+        // issued (two register sets).  Left alone, hipcc sinks every ds_read next to its first use ("2 reads, wait, 2 MFMAs"), so the
+        // matrix pipe idles for one LDS round trip per pair of MFMAs; the sched_barriers pin the order.
+        auto load_frags = [&](int kk, bf16x8 (&fa)[FM], bf16x8 (&fb)[2]) {
             const int koff = kk * 16 + (lane >> 5) * 8;
-            bf16x8 fa[FM], fb[2];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 if (AKC) fa[i] = *(const bf16x8*)&sA[(wm * (FM * 32) + i * 32 + (lane & 31)) * PITCH + koff];
@@ -260,11 +283,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
                 if (BKC) fb[j] = *(const bf16x8*)&sB[(wn * 64 + j * 32 + (lane & 31)) * PITCH + koff];
                 else fb[j] = frag_tr<PTB>(sB, kk * 16, wn * 64 + j * 32, lane);
             }
+        };
+        auto mfmas = [&](const bf16x8 (&fa)[FM], const bf16x8 (&fb)[2]) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        };
+        bf16x8 fa0[FM], fb0[2], fa1[FM], fb1[2];
+        load_frags(0, fa0, fb0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; kk += 2) {
+            load_frags(kk + 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < BK / 16) load_frags(kk + 2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -283,10 +321,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
     const float inv_keep = g.p_drop > 0.f ? 1.0f / (1.0f - g.p_drop) : 1.0f;
     float* sC = (float*)smem;
-    const int ch = tid & 15, n = n0 + ch * 8;
-    float bias8[8];
+    // residual (forward GEMMs) or saved pre-activation (activation-backward GEMMs) rows of a slice are requested one slice ahead, so
+    // their latency hides behind the LDS transposition and the arithmetic of the previous slice instead of stalling every tile
+    const TC* Ex = (!EDGE && g.split_k <= 0 && !g.acc_out) ? (Rz && !Xa ? Rz : (Xa && !Rz ? Xa : nullptr)) : nullptr;
+    const long ldex = (Ex == Rz) ? g.ldr : g.ldc;
+    f8 ex[4], exn[4];
+    auto load_ex = [&](int i, f8 (&dst)[4]) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = (g.bias && (!EDGE || n + e < g.N)) ? g.bias[n + e] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const int r = (tid >> 4) + 16 * k;
+            const int m = m0 + (r >> 5) * (FM * 32) + i * 32 + (r & 31);
+            dst[k] = ld8(Ex + (long)m * ldex + n);
+        }
+    };
+    if (Ex) load_ex(0, exn);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -295,6 +343,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
             for (int gq = 0; gq < 4; ++gq)
                 *(float4*)&sC[(wm * 32 + (lane & 31)) * PC + wn * 64 + j * 32 + 8 * gq + 4 * (lane >> 5)] =
                     make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
+        if (Ex) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ex[k] = exn[k];
+            if (i + 1 < FM) load_ex(i + 1, exn);
+        }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -305,7 +358,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
             const float4 a0 = *(const float4*)&sC[r * PC + ch * 8], a1 = *(const float4*)&sC[r * PC + ch * 8 + 4];
             v.v[0] = g.alpha * a0.x; v.v[1] = g.alpha * a0.y; v.v[2] = g.alpha * a0.z; v.v[3] = g.alpha * a0.w;
             v.v[4] = g.alpha * a1.x; v.v[5] = g.alpha * a1.y; v.v[6] = g.alpha * a1.z; v.v[7] = g.alpha * a1.w;
-            epilogue8<TC, EDGE>(g, v, z, m, n, C, Rz, P, Xa, W, Wp, bias8, vec_ok, inv_keep);
+            epilogue8<TC, EDGE>(g, v, z, m, n, C, Rz, P, Xa, W, Wp, bias8, vec_ok, inv_keep, Ex ? &ex[k] : nullptr);
         }
         if (i + 1 < FM) __syncthreads();
     }
@@ -342,7 +395,10 @@ static int pick_fm(const GemmArgs& g, int nbatch, bool big) {
     if (force == 2 || force == 4) return force;
     const long nsplit = g.split_k > 0 ? g.split_k : 1;
     const long wg4 = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN) * nbatch * nsplit;
-    return (g.M >= 192 && wg4 >= (long)sarssl_cu_count() * 7 / 8) ? 4 : 2;
+    const int k_len = g.split_k > 0 ? g.k_per_split : g.K;
+    // measured on MI355X (tools/bench_kernels.py, tools/gemm_diag.py, M = 16384): the large tile wins from ~2 workgroups per CU and
+    // K >= 768 on (decoder 3072 x 768 / 1024 x 3072: -4 ... -15 %); with one workgroup per CU (N = 512) or short K it loses 5-20 %
+    return (g.M >= 192 && k_len >= 768 && wg4 >= 2L * sarssl_cu_count()) ? 4 : 2;
 }
 
 template <typename TA, typename TB, typename TC, bool BIG>
@@ -351,7 +407,7 @@ static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, int nbatch, hipS
     const int bm = 64 * fm;
     const int k_len = g.split_k > 0 ? g.k_per_split : g.K;
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
-    const bool edge = (g.M % bm) != 0 || (g.N % BN) != 0 || (k_len % BK) != 0 || (g.K % BK) != 0 || !vec_ok;
+    const bool edge = (g.M % bm) != 0 || (g.N % BN) != 0 || (k_len % BK) != 0 || (g.K % BK) != 0 || !vec_ok || g.row_shift != 0;
     dim3 grid((g.N + BN - 1) / BN, (g.M + bm - 1) / bm, nbatch * (g.split_k > 0 ? g.split_k : 1));
     if constexpr (BIG) {
         if (fm == 4) {
@@ -376,7 +432,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
                            float alpha, float out_scale, const float* bias, int act,
                            const void* resid, long ldr, long sR0, long sR1, float res_scale,
                            void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
-                           int precise, float* ws, int split_k, void* stream) {
+                           int precise, float* ws, int split_k, int c_row_shift, void* stream) {
     SARSSL_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0 && batch_inner > 0, "sarssl_gemm");
     SARSSL_REQUIRE(a_kc ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0), "sarssl_gemm(A alignment)");
     SARSSL_REQUIRE(b_kc ? (K % 8 == 0 && ldb % 8 == 0) : (N % 8 == 0 && ldb % 8 == 0), "sarssl_gemm(B alignment)");
@@ -388,6 +444,11 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
     g.p_drop = p_drop; g.seed = seed;
     g.split_k = 0; g.k_per_split = K;
+    g.row_shift = 0;
+    if (c_row_shift) {
+        SARSSL_REQUIRE(M == N && ldc == N && split_k <= 0 && !precise && !resid && !preact && !aux, "sarssl_gemm(c_row_shift)");
+        g.row_shift = N;
+    }
     if (split_k > 0) {
         // accumulate mode: C (f32) += alpha * A*B, no other epilogue; K split over split_k workgroups per tile, partials
         // go to ws (f32, nbatch*split_k*M*N) and a second kernel folds them into C (deterministic, no atomics)

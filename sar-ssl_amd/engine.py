@@ -120,6 +120,7 @@ def stem_fwd(a0, pe, train, saved):
 
 _C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
 _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
+_FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 
 
@@ -267,13 +268,26 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     pos = mm_nt(pe, wt(att.pos_proj.linear.weight))                                          # [T, d]
     qu, qv = hip.bias2(q, att.u_bias.data.view(-1), att.v_bias.data.view(-1))
     nbh = B * H
+    pa = _p(att.dropout, train)
+    sa = RT.next_seed() if pa > 0 else 0
+    scale = 1.0 / math.sqrt(d)                                                               # 1/sqrt(d_model), attention.py:57
+    if _FUSED_ATTN and hip.relpos_attn_supported(T, dh, RT.dtype):
+        # fused path (csrc/attention.hip): the positional-score GEMM writes its product directly in the relative-shift layout and
+        # one flash-style kernel does content score + shifted bias + softmax + dropout + PV; no (B,H,T,T) score / probability tensor
+        bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
+        hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
+                 sC=(H * T * T, T * T), c_row_shift=True)
+        ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa)
+        po = _p(mod.dropout, train)
+        so = RT.next_seed() if po > 0 else 0
+        y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,
+                  resid=x, ldr=x.stride(0), res_scale=1.0)
+        saved.append((x, ln, stats, qu, qv, k, v, pos, pe, bias, lse, pa, sa, ctx, po, so, B, T))
+        return y
     content = hip.gemm(qu, k, M=T, N=T, K=dh, lda=d, ldb=ldk, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * ldk, dh),
                        out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
     pscore = hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh),
                       out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
-    pa = _p(att.dropout, train)
-    sa = RT.next_seed() if pa > 0 else 0
-    scale = 1.0 / math.sqrt(d)                                                               # 1/sqrt(d_model), attention.py:57
     p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, pa, sa)
     del content, pscore
     ctx = torch.empty((M, d), dtype=RT.dtype, device=x.device)
@@ -293,6 +307,7 @@ def mhsa_bwd(dy, mod, saved):
     H, dh, d = att.num_heads, att.d_head, att.d_model
     M, nbh = B * T, B * H
     dev = x.device
+    fused_attn = pd.dtype == torch.float32 and pd.dim() == 3          # fused forward saved (bias, lse) in place of (p, pd)
     dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
     mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight))
     hip.colsum(dout, gbuf(att.out_proj.linear.bias))
@@ -307,19 +322,14 @@ def mhsa_bwd(dy, mod, saved):
         dk = torch.empty((M, d), dtype=RT.dtype, device=dev)
         dv = torch.empty((M, d), dtype=RT.dtype, device=dev)
     ldg = dqu.stride(0)
-    # dP = dctx @ v^T ; dv = P^T @ dctx
-    dpd = hip.gemm(dctx, v, M=T, N=T, K=dh, lda=d, ldb=ldk, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * ldk, dh),
-                   out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
-    hip.gemm(pd, dctx, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
-             sA=(H * T * T, T * T), sB=(T * d, dh), out=dv, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
     scale = 1.0 / math.sqrt(d)
-    ds = hip.softmax_bwd(dpd, p, scale, pa, sa)                                              # d content score
-    del dpd
-    dps = hip.relshift_bwd(ds)                                                               # d (unshifted) pos score
-    hip.gemm(ds, k, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=ldk, nbatch=nbh, batch_inner=H,
-             sA=(H * T * T, T * T), sB=(T * ldk, dh), out=dqu, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
-    hip.gemm(ds, qu, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
-             sA=(H * T * T, T * T), sB=(T * d, dh), out=dk, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
+    if fused_attn:
+        dbias = hip.relpos_attn_bwd(qu, k, v, p, ctx, pd, dctx, dqu, dk, dv, B, H, T, dh, scale, pa, sa)      # p = bias, pd = lse here
+        dps = hip.relshift_bwd(dbias)                                                        # d (unshifted) pos score
+        del dbias
+    else:
+        dps = _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ldg, scale, pa, sa)
+    nbh = B * H
     dqv = torch.empty((M, d), dtype=RT.dtype, device=dev)
     hip.gemm(dps, pos, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(0, dh), out=dqv, ldc=d, sC=(T * d, dh), precise=RT.precise)
@@ -327,6 +337,31 @@ def mhsa_bwd(dy, mod, saved):
     dposb = torch.empty((B, T, d), dtype=RT.dtype, device=dev)
     hip.gemm(dps, qv, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(T * d, dh), out=dposb, ldc=d, sC=(T * d, dh), precise=RT.precise)
+    del dps
+    return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev)
+
+
+def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ldg, scale, pa, sa):
+    """Unfused attention-core backward (f32 mode / shapes the fused kernel does not take): dv, dqu, dk from materialised
+    probabilities; returns the gradient of the unshifted positional score."""
+    nbh = B * H
+    # dP = dctx @ v^T ; dv = P^T @ dctx
+    dpd = hip.gemm(dctx, v, M=T, N=T, K=dh, lda=d, ldb=ldk, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * ldk, dh),
+                   out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
+    hip.gemm(pd, dctx, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dv, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
+    ds = hip.softmax_bwd(dpd, p, scale, pa, sa)                                              # d content score
+    del dpd
+    dps = hip.relshift_bwd(ds)                                                               # d (unshifted) pos score
+    hip.gemm(ds, k, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=ldk, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * ldk, dh), out=dqu, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
+    hip.gemm(ds, qu, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * d, dh), out=dk, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
+    return dps
+
+
+def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev):
+    """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
     dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
     hip.colsum(dposb.view(B, T * d), dpos)
     dpos_rt = to_rt(dpos.view(T, d))

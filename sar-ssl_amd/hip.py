@@ -90,7 +90,7 @@ def workspace(nbytes, device, tag="default"):
 def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=None, ldc=None,
          nbatch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, out_scale=1.0, bias=None, act=0,
          resid=None, ldr=0, sR=(0, 0), res_scale=1.0, preact=None, aux=None, aux_act=0, p_drop=0.0, seed=0, precise=False,
-         out_shape=None, split_k=0):
+         out_shape=None, split_k=0, c_row_shift=False):
     """C[z] = epilogue(alpha * opA(A[z]) @ opB(B[z])^T) - see csrc/gemm.hip for the layout flags."""
     _need_cuda(A, B, out, bias, resid, preact, aux)
     if out is None:
@@ -112,7 +112,7 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
               c_float(alpha), c_float(out_scale), _p(bias), c_int(act),
               _p(resid), c_long(ldr), c_long(sR[0]), c_long(sR[1]), c_float(res_scale),
               _p(preact), _p(aux), c_int(aux_act), c_float(p_drop), c_ulonglong(seed), c_int(1 if (precise and A.dtype == torch.float32) else 0),
-              _p(ws), c_int(split_k), _stream())
+              _p(ws), c_int(split_k), c_int(1 if c_row_shift else 0), _stream())
     return out
 
 
@@ -260,7 +260,9 @@ def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False, want_stats=Fals
     out = torch.empty_like(x)
     ws = _f32ws(x.numel(), x.device, "conv_acc") if (precise and x.dtype == torch.float32) else None
     sums = torch.empty((128,), dtype=torch.float64, device=x.device) if want_stats else None
-    with _Timed("conv3x3_fwd_kernel"):
+    # separate timing labels: the BN+ReLU-prologue launches (forward convolutions) and the identity launches (data gradients) are
+    # different amounts of work per tile
+    with _Timed("conv3x3_fwd:bn_prologue" if scale is not None else "conv3x3_fwd:identity"):
         _lib.call("sarssl_conv3x3_fwd", _p(x), _p(w_tap), _p(out), c_int(dt(x)), c_int(dt(w_tap)), c_int(B), c_int(F), c_int(T),
                   _p(scale), _p(shift), c_int(1 if ws is not None else 0), _p(ws), _p(sums), _stream())
     return (out, sums) if want_stats else out
@@ -433,6 +435,36 @@ def relshift_bwd(dscore):
     dpos = torch.empty_like(dscore)
     _lib.call("sarssl_relshift_bwd", _p(dscore), c_long(dscore.numel() // (T * T)), c_int(T), _p(dpos), c_int(dt(dscore)), _stream())
     return dpos
+
+
+def relpos_attn_supported(T, dh, dtype):
+    """Shapes / dtypes the fused attention kernels take (csrc/attention.hip); otherwise the caller uses the GEMM + softmax path."""
+    return dtype == torch.bfloat16 and bool(_lib.lib().sarssl_relpos_attn_supported(c_int(T), c_int(dh)))
+
+
+def relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop=0.0, seed=0):
+    """qu [B*T, d], k / v [B*T, d] (row-strided views), bias (B,H,T,T) shifted positional score -> ctx [B*T, d], lse (B,H,T)."""
+    _need_cuda(qu, k, v, bias)
+    assert k.stride(0) == v.stride(0) and bias.is_contiguous()
+    ctx = torch.empty((B * T, H * dh), dtype=torch.bfloat16, device=qu.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
+    _lib.call("sarssl_relpos_attn_fwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx),
+              c_long(ctx.stride(0)), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
+              c_ulonglong(seed), _stream())
+    return ctx, lse
+
+
+def relpos_attn_bwd(qu, k, v, bias, ctx, lse, dctx, dqu, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0):
+    """Writes dqu / dk / dv (row-strided [B*T, d] views, dk and dv with the same row stride) and returns dbias (B,H,T,T)."""
+    _need_cuda(qu, k, v, bias, ctx, lse, dctx, dqu, dk, dv)
+    assert k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0)
+    dbias = torch.empty_like(bias)
+    dsum = _f32ws(B * H * T, qu.device, "attn_dsum")
+    _lib.call("sarssl_relpos_attn_bwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx),
+              c_long(ctx.stride(0)), _p(lse), _p(dctx), c_long(dctx.stride(0)), _p(dqu), c_long(dqu.stride(0)), _p(dk), _p(dv),
+              c_long(dk.stride(0)), _p(dbias), _p(dsum), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
+              c_ulonglong(seed), _stream())
+    return dbias
 
 
 def bias2(q2d, u, v):

@@ -57,7 +57,7 @@ def test_gemm_layouts(a_kc, b_kc, mode, M, N, K):
 
 
 @pytest.mark.parametrize("a_kc,b_kc", LAYOUTS)
-@pytest.mark.parametrize("M,N,K,nbatch", [(4096, 1024, 256, 1), (512, 256, 128, 64), (520, 264, 200, 60)])
+@pytest.mark.parametrize("M,N,K,nbatch", [(4096, 1024, 256, 1), (512, 256, 768, 128), (520, 264, 776, 60)])
 def test_gemm_large_tiles_all_epilogues(a_kc, b_kc, M, N, K, nbatch):
     """Grids large enough for the 256 x 128-tile instantiations (plain and ragged-edge): batched product with bias, Swish,
     pre-activation side output, dropout, output scale and residual, in bf16 against an f64 reference of the same bf16 operands;
@@ -80,10 +80,13 @@ def test_gemm_large_tiles_all_epilogues(a_kc, b_kc, M, N, K, nbatch):
     Y0 = hip.gemm(A, B, bias=bias, act=2, out_scale=0.5, resid=R, ldr=N, res_scale=1.0, alpha=0.25, out_shape=(nbatch, M, N), **kw)
     want0 = R.double() + 0.5 * h * torch.sigmoid(h)
     assert _relerr(Y0, want0) < 1e-2
-    kept = (Y.float() - R.float()).abs() > 1e-3 * want0.abs().max().item()          # dropped elements are exactly the residual
-    keep = kept.float().mean().item()
-    assert 0.86 < keep < 0.94, keep
-    want = R.double() + 0.5 * (h * torch.sigmoid(h)) / 0.9
+    branch = 0.5 * h * torch.sigmoid(h)                                              # what dropout acts on
+    sizable = branch.abs() > 0.05 * branch.abs().max()
+    dropped = ((Y.double() - R.double()).abs() < 0.2 * branch.abs()) & sizable        # dropped elements are exactly the residual
+    frac = dropped.float().sum().item() / sizable.float().sum().item()
+    assert 0.07 < frac < 0.13, frac
+    want = R.double() + branch / 0.9
+    kept = sizable & ~dropped
     assert ((Y.double() - want).abs()[kept].max() / want.abs().max()).item() < 1.5e-2
     if nbatch == 1:                                                    # split-K accumulate (weight-gradient form), f32 output
         G = torch.ones((M, N), dtype=torch.float32, device=dev)
@@ -581,3 +584,94 @@ def test_gemm_split_k_accumulate(mode, split):
     hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=N, ldb=K, out=g, ldc=K, precise=(mode == "f32_precise"), split_k=split)
     ref = g0.double() + dy.double().t() @ x.double()
     assert _relerr(g, ref) < (1e-5 if mode == "bf16" else 5e-5)
+
+
+# ---------------------------------------------------------------- fused relative-position attention (csrc/attention.hip)
+def _ref_shift(R):
+    """RelativeMultiHeadAttention._relative_shift (code/common/conformer/attention.py:105-113) on (B,H,T,T)."""
+    B, H, T, _ = R.shape
+    padded = torch.cat([R.new_zeros(B, H, T, 1), R], dim=-1).view(B, H, T + 1, T)
+    return padded[:, :, 1:].reshape(B, H, T, T)
+
+
+def _attn_mask(B, H, T, dh, p_drop, seed, dev):
+    """Keep-mask of the fused kernel's dropout (a pure function of seed and element index): uniform probabilities (q = 0, no bias)
+    against one-hot value blocks expose the dropped probability matrix dh columns at a time."""
+    from sar_ssl_amd import hip
+    d = H * dh
+    z = torch.zeros((B * T, d), dtype=torch.bfloat16, device=dev)
+    zb = torch.zeros((B, H, T, T), dtype=torch.bfloat16, device=dev)
+    mask = torch.zeros((B, H, T, T), dtype=torch.bool, device=dev)
+    for t0 in range(0, T, dh):
+        V = torch.zeros((B, T, H, dh), dtype=torch.bfloat16, device=dev)
+        n = min(dh, T - t0)
+        V[:, t0 + torch.arange(n), :, torch.arange(n)] = 1.0
+        ctx, _ = hip.relpos_attn_fwd(z, z, V.view(B * T, d), zb, B, H, T, dh, 1.0, p_drop, seed)
+        mask[:, :, :, t0:t0 + n] = (ctx.view(B, T, H, dh).permute(0, 2, 1, 3)[..., :n] != 0)
+    return mask
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("B,H,T,dh", [(2, 4, 256, 128), (3, 4, 40, 64), (1, 2, 624, 64), (2, 4, 64, 32), (1, 4, 136, 128)])
+def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop):
+    """Positional-score GEMM written in the relative-shift layout + fused attention forward / backward against an f64 torch
+    restatement of attention.py:87-113 on the same bf16 operands (dropout mask read back from the kernel's own hash)."""
+    from sar_ssl_amd import hip
+    from conftest import check
+    dev = _dev()
+    d = H * dh
+    scale = 1.0 / (d ** 0.5)
+    g = torch.Generator().manual_seed(B * 1000 + T + dh)
+    mk = lambda *shape, s=1.0: (torch.randn(shape, generator=g) * s).to(torch.bfloat16).to(dev)
+    qkv = mk(B * T, 3 * d)
+    qu, k, v = mk(B * T, d), qkv[:, d:2 * d], qkv[:, 2 * d:]                 # k / v as column slices (row stride 3d), as in the engine
+    qv, pos = mk(B * T, d), mk(T, d, s=2.0)
+    dctx = mk(B * T, d)
+    # positional score in the shifted layout straight from the GEMM epilogue
+    bias = torch.full((B, H, T, T), float("nan"), dtype=torch.bfloat16, device=dev)
+    hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=B * H, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
+             sC=(H * T * T, T * T), c_row_shift=True)
+    raw = torch.einsum("bihc,mhc->bhim", qv.view(B, T, H, dh).double(), pos.view(T, H, dh).double())
+    want_bias = _ref_shift(raw)
+    ii = torch.arange(T - 1, device=dev)
+    got_bias = bias.double().clone()
+    assert torch.isnan(got_bias[:, :, ii, ii + 1]).all()                     # the padding zeros are never written ...
+    got_bias[:, :, ii, ii + 1] = 0.0                                         # ... and ignored by the attention kernels
+    check("attn.bias_shift_gemm", _relerr(got_bias, want_bias), 1e-2)
+    seed = 991
+    ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, seed)
+    ctx2, _ = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, seed)
+    assert torch.equal(ctx, ctx2)
+    keep = torch.ones((B, H, T, T), dtype=torch.float64, device=dev)
+    if p_drop > 0:
+        mask = _attn_mask(B, H, T, dh, p_drop, seed, dev)
+        frac = mask.double().mean().item()
+        assert abs(frac - (1 - p_drop)) < 0.01, frac
+        keep = mask.double() / (1 - p_drop)
+    # f64 reference on the same bf16 operands (bias = what the kernel reads)
+    q64 = qu.view(B, T, H, dh).double().permute(0, 2, 1, 3).requires_grad_(True)
+    k64 = k.reshape(B, T, H, dh).double().permute(0, 2, 1, 3).requires_grad_(True)
+    v64 = v.reshape(B, T, H, dh).double().permute(0, 2, 1, 3).requires_grad_(True)
+    b64 = got_bias.clone().requires_grad_(True)
+    A = torch.softmax((q64 @ k64.transpose(-1, -2) + b64) * scale, dim=-1)
+    O = (A * keep) @ v64
+    check("attn.fwd.ctx[p=%g]" % p_drop, _relerr(ctx.view(B, T, H, dh).permute(0, 2, 1, 3), O.detach()), 1e-2)
+    lse_ref = torch.logsumexp((q64 @ k64.transpose(-1, -2) + b64) * scale, dim=-1) / np.log(2.0)
+    check("attn.fwd.lse[p=%g]" % p_drop, (lse.double() - lse_ref.detach()).abs().max().item(), 1e-3)
+    O.backward(dctx.view(B, T, H, dh).double().permute(0, 2, 1, 3))
+    dqkv = torch.full((B * T, 3 * d), float("nan"), dtype=torch.bfloat16, device=dev)
+    dbias = hip.relpos_attn_bwd(qu, k, v, bias, ctx, lse, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, scale,
+                                p_drop, seed)
+    un = lambda t: t.reshape(B, T, H, dh).permute(0, 2, 1, 3)
+    check("attn.bwd.dq[p=%g]" % p_drop, _relerr(un(dqkv[:, :d]), q64.grad), 2e-2)
+    check("attn.bwd.dk[p=%g]" % p_drop, _relerr(un(dqkv[:, d:2 * d]), k64.grad), 2e-2)
+    check("attn.bwd.dv[p=%g]" % p_drop, _relerr(un(dqkv[:, 2 * d:]), v64.grad), 2e-2)
+    gb, wb = dbias.double().clone(), b64.grad.clone()
+    gb[:, :, ii, ii + 1] = 0.0
+    wb[:, :, ii, ii + 1] = 0.0
+    check("attn.bwd.dbias[p=%g]" % p_drop, _relerr(gb, wb), 2e-2)
+    # the unshift the engine applies afterwards equals autograd through the reference's pad-and-reshape
+    dps = hip.relshift_bwd(dbias)
+    raw_leaf = raw.clone().requires_grad_(True)
+    (_ref_shift(raw_leaf) * wb).sum().backward()
+    check("attn.bwd.unshift[p=%g]" % p_drop, _relerr(dps, raw_leaf.grad), 2e-2)
