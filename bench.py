@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="segments per GPU")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,7 +129,7 @@ def main():
     # the same kernel on the same shape with nothing else on the GPU (in the step its launches share the device with the other
     # encoder's stream, which stretches the event-bracketed durations used for `roofline.achieved`)
     iso_ms = None
-    if rank == 0 and args.precision == "bf16":
+    if rank == 0 and args.precision != "fp32":
         xi = torch.randn((args.batch, 256, 256, 64), device=dev).to(torch.bfloat16)
         wi = (torch.randn((9, 64, 64), device=dev) * 0.05).to(torch.bfloat16)
         sci, shi = torch.ones(64, device=dev), torch.zeros(64, device=dev)
@@ -167,7 +167,8 @@ def main():
             "metric": "pretrain_segments_per_sec", "value": round(value, 2), "unit": "segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision if args.precision == "bf16" else "f32(split-bf16 MFMA)",
+            "vs_baseline": None,
+            "dtype": {"bf16": "bf16", "fp32": "f32(split-bf16 MFMA)", "fp8": "bf16 storage, fp8(e4m3) Linear GEMMs"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "SAR-SSL MC-Conformer cross-channel-reconstruction pretrain step (STFT+mask+fwd+bwd+Adam), "
                                    "2ch 4.112s@16kHz segments, batch %d per GPU, dropout on" % args.batch,

@@ -56,6 +56,16 @@ int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC
                 long sR1, float res_scale, void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
                 int precise, float* ws, int split_k, int c_row_shift, void* stream);
 
+/* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
+ *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as
+ *      sarssl_gemm.  sarssl_fp8_quantize: x [rows][cols] (f32 | bf16, row stride ld) -> q fp8 [rows][cols] or (transpose) [cols][rows],
+ *      inv_scale = amax / 448 (device float), amax_ws = one device word.  sarssl_gemm_fp8: C = epilogue(alpha * sa * sb * A8 B8^T). */
+int sarssl_fp8_quantize(const void* x, int dtype, long rows, long cols, long ld, void* q, long ldq, float* amax_ws, float* inv_scale,
+                        int transpose, void* stream);
+int sarssl_gemm_fp8(const void* A8, const void* B8, const float* sa, const float* sb, void* C, int dtC, int M, int N, int K, long lda,
+                    long ldb, long ldc, float alpha, float out_scale, const float* bias, int act, const void* resid, long ldr,
+                    float res_scale, void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed, void* stream);
+
 /* ---- fused relative-position attention, bf16 (RelativeMultiHeadAttention.forward, attention.py:87-101, and its backward):
  *      softmax(((q+u) k^T + bias) * scale) -> dropout -> @ v per (batch, head) without materialising scores / probabilities.
  *      qu, k, v: bf16 [B*T][ld], head h at column h*dh; bias: bf16 (B,H,T,T) = shifted positional score (a sarssl_gemm with

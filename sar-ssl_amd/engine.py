@@ -19,15 +19,47 @@ RELU, SWISH = 1, 2
 
 
 # ------------------------------------------------------------------------------------------------ GEMM helpers
-def mm_nt(x, W, **kw):
+_FP8_KW = {"out", "ldc", "bias", "act", "preact", "aux", "aux_act", "p_drop", "seed", "out_scale", "resid", "ldr", "res_scale", "alpha"}
+_fp8_wcache = {}
+
+
+def _fp8_weight(W, transposed):
+    """fp8 copy (+ device-resident dequantisation scale) of a bf16 weight view [N, K] - as is for the forward GEMM, transposed
+    ([K, N]) for the input-gradient GEMM; cached until the weights change."""
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transposed)
+    ver = weights_version()
+    hit = _fp8_wcache.get(key)
+    if hit is None or hit[0] != ver:
+        if len(_fp8_wcache) > 512:
+            _fp8_wcache.clear()
+        hit = (ver,) + hip.fp8_quantize(W, transpose=transposed)
+        _fp8_wcache[key] = hit
+    return hit[1], hit[2]
+
+
+def _fp8_ok(x, W, kw):
+    return (RT.fp8 and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.dim() == 2 and W.dim() == 2 and x.stride(1) == 1
+            and W.stride(1) == 1 and x.stride(0) % 8 == 0 and W.stride(0) % 8 == 0 and x.shape[1] % 16 == 0 and W.shape[0] % 16 == 0
+            and set(kw) <= _FP8_KW)
+
+
+def mm_nt(x, W, fp8=True, **kw):
     """x [M,K] @ W[N,K]^T -> [M,N]   (nn.Linear forward)."""
     M, K = x.shape
+    if fp8 and _fp8_ok(x, W, kw):
+        xq, sx = hip.fp8_quantize(x)
+        wq, sw = _fp8_weight(W, False)
+        return hip.gemm_fp8(xq, sx, wq, sw, M=M, N=W.shape[0], K=K, **kw)
     return hip.gemm(x, W, M=M, N=W.shape[0], K=K, lda=x.stride(0), ldb=W.stride(0), precise=RT.precise, **kw)
 
 
-def mm_nn(dy, W, **kw):
+def mm_nn(dy, W, fp8=True, **kw):
     """dy [M,N] @ W[N,K] -> [M,K]   (input gradient of nn.Linear)."""
     M, N = dy.shape
+    if fp8 and _fp8_ok(dy, W, kw) and W.shape[1] % 8 == 0:
+        dq, sd = hip.fp8_quantize(dy)
+        wtq, swt = _fp8_weight(W, True)                                       # [K, N]: contraction index contiguous
+        return hip.gemm_fp8(dq, sd, wtq, swt, M=M, N=W.shape[1], K=N, **kw)
     return hip.gemm(dy, W, a_kc=True, b_kc=False, M=M, N=W.shape[1], K=N, lda=dy.stride(0), ldb=W.stride(0),
                     precise=RT.precise, **kw)
 
@@ -113,7 +145,7 @@ def stem_fwd(a0, pe, train, saved):
     y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])           # (B,T,F,4)
     aff4 = bn_affine(y4, 4, pe[10], train)
     z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
-    e = mm_nt(z4, _patch_w(pe[12], F))
+    e = mm_nt(z4, _patch_w(pe[12], F), fp8=False)
     saved.append((a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
     return e
 
@@ -134,7 +166,7 @@ def patch_bwd(de, pe, saved):
     gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
     mm_tn_acc(de, z4, gtmp)
     gbuf(pe[12].weight).add_(gtmp.view(d, F, 4).permute(0, 2, 1).unsqueeze(-1))
-    return mm_nn(de, _patch_w(pe[12], F))                                                  # (B,T,F,4)
+    return mm_nn(de, _patch_w(pe[12], F), fp8=False)                                       # (B,T,F,4)
 
 
 def stem_bwd(dz4, pe, saved):
@@ -265,7 +297,7 @@ def mhsa_fwd(x, mod, B, T, train, saved):
         v = mm_nt(ln, wt(att.value_proj.linear.weight), bias=att.value_proj.linear.bias.data)
     ldk = k.stride(0)
     pe = _pe(mod, T)
-    pos = mm_nt(pe, wt(att.pos_proj.linear.weight))                                          # [T, d]
+    pos = mm_nt(pe, wt(att.pos_proj.linear.weight), fp8=False)                               # [T, d]
     qu, qv = hip.bias2(q, att.u_bias.data.view(-1), att.v_bias.data.view(-1))
     nbh = B * H
     pa = _p(att.dropout, train)

@@ -116,6 +116,34 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     return out
 
 
+def fp8_quantize(x2d, transpose=False):
+    """x [rows, cols] (f32 | bf16, row-strided) -> (q uint8 e4m3fn [rows, cols] or, transposed, [cols, rows]; inv_scale f32[1] on the
+    device) with the per-tensor scale 448 / amax chosen on the device (csrc/gemm_fp8.hip)."""
+    _need_cuda(x2d)
+    rows, cols = x2d.shape
+    assert x2d.stride(1) == 1
+    q = torch.empty((cols, rows) if transpose else (rows, cols), dtype=torch.uint8, device=x2d.device)
+    ws = torch.empty((2,), dtype=torch.float32, device=x2d.device)            # [amax bits | inv_scale]
+    _lib.call("sarssl_fp8_quantize", _p(x2d), c_int(dt(x2d)), c_long(rows), c_long(cols), c_long(x2d.stride(0)), _p(q),
+              c_long(q.stride(0)), _p(ws[0:1]), _p(ws[1:2]), c_int(1 if transpose else 0), _stream())
+    return q, ws[1:2]
+
+
+def gemm_fp8(A8, sa, B8, sb, *, M, N, K, out=None, out_dtype=torch.bfloat16, ldc=None, alpha=1.0, out_scale=1.0, bias=None, act=0,
+             resid=None, ldr=0, res_scale=1.0, preact=None, aux=None, aux_act=0, p_drop=0.0, seed=0):
+    """C [M,N] = epilogue(alpha * sa * sb * A8 [M,K] @ B8 [N,K]^T), fp8 operands with device-resident dequantisation scales."""
+    _need_cuda(A8, B8, out, bias, resid, preact, aux)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A8.device)
+    if ldc is None:
+        ldc = out.stride(0)
+    _lib.call("sarssl_gemm_fp8", _p(A8), _p(B8), _p(sa), _p(sb), _p(out), c_int(dt(out)), c_int(M), c_int(N), c_int(K),
+              c_long(A8.stride(0)), c_long(B8.stride(0)), c_long(ldc), c_float(alpha), c_float(out_scale), _p(bias), c_int(act),
+              _p(resid), c_long(ldr), c_float(res_scale), _p(preact), _p(aux), c_int(aux_act), c_float(p_drop), c_ulonglong(seed),
+              _stream())
+    return out
+
+
 def stft_frontend(sig, eps=1e-6, win_len=512, hop=256, nfft=512, ch_mode="M"):
     """(B, nsample, nch) f32|int16 -> (B*npair, 2, nfft/2, nt, 2) f32 (data_preprocess output); ch_mode 'M' pairs mic 0 with
     every other mic (npair = nch-1), 'MM' takes every mic pair (npair = nch(nch-1)/2)."""

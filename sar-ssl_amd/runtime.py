@@ -18,6 +18,7 @@ from . import hip
 class _RT:
     dtype = torch.bfloat16
     precise = False
+    fp8 = False
     _seed = 0x5A25_5151_0000_0000
     _ctr = 0
 
@@ -34,17 +35,21 @@ RT = _RT()
 
 
 def set_precision(mode):
-    """'bf16' (fast path) or 'fp32' (split-bf16 precise path)."""
+    """'bf16' (fast path), 'fp32' (split-bf16 precise path) or 'fp8' (bf16 storage; the Linear / pointwise-conv forward and
+    input-gradient GEMMs of the Conformer blocks and the decoder on the OCP-e4m3 block-scaled MFMA with per-tensor scales chosen on
+    the device - BASELINE.json config 5; everything else as 'bf16')."""
     if mode in ("bf16", torch.bfloat16):
-        RT.dtype, RT.precise = torch.bfloat16, False
+        RT.dtype, RT.precise, RT.fp8 = torch.bfloat16, False, False
     elif mode in ("fp32", "f32", torch.float32):
-        RT.dtype, RT.precise = torch.float32, True
+        RT.dtype, RT.precise, RT.fp8 = torch.float32, True, False
+    elif mode == "fp8":
+        RT.dtype, RT.precise, RT.fp8 = torch.bfloat16, False, True
     else:
-        raise ValueError("precision must be 'bf16' or 'fp32'")
+        raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
 
 
 def get_precision():
-    return "bf16" if RT.dtype == torch.bfloat16 else "fp32"
+    return "fp8" if RT.fp8 else ("bf16" if RT.dtype == torch.bfloat16 else "fp32")
 
 
 _GLOBAL_VERSION = [0]
@@ -70,6 +75,7 @@ def wt(p):
     cache = getattr(p, "_w16_cache", None)
     if cache is None or cache[0] != p._version:
         p._w16_cache = (p._version, hip.cast(p.data.contiguous(), torch.bfloat16))
+        bump_version()                         # derived copies (fp8 weights, re-laid-out taps) follow
     return p._w16_cache[1]
 
 

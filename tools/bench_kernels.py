@@ -29,7 +29,31 @@ def gemm_case(name, M, N, K, a_kc=True, b_kc=True, out_dtype=torch.bfloat16, spl
     print("%-34s M=%6d N=%5d K=%6d  %8.1f us  %7.1f TFLOP/s" % (name, M, N, K, t * 1e6, 2.0 * M * N * K / t / 1e12))
 
 
+def fp8_case(name, M, N, K, **kw):
+    A = torch.randn((M, K), device=dev).to(torch.bfloat16)
+    B = (torch.randn((N, K), device=dev) * 0.05).to(torch.bfloat16)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+    Bq, sb = hip.fp8_quantize(B)
+    Aq, sa = hip.fp8_quantize(A)
+    t_mm = timeit(lambda: hip.gemm_fp8(Aq, sa, Bq, sb, M=M, N=N, K=K, out=out, **kw))
+    t_q = timeit(lambda: hip.fp8_quantize(A))
+    t_bf = timeit(lambda: hip.gemm(A, B, M=M, N=N, K=K, lda=K, ldb=K, out=out, **kw))
+    print("%-34s M=%6d N=%5d K=%6d  fp8 gemm %7.1f us (%6.1f TFLOP/s) + activation quantise %6.1f us | bf16 gemm %7.1f us | "
+          "speed-up gemm only %.2fx, incl. quantise %.2fx" % (name, M, N, K, t_mm * 1e6, 2.0 * M * N * K / t_mm / 1e12, t_q * 1e6, t_bf * 1e6,
+                                                              t_bf / t_mm, t_bf / (t_mm + t_q)))
+
+
 if __name__ == "__main__":
+    if "--fp8" in sys.argv:
+        bias = torch.zeros(4096, device=dev)
+        for d in (512, 256):
+            fp8_case("fp8 ffn1 NT d=%d (+bias,swish)" % d, 16384, 4 * d, d, bias=bias[:4 * d], act=2)
+            fp8_case("fp8 ffn2 NT d=%d" % d, 16384, d, 4 * d, bias=bias[:d])
+            fp8_case("fp8 qkv NT d=%d" % d, 16384, 3 * d, d, bias=bias[:3 * d])
+        fp8_case("fp8 decoder1 NT", 16384, 3072, 768, bias=bias[:3072], act=1)
+        fp8_case("fp8 decoder2 NT", 16384, 1024, 3072, bias=bias[:1024])
+        fp8_case("fp8 big square", 8192, 8192, 8192)
+        sys.exit(0)
     Mr = 16384
     bias = torch.zeros(4096, device=dev)
     for d in (512, 256):
