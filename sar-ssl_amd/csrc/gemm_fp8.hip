@@ -27,8 +27,12 @@ __global__ void fp8_amax_kernel(const T* __restrict__ x, long rows, long cols, l
 #pragma unroll
         for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v.v[e]));
     }
+    __shared__ float smax[4];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));      // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup (same-address atomics serialise at ~12 ns each); non-negative floats order like their bit patterns
+    if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]))));
 }
 
 __device__ __forceinline__ uint2 cvt8_fp8(const f8& v, float s) {
@@ -85,8 +89,9 @@ extern "C" int sarssl_fp8_quantize(const void* x, int dtype, long rows, long col
     if (hipMemsetAsync(amax_ws, 0, sizeof(unsigned), st) != hipSuccess) { sarssl_set_error("sarssl_fp8_quantize: memset"); return -2; }
     const long n8 = rows * (cols >> 3);
     int nblk = (int)((n8 + 255) / 256); if (nblk > 2048) nblk = 2048;
-    if (dtype == SARSSL_BF16) fp8_amax_kernel<bf16><<<nblk, 256, 0, st>>>((const bf16*)x, rows, cols, ld, (unsigned*)amax_ws);
-    else if (dtype == SARSSL_F32) fp8_amax_kernel<float><<<nblk, 256, 0, st>>>((const float*)x, rows, cols, ld, (unsigned*)amax_ws);
+    const int nblk_amax = nblk > 512 ? 512 : nblk;
+    if (dtype == SARSSL_BF16) fp8_amax_kernel<bf16><<<nblk_amax, 256, 0, st>>>((const bf16*)x, rows, cols, ld, (unsigned*)amax_ws);
+    else if (dtype == SARSSL_F32) fp8_amax_kernel<float><<<nblk_amax, 256, 0, st>>>((const float*)x, rows, cols, ld, (unsigned*)amax_ws);
     else { sarssl_set_error("sarssl_fp8_quantize: unsupported dtype %d", dtype); return -1; }
     if (!transpose) {
         if (dtype == SARSSL_BF16) fp8_quant_kernel<bf16><<<nblk, 256, 0, st>>>((const bf16*)x, rows, cols, ld, (const unsigned*)amax_ws, (uint8_t*)q, ldq, inv_scale);
@@ -106,21 +111,24 @@ extern "C" int sarssl_fp8_quantize(const void* x, int dtype, long rows, long col
 #define F8_BKB 128                    // bytes (= fp8 elements) of K per tile
 #define F8_PITCH (F8_BKB + 16)        // 144-byte rows: conflict-free ds_read_b128 fragment reads (as the bf16 kernel)
 
+// one 16-byte chunk of an operand tile: row (tid >> 3) + 32 i, bytes (tid & 7) * 16 .. + 16 of the current 128-byte K-slab
+// (named registers instead of an array: hipcc 7.2 demoted the array form of this prefetch set to scratch memory)
 template <bool EDGE>
-__device__ __forceinline__ void f8_tile_load(const uint8_t* __restrict__ p, long ld, int r0, int k0, int R, int Kend, int tid,
-                                             uint4 (&regs)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint8_t* q = p + (long)(32 * i) * ld;
-        if constexpr (EDGE) {
-            const int gr = r0 + (tid >> 3) + 32 * i, gk = k0 + (tid & 7) * 16;
-            regs[i] = (gr < R && gk < Kend) ? *(const uint4*)q : make_uint4(0, 0, 0, 0);
-        } else regs[i] = *(const uint4*)q;
-    }
+__device__ __forceinline__ uint4 f8_chunk(const uint8_t* __restrict__ p, long ld, int i, int r0, int k0, int R, int Kend, int tid) {
+    const uint8_t* q = p + (long)(32 * i) * ld;
+    if constexpr (EDGE) {
+        const int gr = r0 + (tid >> 3) + 32 * i, gk = k0 + (tid & 7) * 16;
+        return (gr < R && gk < Kend) ? *(const uint4*)q : make_uint4(0, 0, 0, 0);
+    } else return *(const uint4*)q;
 }
+#define F8_LOAD_TILE(K0)                                                                                                         \
+    ra0 = f8_chunk<EDGE>(pa, g.lda, 0, m0, K0, g.M, g.K, tid); ra1 = f8_chunk<EDGE>(pa, g.lda, 1, m0, K0, g.M, g.K, tid);          \
+    ra2 = f8_chunk<EDGE>(pa, g.lda, 2, m0, K0, g.M, g.K, tid); ra3 = f8_chunk<EDGE>(pa, g.lda, 3, m0, K0, g.M, g.K, tid);          \
+    rb0 = f8_chunk<EDGE>(pb, g.ldb, 0, n0, K0, g.N, g.K, tid); rb1 = f8_chunk<EDGE>(pb, g.ldb, 1, n0, K0, g.N, g.K, tid);          \
+    rb2 = f8_chunk<EDGE>(pb, g.ldb, 2, n0, K0, g.N, g.K, tid); rb3 = f8_chunk<EDGE>(pb, g.ldb, 3, n0, K0, g.N, g.K, tid);
 
 template <typename TC, bool EDGE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_fp8_kernel(GemmArgs g, const float* __restrict__ sa,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void gemm_fp8_kernel(GemmArgs g, const float* __restrict__ sa,
                                                                                                const float* __restrict__ sb) {
     constexpr int PC = F8_BN + 4;
     constexpr int TILE_B = F8_BM * F8_PITCH;                     // 18432 bytes per operand tile
@@ -151,44 +159,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     float bias8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias8[e] = (g.bias && n + e < g.N) ? g.bias[n + e] : 0.f;
-    g.alpha *= sa[0] * sb[0];                                     // per-tensor dequantisation scales (device scalars)
+    const float alpha_q = g.alpha * sa[0] * sb[0];                // per-tensor dequantisation scales (device scalars)
 
-    uint4 ra[4], rb[4];
-    f8_tile_load<EDGE>(pa, g.lda, m0, 0, g.M, g.K, tid, ra);
-    f8_tile_load<EDGE>(pb, g.ldb, n0, 0, g.N, g.K, tid, rb);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    F8_LOAD_TILE(0)
+    uint8_t* wa = &sA[(tid >> 3) * F8_PITCH + (tid & 7) * 16];
+    uint8_t* wb = &sB[(tid >> 3) * F8_PITCH + (tid & 7) * 16];
     for (int k0 = 0; k0 < g.K; k0 += F8_BKB) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(uint4*)&sA[((tid >> 3) + 32 * i) * F8_PITCH + (tid & 7) * 16] = ra[i];
-            *(uint4*)&sB[((tid >> 3) + 32 * i) * F8_PITCH + (tid & 7) * 16] = rb[i];
-        }
+        *(uint4*)(wa) = ra0; *(uint4*)(wa + 32 * F8_PITCH) = ra1; *(uint4*)(wa + 64 * F8_PITCH) = ra2; *(uint4*)(wa + 96 * F8_PITCH) = ra3;
+        *(uint4*)(wb) = rb0; *(uint4*)(wb + 32 * F8_PITCH) = rb1; *(uint4*)(wb + 64 * F8_PITCH) = rb2; *(uint4*)(wb + 96 * F8_PITCH) = rb3;
         __syncthreads();
         if (k0 + F8_BKB < g.K) {
             pa += F8_BKB; pb += F8_BKB;
-            f8_tile_load<EDGE>(pa, g.lda, m0, k0 + F8_BKB, g.M, g.K, tid, ra);
-            f8_tile_load<EDGE>(pb, g.ldb, n0, k0 + F8_BKB, g.N, g.K, tid, rb);
+            F8_LOAD_TILE(k0 + F8_BKB)
+        }
+        // both k-blocks' fragments are requested before the first MFMA (two register sets, order pinned as in gemm.hip)
+        i32x8 fa0[2], fb0[2], fa1[2], fb1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa0[i] = *(const i32x8*)&sA[(wm * 64 + i * 32 + (lane & 31)) * F8_PITCH + half * 32];
+            fb0[i] = *(const i32x8*)&sB[(wn * 64 + i * 32 + (lane & 31)) * F8_PITCH + half * 32];
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            i32x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint8_t* q = &sA[(wm * 64 + i * 32 + (lane & 31)) * F8_PITCH + kb * 64 + half * 32];
-                const uint4 lo = *(const uint4*)q, hi = *(const uint4*)(q + 16);
-                fa[i] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint8_t* q = &sB[(wn * 64 + j * 32 + (lane & 31)) * F8_PITCH + kb * 64 + half * 32];
-                const uint4 lo = *(const uint4*)q, hi = *(const uint4*)(q + 16);
-                fb[j] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        for (int i = 0; i < 2; ++i) {
+            fa1[i] = *(const i32x8*)&sA[(wm * 64 + i * 32 + (lane & 31)) * F8_PITCH + 64 + half * 32];
+            fb1[i] = *(const i32x8*)&sB[(wn * 64 + i * 32 + (lane & 31)) * F8_PITCH + 64 + half * 32];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb0[j], fa0[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb1[j], fa1[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         __syncthreads();
     }
     TC* C = (TC*)g.C;
@@ -214,8 +222,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
             if (EDGE && (m >= g.M || n >= g.N)) continue;
             f8 v;
             const float4 a0 = *(const float4*)&sC[r * PC + ch * 8], a1 = *(const float4*)&sC[r * PC + ch * 8 + 4];
-            v.v[0] = g.alpha * a0.x; v.v[1] = g.alpha * a0.y; v.v[2] = g.alpha * a0.z; v.v[3] = g.alpha * a0.w;
-            v.v[4] = g.alpha * a1.x; v.v[5] = g.alpha * a1.y; v.v[6] = g.alpha * a1.z; v.v[7] = g.alpha * a1.w;
+            v.v[0] = alpha_q * a0.x; v.v[1] = alpha_q * a0.y; v.v[2] = alpha_q * a0.z; v.v[3] = alpha_q * a0.w;
+            v.v[4] = alpha_q * a1.x; v.v[5] = alpha_q * a1.y; v.v[6] = alpha_q * a1.z; v.v[7] = alpha_q * a1.w;
             // (workspace pointers passed as runtime values: literal nullptrs here crash hipcc 7.2's SimplifyCFG at -O2 and above)
             epilogue8<TC, EDGE>(g, v, 0, m, n, C, Rz, P, Xa, g.acc_ws, g.acc_ws, bias8, vec_ok, inv_keep, nullptr);
         }

@@ -300,43 +300,63 @@ __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ 
             cA[e] = sc[e]; cB[e] = -sc[e] * m2 * rs[e]; cC[e] = -sc[e] * m1 - cB[e] * mu[e];
         }
     }
-    const long nthreads = (long)gridDim.x * blockDim.x;
-    constexpr int U = 4;                         // pixels in flight per thread (latency hiding)
-    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads * U) {
-        f8 v[U]; float4 d[U]; bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long g = g0 + u * nthreads;
-            ok[u] = g < npix * 8;
-            if (ok[u]) {
-                const long p = g >> 3;
-                const int t = (int)(p % Tn);
-                const long bf = p / Tn;
-                const int f = (int)(bf % F), b = (int)(bf / F);
-                d[u] = ld4(dy4 + ((((long)b * Tn + t) * F + f) * 4));
-                v[u] = ld8(y3 + p * 64 + cg * 8);
+    // Pixel order.  y3 / g3 are (B,F,T,64) - frames contiguous - while dy4 is (B,T,F,4) - bins contiguous: walking pixels in y3's
+    // order reads dy4 with a 2 KB stride (one useful 8-byte piece per 128-byte line: the L2 -> L1 traffic of the 33 MB dy4 tensor
+    // then equals that of the 537 MB y3 tensor; round-2 counters: 2.3 TB/s for this pass).  Workgroups therefore take 16 x 16
+    // (bin, frame) tiles: the dy4 tile is fetched in 128-byte rows into LDS, the y3 tile in 2 KB rows straight into registers.
+    __shared__ float4 sD[16][17];
+    const int ftiles = (F + 15) >> 4, ttiles = (Tn + 15) >> 4;
+    const long ntile = (long)nb * ftiles * ttiles;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int tt0 = (int)(tile % ttiles) << 4;
+        const long r = tile / ttiles;
+        const int f0 = (int)(r % ftiles) << 4, b = (int)(r / ftiles);
+        __syncthreads();                                             // previous tile's readers are done with sD
+        if (threadIdx.x < 128) {                                     // 16 frames x 8 pieces of 16 bytes (2 bins x 4 channels)
+            const int tt = threadIdx.x >> 3, fc = (threadIdx.x & 7) * 2;
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (tt0 + tt < Tn) {
+                const T* q = dy4 + (((long)b * Tn + tt0 + tt) * F + f0 + fc) * 4;
+                if (f0 + fc + 1 < F) { const f8 v = ld8(q); lo = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); hi = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]); }
+                else if (f0 + fc < F) lo = ld4(q);
             }
+            sD[tt][fc] = lo; sD[tt][fc + 1] = hi;
         }
+        __syncthreads();
+        constexpr int U = 4;                                         // pixels in flight per thread (latency hiding)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
-            const long p = (g0 + u * nthreads) >> 3;
-            f8 o;
+        for (int h = 0; h < 2; ++h) {
+            f8 v[U]; bool ok[U]; long pix[U];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float uu = fmaf(v[u].v[e], sc[e], sh[e]);
-                float gi = d[u].x * w[0][e] + d[u].y * w[1][e] + d[u].z * w[2][e] + d[u].w * w[3][e];
-                gi = (uu > 0.f) ? gi : 0.f;
-                if (MODE == 2) o.v[e] = fmaf(cA[e], gi, fmaf(cB[e], v[u].v[e], cC[e]));
-                else {
-                    const float z = fmaxf(uu, 0.f);
-                    o.v[e] = gi;
-                    acc[0 * 8 + e] += d[u].x * z; acc[1 * 8 + e] += d[u].y * z; acc[2 * 8 + e] += d[u].z * z; acc[3 * 8 + e] += d[u].w * z;
-                    acc[32 + e] += gi;
-                    acc[40 + e] += gi * (v[u].v[e] - mu[e]) * rs[e];
-                }
+            for (int u = 0; u < U; ++u) {
+                const int pl = (threadIdx.x >> 3) + 32 * (h * U + u);       // 0..255: bin pl >> 4, frame pl & 15
+                const int f = f0 + (pl >> 4), t = tt0 + (pl & 15);
+                ok[u] = f < F && t < Tn;
+                pix[u] = ((long)b * F + f) * Tn + t;
+                if (ok[u]) v[u] = ld8(y3 + pix[u] * 64 + cg * 8);
             }
-            if (MODE != 1) st8(g3 + p * 64 + cg * 8, o);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int pl = (threadIdx.x >> 3) + 32 * (h * U + u);
+                const float4 d = sD[pl & 15][pl >> 4];
+                f8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float uu = fmaf(v[u].v[e], sc[e], sh[e]);
+                    float gi = d.x * w[0][e] + d.y * w[1][e] + d.z * w[2][e] + d.w * w[3][e];
+                    gi = (uu > 0.f) ? gi : 0.f;
+                    if (MODE == 2) o.v[e] = fmaf(cA[e], gi, fmaf(cB[e], v[u].v[e], cC[e]));
+                    else {
+                        const float z = fmaxf(uu, 0.f);
+                        o.v[e] = gi;
+                        acc[0 * 8 + e] += d.x * z; acc[1 * 8 + e] += d.y * z; acc[2 * 8 + e] += d.z * z; acc[3 * 8 + e] += d.w * z;
+                        acc[32 + e] += gi;
+                        acc[40 + e] += gi * (v[u].v[e] - mu[e]) * rs[e];
+                    }
+                }
+                if (MODE != 1) st8(g3 + pix[u] * 64 + cg * 8, o);
+            }
         }
     }
     if (MODE == 2) return;

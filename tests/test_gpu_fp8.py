@@ -53,7 +53,7 @@ def test_fp8_gemm_vs_exact_product_of_the_quantised_operands(M, N, K):
     wd = wq.view(torch.float8_e4m3fn).double() * sw.double()
     check("fp8.gemm_vs_dequantised_f64[%dx%dx%d]" % (M, N, K), _relerr(y, xd @ wd.t() + bias.double()), 2e-5)
     yb = hip.gemm(x, w, M=M, N=N, K=K, lda=K, ldb=K, bias=bias, out_dtype=torch.float32)
-    check("fp8.gemm_vs_bf16_gemm[%dx%dx%d]" % (M, N, K), _relerr(y, yb), 3e-2)
+    check("fp8.gemm_vs_bf16_gemm[%dx%dx%d]" % (M, N, K), _relerr(y, yb), 5e-2)            # e4m3 operands: 2^-4 relative rounding per element
     # fused epilogue: Swish + pre-activation + residual + scale, bf16 output
     R = torch.randn((M, N), generator=g).to(torch.bfloat16).cuda()
     pre = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
