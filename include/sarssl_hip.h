@@ -99,6 +99,15 @@ int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int 
  *      Returns 1 without launching when the ping-pong kernel is disabled (caller falls back to sarssl_cl_bn_bwd_reduce). */
 int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, int F, int T, const void* y, const float* aff,
                                double* red, void* stream);
+/* ---- the same two convolution launches with the BatchNorm + ReLU backward of the layer BEHIND them applied to the incoming gradient
+ *      while staging: dz_in = dL/d relu(bn(y)), (y, aff, red) = that BatchNorm's pre-activations / affine / backward sums; the
+ *      normalised gradient dy = gamma*rstd*(g - s1/N - xhat*s2/N) is never stored (replaces sarssl_cl_bn_bwd_apply + the plain
+ *      launches; code/model.py:53-58 backward).  bf16; sarssl_conv3x3_dgrad_bnin returns 1 when the ping-pong kernel is disabled. */
+int sarssl_conv3x3_dgrad_bnin(const void* dz_in, const void* w, void* out, int nb, int F, int T, const void* y, const float* aff,
+                              const double* red, int use_stats, void* stream);
+int sarssl_conv3x3_wgrad_bnin(const void* dz_in, const void* y_bn, const float* aff_bn, const double* red_bn, int use_stats,
+                              const void* zin, int nb, int F, int T, const float* scale, const float* shift, float* dW, float* partial,
+                              void* stream);
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
                          const float* shift, float* dW, float* partial, int precise, void* stream);

@@ -433,9 +433,46 @@ def f6_checkpoint(ref_model, ref_learner):
     print("f6 checkpoint written", os.path.getsize(os.path.join(GOLD, "f6_checkpoint.tar.gz")), flush=True)
 
 
+def f5_curve_dropout(ref_model, ref_learner, nstep=40, B=8):
+    """F5(ii): the same training run as F5 with dropout ON (p = 0.1 everywhere, the reference default).  Before every forward:
+    ``random.seed(9000 + s)`` (masks) and ``torch.manual_seed(7000 + s)`` (the 28 dropout draws of the step).  The
+    oracle is stepped alongside for the first steps under the same seeds: equal losses prove that the draw order / layouts assumed
+    by the build's mask replay (runtime.DropoutReplay) are the reference's."""
+    from sar_ssl_amd import synth
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    man = load_recipe(net, 0)
+    net.train()
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    pool = torch.from_numpy(synth.make_batch(0, 64))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0)   # learner.py:83
+    osd, ostate = recipes.recipe_state_dict(man, 0), {}
+    losses, diffs = [], []
+    for s in range(nstep):
+        sig = pool[(s * B) % 64:(s * B) % 64 + B]
+        x, = lrn.data_preprocess(sig, None)
+        random.seed(9000 + s)
+        torch.manual_seed(7000 + s)
+        loss, diff, _ = net(x)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item()); diffs.append(diff.item())
+        if s < 3:
+            random.seed(9000 + s)
+            torch.manual_seed(7000 + s)
+            ol, od = orc.train_step(sig, osd, ostate, 1e-3, p_drop=0.1)
+            print("  oracle", ol, "rel", abs(ol / losses[-1] - 1), flush=True)
+            assert abs(ol / losses[-1] - 1) < 2e-5, "oracle does not consume the dropout generator like the reference"
+        print("step", s, losses[-1], diffs[-1], flush=True)
+        np.savez_compressed(os.path.join(GOLD, "f5_curve_dropout.npz"), loss=np.array(losses), diff=np.array(diffs), B=B, lr=1e-3,
+                            mask_seed_base=9000, dropout_seed_base=7000, pool=64, weight_seed=0, p_drop=0.1)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--curve", action="store_true")
+    ap.add_argument("--curve-dropout", action="store_true", help="F5(ii): 40 dropout-on steps (~4 min CPU)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -456,4 +493,5 @@ if __name__ == "__main__":
     if "f12" in todo: f12_pretrain_epoch(ref_model, ref_learner)
     if "f6" in todo: f6_checkpoint(ref_model, ref_learner)
     if a.curve: f5_curve(ref_model, ref_learner)
+    if a.curve_dropout: f5_curve_dropout(ref_model, ref_learner)
     print("golden vectors written to", GOLD)

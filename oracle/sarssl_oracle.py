@@ -179,8 +179,11 @@ def conv_module(x, sd, pre, p_drop, train):
     h = F.conv1d(h.transpose(1, 2), wd, None, padding=(K - 1) // 2, groups=d)       # (B, d, T)
     h = batch_norm(h, sd, pre + "5.", train, channel_dim=1)
     h = h * torch.sigmoid(h)
-    h = F.linear(h.transpose(1, 2), sd[pre + "7.conv.weight"][:, :, 0], sd[pre + "7.conv.bias"])
-    return _drop(h, p_drop, train)
+    # the reference applies this Dropout to the (B, d, T) output of the pointwise Conv1d, before the final transpose
+    # (convolution.py:144-149): same values either way, but the mask is DRAWN in (B, d, T) order - kept here so that, under the
+    # same torch seed, the oracle consumes the generator exactly like the reference (28 draws per step)
+    h = F.conv1d(h, sd[pre + "7.conv.weight"], sd[pre + "7.conv.bias"])             # (B, d, T)
+    return _drop(h, p_drop, train).transpose(1, 2)
 
 
 def conformer_block(x, sd, pre, num_heads, p_drop, train):

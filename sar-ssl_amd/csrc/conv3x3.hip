@@ -43,7 +43,44 @@ struct ConvArgs {
     // stats instead receives that BatchNorm's backward sums [sum g | sum g*xhat], g = dz * relu'(bn(y)) (the cl_bn_bwd_reduce pass)
     const void* bn_y;   // (B,F,T,64) pre-BN activations of the layer whose input gradient this launch produces
     const float* bn_aff;    // [4][64]: scale, shift, mean, rstd
+    // BatchNorm-backward INPUT transform of the ping-pong kernel (BNIN): `in` holds dz = dL/d relu(bn(y)) and the convolution
+    // runs on dy = gamma*rstd*(g - s1/N - xhat*s2/N), g = dz*relu'(bn(y)), formed while staging from (dz, in2 = y) - the
+    // stand-alone normalisation pass (cl_bn_bwd_apply: read 2, write 1 tensor of 537 MB) disappears
+    const void* in2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
 };
+
+// per-thread constants of the BatchNorm-backward input transform for channels c0 .. c0+7: dy = cA*g + cB*y + cC
+struct BnInConst { float sc[8], sh[8], cA[8], cB[8], cC[8]; };
+__device__ __forceinline__ void bnin_setup(BnInConst& k, const float* aff, const double* red, int use_stats, long npix, int c0) {
+    const float invN = 1.0f / (float)npix;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const float scale = aff[c], shift = aff[64 + c], mean = aff[128 + c], rstd = aff[192 + c];
+        const float m1 = use_stats ? (float)red[c] * invN : 0.f, m2 = use_stats ? (float)red[64 + c] * invN : 0.f;
+        k.sc[e] = scale; k.sh[e] = shift;
+        k.cA[e] = scale; k.cB[e] = -scale * m2 * rstd; k.cC[e] = -scale * m1 - k.cB[e] * mean;
+    }
+}
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+    v[0] = bf16_bits_to_f32(u.x & 0xffffu); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = bf16_bits_to_f32(u.y & 0xffffu); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = bf16_bits_to_f32(u.z & 0xffffu); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = bf16_bits_to_f32(u.w & 0xffffu); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+// 8 channels of one pixel: (dz, y) -> bf16 dy
+__device__ __forceinline__ uint4 bnin_chunk(const uint4& dz, const uint4& y, bool valid, const BnInConst& k) {
+    if (!valid) return make_uint4(0, 0, 0, 0);
+    float g[8], v[8];
+    unpack8(dz, g); unpack8(y, v);
+    f8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gi = fmaf(v[e], k.sc[e], k.sh[e]) > 0.f ? g[e] : 0.f;
+        o.v[e] = fmaf(k.cA[e], gi, fmaf(k.cB[e], v[e], k.cC[e]));
+    }
+    return pack8_part(o, 0);
+}
 
 __device__ __forceinline__ int swz(int p, int chunk) { return (p * 8 + (chunk ^ ((p >> 1) & 7))) * 8; }
 // input-tile variant: XOR term from the pixel's COLUMN in the halo tile only (same conflict-free ds_read_b128 pattern within a row,
@@ -352,7 +389,7 @@ __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int
     asm volatile("" ::: "memory");
 }
 
-template <bool BNRED>
+template <bool BNRED, bool BNIN = false>
 __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     typedef bf16 T;
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
@@ -367,6 +404,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     const int ntiles = a.nb * tiles_f * tiles_t;
     const int npairs = (ntiles + 1) >> 1;
     const T* in = (const T*)a.in;
+    const T* in2 = (const T*)a.in2;
     uint16_t* sX = sXh[half];
     if (tid < 128) sStats[tid] = 0.f;
     if (tid < 2) sSync[tid] = 0u;
@@ -383,6 +421,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+    BnInConst kin;
+    if (BNIN) bnin_setup(kin, a.bnin_aff, a.bnin_red, a.bnin_use_stats, (long)a.nb * F * Tn, cch * 8);
 
     // lane-constant fragment addresses; this wave computes rows 2*hw and 2*hw+1 (32 pixels x 64 channels each)
     int laneW[4], laneX[3][4];
@@ -400,20 +440,24 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 
     // staging: thread of the half = (pixel column pc = htid >> 3 of 32, chunk): halo rows 0..9 + one chunk of halo columns 32 / 33
     Chunk<T> regs[X_ITERS];
+    Chunk<T> regs2[BNIN ? X_ITERS : 1];            // BNIN: the matching pre-BatchNorm activations
     const int pc = htid >> 3;
     auto issue_loads = [&](int tile) {
         const TileCoord tc = coord(tile);
         const int t = tc.t0 - 1 + pc;
         const bool tv = t >= 0 && t < Tn;
-        const T* base = in + (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
+        const long off = (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int f = tc.f0 - 1 + i;
-            regs[i] = load_chunk<T>(base + (long)i * Tn * 64, tv && f >= 0 && f < F);
+            regs[i] = load_chunk<T>(in + off + (long)i * Tn * 64, tv && f >= 0 && f < F);
+            if (BNIN) regs2[i] = load_chunk<T>(in2 + off + (long)i * Tn * 64, tv && f >= 0 && f < F);
         }
         {
             const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
-            regs[HR] = load_chunk<T>(in + (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8, htid < 160 && f >= 0 && f < F && te < Tn);
+            const long oe = (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8;
+            regs[HR] = load_chunk<T>(in + oe, htid < 160 && f >= 0 && f < F && te < Tn);
+            if (BNIN) regs2[HR] = load_chunk<T>(in2 + oe, htid < 160 && f >= 0 && f < F && te < Tn);
         }
     };
     auto write_tile = [&](int tile) {
@@ -423,11 +467,15 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int f = tc.f0 - 1 + i;
-            *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = xform_chunk<T>(regs[i], tv && f >= 0 && f < F, a.prologue, sc, sh, 0);
+            const bool ok = tv && f >= 0 && f < F;
+            *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = BNIN ? bnin_chunk(regs[i].u, regs2[i].u, ok, kin)
+                                                             : xform_chunk<T>(regs[i], ok, a.prologue, sc, sh, 0);
         }
         if (htid < 160) {
             const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
-            *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = xform_chunk<T>(regs[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, 0);
+            const bool ok = f >= 0 && f < F && te < Tn;
+            *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = BNIN ? bnin_chunk(regs[HR].u, regs2[HR].u, ok, kin)
+                                                                                       : xform_chunk<T>(regs[HR], ok, a.prologue, sc, sh, 0);
         }
     };
 
@@ -580,6 +628,8 @@ struct WgradArgs {
     float* partial;       // [gridDim.x * 2][9][64][64] f32
     int nb, F, T;
     int part_dy, part_z;
+    // BatchNorm-backward transform of the dy operand (see ConvArgs::in2): dy holds dz, dy2 the pre-BN activations (bf16 only)
+    const void* dy2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int pix_base, int ch_base, int lane) {
@@ -618,7 +668,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const uint16_t* p0, const uint16_t* p1
 // 8 waves = (co half) x (ci half) x (tap group: taps 0-4 | taps 5-8).  Every wave walks ALL pixels of the tile, so it only
 // needs 5 (4) accumulator fragments = 80 VGPRs; the registers that frees hold the NEXT tile (z halo + dy, 19 x 16 B per
 // thread) which is fetched from HBM while the current tile is on the matrix cores.
-template <typename T>
+template <typename T, bool BNIN = false>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t sY[Y_ELEMS];     // dy tile  [8*64 px][64 co]
     __shared__ __attribute__((aligned(16))) uint16_t sX[X_ELEMS];     // z halo tile [660 px][64 ci]
@@ -630,6 +680,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     const int ntiles = a.nb * tiles_f * tiles_t;
     const T* zin = (const T*)a.zin;
     const T* dy = (const T*)a.dy;
+    const T* dy2 = (const T*)a.dy2;
     const int cch = tid & 7;
 
     f32x16 acc[5];
@@ -658,6 +709,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 
     // staging as in the forward kernel: thread = (pixel column pc, 8-channel chunk), halo rows 0..9 + one chunk of columns 64/65
     Chunk<T> rz[X_ITERS], ry[8];
+    Chunk<T> ry2[BNIN ? 8 : 1];
     const int pc = tid >> 3;
     auto issue_loads = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
@@ -674,9 +726,12 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
             rz[HR] = load_chunk<T>(zin + (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8, tid < 160 && f >= 0 && f < F && te < Tn);
         }
         const int ty = tc.t0 + pc;
-        const T* yb = dy + (((long)tc.b * F + tc.f0) * Tn + ty) * 64 + cch * 8;
+        const long oy = (((long)tc.b * F + tc.f0) * Tn + ty) * 64 + cch * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ry[i] = load_chunk<T>(yb + (long)i * Tn * 64, tc.f0 + i < F && ty < Tn);
+        for (int i = 0; i < 8; ++i) {
+            ry[i] = load_chunk<T>(dy + oy + (long)i * Tn * 64, tc.f0 + i < F && ty < Tn);
+            if (BNIN) ry2[i] = load_chunk<T>(dy2 + oy + (long)i * Tn * 64, tc.f0 + i < F && ty < Tn);
+        }
     };
     auto write_tile = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
@@ -695,9 +750,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
             *(uint4*)&sX[swzc(hr * HC + TCOL + (pc & 1), TCOL + (pc & 1), cch)] = xform_chunk<T>(rz[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_z);
         }
         const int ty = tc.t0 + pc;
+        if constexpr (BNIN && sizeof(T) == 2) {
+            BnInConst kin;                                     // (live only while staging, like sc / sh)
+            bnin_setup(kin, a.bnin_aff, a.bnin_red, a.bnin_use_stats, (long)a.nb * F * Tn, cch * 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *(uint4*)&sY[swzc(i * 64 + pc, pc, cch)] = xform_chunk<T>(ry[i], tc.f0 + i < F && ty < Tn, 0, sc, sh, a.part_dy);
+            for (int i = 0; i < 8; ++i)
+                *(uint4*)&sY[swzc(i * 64 + pc, pc, cch)] = bnin_chunk(ry[i].u, ry2[i].u, tc.f0 + i < F && ty < Tn, kin);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *(uint4*)&sY[swzc(i * 64 + pc, pc, cch)] = xform_chunk<T>(ry[i], tc.f0 + i < F && ty < Tn, 0, sc, sh, a.part_dy);
+        }
     };
 
     const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -800,13 +863,32 @@ extern "C" int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* d
     return conv3x3_launch(dy, w, dz, SARSSL_BF16, SARSSL_BF16, nb, F, T, nullptr, nullptr, 0, nullptr, red, y, aff, stream);
 }
 
+// Data gradient of a 3x3 convolution whose incoming gradient still needs the BatchNorm + ReLU backward of the layer behind it:
+// dz_in = dL/d relu(bn(y)) (the previous data-gradient launch's output), y / aff / red = that BatchNorm's pre-activations, affine
+// [scale | shift | mean | rstd] and backward sums [s1 | s2] (sarssl_conv3x3_dgrad_bnred / sarssl_cl_bn_bwd_reduce); the normalised
+// gradient is formed while staging, never stored.  bf16, ping-pong kernel only (returns 1 when that kernel is disabled).
+extern "C" int sarssl_conv3x3_dgrad_bnin(const void* dz_in, const void* w, void* out, int nb, int F, int T, const void* y,
+                                         const float* aff, const double* red, int use_stats, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && y && aff && red, "sarssl_conv3x3_dgrad_bnin");
+    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
+    if (!use_pp) return 1;
+    ConvArgs a = {};
+    a.in = dz_in; a.w = w; a.out = out; a.nb = nb; a.F = F; a.T = T;
+    a.in2 = y; a.bnin_aff = aff; a.bnin_red = red; a.bnin_use_stats = use_stats;
+    const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
+    const int ncu = sarssl_cu_count();
+    conv3x3_fwd_pp_kernel<false, true><<<npairs < ncu ? npairs : ncu, 512, 0, (hipStream_t)stream>>>(a);
+    SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<bnin>");
+    return 0;
+}
+
 static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                           const float* scale, const float* shift, int precise, float* ws, double* stats, const void* bn_y,
                           const float* bn_aff, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_fwd");
     SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16, "sarssl_conv3x3_fwd(fused statistics: bf16 storage only)");
     if (stats && hipMemsetAsync(stats, 0, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    ConvArgs a;
+    ConvArgs a = {};
     a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
     a.in = in; a.w = w; a.out = out; a.acc_ws = nullptr; a.acc_in = 0; a.acc_out = 0;
@@ -842,11 +924,28 @@ extern "C" long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T) {
 }
 
 // dW: f32 [9][64][64] ([tap][co][ci]).  partial: workspace of sarssl_conv3x3_wgrad_workspace_bytes.
+// Weight gradient with the BatchNorm-backward transform on the dy operand (see sarssl_conv3x3_dgrad_bnin): dz_in, y_bn bf16.
+extern "C" int sarssl_conv3x3_wgrad_bnin(const void* dz_in, const void* y_bn, const float* aff_bn, const double* red_bn, int use_stats,
+                                         const void* zin, int nb, int F, int T, const float* scale, const float* shift, float* dW,
+                                         float* partial, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && y_bn && aff_bn && red_bn, "sarssl_conv3x3_wgrad_bnin");
+    WgradArgs a = {};
+    a.dy = dz_in; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
+    a.partial = partial; a.nb = nb; a.F = F; a.T = T;
+    a.dy2 = y_bn; a.bnin_aff = aff_bn; a.bnin_red = red_bn; a.bnin_use_stats = use_stats;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = conv_grid(nb, F, T);
+    conv3x3_wgrad_kernel<bf16, true><<<grid, 512, 0, st>>>(a);
+    wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, grid, dW, 0);
+    SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel<bnin>");
+    return 0;
+}
+
 extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T,
                                     const float* scale, const float* shift, float* dW, float* partial, int precise,
                                     void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_wgrad");
-    WgradArgs a;
+    WgradArgs a = {};
     a.dy = dy; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
     a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
     hipStream_t st = (hipStream_t)stream;

@@ -152,6 +152,7 @@ def stem_fwd(a0, pe, train, saved):
 
 _C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
 _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
+_BNIN = os.environ.get("SARSSL_BNIN", "1") != "0"             # layer-2 BatchNorm-backward normalisation folded into the conv staging
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 
@@ -195,12 +196,17 @@ def stem_bwd(dz4, pe, saved):
         dz2 = hip.conv3x3_fwd(dy3, _taps(pe[6])[1], precise=RT.precise)
     if red2 is None:
         red2 = hip.cl_bn_bwd_reduce(dz2, y2, 64, aff2, RELU)
-    dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2)
     bn_param_grads(pe[4], red2, 64)
-    # first 3x3 conv
-    dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise)
+    # first 3x3 conv.  The normalised gradient dy2 = BatchNorm/ReLU backward of (dz2, y2) has two consumers (this layer's weight and
+    # data gradients): in bf16 both form it while staging their tiles, so it is never written (cl_bn_bwd_apply: 3 x 537 MB at B = 64)
+    dz1 = hip.conv3x3_dgrad_bnin(dz2, _taps(pe[3])[1], y2, aff2, red2, train) if (_BNIN and RT.dtype == torch.bfloat16) else None
+    if dz1 is not None:
+        dW = hip.conv3x3_wgrad_bnin(dz2, y2, aff2, red2, y1, aff1[0], aff1[1], train)
+    else:
+        dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2)
+        dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise)
+        dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
     gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
-    dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
     if _C1_FUSED == 2:      # everything the first layer needs from (dz1, y1, a0) in one pass: BN sums, dgamma/dbeta, dW1
         hip.stem_c1_bwd(dz1, y1, a0, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
         return None
@@ -219,13 +225,30 @@ def _p(drop, train):
     return float(drop.p) if train else 0.0
 
 
+def _replaying(train):
+    return train and RT.replay is not None
+
+
 def ffn_fwd(x, ff, factor, train, saved, out=None):
     """x + factor * FeedForwardModule(x)  (conformer/feed_forward.py:47-57, Conformer.py:60-67)."""
     seq = ff.sequential
     ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
-    s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
     hpre = torch.empty((x.shape[0], seq[1].linear.weight.shape[0]), dtype=x.dtype, device=x.device)
+    if _replaying(train) and (p1 > 0 or p2 > 0):          # host-drawn masks in the reference's order: hidden, then output
+        a = mm_nt(ln, wt(seq[1].linear.weight), bias=seq[1].linear.bias.data, act=SWISH, preact=hpre)
+        s1 = RT.replay.mask(tuple(a.shape), p1, x.device, x.dtype) if p1 > 0 else 0
+        if p1 > 0:
+            a = a * s1
+        y = mm_nt(a, wt(seq[4].linear.weight), bias=seq[4].linear.bias.data)
+        s2 = RT.replay.mask(tuple(y.shape), p2, x.device, x.dtype) if p2 > 0 else 0
+        y = torch.add(x, y * s2 if p2 > 0 else y, alpha=factor)
+        if out is not None:
+            out.copy_(y)
+            y = out
+        saved.append((x, ln, stats, hpre, a, p1, s1, p2, s2, factor))
+        return y
+    s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
     a = mm_nt(ln, wt(seq[1].linear.weight), bias=seq[1].linear.bias.data, act=SWISH, preact=hpre, p_drop=p1, seed=s1)
     y = mm_nt(a, wt(seq[4].linear.weight), bias=seq[4].linear.bias.data, p_drop=p2, seed=s2, out_scale=factor,
               resid=x, ldr=x.stride(0), res_scale=1.0, out=out, ldc=(out.stride(0) if out is not None else None))
@@ -236,11 +259,19 @@ def ffn_fwd(x, ff, factor, train, saved, out=None):
 def ffn_bwd(dy, ff, saved):
     x, ln, stats, hpre, a, p1, s1, p2, s2, factor = saved.pop()
     seq = ff.sequential
-    dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
-    mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
-    hip.colsum(dz2, gbuf(seq[4].linear.bias))
-    # dh = (dz2 @ W2) * dropout_mask1 * swish'(hpre): activation backward fused into the GEMM epilogue
-    dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
+    if torch.is_tensor(s1) or torch.is_tensor(s2):        # replayed masks (see ffn_fwd)
+        dz2 = (dy * s2 if torch.is_tensor(s2) else dy) * factor
+        mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
+        hip.colsum(dz2, gbuf(seq[4].linear.bias))
+        dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH)
+        if torch.is_tensor(s1):
+            dh = dh * s1
+    else:
+        dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
+        mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
+        hip.colsum(dz2, gbuf(seq[4].linear.bias))
+        # dh = (dz2 @ W2) * dropout_mask1 * swish'(hpre): activation backward fused into the GEMM epilogue
+        dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
     mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight))
     hip.colsum(dh, gbuf(seq[1].linear.bias))
     dln = mm_nn(dh, wt(seq[1].linear.weight))
@@ -303,7 +334,8 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     pa = _p(att.dropout, train)
     sa = RT.next_seed() if pa > 0 else 0
     scale = 1.0 / math.sqrt(d)                                                               # 1/sqrt(d_model), attention.py:57
-    if _FUSED_ATTN and hip.relpos_attn_supported(T, dh, RT.dtype):
+    replay = _replaying(train) and (pa > 0 or _p(mod.dropout, train) > 0)
+    if _FUSED_ATTN and not replay and hip.relpos_attn_supported(T, dh, RT.dtype):
         # fused path (csrc/attention.hip): the positional-score GEMM writes its product directly in the relative-shift layout and
         # one flash-style kernel does content score + shifted bias + softmax + dropout + PV; no (B,H,T,T) score / probability tensor
         bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
@@ -320,15 +352,26 @@ def mhsa_fwd(x, mod, B, T, train, saved):
                        out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
     pscore = hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh),
                       out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
-    p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, pa, sa)
+    if replay:                                             # host-drawn masks: attention probabilities, then the module output
+        p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, 0.0, 0)
+        if pa > 0:
+            sa = RT.replay.mask((B, H, T, T), pa, x.device, RT.dtype)
+            pd = p * sa
+    else:
+        p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, pa, sa)
     del content, pscore
     ctx = torch.empty((M, d), dtype=RT.dtype, device=x.device)
     hip.gemm(pd, v, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=ldk, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(T * ldk, dh), out=ctx, ldc=d, sC=(T * d, dh), precise=RT.precise)
     po = _p(mod.dropout, train)
-    so = RT.next_seed() if po > 0 else 0
-    y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,
-              resid=x, ldr=x.stride(0), res_scale=1.0)
+    if replay:
+        y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data)
+        so = RT.replay.mask(tuple(y.shape), po, x.device, RT.dtype) if po > 0 else 0
+        y = x + (y * so if po > 0 else y)
+    else:
+        so = RT.next_seed() if po > 0 else 0
+        y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,
+                  resid=x, ldr=x.stride(0), res_scale=1.0)
     saved.append((x, ln, stats, qu, qv, k, v, pos, pe, p, pd, pa, sa, ctx, po, so, B, T))
     return y
 
@@ -340,7 +383,10 @@ def mhsa_bwd(dy, mod, saved):
     M, nbh = B * T, B * H
     dev = x.device
     fused_attn = pd.dtype == torch.float32 and pd.dim() == 3          # fused forward saved (bias, lse) in place of (p, pd)
-    dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
+    if torch.is_tensor(so):
+        dout = dy * so                                     # replayed mask
+    else:
+        dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
     mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight))
     hip.colsum(dout, gbuf(att.out_proj.linear.bias))
     dctx = mm_nn(dout, wt(att.out_proj.linear.weight))
@@ -382,7 +428,10 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
                    out_dtype=torch.float32, precise=RT.precise, out_shape=(B, H, T, T))
     hip.gemm(pd, dctx, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(T * d, dh), out=dv, ldc=ldg, sC=(T * ldg, dh), precise=RT.precise)
-    ds = hip.softmax_bwd(dpd, p, scale, pa, sa)                                              # d content score
+    if torch.is_tensor(sa):                                # replayed mask on the probabilities
+        ds = hip.softmax_bwd(dpd * sa.float(), p, scale, 0.0, 0)
+    else:
+        ds = hip.softmax_bwd(dpd, p, scale, pa, sa)                                          # d content score
     del dpd
     dps = hip.relshift_bwd(ds)                                                               # d (unshifted) pos score
     hip.gemm(ds, k, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=ldk, nbatch=nbh, batch_inner=H,
@@ -428,8 +477,13 @@ def convmod_fwd(x, cm, B, T, train, saved):
     aff = bn_affine(c, d, bn, train)
     s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
     po = _p(seq[8], train)
-    so = RT.next_seed() if po > 0 else 0
-    y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
+    if _replaying(train) and po > 0:                       # the reference draws this mask on the (B, d, T) conv output
+        y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data)
+        so = RT.replay.mask((B, d, T), po, x.device, RT.dtype, to_layout=lambda m: m.permute(0, 2, 1).reshape(B * T, d))
+        y = x + y * so
+    else:
+        so = RT.next_seed() if po > 0 else 0
+        y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
     saved.append((x, ln, stats, h, g, c, aff, s, po, so, B, T, train))
     return y
 
@@ -439,7 +493,10 @@ def convmod_bwd(dy, cm, saved):
     seq = cm.sequential
     d = x.shape[1]
     pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
-    dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
+    if torch.is_tensor(so):
+        dout = dy * so
+    else:
+        dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
     mm_tn_acc(dout, s, gbuf(pw2.weight))
     hip.colsum(dout, gbuf(pw2.bias))
     ds = mm_nn(dout, wt(pw2.weight).view(d, d))
@@ -493,10 +550,11 @@ def encoder_bwd(dy, enc, saved):
 
 # ------------------------------------------------------------------------------------------------ decoder + loss
 def decoder_fwd(e, dec, saved):
-    """EmbedDecoder ['','fc'] (code/model.py:295-301, 321-334): Linear -> ReLU -> Linear."""
+    """EmbedDecoder ['','fc'] (code/model.py:295-301, 321-334): Linear -> ReLU -> Linear.  Stays in bf16 in 'fp8' mode: it produces
+    the predicted spectrogram itself, and config 5 names the attention / FFN GEMMs only."""
     l1, l2 = dec.proj[0], dec.proj[2]
-    h = mm_nt(e, wt(l1.weight), bias=l1.bias.data, act=RELU)
-    pred = mm_nt(h, wt(l2.weight), bias=l2.bias.data)
+    h = mm_nt(e, wt(l1.weight), fp8=False, bias=l1.bias.data, act=RELU)
+    pred = mm_nt(h, wt(l2.weight), fp8=False, bias=l2.bias.data)
     saved.append((e, h))
     return pred
 
@@ -506,7 +564,7 @@ def decoder_bwd(dpred, dec, saved):
     l1, l2 = dec.proj[0], dec.proj[2]
     mm_tn_acc(dpred, h, gbuf(l2.weight))
     hip.colsum(dpred, gbuf(l2.bias))
-    dh = mm_nn(dpred, wt(l2.weight), aux=h, aux_act=RELU)
+    dh = mm_nn(dpred, wt(l2.weight), fp8=False, aux=h, aux_act=RELU)
     mm_tn_acc(dh, e, gbuf(l1.weight))
     hip.colsum(dh, gbuf(l1.bias))
-    return mm_nn(dh, wt(l1.weight))
+    return mm_nn(dh, wt(l1.weight), fp8=False)

@@ -315,6 +315,39 @@ def conv3x3_dgrad_bnred(dy, w_tap_dgrad, y, aff):
     return dz, red
 
 
+def conv3x3_dgrad_bnin(dz_in, w_tap_dgrad, y, aff, red, use_stats=True):
+    """Data gradient conv3x3(dy, flipped taps) with dy = BatchNorm+ReLU backward of (dz_in, y, aff, red) formed while staging (bf16).
+    Returns None when the fused kernel is disabled (the caller then runs cl_bn_bwd_apply + conv3x3_fwd)."""
+    _need_cuda(dz_in, w_tap_dgrad, y, aff, red)
+    B, F, T, C = dz_in.shape
+    assert C == 64 and dz_in.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.shape == dz_in.shape
+    assert dz_in.is_contiguous() and y.is_contiguous() and aff.is_contiguous() and aff.numel() == 256 and red.dtype == torch.float64
+    out = torch.empty_like(dz_in)
+    fn = _lib.lib().sarssl_conv3x3_dgrad_bnin
+    with _Timed("conv3x3_dgrad_bnin"):
+        rc = fn(_p(dz_in), _p(w_tap_dgrad), _p(out), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red), c_int(1 if use_stats else 0),
+                _stream())
+    if rc == 1:
+        return None
+    _lib.check(rc, "sarssl_conv3x3_dgrad_bnin")
+    return out
+
+
+def conv3x3_wgrad_bnin(dz_in, y_bn, aff_bn, red_bn, zin, scale=None, shift=None, use_stats=True):
+    """Weight gradient [9][64][64] f32 with the same BatchNorm-backward transform on the gradient operand (bf16)."""
+    _need_cuda(dz_in, y_bn, zin)
+    B, F, T, C = zin.shape
+    assert dz_in.dtype == torch.bfloat16 and y_bn.dtype == torch.bfloat16 and zin.dtype == torch.bfloat16
+    nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
+    nbytes.restype = c_long
+    part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), zin.device, "wgrad_part")
+    dW = torch.empty((9, 64, 64), dtype=torch.float32, device=zin.device)
+    with _Timed("conv3x3_wgrad_bnin"):
+        _lib.call("sarssl_conv3x3_wgrad_bnin", _p(dz_in), _p(y_bn), _p(aff_bn), _p(red_bn), c_int(1 if use_stats else 0), _p(zin),
+                  c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW), _p(part), _stream())
+    return dW
+
+
 def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False):
     """-> dW f32 [9][64][64] ([tap][co][ci])."""
     _need_cuda(dy, zin)

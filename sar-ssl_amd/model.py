@@ -282,8 +282,8 @@ class SARSSL(nn.Module):
     def _side_stream(self, device):
         """Second HIP stream for the spat encoder (None disables the two-stream schedule: SARSSL_TWO_STREAMS=0)."""
         import os
-        if os.environ.get("SARSSL_TWO_STREAMS", "1") == "0":
-            return None
+        if os.environ.get("SARSSL_TWO_STREAMS", "1") == "0" or RT.replay is not None:       # replayed dropout masks are drawn in the
+            return None                                                                    # reference's order: spec encoder first
         s = self.__dict__.get("_side")
         if s is None:
             s = self.__dict__["_side"] = torch.cuda.Stream(device=device)

@@ -19,6 +19,7 @@ class _RT:
     dtype = torch.bfloat16
     precise = False
     fp8 = False
+    replay = None          # DropoutReplay: masks drawn on the host in the reference's order (parity tests only)
     _seed = 0x5A25_5151_0000_0000
     _ctr = 0
 
@@ -34,10 +35,32 @@ class _RT:
 RT = _RT()
 
 
+class DropoutReplay:
+    """Dropout masks drawn with torch's CPU generator in the reference's order and layouts, instead of the kernels' counter hash.
+
+    ``nn.Dropout`` on the reference's CPU path is ``x * empty_like(x).bernoulli_(1 - p) / (1 - p)`` (checked bit for bit in
+    tests/test_host_cpu.py), seven draws per Conformer block in the fixed order FFN(hidden, out) -> attention(probabilities, out) ->
+    conv module(out) -> FFN(hidden, out), spec encoder before spat encoder (feed_forward.py:51,53,
+    attention.py:98,151, convolution.py:145).  With ``RT.replay`` set (and ``torch.manual_seed`` called like the reference run did),
+    the engine takes its masks from here - unfused and slower, single stream, and only meant for comparing a dropout-ON trajectory
+    with the reference's (fixture F5(ii))."""
+
+    def __init__(self):
+        self.draws = 0
+
+    def mask(self, ref_shape, p, device, dtype, to_layout=None):
+        """keep/(1-p) mask drawn in the reference's tensor layout ``ref_shape``; ``to_layout`` maps it to the engine's layout."""
+        m = torch.empty(ref_shape, dtype=torch.float32).bernoulli_(1.0 - p)
+        self.draws += 1
+        if to_layout is not None:
+            m = to_layout(m)
+        return (m / (1.0 - p)).contiguous().to(device=device, dtype=dtype)
+
+
 def set_precision(mode):
     """'bf16' (fast path), 'fp32' (split-bf16 precise path) or 'fp8' (bf16 storage; the Linear / pointwise-conv forward and
-    input-gradient GEMMs of the Conformer blocks and the decoder on the OCP-e4m3 block-scaled MFMA with per-tensor scales chosen on
-    the device - BASELINE.json config 5; everything else as 'bf16')."""
+    input-gradient GEMMs of the Conformer blocks - FFN, q/k/v and output projections, conv-module pointwise convs - on the OCP-e4m3
+    block-scaled MFMA with per-tensor scales chosen on the device: BASELINE.json config 5; everything else as 'bf16')."""
     if mode in ("bf16", torch.bfloat16):
         RT.dtype, RT.precise, RT.fp8 = torch.bfloat16, False, False
     elif mode in ("fp32", "f32", torch.float32):

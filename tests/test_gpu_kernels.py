@@ -269,6 +269,32 @@ def test_conv3x3_full_batch_shape_against_the_precise_f32_kernels():
     check("conv_full.wgrad_prologue", _relerr(dWp, dWpref.cpu()), 1e-4)
 
 
+@pytest.mark.parametrize("use_stats", [True, False])
+@pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64), (16, 256, 256)])
+def test_conv3x3_with_bn_backward_input_transform(B, F, T, use_stats):
+    """Data- and weight-gradient launches that form the BatchNorm + ReLU backward of their incoming gradient while staging, against
+    the separate normalisation pass (cl_bn_bwd_apply) followed by the plain launches: same bf16 rounding point, so near-identical."""
+    from sar_ssl_amd import hip
+    from conftest import check
+    dev = _dev()
+    g = torch.Generator().manual_seed(17 * B + T)
+    mk = lambda: _cl(torch.randn((B, 64, F, T), generator=g)).to(torch.bfloat16).to(dev)
+    dz, y, zin = mk(), mk(), mk()
+    w = (torch.randn((9, 64, 64), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    sc, sh = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    aff = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.1,
+                       torch.rand(64, generator=g) + 0.7]).to(dev).contiguous()
+    red = hip.cl_bn_bwd_reduce(dz, y, 64, aff, 1)
+    dy = hip.cl_bn_bwd_apply(dz, y, 64, aff, 1, False, use_stats, red)
+    want_dz = hip.conv3x3_fwd(dy, w)
+    want_dW = hip.conv3x3_wgrad(dy, zin, sc, sh)
+    got_dz = hip.conv3x3_dgrad_bnin(dz, w, y, aff, red, use_stats)
+    got_dW = hip.conv3x3_wgrad_bnin(dz, y, aff, red, zin, sc, sh, use_stats)
+    assert got_dz is not None
+    check("conv_bnin.dgrad[%dx%dx%d,stats=%d]" % (B, F, T, use_stats), _relerr(got_dz.float(), want_dz.float()), 5e-3)
+    check("conv_bnin.wgrad[%dx%dx%d,stats=%d]" % (B, F, T, use_stats), _relerr(got_dW, want_dW), 5e-3)
+
+
 @pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64)])
 def test_conv3x3_dgrad_with_fused_bn_backward_sums(B, F, T):
     """The data-gradient launch that also accumulates the BatchNorm-backward sums of the layer in front must store exactly the

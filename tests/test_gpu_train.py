@@ -159,6 +159,48 @@ def test_checkpoint_written_by_reference_resumes(tmp_path):
         runtime.set_precision("bf16")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_dropout_on_curve_with_replayed_masks_vs_reference(prec):
+    """SURVEY fixture F5(ii) / Q17: the reference's dropout-ON training run (p = 0.1, 40 Adam steps, batch 8).  The build draws the
+    step's 28 dropout masks on the host with torch's CPU generator in the reference's order and layouts (runtime.DropoutReplay,
+    seeded like the reference run) instead of its own counter hash, so the whole stochastic trajectory is comparable, not just
+    its statistics."""
+    from sar_ssl_amd import hip, model, runtime, synth
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLD, "f5_curve_dropout.npz"))
+    B, n = int(z["B"]), len(z["loss"])
+    runtime.set_precision(prec)
+    runtime.RT.replay = runtime.DropoutReplay()
+    try:
+        man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+        net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev)
+        net.load_state_dict(recipes.recipe_state_dict(man, int(z["weight_seed"])))
+        net.to(dev).train()                                            # dropout stays at the reference default p = 0.1
+        flat = runtime.FlatParams(net)
+        opt = runtime.FusedAdam(flat, lr=float(z["lr"]))
+        opt.zero_grad()
+        pool = torch.from_numpy(synth.make_batch(0, int(z["pool"]))).to(dev)
+        losses = []
+        for s in range(n):
+            sig = pool[(s * B) % 64:(s * B) % 64 + B]
+            x = hip.stft_frontend(sig)
+            random.seed(int(z["mask_seed_base"]) + s)
+            torch.manual_seed(int(z["dropout_seed_base"]) + s)
+            loss, _, _ = net(x)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.detach())
+        assert runtime.RT.replay.draws == 28 * n                       # 7 draws x (1 spec + 3 spat) blocks per step
+        got = torch.stack(losses).cpu().numpy().astype(np.float64)
+        rel = np.abs(got - z["loss"]) / z["loss"]
+        check("curve_dropout_on.%s.first10" % prec, rel[:10].max(), 1e-3 if prec == "fp32" else 2e-3)
+        check("curve_dropout_on.%s.max" % prec, rel.max(), 1e-3 if prec == "fp32" else 3e-3)
+    finally:
+        runtime.RT.replay = None
+        runtime.set_precision("bf16")
+
+
 def test_learner_epoch_and_checkpoint_roundtrip(tmp_path):
     from sar_ssl_amd import learner as L, model, runtime, synth
     dev = torch.device("cuda:0")

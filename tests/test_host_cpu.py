@@ -237,3 +237,19 @@ def test_reference_written_checkpoint_file_matches_our_state_dict_layout():
     want = recipes.recipe_state_dict(man, int(meta["weight_seed"]))
     for k, v in net.state_dict().items():
         assert torch.equal(v, want[k]), k
+
+
+def test_dropout_replay_draws_the_reference_masks():
+    """runtime.DropoutReplay: ``nn.Dropout`` on the CPU path is x * empty_like(x).bernoulli_(1 - p) / (1 - p) with consecutive
+    draws from torch's global generator - what the replay reproduces (also for the conv module's (B, d, T) draw order)."""
+    from sar_ssl_amd import runtime
+    drop = torch.nn.Dropout(0.1).train()
+    x1, x2 = torch.randn(3, 5, 8, requires_grad=True) + 4, torch.randn(2, 6, 7) + 4
+    torch.manual_seed(123)
+    y1, y2 = drop(x1), drop(x2)
+    rp = runtime.DropoutReplay()
+    torch.manual_seed(123)
+    m1 = rp.mask((3, 5, 8), 0.1, "cpu", torch.float32)
+    m2 = rp.mask((2, 6, 7), 0.1, "cpu", torch.float32, to_layout=lambda m: m.permute(0, 2, 1).reshape(14, 6))
+    assert rp.draws == 2
+    assert torch.allclose(y1.detach(), x1.detach() * m1) and torch.allclose(y2.permute(0, 2, 1).reshape(14, 6), x2.permute(0, 2, 1).reshape(14, 6) * m2)

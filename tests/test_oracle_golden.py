@@ -280,3 +280,22 @@ def test_oracle_pretrain_epoch_vs_reference_pretrain_epoch():
     tot_ref = sum(v * v for v in ref.values()) ** 0.5
     tot = sum(float((sd[k].double() - init[k].double()).norm()) ** 2 for k in ref) ** 0.5
     assert abs(tot / tot_ref - 1) < 1e-3
+
+
+def test_oracle_dropout_on_steps_vs_reference_curve():
+    """Fixture F5(ii): with the reference's seeds (python ``random`` for the masks, ``torch.manual_seed`` for the 28 dropout draws
+    per step) the oracle reproduces the reference's dropout-ON losses - i.e. it consumes the generator in the same order and layouts."""
+    import random
+    from sar_ssl_amd import synth
+    z = np.load(os.path.join(GOLD, "f5_curve_dropout.npz"))
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    sd, state = recipes.recipe_state_dict(man, int(z["weight_seed"])), {}
+    B = int(z["B"])
+    pool = torch.from_numpy(synth.make_batch(0, int(z["pool"])))
+    torch.set_num_threads(8)
+    for s in range(2):
+        random.seed(int(z["mask_seed_base"]) + s)
+        torch.manual_seed(int(z["dropout_seed_base"]) + s)
+        loss, diff = orc.train_step(pool[s * B:(s + 1) * B], sd, state, float(z["lr"]), p_drop=float(z["p_drop"]))
+        assert abs(loss / float(z["loss"][s]) - 1) < 2e-5, (s, loss)
+        assert abs(diff / float(z["diff"][s]) - 1) < 1e-6
