@@ -69,14 +69,15 @@ int sarssl_gemm_fp8(const void* A8, const void* B8, const float* sa, const float
 /* ---- fused relative-position attention, bf16 (RelativeMultiHeadAttention.forward, attention.py:87-101, and its backward):
  *      softmax(((q+u) k^T + bias) * scale) -> dropout -> @ v per (batch, head) without materialising scores / probabilities.
  *      qu, k, v: bf16 [B*T][ld], head h at column h*dh; bias: bf16 (B,H,T,T) = shifted positional score (a sarssl_gemm with
- *      c_row_shift), element (i, i+1) ignored; ctx: bf16 [B*T][ldc]; lse: f32 (B,H,T).  sarssl_relpos_attn_supported: shapes the
+ *      c_row_shift), element (i, i+1) ignored; ctx: bf16 [B*T][ldc]; ctx32: f32 [B*T][H*dh] unrounded copy for backward; lse: f32 (B,H,T).  sarssl_relpos_attn_supported: shapes the
  *      fused kernels take (T % 8 == 0, dh in {32, 64, 128}); otherwise use the GEMM + sarssl_softmax_relshift_fwd path.
  *      Backward: dsum = f32 (B,H,T) workspace; dbias bf16 (B,H,T,T) in the shifted layout (feed sarssl_relshift_bwd). */
 int sarssl_relpos_attn_supported(int T, int dh);
 int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, void* ctx, long ldc,
-                           float* lse, int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed, void* stream);
-int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, const void* ctx,
-                           long ldc, const float* lse, const void* dctx, long lddc, void* dqu, long lddq, void* dk, void* dv,
+                           float* ctx32, float* lse, int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed,
+                           void* stream);
+int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, const float* ctx32,
+                           const float* lse, const void* dctx, long lddc, void* dqu, long lddq, void* dk, void* dv,
                            long lddk, void* dbias, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,
                            unsigned long long seed, void* stream);
 
@@ -167,6 +168,9 @@ int sarssl_axpby(const void* x, const void* y, float a, float b, long n, void* o
 int sarssl_axpby2d(const void* x, long ldx, const void* y, long ldy, float a, float b, long M, int N, void* out, long ldo,
                    int dtype, void* stream);
 int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream);
+/* up to 24 independent column sums in one launch (bias gradients of one backward stage): outs[q][n] += sum_m xs[q][m][n] */
+int sarssl_colsum_multi(const void* const* xs, const long* ldxs, const long* Ms, const int* Ns, float* const* outs, int n, int dtype,
+                        void* stream);
 int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,
                    void* dh, int dtype, void* stream);
 int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);

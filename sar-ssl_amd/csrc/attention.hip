@@ -19,6 +19,9 @@ struct AttnArgs {
     const bf16* k; const bf16* v; long ldk;
     const bf16* bias;                  // (B,H,T,T) shifted positional score (unscaled)
     bf16* ctx; long ldc;               // [B*T][ldc]
+    float* ctx32;                      // [B*T][H*DH] f32 copy of ctx before rounding (forward out, backward in): D_i = dctx_i . ctx_i
+                                       // enters dS as a small difference (flat softmax: 1/sqrt(d_model) scaling), so it must not
+                                       // carry the bf16 rounding of ctx
     float* lse;                        // (B,H,T): log2-domain log-sum-exp of the scaled scores
     const bf16* dctx; long lddc;       // backward: gradient of ctx
     bf16* dqu; long lddq;              // backward outputs
@@ -226,14 +229,17 @@ __global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(AttnArgs a) {
     if (row_ok) {
         if (half == 0 && a.lse) a.lse[(long)bh * T + i] = m_run + log2f(l_tot);
         bf16* out = a.ctx + ((long)b * T + i) * a.ldc + h * DH;
+        float* out32 = a.ctx32 ? a.ctx32 + ((long)b * T + i) * ((long)a.H * DH) + h * DH : nullptr;
 #pragma unroll
         for (int c = 0; c < DH / 32; ++c)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                const float4 v = make_float4(o[c][4 * g + 0] * inv_l, o[c][4 * g + 1] * inv_l, o[c][4 * g + 2] * inv_l, o[c][4 * g + 3] * inv_l);
                 uint2 u;
-                u.x = pack2_bf16(o[c][4 * g + 0] * inv_l, o[c][4 * g + 1] * inv_l);
-                u.y = pack2_bf16(o[c][4 * g + 2] * inv_l, o[c][4 * g + 3] * inv_l);
+                u.x = pack2_bf16(v.x, v.y);
+                u.y = pack2_bf16(v.z, v.w);
                 *(uint2*)(out + c * 32 + 8 * g + 4 * half) = u;
+                if (out32) *(float4*)(out32 + c * 32 + 8 * g + 4 * half) = v;
             }
     }
 }
@@ -247,9 +253,9 @@ __global__ void relpos_attn_dsum_kernel(AttnArgs a, int dh) {
     if (row >= nrow) return;
     const long bt = row / a.H; const int h = (int)(row % a.H);
     const bf16* x = a.dctx + bt * a.lddc + h * dh;
-    const bf16* y = a.ctx + bt * a.ldc + h * dh;
+    const float* y = a.ctx32 + bt * ((long)a.H * dh) + h * dh;
     float s = 0.f;
-    for (int c = lane; c < dh; c += 64) s += ld_f(x + c) * ld_f(y + c);
+    for (int c = lane; c < dh; c += 64) s += ld_f(x + c) * y[c];
     s = wave_sum(s);
     if (lane == 0) {
         const long b = bt / a.T, i = bt % a.T;
@@ -571,15 +577,15 @@ static int attn_check(int B, int H, int T, int dh, long ldq, long ldk, const cha
 extern "C" int sarssl_relpos_attn_supported(int T, int dh) { return (T > 0 && T % 8 == 0 && (dh == 32 || dh == 64 || dh == 128)) ? 1 : 0; }
 
 // qu, k, v: bf16 [B*T][ld] with head h at column h*dh; bias: bf16 (B,H,T,T) shifted positional scores (unscaled);
-// ctx: bf16 [B*T][ldc]; lse: f32 (B,H,T) (log2 domain, saved for backward).
+// ctx: bf16 [B*T][ldc]; ctx32 (optional, needed for backward): f32 [B*T][H*dh]; lse: f32 (B,H,T) (log2 domain, saved for backward).
 extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, void* ctx,
-                                      long ldc, float* lse, int B, int H, int T, int dh, float scale, float p_drop,
+                                      long ldc, float* ctx32, float* lse, int B, int H, int T, int dh, float scale, float p_drop,
                                       unsigned long long seed, void* stream) {
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_fwd")) return -1;
     SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr, "sarssl_relpos_attn_fwd");
     AttnArgs a = {};
     a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
-    a.ctx = (bf16*)ctx; a.ldc = ldc; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    a.ctx = (bf16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
     dim3 grid((T + 127) / 128, B * H);
     hipStream_t st = (hipStream_t)stream;
     if (dh == 128) relpos_attn_fwd_kernel<128><<<grid, 256, 0, st>>>(a);
@@ -592,14 +598,14 @@ extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, c
 // Backward of sarssl_relpos_attn_fwd.  dsum: f32 workspace (B,H,T).  Outputs: dqu [B*T][lddq], dk / dv [B*T][lddk] (head h at
 // column h*dh), dbias bf16 (B,H,T,T) = gradient of the shifted positional score (the element (i, i+1) carries no meaning).
 extern "C" int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias,
-                                      const void* ctx, long ldc, const float* lse, const void* dctx, long lddc, void* dqu, long lddq,
+                                      const float* ctx32, const float* lse, const void* dctx, long lddc, void* dqu, long lddq,
                                       void* dk, void* dv, long lddk, void* dbias, float* dsum, int B, int H, int T, int dh,
                                       float scale, float p_drop, unsigned long long seed, void* stream) {
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_bwd")) return -1;
-    SARSSL_REQUIRE(lddc % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && dsum != nullptr && lse != nullptr, "sarssl_relpos_attn_bwd");
+    SARSSL_REQUIRE(lddc % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && dsum != nullptr && lse != nullptr && ctx32 != nullptr, "sarssl_relpos_attn_bwd");
     AttnArgs a = {};
     a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
-    a.ctx = (bf16*)ctx; a.ldc = ldc; a.lse = (float*)lse; a.dctx = (const bf16*)dctx; a.lddc = lddc;
+    a.ctx32 = (float*)ctx32; a.lse = (float*)lse; a.dctx = (const bf16*)dctx; a.lddc = lddc;
     a.dqu = (bf16*)dqu; a.lddq = lddq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddk = lddk; a.dbias = (bf16*)dbias; a.dsum = dsum;
     a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
     hipStream_t st = (hipStream_t)stream;

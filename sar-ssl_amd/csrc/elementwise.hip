@@ -467,6 +467,43 @@ __global__ void colsum_kernel(const T* __restrict__ x, long ldx, long M, int N, 
         atomicAdd(&out[col0 + c], acc);
     }
 }
+// Several independent column sums in ONE launch (the ~46 bias-gradient reductions of a backward pass were 8 us launches each):
+// problem q: out_q[n] += sum_m x_q[m][n].  Workgroups are numbered through the problems' (column tile, row slice) grids.
+#define COLSUM_MAXP 24
+struct ColsumMulti {
+    const void* x[COLSUM_MAXP]; long ld[COLSUM_MAXP]; long M[COLSUM_MAXP]; int N[COLSUM_MAXP]; float* out[COLSUM_MAXP];
+    int gx[COLSUM_MAXP], gy[COLSUM_MAXP], first[COLSUM_MAXP + 1];
+    int n;
+};
+template <typename T>
+__global__ void colsum_multi_kernel(ColsumMulti a) {
+    __shared__ float sred[256][5];
+    int q = 0;
+    while (q + 1 < a.n && (int)blockIdx.x >= a.first[q + 1]) ++q;
+    const int local = blockIdx.x - a.first[q];
+    const int bx = local % a.gx[q], by = local / a.gx[q];
+    const T* x = (const T*)a.x[q];
+    const long ldx = a.ld[q], M = a.M[q];
+    const int N = a.N[q];
+    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
+    const int col0 = bx * 64, col = col0 + cgp * 4;
+    float s[4] = {0, 0, 0, 0};
+    if (col < N) {
+        for (long m = (long)by * 16 + rslot; m < M; m += (long)a.gy[q] * 16) {
+            const float4 v = ld4(x + m * ldx + col);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sred[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && col0 + threadIdx.x < N) {
+        const int c = threadIdx.x;
+        float acc = 0.f;
+        for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][c & 3];
+        atomicAdd(&a.out[q][col0 + c], acc);
+    }
+}
 // dh = dz * act'(h) * dropout_mask(seed, idx) * gscale
 //   act 1: relu, h_is_post = 1 means h holds relu output;  act 2: swish with h = pre-activation;  act 0: none
 template <typename T>
@@ -725,6 +762,28 @@ extern "C" int sarssl_colsum(const void* x, long ldx, long M, int N, float* out,
     if (gy > cap) gy = cap;
     DISPATCH_T(dtype, (colsum_kernel<T><<<dim3(gx, (unsigned)gy), 256, 0, ST>>>((const T*)x, ldx, M, N, out)));
     SARSSL_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+// n <= 24 problems: xs[q] (dtype, row stride ldxs[q], Ms[q] x Ns[q], Ns[q] % 4 == 0) -> outs[q][Ns[q]] += column sums
+extern "C" int sarssl_colsum_multi(const void* const* xs, const long* ldxs, const long* Ms, const int* Ns, float* const* outs, int n,
+                                   int dtype, void* stream) {
+    SARSSL_REQUIRE(n > 0 && n <= COLSUM_MAXP, "sarssl_colsum_multi");
+    ColsumMulti a;
+    a.n = n;
+    int total = 0;
+    for (int q = 0; q < n; ++q) {
+        SARSSL_REQUIRE((Ns[q] & 3) == 0 && (ldxs[q] & 3) == 0 && Ms[q] > 0, "sarssl_colsum_multi(shape)");
+        a.x[q] = xs[q]; a.ld[q] = ldxs[q]; a.M[q] = Ms[q]; a.N[q] = Ns[q]; a.out[q] = outs[q];
+        const int gx = (Ns[q] + 63) / 64;
+        long gy = (Ms[q] + 255) / 256; if (gy < 1) gy = 1;
+        long cap = 512 / gx; if (cap < 1) cap = 1;
+        if (gy > cap) gy = cap;
+        a.gx[q] = gx; a.gy[q] = (int)gy; a.first[q] = total;
+        total += gx * (int)gy;
+    }
+    a.first[n] = total;
+    DISPATCH_T(dtype, (colsum_multi_kernel<T><<<total, 256, 0, ST>>>(a)));
+    SARSSL_CHECK_LAUNCH("colsum_multi_kernel");
     return 0;
 }
 extern "C" int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,

@@ -152,7 +152,10 @@ def stem_fwd(a0, pe, train, saved):
 
 _C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
 _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
-_BNIN = os.environ.get("SARSSL_BNIN", "1") != "0"             # layer-2 BatchNorm-backward normalisation folded into the conv staging
+# layer-2 BatchNorm-backward normalisation folded into the conv staging: built and measured in round 2 - the fused pair costs 558 + 687 us
+# against 352 (cl_bn_bwd_apply) + 360 + 414 us (both consumers re-read y2, and the extra arithmetic lands in the VALU-bound staging
+# phase of the convolution kernels): 15.2 vs 14.8 ms/step.  Off by default; kept for the next attempt (tests cover it).
+_BNIN = os.environ.get("SARSSL_BNIN", "0") != "0"
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 
@@ -341,7 +344,7 @@ def mhsa_fwd(x, mod, B, T, train, saved):
         bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
         hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
                  sC=(H * T * T, T * T), c_row_shift=True)
-        ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa)
+        ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=torch.is_grad_enabled())   # lse = (ctx32, lse)
         po = _p(mod.dropout, train)
         so = RT.next_seed() if po > 0 else 0
         y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,
@@ -382,7 +385,7 @@ def mhsa_bwd(dy, mod, saved):
     H, dh, d = att.num_heads, att.d_head, att.d_model
     M, nbh = B * T, B * H
     dev = x.device
-    fused_attn = pd.dtype == torch.float32 and pd.dim() == 3          # fused forward saved (bias, lse) in place of (p, pd)
+    fused_attn = isinstance(pd, tuple)                                # fused forward saved (bias, (ctx32, lse)) in place of (p, pd)
     if torch.is_tensor(so):
         dout = dy * so                                     # replayed mask
     else:
@@ -402,7 +405,7 @@ def mhsa_bwd(dy, mod, saved):
     ldg = dqu.stride(0)
     scale = 1.0 / math.sqrt(d)
     if fused_attn:
-        dbias = hip.relpos_attn_bwd(qu, k, v, p, ctx, pd, dctx, dqu, dk, dv, B, H, T, dh, scale, pa, sa)      # p = bias, pd = lse here
+        dbias = hip.relpos_attn_bwd(qu, k, v, p, pd, dctx, dqu, dk, dv, B, H, T, dh, scale, pa, sa)      # p = bias, pd = (ctx32, lse) here
         dps = hip.relshift_bwd(dbias)                                                        # d (unshifted) pos score
         del dbias
     else:
@@ -444,10 +447,10 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
 def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev):
     """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
     dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
-    hip.colsum(dposb.view(B, T * d), dpos)
+    hip.colsum(dposb.view(B, T * d), dpos, now=True)                 # consumed right below
     dpos_rt = to_rt(dpos.view(T, d))
     mm_tn_acc(dpos_rt, pe, gbuf(att.pos_proj.linear.weight))
-    hip.colsum(dqu, gbuf(att.u_bias).view(-1))
+    hip.colsum(dqu, gbuf(att.u_bias).view(-1), now=True)             # dqu is overwritten (dq = dqu + dqv) just below
     hip.colsum(dqv, gbuf(att.v_bias).view(-1))
     dq = hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dqu)
     if fused is not None:
@@ -527,11 +530,13 @@ def block_fwd(x, blk, B, T, train, saved, out=None):
 def block_bwd(dy, blk, saved):
     seq = blk.sequential
     x, stats = saved.pop()
-    d = hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias))
-    d = ffn_bwd(d, seq[3].module, saved)
-    d = convmod_bwd(d, seq[2].module, saved)
-    d = mhsa_bwd(d, seq[1].module, saved)
-    return ffn_bwd(d, seq[0].module, saved)
+    with hip.colsum_batched():                  # the block's ~11 bias-gradient column sums run as one launch at the end
+        d = hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias))
+        d = ffn_bwd(d, seq[3].module, saved)
+        d = convmod_bwd(d, seq[2].module, saved)
+        d = mhsa_bwd(d, seq[1].module, saved)
+        d = ffn_bwd(d, seq[0].module, saved)
+    return d
 
 
 def encoder_fwd(x, enc, B, T, train, saved, out=None):

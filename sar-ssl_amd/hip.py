@@ -503,26 +503,30 @@ def relpos_attn_supported(T, dh, dtype):
     return dtype == torch.bfloat16 and bool(_lib.lib().sarssl_relpos_attn_supported(c_int(T), c_int(dh)))
 
 
-def relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop=0.0, seed=0):
-    """qu [B*T, d], k / v [B*T, d] (row-strided views), bias (B,H,T,T) shifted positional score -> ctx [B*T, d], lse (B,H,T)."""
+def relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True):
+    """qu [B*T, d], k / v [B*T, d] (row-strided views), bias (B,H,T,T) shifted positional score -> ctx [B*T, d] bf16,
+    (ctx32 [B*T, d] f32 unrounded, lse (B,H,T)) for backward."""
     _need_cuda(qu, k, v, bias)
     assert k.stride(0) == v.stride(0) and bias.is_contiguous()
     ctx = torch.empty((B * T, H * dh), dtype=torch.bfloat16, device=qu.device)
+    ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if need_bwd else None
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
     _lib.call("sarssl_relpos_attn_fwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx),
-              c_long(ctx.stride(0)), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
+              c_long(ctx.stride(0)), _p(ctx32), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
               c_ulonglong(seed), _stream())
-    return ctx, lse
+    return ctx, (ctx32, lse)
 
 
-def relpos_attn_bwd(qu, k, v, bias, ctx, lse, dctx, dqu, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0):
-    """Writes dqu / dk / dv (row-strided [B*T, d] views, dk and dv with the same row stride) and returns dbias (B,H,T,T)."""
-    _need_cuda(qu, k, v, bias, ctx, lse, dctx, dqu, dk, dv)
+def relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqu, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0):
+    """aux = (ctx32, lse) from relpos_attn_fwd.  Writes dqu / dk / dv (row-strided [B*T, d] views, dk and dv with the same row
+    stride) and returns dbias (B,H,T,T)."""
+    ctx32, lse = aux
+    _need_cuda(qu, k, v, bias, ctx32, lse, dctx, dqu, dk, dv)
     assert k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0)
     dbias = torch.empty_like(bias)
     dsum = _f32ws(B * H * T, qu.device, "attn_dsum")
-    _lib.call("sarssl_relpos_attn_bwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx),
-              c_long(ctx.stride(0)), _p(lse), _p(dctx), c_long(dctx.stride(0)), _p(dqu), c_long(dqu.stride(0)), _p(dk), _p(dv),
+    _lib.call("sarssl_relpos_attn_bwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx32),
+              _p(lse), _p(dctx), c_long(dctx.stride(0)), _p(dqu), c_long(dqu.stride(0)), _p(dk), _p(dv),
               c_long(dk.stride(0)), _p(dbias), _p(dsum), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
               c_ulonglong(seed), _stream())
     return dbias
@@ -553,10 +557,54 @@ def axpby2d(x2d, y2d, a=1.0, b=1.0, out=None):
     return out
 
 
-def colsum(x2d, out_f32):
-    """out_f32[n] += sum_m x2d[m][n]."""
+_colsum_batch = None          # list of (x2d, out) while a batch is open
+
+
+def colsum(x2d, out_f32, now=False):
+    """out_f32[n] += sum_m x2d[m][n].  Inside ``colsum_batched()`` the request is queued and executed with the others in one
+    launch when the batch closes: x2d must stay unmodified and out_f32 unread until then; ``now=True`` opts out."""
+    if _colsum_batch is not None and not now and x2d.dtype == torch.bfloat16:
+        _colsum_batch.append((x2d, out_f32))
+        if len(_colsum_batch) == 24:
+            colsum_flush()
+        return
     M, N = x2d.shape
     _lib.call("sarssl_colsum", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(N), _p(out_f32), c_int(dt(x2d)), _stream())
+
+
+def colsum_flush():
+    """Runs the queued column sums (one launch) on the current stream."""
+    global _colsum_batch
+    if not _colsum_batch:
+        return
+    items, n = _colsum_batch, len(_colsum_batch)
+    _colsum_batch = []
+    import ctypes
+    xs = (ctypes.c_void_p * n)(*[x.data_ptr() for x, _ in items])
+    outs = (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in items])
+    lds = (ctypes.c_long * n)(*[x.stride(0) for x, _ in items])
+    Ms = (ctypes.c_long * n)(*[x.shape[0] for x, _ in items])
+    Ns = (ctypes.c_int * n)(*[x.shape[1] for x, _ in items])
+    _lib.call("sarssl_colsum_multi", xs, lds, Ms, Ns, outs, c_int(n), c_int(BF16), _stream())
+
+
+class colsum_batched:
+    """Context manager: queue the column sums issued inside and run them in one launch at exit (per backward stage)."""
+
+    def __enter__(self):
+        global _colsum_batch
+        self._outer = _colsum_batch
+        if _colsum_batch is None:
+            _colsum_batch = []
+        return self
+
+    def __exit__(self, *exc):
+        global _colsum_batch
+        if self._outer is None:
+            if exc[0] is None:
+                colsum_flush()
+            _colsum_batch = None
+        return False
 
 
 def act_bwd(dz, h, act, p_drop=0.0, seed=0, gscale=1.0, out=None):

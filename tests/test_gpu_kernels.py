@@ -632,7 +632,7 @@ def _attn_mask(B, H, T, dh, p_drop, seed, dev):
         V = torch.zeros((B, T, H, dh), dtype=torch.bfloat16, device=dev)
         n = min(dh, T - t0)
         V[:, t0 + torch.arange(n), :, torch.arange(n)] = 1.0
-        ctx, _ = hip.relpos_attn_fwd(z, z, V.view(B * T, d), zb, B, H, T, dh, 1.0, p_drop, seed)
+        ctx, _ = hip.relpos_attn_fwd(z, z, V.view(B * T, d), zb, B, H, T, dh, 1.0, p_drop, seed, need_bwd=False)
         mask[:, :, :, t0:t0 + n] = (ctx.view(B, T, H, dh).permute(0, 2, 1, 3)[..., :n] != 0)
     return mask
 
@@ -665,7 +665,8 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop):
     got_bias[:, :, ii, ii + 1] = 0.0                                         # ... and ignored by the attention kernels
     check("attn.bias_shift_gemm", _relerr(got_bias, want_bias), 1e-2)
     seed = 991
-    ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, seed)
+    ctx, aux = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, seed)
+    lse = aux[1]
     ctx2, _ = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, seed)
     assert torch.equal(ctx, ctx2)
     keep = torch.ones((B, H, T, T), dtype=torch.float64, device=dev)
@@ -686,7 +687,7 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop):
     check("attn.fwd.lse[p=%g]" % p_drop, (lse.double() - lse_ref.detach()).abs().max().item(), 1e-3)
     O.backward(dctx.view(B, T, H, dh).double().permute(0, 2, 1, 3))
     dqkv = torch.full((B * T, 3 * d), float("nan"), dtype=torch.bfloat16, device=dev)
-    dbias = hip.relpos_attn_bwd(qu, k, v, bias, ctx, lse, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, scale,
+    dbias = hip.relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, scale,
                                 p_drop, seed)
     un = lambda t: t.reshape(B, T, H, dh).permute(0, 2, 1, 3)
     check("attn.bwd.dq[p=%g]" % p_drop, _relerr(un(dqkv[:, :d]), q64.grad), 2e-2)
