@@ -56,6 +56,11 @@ int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC
                 long sR1, float res_scale, void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
                 int precise, float* ws, int split_k, int c_row_shift, void* stream);
 
+/* several split-K products reduced in one launch: C_q[m][n] += sum_s ws_q[s][m][n].  Pair with sarssl_gemm(split_k > 0, C = NULL,
+ * bf16 operands), which then only writes the partials (split count = ceil(K / (ceil(ceil(K / split_k) / 64) * 64))). */
+int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsplit, const int* M, const int* N, float* const* C, const long* ldc,
+                               int n_prob, void* stream);
+
 /* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
  *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as
  *      sarssl_gemm.  sarssl_fp8_quantize: x [rows][cols] (f32 | bf16, row stride ld) -> q fp8 [rows][cols] or (transpose) [cols][rows],

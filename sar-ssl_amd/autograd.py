@@ -39,4 +39,8 @@ def tape_apply(module, fwd, bwd, x):
         return _TapeFn.apply(fwd, bwd, x, *params)
     if not x.is_cuda:
         raise hip._lib.SarsslHipError("sar_ssl_amd modules run on the GPU only (no CPU fallback); got a CPU tensor")
-    return fwd(_to_rt(x.detach().contiguous()), [])
+    RT.inference = True                       # no backward follows (no_grad, or nothing upstream / inside requires a gradient)
+    try:
+        return fwd(_to_rt(x.detach().contiguous()), [])
+    finally:
+        RT.inference = False

@@ -263,6 +263,56 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, i
     }
 }
 
+// The same reduction for several split-K products in one launch (the weight-gradient GEMMs of one backward stage are reduced
+// together when the stage ends: 40 launches of ~12 us per step otherwise).
+#define SPLITK_MAXP 16
+struct SplitKMulti {
+    const float* ws[SPLITK_MAXP]; float* C[SPLITK_MAXP]; long ldc[SPLITK_MAXP];
+    int nsplit[SPLITK_MAXP], M[SPLITK_MAXP], N[SPLITK_MAXP], first[SPLITK_MAXP + 1];
+    int n;
+};
+__global__ void splitk_reduce_multi_kernel(SplitKMulti a) {
+    int q = 0;
+    while (q + 1 < a.n && (int)blockIdx.x >= a.first[q + 1]) ++q;
+    const int nblk = a.first[q + 1] - a.first[q], local = blockIdx.x - a.first[q];
+    const long mn = (long)a.M[q] * a.N[q];
+    const float* wz = a.ws[q];
+    float* Cz = a.C[q];
+    const int N = a.N[q], nsplit = a.nsplit[q];
+    const long ldc = a.ldc[q];
+    for (long i = ((long)local * blockDim.x + threadIdx.x) * 4; i < mn; i += (long)nblk * blockDim.x * 4) {      // N % 4 == 0
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nsplit; ++k) {
+            const float4 v = *(const float4*)(wz + (long)k * mn + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const long m = i / N, n = i - m * N;
+        float4* dst = (float4*)(Cz + m * ldc + n);
+        float4 c = *dst;
+        c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w;
+        *dst = c;
+    }
+}
+// C_q[m][n] += sum_s ws_q[s][m][n] for n_prob <= 16 products (N_q % 4 == 0, ldc_q % 4 == 0)
+extern "C" int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsplit, const int* M, const int* N, float* const* C,
+                                          const long* ldc, int n_prob, void* stream) {
+    SARSSL_REQUIRE(n_prob > 0 && n_prob <= SPLITK_MAXP, "sarssl_splitk_reduce_multi");
+    SplitKMulti a;
+    a.n = n_prob;
+    int total = 0;
+    for (int q = 0; q < n_prob; ++q) {
+        SARSSL_REQUIRE(N[q] % 4 == 0 && ldc[q] % 4 == 0 && nsplit[q] > 0, "sarssl_splitk_reduce_multi(shape)");
+        a.ws[q] = ws[q]; a.C[q] = C[q]; a.ldc[q] = ldc[q]; a.nsplit[q] = nsplit[q]; a.M[q] = M[q]; a.N[q] = N[q];
+        const long mn4 = (long)M[q] * N[q] / 4;
+        int nb = (int)((mn4 + 255) / 256); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+        a.first[q] = total; total += nb;
+    }
+    a.first[n_prob] = total;
+    splitk_reduce_multi_kernel<<<total, 256, 0, (hipStream_t)stream>>>(a);
+    SARSSL_CHECK_LAUNCH("splitk_reduce_multi_kernel");
+    return 0;
+}
+
 template <typename TA, typename TB, typename TC, int FM, bool EDGE>
 static void launch_fm(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
     if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, FM, EDGE><<<grid, 256, 0, st>>>(g);
@@ -354,7 +404,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
         return launch_layout<bf16, bf16, bf16, true>(g, a_kc, b_kc, nbatch, st);
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_F32) {
         int rc = launch_layout<bf16, bf16, float, true>(g, a_kc, b_kc, nbatch, st);
-        if (rc || g.split_k <= 0) return rc;
+        if (rc || g.split_k <= 0 || C == nullptr) return rc;          // C == null: partials only, reduced later (sarssl_splitk_reduce_multi)
         return reduce();
     }
     if (dtA == SARSSL_F32 && dtB == SARSSL_F32 && dtC == SARSSL_F32) {

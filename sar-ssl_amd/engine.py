@@ -344,7 +344,7 @@ def mhsa_fwd(x, mod, B, T, train, saved):
         bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
         hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
                  sC=(H * T * T, T * T), c_row_shift=True)
-        ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=torch.is_grad_enabled())   # lse = (ctx32, lse)
+        ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)   # lse = (ctx32, lse)
         po = _p(mod.dropout, train)
         so = RT.next_seed() if po > 0 else 0
         y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,
@@ -530,7 +530,8 @@ def block_fwd(x, blk, B, T, train, saved, out=None):
 def block_bwd(dy, blk, saved):
     seq = blk.sequential
     x, stats = saved.pop()
-    with hip.colsum_batched():                  # the block's ~11 bias-gradient column sums run as one launch at the end
+    # the block's ~9 bias-gradient column sums and the reductions of its 9 split-K weight-gradient products: one launch each, at the end
+    with hip.colsum_batched(), hip.splitk_batched():
         d = hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias))
         d = ffn_bwd(d, seq[3].module, saved)
         d = convmod_bwd(d, seq[2].module, saved)

@@ -101,11 +101,21 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     if nbatch > 1 and sC == (0, 0):
         sC = (M * N * batch_inner, M * N)
     ws = None
+    deferred = None
     if split_k > 0:
-        ws = workspace(4 * nbatch * split_k * M * N, A.device, "gemm_split")
+        if (_splitk_batch is not None and nbatch == 1 and A.dtype == torch.bfloat16 and out.dtype == torch.float32 and N % 4 == 0
+                and ldc % 4 == 0):
+            # weight-gradient product inside splitk_batched(): write the partials only, fold them into `out` together with the
+            # stage's other products when the batch closes
+            per = ((K + split_k - 1) // split_k + 63) // 64 * 64
+            nsplit = (K + per - 1) // per
+            ws = torch.empty((nsplit * M * N,), dtype=torch.float32, device=A.device)
+            deferred = (ws, nsplit, M, N, out, ldc)
+        else:
+            ws = workspace(4 * nbatch * split_k * M * N, A.device, "gemm_split")
     elif precise and A.dtype == torch.float32:
         ws = workspace(4 * nbatch * M * N, A.device, "gemm_acc")
-    _lib.call("sarssl_gemm", _p(A), _p(B), _p(out), c_int(dt(A)), c_int(dt(B)), c_int(dt(out)),
+    _lib.call("sarssl_gemm", _p(A), _p(B), _p(out) if deferred is None else c_void_p(0), c_int(dt(A)), c_int(dt(B)), c_int(dt(out)),
               c_int(1 if a_kc else 0), c_int(1 if b_kc else 0), c_int(M), c_int(N), c_int(K),
               c_long(lda), c_long(ldb), c_long(ldc), c_int(nbatch), c_int(batch_inner),
               c_long(sA[0]), c_long(sA[1]), c_long(sB[0]), c_long(sB[1]), c_long(sC[0]), c_long(sC[1]),
@@ -113,7 +123,50 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
               _p(resid), c_long(ldr), c_long(sR[0]), c_long(sR[1]), c_float(res_scale),
               _p(preact), _p(aux), c_int(aux_act), c_float(p_drop), c_ulonglong(seed), c_int(1 if (precise and A.dtype == torch.float32) else 0),
               _p(ws), c_int(split_k), c_int(1 if c_row_shift else 0), _stream())
+    if deferred is not None:
+        _splitk_batch.append(deferred)
+        if len(_splitk_batch) == 16:
+            splitk_flush()
     return out
+
+
+_splitk_batch = None
+
+
+def splitk_flush():
+    global _splitk_batch
+    if not _splitk_batch:
+        return
+    items, n = _splitk_batch, len(_splitk_batch)
+    _splitk_batch = []
+    import ctypes
+    ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+    C = (ctypes.c_void_p * n)(*[it[4].data_ptr() for it in items])
+    ns = (ctypes.c_int * n)(*[it[1] for it in items])
+    Ms = (ctypes.c_int * n)(*[it[2] for it in items])
+    Ns = (ctypes.c_int * n)(*[it[3] for it in items])
+    ld = (ctypes.c_long * n)(*[it[5] for it in items])
+    _lib.call("sarssl_splitk_reduce_multi", ws, ns, Ms, Ns, C, ld, c_int(n), _stream())
+
+
+class splitk_batched:
+    """Context manager: split-K (weight-gradient) products issued inside keep their partial sums in their own buffers and are
+    reduced into the gradient buffers by ONE launch at exit, instead of one reduce launch per product."""
+
+    def __enter__(self):
+        global _splitk_batch
+        self._outer = _splitk_batch
+        if _splitk_batch is None:
+            _splitk_batch = []
+        return self
+
+    def __exit__(self, *exc):
+        global _splitk_batch
+        if self._outer is None:
+            if exc[0] is None:
+                splitk_flush()
+            _splitk_batch = None
+        return False
 
 
 def fp8_quantize(x2d, transpose=False):

@@ -331,7 +331,11 @@ class SARSSL(nn.Module):
             if torch.is_grad_enabled() and self._param_list:
                 loss, out, pred = _PretrainFn.apply(self, x, idx, ch, mp, *self._param_list)
             else:
-                loss, out, pred = _PretrainFn.forward(_NoCtx(), self, x, idx, ch, mp)
+                RT.inference = True
+                try:
+                    loss, out, pred = _PretrainFn.forward(_NoCtx(), self, x, idx, ch, mp)
+                finally:
+                    RT.inference = False
             return loss, out[1], LazyVis(pred, x, mp, ch)
         # ---- downstream branch (code/model.py:667-719): both encoders on the unmasked input, mean over frames, MLP head
         B, T, F = nbatch, nt, nf

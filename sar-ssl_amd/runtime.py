@@ -19,6 +19,7 @@ class _RT:
     dtype = torch.bfloat16
     precise = False
     fp8 = False
+    inference = False      # set while a forward runs that no backward will follow (no_grad / frozen): skips backward-only outputs
     replay = None          # DropoutReplay: masks drawn on the host in the reference's order (parity tests only)
     _seed = 0x5A25_5151_0000_0000
     _ctr = 0
