@@ -146,6 +146,15 @@ int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const f
                            const float* mean, const float* rstd, int act, int g_is_masked, int use_stats, const double* red,
                            void* dy, int dtype, void* stream);
 
+/* ---- depthwise-conv part of the Conformer convolution module as LDS tiles (convolution.py:139-143 and its backward): GLU fused
+ *      into the tile load, BatchNorm1d batch sums in the epilogue; the data gradient fused with the GLU backward; the weight gradient
+ *      recomputes the GLU output.  h: [nb*Tn][2d] pointwise-conv output, c / dc: [nb*Tn][d], w / dw: f32 [d][31], sums: f64[2d]. */
+int sarssl_dwglu_fwd(const void* h, const float* w, int nb, int Tn, int d, int ksize, void* c, double* sums, int dtype, void* stream);
+int sarssl_dwglu_bwd(const void* dc, const void* h, const float* w, int nb, int Tn, int d, int ksize, void* dh, int dtype, void* stream);
+long sarssl_dwglu_wgrad_workspace_bytes(int nb, int Tn, int d);
+int sarssl_dwglu_wgrad(const void* dc, const void* h, int nb, int Tn, int d, int ksize, float* dw, float* partial, int dtype,
+                       void* stream);
+
 /* ---- Conformer row / elementwise kernels: LayerNorm (feed_forward.py:48, attention.py:139, convolution.py:137,
  *      Conformer.py:87), GLU (activation.py:31-42), depthwise conv k=31 (convolution.py:140), relative-shift softmax
  *      (attention.py:87-113), u/v bias add (attention.py:87-88) */

@@ -156,6 +156,7 @@ _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
 # against 352 (cl_bn_bwd_apply) + 360 + 414 us (both consumers re-read y2, and the extra arithmetic lands in the VALU-bound staging
 # phase of the convolution kernels): 15.2 vs 14.8 ms/step.  Off by default; kept for the next attempt (tests cover it).
 _BNIN = os.environ.get("SARSSL_BNIN", "0") != "0"
+_DWGLU = os.environ.get("SARSSL_DWGLU", "1") != "0"             # 0: separate glu / dwconv / cl_stats kernels (A/B runs)
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 
@@ -475,9 +476,15 @@ def convmod_fwd(x, cm, B, T, train, saved):
     ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
     pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
     h = mm_nt(ln, wt(pw1.weight).view(2 * d, d), bias=pw1.bias.data)                         # [M, 2d]
-    g = hip.glu_fwd(h)
-    c = hip.dwconv(g.view(B, T, d), dw.weight.data.view(d, -1))
-    aff = bn_affine(c, d, bn, train)
+    g = None
+    if _DWGLU and d % 8 == 0:            # GLU + depthwise conv + BatchNorm batch sums in one LDS-tiled pass (csrc/dwconv.hip)
+        c, sums = hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T, want_stats=True) if train else \
+            (hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T), None)
+        aff = bn_affine(c, d, bn, train, sums=sums)
+    else:
+        g = hip.glu_fwd(h)
+        c = hip.dwconv(g.view(B, T, d), dw.weight.data.view(d, -1))
+        aff = bn_affine(c, d, bn, train)
     s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
     po = _p(seq[8], train)
     if _replaying(train) and po > 0:                       # the reference draws this mask on the (B, d, T) conv output
@@ -506,9 +513,13 @@ def convmod_bwd(dy, cm, saved):
     red = hip.cl_bn_bwd_reduce(ds, c, d, aff, SWISH)
     dc = hip.cl_bn_bwd_apply(ds, c, d, aff, SWISH, False, train, red, out=ds).view(B, T, d)
     bn_param_grads(bn, red, d)
-    dg = hip.dwconv(dc, dw.weight.data.view(d, -1), flip=True)
-    hip.dwconv_wgrad(dc, g.view(B, T, d), gbuf(dw.weight).view(d, -1))
-    dh = hip.glu_bwd(dg.view(B * T, d), h)
+    if g is None:                        # fused forward: the GLU output was never stored
+        dh = hip.dwglu_bwd(dc.view(B * T, d), h, dw.weight.data.view(d, -1), B, T)
+        hip.dwglu_wgrad(dc.view(B * T, d), h, gbuf(dw.weight).view(d, -1), B, T)
+    else:
+        dg = hip.dwconv(dc, dw.weight.data.view(d, -1), flip=True)
+        hip.dwconv_wgrad(dc, g.view(B, T, d), gbuf(dw.weight).view(d, -1))
+        dh = hip.glu_bwd(dg.view(B * T, d), h)
     mm_tn_acc(dh, ln, gbuf(pw1.weight))
     hip.colsum(dh, gbuf(pw1.bias))
     dln = mm_nn(dh, wt(pw1.weight).view(2 * d, d))

@@ -516,6 +516,36 @@ def dwconv(x3d, w, flip=False):
     return y
 
 
+def dwglu_fwd(h2d, w, B, T, want_stats=False):
+    """h [B*T, 2d] -> c [B*T, d] = depthwise conv (k = 31) of GLU(h) over frames, (+ f64[2d] BatchNorm sums of c)."""
+    _need_cuda(h2d, w)
+    d = h2d.shape[1] // 2
+    c = torch.empty((B * T, d), dtype=h2d.dtype, device=h2d.device)
+    sums = torch.empty((2 * d,), dtype=torch.float64, device=h2d.device) if want_stats else None
+    _lib.call("sarssl_dwglu_fwd", _p(h2d), _p(w), c_int(B), c_int(T), c_int(d), c_int(w.shape[-1]), _p(c), _p(sums), c_int(dt(h2d)),
+              _stream())
+    return (c, sums) if want_stats else c
+
+
+def dwglu_bwd(dc2d, h2d, w, B, T):
+    """dc [B*T, d], h [B*T, 2d] -> dh [B*T, 2d] (depthwise-conv data gradient + GLU backward)."""
+    d = dc2d.shape[1]
+    dh = torch.empty_like(h2d)
+    _lib.call("sarssl_dwglu_bwd", _p(dc2d), _p(h2d), _p(w), c_int(B), c_int(T), c_int(d), c_int(w.shape[-1]), _p(dh), c_int(dt(h2d)),
+              _stream())
+    return dh
+
+
+def dwglu_wgrad(dc2d, h2d, dw_out, B, T):
+    """dw_out f32 (d, 31) += depthwise-conv weight gradient, GLU(h) recomputed."""
+    d = dc2d.shape[1]
+    fn = _lib.lib().sarssl_dwglu_wgrad_workspace_bytes
+    fn.restype = c_long
+    part = workspace(fn(c_int(B), c_int(T), c_int(d)), dc2d.device, "dwglu_part")
+    _lib.call("sarssl_dwglu_wgrad", _p(dc2d), _p(h2d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), _p(dw_out), _p(part),
+              c_int(dt(h2d)), _stream())
+
+
 def dwconv_wgrad(dy3d, x3d, dw_out):
     B, T, d = x3d.shape
     fn = _lib.lib().sarssl_dwconv_wgrad_workspace_bytes

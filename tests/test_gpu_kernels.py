@@ -702,3 +702,35 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop):
     raw_leaf = raw.clone().requires_grad_(True)
     (_ref_shift(raw_leaf) * wb).sum().backward()
     check("attn.bwd.unshift[p=%g]" % p_drop, _relerr(dps, raw_leaf.grad), 2e-2)
+
+
+# ---------------------------------------------------------------- depthwise-conv tiles of the convolution module (csrc/dwconv.hip)
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,d", [(2, 40, 32), (3, 256, 512), (1, 624, 256), (2, 70, 72)])
+def test_dwglu_fused_kernels(B, T, d, dtp):
+    """GLU + depthwise conv (k = 31, pad 15) + BatchNorm sums / data gradient + GLU backward / weight gradient against torch
+    (convolution.py:139-143) in f64 on the same stored operands."""
+    from sar_ssl_amd import hip
+    from conftest import check
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 100 + T + d)
+    h = torch.randn((B * T, 2 * d), generator=g).to(dtp).to(dev)
+    w = (torch.randn((d, 31), generator=g) * 0.2).to(dev)
+    dc = torch.randn((B * T, d), generator=g).to(dtp).to(dev)
+    tol = 1e-5 if dtp == torch.float32 else 1e-2
+    c, sums = hip.dwglu_fwd(h, w, B, T, want_stats=True)
+    h64 = h.double().view(B, T, 2 * d).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    glu = h64[..., :d] * torch.sigmoid(h64[..., d:])
+    if dtp == torch.bfloat16:
+        glu = glu + (glu.detach().to(dtp).double() - glu.detach())          # forward value as stored (bf16), gradient of the exact op
+    ref = torch.nn.functional.conv1d(glu.transpose(1, 2), w64.view(d, 1, 31), padding=15, groups=d).transpose(1, 2)
+    check("dwglu.fwd[%d,%d,%d,%s]" % (B, T, d, dtp), _relerr(c.view(B, T, d), ref.detach()), tol)
+    cs = c.double().view(-1, d)
+    check("dwglu.fwd_sums", max(_relerr(sums[:d], cs.sum(0)), _relerr(sums[d:], (cs ** 2).sum(0))), 1e-5)
+    ref.backward(dc.double().view(B, T, d))
+    dh = hip.dwglu_bwd(dc, h, w, B, T)
+    check("dwglu.bwd[%d,%d,%d,%s]" % (B, T, d, dtp), _relerr(dh.view(B, T, 2 * d), h64.grad), tol)
+    dw = torch.ones((d, 31), dtype=torch.float32, device=dev)
+    hip.dwglu_wgrad(dc, h, dw, B, T)
+    check("dwglu.wgrad[%d,%d,%d,%s]" % (B, T, d, dtp), _relerr(dw - 1.0, w64.grad), 1e-4 if dtp == torch.float32 else 1e-2)
