@@ -36,6 +36,22 @@ __global__ void mask_inputs_kernel(const float* __restrict__ x, const uint8_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8 consecutive elements kept as loaded (bf16: one 16-byte register quad) until they are consumed
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> { uint4 u; };
+template <> struct Raw8<float> { f8 v; };
+__device__ __forceinline__ Raw8<bf16> raw8_load(const bf16* p) { Raw8<bf16> r; r.u = *(const uint4*)p; return r; }
+__device__ __forceinline__ Raw8<float> raw8_load(const float* p) { Raw8<float> r; r.v = ld8(p); return r; }
+__device__ __forceinline__ f8 raw8_unpack(const Raw8<float>& r) { return r.v; }
+__device__ __forceinline__ f8 raw8_unpack(const Raw8<bf16>& r) {
+    f8 o;
+    o.v[0] = bf16_bits_to_f32(r.u.x & 0xffffu); o.v[1] = __uint_as_float(r.u.x & 0xffff0000u);
+    o.v[2] = bf16_bits_to_f32(r.u.y & 0xffffu); o.v[3] = __uint_as_float(r.u.y & 0xffff0000u);
+    o.v[4] = bf16_bits_to_f32(r.u.z & 0xffffu); o.v[5] = __uint_as_float(r.u.z & 0xffff0000u);
+    o.v[6] = bf16_bits_to_f32(r.u.w & 0xffffu); o.v[7] = __uint_as_float(r.u.w & 0xffff0000u);
+    return o;
+}
+
 // y1[p][co] = sum_c W1[co][c] a0[p][c]     a0: (N,4), y1: (N,64).  Thread = (pixel, 8-channel group).
 // stats (optional f64[128]): per-channel sum / sum of squares of the stored y1 for the following BatchNorm.
 template <typename T>
@@ -52,18 +68,28 @@ __global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const long nthreads = (long)gridDim.x * blockDim.x;
-    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
-        const long p = g >> 3;
-        const float4 a = ld4(a0 + p * 4);
-        f8 o;
+    constexpr int U = 4;                               // pixels in flight per thread: the pass is a pure 537 MB write stream
+    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads * U) {
+        float4 a[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.v[e] = w[e][0] * a.x + w[e][1] * a.y + w[e][2] * a.z + w[e][3] * a.w;
-        st8(y1 + p * 64 + cg * 8, o);
-        if (stats) {
+        for (int u = 0; u < U; ++u) {
+            const long g = g0 + u * nthreads;
+            a[u] = g < npix * 8 ? ld4(a0 + (g >> 3) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float r = (sizeof(T) == 2) ? bf16_bits_to_f32(f32_to_bf16_bits(o.v[e])) : o.v[e];   // what was stored
-                acc[e] += r; acc[8 + e] += r * r;
+        for (int u = 0; u < U; ++u) {
+            const long g = g0 + u * nthreads;
+            if (g >= npix * 8) continue;
+            f8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] = w[e][0] * a[u].x + w[e][1] * a[u].y + w[e][2] * a[u].z + w[e][3] * a[u].w;
+            st8(y1 + (g >> 3) * 64 + cg * 8, o);
+            if (stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r = (sizeof(T) == 2) ? bf16_bits_to_f32(f32_to_bf16_bits(o.v[e])) : o.v[e];   // what was stored
+                    acc[e] += r; acc[8 + e] += r * r;
+                }
             }
         }
     }
@@ -237,27 +263,52 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[c][e] = W4[c * 64 + cg * 8 + e];
     }
-    const long npix = (long)nb * F * Tn;
-    const long nthreads = (long)gridDim.x * blockDim.x;
-    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
-        const long p = g >> 3;
-        const f8 v = ld8(y3 + p * 64 + cg * 8);
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
+    // 16 x 16 (bin, frame) tiles: y3 (B,F,T,64) is read in 2 KB rows (16 frames x 128 B), the (B,T,F,4) output tile leaves through
+    // LDS as 128-byte rows (16 bins x 8 B) - written pixel by pixel in y3's order it was one 8-byte store per 2 KB (round-2 counters:
+    // 3.7 TB/s for this pass).  8 pixels are in flight per thread.
+    __shared__ float4 sO[16][17];
+    const int ftiles = (F + 15) >> 4, ttiles = (Tn + 15) >> 4;
+    const long ntile = (long)nb * ftiles * ttiles;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int tt0 = (int)(tile % ttiles) << 4;
+        const long rr = tile / ttiles;
+        const int f0 = (int)(rr % ftiles) << 4, b = (int)(rr / ftiles);
+        f8 v[8]; bool ok[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float z = fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] += w[c][e] * z;
+        for (int u = 0; u < 8; ++u) {
+            const int pl = (threadIdx.x >> 3) + 32 * u;               // bin pl >> 4, frame pl & 15
+            const int f = f0 + (pl >> 4), t = tt0 + (pl & 15);
+            ok[u] = f < F && t < Tn;
+            if (ok[u]) v[u] = ld8(y3 + (((long)b * F + f) * Tn + t) * 64 + cg * 8);
         }
+        __syncthreads();                                              // previous tile's output rows have been stored
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            o[c] += __shfl_xor(o[c], 1, 64); o[c] += __shfl_xor(o[c], 2, 64); o[c] += __shfl_xor(o[c], 4, 64);
+        for (int u = 0; u < 8; ++u) {
+            const int pl = (threadIdx.x >> 3) + 32 * u;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ok[u]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = fmaxf(fmaf(v[u].v[e], sc[e], sh[e]), 0.f);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] += w[c][e] * z;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                o[c] += __shfl_xor(o[c], 1, 64); o[c] += __shfl_xor(o[c], 2, 64); o[c] += __shfl_xor(o[c], 4, 64);
+            }
+            if (cg == 0) sO[pl & 15][pl >> 4] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        if (cg == 0) {
-            const int t = (int)(p % Tn);
-            const long bf = p / Tn;
-            const int f = (int)(bf % F), b = (int)(bf / F);
-            st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
+        __syncthreads();
+        if (threadIdx.x < 128) {                                      // 16 frames x 8 pieces of 2 bins (16 bytes in bf16)
+            const int tt = threadIdx.x >> 3, fc = (threadIdx.x & 7) * 2;
+            if (tt0 + tt < Tn && f0 + fc < F) {
+                T* q = y4 + (((long)b * Tn + tt0 + tt) * F + f0 + fc) * 4;
+                const float4 lo = sO[tt][fc], hi = sO[tt][fc + 1];
+                if (f0 + fc + 1 < F) { f8 o8; o8.v[0] = lo.x; o8.v[1] = lo.y; o8.v[2] = lo.z; o8.v[3] = lo.w; o8.v[4] = hi.x; o8.v[5] = hi.y; o8.v[6] = hi.z; o8.v[7] = hi.w; st8(q, o8); }
+                else st4(q, lo);
+            }
         }
     }
 }
@@ -323,40 +374,40 @@ __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ 
             sD[tt][fc] = lo; sD[tt][fc + 1] = hi;
         }
         __syncthreads();
-        constexpr int U = 4;                                         // pixels in flight per thread (latency hiding)
+        // all 8 pixel chunks of the thread are requested before the first is used and stay packed (4 VGPRs each for bf16) until
+        // then: the accumulators keep this kernel at 2 waves / SIMD, so bytes in flight per wave is what sets its bandwidth
+        constexpr int U = 8;
+        Raw8<T> v[U]; bool ok[U]; long pix[U];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f8 v[U]; bool ok[U]; long pix[U];
+        for (int u = 0; u < U; ++u) {
+            const int pl = (threadIdx.x >> 3) + 32 * u;                 // 0..255: bin pl >> 4, frame pl & 15
+            const int f = f0 + (pl >> 4), t = tt0 + (pl & 15);
+            ok[u] = f < F && t < Tn;
+            pix[u] = ((long)b * F + f) * Tn + t;
+            if (ok[u]) v[u] = raw8_load(y3 + pix[u] * 64 + cg * 8);
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pl = (threadIdx.x >> 3) + 32 * (h * U + u);       // 0..255: bin pl >> 4, frame pl & 15
-                const int f = f0 + (pl >> 4), t = tt0 + (pl & 15);
-                ok[u] = f < F && t < Tn;
-                pix[u] = ((long)b * F + f) * Tn + t;
-                if (ok[u]) v[u] = ld8(y3 + pix[u] * 64 + cg * 8);
-            }
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const int pl = (threadIdx.x >> 3) + 32 * u;
+            const float4 d = sD[pl & 15][pl >> 4];
+            const f8 vv = raw8_unpack(v[u]);
+            f8 o;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!ok[u]) continue;
-                const int pl = (threadIdx.x >> 3) + 32 * (h * U + u);
-                const float4 d = sD[pl & 15][pl >> 4];
-                f8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float uu = fmaf(v[u].v[e], sc[e], sh[e]);
-                    float gi = d.x * w[0][e] + d.y * w[1][e] + d.z * w[2][e] + d.w * w[3][e];
-                    gi = (uu > 0.f) ? gi : 0.f;
-                    if (MODE == 2) o.v[e] = fmaf(cA[e], gi, fmaf(cB[e], v[u].v[e], cC[e]));
-                    else {
-                        const float z = fmaxf(uu, 0.f);
-                        o.v[e] = gi;
-                        acc[0 * 8 + e] += d.x * z; acc[1 * 8 + e] += d.y * z; acc[2 * 8 + e] += d.z * z; acc[3 * 8 + e] += d.w * z;
-                        acc[32 + e] += gi;
-                        acc[40 + e] += gi * (v[u].v[e] - mu[e]) * rs[e];
-                    }
+            for (int e = 0; e < 8; ++e) {
+                const float uu = fmaf(vv.v[e], sc[e], sh[e]);
+                float gi = d.x * w[0][e] + d.y * w[1][e] + d.z * w[2][e] + d.w * w[3][e];
+                gi = (uu > 0.f) ? gi : 0.f;
+                if (MODE == 2) o.v[e] = fmaf(cA[e], gi, fmaf(cB[e], vv.v[e], cC[e]));
+                else {
+                    const float z = fmaxf(uu, 0.f);
+                    o.v[e] = gi;
+                    acc[0 * 8 + e] += d.x * z; acc[1 * 8 + e] += d.y * z; acc[2 * 8 + e] += d.z * z; acc[3 * 8 + e] += d.w * z;
+                    acc[32 + e] += gi;
+                    acc[40 + e] += gi * (vv.v[e] - mu[e]) * rs[e];
                 }
-                if (MODE != 1) st8(g3 + pix[u] * 64 + cg * 8, o);
             }
+            if (MODE != 1) st8(g3 + pix[u] * 64 + cg * 8, o);
         }
     }
     if (MODE == 2) return;
