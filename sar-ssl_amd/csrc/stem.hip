@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ 
         float4 a[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long g = g0 + u * nthreads;
-            a[u] = g < npix * 8 ? ld4(a0 + (g >> 3) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const long g = min(g0 + u * nthreads, npix * 8 - 1);     // clamped, unconditional (results of the overshoot are dropped)
+            a[u] = ld4(a0 + (g >> 3) * 4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -263,51 +263,38 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[c][e] = W4[c * 64 + cg * 8 + e];
     }
-    // 16 x 16 (bin, frame) tiles: y3 (B,F,T,64) is read in 2 KB rows (16 frames x 128 B), the (B,T,F,4) output tile leaves through
-    // LDS as 128-byte rows (16 bins x 8 B) - written pixel by pixel in y3's order it was one 8-byte store per 2 KB (round-2 counters:
-    // 3.7 TB/s for this pass).  8 pixels are in flight per thread.
-    __shared__ float4 sO[16][17];
-    const int ftiles = (F + 15) >> 4, ttiles = (Tn + 15) >> 4;
-    const long ntile = (long)nb * ftiles * ttiles;
-    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int tt0 = (int)(tile % ttiles) << 4;
-        const long rr = tile / ttiles;
-        const int f0 = (int)(rr % ftiles) << 4, b = (int)(rr / ftiles);
-        f8 v[8]; bool ok[8];
+    // (a (bin, frame)-tiled variant that writes the (B,T,F,4) output in 128-byte rows through LDS was measured slower - 182 vs 146 us
+    //  at B = 64: the two barriers per tile cost more than the scattered 8-byte stores of this 33 MB tensor)
+    const long npix = (long)nb * F * Tn;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    constexpr int U = 4;                               // pixels in flight per thread
+    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads * U) {
+        f8 v[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int pl = (threadIdx.x >> 3) + 32 * u;               // bin pl >> 4, frame pl & 15
-            const int f = f0 + (pl >> 4), t = tt0 + (pl & 15);
-            ok[u] = f < F && t < Tn;
-            if (ok[u]) v[u] = ld8(y3 + (((long)b * F + f) * Tn + t) * 64 + cg * 8);
+        for (int u = 0; u < U; ++u) {
+            const long g = min(g0 + u * nthreads, npix * 8 - 1);     // clamped: unconditional loads stay in flight together
+            v[u] = ld8(y3 + (g >> 3) * 64 + cg * 8);
         }
-        __syncthreads();                                              // previous tile's output rows have been stored
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int pl = (threadIdx.x >> 3) + 32 * u;
+        for (int u = 0; u < U; ++u) {
+            const long g = g0 + u * nthreads;
+            const long p = g >> 3;
             float o[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ok[u]) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float z = fmaxf(fmaf(v[u].v[e], sc[e], sh[e]), 0.f);
+            for (int e = 0; e < 8; ++e) {
+                const float z = fmaxf(fmaf(v[u].v[e], sc[e], sh[e]), 0.f);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] += w[c][e] * z;
-                }
+                for (int c = 0; c < 4; ++c) o[c] += w[c][e] * z;
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 o[c] += __shfl_xor(o[c], 1, 64); o[c] += __shfl_xor(o[c], 2, 64); o[c] += __shfl_xor(o[c], 4, 64);
             }
-            if (cg == 0) sO[pl & 15][pl >> 4] = make_float4(o[0], o[1], o[2], o[3]);
-        }
-        __syncthreads();
-        if (threadIdx.x < 128) {                                      // 16 frames x 8 pieces of 2 bins (16 bytes in bf16)
-            const int tt = threadIdx.x >> 3, fc = (threadIdx.x & 7) * 2;
-            if (tt0 + tt < Tn && f0 + fc < F) {
-                T* q = y4 + (((long)b * Tn + tt0 + tt) * F + f0 + fc) * 4;
-                const float4 lo = sO[tt][fc], hi = sO[tt][fc + 1];
-                if (f0 + fc + 1 < F) { f8 o8; o8.v[0] = lo.x; o8.v[1] = lo.y; o8.v[2] = lo.z; o8.v[3] = lo.w; o8.v[4] = hi.x; o8.v[5] = hi.y; o8.v[6] = hi.z; o8.v[7] = hi.w; st8(q, o8); }
-                else st4(q, lo);
+            if (cg == 0 && g < npix * 8) {
+                const int t = (int)(p % Tn);
+                const long bf = p / Tn;
+                const int f = (int)(bf % F), b = (int)(bf / F);
+                st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
             }
         }
     }
@@ -383,8 +370,8 @@ __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ 
             const int pl = (threadIdx.x >> 3) + 32 * u;                 // 0..255: bin pl >> 4, frame pl & 15
             const int f = f0 + (pl >> 4), t = tt0 + (pl & 15);
             ok[u] = f < F && t < Tn;
-            pix[u] = ((long)b * F + f) * Tn + t;
-            if (ok[u]) v[u] = raw8_load(y3 + pix[u] * 64 + cg * 8);
+            pix[u] = ((long)b * F + min(f, F - 1)) * Tn + min(t, Tn - 1);      // clamped: the load is unconditional (see stem_c4_fwd)
+            v[u] = raw8_load(y3 + pix[u] * 64 + cg * 8);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
