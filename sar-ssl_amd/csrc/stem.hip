@@ -263,39 +263,30 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[c][e] = W4[c * 64 + cg * 8 + e];
     }
-    // (a (bin, frame)-tiled variant that writes the (B,T,F,4) output in 128-byte rows through LDS was measured slower - 182 vs 146 us
-    //  at B = 64: the two barriers per tile cost more than the scattered 8-byte stores of this 33 MB tensor)
+    // (measured and rejected in round 2, B = 64: a (bin, frame)-tiled variant writing the (B,T,F,4) output in 128-byte rows through
+    //  LDS - 182 us, two barriers per tile cost more than the scattered 8-byte stores of this 33 MB tensor; four loads in flight per
+    //  thread - 162 us; this one-chunk-per-iteration loop at 16 waves / CU: 146 us)
     const long npix = (long)nb * F * Tn;
     const long nthreads = (long)gridDim.x * blockDim.x;
-    constexpr int U = 4;                               // pixels in flight per thread
-    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads * U) {
-        f8 v[U];
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
+        const long p = g >> 3;
+        const f8 v = ld8(y3 + p * 64 + cg * 8);
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long g = min(g0 + u * nthreads, npix * 8 - 1);     // clamped: unconditional loads stay in flight together
-            v[u] = ld8(y3 + (g >> 3) * 64 + cg * 8);
+        for (int e = 0; e < 8; ++e) {
+            const float z = fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] += w[c][e] * z;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long g = g0 + u * nthreads;
-            const long p = g >> 3;
-            float o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float z = fmaxf(fmaf(v[u].v[e], sc[e], sh[e]), 0.f);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] += w[c][e] * z;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                o[c] += __shfl_xor(o[c], 1, 64); o[c] += __shfl_xor(o[c], 2, 64); o[c] += __shfl_xor(o[c], 4, 64);
-            }
-            if (cg == 0 && g < npix * 8) {
-                const int t = (int)(p % Tn);
-                const long bf = p / Tn;
-                const int f = (int)(bf % F), b = (int)(bf / F);
-                st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
-            }
+        for (int c = 0; c < 4; ++c) {
+            o[c] += __shfl_xor(o[c], 1, 64); o[c] += __shfl_xor(o[c], 2, 64); o[c] += __shfl_xor(o[c], 4, 64);
+        }
+        if (cg == 0) {
+            const int t = (int)(p % Tn);
+            const long bf = p / Tn;
+            const int f = (int)(bf % F), b = (int)(bf / F);
+            st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
         }
     }
 }
