@@ -61,6 +61,7 @@ def main():
     aux = rnd(Mr, 4 * d)
     gemm_group(4, "gemm ffn2 dX NN d=512 (+swish' aux)", Mr, 4 * d, d, b_kc=False, aux=aux, aux_act=2)
     gemm_group(5, "gemm ffn1 dX NN d=512", Mr, d, 4 * d, b_kc=False)
+    d = 512
     gemm_group(6, "gemm ffn dW TN d=512 (split-K)", 4 * d, d, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8)
     gemm_group(7, "gemm decoder1 NT (768->3072, relu)", Mr, 3072, 768, bias=bias[:3072], act=1)
     gemm_group(8, "gemm decoder2 NT (3072->1024)", Mr, 1024, 3072, bias=bias[:1024])
@@ -97,8 +98,41 @@ def main():
     T, H = 256, 4
     content = torch.randn((B, H, T, T), device=dev)
     pos = torch.randn((B, H, T, T), device=dev)
-    group(40, "softmax_relshift_fwd (B,4,256,256)", lambda: hip.softmax_relshift_fwd(content, pos, 0.044, torch.bfloat16, 0.1, 5), 0,
+    group(40, "softmax_relshift_fwd (B,4,256,256) [unfused core, fp32 mode only]", lambda: hip.softmax_relshift_fwd(content, pos, 0.044, torch.bfloat16, 0.1, 5), 0,
           content.numel() * (8.0 + 4.0))
+    del content, pos
+    # ---- fused attention (csrc/attention.hip)
+    for tag, dh in ((41, 128), (44, 64)):
+        d = H * dh
+        qkv = rnd(B * T, 3 * d)
+        qu, dctx = rnd(B * T, d), rnd(B * T, d)
+        bias = rnd(B, H, T, T)
+        aflop = 2.0 * 2 * B * H * T * T * dh                        # QK^T + PV
+        abytes = 2.0 * (4 * B * T * d + B * H * T * T)
+        k_, v_ = qkv[:, d:2 * d], qkv[:, 2 * d:]
+        group(tag, "relpos_attn_fwd dh=%d (B=64,H=4,T=256)" % dh, lambda: hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5), aflop, abytes)
+        ctx, aux = hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5)
+        dqkv = torch.empty_like(qkv)
+        group(tag + 1, "relpos_attn_bwd dh=%d (dsum + dQ/dbias + dK/dV kernels)" % dh,
+              lambda: hip.relpos_attn_bwd(qu, k_, v_, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, 0.044, 0.1, 5),
+              3.5 * aflop, 2.0 * (8 * B * T * d + 2 * B * H * T * T))
+    # ---- convolution-module tiles (csrc/dwconv.hip)
+    d = 512
+    hh, dcc = rnd(B * T, 2 * d), rnd(B * T, d)
+    wdw = torch.randn((d, 31), device=dev)
+    gdw = torch.zeros((d, 31), device=dev)
+    eb = 2.0 * B * T * d
+    group(50, "dwglu_fwd d=512 (GLU + depthwise conv + BN sums)", lambda: hip.dwglu_fwd(hh, wdw, B, T, want_stats=True), 0, 3 * eb)
+    group(51, "dwglu_bwd d=512 (data gradient + GLU backward)", lambda: hip.dwglu_bwd(dcc, hh, wdw, B, T), 0, 5 * eb)
+    group(52, "dwglu_wgrad d=512", lambda: hip.dwglu_wgrad(dcc, hh, gdw, B, T), 0, 3 * eb)
+    # ---- fp8 GEMM (csrc/gemm_fp8.hip)
+    for tag, (M_, N_, K_) in ((60, (Mr, 2048, 512)), (61, (Mr, 1024, 3072))):
+        A = rnd(M_, K_); Bm = rnd(N_, K_, scale=0.05)
+        Aq, sa = hip.fp8_quantize(A); Bq, sb = hip.fp8_quantize(Bm)
+        out = torch.empty((M_, N_), dtype=torch.bfloat16, device=dev)
+        group(tag, "fp8 gemm %dx%dx%d (e4m3, block-scaled MFMA)" % (M_, N_, K_), lambda: hip.gemm_fp8(Aq, sa, Bq, sb, M=M_, N=N_, K=K_, out=out),
+              2.0 * M_ * N_ * K_, 1.0 * (M_ * K_ + N_ * K_) + 2.0 * M_ * N_)
+        group(tag + 2, "fp8 activation quantise %dx%d (amax + convert)" % (M_, K_), lambda: hip.fp8_quantize(A), 0, 2.0 * 2 * M_ * K_ + M_ * K_)
     import json
     print("PROF_TAGS " + json.dumps(TAGS))
 
