@@ -201,6 +201,20 @@ int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char*
 int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, long n, float gscale, float lr, float beta1,
                      float beta2, float eps, int step, void* stream);
 
+/* ---- device-resident step state: what varies from step to step when the whole step (code/learner.py:93-115: forward, backward,
+ *      optimizer.step(), optimizer.zero_grad()) is replayed from a hipGraph with frozen launch arguments.  `state` is
+ *      sarssl_step_state_bytes() of device memory: dropout salt (added to every launch's seed), Adam step count, lr, betas and the
+ *      bias-correction factors.  sarssl_step_tick is the first node of a step (next salt, step += 1); sarssl_step_state_reset is the
+ *      "optimizer re-created at the start of every epoch" of code/learner.py:83; attach(state) makes the launch wrappers hand the
+ *      salt pointer to the dropout-drawing kernels (attach(NULL) detaches - keep it attached only around graph capture). */
+long sarssl_step_state_bytes(void);
+int sarssl_step_state_init(void* state, unsigned long long salt, float lr, float beta1, float beta2, void* stream);
+int sarssl_step_state_reset(void* state, float lr, float beta1, float beta2, void* stream);
+int sarssl_step_state_attach(void* state);
+int sarssl_step_tick(void* state, void* stream);
+int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, long n, float gscale, const void* state, float eps,
+                         int zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

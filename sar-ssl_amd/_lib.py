@@ -34,7 +34,12 @@ def check(rc, what=""):
         raise SarsslHipError("%s failed (rc=%d): %s" % (what, rc, lib().sarssl_last_error().decode()))
 
 
+ncalls = 0          # C-ABI calls made so far (launch accounting: tools/host_time.py, graph.py's empty-segment check)
+
+
 def call(name, *args):
+    global ncalls
+    ncalls += 1
     fn = getattr(lib(), name)
     check(fn(*args), name)
 

@@ -34,3 +34,49 @@ int sarssl_cu_count() {
     }
     return cached[dev];
 }
+
+// ---- device-resident step state ----------------------------------------------------------------------------------------------------
+// A training step captured into a hipGraph replays with frozen kernel arguments, so everything that changes from step to step lives
+// in device memory: the dropout salt (added to each launch's static seed) and the Adam step count / bias corrections.
+static const unsigned long long* g_salt = nullptr;
+const unsigned long long* sarssl_dropout_salt() { return g_salt; }
+// state: device pointer to a SarsslStepState (or null to detach).  While attached, every launch that draws dropout masks reads the
+// salt through this pointer - attach only around graph capture: the pointer is baked into the captured launches.
+extern "C" int sarssl_step_state_attach(void* state) {
+    g_salt = state ? &((const SarsslStepState*)state)->salt : nullptr;
+    return 0;
+}
+extern "C" long sarssl_step_state_bytes() { return (long)sizeof(SarsslStepState); }
+
+__global__ void step_state_init_kernel(SarsslStepState* s, unsigned long long salt, float lr, float beta1, float beta2) {
+    s->salt = salt; s->step = 0; s->lr = lr; s->beta1 = beta1; s->beta2 = beta2; s->step_size = 0.f; s->inv_bc2_sqrt = 1.f;
+}
+// (re)start: step count 0 (a fresh torch.optim.Adam, code/learner.py:83), learning rate, betas; salt_seed != 0 also reseeds the salt
+__global__ void step_state_reset_kernel(SarsslStepState* s, float lr, float beta1, float beta2) {
+    s->step = 0; s->lr = lr; s->beta1 = beta1; s->beta2 = beta2;
+}
+extern "C" int sarssl_step_state_init(void* state, unsigned long long salt, float lr, float beta1, float beta2, void* stream) {
+    step_state_init_kernel<<<1, 1, 0, (hipStream_t)stream>>>((SarsslStepState*)state, salt, lr, beta1, beta2);
+    SARSSL_CHECK_LAUNCH("step_state_init_kernel");
+    return 0;
+}
+extern "C" int sarssl_step_state_reset(void* state, float lr, float beta1, float beta2, void* stream) {
+    step_state_reset_kernel<<<1, 1, 0, (hipStream_t)stream>>>((SarsslStepState*)state, lr, beta1, beta2);
+    SARSSL_CHECK_LAUNCH("step_state_reset_kernel");
+    return 0;
+}
+// once per step, first node of the graph: next salt (SplitMix64 increment), next Adam step and its bias corrections - computed in
+// double exactly like the host does for sarssl_adam_step, so both paths produce the same f32 factors
+__global__ void step_tick_kernel(SarsslStepState* s) {
+    s->salt += 0x9E3779B97F4A7C15ull;
+    const int t = s->step + 1;
+    s->step = t;
+    const double bc1 = 1.0 - pow((double)s->beta1, (double)t), bc2 = 1.0 - pow((double)s->beta2, (double)t);
+    s->step_size = (float)((double)s->lr / bc1);
+    s->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
+extern "C" int sarssl_step_tick(void* state, void* stream) {
+    step_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>((SarsslStepState*)state);
+    SARSSL_CHECK_LAUNCH("step_tick_kernel");
+    return 0;
+}

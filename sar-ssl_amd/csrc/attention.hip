@@ -30,6 +30,7 @@ struct AttnArgs {
     float* dsum;                       // (B,H,T): sum_c dctx * ctx
     int B, H, T;
     float scale, p_drop; unsigned long long seed;
+    const unsigned long long* salt;    // device-resident addend of the seed (graph replay), or null
 };
 
 #define LOG2E 1.4426950408889634f
@@ -74,7 +75,7 @@ __device__ __forceinline__ float half_swap_f(float v) { return __shfl_xor(v, 32,
 
 // keep-scale of attention probability (bh, i, j)
 __device__ __forceinline__ float attn_keep(const AttnArgs& a, unsigned long long rowbase, int j, float inv_keep) {
-    return dropout_scale(a.seed, rowbase + (unsigned long long)j, a.p_drop, inv_keep);
+    return dropout_scale(salted_seed(a.seed, a.salt), rowbase + (unsigned long long)j, a.p_drop, inv_keep);
 }
 
 // ------------------------------------------------------------------------------------------------------------------- forward
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
                 const float p = (i < T && key_ok) ? exp2f(x - sStat[il]) : 0.f;
                 float keep = 1.0f;
                 if (a.p_drop > 0.f)
-                    keep = dropout_scale(a.seed, ((unsigned long long)bh * T + (unsigned long long)(i < T ? i : 0)) * (unsigned long long)T + (unsigned long long)(key_ok ? j : 0),
+                    keep = dropout_scale(salted_seed(a.seed, a.salt), ((unsigned long long)bh * T + (unsigned long long)(i < T ? i : 0)) * (unsigned long long)T + (unsigned long long)(key_ok ? j : 0),
                                          a.p_drop, inv_keep);
                 s[f][r] = a.scale * p * (keep * dp[f][r] - sStat[TQ + il]);       // dScore^T
                 dp[f][r] = p * keep;                                               // dropped probability
@@ -585,7 +586,7 @@ extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, c
     SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr, "sarssl_relpos_attn_fwd");
     AttnArgs a = {};
     a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
-    a.ctx = (bf16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    a.ctx = (bf16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     dim3 grid((T + 127) / 128, B * H);
     hipStream_t st = (hipStream_t)stream;
     if (dh == 128) relpos_attn_fwd_kernel<128><<<grid, 256, 0, st>>>(a);
@@ -607,7 +608,7 @@ extern "C" int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, c
     a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
     a.ctx32 = (float*)ctx32; a.lse = (float*)lse; a.dctx = (const bf16*)dctx; a.lddc = lddc;
     a.dqu = (bf16*)dqu; a.lddq = lddq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddk = lddk; a.dbias = (bf16*)dbias; a.dsum = dsum;
-    a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     hipStream_t st = (hipStream_t)stream;
     const long nrow = (long)B * T * H;
     relpos_attn_dsum_kernel<<<(unsigned)((nrow + 3) / 4), 256, 0, st>>>(a, dh);

@@ -15,6 +15,16 @@ enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2 };
 extern "C" const char* sarssl_last_error();
 void sarssl_set_error(const char* fmt, ...);
 int sarssl_cu_count();          // CUs of the current device (api.hip): grid size of the persistent kernels
+// Device-resident step state (api.hip, sarssl_step_state_*): lets a step captured in a hipGraph vary per replay.  `salt` is added to
+// every dropout seed by the kernels (null / 0 outside graph capture); the Adam fields are advanced by sarssl_step_tick.
+struct SarsslStepState {
+    unsigned long long salt;
+    int step;                    // Adam step count (1-based after the first tick)
+    float lr, beta1, beta2;
+    float step_size;             // lr / (1 - beta1^step)
+    float inv_bc2_sqrt;          // 1 / sqrt(1 - beta2^step)
+};
+const unsigned long long* sarssl_dropout_salt();   // pointer the launch wrappers hand to kernels that draw dropout masks (may be null)
 #define SARSSL_CHECK_LAUNCH(name)                                          \
     do {                                                                   \
         hipError_t e__ = hipGetLastError();                                \
@@ -125,6 +135,7 @@ __device__ __forceinline__ uint32_t dropout_key(uint64_t seed, uint32_t idx_hi) 
     return hash_u32(idx_hi + (uint32_t)seed) ^ (uint32_t)(seed >> 32) * 0x9e3779b9u;
 }
 __device__ __forceinline__ uint32_t dropout_thr16(float p_drop) { return (uint32_t)(p_drop * 65536.0f + 0.5f); }
+__device__ __forceinline__ uint64_t salted_seed(uint64_t seed, const unsigned long long* salt) { return salt ? seed + *salt : seed; }
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p_drop, float inv_keep) {
     const uint32_t h = hash_u32((uint32_t)(idx >> 1) ^ dropout_key(seed, (uint32_t)(idx >> 33)));
     const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);

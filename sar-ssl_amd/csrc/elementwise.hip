@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_relshift_fwd_kernel(const float* __restrict__ content, const float* __restrict__ pos,
                                                                    long nrows_total, int Tn, float scale, T* __restrict__ p,
-                                                                   T* __restrict__ pd, float p_drop, unsigned long long seed) {
+                                                                   T* __restrict__ pd, float p_drop, unsigned long long seed0,
+                                                                   const unsigned long long* __restrict__ salt) {
+    const unsigned long long seed = salted_seed(seed0, salt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (long row = (long)blockIdx.x * 4 + wave; row < nrows_total; row += (long)gridDim.x * 4) {
@@ -368,8 +370,9 @@ __global__ __launch_bounds__(256) void softmax_relshift_fwd_kernel(const float* 
 // dscore = scale * p * (dp - sum_j dp*p),  dp = dpd * dropout mask
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dpd, const T* __restrict__ p, long nrows_total,
-                                                          int Tn, float scale, float p_drop, unsigned long long seed,
-                                                          T* __restrict__ dscore) {
+                                                          int Tn, float scale, float p_drop, unsigned long long seed0,
+                                                          T* __restrict__ dscore, const unsigned long long* __restrict__ salt) {
+    const unsigned long long seed = salted_seed(seed0, salt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (long row = (long)blockIdx.x * 4 + wave; row < nrows_total; row += (long)gridDim.x * 4) {
@@ -508,7 +511,8 @@ __global__ void colsum_multi_kernel(ColsumMulti a) {
 //   act 1: relu, h_is_post = 1 means h holds relu output;  act 2: swish with h = pre-activation;  act 0: none
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ h, long n, int act, float p_drop,
-                               unsigned long long seed, float gscale, T* __restrict__ dh) {
+                               unsigned long long seed0, float gscale, T* __restrict__ dh, const unsigned long long* __restrict__ salt) {
+    const unsigned long long seed = salted_seed(seed0, salt);
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += (long)gridDim.x * blockDim.x) {
         const float4 d = ld4(dz + i * 4);
@@ -640,6 +644,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Same update with the step-dependent factors read from the device-resident step state (graph replay), optionally clearing the
+// gradient buffer in the same pass (the reference's optimizer.zero_grad() right after optimizer.step(), code/learner.py:113-115).
+__global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                bf16* __restrict__ p16, long n, float gscale, const SarsslStepState* __restrict__ st, float eps, int zero_g) {
+    const float beta1 = st->beta1, beta2 = st->beta2, step_size = st->step_size, inv_bc2_sqrt = st->inv_bc2_sqrt;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        const float pi = p[i] - step_size * mi / denom;
+        p[i] = pi;
+        if (p16) st_f(p16 + i, pi);
+        if (zero_g) g[i] = 0.f;
+    }
+}
+
 // ================================================================================================ C ABI
 extern "C" int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps,
                                     void* y, long ldy, float* mean, float* rstd, int dtype, void* stream) {
@@ -717,7 +739,7 @@ extern "C" int sarssl_softmax_relshift_fwd(const float* content, const float* po
                                            void* pd, float p_drop, unsigned long long seed, int dtype, void* stream) {
     SARSSL_REQUIRE(Tn > 0 && Tn <= 64 * SM_MAXV, "sarssl_softmax_relshift_fwd(T <= 1024)");
     const int nblk = nblocks_for(nmat * Tn, 4, 8192);
-    DISPATCH_T(dtype, (softmax_relshift_fwd_kernel<T><<<nblk, 256, 0, ST>>>(content, pos, nmat * Tn, Tn, scale, (T*)p, (T*)pd, p_drop, seed)));
+    DISPATCH_T(dtype, (softmax_relshift_fwd_kernel<T><<<nblk, 256, 0, ST>>>(content, pos, nmat * Tn, Tn, scale, (T*)p, (T*)pd, p_drop, seed, sarssl_dropout_salt())));
     SARSSL_CHECK_LAUNCH("softmax_relshift_fwd_kernel");
     return 0;
 }
@@ -725,7 +747,7 @@ extern "C" int sarssl_softmax_bwd(const float* dpd, const void* p, long nmat, in
                                   unsigned long long seed, void* dscore, int dtype, void* stream) {
     SARSSL_REQUIRE(Tn > 0 && Tn <= 64 * SM_MAXV, "sarssl_softmax_bwd(T <= 1024)");
     const int nblk = nblocks_for(nmat * Tn, 4, 8192);
-    DISPATCH_T(dtype, (softmax_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dpd, (const T*)p, nmat * Tn, Tn, scale, p_drop, seed, (T*)dscore)));
+    DISPATCH_T(dtype, (softmax_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dpd, (const T*)p, nmat * Tn, Tn, scale, p_drop, seed, (T*)dscore, sarssl_dropout_salt())));
     SARSSL_CHECK_LAUNCH("softmax_bwd_kernel");
     return 0;
 }
@@ -789,7 +811,7 @@ extern "C" int sarssl_colsum_multi(const void* const* xs, const long* ldxs, cons
 extern "C" int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,
                               void* dh, int dtype, void* stream) {
     SARSSL_REQUIRE((n & 3) == 0, "sarssl_act_bwd(n % 4)");
-    DISPATCH_T(dtype, (act_bwd_kernel<T><<<nblocks_for(n >> 2, 256), 256, 0, ST>>>((const T*)dz, (const T*)h, n, act, p_drop, seed, gscale, (T*)dh)));
+    DISPATCH_T(dtype, (act_bwd_kernel<T><<<nblocks_for(n >> 2, 256), 256, 0, ST>>>((const T*)dz, (const T*)h, n, act, p_drop, seed, gscale, (T*)dh, sarssl_dropout_salt())));
     SARSSL_CHECK_LAUNCH("act_bwd_kernel");
     return 0;
 }
@@ -835,5 +857,13 @@ extern "C" int sarssl_adam_step(float* p, const float* g, float* m, float* v, vo
     adam_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, n, gscale, beta1, beta2, (float)(lr / bc1),
                                                            (float)(1.0 / sqrt(bc2)), eps);
     SARSSL_CHECK_LAUNCH("adam_kernel");
+    return 0;
+}
+extern "C" int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, long n, float gscale, const void* state,
+                                    float eps, int zero_grad, void* stream) {
+    SARSSL_REQUIRE(n > 0 && state, "sarssl_adam_step_dev");
+    adam_dev_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, n, gscale, (const SarsslStepState*)state, eps,
+                                                               zero_grad);
+    SARSSL_CHECK_LAUNCH("adam_dev_kernel");
     return 0;
 }

@@ -376,7 +376,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.alpha = alpha; g.out_scale = out_scale; g.bias = bias; g.act = act;
     g.resid = resid; g.ldr = ldr; g.sR0 = sR0; g.sR1 = sR1; g.res_scale = res_scale;
     g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
-    g.p_drop = p_drop; g.seed = seed;
+    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt();
     g.split_k = 0; g.k_per_split = K;
     g.row_shift = 0;
     if (c_row_shift) {

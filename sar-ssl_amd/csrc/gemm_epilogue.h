@@ -16,7 +16,7 @@ struct GemmArgs {
     const void* aux; int aux_act;   // optional (same dtype/ld as C): multiply by act'(aux) (1 relu, 2 swish) - fused activation backward
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
-    float p_drop; unsigned long long seed;
+    float p_drop; unsigned long long seed; const unsigned long long* salt;   // salt: device-resident seed addend (graph replay) or null
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
     int row_shift;              // != 0 (= T, with M = N = ldc = T): row m of every batch matrix is stored m + 1 - T elements further
                                 // (elements falling before the matrix are dropped): the relative-position shift of the reference
@@ -86,10 +86,11 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m,
     }
     if (g.p_drop > 0.f) {
         const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
-        if ((base & 1ull) == 0 && (((base + 7) >> 33) == (base >> 33))) dropout_apply8(v.v, g.seed, base, g.p_drop, inv_keep);
+        const unsigned long long seed = salted_seed(g.seed, g.salt);
+        if ((base & 1ull) == 0 && (((base + 7) >> 33) == (base >> 33))) dropout_apply8(v.v, seed, base, g.p_drop, inv_keep);
         else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(g.seed, base + e, g.p_drop, inv_keep);
+            for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(seed, base + e, g.p_drop, inv_keep);
         }
     }
 #pragma unroll

@@ -1,0 +1,277 @@
+"""One pretraining step (code/learner.py:93-115: data -> model -> loss.backward() -> optimizer.step() -> optimizer.zero_grad())
+captured into HIP graphs and replayed.
+
+Why: the eager step enqueues ~450 launches from Python (9 ms of host time against 14 ms of GPU time at batch 64); every kernel-side
+gain beyond that would be hidden by the host.  A captured step costs the host one graph launch.
+
+What makes a step replayable although launch arguments are frozen at capture:
+  * masks: drawn on the host exactly as before (Python's MT19937, bit-identical to the reference), written into ONE pinned staging
+    buffer and copied into fixed device buffers before the replay;
+  * dropout: every launch keeps its static seed and adds a device-resident salt that the first node of the graph advances
+    (csrc/api.hip, SarsslStepState) - forward and backward of one replay see the same salt, two replays never do;
+  * Adam: step count and bias corrections live in the same device state (``sarssl_adam_step_dev``); learning rate / "optimizer
+    re-created per epoch" (learner.py:83) are a one-thread reset kernel; the gradient buffer is cleared in the Adam pass;
+  * re-laid-out weights (conv taps, patch-GEMM weight, fp8 copies) are rebuilt inside the graph from the shadow weights the Adam
+    kernel of the previous replay wrote.
+
+Data parallel (world > 1): the collectives stay OUTSIDE the graphs.  The step is cut into segments at the points where a gradient
+bucket becomes final (model._PretrainFn.backward: decoder | Conformer blocks + patch GEMMs | stems); between two segments the
+bucket's all-reduce is issued eagerly (RCCL, its own stream) and runs underneath the next segment - four graph launches and four
+collectives per step instead of ~450 launches.
+"""
+import numpy as np
+import torch
+
+from . import hip, runtime, _lib
+from .runtime import RT
+
+
+class _Ctx:
+    """Stand-in for the autograd ctx: the hand-written forward / backward pair is called directly."""
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+class PretrainStepGraph:
+    """``g = PretrainStepGraph(net, flat, lr=...)``; ``g.step(x)`` or ``g.step(pcm=...)`` runs one training step and returns the
+    device tensor ``[loss, diff]`` (overwritten by the next step).  Captured lazily for the first input shape; inputs of another
+    shape raise (the caller falls back to the eager step for ragged tail batches)."""
+
+    def __init__(self, net, flat, reducer=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, two_streams=None):
+        assert net.pretrain and flat.on_gpu
+        self.net, self.flat, self.reducer = net, flat, reducer
+        self.lr, self.betas, self.eps = float(lr), betas, eps
+        self.dev = flat.flat.device
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.state = hip.step_state_new(self.dev, RT._seed ^ 0x6A09E667F3BCC909, self.lr, betas)
+        self.acc = torch.zeros(2, dtype=torch.float64, device=self.dev)        # running sum of (loss, diff) since reset_epoch()
+        self.nsteps = 0
+        self._plan = None
+        self._key = None
+        self._pool = None
+        self._stage = []          # ring of (pinned staging buffer, event) for the masks
+        self._stage_i = 0
+        self.zero_grad_in_adam = True     # optimizer.zero_grad() folded into the Adam pass (tests switch it off to read the gradient)
+
+    # ------------------------------------------------------------------------------------------------ optimizer interface
+    def reset_epoch(self, lr=None):
+        """The reference constructs a new Adam at the start of every epoch (learner.py:83): moments and step count restart."""
+        if lr is not None:
+            self.lr = float(lr)
+        self.m.zero_()
+        self.v.zero_()
+        hip.step_state_reset(self.state, self.lr, self.betas)
+        self.acc.zero_()
+        self.nsteps = 0
+
+    # ------------------------------------------------------------------------------------------------ masks
+    def _mask_layout(self, B, T, nm):
+        o_idx, o_ch, o_mp = 0, B * nm * 4, B * nm * 4 + B * 4
+        return o_idx, o_ch, o_mp, o_mp + B * T
+
+    def _draw_masks(self, B, T, consume_rng=True):
+        net = self.net
+        if consume_rng and net._forced_masks is not None:
+            idx, ch = net._forced_masks
+            net._forced_masks = None
+        elif consume_rng:
+            idx, ch = net.patch_mask.sample(B, 2)
+        else:                                               # capture warm-up: must not advance the python RNG the reference shares
+            nm = net.patch_mask.nmasked_patch
+            idx = np.tile(np.arange(nm, dtype=np.int64)[None, :] * 2 % T, (B, 1))
+            ch = np.zeros((B,), dtype=np.int64)
+        return np.asarray(idx), np.asarray(ch).reshape(-1)
+
+    def _upload_masks(self, idx, ch, B, T):
+        nm = idx.shape[1]
+        o_idx, o_ch, o_mp, total = self._mask_layout(B, T, nm)
+        if not self._stage:
+            self._stage = [(torch.empty(total, dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+        buf, ev = self._stage[self._stage_i]
+        self._stage_i = (self._stage_i + 1) % len(self._stage)
+        ev.synchronize()                                    # the copy issued four steps ago has long been consumed
+        h = buf.numpy()
+        h[o_idx:o_ch].view(np.int32)[:] = idx.astype(np.int32).reshape(-1)
+        h[o_ch:o_mp].view(np.int32)[:] = ch.astype(np.int32)
+        mp = h[o_mp:total].reshape(B, T)
+        mp[:] = 1
+        np.put_along_axis(mp, idx.astype(np.int64), 0, axis=1)
+        self.mbuf.copy_(buf, non_blocking=True)
+        ev.record()
+
+    # ------------------------------------------------------------------------------------------------ capture
+    def _body(self, seg, src, idx, ch, mp, from_pcm, with_adam=True):
+        """Enqueues one full step on the current stream(s); ``seg`` receives the cut points (None: plain eager enqueue)."""
+        from .model import _PretrainFn
+        net = self.net
+        if with_adam:
+            hip.step_tick(self.state)
+        x = hip.stft_frontend(src) if from_pcm else src
+        ctx = _Ctx()
+        loss, out, pred = _PretrainFn.forward(ctx, net, x, idx, ch, mp)
+        self.out.copy_(out)
+        self.acc.add_(out.double())
+        self.pred, self.xin, self.vis_masks = pred, x, (mp, ch)
+        _PretrainFn.backward(ctx, self.one, None, None)
+        if not with_adam:
+            return
+        world = self.reducer.world if self.reducer is not None else 1
+        if world > 1:
+            if seg is not None:
+                seg.cut(("finish", None))
+            else:
+                self.reducer.finish()
+        hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
+                          zero_grad=self.zero_grad_in_adam)
+
+    def step_eager(self, x=None, pcm=None):
+        """The same step enqueued launch by launch (inputs whose shape differs from the captured one, e.g. a ragged last batch):
+        shares the Adam moments / step count / accumulators with the captured step."""
+        assert (x is None) != (pcm is None)
+        src = pcm if pcm is not None else x
+        if pcm is not None:
+            B, T = pcm.shape[0], (pcm.shape[1] - 512) // 256 + 1
+        else:
+            B, T = x.shape[0], x.shape[3]
+        if not hasattr(self, "out"):
+            self.out = torch.zeros(2, dtype=torch.float32, device=self.dev)
+            self.one = torch.ones((), dtype=torch.float32, device=self.dev)
+        self.flat._fresh = False
+        self.flat.ensure_shadow()
+        idx, ch, mp = self.net._masks(B, T, self.dev)
+        self._body(None, src, idx, ch, mp, pcm is not None, with_adam=True)
+        runtime.bump_version()
+        self.nsteps += 1
+        return self.out
+
+    def _capture(self, x, pcm, static=False):
+        net, dev = self.net, self.dev
+        src = pcm if pcm is not None else x
+        self.src = src if static else src.clone()          # input buffer of the graph (static: the caller's tensor is persistent and refilled in place)
+        if pcm is not None:
+            nb, nsample, nch = pcm.shape
+            assert nch == 2, "graph step: 2-channel segments ('M' pairing of two mics)"
+            B, T = nb, (nsample - 512) // 256 + 1
+        else:
+            B, T = x.shape[0], x.shape[3]
+        nm = net.patch_mask.nmasked_patch
+        o_idx, o_ch, o_mp, total = self._mask_layout(B, T, nm)
+        self.mbuf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        self.idx = self.mbuf[o_idx:o_ch].view(torch.int32).view(B, nm)
+        self.ch = self.mbuf[o_ch:o_mp].view(torch.int32)
+        self.mp = self.mbuf[o_mp:total].view(B, T)
+        self.out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.one = torch.ones((), dtype=torch.float32, device=dev)
+        self.B, self.T = B, T
+
+        # ---- warm-up: one eager pass without side effects (lazy kernel loading, workspaces, allocator) - buffers restored, no Adam
+        bufs = [b for b in net.buffers()]
+        keep = [b.clone() for b in bufs]
+        acc_keep = self.acc.clone()
+        hook, net._stage_hook = net._stage_hook, None
+        idx, ch = self._draw_masks(B, T, consume_rng=False)
+        self._upload_masks(idx, ch, B, T)
+        torch.cuda.synchronize()
+        cur = torch.cuda.current_stream()
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(cur)
+        try:
+            with torch.cuda.stream(cap):
+                self._body(None, self.src, self.idx, self.ch, self.mp, pcm is not None, with_adam=False)
+                cap.synchronize()
+                self.flat.grad.zero_()
+                for b, k in zip(bufs, keep):
+                    b.copy_(k)
+                self.acc.copy_(acc_keep)
+                runtime.bump_version()            # every re-laid-out weight cache misses during capture: its rebuild becomes graph nodes
+                seg = _Segments(self, cap)
+                net._stage_hook = seg.on_stage
+                net._cut_mode = self.reducer is not None and self.reducer.world > 1
+                hip.step_state_attach(self.state)
+                try:
+                    self._seed_ctr0 = RT._ctr               # (tests: the static dropout seeds of the captured launches)
+                    seg.begin()
+                    self._body(seg, self.src, self.idx, self.ch, self.mp, pcm is not None, with_adam=True)
+                    seg.end()
+                finally:
+                    hip.step_state_attach(None)
+                    net._cut_mode = False
+        finally:
+            net._stage_hook = hook
+        cur.wait_stream(cap)
+        torch.cuda.synchronize()
+        self._plan = seg.plan
+        self._key = (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, net.training)
+
+    # ------------------------------------------------------------------------------------------------ replay
+    def matches(self, x=None, pcm=None):
+        src = pcm if pcm is not None else x
+        return self._key is None or self._key == (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, self.net.training)
+
+    def step(self, x=None, pcm=None, static=False):
+        assert (x is None) != (pcm is None)
+        assert RT.replay is None, "replayed dropout masks (parity tests) need the eager step"
+        src = pcm if pcm is not None else x
+        if self._plan is None:
+            self._capture(x, pcm, static)
+        elif not self.matches(x, pcm):
+            raise ValueError("PretrainStepGraph was captured for %r, got %r" % (self._key[0], tuple(src.shape)))
+        else:
+            if self.src.data_ptr() != src.data_ptr():
+                self.src.copy_(src, non_blocking=True)
+        self.flat._fresh = False
+        self.flat.ensure_shadow()                          # parameters changed through torch since the last step (load_state_dict, ...)
+        idx, ch = self._draw_masks(self.B, self.T)
+        self._upload_masks(idx, ch, self.B, self.T)
+        for kind, item in self._plan:
+            if kind == "graph":
+                item.replay()
+            elif kind == "reduce":
+                self.reducer._on_stage(item)
+            else:                                           # "finish": wait for the buckets (stream-side for RCCL)
+                self.reducer.finish()
+        runtime.bump_version()                             # weights moved: eager users of the re-laid-out caches must rebuild
+        self.nsteps += 1
+        return self.out
+
+    def vis(self):
+        """vis dict of the last step (same keys as SARSSL.forward's third result)."""
+        from .model import LazyVis
+        return LazyVis(self.pred, self.xin, self.vis_masks[0], self.vis_masks[1])
+
+
+class _Segments:
+    """Capture as a sequence of graphs sharing one memory pool, cut where an eager action (a collective) has to run in between."""
+
+    def __init__(self, owner, stream):
+        self.owner, self.stream = owner, stream
+        self.plan = []
+        self.g = None
+        self.pool = None
+
+    def begin(self):
+        self.g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        self.g.capture_begin(pool=self.pool, capture_error_mode="thread_local")      # (loader threads may be making HIP calls)
+        self.mark = _lib.ncalls
+
+    def end(self):
+        self.g.capture_end()
+        self.plan.append(("graph", self.g))
+        self.g = None
+
+    def cut(self, action):
+        if _lib.ncalls == self.mark and self.plan and self.plan[-1][0] != "graph":
+            self.plan.append(action)                       # nothing was enqueued since the previous cut: no empty graph in between
+            return
+        self.end()
+        self.plan.append(action)
+        self.begin()
+
+    def on_stage(self, name):
+        red = self.owner.reducer
+        if red is not None and red.world > 1 and name in red.spans:
+            self.cut(("reduce", name))

@@ -728,3 +728,33 @@ def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0, gscale_dev=None):
 def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8):
     _lib.call("sarssl_adam_step", _p(p), _p(g), _p(m), _p(v), _p(p16), c_long(p.numel()), c_float(gscale), c_float(lr),
               c_float(betas[0]), c_float(betas[1]), c_float(eps), c_int(step), _stream())
+
+
+# ---- device-resident step state (graph replay: dropout salt, Adam step count / bias corrections; csrc/api.hip) --------------
+def step_state_new(device, salt, lr, betas=(0.9, 0.999)):
+    nbytes = _lib.lib().sarssl_step_state_bytes
+    nbytes.restype = c_long
+    st = torch.zeros((int(nbytes()) + 7) // 8 * 8, dtype=torch.uint8, device=device)
+    _lib.call("sarssl_step_state_init", _p(st), c_ulonglong(salt & 0xFFFFFFFFFFFFFFFF), c_float(lr), c_float(betas[0]), c_float(betas[1]),
+              _stream())
+    return st
+
+
+def step_state_reset(st, lr, betas=(0.9, 0.999)):
+    """Adam step count back to 0 (a freshly constructed optimizer), new learning rate; the dropout salt keeps running."""
+    _lib.call("sarssl_step_state_reset", _p(st), c_float(lr), c_float(betas[0]), c_float(betas[1]), _stream())
+
+
+def step_state_attach(st):
+    """While attached (st not None) every launch that draws dropout masks adds the state's salt to its seed: attach only around
+    graph capture - the pointer is baked into the captured launches, eager launches afterwards run unsalted again."""
+    _lib.call("sarssl_step_state_attach", _p(st))
+
+
+def step_tick(st):
+    _lib.call("sarssl_step_tick", _p(st), _stream())
+
+
+def adam_step_dev(p, g, m, v, p16, st, gscale=1.0, eps=1e-8, zero_grad=False):
+    _lib.call("sarssl_adam_step_dev", _p(p), _p(g), _p(m), _p(v), _p(p16), c_long(p.numel()), c_float(gscale), _p(st), c_float(eps),
+              c_int(1 if zero_grad else 0), _stream())

@@ -61,6 +61,8 @@ class Learner(ABC):
     # ---- pretraining (code/learner.py:76-167) ------------------------------------------------------------------------
     def pretrain_epoch(self, dataset, lr=0.0001, epoch=None, return_diff=True):
         self.model.train()
+        if self._use_step_graph():
+            return self._pretrain_epoch_graph(dataset, lr, return_diff)
         optimizer = runtime.FusedAdam(self._flat, lr=float(lr), betas=(0.9, 0.999))        # re-created every epoch (learner.py:83)
         optimizer.zero_grad()
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)
@@ -77,12 +79,41 @@ class Learner(ABC):
             acc[0] += loss_batch.detach().double()                                           # no per-step .item() sync
             acc[1] += diff_batch.detach().double()
             n += 1
+        return self._epoch_means(acc, n, vis_batch, return_diff)
+
+    def _epoch_means(self, acc, n, vis_batch, return_diff):
         acc = acc / max(n, 1)
         if sdist.world_size() > 1:
             torch.distributed.all_reduce(acc)
             acc /= sdist.world_size()
         loss, diff = float(acc[0]), float(acc[1])
         return (loss, diff, vis_batch) if return_diff else loss
+
+    def _use_step_graph(self):
+        """The captured step (graph.py) is the default training step; SARSSL_GRAPH=0, replayed dropout masks (parity fixtures that
+        need the reference's draw order) and models without the pretraining node fall back to the launch-by-launch step."""
+        return (os.environ.get("SARSSL_GRAPH", "1") != "0" and runtime.RT.replay is None and getattr(self.model, "pretrain", False)
+                and self._flat is not None and self._flat.on_gpu)
+
+    def _pretrain_epoch_graph(self, dataset, lr, return_diff):
+        """Same epoch with every full-size batch replayed from the captured HIP graph(s); batches of another shape (a ragged last
+        batch) take the same step eagerly and share the optimizer state."""
+        from .graph import PretrainStepGraph
+        g = self.__dict__.get("_step_graph")
+        if g is None:
+            g = self.__dict__["_step_graph"] = PretrainStepGraph(self.model, self._flat, self._reducer, lr=float(lr), betas=(0.9, 0.999))
+        g.reset_epoch(float(lr))                                                            # "Adam re-created every epoch" (learner.py:83)
+        self._flat.grad.zero_()
+        for batch in dataset:
+            mic_sig_batch = batch[0] if isinstance(batch, (list, tuple)) else batch
+            in_batch, = self.data_preprocess(mic_sig_batch, None)
+            in_batch = in_batch.contiguous().float()
+            if g.matches(x=in_batch):
+                g.step(x=in_batch)
+            else:
+                g.step_eager(x=in_batch)
+        vis_batch = g.vis() if g.nsteps else None
+        return self._epoch_means(g.acc.clone(), g.nsteps, vis_batch, return_diff)
 
     def pretest_epoch(self, dataset, return_diff=True, return_eval=False):
         self.model.eval()

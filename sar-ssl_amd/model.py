@@ -206,12 +206,19 @@ class _PretrainFn(torch.autograd.Function):
         d_spec = decat[:, :ds]
         for blk in reversed(spe.embed.layers):
             d_spec = engine.block_bwd(d_spec, blk, saved)
-        with on_side():
+        cut = side is not None and getattr(net, "_cut_mode", False)   # graph capture cut at the bucket boundaries (graph.py): a cut
+        with on_side():                                               # needs both streams joined, so the two hooks fire after the join
             d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat)
             dz_spat = engine.patch_bwd(d_spat, spa.patch_embed, saved_spat)
-            net._after_backward_stage("spat_encoder")          # its bucket is reduced behind the side stream
+            if not cut:
+                net._after_backward_stage("spat_encoder")      # its bucket is reduced behind the side stream
         dz_spec = engine.patch_bwd(d_spec, spe.patch_embed, saved)
+        if cut:
+            main.wait_stream(side)
+            net._after_backward_stage("spat_encoder")
         net._after_backward_stage("spec_encoder")
+        if cut:
+            side.wait_stream(main)
         net._after_backward_stage("stem_bwd_begin")            # (not a bucket: a marker for tests / tracing)
         engine.stem_bwd(dz_spec, spe.patch_embed, saved)
         with on_side():
@@ -262,6 +269,7 @@ class SARSSL(nn.Module):
                                                     nn.Linear(dembed_ds, downstream_dlabel))
             self.downstream_head, self.downstream_dlabel, self.ds_token = downstream_head, downstream_dlabel, downstream_token
         self._stage_hook = None
+        self._cut_mode = False
         self._param_list = None
         self._forced_masks = None
 

@@ -1,0 +1,206 @@
+"""GPU: the captured training step (sar_ssl_amd/graph.py) against the launch-by-launch step it replaces - same kernels, so the
+two must agree to accumulation-order noise; plus what only exists in the captured form (device-resident dropout salt / Adam step
+state, per-epoch optimizer reset, ragged tail batches, bucket-boundary cuts for data parallel)."""
+import json
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, check
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_dropout(m, p):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = p
+
+
+def _make(T, seed, p_drop):
+    from sar_ssl_amd import model, runtime
+    dev = torch.device("cuda:0")
+    torch.manual_seed(seed)
+    net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev)
+    _set_dropout(net, p_drop)
+    net.to(dev).train()
+    return net, runtime.FlatParams(net)
+
+
+def _batches(T, n, B):
+    from sar_ssl_amd import hip, synth
+    nsample = 512 + 256 * (T - 1)
+    sig = torch.from_numpy(synth.make_batch(3, n * B, nsample=nsample)).cuda()
+    return [hip.stft_frontend(sig[i * B:(i + 1) * B]) for i in range(n)]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_graph_step_equals_eager_step(prec):
+    """6 Adam steps, dropout off, same masks: per-step loss / diff, final parameters, BatchNorm running statistics."""
+    from sar_ssl_amd import runtime
+    from sar_ssl_amd.graph import PretrainStepGraph
+    runtime.set_precision(prec)
+    try:
+        T, B, n = 16, 4, 6
+        xs = _batches(T, n, B)
+        # eager
+        net_a, flat_a = _make(T, 11, 0.0)
+        opt = runtime.FusedAdam(flat_a, lr=1e-3)
+        opt.zero_grad()
+        random.seed(77)
+        ref = []
+        for x in xs:
+            loss, diff, _ = net_a(x)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            ref.append((float(loss), float(diff)))
+        # captured
+        net_b, flat_b = _make(T, 11, 0.0)
+        g = PretrainStepGraph(net_b, flat_b, lr=1e-3)
+        random.seed(77)
+        got = []
+        for x in xs:
+            out = g.step(x=x)
+            got.append((float(out[0]), float(out[1])))
+        assert sum(1 for k, _ in g._plan if k == "graph") == 1
+        ref, got = np.array(ref), np.array(got)
+        check("graph_vs_eager.%s.loss" % prec, np.abs(got[:, 0] - ref[:, 0]).max() / ref[:, 0].max(), 2e-5 if prec == "fp32" else 1.5e-3)
+        check("graph_vs_eager.%s.diff" % prec, np.abs(got[:, 1] - ref[:, 1]).max() / ref[:, 1].max(), 2e-5 if prec == "fp32" else 1.5e-3)
+        # the accumulators the epoch mean is read from
+        check("graph.acc_mean", abs(float(g.acc[0]) / n - got[:, 0].mean()) / got[:, 0].mean(), 1e-6)
+        # parameters: Adam's first updates are lr * sign(g), so accumulation-order noise in near-zero gradients moves single weights by
+        # up to 2 lr per step in bf16 - gate the bulk: fraction of weights further apart than half a step, and the difference norm
+        # relative to the norm of everything the six steps moved
+        moved = (flat_b.flat - flat_a.flat).abs().gt(0.5e-3).float().mean()
+        check("graph_vs_eager.%s.frac_params_off_by_half_lr" % prec, float(moved), 1e-3 if prec == "fp32" else 0.5)    # (bf16: run-to-run noise of the eager step itself, f32 atomics order; the sharp gate is the fp32 run)
+        torch.manual_seed(11)
+        from sar_ssl_amd import model as _model
+        p0 = torch.cat([p.detach().reshape(-1) for p in _model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device="cpu").parameters()])
+        total = float((torch.cat([p.detach().reshape(-1) for p in net_a.parameters()]).cpu() - p0).norm())
+        dn = float((torch.cat([p.detach().reshape(-1) for p in net_b.parameters()]) - torch.cat([p.detach().reshape(-1) for p in net_a.parameters()])).norm())
+        check("graph_vs_eager.%s.param_diff_norm_over_update_norm" % prec, dn / total, 2e-2 if prec == "fp32" else 0.6)
+        for (ka, a), (_, b) in zip(net_a.named_buffers(), net_b.named_buffers()):
+            if ka.endswith("num_batches_tracked"):
+                assert int(a) == int(b) == n, ka                       # the capture warm-up left no trace
+            elif "running" in ka:
+                assert float((a - b).abs().max()) <= (1e-3 if prec == "fp32" else 5e-2) * float(a.abs().max()) + 1e-6, ka
+    finally:
+        runtime.set_precision("bf16")
+
+
+def test_graph_dropout_salt_advances_per_replay_and_is_shared_by_backward():
+    """lr = 0: the weights never move, so with the same input and masks every replay computes the same function - outputs differ
+    between replays iff dropout is on (the salt advanced), and the gradient matches the eager gradient statistically."""
+    from sar_ssl_amd import runtime
+    from sar_ssl_amd.graph import PretrainStepGraph
+    T, B = 16, 4
+    x = _batches(T, 1, B)[0]
+    idx = np.tile(np.arange(T // 2)[None, :] * 2, (B, 1))
+    ch = np.array([0, 1, 0, 1])
+    for p, same in ((0.0, True), (0.1, False)):
+        net, flat = _make(T, 5, p)
+        g = PretrainStepGraph(net, flat, lr=0.0)
+        losses = []
+        for _ in range(4):
+            net.set_masks(idx, ch)
+            losses.append(float(g.step(x=x)[0]))
+        assert all(np.isfinite(losses))
+        if same:
+            assert max(losses) - min(losses) <= 5e-5 * abs(losses[0]), losses      # (f32 atomics order)
+        else:
+            assert len(set(losses)) == 4, losses                       # four different dropout draws
+            check("graph.dropout_loss_spread", (max(losses) - min(losses)) / abs(np.mean(losses)), 0.2)
+        assert float(flat.grad.abs().max()) == 0.0                     # cleared inside the Adam pass
+
+
+def test_graph_replay_gradient_equals_eager_gradient_under_the_same_salt():
+    """Dropout ON.  The gradient a replay leaves behind (Adam's zero_grad switched off, lr = 0) equals the gradient of the same
+    body enqueued eagerly with the step state attached, the same static seeds and the salt of that replay: the captured launches
+    read the salt the tick node wrote - forward and backward alike."""
+    from sar_ssl_amd import hip, runtime
+    from sar_ssl_amd.graph import PretrainStepGraph
+    T, B = 16, 4
+    x = _batches(T, 1, B)[0]
+    idx = np.tile(np.arange(T // 2)[None, :] * 2, (B, 1))
+    ch = np.array([1, 0, 1, 0])
+    net, flat = _make(T, 9, 0.1)
+    g = PretrainStepGraph(net, flat, lr=0.0)
+    g.zero_grad_in_adam = False
+    net.set_masks(idx, ch)
+    loss_replay = float(g.step(x=x)[0])                                # capture + first replay
+    g1 = flat.grad.clone()
+    assert float(g1.abs().max()) > 0
+    flat.grad.zero_()
+    keep = runtime.RT._ctr
+    hip.step_state_attach(g.state)
+    try:
+        runtime.RT._ctr = g._seed_ctr0
+        g._body(None, g.src, g.idx, g.ch, g.mp, False, with_adam=False)      # no tick: the salt is still the replay's
+    finally:
+        hip.step_state_attach(None)
+        runtime.RT._ctr = keep
+    g2 = flat.grad.clone()
+    check("graph.replay_vs_salted_eager.loss", abs(float(g.out[0]) - loss_replay) / abs(loss_replay), 5e-5)     # (f32 atomics order)
+    check("graph.replay_vs_salted_eager.grad", float((g1 - g2).abs().max() / g1.abs().max()), 1e-4)
+    # and an unsalted eager pass draws other masks
+    flat.grad.zero_()
+    runtime.RT._ctr = g._seed_ctr0
+    g._body(None, g.src, g.idx, g.ch, g.mp, False, with_adam=False)
+    runtime.RT._ctr = keep
+    assert abs(float(g.out[0]) - loss_replay) > 2e-4 * abs(loss_replay)
+
+
+def test_learner_epoch_graph_equals_eager_incl_ragged_tail_and_epoch_reset(monkeypatch):
+    """learner.pretrain_epoch through the captured step (default) vs SARSSL_GRAPH=0: two epochs (Adam restarted per epoch,
+    learner.py:83), batches of 4 + 4 + 2 (the last one takes the eager twin of the captured step), dropout off."""
+    from sar_ssl_amd import learner as L, model, runtime, synth
+    dev = torch.device("cuda:0")
+    T = 8
+    nsample = 512 + 256 * (T - 1)
+    data = torch.from_numpy(synth.make_batch(0, 10, nsample=nsample))
+    loader = [[data[0:4]], [data[4:8]], [data[8:10]]]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SARSSL_GRAPH", mode)
+        torch.manual_seed(3)
+        net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev)
+        _set_dropout(net, 0.0)
+        lrn = L.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+        lrn.cuda()                                                     # fp32 mode: run-to-run noise ~1e-7, so the comparison is sharp
+        random.seed(0)
+        l1, d1, vis = lrn.pretrain_epoch(loader, lr=1e-3, epoch=1)
+        l2, d2, _ = lrn.pretrain_epoch(loader, lr=5e-4, epoch=2)
+        assert vis["pred"].shape == (2, 256, T, 2, 2) and vis["mask"].shape == (2, 256, T, 2)
+        lv = lrn.pretest_epoch(loader)[0]                              # eager eval right after graph replays: fresh weight caches
+        res[mode] = (l1, d1, l2, d2, lv, lrn._flat.flat.clone())
+        if mode == "1":
+            assert lrn._step_graph is not None and lrn._step_graph._plan is not None
+    a, b = res["0"], res["1"]
+    for name, i in (("loss_ep1", 0), ("diff_ep1", 1), ("loss_ep2", 2), ("diff_ep2", 3), ("val_loss", 4)):
+        check("learner_graph_vs_eager." + name, abs(a[i] - b[i]) / abs(a[i]), 5e-4)
+    runtime.set_precision("bf16")
+
+
+def test_two_rank_graph_step_equals_two_rank_eager_step():
+    """Data parallel through the captured step: graphs cut at the bucket boundaries, the collectives issued eagerly in between
+    (tools/dp_graph_check.py; 2 ranks share this GPU over gloo - RCCL needs one GPU per rank)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SARSSL_DIST_BACKEND="gloo", DPCHECK_PRECISION="fp32")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dp_graph_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["world"] == 2
+    assert out["plan"] == ["graph", "reduce:decoder", "graph", "reduce:spat_encoder", "reduce:spec_encoder", "graph", "reduce:stems",
+                           "finish", "graph"], out["plan"]
+    check("dp2_graph.loss_vs_eager", out["loss_rel"], 2e-4)
+    check("dp2_graph.params_in_lr_units", out["param_lr_units"], 6.5)          # 3 steps: at most 2 lr per step for a sign-flipping weight
+    assert out["rank_param_diff"] == 0.0
