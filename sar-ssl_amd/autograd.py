@@ -27,6 +27,8 @@ class _TapeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         dx = ctx.bwd(_to_rt(dy.contiguous()), ctx.saved)
+        from .engine import wgrad_join
+        wgrad_join()                              # weight-gradient side stream (engine._WgradSide): gradients are read after this node
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = hip.cast(dx.contiguous(), ctx.in_dtype)
         return (None, None, dx) + (None,) * ctx.nparams

@@ -64,16 +64,123 @@ def mm_nn(dy, W, fp8=True, **kw):
                     precise=RT.precise, **kw)
 
 
-def mm_tn_acc(dy, x, gW):
+_ABLATE_WGRAD = os.environ.get("SARSSL_ABLATE_WGRAD", "0") == "1"     # timing experiment only (tools/): skips the Linear weight-gradient products
+
+
+# Weight-gradient side stream.  The weight-gradient products (and the bias-gradient column sums / split-K folds batched per block)
+# feed nothing but the gradient buffer, so they need not sit on the input-gradient chain.  SARSSL_WGRAD_MODE:
+#   "off" (default)    everything on the chain's own stream;
+#   "block"            the products of one Conformer block / the decoder are collected and enqueued together at the end of that
+#                      block's backward on a companion stream of the stream running the chain - ONE fork per block - so they run
+#                      underneath the next block's (or the CNN stem's) backward;
+#   "fork"             every product forks to the companion stream as soon as its operands exist.
+# Measured on MI355X (same box, B = 64): without the products the step is 1.4 ms shorter (SARSSL_ABLATE_WGRAD), but neither schedule
+# recovers it - "block" 13.67 vs "off" 13.70 ms in the captured step, and a captured graph with the many cross-stream edges of
+# "fork" replays SLOWER than the plain two-stream graph (14.69 ms; eager 13.67).  The two encoder streams already fill the CUs.
+# Joined (wgrad_join) only where gradients are consumed: bucket all-reduce hooks, Adam.
+_WGRAD_MODE = os.environ.get("SARSSL_WGRAD_MODE", "off")
+_wg_streams = {}
+_wg_hold = {}
+_wg_nofork = set()           # stream handles that must not fork a companion (see wgrad_no_fork)
+_wg_nest = [0]
+_wg_blocks = []              # stack of pending-product lists (wgrad_block)
+
+
+def wgrad_no_fork(stream):
+    """No companion stream for ``stream``: its weight-gradient work stays on it.  Needed for the second encoder's stream - a stream
+    forked off a FORKED stream (i.e. waiting on an event recorded on a non-origin stream) crashes hipStreamEndCapture on ROCm 7.2
+    (tools/scratch/cap_repro2.py), so inside a capture only the origin stream gets a companion."""
+    _wg_nofork.add(stream.cuda_stream)
+
+
+class _WgradSide:
+    """``with _WgradSide(t1, t2, ...):`` - enqueue on the companion stream of the current stream, after everything enqueued so far;
+    the tensors are kept alive until the join (their memory is not recycled under the other stream's pending reads)."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        self.ctx = None
+        if _WGRAD_MODE == "off" or RT.replay is not None or _wg_nest[0]:
+            return self
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream in _wg_nofork:
+            return self
+        ws = _wg_streams.get(cur.cuda_stream)
+        if ws is None:
+            ws = _wg_streams[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
+        ws.wait_stream(cur)
+        _wg_hold.setdefault(cur.cuda_stream, []).extend(t for t in self.tensors if t is not None)
+        self.ctx = torch.cuda.stream(ws)
+        self.ctx.__enter__()
+        _wg_nest[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            _wg_nest[0] -= 1
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def wgrad_join():
+    """The current stream waits for its companion weight-gradient stream (call before gradients are read)."""
+    if not _wg_streams:
+        return
+    cur = torch.cuda.current_stream()
+    ws = _wg_streams.get(cur.cuda_stream)
+    if ws is not None:
+        cur.wait_stream(ws)
+        _wg_hold.pop(cur.cuda_stream, None)
+
+
+class wgrad_block:
+    """Backward of one block: weight-gradient products issued inside are collected ("block" mode) and enqueued at exit, together
+    with the block's batched split-K folds and bias-gradient column sums, under one fork to the companion stream.  Their operands
+    must stay unmodified until then (true for every product in this file: operands are saved activations or fresh gradients)."""
+
+    def __enter__(self):
+        _wg_blocks.append([])
+        return self
+
+    def __exit__(self, *exc):
+        items = _wg_blocks.pop()
+        if exc[0] is not None:
+            return False
+        held = [t for it in items for t in it[:2]] + [x for x, _ in (hip._colsum_batch or [])]
+        with _WgradSide(*held):
+            for dy, x, g2, split in items:
+                _wgrad_gemm(dy, x, g2, split)
+            hip.splitk_flush()
+            hip.colsum_flush()
+        return False
+
+
+def _wgrad_gemm(dy, x, g2, split):
+    M, N = dy.shape
+    K = x.shape[1]
+    hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), out=g2, ldc=K, precise=RT.precise,
+             split_k=split)
+
+
+def mm_tn_acc(dy, x, gW, side=True):
     """gW[N,K] += dy[M,N]^T @ x[M,K]   (weight gradient of nn.Linear, f32 accumulate into the grad buffer)."""
     M, N = dy.shape
     K = x.shape[1]
+    if _ABLATE_WGRAD:
+        return
     g2 = gW.view(N, K)
     tiles = ((N + 255) // 256) * ((K + 127) // 128)                          # 256 x 128 output tiles (csrc/gemm.hip)
     split = max(1, min((M + 511) // 512, (512 + tiles - 1) // tiles))       # ~2 workgroups per CU, >= 8 K-tiles each
     split = max(1, min(split, (1 << 23) // (N * K)))                         # partial-sum workspace <= 32 MB (reduce pass cost)
-    hip.gemm(dy, x, a_kc=False, b_kc=False, M=N, N=K, K=M, lda=dy.stride(0), ldb=x.stride(0), out=g2, ldc=K,
-             precise=RT.precise, split_k=split)
+    if side and _WGRAD_MODE == "block" and _wg_blocks and RT.replay is None:
+        _wg_blocks[-1].append((dy, x, g2, split))
+    elif side and _WGRAD_MODE == "fork":
+        with _WgradSide(dy, x):
+            _wgrad_gemm(dy, x, g2, split)
+    else:
+        _wgrad_gemm(dy, x, g2, split)
 
 
 def to_rt(x):
@@ -169,7 +276,7 @@ def patch_bwd(de, pe, saved):
     B, F, T, _ = a0.shape
     d = de.shape[1]
     gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
-    mm_tn_acc(de, z4, gtmp)
+    mm_tn_acc(de, z4, gtmp, side=False)
     gbuf(pe[12].weight).add_(gtmp.view(d, F, 4).permute(0, 2, 1).unsqueeze(-1))
     return mm_nn(de, _patch_w(pe[12], F), fp8=False)                                       # (B,T,F,4)
 
@@ -542,7 +649,7 @@ def block_bwd(dy, blk, saved):
     seq = blk.sequential
     x, stats = saved.pop()
     # the block's ~9 bias-gradient column sums and the reductions of its 9 split-K weight-gradient products: one launch each, at the end
-    with hip.colsum_batched(), hip.splitk_batched():
+    with hip.colsum_batched(flush_ctx=_WgradSide), hip.splitk_batched(flush_ctx=_WgradSide), wgrad_block():
         d = hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias))
         d = ffn_bwd(d, seq[3].module, saved)
         d = convmod_bwd(d, seq[2].module, saved)
@@ -579,9 +686,10 @@ def decoder_fwd(e, dec, saved):
 def decoder_bwd(dpred, dec, saved):
     e, h = saved.pop()
     l1, l2 = dec.proj[0], dec.proj[2]
-    mm_tn_acc(dpred, h, gbuf(l2.weight))
-    hip.colsum(dpred, gbuf(l2.bias))
-    dh = mm_nn(dpred, wt(l2.weight), fp8=False, aux=h, aux_act=RELU)
-    mm_tn_acc(dh, e, gbuf(l1.weight))
-    hip.colsum(dh, gbuf(l1.bias))
-    return mm_nn(dh, wt(l1.weight), fp8=False)
+    with hip.colsum_batched(flush_ctx=_WgradSide), hip.splitk_batched(flush_ctx=_WgradSide), wgrad_block():
+        mm_tn_acc(dpred, h, gbuf(l2.weight))
+        hip.colsum(dpred, gbuf(l2.bias))
+        dh = mm_nn(dpred, wt(l2.weight), fp8=False, aux=h, aux_act=RELU)
+        mm_tn_acc(dh, e, gbuf(l1.weight))
+        hip.colsum(dh, gbuf(l1.bias))
+        return mm_nn(dh, wt(l1.weight), fp8=False)

@@ -133,12 +133,23 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
 _splitk_batch = None
 
 
+_splitk_ctx = None            # optional context-manager factory (tensors...) the flush launch runs under (engine._WgradSide)
+
+
 def splitk_flush():
     global _splitk_batch
     if not _splitk_batch:
         return
     items, n = _splitk_batch, len(_splitk_batch)
     _splitk_batch = []
+    if _splitk_ctx is not None:
+        with _splitk_ctx(*[it[0] for it in items]):
+            _splitk_flush_items(items, n)
+    else:
+        _splitk_flush_items(items, n)
+
+
+def _splitk_flush_items(items, n):
     import ctypes
     ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
     C = (ctypes.c_void_p * n)(*[it[4].data_ptr() for it in items])
@@ -151,21 +162,27 @@ def splitk_flush():
 
 class splitk_batched:
     """Context manager: split-K (weight-gradient) products issued inside keep their partial sums in their own buffers and are
-    reduced into the gradient buffers by ONE launch at exit, instead of one reduce launch per product."""
+    reduced into the gradient buffers by ONE launch at exit, instead of one reduce launch per product.  ``flush_ctx``: context
+    manager factory the reduce launch is issued under (a side stream)."""
+
+    def __init__(self, flush_ctx=None):
+        self._ctx = flush_ctx
 
     def __enter__(self):
-        global _splitk_batch
+        global _splitk_batch, _splitk_ctx
         self._outer = _splitk_batch
         if _splitk_batch is None:
             _splitk_batch = []
+            _splitk_ctx = self._ctx
         return self
 
     def __exit__(self, *exc):
-        global _splitk_batch
+        global _splitk_batch, _splitk_ctx
         if self._outer is None:
             if exc[0] is None:
                 splitk_flush()
             _splitk_batch = None
+            _splitk_ctx = None
         return False
 
 
@@ -655,13 +672,24 @@ def colsum(x2d, out_f32, now=False):
     _lib.call("sarssl_colsum", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(N), _p(out_f32), c_int(dt(x2d)), _stream())
 
 
+_colsum_ctx = None
+
+
 def colsum_flush():
-    """Runs the queued column sums (one launch) on the current stream."""
+    """Runs the queued column sums (one launch) on the current stream (or under the batch's flush context)."""
     global _colsum_batch
     if not _colsum_batch:
         return
     items, n = _colsum_batch, len(_colsum_batch)
     _colsum_batch = []
+    if _colsum_ctx is not None:
+        with _colsum_ctx(*[x for x, _ in items]):
+            _colsum_flush_items(items, n)
+    else:
+        _colsum_flush_items(items, n)
+
+
+def _colsum_flush_items(items, n):
     import ctypes
     xs = (ctypes.c_void_p * n)(*[x.data_ptr() for x, _ in items])
     outs = (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in items])
@@ -672,21 +700,27 @@ def colsum_flush():
 
 
 class colsum_batched:
-    """Context manager: queue the column sums issued inside and run them in one launch at exit (per backward stage)."""
+    """Context manager: queue the column sums issued inside and run them in one launch at exit (per backward stage).
+    ``flush_ctx``: context manager factory the launch is issued under (a side stream)."""
+
+    def __init__(self, flush_ctx=None):
+        self._ctx = flush_ctx
 
     def __enter__(self):
-        global _colsum_batch
+        global _colsum_batch, _colsum_ctx
         self._outer = _colsum_batch
         if _colsum_batch is None:
             _colsum_batch = []
+            _colsum_ctx = self._ctx
         return self
 
     def __exit__(self, *exc):
-        global _colsum_batch
+        global _colsum_batch, _colsum_ctx
         if self._outer is None:
             if exc[0] is None:
                 colsum_flush()
             _colsum_batch = None
+            _colsum_ctx = None
         return False
 
 

@@ -78,7 +78,10 @@ def test_graph_step_equals_eager_step(prec):
         # up to 2 lr per step in bf16 - gate the bulk: fraction of weights further apart than half a step, and the difference norm
         # relative to the norm of everything the six steps moved
         moved = (flat_b.flat - flat_a.flat).abs().gt(0.5e-3).float().mean()
-        check("graph_vs_eager.%s.frac_params_off_by_half_lr" % prec, float(moved), 1e-3 if prec == "fp32" else 0.5)    # (bf16: run-to-run noise of the eager step itself, f32 atomics order; the sharp gate is the fp32 run)
+        # (bf16: the eager step is not run-to-run reproducible itself - f32 atomics order in the fused statistics epilogues flips single
+        #  bf16 roundings / ReLU masks, and with 64 rows per gradient one flipped mask moves an entry by 10 % (tools/graph_debug.py:
+        #  eager vs eager 3e-2 of max|g|); fp32 mode is bit-reproducible, so the sharp gates are the fp32 run's)
+        check("graph_vs_eager.%s.frac_params_off_by_half_lr" % prec, float(moved), 1e-3 if prec == "fp32" else 0.5)
         torch.manual_seed(11)
         from sar_ssl_amd import model as _model
         p0 = torch.cat([p.detach().reshape(-1) for p in _model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device="cpu").parameters()])
@@ -89,7 +92,7 @@ def test_graph_step_equals_eager_step(prec):
             if ka.endswith("num_batches_tracked"):
                 assert int(a) == int(b) == n, ka                       # the capture warm-up left no trace
             elif "running" in ka:
-                assert float((a - b).abs().max()) <= (1e-3 if prec == "fp32" else 5e-2) * float(a.abs().max()) + 1e-6, ka
+                assert float((a - b).abs().max()) <= (1e-4 if prec == "fp32" else 0.5) * float(a.abs().max()) + 1e-6, ka
     finally:
         runtime.set_precision("bf16")
 
@@ -126,34 +129,38 @@ def test_graph_replay_gradient_equals_eager_gradient_under_the_same_salt():
     from sar_ssl_amd import hip, runtime
     from sar_ssl_amd.graph import PretrainStepGraph
     T, B = 16, 4
-    x = _batches(T, 1, B)[0]
-    idx = np.tile(np.arange(T // 2)[None, :] * 2, (B, 1))
-    ch = np.array([1, 0, 1, 0])
-    net, flat = _make(T, 9, 0.1)
-    g = PretrainStepGraph(net, flat, lr=0.0)
-    g.zero_grad_in_adam = False
-    net.set_masks(idx, ch)
-    loss_replay = float(g.step(x=x)[0])                                # capture + first replay
-    g1 = flat.grad.clone()
-    assert float(g1.abs().max()) > 0
-    flat.grad.zero_()
-    keep = runtime.RT._ctr
-    hip.step_state_attach(g.state)
+    runtime.set_precision("fp32")                 # bit-reproducible mode (see test_graph_step_equals_eager_step): equality is exact
     try:
+        x = _batches(T, 1, B)[0]
+        idx = np.tile(np.arange(T // 2)[None, :] * 2, (B, 1))
+        ch = np.array([1, 0, 1, 0])
+        net, flat = _make(T, 9, 0.1)
+        g = PretrainStepGraph(net, flat, lr=0.0)
+        g.zero_grad_in_adam = False
+        net.set_masks(idx, ch)
+        loss_replay = float(g.step(x=x)[0])                                # capture + first replay
+        g1 = flat.grad.clone()
+        assert float(g1.abs().max()) > 0
+        flat.grad.zero_()
+        keep = runtime.RT._ctr
+        hip.step_state_attach(g.state)
+        try:
+            runtime.RT._ctr = g._seed_ctr0
+            g._body(None, g.src, g.idx, g.ch, g.mp, False, with_adam=False)      # no tick: the salt is still the replay's
+        finally:
+            hip.step_state_attach(None)
+            runtime.RT._ctr = keep
+        g2 = flat.grad.clone()
+        check("graph.replay_vs_salted_eager.loss", abs(float(g.out[0]) - loss_replay) / abs(loss_replay), 1e-6)
+        check("graph.replay_vs_salted_eager.grad", float((g1 - g2).abs().max() / g1.abs().max()), 1e-6)
+        # and an unsalted eager pass draws other masks
+        flat.grad.zero_()
         runtime.RT._ctr = g._seed_ctr0
-        g._body(None, g.src, g.idx, g.ch, g.mp, False, with_adam=False)      # no tick: the salt is still the replay's
-    finally:
-        hip.step_state_attach(None)
+        g._body(None, g.src, g.idx, g.ch, g.mp, False, with_adam=False)
         runtime.RT._ctr = keep
-    g2 = flat.grad.clone()
-    check("graph.replay_vs_salted_eager.loss", abs(float(g.out[0]) - loss_replay) / abs(loss_replay), 5e-5)     # (f32 atomics order)
-    check("graph.replay_vs_salted_eager.grad", float((g1 - g2).abs().max() / g1.abs().max()), 1e-4)
-    # and an unsalted eager pass draws other masks
-    flat.grad.zero_()
-    runtime.RT._ctr = g._seed_ctr0
-    g._body(None, g.src, g.idx, g.ch, g.mp, False, with_adam=False)
-    runtime.RT._ctr = keep
-    assert abs(float(g.out[0]) - loss_replay) > 2e-4 * abs(loss_replay)
+        assert abs(float(g.out[0]) - loss_replay) > 2e-4 * abs(loss_replay)
+    finally:
+        runtime.set_precision("bf16")
 
 
 def test_learner_epoch_graph_equals_eager_incl_ragged_tail_and_epoch_reset(monkeypatch):
