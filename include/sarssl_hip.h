@@ -60,6 +60,12 @@ int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC
  * bf16 operands), which then only writes the partials (split count = ceil(K / (ceil(ceil(K / split_k) / 64) * 64))). */
 int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsplit, const int* M, const int* N, float* const* C, const long* ldc,
                                int n_prob, void* stream);
+/* up to 12 independent weight-gradient products dY_q^T X_q (the nn.Linear weight gradients autograd computes one by one for the
+ * layers of a Conformer block, code/common/conformer/*.py) as ONE launch: A_q = dY [K_q][M_q], B_q = X [K_q][N_q], bf16, row strides
+ * lda / ldb; f32 partial sums of split_out[q] K-slices to ws[q] (size it for split_k[q] slices), folded by
+ * sarssl_splitk_reduce_multi.  Returns 1 without launching when a shape is ragged (M, N % 128 or a K slice % 64). */
+int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* const* ws, const int* M, const int* N, const int* K,
+                         const long* lda, const long* ldb, const int* split_k, int* split_out, int n_prob, void* stream);
 
 /* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
  *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as
@@ -117,6 +123,15 @@ int sarssl_conv3x3_wgrad_bnin(const void* dz_in, const void* y_bn, const float* 
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
                          const float* shift, float* dW, float* partial, int precise, void* stream);
+/*      bf16: the weight gradient ADDED straight into the f32 (64,64,3,3) parameter-gradient buffer (nn.Conv2d layout) */
+int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb, int F, int T, const float* scale, const float* shift,
+                             float* grad_oihw, float* partial, void* stream);
+/*      re-laid-out operands of the stem convolutions, one launch each (they follow the weights every step): conv_taps: (64,64,3,3)
+ *      f32 -> fwd [9][co][ci] and dgr [9][ci][co] with flipped taps, f32 | bf16; patch_w: the frame-patch conv weight (d,4,F,1)
+ *      (code/model.py:63) -> GEMM operand [d][f*4+c]; patch_wgrad_accum: grad (d,4,F,1) += g [d][f*4+c]. */
+int sarssl_conv_taps(const float* W, void* fwd, void* dgr, int dtype, void* stream);
+int sarssl_patch_w(const float* W, void* out, int d, int F, int dtype, void* stream);
+int sarssl_patch_wgrad_accum(const float* g, float* grad, int d, int F, void* stream);
 int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
                        int dtype, void* stream);
 int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
@@ -164,6 +179,11 @@ long sarssl_layernorm_bwd_workspace_bytes(long M, int d);
 int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
                          const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
                          float* dgamma, float* dbeta, float* partial, int dtype, void* stream);
+/*      dgamma == NULL with partial != NULL: the [nparts][2 d] partial sums only (nparts = sarssl_layernorm_bwd_nparts(M)); the folds
+ *      of up to 8 such launches (the LayerNorms of one Conformer block) then run as one launch: dgamma_q / dbeta_q += ... */
+int sarssl_layernorm_bwd_nparts(long M);
+int sarssl_ln_param_reduce_multi(const float* const* partial, const int* nparts, const int* d, float* const* dgamma,
+                                 float* const* dbeta, int n_prob, void* stream);
 int sarssl_glu_fwd(const void* h, long M, int d, void* g, int dtype, void* stream);
 int sarssl_glu_bwd(const void* dg, const void* h, long M, int d, void* dh, int dtype, void* stream);
 int sarssl_dwconv_fwd(const void* x, const float* w, int nb, int Tn, int d, int ksize, int flip, void* y, int dtype,
@@ -189,6 +209,10 @@ int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop,
                    void* dh, int dtype, void* stream);
 int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 int sarssl_f64_accum(const double* src, float* dst, int n, float scale, void* stream);
+int sarssl_f64_accum2(const double* src, float* dst1, float* dst2, int n, void* stream);     /* dst1 += src[:n], dst2 += src[n:2n] */
+/* f64 accumulators (BatchNorm / loss sums) handed to the reduction entry points are zeroed by a memset in front of each launch - unless
+ * they lie inside [base, base + bytes), an arena the caller zeroes itself once per forward / backward pass (NULL unregisters). */
+int sarssl_zero_arena(const void* base, long bytes);
 
 /* ---- loss: code/model.py:585-592 (channel select) + 721-747 (gen_loss).  fwd: sums = f64[128] scratch, out = f32[2]
  * (loss, diff); F <= 480. */

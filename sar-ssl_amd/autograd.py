@@ -26,6 +26,7 @@ class _TapeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        hip.sums_arena_reset(dy.device)
         dx = ctx.bwd(_to_rt(dy.contiguous()), ctx.saved)
         from .engine import wgrad_join
         wgrad_join()                              # weight-gradient side stream (engine._WgradSide): gradients are read after this node

@@ -80,3 +80,15 @@ extern "C" int sarssl_step_tick(void* state, void* stream) {
     SARSSL_CHECK_LAUNCH("step_tick_kernel");
     return 0;
 }
+
+// ---- pre-zeroed arena ----------------------------------------------------------------------------------------------------------------
+// The f64 accumulators of the reductions (BatchNorm sums, backward sums, loss sums) are zeroed by a hipMemsetAsync in front of every
+// launch: ~26 memset nodes per training step.  The host side can instead hand out slices of ONE arena it zeroes once per forward /
+// backward pass (hip.py: sums_zeroed); a pointer inside the registered range is taken as already zero and its memset is skipped.
+static const char* g_zero_lo = nullptr;
+static const char* g_zero_hi = nullptr;
+extern "C" int sarssl_zero_arena(const void* base, long bytes) {
+    g_zero_lo = (const char*)base; g_zero_hi = base ? (const char*)base + bytes : nullptr;
+    return 0;
+}
+bool sarssl_prezeroed(const void* p) { return p && (const char*)p >= g_zero_lo && (const char*)p < g_zero_hi; }

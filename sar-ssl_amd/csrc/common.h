@@ -24,6 +24,9 @@ struct SarsslStepState {
     float step_size;             // lr / (1 - beta1^step)
     float inv_bc2_sqrt;          // 1 / sqrt(1 - beta2^step)
 };
+bool sarssl_prezeroed(const void* p);               // pointer inside the host-zeroed arena (api.hip): its memset can be skipped
+// zero `bytes` at p on `st` unless p is a slice of the pre-zeroed arena
+#define SARSSL_ZERO(p, bytes, st) (sarssl_prezeroed(p) ? hipSuccess : hipMemsetAsync((p), 0, (bytes), (st)))
 const unsigned long long* sarssl_dropout_salt();   // pointer the launch wrappers hand to kernels that draw dropout masks (may be null)
 #define SARSSL_CHECK_LAUNCH(name)                                          \
     do {                                                                   \

@@ -813,8 +813,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 }
 
 // dW[e] (+)= sum_p partial[p][e]; workgroup = 64 elements x 4 part-slots, 4-way unrolled loads
+// grad_oihw != null: the sum is ADDED to the parameter-gradient buffer in nn.Conv2d's own (co, ci, kh, kw) layout instead.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW,
-                                                           int accumulate) {
+                                                           int accumulate, float* __restrict__ grad_oihw = nullptr) {
     __shared__ float sred[4][64];
     const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + col;
@@ -829,7 +830,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     __syncthreads();
     if (slot == 0) {
         const float t = (sred[0][col] + sred[1][col]) + (sred[2][col] + sred[3][col]);
-        dW[e] = accumulate ? dW[e] + t : t;
+        if (grad_oihw) { const int tap = e >> 12, coci = e & 4095; grad_oihw[coci * 9 + tap] += t; }
+        else dW[e] = accumulate ? dW[e] + t : t;
     }
 }
 
@@ -887,7 +889,7 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
                           const float* bn_aff, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_fwd");
     SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16, "sarssl_conv3x3_fwd(fused statistics: bf16 storage only)");
-    if (stats && hipMemsetAsync(stats, 0, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
     a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
@@ -941,6 +943,54 @@ extern "C" int sarssl_conv3x3_wgrad_bnin(const void* dz_in, const void* y_bn, co
     return 0;
 }
 
+// Re-laid-out taps of a (64, 64, 3, 3) f32 convolution weight in ONE launch (a permute + flip + 2 casts = 5 torch launches per
+// convolution otherwise, redone every step because the weights move): fwd [9][co][ci] and dgr [9][ci][co] with flipped taps
+// (= W.flip(2,3).permute(2,3,1,0)), as f32 (dtype 0) or bf16 (dtype 1).
+template <typename T>
+__global__ void conv_taps_kernel(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ dgr) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 9 * 4096) return;
+    const int tap = e >> 12, a = (e >> 6) & 63, b = e & 63;
+    st_f(fwd + e, W[(a * 64 + b) * 9 + tap]);                    // fwd[tap][co = a][ci = b]
+    st_f(dgr + e, W[(b * 64 + a) * 9 + (8 - tap)]);              // dgr[tap][ci = a][co = b] = W[co][ci][2 - kh][2 - kw]
+}
+extern "C" int sarssl_conv_taps(const float* W, void* fwd, void* dgr, int dtype, void* stream) {
+    if (dtype == SARSSL_BF16) conv_taps_kernel<bf16><<<144, 256, 0, (hipStream_t)stream>>>(W, (bf16*)fwd, (bf16*)dgr);
+    else if (dtype == SARSSL_F32) conv_taps_kernel<float><<<144, 256, 0, (hipStream_t)stream>>>(W, (float*)fwd, (float*)dgr);
+    else { sarssl_set_error("sarssl_conv_taps: unsupported dtype %d", dtype); return -1; }
+    SARSSL_CHECK_LAUNCH("conv_taps_kernel");
+    return 0;
+}
+// (d, 4, F, 1) f32 frame-patch convolution weight -> [d][f * 4 + c] (the GEMM operand over the (B, T, F, 4) activations)
+template <typename T>
+__global__ void patch_w_kernel(const float* __restrict__ W, T* __restrict__ out, int d, int F) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)d * F * 4) return;
+    const int c = e & 3; const long of = e >> 2; const int f = of % F; const long o = of / F;
+    st_f(out + e, W[(o * 4 + c) * F + f]);
+}
+extern "C" int sarssl_patch_w(const float* W, void* out, int d, int F, int dtype, void* stream) {
+    const long n = (long)d * F * 4;
+    if (dtype == SARSSL_BF16) patch_w_kernel<bf16><<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, (bf16*)out, d, F);
+    else if (dtype == SARSSL_F32) patch_w_kernel<float><<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, (float*)out, d, F);
+    else { sarssl_set_error("sarssl_patch_w: unsupported dtype %d", dtype); return -1; }
+    SARSSL_CHECK_LAUNCH("patch_w_kernel");
+    return 0;
+}
+// grad (d, 4, F, 1) f32 += g [d][f * 4 + c]  (the frame-patch weight gradient back in nn.Conv2d layout)
+__global__ void patch_wgrad_accum_kernel(const float* __restrict__ g, float* __restrict__ grad, int d, int F) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)d * F * 4) return;
+    const int c = e & 3; const long of = e >> 2; const int f = of % F; const long o = of / F;
+    grad[(o * 4 + c) * F + f] += g[e];
+}
+extern "C" int sarssl_patch_wgrad_accum(const float* g, float* grad, int d, int F, void* stream) {
+    const long n = (long)d * F * 4;
+    patch_wgrad_accum_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(g, grad, d, F);
+    SARSSL_CHECK_LAUNCH("patch_wgrad_accum_kernel");
+    return 0;
+}
+
 extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T,
                                     const float* scale, const float* shift, float* dW, float* partial, int precise,
                                     void* stream) {
@@ -964,5 +1014,21 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
         }
     } else { sarssl_set_error("sarssl_conv3x3_wgrad: unsupported dtype %d", dtype); return -1; }
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel");
+    return 0;
+}
+
+// bf16 weight gradient ADDED straight into the f32 (64, 64, 3, 3) parameter-gradient buffer (nn.Conv2d layout): no [9][64][64]
+// intermediate, no permute-add pass.
+extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb, int F, int T, const float* scale, const float* shift,
+                                        float* grad_oihw, float* partial, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && grad_oihw && partial, "sarssl_conv3x3_wgrad_acc");
+    WgradArgs a = {};
+    a.dy = dy; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
+    a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = conv_grid(nb, F, T);
+    conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
+    wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, grid, nullptr, 0, grad_oihw);
+    SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel(acc)");
     return 0;
 }

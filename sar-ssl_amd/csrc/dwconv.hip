@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void dw_partial_reduce_kernel(const float* __r
 extern "C" int sarssl_dwglu_fwd(const void* h, const float* w, int nb, int Tn, int d, int ksize, void* c, double* sums, int dtype,
                                 void* stream) {
     SARSSL_REQUIRE(ksize == DWK && nb > 0 && Tn > 0 && d > 0 && d % 8 == 0, "sarssl_dwglu_fwd(kernel size 31, d % 8 == 0)");
-    if (sums && hipMemsetAsync(sums, 0, 2L * d * sizeof(double), ST) != hipSuccess) { sarssl_set_error("sarssl_dwglu_fwd: memset"); return -2; }
+    if (sums && SARSSL_ZERO(sums, 2L * d * sizeof(double), ST) != hipSuccess) { sarssl_set_error("sarssl_dwglu_fwd: memset"); return -2; }
     dim3 grid((d + DTC - 1) / DTC, (Tn + DTT - 1) / DTT, nb);
     DW_DISPATCH(dtype, (dwglu_fwd_kernel<T><<<grid, 256, 0, ST>>>((const T*)h, w, Tn, d, (T*)c, sums)));
     SARSSL_CHECK_LAUNCH("dwglu_fwd_kernel");

@@ -218,6 +218,42 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     }
 }
 
+// The same fold for the LayerNorm modules of one Conformer block in ONE launch (5 per block, 20 launches of ~5 us per step otherwise;
+// each launch is 8-16 workgroups, so together they also fill more of the chip).
+#define LNR_MAXP 8
+struct LnReduceMulti {
+    const float* partial[LNR_MAXP]; float* dgamma[LNR_MAXP]; float* dbeta[LNR_MAXP];
+    int nparts[LNR_MAXP], d[LNR_MAXP], first[LNR_MAXP + 1];
+    int n;
+};
+__global__ __launch_bounds__(1024) void ln_param_reduce_multi_kernel(LnReduceMulti a) {
+    __shared__ float sred[16][64];
+    int q = 0;
+    while (q + 1 < a.n && (int)blockIdx.x >= a.first[q + 1]) ++q;
+    const float* __restrict__ partial = a.partial[q];
+    const int nparts = a.nparts[q], d = a.d[q];
+    const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const int i = (blockIdx.x - a.first[q]) * 64 + col;
+    const long pitch = 2L * d;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < 2 * d) {
+        int p = slot;
+        for (; p + 48 < nparts; p += 64) {
+            s0 += partial[(long)p * pitch + i]; s1 += partial[(long)(p + 16) * pitch + i];
+            s2 += partial[(long)(p + 32) * pitch + i]; s3 += partial[(long)(p + 48) * pitch + i];
+        }
+        for (; p < nparts; p += 16) s0 += partial[(long)p * pitch + i];
+    }
+    sred[slot][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slot == 0 && i < 2 * d) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sred[k][col];
+        if (i < d) a.dgamma[q][i] += t; else a.dbeta[q][i - d] += t;
+    }
+}
+
 // ------------------------------------------------------------------------------------ GLU
 template <typename T>
 __global__ void glu_fwd_kernel(const T* __restrict__ h, long M, int d, T* __restrict__ g) {
@@ -537,6 +573,12 @@ __global__ void f64_accum_kernel(const double* __restrict__ s, float* __restrict
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] += (float)(s[i]) * scale;
 }
+// two destinations in one launch: d1[i] += s[i], d2[i] += s[n + i]  (BatchNorm dbeta | dgamma from the backward sums)
+__global__ void f64_accum2_kernel(const double* __restrict__ s, float* __restrict__ d1, float* __restrict__ d2, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d1[i] += (float)s[i];
+    else if (i < 2 * n) d2[i - n] += (float)s[i];
+}
 
 // ------------------------------------------------------------------------------------ loss
 // pred: (B, T, F, 2, 2) [f][reim][mic];  x: (B, 2, F, T, 2) f32;  idx: (B, nm) int32 masked frames; mch: (B) int32
@@ -682,7 +724,7 @@ extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, lo
                                     float* dgamma, float* dbeta, float* partial, int dtype, void* stream) {
     SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (!dgamma || partial), "sarssl_layernorm_bwd");
     const int nblk = ln_bwd_blocks(M);
-    float* part = dgamma ? partial : nullptr;
+    float* part = partial;          // dgamma == null && partial != null: partials only, folded later (sarssl_ln_param_reduce_multi)
 #define LN_BWD_LAUNCH(NVv) layernorm_bwd_kernel<T, NVv><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd, \
                                                                            (const T*)resid, ldr, (T*)dx, lddx, part)
     DISPATCH_T(dtype, (d <= 256 ? LN_BWD_LAUNCH(1) : (d <= 512 ? LN_BWD_LAUNCH(2) : LN_BWD_LAUNCH(4))));
@@ -691,6 +733,23 @@ extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, lo
         ln_param_reduce_kernel<<<(2 * d + 63) / 64, 1024, 0, ST>>>(part, nblk, d, dgamma, dbeta);
     }
     SARSSL_CHECK_LAUNCH("layernorm_bwd_kernel");
+    return 0;
+}
+extern "C" int sarssl_layernorm_bwd_nparts(long M) { return ln_bwd_blocks(M); }
+// dgamma_q / dbeta_q += column halves of partial_q [nparts_q][2 d_q] for n_prob <= 8 LayerNorm backward launches that wrote partials only
+extern "C" int sarssl_ln_param_reduce_multi(const float* const* partial, const int* nparts, const int* d, float* const* dgamma,
+                                            float* const* dbeta, int n_prob, void* stream) {
+    SARSSL_REQUIRE(n_prob > 0 && n_prob <= LNR_MAXP, "sarssl_ln_param_reduce_multi");
+    LnReduceMulti a;
+    a.n = n_prob;
+    int total = 0;
+    for (int q = 0; q < n_prob; ++q) {
+        a.partial[q] = partial[q]; a.dgamma[q] = dgamma[q]; a.dbeta[q] = dbeta[q]; a.nparts[q] = nparts[q]; a.d[q] = d[q];
+        a.first[q] = total; total += (2 * d[q] + 63) / 64;
+    }
+    a.first[n_prob] = total;
+    ln_param_reduce_multi_kernel<<<total, 1024, 0, ST>>>(a);
+    SARSSL_CHECK_LAUNCH("ln_param_reduce_multi_kernel");
     return 0;
 }
 extern "C" int sarssl_glu_fwd(const void* h, long M, int d, void* g, int dtype, void* stream) {
@@ -824,6 +883,11 @@ extern "C" int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dt
     SARSSL_CHECK_LAUNCH("cast_kernel");
     return 0;
 }
+extern "C" int sarssl_f64_accum2(const double* src, float* dst1, float* dst2, int n, void* stream) {
+    f64_accum2_kernel<<<(2 * n + 255) / 256, 256, 0, ST>>>(src, dst1, dst2, n);
+    SARSSL_CHECK_LAUNCH("f64_accum2_kernel");
+    return 0;
+}
 extern "C" int sarssl_f64_accum(const double* src, float* dst, int n, float scale, void* stream) {
     f64_accum_kernel<<<(n + 255) / 256, 256, 0, ST>>>(src, dst, n, scale);
     SARSSL_CHECK_LAUNCH("f64_accum_kernel");
@@ -835,7 +899,7 @@ extern "C" int sarssl_masked_mse_fwd(const void* pred, const float* x, const int
     const size_t lds = (size_t)MSE_TT * F * 4 * sizeof(float);
     SARSSL_REQUIRE(nb > 0 && nm > 0 && lds <= 60 * 1024, "sarssl_masked_mse_fwd (F <= 480)");
     const int groups = (Tn + MSE_TT - 1) / MSE_TT;
-    if (hipMemsetAsync(sums, 0, 2 * MSE_SLOTS * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (SARSSL_ZERO(sums, 2 * MSE_SLOTS * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     DISPATCH_T(dtype, (masked_mse_fwd_kernel<T><<<nb * groups, 256, lds, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
     loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out);
     SARSSL_CHECK_LAUNCH("masked_mse_fwd_kernel");

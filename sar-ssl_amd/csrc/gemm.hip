@@ -57,21 +57,28 @@ __device__ __forceinline__ void tile_load(const T* __restrict__ p, long ld, int 
         } else regs[i] = load_chunk(q, part);
     }
 }
-template <bool KC, int ROWS>
+// SWZ ([k][row] tiles of the double-buffered kernel): no row padding (pitch = ROWS elements, a multiple of 256 bytes, so every k-row
+// starts on bank 0); instead the 16-byte chunk index is XORed with 4 * (k & 3), which moves the 64 bytes a transpose read takes from
+// k-rows k .. k+3 onto four different bank quarters - the same conflict-free pattern as the 64-byte padding, 20 % less LDS.
+template <bool KC, int ROWS, bool SWZ = false>
 __device__ __forceinline__ void tile_store(uint16_t* __restrict__ s, int tid, const uint4 (&regs)[ROWS / 32]) {
-    constexpr int CPR = ROWS / 8, KPP = 256 / CPR, PT = ROWS + 32;
+    constexpr int CPR = ROWS / 8, KPP = 256 / CPR, PT = SWZ ? ROWS : ROWS + 32;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
         if (KC) *(uint4*)&s[((tid >> 3) + 32 * i) * PITCH + (tid & 7) * 8] = regs[i];
-        else *(uint4*)&s[(tid / CPR + KPP * i) * PT + (tid % CPR) * 8] = regs[i];
+        else {
+            const int k = tid / CPR + KPP * i, c = tid % CPR;
+            *(uint4*)&s[k * PT + ((SWZ ? (c ^ ((k & 3) << 2)) : c) << 3)] = regs[i];
+        }
     }
 }
 
 // MFMA fragment (8 consecutive k for row r0 + (lane&31)) from a [k][row] tile (pitch PT) via two transpose reads
-template <int PT>
+template <int PT, bool SWZ = false>
 __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, int lane) {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
-    const int col = r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    int col = r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    if (SWZ) col ^= ((lane & 15) >> 2) << 5;           // chunk index ^ 4 * (k & 3): k & 3 == (lane & 15) >> 2 for both halves (kbase % 4 == 0)
     union { s16x4 v[2]; bf16x8 b; } u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -81,22 +88,30 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
     return u.b;
 }
 
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_kernel(GemmArgs g) {
+// DB (FM = 2): two LDS buffers and two register stages.  With one buffer and one tile of prefetch a K-tile costs a full memory round
+// trip - the loads of tile k+1 are only issued behind the barrier of tile k and must have landed before the next store - which
+// measured 0.7-0.8 us per K-tile against 0.25 us of MFMA (ffn2 d=256: 22 us for 16 tiles, qkv d=256: 12 us for 4).  Here the loads
+// of tile k+2 are issued before the MFMAs of tile k, tile k+1 is written to the OTHER buffer behind those MFMAs, and there is one
+// barrier per tile: a load has two MFMA phases (plus the co-resident workgroup's) to land.
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool DB>
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, const int bid_y, const int bid_z, const int grid_x,
+                                          const int grid_y) {
+    static_assert(!DB || FM == 2, "double-buffered variant: 128 x 128 tiles only");
     constexpr int BM = 64 * FM;
-    constexpr int PTA = BM + 32, PTB = BN + 32;
+    constexpr int PTA = DB ? BM : BM + 32, PTB = DB ? BN : BN + 32;
     constexpr int A_ELEMS = AKC ? BM * PITCH : BK * PTA;
     constexpr int B_ELEMS = BKC ? BN * PITCH : BK * PTB;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
     constexpr int PC = BN + 4;                                  // f32 staging pitch of the epilogue (conflict-free 16-byte LDS writes)
     constexpr int EPI_ELEMS = 64 * PC * 2;                      // 64 x 132 f32, in 16-bit units
-    constexpr int LDS_ELEMS = (A_ELEMS + B_ELEMS) > EPI_ELEMS ? (A_ELEMS + B_ELEMS) : EPI_ELEMS;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];    // FM = 2: 40 KiB (3-4 workgroups / CU), FM = 4: 56 KiB (2 / CU)
+    constexpr int LDS_ELEMS = (DB ? 2 : 1) * STAGE > EPI_ELEMS ? (DB ? 2 : 1) * STAGE : EPI_ELEMS;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];    // FM = 2: 2 x 32-37 KiB (2 workgroups / CU), FM = 4: 56 KiB (2 / CU)
     uint16_t* sA = smem;
     uint16_t* sB = smem + A_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nsplit = g.split_k > 0 ? g.split_k : 1;
-    const int z = blockIdx.z / nsplit, ks = blockIdx.z % nsplit;
+    const int z = bid_z / nsplit, ks = bid_z % nsplit;
     const int z0 = z / g.batch_inner, z1 = z % g.batch_inner;
     const int k_begin = g.split_k > 0 ? ks * g.k_per_split : 0;
     const int k_end = g.split_k > 0 ? min(g.K, k_begin + g.k_per_split) : g.K;
@@ -104,12 +119,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
     // natural order the column tiles of one A row panel land on different XCDs and the panel is fetched from HBM by every one of
     // them.  Remap so that XCD x owns row panels x, x+8, ... and walks all their column tiles back to back - the A panel is then
     // served by that XCD's L2.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if ((gridDim.y & 7) == 0) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    int bx = bid_x, by = bid_y;
+    if ((grid_y & 7) == 0) {
+        const int lin = bid_y * grid_x + bid_x;
         const int xcd = lin & 7, j = lin >> 3;
-        by = xcd + 8 * (j / (int)gridDim.x);
-        bx = j % (int)gridDim.x;
+        by = xcd + 8 * (j / grid_x);
+        bx = j % grid_x;
     }
     const int m0 = by * BM, n0 = bx * BN;
     // this thread's chunk 0 of the first K-tile; advanced by a constant per K-tile
@@ -140,32 +155,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
         for (int e = 0; e < 8; ++e) bias8[e] = (g.bias && n + e < g.N) ? g.bias[n + e] : 0.f;
     }
 
-    uint4 ra[BM / 32], rb[BN / 32];
-    tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
-    tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        tile_store<AKC, BM>(sA, tid, ra);
-        tile_store<BKC, BN>(sB, tid, rb);
-        __syncthreads();
-        if (k0 + BK < k_end) {                           // next K-tile in flight behind the MFMAs
-            pa += stepA; pb += stepB;
-            tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
-            tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
-        }
-        // MFMA phase, software-pipelined by hand: the fragments of k-step kk+1 are read from LDS BEFORE the MFMAs of step kk are
-        // issued (two register sets).  Left alone, hipcc sinks every ds_read next to its first use ("2 reads, wait, 2 MFMAs"), so the
-        // matrix pipe idles for one LDS round trip per pair of MFMAs; the sched_barriers pin the order.
+    // MFMA phase of one K-tile, software-pipelined by hand: the fragments of k-step kk+1 are read from LDS BEFORE the MFMAs of step kk
+    // are issued (two register sets).  Left alone, hipcc sinks every ds_read next to its first use ("2 reads, wait, 2 MFMAs"), so the
+    // matrix pipe idles for one LDS round trip per pair of MFMAs; the sched_barriers pin the order.
+    auto mfma_phase = [&](const uint16_t* tA, const uint16_t* tB) {
         auto load_frags = [&](int kk, bf16x8 (&fa)[FM], bf16x8 (&fb)[2]) {
             const int koff = kk * 16 + (lane >> 5) * 8;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                if (AKC) fa[i] = *(const bf16x8*)&sA[(wm * (FM * 32) + i * 32 + (lane & 31)) * PITCH + koff];
-                else fa[i] = frag_tr<PTA>(sA, kk * 16, wm * (FM * 32) + i * 32, lane);
+                if (AKC) fa[i] = *(const bf16x8*)&tA[(wm * (FM * 32) + i * 32 + (lane & 31)) * PITCH + koff];
+                else fa[i] = frag_tr<PTA, DB>(tA, kk * 16, wm * (FM * 32) + i * 32, lane);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (BKC) fb[j] = *(const bf16x8*)&sB[(wn * 64 + j * 32 + (lane & 31)) * PITCH + koff];
-                else fb[j] = frag_tr<PTB>(sB, kk * 16, wn * 64 + j * 32, lane);
+                if (BKC) fb[j] = *(const bf16x8*)&tB[(wn * 64 + j * 32 + (lane & 31)) * PITCH + koff];
+                else fb[j] = frag_tr<PTB, DB>(tB, kk * 16, wn * 64 + j * 32, lane);
             }
         };
         auto mfmas = [&](const bf16x8 (&fa)[FM], const bf16x8 (&fb)[2]) {
@@ -188,7 +192,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
             mfmas(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    if constexpr (DB) {
+        uint4 ra[2][BM / 32], rb[2][BN / 32];
+        uint16_t* const sA1 = smem + STAGE;
+        uint16_t* const sB1 = sA1 + A_ELEMS;
+        const int ntile = (k_end - k_begin + BK - 1) / BK;
+        tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra[0]);
+        tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb[0]);
+        {
+            const bool more = ntile > 1;
+            pa += more ? stepA : 0; pb += more ? stepB : 0;
+            const int kt = k_begin + (more ? BK : 0);
+            tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, kt, g.M, k_end, g.partA, tid, ra[1]);
+            tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, kt, g.N, k_end, g.partB, tid, rb[1]);
+        }
+        tile_store<AKC, BM, true>(sA, tid, ra[0]);
+        tile_store<BKC, BN, true>(sB, tid, rb[0]);
         __syncthreads();
+        // The prefetch loads are issued UNCONDITIONALLY (past the last tile the pointers simply stop advancing and the tile is fetched
+        // again, unused): a load under a runtime condition makes hipcc wait for vmcnt(0) before every LDS store - it cannot count
+        // the loads that may not have been issued - which serialises the very loads this loop is meant to keep in flight.
+        for (int t = 0; t < ntile; t += 2) {
+            // even tile t in buffer 0; registers [1] hold tile t+1, registers [0] are free
+            {
+                const bool more = t + 2 < ntile;
+                pa += more ? stepA : 0; pb += more ? stepB : 0;
+                const int kt = k_begin + (more ? t + 2 : ntile - 1) * BK;
+                tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, kt, g.M, k_end, g.partA, tid, ra[0]);
+                tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, kt, g.N, k_end, g.partB, tid, rb[0]);
+            }
+            mfma_phase(sA, sB);
+            tile_store<AKC, BM, true>(sA1, tid, ra[1]);       // (t + 1 == ntile: a stale tile nobody reads)
+            tile_store<BKC, BN, true>(sB1, tid, rb[1]);
+            __syncthreads();
+            if (t + 1 >= ntile) break;
+            // odd tile t+1 in buffer 1; registers [0] hold tile t+2, registers [1] are free
+            {
+                const bool more = t + 3 < ntile;
+                pa += more ? stepA : 0; pb += more ? stepB : 0;
+                const int kt = k_begin + (more ? t + 3 : ntile - 1) * BK;
+                tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, kt, g.M, k_end, g.partA, tid, ra[1]);
+                tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, kt, g.N, k_end, g.partB, tid, rb[1]);
+            }
+            mfma_phase(sA1, sB1);
+            tile_store<AKC, BM, true>(sA, tid, ra[0]);
+            tile_store<BKC, BN, true>(sB, tid, rb[0]);
+            __syncthreads();
+        }
+    } else {
+        uint4 ra[BM / 32], rb[BN / 32];
+        tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
+        tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            tile_store<AKC, BM>(sA, tid, ra);
+            tile_store<BKC, BN>(sB, tid, rb);
+            __syncthreads();
+            if (k0 + BK < k_end) {                           // next K-tile in flight behind the MFMAs
+                pa += stepA; pb += stepB;
+                tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
+                tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
+            }
+            mfma_phase(sA, sB);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  The MFMA leaves each lane with 4 consecutive n for ONE row m (32 different rows per wave instruction):
@@ -246,6 +314,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2
         }
         if (i + 1 < FM) __syncthreads();
     }
+}
+
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool DB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FM == 4 || DB) ? 2 : 3))) void gemm_kernel(GemmArgs g) {
+    gemm_body<TA, TB, TC, AKC, BKC, FM, EDGE, DB>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// ---- grouped launch: up to GROUP_MAXP independent split-K weight-gradient products (A = dY [K][M], B = X [K][N], both with the
+// contraction index slow: layout (0,0); bf16 in, f32 partial sums out) in ONE grid.  The ~9 products of a Conformer block's backward
+// are each too small to fill the chip (82-440 TFLOP/s alone, ~14 us of launch / fill / drain per launch); together they are one
+// launch of a few thousand workgroups.  Each product keeps its own tile grid (first[q] .. first[q+1]) and its own partial buffer,
+// folded into the gradient buffers afterwards by sarssl_splitk_reduce_multi.
+#define GROUP_MAXP 12
+struct GemmGroup {
+    GemmArgs p[GROUP_MAXP];                      // (12 x 272 bytes of kernel arguments)
+    int gx[GROUP_MAXP], gy[GROUP_MAXP], first[GROUP_MAXP + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_group_tn_kernel(GemmGroup a) {
+    int q = 0;
+    while (q + 1 < a.n && (int)blockIdx.x >= a.first[q + 1]) ++q;
+    const int local = blockIdx.x - a.first[q];
+    const int gx = a.gx[q], gy = a.gy[q];
+    const int bz = local / (gx * gy), rem = local - bz * (gx * gy);
+    gemm_body<bf16, bf16, float, false, false, 2, false, false>(a.p[q], rem % gx, rem / gx, bz, gx, gy);
 }
 
 // C[z][m][n] += sum_s ws[z][s][m][n]   (second stage of split-K weight-gradient GEMMs; C is f32)
@@ -313,12 +406,12 @@ extern "C" int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsp
     return 0;
 }
 
-template <typename TA, typename TB, typename TC, int FM, bool EDGE>
+template <typename TA, typename TB, typename TC, int FM, bool EDGE, bool DB = false>
 static void launch_fm(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
-    if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, FM, EDGE><<<grid, 256, 0, st>>>(g);
-    else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, FM, EDGE><<<grid, 256, 0, st>>>(g);
-    else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, FM, EDGE><<<grid, 256, 0, st>>>(g);
-    else gemm_kernel<TA, TB, TC, false, false, FM, EDGE><<<grid, 256, 0, st>>>(g);
+    if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
+    else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
+    else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
+    else gemm_kernel<TA, TB, TC, false, false, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
 }
 
 // Tile choice: 256 x 128 tiles (FM = 4) halve the staged bytes and barriers per MFMA but also the number of workgroups; they are
@@ -350,6 +443,16 @@ static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, int nbatch, hipS
             SARSSL_CHECK_LAUNCH("sarssl_gemm");
             return 0;
         }
+    }
+    // double-buffered variant (2 workgroups / CU, two K-tiles of loads in flight) for grids of at most ~2 workgroups per CU, where
+    // nothing else hides the memory round trip of a K-tile.  Measured alone: ffn2 / dX d=256 22 -> 19 us, dW d=256 35 -> 31 us, but
+    // ffn1 d=512 64 -> 72 us (2 instead of 3 workgroups per CU) - and inside the training step, where the other encoder's stream
+    // already fills the gaps, 14.08 vs 14.01 ms: kept as an opt-in (SARSSL_GEMM_DB=1) for single-stream use
+    static const int force_db = getenv("SARSSL_GEMM_DB") ? atoi(getenv("SARSSL_GEMM_DB")) : -1;        // A/B experiments only
+    const long nwg = (long)grid.x * grid.y * grid.z;
+    const bool db = BIG && !edge && force_db > 0 && nwg <= 2L * sarssl_cu_count() + 64;      // opt-in: neutral inside the step (see above)
+    if constexpr (BIG) {
+        if (db) { launch_fm<TA, TB, TC, 2, false, true>(g, a_kc, b_kc, grid, st); SARSSL_CHECK_LAUNCH("sarssl_gemm"); return 0; }
     }
     if (edge) launch_fm<TA, TB, TC, 2, true>(g, a_kc, b_kc, grid, st);
     else launch_fm<TA, TB, TC, 2, false>(g, a_kc, b_kc, grid, st);
@@ -431,4 +534,43 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     }
     sarssl_set_error("sarssl_gemm: unsupported dtype combination (%d,%d,%d)", dtA, dtB, dtC);
     return -1;
+}
+
+// Grouped split-K weight-gradient products: ws[q] (f32, split_q * M_q * N_q, see `split_out`) receives the partial sums of
+// dY_q^T X_q with A_q = dY [K_q][M_q] (row stride lda), B_q = X [K_q][N_q] (row stride ldb), bf16; fold with
+// sarssl_splitk_reduce_multi.  split_k[q] is the requested split; the effective number of partial slices (ceil(K / per), per a
+// multiple of 64) is returned in split_out[q] - size ws[q] for split_k[q] slices.  Returns 1 without launching when any shape is
+// ragged (M % 128, N % 128 or the K slices % 64).
+extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* const* ws, const int* M, const int* N,
+                                    const int* K, const long* lda, const long* ldb, const int* split_k, int* split_out, int n_prob,
+                                    void* stream) {
+    SARSSL_REQUIRE(n_prob > 0 && n_prob <= GROUP_MAXP, "sarssl_gemm_group_tn");
+    GemmGroup a;
+    a.n = n_prob;
+    int total = 0;
+    bool edge = false;
+    for (int q = 0; q < n_prob; ++q) {
+        SARSSL_REQUIRE(M[q] > 0 && N[q] > 0 && K[q] > 0 && split_k[q] > 0 && M[q] % 8 == 0 && N[q] % 8 == 0 && lda[q] % 8 == 0 &&
+                       ldb[q] % 8 == 0 && ws[q] != nullptr, "sarssl_gemm_group_tn(shape)");
+        const int per = ((K[q] + split_k[q] - 1) / split_k[q] + BK - 1) / BK * BK;
+        const int ns = (K[q] + per - 1) / per;
+        GemmArgs& g = a.p[q];
+        g.A = A[q]; g.B = B[q]; g.C = nullptr; g.M = M[q]; g.N = N[q]; g.K = K[q]; g.lda = lda[q]; g.ldb = ldb[q]; g.ldc = N[q];
+        g.batch_inner = 1; g.sA0 = g.sA1 = g.sB0 = g.sB1 = g.sC0 = g.sC1 = 0;
+        g.alpha = 1.f; g.out_scale = 1.f; g.bias = nullptr; g.act = 0;
+        g.resid = nullptr; g.ldr = 0; g.sR0 = g.sR1 = 0; g.res_scale = 0.f;
+        g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
+        g.p_drop = 0.f; g.seed = 0; g.salt = nullptr;
+        g.split_k = ns; g.k_per_split = per; g.row_shift = 0;
+        a.gx[q] = (N[q] + BN - 1) / BN; a.gy[q] = (M[q] + 127) / 128;
+        a.first[q] = total; total += a.gx[q] * a.gy[q] * ns;
+        split_out[q] = ns;
+        edge = edge || (M[q] % 128) != 0 || (N[q] % BN) != 0 || (per % BK) != 0 || (K[q] % BK) != 0;
+    }
+    a.first[n_prob] = total;
+    if (edge) return 1;            // ragged shapes: not taken (the caller launches the products one by one); the EDGE instantiation of
+                                   // the grouped kernel crashes hipcc 7.2's simplifycfg
+    gemm_group_tn_kernel<<<total, 256, 0, (hipStream_t)stream>>>(a);
+    SARSSL_CHECK_LAUNCH("gemm_group_tn_kernel");
+    return 0;
 }

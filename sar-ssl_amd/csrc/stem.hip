@@ -681,7 +681,7 @@ extern "C" int sarssl_mask_inputs(const float* x, const unsigned char* mp, const
 }
 
 extern "C" int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, double* stats, int dtype, void* stream) {
-    if (stats && hipMemsetAsync(stats, 0, 128 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for(npix * 8, 256, stats ? 1024 : 4096);
     DISPATCH_T(dtype, (stem_c1_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)a0, W1, npix, (T*)y1, stats)));
     SARSSL_CHECK_LAUNCH("stem_c1_fwd_kernel");
@@ -712,7 +712,7 @@ extern "C" int sarssl_stem_c1_wgrad_bn(const void* dz1, const void* y1, const vo
 extern "C" int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a0, long npix, const float* aff, int use_stats,
                                   double* red, float* dW1, float* dgamma, float* dbeta, int dtype, void* stream) {
     SARSSL_REQUIRE(npix > 0 && red && dW1 && dgamma && dbeta, "sarssl_stem_c1_bwd");
-    if (hipMemsetAsync(red, 0, 644 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (SARSSL_ZERO(red, 644 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for(npix * 8, 256, 1024);
     DISPATCH_T(dtype, (stem_c1_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)y1, (const T*)a0, npix, aff, red)));
     stem_c1_bwd_finalize_kernel<<<1, 256, 0, ST>>>(red, npix, aff, use_stats, dW1, dgamma, dbeta);
@@ -732,7 +732,7 @@ extern "C" int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* 
 extern "C" int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
                                   const float* mean, const float* rstd, int nb, int F, int Tn, void* g3, double* red,
                                   int dtype, void* stream) {
-    if (hipMemsetAsync(red, 0, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (SARSSL_ZERO(red, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 1024);
     DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 0><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
                                                                      nb, F, Tn, (T*)g3, red, 1)));
@@ -744,7 +744,7 @@ extern "C" int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* 
 extern "C" int sarssl_stem_c4_bwd_sums(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
                                        const float* mean, const float* rstd, int nb, int F, int Tn, double* red, int dtype,
                                        void* stream) {
-    if (hipMemsetAsync(red, 0, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (SARSSL_ZERO(red, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 1024);
     DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 1><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
                                                                      nb, F, Tn, (T*)nullptr, red, 1)));
@@ -786,7 +786,7 @@ static inline dim3 cl_grid(long rows, int L, int C) {
 extern "C" int sarssl_cl_stats(const void* x, long N, int C, double* sums, int dtype, void* stream) {
     long rows; int L;
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_stats(C % 8 == 0 or C | 64; C < 64 needs N*C % 64 == 0)");
-    if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (SARSSL_ZERO(sums, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const dim3 grid = cl_grid(rows, L, C);
     DISPATCH_T(dtype, (cl_stats_kernel<T><<<grid, 256, 0, ST>>>((const T*)x, rows, L, C, sums)));
     SARSSL_CHECK_LAUNCH("cl_stats_kernel");
@@ -824,7 +824,7 @@ extern "C" int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, in
                                        const float* mean, const float* rstd, int act, double* red, int dtype, void* stream) {
     long rows; int L;
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_bn_bwd_reduce");
-    if (hipMemsetAsync(red, 0, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    if (SARSSL_ZERO(red, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const dim3 grid = cl_grid(rows, L, C);
     DISPATCH_T(dtype, (cl_bn_bwd_reduce_kernel<T><<<grid, 256, 0, ST>>>((const T*)dz, (const T*)y, rows, L, C, scale, shift,
                                                                        mean, rstd, act, red)));

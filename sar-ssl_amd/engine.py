@@ -79,6 +79,9 @@ _ABLATE_WGRAD = os.environ.get("SARSSL_ABLATE_WGRAD", "0") == "1"     # timing e
 # "fork" replays SLOWER than the plain two-stream graph (14.69 ms; eager 13.67).  The two encoder streams already fill the CUs.
 # Joined (wgrad_join) only where gradients are consumed: bucket all-reduce hooks, Adam.
 _WGRAD_MODE = os.environ.get("SARSSL_WGRAD_MODE", "off")
+# Grouped launch: independently of the stream schedule, the weight-gradient products of one block (bf16) are collected and issued as
+# ONE launch when the block's backward ends (hip.gemm_group_tn); SARSSL_WGRAD_GROUP=0 issues them one by one where they occur.
+_WGRAD_GROUP = os.environ.get("SARSSL_WGRAD_GROUP", "1") != "0"
 _wg_streams = {}
 _wg_hold = {}
 _wg_nofork = set()           # stream handles that must not fork a companion (see wgrad_no_fork)
@@ -150,8 +153,11 @@ class wgrad_block:
             return False
         held = [t for it in items for t in it[:2]] + [x for x, _ in (hip._colsum_batch or [])]
         with _WgradSide(*held):
-            for dy, x, g2, split in items:
-                _wgrad_gemm(dy, x, g2, split)
+            for i in range(0, len(items), 12):                 # one grouped launch per <= 12 products (csrc/gemm.hip)
+                chunk = items[i:i + 12]
+                if not (_WGRAD_GROUP and len(chunk) > 1 and hip.gemm_group_tn(chunk)):
+                    for dy, x, g2, split in chunk:
+                        _wgrad_gemm(dy, x, g2, split)
             hip.splitk_flush()
             hip.colsum_flush()
         return False
@@ -174,8 +180,8 @@ def mm_tn_acc(dy, x, gW, side=True):
     tiles = ((N + 255) // 256) * ((K + 127) // 128)                          # 256 x 128 output tiles (csrc/gemm.hip)
     split = max(1, min((M + 511) // 512, (512 + tiles - 1) // tiles))       # ~2 workgroups per CU, >= 8 K-tiles each
     split = max(1, min(split, (1 << 23) // (N * K)))                         # partial-sum workspace <= 32 MB (reduce pass cost)
-    if side and _WGRAD_MODE == "block" and _wg_blocks and RT.replay is None:
-        _wg_blocks[-1].append((dy, x, g2, split))
+    if side and _wg_blocks and RT.replay is None and (_WGRAD_MODE == "block" or (_WGRAD_GROUP and RT.dtype == torch.bfloat16)):
+        _wg_blocks[-1].append((dy, x, g2, split))            # enqueued when the block's backward ends (wgrad_block)
     elif side and _WGRAD_MODE == "fork":
         with _WgradSide(dy, x):
             _wgrad_gemm(dy, x, g2, split)
@@ -214,26 +220,21 @@ def bn_affine(x, C, bn, train, sums=None):
 
 def bn_param_grads(bn, red, C):
     """red = [sum g | sum g*xhat] (f64, 2C) -> dbeta, dgamma."""
-    hip.f64_accum(red[:C], gbuf(bn.bias))
-    hip.f64_accum(red[C:2 * C], gbuf(bn.weight))
+    hip.f64_accum2(red, gbuf(bn.bias), gbuf(bn.weight))
 
 
 # ------------------------------------------------------------------------------------------------ CNN stem
 def _taps(conv):
     """(co,ci,3,3) -> forward taps [9][co][ci] and data-gradient taps [9][ci][co] (flipped), runtime dtype."""
-    def build():
-        W = conv.weight.data
-        fwd = W.permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous()
-        dgr = W.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous()
-        return to_rt(fwd), to_rt(dgr)
+    def build():                                              # one launch (rebuilt every step: the weights move)
+        return hip.conv_taps(conv.weight.data.contiguous(), RT.dtype)
     return _cached(conv, "taps", build)
 
 
 def _patch_w(conv, F):
     """(d,4,F,1) -> [d][f*4+c] so the patch conv is a plain GEMM over the (B,T,F,4) tensor."""
     def build():
-        W = conv.weight.data
-        return to_rt(W[:, :, :, 0].permute(0, 2, 1).reshape(W.shape[0], F * 4).contiguous())
+        return hip.patch_w(conv.weight.data.contiguous(), RT.dtype)
     return _cached(conv, "patchw", build)
 
 
@@ -277,7 +278,7 @@ def patch_bwd(de, pe, saved):
     d = de.shape[1]
     gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
     mm_tn_acc(de, z4, gtmp, side=False)
-    gbuf(pe[12].weight).add_(gtmp.view(d, F, 4).permute(0, 2, 1).unsqueeze(-1))
+    hip.patch_wgrad_accum(gtmp, gbuf(pe[12].weight))
     return mm_nn(de, _patch_w(pe[12], F), fp8=False)                                       # (B,T,F,4)
 
 
@@ -298,8 +299,9 @@ def stem_bwd(dz4, pe, saved):
         dy3 = hip.cl_bn_bwd_apply(g3, y3, 64, aff3, RELU, True, train, red[256:], out=g3)
     bn_param_grads(pe[7], red[256:], 64)
     # second 3x3 conv
-    dW = hip.conv3x3_wgrad(dy3, y2, aff2[0], aff2[1], precise=RT.precise)
-    gbuf(pe[6].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
+    dW = hip.conv3x3_wgrad(dy3, y2, aff2[0], aff2[1], precise=RT.precise, acc_into=gbuf(pe[6].weight))
+    if dW is not None:
+        gbuf(pe[6].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
     red2 = None
     if _DGRAD_BNRED and RT.dtype == torch.bfloat16:   # BatchNorm-backward sums accumulated in the data-gradient kernel's epilogue
         dz2, red2 = hip.conv3x3_dgrad_bnred(dy3, _taps(pe[6])[1], y2, aff2)
@@ -315,9 +317,10 @@ def stem_bwd(dz4, pe, saved):
         dW = hip.conv3x3_wgrad_bnin(dz2, y2, aff2, red2, y1, aff1[0], aff1[1], train)
     else:
         dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2)
-        dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise)
+        dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise, acc_into=gbuf(pe[3].weight))
         dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
-    gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
+    if dW is not None:
+        gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
     if _C1_FUSED == 2:      # everything the first layer needs from (dz1, y1, a0) in one pass: BN sums, dgamma/dbeta, dW1
         hip.stem_c1_bwd(dz1, y1, a0, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
         return None
@@ -649,7 +652,7 @@ def block_bwd(dy, blk, saved):
     seq = blk.sequential
     x, stats = saved.pop()
     # the block's ~9 bias-gradient column sums and the reductions of its 9 split-K weight-gradient products: one launch each, at the end
-    with hip.colsum_batched(flush_ctx=_WgradSide), hip.splitk_batched(flush_ctx=_WgradSide), wgrad_block():
+    with hip.colsum_batched(flush_ctx=_WgradSide), hip.splitk_batched(flush_ctx=_WgradSide), hip.ln_reduce_batched(), wgrad_block():
         d = hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias))
         d = ffn_bwd(d, seq[3].module, saved)
         d = convmod_bwd(d, seq[2].module, saved)

@@ -75,6 +75,37 @@ class _Timed:
         return False
 
 
+# ---- pre-zeroed f64 arena for the reductions' accumulators (csrc/api.hip sarssl_zero_arena): one memset per forward / backward
+#      pass instead of one in front of every reduction launch
+_ARENA_DOUBLES = 1 << 16
+_arena = {}                 # device index -> [tensor, cursor]
+
+
+def sums_arena_reset(device):
+    """Zero the arena (one memset on the current stream) and start handing out slices from its beginning.  Call at the start of a
+    forward and of a backward pass: every slice handed out before has been consumed inside the pass that took it."""
+    if device.type != "cuda":
+        return
+    ent = _arena.get(device.index)
+    if ent is None:
+        t = torch.zeros((_ARENA_DOUBLES,), dtype=torch.float64, device=device)
+        ent = _arena[device.index] = [t, 0]
+        _lib.call("sarssl_zero_arena", _p(t), c_long(t.numel() * 8))
+    ent[0].zero_()
+    ent[1] = 0
+
+
+def _sums(n, device):
+    """f64[n] accumulator: a zeroed arena slice when the arena is active for this device, else uninitialised memory (the launch
+    wrappers memset whatever lies outside the arena)."""
+    ent = _arena.get(device.index)
+    if ent is not None and ent[1] + n <= _ARENA_DOUBLES:
+        o = ent[1]
+        ent[1] = o + (n + 15) // 16 * 16
+        return ent[0][o:o + n]
+    return torch.empty((n,), dtype=torch.float64, device=device)
+
+
 _ws_cache = {}
 
 
@@ -131,6 +162,40 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
 
 
 _splitk_batch = None
+
+
+def gemm_group_tn(items):
+    """items: [(dy [K,M] bf16, x [K,N] bf16, out f32 [M,N] view, split)] - the split-K partial sums of every out_q += dy_q^T x_q in ONE
+    launch (csrc/gemm.hip, gemm_group_tn_kernel); the partials join the open splitk_batched() batch and are folded into the
+    gradient buffers when it closes.  Returns False (nothing launched) when a shape is ragged or no batch is open."""
+    import ctypes
+    n = len(items)
+    if _splitk_batch is None or n == 0 or n > 12:
+        return False
+    for dy, x, out, split in items:
+        if not (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and out.dtype == torch.float32 and dy.stride(1) == 1
+                and x.stride(1) == 1 and out.shape[1] % 4 == 0 and out.stride(0) % 4 == 0 and dy.shape[1] % 128 == 0
+                and x.shape[1] % 128 == 0):
+            return False
+    _need_cuda(*[t for it in items for t in it[:3]])
+    ws = [torch.empty((it[3] * it[0].shape[1] * it[1].shape[1],), dtype=torch.float32, device=it[0].device) for it in items]
+    arr = lambda ty, vals: (ty * n)(*vals)
+    split_out = (ctypes.c_int * n)()
+    rc = _lib.lib().sarssl_gemm_group_tn(
+        arr(ctypes.c_void_p, [it[0].data_ptr() for it in items]), arr(ctypes.c_void_p, [it[1].data_ptr() for it in items]),
+        arr(ctypes.c_void_p, [w.data_ptr() for w in ws]), arr(ctypes.c_int, [it[0].shape[1] for it in items]),
+        arr(ctypes.c_int, [it[1].shape[1] for it in items]), arr(ctypes.c_int, [it[0].shape[0] for it in items]),
+        arr(ctypes.c_long, [it[0].stride(0) for it in items]), arr(ctypes.c_long, [it[1].stride(0) for it in items]),
+        arr(ctypes.c_int, [it[3] for it in items]), split_out, c_int(n), _stream())
+    _lib.ncalls += 1
+    if rc == 1:
+        return False
+    _lib.check(rc, "sarssl_gemm_group_tn")
+    for q, (dy, x, out, split) in enumerate(items):
+        _splitk_batch.append((ws[q], int(split_out[q]), dy.shape[1], x.shape[1], out, out.stride(0)))
+        if len(_splitk_batch) == 16:
+            splitk_flush()
+    return True
 
 
 _splitk_ctx = None            # optional context-manager factory (tensors...) the flush launch runs under (engine._WgradSide)
@@ -284,7 +349,7 @@ def stem_c1_fwd(a0, W1, want_stats=False):
     """-> y1, or (y1, sums f64[128]) with the BatchNorm sums of y1 accumulated in the same pass."""
     npix = a0.numel() // 4
     y = torch.empty(a0.shape[:-1] + (64,), dtype=a0.dtype, device=a0.device)
-    sums = torch.empty((128,), dtype=torch.float64, device=a0.device) if want_stats else None
+    sums = _sums(128, a0.device) if want_stats else None
     _lib.call("sarssl_stem_c1_fwd", _p(a0), _p(W1), c_long(npix), _p(y), _p(sums), c_int(dt(a0)), _stream())
     return (y, sums) if want_stats else y
 
@@ -326,7 +391,7 @@ def stem_c4_bwd(y3, dy4, W4, aff):
     """-> g3 (B,F,T,64), red f64[384] = [dW4 (4x64) | s1 (64) | s2 (64)]."""
     B, F, T, _ = y3.shape
     g3 = torch.empty_like(y3)
-    red = torch.empty((384,), dtype=torch.float64, device=y3.device)
+    red = _sums(384, y3.device)
     _lib.call("sarssl_stem_c4_bwd", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
               c_int(T), _p(g3), _p(red), c_int(dt(y3)), _stream())
     return g3, red
@@ -336,13 +401,45 @@ def stem_c4_bwd_two_phase(y3, dy4, W4, aff, train):
     """-> dy3 (B,F,T,64) = gradient w.r.t. the third BatchNorm's input, red f64[384] = [dW4 | s1 | s2]; two kernels, no
     intermediate 64-channel tensor."""
     B, F, T, _ = y3.shape
-    red = torch.empty((384,), dtype=torch.float64, device=y3.device)
+    red = _sums(384, y3.device)
     _lib.call("sarssl_stem_c4_bwd_sums", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
               c_int(T), _p(red), c_int(dt(y3)), _stream())
     dy3 = torch.empty_like(y3)
     _lib.call("sarssl_stem_c4_bwd_apply", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
               c_int(T), _p(red), c_int(1 if train else 0), _p(dy3), c_int(dt(y3)), _stream())
     return dy3, red
+
+
+def f64_accum2(src, dst1, dst2):
+    """dst1 += src[:n], dst2 += src[n:2n] (n = dst1.numel()) in one launch."""
+    _lib.call("sarssl_f64_accum2", _p(src), _p(dst1), _p(dst2), c_int(dst1.numel()), _stream())
+
+
+def conv_taps(W, dtype):
+    """(64,64,3,3) f32 weight -> (fwd [9][co][ci], dgrad [9][ci][co] with flipped taps) in `dtype`, one launch."""
+    _need_cuda(W)
+    assert W.shape == (64, 64, 3, 3) and W.dtype == torch.float32 and W.is_contiguous()
+    fwd = torch.empty((9, 64, 64), dtype=dtype, device=W.device)
+    dgr = torch.empty((9, 64, 64), dtype=dtype, device=W.device)
+    _lib.call("sarssl_conv_taps", _p(W), _p(fwd), _p(dgr), c_int(_DT[dtype]), _stream())
+    return fwd, dgr
+
+
+def patch_w(W, dtype):
+    """(d,4,F,1) f32 frame-patch conv weight -> [d][f*4+c] GEMM operand in `dtype`."""
+    _need_cuda(W)
+    d, _, F, _ = W.shape
+    assert W.dtype == torch.float32 and W.is_contiguous() and W.shape[1] == 4 and W.shape[3] == 1
+    out = torch.empty((d, F * 4), dtype=dtype, device=W.device)
+    _lib.call("sarssl_patch_w", _p(W), _p(out), c_int(d), c_int(F), c_int(_DT[dtype]), _stream())
+    return out
+
+
+def patch_wgrad_accum(g, grad):
+    """grad (d,4,F,1) f32 += g [d][f*4+c] f32."""
+    d, _, F, _ = grad.shape
+    assert g.is_contiguous() and grad.is_contiguous() and g.numel() == grad.numel()
+    _lib.call("sarssl_patch_wgrad_accum", _p(g), _p(grad), c_int(d), c_int(F), _stream())
 
 
 def f64_accum(src, dst, scale=1.0):
@@ -357,7 +454,7 @@ def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False, want_stats=Fals
     assert C == 64 and w_tap.dtype == x.dtype and w_tap.is_contiguous() and x.is_contiguous()
     out = torch.empty_like(x)
     ws = _f32ws(x.numel(), x.device, "conv_acc") if (precise and x.dtype == torch.float32) else None
-    sums = torch.empty((128,), dtype=torch.float64, device=x.device) if want_stats else None
+    sums = _sums(128, x.device) if want_stats else None
     # separate timing labels: the BN+ReLU-prologue launches (forward convolutions) and the identity launches (data gradients) are
     # different amounts of work per tile
     with _Timed("conv3x3_fwd:bn_prologue" if scale is not None else "conv3x3_fwd:identity"):
@@ -375,7 +472,7 @@ def conv3x3_dgrad_bnred(dy, w_tap_dgrad, y, aff):
     assert C == 64 and dy.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.shape == dy.shape
     assert aff.dtype == torch.float32 and aff.is_contiguous() and aff.numel() == 256 and dy.is_contiguous() and y.is_contiguous()
     dz = torch.empty_like(dy)
-    red = torch.empty((128,), dtype=torch.float64, device=dy.device)
+    red = _sums(128, dy.device)
     fn = _lib.lib().sarssl_conv3x3_dgrad_bnred
     with _Timed("conv3x3_dgrad_bnred"):          # (its own label: this launch also reads y and reduces)
         rc = fn(_p(dy), _p(w_tap_dgrad), _p(dz), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red), _stream())
@@ -418,13 +515,20 @@ def conv3x3_wgrad_bnin(dz_in, y_bn, aff_bn, red_bn, zin, scale=None, shift=None,
     return dW
 
 
-def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False):
-    """-> dW f32 [9][64][64] ([tap][co][ci])."""
+def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False, acc_into=None):
+    """-> dW f32 [9][64][64] ([tap][co][ci]); or, with acc_into = the (64,64,3,3) f32 parameter-gradient buffer (bf16 operands), the
+    weight gradient is added straight into it (nn.Conv2d layout) and None is returned."""
     _need_cuda(dy, zin)
     B, F, T, C = zin.shape
     nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
     nbytes.restype = c_long
     part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), zin.device, "wgrad_part")
+    if acc_into is not None and zin.dtype == torch.bfloat16:
+        assert acc_into.shape == (64, 64, 3, 3) and acc_into.dtype == torch.float32 and acc_into.is_contiguous()
+        with _Timed("conv3x3_wgrad_kernel"):
+            _lib.call("sarssl_conv3x3_wgrad_acc", _p(dy), _p(zin), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(acc_into),
+                      _p(part), _stream())
+        return None
     dW = torch.empty((9, 64, 64), dtype=torch.float32, device=zin.device)
     with _Timed("conv3x3_wgrad_kernel"):
         _lib.call("sarssl_conv3x3_wgrad", _p(dy), _p(zin), c_int(dt(zin)), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW),
@@ -436,7 +540,7 @@ def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False):
 # channels-last BatchNorm pieces.  aff = (scale, shift, mean, rstd) f32 [C] each
 def cl_stats(x, C):
     N = x.numel() // C
-    sums = torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+    sums = _sums(2 * C, x.device)
     _lib.call("sarssl_cl_stats", _p(x), c_long(N), c_int(C), _p(sums), c_int(dt(x)), _stream())
     return sums, N
 
@@ -468,7 +572,7 @@ def cl_affine_act(x, C, aff, act):
 
 
 def cl_bn_bwd_reduce(dz, y, C, aff, act):
-    red = torch.empty((2 * C,), dtype=torch.float64, device=y.device)
+    red = _sums(2 * C, y.device)
     _lib.call("sarssl_cl_bn_bwd_reduce", _p(dz), _p(y), c_long(y.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), _p(aff[2]),
               _p(aff[3]), c_int(act), _p(red), c_int(dt(y)), _stream())
     return red
@@ -496,6 +600,44 @@ def layernorm_fwd(x2d, gamma, beta, eps=1e-5, out=None, save=True):
     return out, stats
 
 
+_ln_batch = None              # list of (partials, nparts, d, dgamma, dbeta) while an ln_reduce_batched() context is open
+
+
+class ln_reduce_batched:
+    """Context manager: the dgamma / dbeta folds of the LayerNorm backward launches issued inside run as ONE launch at exit
+    (sarssl_ln_param_reduce_multi) instead of one small reduce per LayerNorm."""
+
+    def __enter__(self):
+        global _ln_batch
+        self._outer = _ln_batch
+        if _ln_batch is None:
+            _ln_batch = []
+        return self
+
+    def __exit__(self, *exc):
+        global _ln_batch
+        if self._outer is None:
+            if exc[0] is None:
+                ln_reduce_flush()
+            _ln_batch = None
+        return False
+
+
+def ln_reduce_flush():
+    global _ln_batch
+    if not _ln_batch:
+        return
+    import ctypes
+    items, _ln_batch = _ln_batch, []
+    for i in range(0, len(items), 8):
+        ch = items[i:i + 8]
+        n = len(ch)
+        _lib.call("sarssl_ln_param_reduce_multi", (ctypes.c_void_p * n)(*[c[0].data_ptr() for c in ch]),
+                  (ctypes.c_int * n)(*[c[1] for c in ch]), (ctypes.c_int * n)(*[c[2] for c in ch]),
+                  (ctypes.c_void_p * n)(*[c[3].data_ptr() for c in ch]), (ctypes.c_void_p * n)(*[c[4].data_ptr() for c in ch]),
+                  c_int(n), _stream())
+
+
 def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, out=None):
     M, d = x2d.shape
     if out is None:
@@ -504,7 +646,12 @@ def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, 
     if dgamma is not None:
         fn = _lib.lib().sarssl_layernorm_bwd_workspace_bytes
         fn.restype = c_long
-        part = workspace(fn(c_long(M), c_int(d)), x2d.device, "ln_part")
+        if _ln_batch is not None:              # partials only; folded with the block's other LayerNorms when the batch closes
+            part = torch.empty((fn(c_long(M), c_int(d)) // 4,), dtype=torch.float32, device=x2d.device)
+            _ln_batch.append((part, int(_lib.lib().sarssl_layernorm_bwd_nparts(c_long(M))), d, dgamma, dbeta))
+            dgamma = dbeta = None
+        else:
+            part = workspace(fn(c_long(M), c_int(d)), x2d.device, "ln_part")
     _lib.call("sarssl_layernorm_bwd", _p(dy2d), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
               _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out),
               c_long(out.stride(0)), _p(dgamma), _p(dbeta), _p(part), c_int(dt(x2d)), _stream())
@@ -538,7 +685,7 @@ def dwglu_fwd(h2d, w, B, T, want_stats=False):
     _need_cuda(h2d, w)
     d = h2d.shape[1] // 2
     c = torch.empty((B * T, d), dtype=h2d.dtype, device=h2d.device)
-    sums = torch.empty((2 * d,), dtype=torch.float64, device=h2d.device) if want_stats else None
+    sums = _sums(2 * d, h2d.device) if want_stats else None
     _lib.call("sarssl_dwglu_fwd", _p(h2d), _p(w), c_int(B), c_int(T), c_int(d), c_int(w.shape[-1]), _p(c), _p(sums), c_int(dt(h2d)),
               _stream())
     return (c, sums) if want_stats else c
@@ -743,7 +890,7 @@ def masked_mse_fwd(pred, x, idx_i32, mch_i32):
     """pred (B,T,F*4) -> f32[2] device tensor (loss, diff)."""
     B, _, F, T, _ = x.shape
     nm = idx_i32.shape[1]
-    sums = torch.empty((128,), dtype=torch.float64, device=x.device)
+    sums = _sums(128, x.device)
     out = torch.empty((2,), dtype=torch.float32, device=x.device)
     _lib.call("sarssl_masked_mse_fwd", _p(pred), _p(x), _p(idx_i32), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm), _p(sums),
               _p(out), c_int(dt(pred)), _stream())

@@ -184,6 +184,7 @@ class _PretrainFn(torch.autograd.Function):
     def backward(ctx, dloss, _dout, _dpred):
         net, saved = ctx.net, ctx.saved
         pred, x, mp_u8, ch_i32, nm, ds = ctx.aux
+        hip.sums_arena_reset(x.device)
         dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
         decat = engine.decoder_bwd(dpred, net.decoder, saved)
         engine.wgrad_join()                                    # (weight-gradient side stream: the bucket is about to be read)

@@ -107,7 +107,12 @@ def begin_forward(params):
     """Called once at every top-level forward entry (the pretraining autograd node, tape_apply): re-validates the bf16 shadow
     weights of the flat buffer(s) the parameters live in.  ``wt`` then trusts it for the rest of that forward / backward."""
     seen = None
+    first = True
     for p in params:
+        if first:
+            first = False
+            if p.is_cuda:
+                hip.sums_arena_reset(p.device)         # zeroed accumulators for this pass's reductions (hip._sums)
         flat = getattr(p, "_flat", None)
         if flat is not None and flat is not seen:
             flat._fresh = False

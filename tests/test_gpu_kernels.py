@@ -734,3 +734,34 @@ def test_dwglu_fused_kernels(B, T, d, dtp):
     dw = torch.ones((d, 31), dtype=torch.float32, device=dev)
     hip.dwglu_wgrad(dc, h, dw, B, T)
     check("dwglu.wgrad[%d,%d,%d,%s]" % (B, T, d, dtp), _relerr(dw - 1.0, w64.grad), 1e-4 if dtp == torch.float32 else 1e-2)
+
+
+def test_gemm_group_tn_equals_separate_products():
+    """Grouped weight-gradient launch (csrc/gemm.hip gemm_group_tn_kernel) vs the same products issued one by one and vs f64."""
+    from sar_ssl_amd import hip
+    torch.manual_seed(3)
+    K = 1024
+    shapes = [(512, 256), (256, 256), (2048, 512), (128, 128), (768, 256)]
+    items, refs, outs = [], [], []
+    for M, N in shapes:
+        dy = (torch.randn(K, M, device="cuda") * 0.1).to(torch.bfloat16)
+        x = torch.randn(K, N, device="cuda").to(torch.bfloat16)
+        out = torch.zeros(M, N, device="cuda") + 1.0                    # (+= semantics: starts non-zero)
+        items.append((dy, x, out, 4))
+        refs.append(1.0 + dy.double().t() @ x.double())
+        outs.append(out)
+    with hip.splitk_batched():
+        assert hip.gemm_group_tn(items)
+    sep = []
+    for dy, x, _, split in items:
+        o = torch.zeros(dy.shape[1], x.shape[1], device="cuda") + 1.0
+        hip.gemm(dy, x, a_kc=False, b_kc=False, M=dy.shape[1], N=x.shape[1], K=K, lda=dy.stride(0), ldb=x.stride(0), out=o, ldc=x.shape[1],
+                 split_k=split)
+        sep.append(o)
+    for o, r, s_ in zip(outs, refs, sep):
+        assert float((o.double() - r).abs().max() / r.abs().max()) < 2e-3
+        assert torch.equal(o, s_)                                        # same tiles, same split, same fold order
+    # ragged shape: refused, nothing launched
+    dy = torch.randn(K, 192, device="cuda").to(torch.bfloat16)
+    with hip.splitk_batched():
+        assert not hip.gemm_group_tn([(dy, dy, torch.zeros(192, 192, device="cuda"), 2), items[0]])
