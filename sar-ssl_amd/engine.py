@@ -92,7 +92,7 @@ _wg_blocks = []              # stack of pending-product lists (wgrad_block)
 def wgrad_no_fork(stream):
     """No companion stream for ``stream``: its weight-gradient work stays on it.  Needed for the second encoder's stream - a stream
     forked off a FORKED stream (i.e. waiting on an event recorded on a non-origin stream) crashes hipStreamEndCapture on ROCm 7.2
-    (tools/scratch/cap_repro2.py), so inside a capture only the origin stream gets a companion."""
+    (tools/capture_nested_fork_repro.py), so inside a capture only the origin stream gets a companion."""
     _wg_nofork.add(stream.cuda_stream)
 
 

@@ -1,3 +1,12 @@
+"""Minimal reproduction of a ROCm 7.2 stream-capture crash (no sar_ssl_amd code involved): a stream that joins a capture by waiting
+on an event recorded on another NON-origin stream ("a fork off a fork") makes hipStreamEndCapture segfault; any number of streams
+forked directly off the origin stream is fine.
+
+    python tools/capture_nested_fork_repro.py ws 3          # origin + one fork               -> OK
+    python tools/capture_nested_fork_repro.py ws+side 3     # origin + two forks              -> OK
+    python tools/capture_nested_fork_repro.py side+ws2 3    # origin -> side -> ws2 (nested)  -> segfault in capture_end
+
+Consequence for this package (engine.wgrad_no_fork): inside a captured step only the origin stream may have a companion stream."""
 import os, sys, torch
 flags = sys.argv[1].split("+")
 n = int(sys.argv[2])
