@@ -147,9 +147,17 @@ def main():
             step_eager()
         torch.cuda.synchronize()
         hip.profile_start()
-        for _ in range(10):
+        for _ in range(6):
+            step_eager()
+        prof2 = hip.profile_stop()                         # two encoder streams: durations stretched by the co-running stream
+        os.environ["SARSSL_TWO_STREAMS"] = "0"             # one stream: each launch has the GPU to itself, as in rocprof's
+        step_eager()                                       # per-kernel statistics of a single-stream run
+        torch.cuda.synchronize()
+        hip.profile_start()
+        for _ in range(6):
             step_eager()
         prof = hip.profile_stop()
+        os.environ["SARSSL_TWO_STREAMS"] = "1"
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -206,8 +214,10 @@ def main():
                        "global_batch": args.batch * world, "segment_samples": NSAMPLE, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma",
                          "kernel": "conv3x3_fwd_pp_kernel<false>, BN+ReLU-prologue launches (the forward 3x3 convolutions; events around "
-                                   "exactly these launches, in-step, the other encoder's stream running concurrently" +
-                                   ("" if graph is None else "; taken over 10 eager steps right after the timed graph replays") + ")",
+                                   "exactly these launches inside training steps" +
+                                   (", the other encoder's stream running concurrently" if graph is None else
+                                    "; a graph replay has no per-launch host events, so: 6 eager single-stream steps of the same run "
+                                    "right after the timed replays - two_stream_avg_ms = the same with both encoder streams") + ")",
                          "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "mfma_busy": mfma_busy, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
@@ -215,6 +225,8 @@ def main():
                          "dgrad_identity_avg_ms": round(msd / nd, 4) if nd else None,
                          "dgrad_bnred_avg_ms": round(msb / nb, 4) if nb else None,
                          "wgrad_avg_ms": round(msw / nw, 4) if nw else None,
+                         "two_stream_avg_ms": (round(prof2["conv3x3_fwd:bn_prologue"][1] / prof2["conv3x3_fwd:bn_prologue"][0], 4)
+                                               if graph is not None and prof2.get("conv3x3_fwd:bn_prologue", (0, 0))[0] else None),
                          "isolated_avg_ms": round(iso_ms, 4) if iso_ms else None,
                          "isolated_achieved": round(flop_per_launch / (iso_ms * 1e-3) / 1e12, 1) if iso_ms else None,
                          "end_to_end_frac": round(value / world * FLOP_PER_SEG_STEP / (PEAK_BF16_TFLOPS * 1e12), 4)},

@@ -275,9 +275,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     float* sC = (float*)smem;
     // residual (forward GEMMs) or saved pre-activation (activation-backward GEMMs) rows of a slice are requested one slice ahead, so
     // their latency hides behind the LDS transposition and the arithmetic of the previous slice instead of stalling every tile
-    const TC* Ex = (!EDGE && g.split_k <= 0 && !g.acc_out) ? (Rz && !Xa ? Rz : (Xa && !Rz ? Xa : nullptr)) : nullptr;
+    // (bf16 outputs only: with f32 outputs the two register sets did not survive hipcc's register allocation - they went to scratch)
+    const TC* Ex = (!EDGE && sizeof(TC) == 2 && g.split_k <= 0 && !g.acc_out) ? (Rz && !Xa ? Rz : (Xa && !Rz ? Xa : nullptr)) : nullptr;
     const long ldex = (Ex == Rz) ? g.ldr : g.ldc;
-    f8 ex[4], exn[4];
+    // (two register sets addressed with compile-time indices only: an array that is copied / passed by pointer here ends up in
+    //  scratch memory - 144 bytes per lane of private memory traffic per tile, which tripled the HBM writes of the residual /
+    //  activation-backward GEMMs in the round-2 counters)
+    f8 exa[4], exb[4];
     auto load_ex = [&](int i, f8 (&dst)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -286,20 +290,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             dst[k] = ld8(Ex + (long)m * ldex + n);
         }
     };
-    if (Ex) load_ex(0, exn);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    const bool has_ex = !EDGE && sizeof(TC) == 2 && Ex != nullptr;
+    if (has_ex) load_ex(0, exa);
+    auto slice = [&](const int i, f8 (&cur)[4], f8 (&nxt)[4]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
                 *(float4*)&sC[(wm * 32 + (lane & 31)) * PC + wn * 64 + j * 32 + 8 * gq + 4 * (lane >> 5)] =
                     make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
-        if (Ex) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ex[k] = exn[k];
-            if (i + 1 < FM) load_ex(i + 1, exn);
-        }
+        if (has_ex && i + 1 < FM) load_ex(i + 1, nxt);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -310,10 +310,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             const float4 a0 = *(const float4*)&sC[r * PC + ch * 8], a1 = *(const float4*)&sC[r * PC + ch * 8 + 4];
             v.v[0] = g.alpha * a0.x; v.v[1] = g.alpha * a0.y; v.v[2] = g.alpha * a0.z; v.v[3] = g.alpha * a0.w;
             v.v[4] = g.alpha * a1.x; v.v[5] = g.alpha * a1.y; v.v[6] = g.alpha * a1.z; v.v[7] = g.alpha * a1.w;
-            epilogue8<TC, EDGE>(g, v, z, m, n, C, Rz, P, Xa, W, Wp, bias8, vec_ok, inv_keep, Ex ? &ex[k] : nullptr);
+            epilogue8<TC, EDGE>(g, v, z, m, n, C, Rz, P, Xa, W, Wp, bias8, vec_ok, inv_keep, has_ex, cur[k]);
         }
         if (i + 1 < FM) __syncthreads();
-    }
+    };
+    slice(0, exa, exb);
+    if constexpr (FM >= 2) slice(1, exb, exa);
+    if constexpr (FM >= 4) { slice(2, exa, exb); slice(3, exb, exa); }
 }
 
 template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool DB>

@@ -27,7 +27,7 @@ struct GemmArgs {
 template <typename TC, bool EDGE>
 __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m, int n, TC* __restrict__ C, const TC* __restrict__ Rz,
                                           TC* __restrict__ P, const TC* __restrict__ Xa, float* __restrict__ W, float* __restrict__ Wp,
-                                          const float (&bias8)[8], bool vec_ok, float inv_keep, const f8* pre) {
+                                          const float (&bias8)[8], bool vec_ok, float inv_keep, const bool has_pre, const f8& pre) {
     const int nvalid = EDGE ? min(8, g.N - n) : 8;
     const bool vec = EDGE ? (vec_ok && nvalid == 8) : true;
     if (g.split_k > 0) {                                 // raw partial for the split-K second stage
@@ -72,7 +72,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m,
     }
     if (Xa) {                                            // dX epilogue: times act'(saved pre-activation)
         f8 h;
-        if (pre) h = *pre;
+        if (has_pre) h = pre;
         else if (vec) h = ld8(Xa + co);
         else {
 #pragma unroll
@@ -98,7 +98,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m,
     if (Rz) {
         const long ro = (long)m * g.ldr + n;
         if (vec) {
-            const f8 rr = pre ? *pre : ld8(Rz + ro);
+            const f8 rr = has_pre ? pre : ld8(Rz + ro);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] += g.res_scale * rr.v[e];
         } else {

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             v.v[0] = alpha_q * a0.x; v.v[1] = alpha_q * a0.y; v.v[2] = alpha_q * a0.z; v.v[3] = alpha_q * a0.w;
             v.v[4] = alpha_q * a1.x; v.v[5] = alpha_q * a1.y; v.v[6] = alpha_q * a1.z; v.v[7] = alpha_q * a1.w;
             // (workspace pointers passed as runtime values: literal nullptrs here crash hipcc 7.2's SimplifyCFG at -O2 and above)
-            epilogue8<TC, EDGE>(g, v, 0, m, n, C, Rz, P, Xa, g.acc_ws, g.acc_ws, bias8, vec_ok, inv_keep, nullptr);
+            epilogue8<TC, EDGE>(g, v, 0, m, n, C, Rz, P, Xa, g.acc_ws, g.acc_ws, bias8, vec_ok, inv_keep, false, v);
         }
         if (i == 0) __syncthreads();
     }
