@@ -170,6 +170,19 @@ def _wgrad_gemm(dy, x, g2, split):
              split_k=split)
 
 
+def _wgrad_split(M, N, K, grouped):
+    """Number of K-slices (M = rows of dy / x = the contraction length) of the weight-gradient product dy[M,N]^T x[M,K].  Multiples
+    of 8 select the slice-major workgroup order of csrc/gemm.hip (each XCD's L2 reads one eighth of both operands once instead of
+    the whole second operand).  Inside a grouped launch the other products of the block fill the chip, so 8 slices of >= 8 K-tiles
+    are enough and keep the partial-sum traffic (2 x slices x N x K x 4 bytes) small; alone, ~2 workgroups per CU."""
+    if grouped and M >= 4096:
+        return 8
+    tiles = ((N + 255) // 256) * ((K + 127) // 128)                          # 256 x 128 output tiles (csrc/gemm.hip)
+    split = max(1, min((M + 511) // 512, (512 + tiles - 1) // tiles))       # ~2 workgroups per CU, >= 8 K-tiles each
+    split = max(1, min(split, (1 << 23) // (N * K)))                         # partial-sum workspace <= 32 MB (reduce pass cost)
+    return split // 8 * 8 if split >= 8 else split
+
+
 def mm_tn_acc(dy, x, gW, side=True):
     """gW[N,K] += dy[M,N]^T @ x[M,K]   (weight gradient of nn.Linear, f32 accumulate into the grad buffer)."""
     M, N = dy.shape
@@ -177,10 +190,9 @@ def mm_tn_acc(dy, x, gW, side=True):
     if _ABLATE_WGRAD:
         return
     g2 = gW.view(N, K)
-    tiles = ((N + 255) // 256) * ((K + 127) // 128)                          # 256 x 128 output tiles (csrc/gemm.hip)
-    split = max(1, min((M + 511) // 512, (512 + tiles - 1) // tiles))       # ~2 workgroups per CU, >= 8 K-tiles each
-    split = max(1, min(split, (1 << 23) // (N * K)))                         # partial-sum workspace <= 32 MB (reduce pass cost)
-    if side and _wg_blocks and RT.replay is None and (_WGRAD_MODE == "block" or (_WGRAD_GROUP and RT.dtype == torch.bfloat16)):
+    grouped = side and _wg_blocks and RT.replay is None and (_WGRAD_MODE == "block" or (_WGRAD_GROUP and RT.dtype == torch.bfloat16))
+    split = _wgrad_split(M, N, K, grouped)
+    if grouped:
         _wg_blocks[-1].append((dy, x, g2, split))            # enqueued when the block's backward ends (wgrad_block)
     elif side and _WGRAD_MODE == "fork":
         with _WgradSide(dy, x):

@@ -65,7 +65,7 @@ def main():
     gemm_group(6, "gemm ffn dW TN d=512 (split-K)", 4 * d, d, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8)
     gemm_group(7, "gemm decoder1 NT (768->3072, relu)", Mr, 3072, 768, bias=bias[:3072], act=1)
     gemm_group(8, "gemm decoder2 NT (3072->1024)", Mr, 1024, 3072, bias=bias[:1024])
-    gemm_group(9, "gemm decoder2 dW TN (split-K)", 1024, 3072, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=2)
+    gemm_group(9, "gemm decoder2 dW TN (split-K 8, slice-major)", 1024, 3072, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8)
     gemm_group(10, "gemm patch NT (1024->512)", Mr, 512, 1024)
     gemm_group(11, "gemm ffn1 NT d=256", Mr, 1024, 256, bias=bias[:1024], act=2)
     gemm_group(12, "gemm ffn2 NT d=256", Mr, 256, 1024, bias=bias[:256])
