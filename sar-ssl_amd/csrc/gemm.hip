@@ -57,28 +57,21 @@ __device__ __forceinline__ void tile_load(const T* __restrict__ p, long ld, int 
         } else regs[i] = load_chunk(q, part);
     }
 }
-// SWZ ([k][row] tiles of the double-buffered kernel): no row padding (pitch = ROWS elements, a multiple of 256 bytes, so every k-row
-// starts on bank 0); instead the 16-byte chunk index is XORed with 4 * (k & 3), which moves the 64 bytes a transpose read takes from
-// k-rows k .. k+3 onto four different bank quarters - the same conflict-free pattern as the 64-byte padding, 20 % less LDS.
-template <bool KC, int ROWS, bool SWZ = false>
+template <bool KC, int ROWS>
 __device__ __forceinline__ void tile_store(uint16_t* __restrict__ s, int tid, const uint4 (&regs)[ROWS / 32]) {
-    constexpr int CPR = ROWS / 8, KPP = 256 / CPR, PT = SWZ ? ROWS : ROWS + 32;
+    constexpr int CPR = ROWS / 8, KPP = 256 / CPR, PT = ROWS + 32;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
         if (KC) *(uint4*)&s[((tid >> 3) + 32 * i) * PITCH + (tid & 7) * 8] = regs[i];
-        else {
-            const int k = tid / CPR + KPP * i, c = tid % CPR;
-            *(uint4*)&s[k * PT + ((SWZ ? (c ^ ((k & 3) << 2)) : c) << 3)] = regs[i];
-        }
+        else *(uint4*)&s[(tid / CPR + KPP * i) * PT + (tid % CPR) * 8] = regs[i];
     }
 }
 
 // MFMA fragment (8 consecutive k for row r0 + (lane&31)) from a [k][row] tile (pitch PT) via two transpose reads
-template <int PT, bool SWZ = false>
+template <int PT>
 __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, int lane) {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
-    int col = r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
-    if (SWZ) col ^= ((lane & 15) >> 2) << 5;           // chunk index ^ 4 * (k & 3): k & 3 == (lane & 15) >> 2 for both halves (kbase % 4 == 0)
+    const int col = r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
     union { s16x4 v[2]; bf16x8 b; } u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -88,23 +81,18 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
     return u.b;
 }
 
-// DB (FM = 2): two LDS buffers and two register stages.  With one buffer and one tile of prefetch a K-tile costs a full memory round
-// trip - the loads of tile k+1 are only issued behind the barrier of tile k and must have landed before the next store - which
-// measured 0.7-0.8 us per K-tile against 0.25 us of MFMA (ffn2 d=256: 22 us for 16 tiles, qkv d=256: 12 us for 4).  Here the loads
-// of tile k+2 are issued before the MFMAs of tile k, tile k+1 is written to the OTHER buffer behind those MFMAs, and there is one
-// barrier per tile: a load has two MFMA phases (plus the co-resident workgroup's) to land.
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool DB>
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, const int bid_y, const int bid_z, const int grid_x,
                                           const int grid_y, const int grid_z) {
-    static_assert(!DB || FM == 2, "double-buffered variant: 128 x 128 tiles only");
     constexpr int BM = 64 * FM;
-    constexpr int PTA = DB ? BM : BM + 32, PTB = DB ? BN : BN + 32;
+    constexpr int PTA = BM + 32, PTB = BN + 32;
     constexpr int A_ELEMS = AKC ? BM * PITCH : BK * PTA;
     constexpr int B_ELEMS = BKC ? BN * PITCH : BK * PTB;
     constexpr int STAGE = A_ELEMS + B_ELEMS;
     constexpr int PC = BN + 4;                                  // f32 staging pitch of the epilogue (conflict-free 16-byte LDS writes)
     constexpr int EPI_ELEMS = 64 * PC * 2;                      // 64 x 132 f32, in 16-bit units
-    constexpr int LDS_ELEMS = (DB ? 2 : 1) * STAGE > EPI_ELEMS ? (DB ? 2 : 1) * STAGE : EPI_ELEMS;
+    constexpr int LDS_ELEMS = STAGE > EPI_ELEMS ? STAGE : EPI_ELEMS;      // (a double-buffered variant - two LDS stages, two register
+                                                                           //  stages - measured neutral inside the step: DESIGN.md 4.2)
     __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];    // FM = 2: 2 x 32-37 KiB (2 workgroups / CU), FM = 4: 56 KiB (2 / CU)
     uint16_t* sA = smem;
     uint16_t* sB = smem + A_ELEMS;
@@ -174,12 +162,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 if (AKC) fa[i] = *(const bf16x8*)&tA[(wm * (FM * 32) + i * 32 + (lane & 31)) * PITCH + koff];
-                else fa[i] = frag_tr<PTA, DB>(tA, kk * 16, wm * (FM * 32) + i * 32, lane);
+                else fa[i] = frag_tr<PTA>(tA, kk * 16, wm * (FM * 32) + i * 32, lane);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (BKC) fb[j] = *(const bf16x8*)&tB[(wn * 64 + j * 32 + (lane & 31)) * PITCH + koff];
-                else fb[j] = frag_tr<PTB, DB>(tB, kk * 16, wn * 64 + j * 32, lane);
+                else fb[j] = frag_tr<PTB>(tB, kk * 16, wn * 64 + j * 32, lane);
             }
         };
         auto mfmas = [&](const bf16x8 (&fa)[FM], const bf16x8 (&fb)[2]) {
@@ -204,54 +192,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
         }
     };
 
-    if constexpr (DB) {
-        uint4 ra[2][BM / 32], rb[2][BN / 32];
-        uint16_t* const sA1 = smem + STAGE;
-        uint16_t* const sB1 = sA1 + A_ELEMS;
-        const int ntile = (k_end - k_begin + BK - 1) / BK;
-        tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra[0]);
-        tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb[0]);
-        {
-            const bool more = ntile > 1;
-            pa += more ? stepA : 0; pb += more ? stepB : 0;
-            const int kt = k_begin + (more ? BK : 0);
-            tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, kt, g.M, k_end, g.partA, tid, ra[1]);
-            tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, kt, g.N, k_end, g.partB, tid, rb[1]);
-        }
-        tile_store<AKC, BM, true>(sA, tid, ra[0]);
-        tile_store<BKC, BN, true>(sB, tid, rb[0]);
-        __syncthreads();
-        // The prefetch loads are issued UNCONDITIONALLY (past the last tile the pointers simply stop advancing and the tile is fetched
-        // again, unused): a load under a runtime condition makes hipcc wait for vmcnt(0) before every LDS store - it cannot count
-        // the loads that may not have been issued - which serialises the very loads this loop is meant to keep in flight.
-        for (int t = 0; t < ntile; t += 2) {
-            // even tile t in buffer 0; registers [1] hold tile t+1, registers [0] are free
-            {
-                const bool more = t + 2 < ntile;
-                pa += more ? stepA : 0; pb += more ? stepB : 0;
-                const int kt = k_begin + (more ? t + 2 : ntile - 1) * BK;
-                tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, kt, g.M, k_end, g.partA, tid, ra[0]);
-                tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, kt, g.N, k_end, g.partB, tid, rb[0]);
-            }
-            mfma_phase(sA, sB);
-            tile_store<AKC, BM, true>(sA1, tid, ra[1]);       // (t + 1 == ntile: a stale tile nobody reads)
-            tile_store<BKC, BN, true>(sB1, tid, rb[1]);
-            __syncthreads();
-            if (t + 1 >= ntile) break;
-            // odd tile t+1 in buffer 1; registers [0] hold tile t+2, registers [1] are free
-            {
-                const bool more = t + 3 < ntile;
-                pa += more ? stepA : 0; pb += more ? stepB : 0;
-                const int kt = k_begin + (more ? t + 3 : ntile - 1) * BK;
-                tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, kt, g.M, k_end, g.partA, tid, ra[1]);
-                tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, kt, g.N, k_end, g.partB, tid, rb[1]);
-            }
-            mfma_phase(sA1, sB1);
-            tile_store<AKC, BM, true>(sA, tid, ra[0]);
-            tile_store<BKC, BN, true>(sB, tid, rb[0]);
-            __syncthreads();
-        }
-    } else {
+    {
         uint4 ra[BM / 32], rb[BN / 32];
         tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
         tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
@@ -329,9 +270,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     if constexpr (FM >= 4) { slice(2, exa, exb); slice(3, exb, exa); }
 }
 
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool DB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FM == 4 || DB) ? 2 : 3))) void gemm_kernel(GemmArgs g) {
-    gemm_body<TA, TB, TC, AKC, BKC, FM, EDGE, DB>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_kernel(GemmArgs g) {
+    gemm_body<TA, TB, TC, AKC, BKC, FM, EDGE>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
 }
 
 // ---- grouped launch: up to GROUP_MAXP independent split-K weight-gradient products (A = dY [K][M], B = X [K][N], both with the
@@ -352,7 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     const int gx = a.gx[q], gy = a.gy[q], ns = a.p[q].split_k;
     if (local >= gx * gy * ns) return;               // (first[] is padded to multiples of 8: linear id % 8 stays the XCD inside a product)
     const int bz = local / (gx * gy), rem = local - bz * (gx * gy);
-    gemm_body<bf16, bf16, float, false, false, 2, false, false>(a.p[q], rem % gx, rem / gx, bz, gx, gy, ns);
+    gemm_body<bf16, bf16, float, false, false, 2, false>(a.p[q], rem % gx, rem / gx, bz, gx, gy, ns);
 }
 
 // C[z][m][n] += sum_s ws[z][s][m][n]   (second stage of split-K weight-gradient GEMMs; C is f32)
@@ -420,22 +361,26 @@ extern "C" int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsp
     return 0;
 }
 
-template <typename TA, typename TB, typename TC, int FM, bool EDGE, bool DB = false>
+template <typename TA, typename TB, typename TC, int FM, bool EDGE>
 static void launch_fm(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
-    if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
-    else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
-    else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
-    else gemm_kernel<TA, TB, TC, false, false, FM, EDGE, DB><<<grid, 256, 0, st>>>(g);
+    if (a_kc && b_kc) gemm_kernel<TA, TB, TC, true, true, FM, EDGE><<<grid, 256, 0, st>>>(g);
+    else if (a_kc && !b_kc) gemm_kernel<TA, TB, TC, true, false, FM, EDGE><<<grid, 256, 0, st>>>(g);
+    else if (!a_kc && b_kc) gemm_kernel<TA, TB, TC, false, true, FM, EDGE><<<grid, 256, 0, st>>>(g);
+    else gemm_kernel<TA, TB, TC, false, false, FM, EDGE><<<grid, 256, 0, st>>>(g);
 }
 
 // Tile choice: 256 x 128 tiles (FM = 4) halve the staged bytes and barriers per MFMA but also the number of workgroups; they are
 // used when the grid still has at least ~one workgroup per CU, otherwise 128 x 128 (FM = 2).  big = allowed for this dtype combo.
 static int pick_fm(const GemmArgs& g, int nbatch, bool big) {
-    static const int force = getenv("SARSSL_GEMM_FM") ? atoi(getenv("SARSSL_GEMM_FM")) : 0;        // A/B experiments only
+    static const int force = getenv("SARSSL_GEMM_FM") ? atoi(getenv("SARSSL_GEMM_FM")) : 0;        // A/B experiments only (-1: never FM = 1)
     if (!big) return 2;
-    if (force == 2 || force == 4) return force;
+    if (force == 1 || force == 2 || force == 4) return force;
     const long nsplit = g.split_k > 0 ? g.split_k : 1;
     const long wg4 = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN) * nbatch * nsplit;
+    // 64 x 128 tiles (FM = 1) when 128 x 128 tiles give at most ~one workgroup per CU (N <= 256 at M = 16384): nothing else on the
+    // CU hides a K-tile's memory round trip then (0.7-0.8 us per K-tile measured against 0.25 us of MFMA)
+    const long wg2 = (long)((g.M + 127) / 128) * ((g.N + BN - 1) / BN) * nbatch * nsplit;
+    if (force != -1 && g.split_k <= 0 && g.M >= 128 && wg2 <= (long)sarssl_cu_count() + 32) return 1;
     const int k_len = g.split_k > 0 ? g.k_per_split : g.K;
     // measured on MI355X (tools/bench_kernels.py, tools/gemm_diag.py, M = 16384): the large tile wins from ~2 workgroups per CU and
     // K >= 768 on (decoder 3072 x 768 / 1024 x 3072: -4 ... -15 %); with one workgroup per CU (N = 512) or short K it loses 5-20 %
@@ -458,15 +403,13 @@ static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, int nbatch, hipS
             return 0;
         }
     }
-    // double-buffered variant (2 workgroups / CU, two K-tiles of loads in flight) for grids of at most ~2 workgroups per CU, where
-    // nothing else hides the memory round trip of a K-tile.  Measured alone: ffn2 / dX d=256 22 -> 19 us, dW d=256 35 -> 31 us, but
-    // ffn1 d=512 64 -> 72 us (2 instead of 3 workgroups per CU) - and inside the training step, where the other encoder's stream
-    // already fills the gaps, 14.08 vs 14.01 ms: kept as an opt-in (SARSSL_GEMM_DB=1) for single-stream use
-    static const int force_db = getenv("SARSSL_GEMM_DB") ? atoi(getenv("SARSSL_GEMM_DB")) : -1;        // A/B experiments only
-    const long nwg = (long)grid.x * grid.y * grid.z;
-    const bool db = BIG && !edge && force_db > 0 && nwg <= 2L * sarssl_cu_count() + 64;      // opt-in: neutral inside the step (see above)
     if constexpr (BIG) {
-        if (db) { launch_fm<TA, TB, TC, 2, false, true>(g, a_kc, b_kc, grid, st); SARSSL_CHECK_LAUNCH("sarssl_gemm"); return 0; }
+        if (fm == 1) {
+            if (edge) launch_fm<TA, TB, TC, 1, true>(g, a_kc, b_kc, grid, st);
+            else launch_fm<TA, TB, TC, 1, false>(g, a_kc, b_kc, grid, st);
+            SARSSL_CHECK_LAUNCH("sarssl_gemm");
+            return 0;
+        }
     }
     if (edge) launch_fm<TA, TB, TC, 2, true>(g, a_kc, b_kc, grid, st);
     else launch_fm<TA, TB, TC, 2, false>(g, a_kc, b_kc, grid, st);
