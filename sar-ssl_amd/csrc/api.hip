@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -92,3 +93,8 @@ extern "C" int sarssl_zero_arena(const void* base, long bytes) {
     return 0;
 }
 bool sarssl_prezeroed(const void* p) { return p && (const char*)p >= g_zero_lo && (const char*)p < g_zero_hi; }
+
+int sarssl_mfma_prio() {
+    static const int v = getenv("SARSSL_MFMA_PRIO") ? atoi(getenv("SARSSL_MFMA_PRIO")) : 2;
+    return v;
+}

@@ -47,6 +47,7 @@ struct ConvArgs {
     // runs on dy = gamma*rstd*(g - s1/N - xhat*s2/N), g = dz*relu'(bn(y)), formed while staging from (dz, in2 = y) - the
     // stand-alone normalisation pass (cl_bn_bwd_apply: read 2, write 1 tensor of 537 MB) disappears
     const void* in2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
+    int prio;           // != 0: raise the wave's issue priority for its MFMA phase (s_setprio), see sarssl_mfma_prio()
 };
 
 // per-thread constants of the BatchNorm-backward input transform for channels c0 .. c0+7: dy = cA*g + cB*y + cC
@@ -509,6 +510,9 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) xf[buf][j] = *(const bf16x8*)(sX + laneX[kw][kc] + ((kh + j) * PHC) * 64);
             };
+            // the wave that is on the matrix cores gets issue priority over the other half's wave on the same SIMD (which is staging
+            // its next tile / draining its outputs on the VALU): its MFMAs and fragment reads are never queued behind that work
+            if (a.prio) __builtin_amdgcn_s_setprio(3);
             fetch(0, 0);
 #pragma unroll
             for (int s = 0; s < 36; ++s) {
@@ -521,6 +525,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
             }
+            if (a.prio) __builtin_amdgcn_s_setprio(0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // retire the prefetch before any output store is issued
         half_barrier(cnt, epoch, lane);                        // the half is done reading its input tile
@@ -891,6 +896,7 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16, "sarssl_conv3x3_fwd(fused statistics: bf16 storage only)");
     if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
+    a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
     a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
     a.in = in; a.w = w; a.out = out; a.acc_ws = nullptr; a.acc_in = 0; a.acc_out = 0;

@@ -178,6 +178,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         };
         bf16x8 fa0[FM], fb0[2], fa1[FM], fb1[2];
+        if (g.prio) __builtin_amdgcn_s_setprio(2);      // over the co-resident workgroups' waves that are staging / storing
         load_frags(0, fa0, fb0);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; kk += 2) {
@@ -190,6 +191,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             mfmas(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (g.prio) __builtin_amdgcn_s_setprio(0);
     };
 
     {
@@ -437,7 +439,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.alpha = alpha; g.out_scale = out_scale; g.bias = bias; g.act = act;
     g.resid = resid; g.ldr = ldr; g.sR0 = sR0; g.sR1 = sR1; g.res_scale = res_scale;
     g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
-    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt();
+    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K;
     g.row_shift = 0;
     if (c_row_shift) {
@@ -518,7 +520,7 @@ extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, 
         g.alpha = 1.f; g.out_scale = 1.f; g.bias = nullptr; g.act = 0;
         g.resid = nullptr; g.ldr = 0; g.sR0 = g.sR1 = 0; g.res_scale = 0.f;
         g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
-        g.p_drop = 0.f; g.seed = 0; g.salt = nullptr;
+        g.p_drop = 0.f; g.seed = 0; g.salt = nullptr; g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
         g.split_k = ns; g.k_per_split = per; g.row_shift = 0;
         a.gx[q] = (N[q] + BN - 1) / BN; a.gy[q] = (M[q] + 127) / 128;
         a.first[q] = total; total += (a.gx[q] * a.gy[q] * ns + 7) / 8 * 8;

@@ -17,6 +17,7 @@ struct GemmArgs {
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
     float p_drop; unsigned long long seed; const unsigned long long* salt;   // salt: device-resident seed addend (graph replay) or null
+    int prio;                   // != 0: waves raise their issue priority during the MFMA phase of a K-tile (s_setprio)
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
     int row_shift;              // != 0 (= T, with M = N = ldc = T): row m of every batch matrix is stored m + 1 - T elements further
                                 // (elements falling before the matrix are dropped): the relative-position shift of the reference
