@@ -48,6 +48,9 @@ struct ConvArgs {
     // stand-alone normalisation pass (cl_bn_bwd_apply: read 2, write 1 tensor of 537 MB) disappears
     const void* in2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
     int prio;           // != 0: raise the wave's issue priority for its MFMA phase (s_setprio), see sarssl_mfma_prio()
+#ifdef CONV_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
 // per-thread constants of the BatchNorm-backward input transform for channels c0 .. c0+7: dy = cA*g + cB*y + cC
@@ -105,6 +108,17 @@ __device__ __forceinline__ Chunk<T> load_chunk(const T* p, bool valid) {
         }
     }
     return c;
+}
+
+// Prefetch load of the 8 channels at c8 of pixel (b, f, t) with the coordinates CLAMPED into the image: always a valid address, so
+// the load is unconditional.  A load under a runtime condition is a serialised load - hipcc branches around it and waits for it before
+// issuing the next one: cycle stamps (tools/conv_stamps.py) showed 4.3 k cycles per tile for "issuing" 11 predicated loads, i.e. 11
+// back-to-back memory round trips.  Out-of-image chunks are zeroed when the tile is written to LDS (xform_chunk's `valid`).
+template <typename T>
+__device__ __forceinline__ Chunk<T> load_chunk_clamped(const T* __restrict__ base, int b, int f, int t, int F, int Tn, int c8) {
+    f = min(max(f, 0), F - 1);
+    t = min(max(t, 0), Tn - 1);
+    return load_chunk<T>(base + (((long)b * F + f) * Tn + t) * 64 + c8, true);
 }
 
 // prologue + (split) conversion to 8 bf16
@@ -196,16 +210,11 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
     auto issue_loads = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
         const int t = tc.t0 - 1 + pc;
-        const bool tv = t >= 0 && t < Tn;
-        const T* base = in + (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
 #pragma unroll
-        for (int i = 0; i < HR; ++i) {
-            const int f = tc.f0 - 1 + i;
-            regs[i] = load_chunk<T>(base + (long)i * Tn * 64, tv && f >= 0 && f < F);
-        }
+        for (int i = 0; i < HR; ++i) regs[i] = load_chunk_clamped<T>(in, tc.b, tc.f0 - 1 + i, t, F, Tn, cch * 8);
         {
-            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
-            regs[HR] = load_chunk<T>(in + (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8, tid < 160 && f >= 0 && f < F && te < Tn);
+            const int hr = pc >> 1, te = tc.t0 + TCOL - 1 + (pc & 1);       // (threads >= 160: an unused, harmless extra chunk)
+            regs[HR] = load_chunk_clamped<T>(in, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
         }
     };
     auto write_tile = [&](int tile) {
@@ -375,6 +384,16 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
 // tiles; the halves only synchronise among their own four waves (an LDS arrival counter - s_barrier would couple all eight).
 // The SIMD arbiter favours the older wave, so the halves drift out of phase by themselves: while one is on the matrix cores the
 // other stages its next tile / drains its outputs.
+#ifdef CONV_STAMPS
+// per-phase cycle stamps of workgroup 0 (tools/conv_stamps.py; compiled into a separate probe library only)
+// (the buffer pointer travels as a kernel argument: fetching it from a __device__ global would put a load + vmcnt(0) into every stamp
+//  and serialise exactly the prefetch loads / output stores the stamps are meant to time)
+static unsigned long long* g_conv_stamps_host = nullptr;
+extern "C" int sarssl_conv_stamp_buffer(void* p) { g_conv_stamps_host = (unsigned long long*)p; return 0; }
+#define STAMP(k) do { if (blockIdx.x == 0 && it < 8 && lane == 0 && a.stamps) a.stamps[(wave * 8 + it) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 #define PTC 32
 #define PHC (PTC + 2)
 #define PX_ELEMS (HR * PHC * 64)                   // 21760 bf16 per half
@@ -398,7 +417,10 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     __shared__ float sStats[128];
     __shared__ float sAff[256];
     __shared__ unsigned sSync[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform ids as SCALARS (hipcc cannot prove tid >> 6 uniform): the tile coordinates (two integer divisions), row bases and
+    // validity tests derived from them then live on the scalar unit instead of costing ~250 vector instructions per tile
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, hw = wave & 3, htid = tid & 255;
     const int F = a.F, Tn = a.T;
     const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + PTC - 1) / PTC;
@@ -443,26 +465,25 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     Chunk<T> regs[X_ITERS];
     Chunk<T> regs2[BNIN ? X_ITERS : 1];            // BNIN: the matching pre-BatchNorm activations
     const int pc = htid >> 3;
-    auto issue_loads = [&](int tile) {
-        const TileCoord tc = coord(tile);
-        const int t = tc.t0 - 1 + pc;
-        const bool tv = t >= 0 && t < Tn;
-        const long off = (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
+    // addresses: row bases are scalar (tile coordinates are wave-uniform), each thread adds ONE byte offset (its clamped frame and chunk)
+    auto issue_loads = [&](const TileCoord tc) {
+        const int tcl = min(max(tc.t0 - 1 + pc, 0), Tn - 1);
+        const unsigned voff = (unsigned)(tcl * 64 + cch * 8) * 2u;
+        const long img = (long)tc.b * F;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
-            const int f = tc.f0 - 1 + i;
-            regs[i] = load_chunk<T>(in + off + (long)i * Tn * 64, tv && f >= 0 && f < F);
-            if (BNIN) regs2[i] = load_chunk<T>(in2 + off + (long)i * Tn * 64, tv && f >= 0 && f < F);
+            const int f = min(max(tc.f0 - 1 + i, 0), F - 1);                      // (clamped: unconditional loads, see load_chunk_clamped)
+            const long rowb = (img + f) * (long)Tn * 128;                        // bytes
+            regs[i].u = *(const uint4*)((const char*)in + rowb + voff);
+            if (BNIN) regs2[i].u = *(const uint4*)((const char*)in2 + rowb + voff);
         }
         {
-            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
-            const long oe = (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8;
-            regs[HR] = load_chunk<T>(in + oe, htid < 160 && f >= 0 && f < F && te < Tn);
-            if (BNIN) regs2[HR] = load_chunk<T>(in2 + oe, htid < 160 && f >= 0 && f < F && te < Tn);
+            const int hr = pc >> 1, te = tc.t0 + PTC - 1 + (pc & 1);        // (threads >= 160: an unused, harmless extra chunk)
+            regs[HR] = load_chunk_clamped<T>(in, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
+            if (BNIN) regs2[HR] = load_chunk_clamped<T>(in2, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
         }
     };
-    auto write_tile = [&](int tile) {
-        const TileCoord tc = coord(tile);
+    auto write_tile = [&](const TileCoord tc) {
         const int t = tc.t0 - 1 + pc;
         const bool tv = t >= 0 && t < Tn;
 #pragma unroll
@@ -483,15 +504,21 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     unsigned epoch = 0;
     unsigned* cnt = &sSync[half];
     const int nrounds = (npairs + gridDim.x - 1) / gridDim.x;
-    if (tile_of(0) < ntiles) issue_loads(tile_of(0));
+    int tile = tile_of(0);
+    TileCoord tc = coord(tile < ntiles ? tile : 0);
+    if (tile < ntiles) issue_loads(tc);
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0) (see conv3x3_fwd_kernel)
     for (int it = 0; it < nrounds; ++it) {
-        const int tile = tile_of(it);
         if (tile >= ntiles) break;                 // (all four waves of the half take the same branch)
-        write_tile(tile);
+        STAMP(0);
+        write_tile(tc);
+        STAMP(1);
         half_barrier(cnt, epoch, lane);
+        STAMP(2);
         const int next = (it + 1 < nrounds) ? tile_of(it + 1) : ntiles;
-        if (next < ntiles) issue_loads(next);
+        const TileCoord tcn = coord(next < ntiles ? next : 0);
+        if (next < ntiles) issue_loads(tcn);
+        STAMP(3);
 
         f32x16 acc[2][2];                          // [co half][row]
 #pragma unroll
@@ -527,9 +554,11 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             }
             if (a.prio) __builtin_amdgcn_s_setprio(0);
         }
+        STAMP(4);
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // retire the prefetch before any output store is issued
+        STAMP(5);
         half_barrier(cnt, epoch, lane);                        // the half is done reading its input tile
-        const TileCoord tc = coord(tile);
+        STAMP(6);
         uint16_t* stg = sX + hw * (64 * 64);                   // this wave's [64 px][64 co] slice (px = row * 32 + column)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -570,6 +599,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         if (BNRED) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        STAMP(7);
         float ssum[8], ssq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
@@ -604,6 +634,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                 }
             }
         }
+        STAMP(8);
         if (BNRED || a.stats) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -619,7 +650,10 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                 }
             }
         }
+        STAMP(9);
         half_barrier(cnt, epoch, lane);                        // slices drained before the next tile overwrites the buffer
+        STAMP(10);
+        tile = next; tc = tcn;
     }
     __syncthreads();
     if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
@@ -719,23 +753,17 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     auto issue_loads = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
         const int t = tc.t0 - 1 + pc;
-        const bool tv = t >= 0 && t < Tn;
-        const T* zb = zin + (((long)tc.b * F + (tc.f0 - 1)) * Tn + t) * 64 + cch * 8;
 #pragma unroll
-        for (int i = 0; i < HR; ++i) {
-            const int f = tc.f0 - 1 + i;
-            rz[i] = load_chunk<T>(zb + (long)i * Tn * 64, tv && f >= 0 && f < F);
-        }
+        for (int i = 0; i < HR; ++i) rz[i] = load_chunk_clamped<T>(zin, tc.b, tc.f0 - 1 + i, t, F, Tn, cch * 8);
         {
-            const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + TCOL - 1 + (pc & 1);
-            rz[HR] = load_chunk<T>(zin + (((long)tc.b * F + f) * Tn + te) * 64 + cch * 8, tid < 160 && f >= 0 && f < F && te < Tn);
+            const int hr = pc >> 1, te = tc.t0 + TCOL - 1 + (pc & 1);       // (threads >= 160: an unused, harmless extra chunk)
+            rz[HR] = load_chunk_clamped<T>(zin, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
         }
         const int ty = tc.t0 + pc;
-        const long oy = (((long)tc.b * F + tc.f0) * Tn + ty) * 64 + cch * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            ry[i] = load_chunk<T>(dy + oy + (long)i * Tn * 64, tc.f0 + i < F && ty < Tn);
-            if (BNIN) ry2[i] = load_chunk<T>(dy2 + oy + (long)i * Tn * 64, tc.f0 + i < F && ty < Tn);
+            ry[i] = load_chunk_clamped<T>(dy, tc.b, tc.f0 + i, ty, F, Tn, cch * 8);
+            if (BNIN) ry2[i] = load_chunk_clamped<T>(dy2, tc.b, tc.f0 + i, ty, F, Tn, cch * 8);
         }
     };
     auto write_tile = [&](int tile) {
@@ -896,6 +924,9 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16, "sarssl_conv3x3_fwd(fused statistics: bf16 storage only)");
     if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
+#ifdef CONV_STAMPS
+    a.stamps = g_conv_stamps_host;
+#endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
     a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
