@@ -503,6 +503,9 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 
     unsigned epoch = 0;
     unsigned* cnt = &sSync[half];
+    float ssum[8], ssq[8];                         // this thread's 8 output channels ((lane & 7) * 8 + e), summed over all its tiles
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     const int nrounds = (npairs + gridDim.x - 1) / gridDim.x;
     int tile = tile_of(0);
     TileCoord tc = coord(tile < ntiles ? tile : 0);
@@ -600,9 +603,6 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         __builtin_amdgcn_wave_barrier();
         if (BNRED) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         STAMP(7);
-        float ssum[8], ssq[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int px = (lane >> 3) + 8 * k;
@@ -635,25 +635,27 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             }
         }
         STAMP(8);
-        if (BNRED || a.stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
-                ssq[e] += __shfl_xor(ssq[e], 8, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
-            }
-            if (lane < 8) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float s2 = ssq[e];
-                    if (BNRED) s2 = sAff[192 + lane * 8 + e] * (s2 - sAff[128 + lane * 8 + e] * ssum[e]);     // rstd * (sum g*y - mean * sum g)
-                    atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], s2);
-                }
-            }
-        }
         STAMP(9);
         half_barrier(cnt, epoch, lane);                        // slices drained before the next tile overwrites the buffer
         STAMP(10);
         tile = next; tc = tcn;
+    }
+    // per-channel sums: the thread's 8 channels were accumulated over ALL its tiles in registers (folding them per tile - 48 lane
+    // exchanges + 16 LDS atomics - showed as ~2.5 k of a half-tile's ~22 k cycles in the stamps); one fold per launch
+    if (BNRED || a.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
+            ssq[e] += __shfl_xor(ssq[e], 8, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s2 = ssq[e];
+                if (BNRED) s2 = sAff[192 + lane * 8 + e] * (s2 - sAff[128 + lane * 8 + e] * ssum[e]);     // rstd * (sum g*y - mean * sum g)
+                atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], s2);
+            }
+        }
     }
     __syncthreads();
     if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
