@@ -847,6 +847,158 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---- weight gradient, double-buffered variant (bf16).  In conv3x3_wgrad_kernel all eight waves stage, barrier, run their MFMAs,
+// barrier: the matrix pipe idles for the whole staging phase (one tile = ~25 k cycles of which 2 x 5.1 k are MFMA, mfma_busy 0.38 in
+// the round-2 counters) and the 150 KB of one 8 x 64-pixel tile pair leave no room for a second buffer.  Here the tile is 8 x 32 pixels
+// (z halo 43.5 KB + dy 32.8 KB), LDS holds TWO of them, the next tile is written into the other buffer right behind this tile's
+// MFMAs and there is ONE barrier per tile; the waves of a SIMD drift against each other inside a tile, so one wave's staging (VALU,
+// LDS writes) runs under the other's MFMAs.  Same wave roles / accumulators / partial-sum output as conv3x3_wgrad_kernel.
+#define WTC 32
+#define WHC (WTC + 2)
+#define WX_ELEMS (HR * WHC * 64)
+#define WY_ELEMS (TR * WTC * 64)
+__global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
+    typedef bf16 T;
+    __shared__ __attribute__((aligned(16))) uint16_t sYb[2][WY_ELEMS];   // dy tiles  [8*32 px][64 co]
+    __shared__ __attribute__((aligned(16))) uint16_t sXb[2][WX_ELEMS];   // z halo tiles [340 px][64 ci]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = (wave >> 1) & 1, wt = wave >> 2;     // co half, ci half, tap group
+    const int tap0 = wt ? 5 : 0, ntap = wt ? 4 : 5;
+    const int F = a.F, Tn = a.T;
+    const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + WTC - 1) / WTC;
+    const int ntiles = a.nb * tiles_f * tiles_t;
+    const T* zin = (const T*)a.zin;
+    const T* dy = (const T*)a.dy;
+    const int cch = tid & 7;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t9 = 0; t9 < 5; ++t9)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t9][r] = 0.f;
+
+    int baseA[2], baseB[5][2];
+    {
+        const int chA = wi * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4, chB = wj * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int loff = (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
+            baseA[h] = swzc(loff, loff, chA >> 3) + (chA & 7);
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) {
+                const int tap = tap0 + (tt < ntap ? tt : 0);
+                const int kh = tap / 3, kw = tap - kh * 3;
+                baseB[tt][h] = swzc(kh * WHC + kw + loff, kw + loff, chB >> 3) + (chB & 7);
+            }
+        }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+
+    // staging: thread = (row parity pr, pixel column pcol of 32, 8-channel chunk): halo rows pr, pr+2, .. pr+8 and dy rows pr, pr+2, ..
+    // pr+6 of its column; threads < 160 also one chunk of halo columns 32 / 33
+    Chunk<T> rz[6], ry[4];
+    const int pcol = (tid >> 3) & 31, pr = tid >> 8;
+    auto coord = [&](int tile) { TileCoord c; c.t0 = (tile % tiles_t) * WTC; tile /= tiles_t; c.f0 = (tile % tiles_f) * TR; c.b = tile / tiles_f; return c; };
+    auto issue_loads = [&](const TileCoord tc) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) rz[k] = load_chunk_clamped<T>(zin, tc.b, tc.f0 - 1 + pr + 2 * k, tc.t0 - 1 + pcol, F, Tn, cch * 8);
+        {
+            const int q = tid >> 3, hr = q >> 1, te = tc.t0 + WTC - 1 + (q & 1);        // (threads >= 160: an unused, harmless extra chunk)
+            rz[5] = load_chunk_clamped<T>(zin, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ry[k] = load_chunk_clamped<T>(dy, tc.b, tc.f0 + pr + 2 * k, tc.t0 + pcol, F, Tn, cch * 8);
+    };
+    // the tile is written in three pieces (halo rows 0-2 of this thread | halo rows 3-4 + edge columns | dy rows) so that the pieces can be
+    // placed between the row iterations of the PREVIOUS tile's MFMA loop
+    auto write_piece = [&](const int piece, const TileCoord tc, uint16_t* __restrict__ sX, uint16_t* __restrict__ sY) {
+        if (piece < 2) {
+            const int t = tc.t0 - 1 + pcol;
+            const bool tv = t >= 0 && t < Tn;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if ((piece == 0) != (k < 3)) continue;
+                const int i = pr + 2 * k, f = tc.f0 - 1 + i;
+                *(uint4*)&sX[swzc(i * WHC + pcol, pcol, cch)] = xform_chunk<T>(rz[k], tv && f >= 0 && f < F, a.prologue, sc, sh, 0);
+            }
+            if (piece == 1 && tid < 160) {
+                const int q = tid >> 3, hr = q >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + WTC - 1 + (q & 1);
+                *(uint4*)&sX[swzc(hr * WHC + WTC + (q & 1), WTC + (q & 1), cch)] = xform_chunk<T>(rz[5], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, 0);
+            }
+        } else {
+            const int ty = tc.t0 + pcol;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = pr + 2 * k;
+                *(uint4*)&sY[swzc(i * WTC + pcol, pcol, cch)] = xform_chunk<T>(ry[k], tc.f0 + i < F && ty < Tn, 0, sc, sh, 0);
+            }
+        }
+    };
+    auto write_tile = [&](const TileCoord tc, uint16_t* __restrict__ sX, uint16_t* __restrict__ sY) {
+        write_piece(0, tc, sX, sY); write_piece(1, tc, sX, sY); write_piece(2, tc, sX, sY);
+    };
+
+    const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
+    int tile = xcd_tile(0, blockIdx.x, gridDim.x);
+    TileCoord tc = coord(tile < ntiles ? tile : 0);
+    if (tile < ntiles) {
+        issue_loads(tc);
+        write_tile(tc, sXb[0], sYb[0]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < nrounds; ++it) {
+        if (tile >= ntiles) break;
+        const int next = (it + 1 < nrounds) ? xcd_tile(it + 1, blockIdx.x, gridDim.x) : ntiles;
+        const TileCoord tcn = coord(next < ntiles ? next : 0);
+        if (next < ntiles) issue_loads(tcn);
+        const uint16_t* sX = sXb[cur];
+        const uint16_t* sY = sYb[cur];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const uint16_t* ya[2] = {sY + baseA[0] + r * (WTC * 64), sY + baseA[1] + r * (WTC * 64)};
+            const uint16_t* xb[5][2];
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) { xb[tt][0] = sX + baseB[tt][0] + r * (WHC * 64); xb[tt][1] = sX + baseB[tt][1] + r * (WHC * 64); }
+#pragma unroll
+            for (int cb = 0; cb < WTC / 16; ++cb) {
+                const int co_ = cb * 16 * 64;                  // 16 pixels x 64 channels further on
+                const bf16x8 fa = tr_pair(ya[0] + co_, ya[1] + co_);
+                bf16x8 fb[2];
+                fb[0] = tr_pair(xb[0][0] + co_, xb[0][1] + co_);
+#pragma unroll
+                for (int tt = 0; tt < 5; ++tt) {
+                    if (tt + 1 < 5 && tt + 1 < ntap) fb[(tt + 1) & 1] = tr_pair(xb[tt + 1][0] + co_, xb[tt + 1][1] + co_);
+                    __builtin_amdgcn_sched_barrier(0);         // pin the next tap's transpose reads above this MFMA
+                    if (tt < ntap) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tt & 1], acc[tt], 0, 0, 0);
+                }
+            }
+            // next tile -> the other buffer, in pieces behind the later rows (its loads were issued before this tile's first MFMA and
+            // have had rows 0-4 to land): this wave's VALU / LDS-write work runs under the MFMAs it has just queued and the other
+            // wave's on the same SIMD
+            if (next < ntiles && r >= 5) write_piece(r - 5, tcn, sXb[cur ^ 1], sYb[cur ^ 1]);
+        }
+        __syncthreads();
+        cur ^= 1; tile = next; tc = tcn;
+    }
+    float* P = a.partial + (long)blockIdx.x * W_ELEMS;
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) {
+        if (tt < ntap) {
+            const int tap = tap0 + tt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ci = wj * 32 + (lane & 31);
+                P[(tap * 64 + co) * 64 + ci] = acc[tt][r];
+            }
+        }
+    }
+}
+
 // dW[e] (+)= sum_p partial[p][e]; workgroup = 64 elements x 4 part-slots, 4-way unrolled loads
 // grad_oihw != null: the sum is ADDED to the parameter-gradient buffer in nn.Conv2d's own (co, ci, kh, kw) layout instead.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW,
@@ -870,6 +1022,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+static bool wgrad_db_enabled() {
+    static const int v = getenv("SARSSL_WGRAD_DB") ? atoi(getenv("SARSSL_WGRAD_DB")) : 1;       // A/B switch: 0 = single-buffered kernel
+    return v != 0;
+}
+static int wgrad_db_grid(int nb, int F, int T) {
+    const int ntiles = nb * ((F + TR - 1) / TR) * ((T + WTC - 1) / WTC);
+    const int ncu = sarssl_cu_count();
+    return ntiles < ncu ? ntiles : ncu;
+}
 static int conv_grid(int nb, int F, int T) {
     int ntiles = nb * ((F + TR - 1) / TR) * ((T + TCOL - 1) / TCOL);
     const int ncu = sarssl_cu_count();              // persistent: one workgroup per CU
@@ -961,7 +1122,8 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
 }
 
 extern "C" long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T) {
-    return (long)conv_grid(nb, F, T) * W_ELEMS * sizeof(float);
+    const int g1 = conv_grid(nb, F, T), g2 = wgrad_db_grid(nb, F, T);          // (either weight-gradient kernel may run)
+    return (long)(g1 > g2 ? g1 : g2) * W_ELEMS * sizeof(float);
 }
 
 // dW: f32 [9][64][64] ([tap][co][ci]).  partial: workspace of sarssl_conv3x3_wgrad_workspace_bytes.
@@ -1041,8 +1203,8 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
     const int grid = conv_grid(nb, F, T);
     const int rblocks = W_ELEMS / 64;
     if (dtype == SARSSL_BF16) {
-        conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
-        wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid, dW, 0);
+        if (wgrad_db_enabled()) { const int g2 = wgrad_db_grid(nb, F, T); conv3x3_wgrad_db_kernel<<<g2, 512, 0, st>>>(a); wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, g2, dW, 0); }
+        else { conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a); wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid, dW, 0); }
     } else if (dtype == SARSSL_F32) {
         const int npass = precise ? 3 : 1;
         for (int pass = 0; pass < npass; ++pass) {
@@ -1065,9 +1227,15 @@ extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb,
     a.dy = dy; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
     a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = conv_grid(nb, F, T);
-    conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
-    wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, grid, nullptr, 0, grad_oihw);
+    if (wgrad_db_enabled()) {
+        const int g2 = wgrad_db_grid(nb, F, T);
+        conv3x3_wgrad_db_kernel<<<g2, 512, 0, st>>>(a);
+        wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
+    } else {
+        const int grid = conv_grid(nb, F, T);
+        conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
+        wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, grid, nullptr, 0, grad_oihw);
+    }
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel(acc)");
     return 0;
 }
