@@ -179,6 +179,12 @@ long sarssl_layernorm_bwd_workspace_bytes(long M, int d);
 int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
                          const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
                          float* dgamma, float* dbeta, float* partial, int dtype, void* stream);
+/*      + dx2 [M][d] = dx * dropout_mask(seed, m*d + c) * gscale, i.e. the sarssl_act_bwd(act = 0) pass the next module of the backward
+ *      chain (Dropout backward of feed_forward.py:53 / attention.py:151 / convolution.py:145 + the half-step factor) starts with */
+int sarssl_layernorm_bwd_drop(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
+                              const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
+                              float* dgamma, float* dbeta, float* partial, void* dx2, float p_drop, unsigned long long seed,
+                              float gscale, int dtype, void* stream);
 /*      dgamma == NULL with partial != NULL: the [nparts][2 d] partial sums only (nparts = sarssl_layernorm_bwd_nparts(M)); the folds
  *      of up to 8 such launches (the LayerNorms of one Conformer block) then run as one launch: dgamma_q / dbeta_q += ... */
 int sarssl_layernorm_bwd_nparts(long M);

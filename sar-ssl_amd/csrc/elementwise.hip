@@ -67,7 +67,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             long M, int d, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const T* __restrict__ resid, long ldr, T* __restrict__ dx, long lddx,
-                                                            float* __restrict__ partial /* [gridDim.x][2][d] or null */) {
+                                                            float* __restrict__ partial /* [gridDim.x][2][d] or null */,
+                                                            T* __restrict__ dx2 = nullptr, float p_drop = 0.f, unsigned long long seed0 = 0,
+                                                            const unsigned long long* __restrict__ salt = nullptr, float gscale = 1.f) {
+    // dx2 (optional, contiguous [M][d]): dx * dropout_mask(seed, m*d + c) * gscale - the dropout backward the NEXT module of the
+    // backward chain applies to its incoming gradient (act_bwd), produced here while dx is still in registers
+    const unsigned long long seed = salted_seed(seed0, salt);
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
     __shared__ float4 sg[4][64 * NV];
     __shared__ float4 sb[4][64 * NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -130,6 +136,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                            rs[u] * (g[i].z - s1 - xh[i].z * s2), rs[u] * (g[i].w - s1 - xh[i].w * s2));
                     if (resid) { o.x += rv[u][i].x; o.y += rv[u][i].y; o.z += rv[u][i].z; o.w += rv[u][i].w; }
                     st4(dx + row * lddx + c4 * 4, o);
+                    if (dx2) {
+                        const unsigned long long idx = (unsigned long long)row * d + c4 * 4;
+                        float4 q = o;
+                        if (p_drop > 0.f) {
+                            q.x *= dropout_scale(seed, idx, p_drop, inv_keep); q.y *= dropout_scale(seed, idx + 1, p_drop, inv_keep);
+                            q.z *= dropout_scale(seed, idx + 2, p_drop, inv_keep); q.w *= dropout_scale(seed, idx + 3, p_drop, inv_keep);
+                        }
+                        q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale;
+                        st4(dx2 + row * d + c4 * 4, q);
+                    }
                 }
             }
         }
@@ -733,6 +749,24 @@ extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, lo
         ln_param_reduce_kernel<<<(2 * d + 63) / 64, 1024, 0, ST>>>(part, nblk, d, dgamma, dbeta);
     }
     SARSSL_CHECK_LAUNCH("layernorm_bwd_kernel");
+    return 0;
+}
+// The same with a second output dx2 [M][d] (contiguous) = dx * dropout_mask(seed, m*d + c) * gscale: the dropout backward (sarssl_act_bwd,
+// act = 0) the next module of the backward chain would run on dx as its first step.
+extern "C" int sarssl_layernorm_bwd_drop(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
+                                         const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,
+                                         float* dgamma, float* dbeta, float* partial, void* dx2, float p_drop, unsigned long long seed,
+                                         float gscale, int dtype, void* stream) {
+    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (!dgamma || partial) && dx2, "sarssl_layernorm_bwd_drop");
+    const int nblk = ln_bwd_blocks(M);
+    float* part = partial;
+    const unsigned long long* salt = sarssl_dropout_salt();
+#define LN_BWD_LAUNCH(NVv) layernorm_bwd_kernel<T, NVv><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd, \
+                                                                           (const T*)resid, ldr, (T*)dx, lddx, part, (T*)dx2, p_drop, seed, salt, gscale)
+    DISPATCH_T(dtype, (d <= 256 ? LN_BWD_LAUNCH(1) : (d <= 512 ? LN_BWD_LAUNCH(2) : LN_BWD_LAUNCH(4))));
+#undef LN_BWD_LAUNCH
+    if (dgamma) ln_param_reduce_kernel<<<(2 * d + 63) / 64, 1024, 0, ST>>>(part, nblk, d, dgamma, dbeta);
+    SARSSL_CHECK_LAUNCH("layernorm_bwd_kernel(drop)");
     return 0;
 }
 extern "C" int sarssl_layernorm_bwd_nparts(long M) { return ln_bwd_blocks(M); }

@@ -382,7 +382,29 @@ def ffn_fwd(x, ff, factor, train, saved, out=None):
     return y
 
 
-def ffn_bwd(dy, ff, saved):
+_FUSE_DROP_BWD = os.environ.get("SARSSL_FUSE_DROP_BWD", "1") != "0"
+
+
+def _next_drop(kind, saved):
+    """(p, seed, gscale) of the dropout backward the NEXT module of the backward chain (``kind``: 'ffn' | 'conv' | 'mhsa', its entry
+    is on top of ``saved``) applies to its incoming gradient, or None when there is nothing to apply (or the masks are replayed host
+    tensors).  The LayerNorm backward that produces that gradient then writes the dropped copy as a second output
+    (hip.layernorm_bwd(drop=...)) instead of a separate act_bwd pass."""
+    if not _FUSE_DROP_BWD or kind is None or not saved:
+        return None
+    e = saved[-1]
+    if kind == "ffn":
+        p, seed, g = e[7], e[8], e[9]
+    elif kind == "conv":
+        p, seed, g = e[8], e[9], 1.0
+    else:
+        p, seed, g = e[-4], e[-3], 1.0
+    if torch.is_tensor(seed) or torch.is_tensor(p) or (p <= 0 and g == 1.0):
+        return None
+    return (float(p), int(seed), float(g))
+
+
+def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
     x, ln, stats, hpre, a, p1, s1, p2, s2, factor = saved.pop()
     seq = ff.sequential
     if torch.is_tensor(s1) or torch.is_tensor(s2):        # replayed masks (see ffn_fwd)
@@ -393,7 +415,10 @@ def ffn_bwd(dy, ff, saved):
         if torch.is_tensor(s1):
             dh = dh * s1
     else:
-        dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
+        if dy_dropped is not None:
+            dz2 = dy_dropped                                  # written by the previous LayerNorm backward (see _next_drop)
+        else:
+            dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
         mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
         hip.colsum(dz2, gbuf(seq[4].linear.bias))
         # dh = (dz2 @ W2) * dropout_mask1 * swish'(hpre): activation backward fused into the GEMM epilogue
@@ -401,7 +426,8 @@ def ffn_bwd(dy, ff, saved):
     mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight))
     hip.colsum(dh, gbuf(seq[1].linear.bias))
     dln = mm_nn(dh, wt(seq[1].linear.weight))
-    return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias))
+    return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
+                             drop=_next_drop(next_kind, saved))
 
 
 def _pe(mod, T):
@@ -502,7 +528,7 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     return y
 
 
-def mhsa_bwd(dy, mod, saved):
+def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
     x, ln, stats, qu, qv, k, v, pos, pe, p, pd, pa, sa, ctx, po, so, B, T = saved.pop()
     att = mod.attention
     H, dh, d = att.num_heads, att.d_head, att.d_model
@@ -511,6 +537,8 @@ def mhsa_bwd(dy, mod, saved):
     fused_attn = isinstance(pd, tuple)                                # fused forward saved (bias, (ctx32, lse)) in place of (p, pd)
     if torch.is_tensor(so):
         dout = dy * so                                     # replayed mask
+    elif dy_dropped is not None:
+        dout = dy_dropped
     else:
         dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
     mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight))
@@ -542,7 +570,8 @@ def mhsa_bwd(dy, mod, saved):
     hip.gemm(dps, qv, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(T * d, dh), out=dposb, ldc=d, sC=(T * d, dh), precise=RT.precise)
     del dps
-    return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev)
+    return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev,
+                          drop=_next_drop(next_kind, saved))
 
 
 def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ldg, scale, pa, sa):
@@ -567,7 +596,7 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
     return dps
 
 
-def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev):
+def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None):
     """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
     dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
     hip.colsum(dposb.view(B, T * d), dpos, now=True)                 # consumed right below
@@ -588,7 +617,7 @@ def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb
         dln = mm_nn(dk, wt(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
         dln = mm_nn(dv, wt(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
     return hip.layernorm_bwd(dln, x, mod.layer_norm.weight.data, stats, resid=dy, dgamma=gbuf(mod.layer_norm.weight),
-                             dbeta=gbuf(mod.layer_norm.bias))
+                             dbeta=gbuf(mod.layer_norm.bias), drop=drop)
 
 
 def convmod_fwd(x, cm, B, T, train, saved):
@@ -620,13 +649,15 @@ def convmod_fwd(x, cm, B, T, train, saved):
     return y
 
 
-def convmod_bwd(dy, cm, saved):
+def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
     x, ln, stats, h, g, c, aff, s, po, so, B, T, train = saved.pop()
     seq = cm.sequential
     d = x.shape[1]
     pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
     if torch.is_tensor(so):
         dout = dy * so
+    elif dy_dropped is not None:
+        dout = dy_dropped
     else:
         dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
     mm_tn_acc(dout, s, gbuf(pw2.weight))
@@ -645,7 +676,8 @@ def convmod_bwd(dy, cm, saved):
     mm_tn_acc(dh, ln, gbuf(pw1.weight))
     hip.colsum(dh, gbuf(pw1.bias))
     dln = mm_nn(dh, wt(pw1.weight).view(2 * d, d))
-    return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias))
+    return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
+                             drop=_next_drop(next_kind, saved))
 
 
 def block_fwd(x, blk, B, T, train, saved, out=None):
@@ -665,11 +697,15 @@ def block_bwd(dy, blk, saved):
     x, stats = saved.pop()
     # the block's ~9 bias-gradient column sums and the reductions of its 9 split-K weight-gradient products: one launch each, at the end
     with hip.colsum_batched(flush_ctx=_WgradSide), hip.splitk_batched(flush_ctx=_WgradSide), hip.ln_reduce_batched(), wgrad_block():
-        d = hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias))
-        d = ffn_bwd(d, seq[3].module, saved)
-        d = convmod_bwd(d, seq[2].module, saved)
-        d = mhsa_bwd(d, seq[1].module, saved)
-        d = ffn_bwd(d, seq[0].module, saved)
+        # each module's backward starts with the dropout backward of its incoming gradient: the LayerNorm backward that produces
+        # that gradient writes the dropped copy as a second output (d = (gradient, dropped gradient) where a mask applies)
+        pair = lambda r: r if isinstance(r, tuple) else (r, None)
+        d, dd = pair(hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias),
+                                       drop=_next_drop("ffn", saved)))
+        d, dd = pair(ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind="conv"))
+        d, dd = pair(convmod_bwd(d, seq[2].module, saved, dy_dropped=dd, next_kind="mhsa"))
+        d, dd = pair(mhsa_bwd(d, seq[1].module, saved, dy_dropped=dd, next_kind="ffn"))
+        d = ffn_bwd(d, seq[0].module, saved, dy_dropped=dd)
     return d
 
 

@@ -638,7 +638,9 @@ def ln_reduce_flush():
                   c_int(n), _stream())
 
 
-def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, out=None):
+def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, out=None, drop=None):
+    """drop = (p, seed, gscale): also returns out2 = out * dropout_mask(seed) * gscale (contiguous) - what ``act_bwd(out, None, 0, p, seed,
+    gscale)`` would compute in its own pass; then the result is (out, out2)."""
     M, d = x2d.shape
     if out is None:
         out = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
@@ -652,6 +654,14 @@ def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, 
             dgamma = dbeta = None
         else:
             part = workspace(fn(c_long(M), c_int(d)), x2d.device, "ln_part")
+    if drop is not None:
+        p, seed, gscale = drop
+        out2 = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+        _lib.call("sarssl_layernorm_bwd_drop", _p(dy2d), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
+                  _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out),
+                  c_long(out.stride(0)), _p(dgamma), _p(dbeta), _p(part), _p(out2), c_float(p), c_ulonglong(seed), c_float(gscale),
+                  c_int(dt(x2d)), _stream())
+        return out, out2
     _lib.call("sarssl_layernorm_bwd", _p(dy2d), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
               _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out),
               c_long(out.stride(0)), _p(dgamma), _p(dbeta), _p(part), c_int(dt(x2d)), _stream())
