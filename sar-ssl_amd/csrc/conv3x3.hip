@@ -506,6 +506,18 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     float ssum[8], ssq[8];                         // this thread's 8 output channels ((lane & 7) * 8 + e), summed over all its tiles
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    float bthr[8];                                 // BNRED: relu'(y*sc + sh) as a threshold test on y (see cl_bn_bwd_reduce), lane-constant
+    unsigned bsgn = 0u;
+    if (BNRED) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (lane & 7) * 8 + e;
+            const float sc_ = sAff[c], sh_ = sAff[64 + c];
+            float thr = sc_ != 0.f ? -sh_ / sc_ : (sh_ > 0.f ? -INFINITY : INFINITY);
+            if (sc_ < 0.f) { thr = -thr; bsgn |= 1u << e; }
+            bthr[e] = thr;
+        }
+    }
     const int nrounds = (npairs + gridDim.x - 1) / gridDim.x;
     int tile = tile_of(0);
     TileCoord tc = coord(tile < ntiles ? tile : 0);
@@ -560,6 +572,18 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         STAMP(4);
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // retire the prefetch before any output store is issued
         STAMP(5);
+        // BatchNorm-backward mode: fetch the matching pre-BN activations now - their round trip runs under the half barrier and the
+        // accumulator hand-over below - and retire them BEFORE the first output store is issued (loads and stores share vmcnt and
+        // complete out of order on gfx9).  Unconditional loads from clamped addresses (out-of-image chunks are skipped in the drain).
+        uint4 yv[BNRED ? 8 : 1];
+        if (BNRED) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int px = (lane >> 3) + 8 * k;
+                const int f = min(tc.f0 + 2 * hw + (px >> 5), F - 1), t = min(tc.t0 + (px & 31), Tn - 1);
+                yv[k] = *(const uint4*)((const uint16_t*)a.bn_y + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8);
+            }
+        }
         half_barrier(cnt, epoch, lane);                        // the half is done reading its input tile
         STAMP(6);
         uint16_t* stg = sX + hw * (64 * 64);                   // this wave's [64 px][64 co] slice (px = row * 32 + column)
@@ -577,28 +601,6 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                     *(uint2*)(q + j * 32 * 64) = w2;
                 }
             }
-        // BatchNorm-backward mode: fetch the matching pre-BN activations now (the accumulator registers are free) and retire the
-        // loads BEFORE the first output store is issued (loads and stores share vmcnt and complete out of order on gfx9)
-        uint4 yv[8];
-        float bthr[8];
-        unsigned bsgn = 0u;
-        if (BNRED) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int px = (lane >> 3) + 8 * k;
-                const int f = tc.f0 + 2 * hw + (px >> 5), t = tc.t0 + (px & 31);
-                yv[k] = (f < F && t < Tn) ? *(const uint4*)((const uint16_t*)a.bn_y + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8)
-                                          : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {                       // relu'(y*sc + sh) as a threshold test on y (see cl_bn_bwd_reduce)
-                const int c = (lane & 7) * 8 + e;
-                const float sc_ = sAff[c], sh_ = sAff[64 + c];
-                float thr = sc_ != 0.f ? -sh_ / sc_ : (sh_ > 0.f ? -INFINITY : INFINITY);
-                if (sc_ < 0.f) { thr = -thr; bsgn |= 1u << e; }
-                bthr[e] = thr;
-            }
-        }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
         if (BNRED) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
