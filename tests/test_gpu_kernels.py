@@ -765,3 +765,28 @@ def test_gemm_group_tn_equals_separate_products():
     dy = torch.randn(K, 192, device="cuda").to(torch.bfloat16)
     with hip.splitk_batched():
         assert not hip.gemm_group_tn([(dy, dy, torch.zeros(192, 192, device="cuda"), 2), items[0]])
+
+
+@pytest.mark.parametrize("dtp", [torch.bfloat16, torch.float32])
+def test_layernorm_bwd_fused_dropout_output_equals_act_bwd(dtp):
+    """hip.layernorm_bwd(drop=(p, seed, gscale)): the second output is what act_bwd would make of the first one - same keep mask
+    (same counter hash on the element index), same scaling; in bf16 it is rounded once from the unrounded gradient instead of twice."""
+    from sar_ssl_amd import hip
+    torch.manual_seed(5)
+    M, d = 384, 256
+    x = torch.randn(M, d, device="cuda").to(dtp)
+    dy = torch.randn(M, d, device="cuda").to(dtp)
+    res = torch.randn(M, d, device="cuda").to(dtp)
+    gamma = torch.rand(d, device="cuda") + 0.5
+    beta = torch.zeros(d, device="cuda")
+    _, stats = hip.layernorm_fwd(x, gamma, beta, 1e-5)
+    p, seed, g = 0.1, 0x1234567887654321, 0.5
+    out, out2 = hip.layernorm_bwd(dy, x, gamma, stats, resid=res, drop=(p, seed, g))
+    ref = hip.layernorm_bwd(dy, x, gamma, stats, resid=res)
+    assert torch.equal(out, ref)
+    want = hip.act_bwd(ref, None, 0, p_drop=p, seed=seed, gscale=g)
+    assert torch.equal(out2 == 0, want == 0)                               # identical keep mask
+    frac = float((out2 == 0).float().mean())
+    assert 0.07 < frac < 0.13
+    tol = 1e-6 if dtp == torch.float32 else 1e-2
+    assert float((out2.float() - want.float()).abs().max()) <= tol * float(want.float().abs().max())
