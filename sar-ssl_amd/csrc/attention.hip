@@ -79,8 +79,10 @@ __device__ __forceinline__ float attn_keep(const AttnArgs& a, unsigned long long
 }
 
 // ------------------------------------------------------------------------------------------------------------------- forward
+// (d_head <= 64: capped at 256 registers - 243 used, no spills - so that TWO workgroups share a CU: the kernel is a chain of
+//  latencies (K / V / bias tiles, softmax exchanges) and ran one wave per SIMD at 263 registers)
 template <int DH>
-__global__ __launch_bounds__(256) void relpos_attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
     constexpr int PK = DH + 8, PV = DH + 32, PB = TK + 8;
     constexpr int CPR = DH / 8;                               // 16-byte chunks per K / V row
@@ -266,7 +268,7 @@ __global__ void relpos_attn_dsum_kernel(AttnArgs a, int dh) {
 
 // ---------------------------------------------------------------------------- backward, part 1: dQ and d(bias), per query tile
 template <int DH>
-__global__ __launch_bounds__(256) void relpos_attn_bwd_q_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 2 : 1))) void relpos_attn_bwd_q_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
     constexpr int PK = DH + 8, PT = DH + 32, PB = TK + 8;
     constexpr int CPR = DH / 8;
