@@ -114,10 +114,21 @@ def main():
         from sar_ssl_amd.graph import PretrainStepGraph
         graph = PretrainStepGraph(net, flat, reducer, lr=1e-3)
 
+    state = {"graph": graph}
+
     def step():
-        if graph is None:
+        g = state["graph"]
+        if g is None:
             return step_eager()
-        return graph.step(pcm=pcm, static=True)[0]      # the resident batch IS the graph's input buffer: no per-step copy
+        try:
+            return g.step(pcm=pcm, static=True)[0]      # the resident batch IS the graph's input buffer: no per-step copy
+        except Exception as e:                          # (never seen; a failed capture must not cost the whole run its number)
+            if g._plan is not None:
+                raise
+            print("bench: graph capture failed (%r) - falling back to the launch-by-launch step" % (e,), file=sys.stderr, flush=True)
+            state["graph"] = None
+            opt.zero_grad()
+            return step_eager()
 
     def barrier():
         if world > 1:
@@ -126,6 +137,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    graph = state["graph"]
     if graph is None:
         hip.profile_start()
     n0 = _lib.ncalls
