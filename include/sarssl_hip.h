@@ -128,10 +128,11 @@ int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb, int F, int
                              float* grad_oihw, float* partial, void* stream);
 /*      re-laid-out operands of the stem convolutions, one launch each (they follow the weights every step): conv_taps: (64,64,3,3)
  *      f32 -> fwd [9][co][ci] and dgr [9][ci][co] with flipped taps, f32 | bf16; patch_w: the frame-patch conv weight (d,4,F,1)
- *      (code/model.py:63) -> GEMM operand [d][f*4+c]; patch_wgrad_accum: grad (d,4,F,1) += g [d][f*4+c]. */
+ *      (code/model.py:63) -> GEMM operand [d][f*4+c]; patch_wgrad_accum: grad (d,4,F,1) += sum over the nslice
+ *      split-K partial products g [nslice][d][f*4+c]. */
 int sarssl_conv_taps(const float* W, void* fwd, void* dgr, int dtype, void* stream);
 int sarssl_patch_w(const float* W, void* out, int d, int F, int dtype, void* stream);
-int sarssl_patch_wgrad_accum(const float* g, float* grad, int d, int F, void* stream);
+int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad, int d, int F, void* stream);
 int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
                        int dtype, void* stream);
 int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
@@ -208,6 +209,8 @@ int sarssl_axpby(const void* x, const void* y, float a, float b, long n, void* o
 int sarssl_axpby2d(const void* x, long ldx, const void* y, long ldy, float a, float b, long M, int N, void* out, long ldo,
                    int dtype, void* stream);
 int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream);
+/* out[n] (x's dtype) = sum_m x[m][n]: few rows, many columns (batch sum of the positional-score gradient, model.py:RelPositionMultiHeadAttention) */
+int sarssl_colsum_store(const void* x, long ldx, long M, int N, void* out, int dtype, void* stream);
 /* up to 24 independent column sums in one launch (bias gradients of one backward stage): outs[q][n] += sum_m xs[q][m][n] */
 int sarssl_colsum_multi(const void* const* xs, const long* ldxs, const long* Ms, const int* Ns, float* const* outs, int n, int dtype,
                         void* stream);

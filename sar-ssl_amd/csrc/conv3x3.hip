@@ -1180,16 +1180,21 @@ extern "C" int sarssl_patch_w(const float* W, void* out, int d, int F, int dtype
     SARSSL_CHECK_LAUNCH("patch_w_kernel");
     return 0;
 }
-// grad (d, 4, F, 1) f32 += g [d][f * 4 + c]  (the frame-patch weight gradient back in nn.Conv2d layout)
-__global__ void patch_wgrad_accum_kernel(const float* __restrict__ g, float* __restrict__ grad, int d, int F) {
+// grad (d, 4, F, 1) f32 += sum_s g[s][d][f * 4 + c]  (the frame-patch weight gradient back in nn.Conv2d layout; g = nslice split-K
+// partial products, so the fold of the partials and the re-layout are one pass and nothing has to be zeroed)
+__global__ void patch_wgrad_accum_kernel(const float* __restrict__ g, int nslice, float* __restrict__ grad, int d, int F) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)d * F * 4) return;
-    const int c = e & 3; const long of = e >> 2; const int f = of % F; const long o = of / F;
-    grad[(o * 4 + c) * F + f] += g[e];
-}
-extern "C" int sarssl_patch_wgrad_accum(const float* g, float* grad, int d, int F, void* stream) {
     const long n = (long)d * F * 4;
-    patch_wgrad_accum_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(g, grad, d, F);
+    if (e >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslice; ++k) s += g[k * n + e];
+    const int c = e & 3; const long of = e >> 2; const int f = of % F; const long o = of / F;
+    grad[(o * 4 + c) * F + f] += s;
+}
+extern "C" int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad, int d, int F, void* stream) {
+    SARSSL_REQUIRE(nslice > 0, "sarssl_patch_wgrad_accum");
+    const long n = (long)d * F * 4;
+    patch_wgrad_accum_kernel<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(g, nslice, grad, d, F);
     SARSSL_CHECK_LAUNCH("patch_wgrad_accum_kernel");
     return 0;
 }

@@ -522,6 +522,30 @@ __global__ void colsum_kernel(const T* __restrict__ x, long ldx, long M, int N, 
         atomicAdd(&out[col0 + c], acc);
     }
 }
+// out[n] = sum_m x[m][n] written in the activation dtype (few rows, many columns: the batch sum of the positional-score gradient that
+// feeds the positional projection's weight-gradient GEMM - was memset + colsum_kernel + cast_kernel).  One workgroup per 64 columns.
+template <typename T>
+__global__ void colsum_store_kernel(const T* __restrict__ x, long ldx, long M, int N, T* __restrict__ out) {
+    __shared__ float sred[256][5];
+    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * 64, col = col0 + cgp * 4;
+    float s[4] = {0, 0, 0, 0};
+    if (col < N) {
+        for (long m = rslot; m < M; m += 16) {
+            const float4 v = ld4(x + m * ldx + col);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sred[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && col0 + threadIdx.x < N) {
+        const int c = threadIdx.x;
+        float acc = 0.f;
+        for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][c & 3];
+        st_f(out + col0 + c, acc);
+    }
+}
 // Several independent column sums in ONE launch (the ~46 bias-gradient reductions of a backward pass were 8 us launches each):
 // problem q: out_q[n] += sum_m x_q[m][n].  Workgroups are numbered through the problems' (column tile, row slice) grids.
 #define COLSUM_MAXP 24
@@ -877,6 +901,13 @@ extern "C" int sarssl_colsum(const void* x, long ldx, long M, int N, float* out,
     if (gy > cap) gy = cap;
     DISPATCH_T(dtype, (colsum_kernel<T><<<dim3(gx, (unsigned)gy), 256, 0, ST>>>((const T*)x, ldx, M, N, out)));
     SARSSL_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+// out[n] (same dtype as x) = sum_m x[m][n]; N % 4 == 0
+extern "C" int sarssl_colsum_store(const void* x, long ldx, long M, int N, void* out, int dtype, void* stream) {
+    SARSSL_REQUIRE((N & 3) == 0 && (ldx & 3) == 0 && M > 0, "sarssl_colsum_store(shape)");
+    DISPATCH_T(dtype, (colsum_store_kernel<T><<<(N + 63) / 64, 256, 0, ST>>>((const T*)x, ldx, M, N, (T*)out)));
+    SARSSL_CHECK_LAUNCH("colsum_store_kernel");
     return 0;
 }
 // n <= 24 problems: xs[q] (dtype, row stride ldxs[q], Ms[q] x Ns[q], Ns[q] % 4 == 0) -> outs[q][Ns[q]] += column sums

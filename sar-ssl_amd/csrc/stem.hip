@@ -412,6 +412,143 @@ __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// Phase 1 of the two-phase 64->4 backward (stem_c4_bwd_kernel<T, 1>) for 16-bit activations and full 16 x 16 tiles, rebuilt around
+// occupancy and bytes in flight.  The general kernel keeps 48 accumulators + 32 weights per thread (8 channels each): 228 VGPRs,
+// 2 waves / SIMD, and its load - wait - reduce loop left HBM idle during the ~800 VALU instructions of a tile: 238 us for 570 MB
+// (2.4 TB/s) at B = 64 while its VALU work alone is ~100 us.  Here a thread owns 4 channels (24 accumulators, 16 weights):
+// <= 128 VGPRs = 4 waves / SIMD, and the 8-byte chunks of the next half tile (8 bins x 16 frames; plus the thread's piece of the
+// next dy4 tile) are requested before the current half is reduced.  Addresses are a scalar base (tile, bin) plus a per-thread
+// byte offset that never changes (8 * threadIdx.x: one bin row of 16 frames is 2 KB contiguous).
+// sum g*xhat is accumulated as the raw moment sum g*y and converted per thread at the end (frees the mean / rstd registers).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void stem_c4_bwd_sums16_kernel(const bf16* __restrict__ y3, const bf16* __restrict__ dy4, const float* __restrict__ W4,
+                               const float* __restrict__ scale, const float* __restrict__ shift,
+                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                               int nb, int F, int Tn, double* __restrict__ red) {
+    __shared__ float4 sD[2][16][17];                     // dy4 tile [frame][bin] (f32), two stages: one barrier per tile
+    __shared__ float sred[4][16][24];
+    const int cq = threadIdx.x & 15, ps = threadIdx.x >> 4;          // channels 4cq..4cq+3; frame ps of every bin row
+    // everything per channel pair (packed f32 math: v_pk_fma_f32 on register pairs, dy4 values broadcast through op_sel)
+    typedef sarssl_f32x2 f2;
+    f2 w[4][2], sc[2], sh[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ci = cq * 4 + 2 * h;
+        sc[h] = f2{scale[ci], scale[ci + 1]}; sh[h] = f2{shift[ci], shift[ci + 1]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c][h] = f2{W4[c * 64 + ci], W4[c * 64 + ci + 1]};
+    }
+    f2 aW[4][2], aS1[2], aS2[2];                         // dW4[c][pair], s1[pair], sum g*y [pair]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        aS1[h] = f2{0.f, 0.f}; aS2[h] = f2{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) aW[c][h] = f2{0.f, 0.f};
+    }
+    const int ftiles = F >> 4, ttiles = Tn >> 4;
+    const int ntile = nb * ftiles * ttiles;
+    const long ystride = (long)Tn * 64;                  // one bin
+    const int ttl = threadIdx.x >> 3 & 15, fcl = (threadIdx.x & 7) * 2;     // dy4 piece: frame ttl, bins fcl, fcl+1 (threads 0..127 stage it)
+    const unsigned yoff = threadIdx.x * 8u, doff = (unsigned)((ttl * F + fcl) * 4) * 2u;
+    constexpr int H = 8;
+    auto tile_base = [&](int tile, long& ybase, long& dbase) {
+        // (hipcc divides on the vector unit and would keep everything derived from the quotients in vector registers)
+        const int tt0 = __builtin_amdgcn_readfirstlane((tile % ttiles) << 4);
+        const int r = tile / ttiles;
+        const int f0 = __builtin_amdgcn_readfirstlane((r % ftiles) << 4), b = __builtin_amdgcn_readfirstlane(r / ftiles);
+        ybase = (((long)b * F + f0) * Tn + tt0) * 64;
+        dbase = (((long)b * Tn + tt0) * F + f0) * 4;
+    };
+    auto issue_y = [&](int tile, int half, uint2 (&v)[H]) {             // past the last tile: clamped to it, never used
+        long ybase, dbase; tile_base(tile < ntile ? tile : ntile - 1, ybase, dbase);
+        unsigned yo = yoff;
+        asm volatile("" : "+v"(yo));                     // opaque: nothing per-thread and 64-bit for hipcc to hoist out of the loop (and spill)
+#pragma unroll
+        for (int u = 0; u < H; ++u) v[u] = *(const uint2*)((const char*)(y3 + ybase + (half * H + u) * ystride) + yo);
+    };
+    auto issue_d = [&](int tile, uint4& dp) {
+        long ybase, dbase; tile_base(tile < ntile ? tile : ntile - 1, ybase, dbase);
+        unsigned dof = doff;
+        asm volatile("" : "+v"(dof));
+        dp = *(const uint4*)((const char*)(dy4 + dbase) + dof);
+    };
+    auto reduce = [&](int half, int buf, const uint2 (&v)[H]) {
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            const float4 d = sD[buf][ps][half * H + u];
+            const f2 y[2] = {f2{bf16_bits_to_f32(v[u].x & 0xffffu), __uint_as_float(v[u].x & 0xffff0000u)},
+                             f2{bf16_bits_to_f32(v[u].y & 0xffffu), __uint_as_float(v[u].y & 0xffff0000u)}};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f2 uu = y[h] * sc[h] + sh[h];
+                f2 gi = w[0][h] * d.x + w[1][h] * d.y + w[2][h] * d.z + w[3][h] * d.w;
+                gi = f2{uu.x > 0.f ? gi.x : 0.f, uu.y > 0.f ? gi.y : 0.f};
+                const f2 z = f2{fmaxf(uu.x, 0.f), fmaxf(uu.y, 0.f)};
+                aW[0][h] += z * d.x; aW[1][h] += z * d.y; aW[2][h] += z * d.z; aW[3][h] += z * d.w;
+                aS1[h] += gi;
+                aS2[h] += gi * y[h];
+            }
+            // pin the chunk order: hipcc otherwise computes the masked gradients of all 8 chunks first and keeps them (and the 8
+            // dy4 rows, and the unpacked y) live until the accumulation - ~100 registers, spilled and reloaded through vmcnt
+            asm volatile("" : "+v"(aW[0][0]), "+v"(aW[0][1]), "+v"(aW[1][0]), "+v"(aW[1][1]), "+v"(aW[2][0]), "+v"(aW[2][1]),
+                              "+v"(aW[3][0]), "+v"(aW[3][1]), "+v"(aS1[0]), "+v"(aS1[1]), "+v"(aS2[0]), "+v"(aS2[1]));
+        }
+    };
+    uint2 vA[H], vB[H];
+    uint4 dp;
+    int tile = blockIdx.x;
+    if (tile < ntile) {
+        issue_d(tile, dp);
+        issue_y(tile, 0, vA);
+        for (int buf = 0;; buf ^= 1) {
+            if (threadIdx.x < 128) {
+                sD[buf][ttl][fcl] = make_float4(bf16_bits_to_f32(dp.x & 0xffffu), __uint_as_float(dp.x & 0xffff0000u),
+                                                bf16_bits_to_f32(dp.y & 0xffffu), __uint_as_float(dp.y & 0xffff0000u));
+                sD[buf][ttl][fcl + 1] = make_float4(bf16_bits_to_f32(dp.z & 0xffffu), __uint_as_float(dp.z & 0xffff0000u),
+                                                    bf16_bits_to_f32(dp.w & 0xffffu), __uint_as_float(dp.w & 0xffff0000u));
+            }
+            __syncthreads();
+            issue_y(tile, 1, vB);
+            __builtin_amdgcn_sched_barrier(0);
+            reduce(0, buf, vA);
+            issue_d(tile + gridDim.x, dp);
+            issue_y(tile + gridDim.x, 0, vA);
+            __builtin_amdgcn_sched_barrier(0);
+            reduce(1, buf, vB);
+            tile += gridDim.x;
+            if (tile >= ntile) break;
+        }
+    }
+    float acc[24];                                       // [0,16) dW4[c][e], [16,20) s1[e], [20,24) s2[e]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { acc[c * 4 + 2 * h] = aW[c][h].x; acc[c * 4 + 2 * h + 1] = aW[c][h].y; }
+        acc[16 + 2 * h] = aS1[h].x; acc[17 + 2 * h] = aS1[h].y;
+        acc[20 + 2 * h] = aS2[h].x; acc[21 + 2 * h] = aS2[h].y;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)        // sum g*xhat = rstd * (sum g*y - mean * sum g) over the thread's own pixels
+        acc[20 + e] = (acc[20 + e] - mean[cq * 4 + e] * acc[16 + e]) * rstd[cq * 4 + e];
+    // lanes sharing a channel quad are 16 apart: butterfly over lane bits 4, 5, then across the 4 waves through LDS
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { acc[i] += __shfl_xor(acc[i], 16, 64); acc[i] += __shfl_xor(acc[i], 32, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) sred[wave][lane][i] = acc[i];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 384; o += 256) {       // [0,256) dW4[c][ci], [256,320) s1[ci], [320,384) s2[ci]
+        int ci, slot;
+        if (o < 256) { ci = o & 63; slot = (o >> 6) * 4 + (ci & 3); }
+        else if (o < 320) { ci = o - 256; slot = 16 + (ci & 3); }
+        else { ci = o - 320; slot = 20 + (ci & 3); }
+        const int q = ci >> 2;
+        atomicAdd(&red[o], (double)(sred[0][q][slot] + sred[1][q][slot] + sred[2][q][slot] + sred[3][q][slot]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Generic channels-last helpers on X[N][C], C = 4 * 2^k <= 1024.  Thread = (row slot, 4-channel group).
 
@@ -745,6 +882,14 @@ extern "C" int sarssl_stem_c4_bwd_sums(const void* y3, const void* dy4, const fl
                                        const float* mean, const float* rstd, int nb, int F, int Tn, double* red, int dtype,
                                        void* stream) {
     if (SARSSL_ZERO(red, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    static const int fast = []() { const char* e = getenv("SARSSL_C4_SUMS16"); return e ? atoi(e) : 1; }();
+    if (fast && dtype == SARSSL_BF16 && (F & 15) == 0 && (Tn & 15) == 0 && nb > 0) {
+        const long ntile = (long)nb * (F >> 4) * (Tn >> 4);
+        const int nblk = (int)(ntile < 1024 ? ntile : 1024);              // 4 workgroups per CU
+        stem_c4_bwd_sums16_kernel<<<nblk, 256, 0, ST>>>((const bf16*)y3, (const bf16*)dy4, W4, scale, shift, mean, rstd, nb, F, Tn, red);
+        SARSSL_CHECK_LAUNCH("stem_c4_bwd_sums16_kernel");
+        return 0;
+    }
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 1024);
     DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 1><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
                                                                      nb, F, Tn, (T*)nullptr, red, 1)));

@@ -288,9 +288,15 @@ def patch_bwd(de, pe, saved):
     a0, z4 = saved[-1][0], saved[-1][9]
     B, F, T, _ = a0.shape
     d = de.shape[1]
-    gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
-    mm_tn_acc(de, z4, gtmp, side=False)
-    hip.patch_wgrad_accum(gtmp, gbuf(pe[12].weight))
+    if _ABLATE_WGRAD:
+        pass
+    elif RT.dtype == torch.bfloat16 and RT.replay is None:   # split-K partials folded and re-laid-out in one pass (nothing zeroed)
+        ws, nslice = hip.gemm_tn_partials(de, z4, _wgrad_split(de.shape[0], d, F * 4, False))
+        hip.patch_wgrad_accum(ws, gbuf(pe[12].weight), nslice)
+    else:
+        gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
+        mm_tn_acc(de, z4, gtmp, side=False)
+        hip.patch_wgrad_accum(gtmp, gbuf(pe[12].weight))
     return mm_nn(de, _patch_w(pe[12], F), fp8=False)                                       # (B,T,F,4)
 
 
@@ -549,6 +555,8 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
     if fused is not None:                       # dq | dk | dv are written straight into one [M, 3d] buffer
         dqkv = torch.empty((M, 3 * d), dtype=RT.dtype, device=dev)
         dqu, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        if fused_attn:      # the content-score part of dq in its own buffer: its column sum (u_bias gradient) can then wait for the
+            dqu = torch.empty((M, d), dtype=RT.dtype, device=dev)     # block's batched launch instead of running before dq overwrites it
     else:
         dqu = torch.empty((M, d), dtype=RT.dtype, device=dev)
         dk = torch.empty((M, d), dtype=RT.dtype, device=dev)
@@ -571,7 +579,7 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
              sA=(H * T * T, T * T), sB=(T * d, dh), out=dposb, ldc=d, sC=(T * d, dh), precise=RT.precise)
     del dps
     return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev,
-                          drop=_next_drop(next_kind, saved))
+                          drop=_next_drop(next_kind, saved), dq_out=dqkv[:, :d] if fused is not None else dqu)
 
 
 def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ldg, scale, pa, sa):
@@ -596,15 +604,21 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
     return dps
 
 
-def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None):
+def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None, dq_out=None):
     """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
-    dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
-    hip.colsum(dposb.view(B, T * d), dpos, now=True)                 # consumed right below
-    dpos_rt = to_rt(dpos.view(T, d))
+    if dposb.dtype == RT.dtype:                                      # batch sum straight into the GEMM operand's dtype: one launch
+        dpos_rt = hip.colsum_store(dposb.view(B, T * d)).view(T, d)
+    else:
+        dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
+        hip.colsum(dposb.view(B, T * d), dpos, now=True)             # consumed right below
+        dpos_rt = to_rt(dpos.view(T, d))
     mm_tn_acc(dpos_rt, pe, gbuf(att.pos_proj.linear.weight))
-    hip.colsum(dqu, gbuf(att.u_bias).view(-1), now=True)             # dqu is overwritten (dq = dqu + dqv) just below
+    if dq_out is None:
+        dq_out = dqu
+    inplace = dq_out.data_ptr() == dqu.data_ptr()                    # dq = dqu + dqv overwrites dqu: its column sum has to run first
+    hip.colsum(dqu, gbuf(att.u_bias).view(-1), now=inplace)
     hip.colsum(dqv, gbuf(att.v_bias).view(-1))
-    dq = hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dqu)
+    dq = hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dq_out)
     if fused is not None:
         mm_tn_acc(dqkv, ln, fused[2])
         hip.colsum(dqkv, fused[3])

@@ -435,11 +435,28 @@ def patch_w(W, dtype):
     return out
 
 
-def patch_wgrad_accum(g, grad):
-    """grad (d,4,F,1) f32 += g [d][f*4+c] f32."""
+def patch_wgrad_accum(g, grad, nslice=1):
+    """grad (d,4,F,1) f32 += sum over the nslice slices of g [nslice][d][f*4+c] f32 (split-K partials of gemm_tn_partials)."""
     d, _, F, _ = grad.shape
-    assert g.is_contiguous() and grad.is_contiguous() and g.numel() == grad.numel()
-    _lib.call("sarssl_patch_wgrad_accum", _p(g), _p(grad), c_int(d), c_int(F), _stream())
+    assert g.is_contiguous() and grad.is_contiguous() and g.numel() == nslice * grad.numel()
+    _lib.call("sarssl_patch_wgrad_accum", _p(g), c_int(nslice), _p(grad), c_int(d), c_int(F), _stream())
+
+
+def gemm_tn_partials(dy, x, split):
+    """Split-K partial products of dy[M,N]^T @ x[M,K] (bf16) -> (ws f32 [nslice][N][K], nslice): the caller folds them."""
+    _need_cuda(dy, x)
+    Mr, N = dy.shape
+    K = x.shape[1]
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and split > 0
+    per = ((Mr + split - 1) // split + 63) // 64 * 64
+    nslice = (Mr + per - 1) // per
+    ws = torch.empty((nslice, N, K), dtype=torch.float32, device=dy.device)
+    _lib.call("sarssl_gemm", _p(dy), _p(x), c_void_p(0), c_int(BF16), c_int(BF16), c_int(F32), c_int(0), c_int(0), c_int(N), c_int(K),
+              c_int(Mr), c_long(dy.stride(0)), c_long(x.stride(0)), c_long(K), c_int(1), c_int(1),
+              c_long(0), c_long(0), c_long(0), c_long(0), c_long(0), c_long(0), c_float(1.0), c_float(1.0), c_void_p(0), c_int(0),
+              c_void_p(0), c_long(0), c_long(0), c_long(0), c_float(1.0), c_void_p(0), c_void_p(0), c_int(0), c_float(0.0),
+              c_ulonglong(0), c_int(0), _p(ws), c_int(split), c_int(0), _stream())
+    return ws, nslice
 
 
 def f64_accum(src, dst, scale=1.0):
@@ -830,6 +847,15 @@ def colsum(x2d, out_f32, now=False):
 
 
 _colsum_ctx = None
+
+
+def colsum_store(x2d, out=None):
+    """out[n] = sum_m x2d[m][n] in x2d's dtype (one launch, nothing to zero)."""
+    M, N = x2d.shape
+    if out is None:
+        out = torch.empty((N,), dtype=x2d.dtype, device=x2d.device)
+    _lib.call("sarssl_colsum_store", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(N), _p(out), c_int(dt(x2d)), _stream())
+    return out
 
 
 def colsum_flush():

@@ -1,5 +1,6 @@
 """Runs every hot kernel family of the pretraining step at BASELINE config-2 shapes (B = 64), each group preceded by a marker
-launch (tools/prof_marker.hip, grid = tag) - the target of tools/prof_counters.py's rocprofv3 --pmc passes."""
+launch (tools/prof_marker.hip, grid = tag) - the target of tools/prof_counters.py's rocprofv3 --pmc passes.
+PROF_TIME=1: no markers, each group timed with events (median / min over >= 15 calls; PROF_ONLY=30,31 selects groups)."""
 import ctypes
 import os
 import subprocess
@@ -18,6 +19,7 @@ if not os.path.exists(MARK) or os.path.getmtime(MARK) < os.path.getmtime(os.path
 _mk = ctypes.CDLL(MARK)
 dev = torch.device("cuda:0")
 NREP = int(os.environ.get("PROF_NREP", "3"))
+TIME = os.environ.get("PROF_TIME", "0") != "0"
 ONLY = set(int(t) for t in os.environ.get("PROF_ONLY", "").split(",") if t)
 
 TAGS = {}          # tag -> (label, algorithmic flop per launch, algorithmic bytes per launch)
@@ -29,6 +31,17 @@ def group(tag, label, fn, flop=0.0, nbytes=0.0):
         return
     fn()                                             # warm (allocations)
     torch.cuda.synchronize()
+    if TIME:                                         # PROF_TIME=1: event-timed median instead of the marker protocol
+        ts = []
+        for _ in range(max(NREP, 15)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort()
+        us = ts[len(ts) // 2]
+        print("%3d %-62s %8.1f us  min %8.1f%s%s" % (tag, label, us, ts[0], "  %6.0f TFLOP/s" % (flop / us / 1e6) if flop else "",
+                                                    "  %5.2f TB/s" % (nbytes / us / 1e6) if nbytes else ""), flush=True)
+        return
     _mk.prof_marker(ctypes.c_int(tag), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     for _ in range(NREP):
         fn()
