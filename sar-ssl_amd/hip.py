@@ -375,7 +375,7 @@ def stem_c1_bwd(dz1, y1, a0, aff, train, dW1, dgamma, dbeta):
     """One pass: dW1 (64,4,1,1) += ..., dgamma / dbeta (64) += BatchNorm(1) parameter gradients, from the gradient w.r.t.
     relu(bn1(y1))."""
     npix = a0.numel() // 4
-    ws = _f64ws(644, a0.device, "c1b")
+    ws = _sums(644, a0.device)                 # (arena slice: already zero, no memset launch)
     _lib.call("sarssl_stem_c1_bwd", _p(dz1), _p(y1), _p(a0), c_long(npix), _p(aff), c_int(1 if train else 0), _p(ws), _p(dW1),
               _p(dgamma), _p(dbeta), c_int(dt(a0)), _stream())
 
