@@ -68,13 +68,21 @@ __global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const long nthreads = (long)gridDim.x * blockDim.x;
-    constexpr int U = 4;                               // pixels in flight per thread: the pass is a pure 537 MB write stream
-    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads * U) {
-        float4 a[U];
+#ifndef SARSSL_C1F_U
+#define SARSSL_C1F_U 4
+#endif
+    constexpr int U = SARSSL_C1F_U;                    // pixels in flight per thread: the pass is a pure 537 MB write stream
+    // the input pixels of the NEXT round are requested before this round is computed and stored: the loads are tiny (8 bytes per
+    // pixel, shared by 8 lanes) but their latency was the whole round trip of a wave (3.7 TB/s of stores at 4 waves / SIMD)
+    float4 a[U], an[U];
+    long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = ld4(a0 + (min(g0 + u * nthreads, npix * 8 - 1) >> 3) * 4);
+    for (; g0 < npix * 8; g0 += nthreads * U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long g = min(g0 + u * nthreads, npix * 8 - 1);     // clamped, unconditional (results of the overshoot are dropped)
-            a[u] = ld4(a0 + (g >> 3) * 4);
+            const long g = min(g0 + (U + u) * nthreads, npix * 8 - 1);     // clamped, unconditional (results of the overshoot are dropped)
+            an[u] = ld4(a0 + (g >> 3) * 4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -92,6 +100,8 @@ __global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ 
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = an[u];
     }
     if (stats) {
 #pragma unroll
@@ -350,7 +360,7 @@ __global__ void stem_c1_bwd_finalize_kernel(const double* __restrict__ red, long
 // 8 lanes per pixel (one 16-byte chunk each), shuffle-reduced.
 template <typename T>
 __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __restrict__ W4, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4) {
+                                   const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4, int nstream) {
     const int cg = threadIdx.x & 7;
     float w[4][8], sc[8], sh[8];
 #pragma unroll
@@ -364,7 +374,14 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
     //  thread - 162 us; this one-chunk-per-iteration loop at 16 waves / CU: 146 us)
     const long npix = (long)nb * F * Tn;
     const long nthreads = (long)gridDim.x * blockDim.x;
-    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < npix * 8; g += nthreads) {
+    // nstream > 1: the 256-thread chunks are dealt round-robin to nstream equal address ranges, so the chip reads nstream moving
+    // windows instead of one (a single sequential read stream tops out near 3.8 TB/s on this part, two reach 5+)
+    const long nq = npix * 8 / 256;
+    const bool split = nstream > 1 && (npix * 8) % 256 == 0 && nq % nstream == 0;
+    const long qper = split ? nq / nstream : 0;
+    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads) {
+        long g = g0;
+        if (split) { const long q = g0 >> 8; g = ((q % nstream) * qper + q / nstream) * 256 + (g0 & 255); }
         const long p = g >> 3;
         const f8 v = ld8(y3 + p * 64 + cg * 8);
         float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void stem_c4_bwd_sums16_kernel(const bf16* __restrict__ y3, const bf16* __restrict__ dy4, const float* __restrict__ W4,
                                const float* __restrict__ scale, const float* __restrict__ shift,
                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                               int nb, int F, int Tn, double* __restrict__ red) {
+                               int nb, int F, int Tn, double* __restrict__ red, int nstream) {
     __shared__ float4 sD[2][16][17];                     // dy4 tile [frame][bin] (f32), two stages: one barrier per tile
     __shared__ float sred[4][16][24];
     const int cq = threadIdx.x & 15, ps = threadIdx.x >> 4;          // channels 4cq..4cq+3; frame ps of every bin row
@@ -547,7 +564,9 @@ void stem_c4_bwd_sums16_kernel(const bf16* __restrict__ y3, const bf16* __restri
     const int ttl = threadIdx.x >> 3 & 15, fcl = (threadIdx.x & 7) * 2;     // dy4 piece: frame ttl, bins fcl, fcl+1 (threads 0..127 stage it)
     const unsigned yoff = threadIdx.x * 8u, doff = (unsigned)((ttl * F + fcl) * 4) * 2u;
     constexpr int H = 8;
+    const int tper = (nstream > 1 && ntile % nstream == 0) ? ntile / nstream : 0;      // tiles dealt round-robin to nstream address ranges
     auto tile_base = [&](int tile, long& ybase, long& dbase) {
+        if (tper) tile = (tile % nstream) * tper + tile / nstream;
         // (hipcc divides on the vector unit and would keep everything derived from the quotients in vector registers)
         const int tt0 = __builtin_amdgcn_readfirstlane((tile % ttiles) << 4);
         const int r = tile / ttiles;
@@ -893,6 +912,12 @@ __global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __rest
 }
 
 // ================================================================================================ C ABI
+// grid caps of the stem passes: tuning knobs (A/B runs), e.g. SARSSL_GRID_C1F=2048
+static inline int grid_cap(const char* env, int dflt) {
+    const char* e = getenv(env);
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
 static inline int nblocks_for(long work, int per_block, int cap = 2048) {
     long b = (work + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -915,7 +940,8 @@ extern "C" int sarssl_mask_inputs(const float* x, const unsigned char* mp, const
 
 extern "C" int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, void* y1, double* stats, int dtype, void* stream) {
     if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    const int nblk = nblocks_for(npix * 8, 256, stats ? 1024 : 4096);
+    static const int cap_stats = grid_cap("SARSSL_GRID_C1F", 1024);
+    const int nblk = nblocks_for(npix * 8, 256, stats ? cap_stats : 4096);
     DISPATCH_T(dtype, (stem_c1_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)a0, W1, npix, (T*)y1, stats)));
     SARSSL_CHECK_LAUNCH("stem_c1_fwd_kernel");
     return 0;
@@ -949,7 +975,8 @@ extern "C" int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a
     static const int fast = []() { const char* e = getenv("SARSSL_C1_BWD16"); return e ? atoi(e) : 1; }();
     if (fast && dtype == SARSSL_BF16 && (npix & 63) == 0) {
         const long nb64 = npix >> 6;
-        stem_c1_bwd16_kernel<<<(int)(nb64 < 1024 ? nb64 : 1024), 256, 0, ST>>>((const bf16*)dz1, (const bf16*)y1, (const bf16*)a0, npix, aff, red);
+        static const int cap = grid_cap("SARSSL_GRID_C1B", 1024);
+        stem_c1_bwd16_kernel<<<(int)(nb64 < cap ? nb64 : cap), 256, 0, ST>>>((const bf16*)dz1, (const bf16*)y1, (const bf16*)a0, npix, aff, red);
     } else {
         const int nblk = nblocks_for(npix * 8, 256, 1024);
         DISPATCH_T(dtype, (stem_c1_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)y1, (const T*)a0, npix, aff, red)));
@@ -961,8 +988,10 @@ extern "C" int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a
 
 extern "C" int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F,
                                   int Tn, void* y4, int dtype, void* stream) {
-    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 4096);
-    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4)));
+    static const int cap = grid_cap("SARSSL_GRID_C4F", 8192);
+    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
+    static const int nstream = grid_cap("SARSSL_C4F_STREAMS", 1);
+    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, nstream)));
     SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel");
     return 0;
 }
@@ -987,8 +1016,10 @@ extern "C" int sarssl_stem_c4_bwd_sums(const void* y3, const void* dy4, const fl
     static const int fast = []() { const char* e = getenv("SARSSL_C4_SUMS16"); return e ? atoi(e) : 1; }();
     if (fast && dtype == SARSSL_BF16 && (F & 15) == 0 && (Tn & 15) == 0 && nb > 0) {
         const long ntile = (long)nb * (F >> 4) * (Tn >> 4);
-        const int nblk = (int)(ntile < 1024 ? ntile : 1024);              // 4 workgroups per CU
-        stem_c4_bwd_sums16_kernel<<<nblk, 256, 0, ST>>>((const bf16*)y3, (const bf16*)dy4, W4, scale, shift, mean, rstd, nb, F, Tn, red);
+        static const int cap = grid_cap("SARSSL_GRID_C4S", 1024);         // 4 workgroups per CU
+        const int nblk = (int)(ntile < cap ? ntile : cap);
+        static const int nstream = grid_cap("SARSSL_C4S_STREAMS", 1);
+        stem_c4_bwd_sums16_kernel<<<nblk, 256, 0, ST>>>((const bf16*)y3, (const bf16*)dy4, W4, scale, shift, mean, rstd, nb, F, Tn, red, nstream);
         SARSSL_CHECK_LAUNCH("stem_c4_bwd_sums16_kernel");
         return 0;
     }
@@ -1001,7 +1032,8 @@ extern "C" int sarssl_stem_c4_bwd_sums(const void* y3, const void* dy4, const fl
 extern "C" int sarssl_stem_c4_bwd_apply(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
                                         const float* mean, const float* rstd, int nb, int F, int Tn, const double* red,
                                         int use_stats, void* dy3, int dtype, void* stream) {
-    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 4096);
+    static const int cap = grid_cap("SARSSL_GRID_C4A", 4096);
+    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
     DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 2><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
                                                                      nb, F, Tn, (T*)dy3, (double*)red, use_stats)));
     SARSSL_CHECK_LAUNCH("stem_c4_bwd_kernel<apply>");

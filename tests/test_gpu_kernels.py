@@ -318,12 +318,13 @@ def test_conv3x3_dgrad_with_fused_bn_backward_sums(B, F, T):
 
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("train", [True, False])
-def test_stem_c4_backward_two_phase_matches_one_pass_plus_apply(dtp, train):
+@pytest.mark.parametrize("shape", [(2, 24, 40), (3, 32, 48)])      # ragged tiles (general kernel) / full 16 x 16 tiles (bf16: stem_c4_bwd_sums16_kernel)
+def test_stem_c4_backward_two_phase_matches_one_pass_plus_apply(dtp, train, shape):
     """sums-only pass + direct dy3 pass == (g3 + sums) pass followed by the in-place BatchNorm-backward normalisation."""
     from sar_ssl_amd import hip
     dev = _dev()
     g = torch.Generator().manual_seed(21)
-    B, F, T = 2, 24, 40
+    B, F, T = shape
     y3 = torch.randn((B, F, T, 64), generator=g).to(dtp).to(dev)
     dy4 = torch.randn((B, T, F, 4), generator=g).to(dtp).to(dev)
     W4 = (torch.randn((4, 64), generator=g) * 0.2).to(dev)
@@ -332,7 +333,8 @@ def test_stem_c4_backward_two_phase_matches_one_pass_plus_apply(dtp, train):
     g3, red_ref = hip.stem_c4_bwd(y3, dy4, W4, aff)
     dy3_ref = hip.cl_bn_bwd_apply(g3, y3, 64, aff, 1, True, train, red_ref[256:])
     dy3, red = hip.stem_c4_bwd_two_phase(y3, dy4, W4, aff, train)
-    assert _relerr(red, red_ref) < 1e-6
+    for a, b in ((0, 256), (256, 320), (320, 384)):           # dW4 | sum g | sum g*xhat (the 16-bit kernel forms the last from raw moments)
+        assert _relerr(red[a:b], red_ref[a:b]) < 2e-6
     assert _relerr(dy3.float(), dy3_ref.float()) < (1e-5 if dtp == torch.float32 else 1.5e-2)
 
 
@@ -790,3 +792,30 @@ def test_layernorm_bwd_fused_dropout_output_equals_act_bwd(dtp):
     assert 0.07 < frac < 0.13
     tol = 1e-6 if dtp == torch.float32 else 1e-2
     assert float((out2.float() - want.float()).abs().max()) <= tol * float(want.float().abs().max())
+
+
+def test_colsum_store_is_the_batch_sum_in_the_activation_dtype():
+    from sar_ssl_amd import hip
+    dev = _dev()
+    x = _mk((64, 40 * 256), torch.bfloat16, dev, 3)
+    got = hip.colsum_store(x)
+    ref = x.float().sum(0)
+    assert got.dtype == torch.bfloat16 and _relerr(got.float(), ref) < 6e-3
+    xf = _mk((7, 132), torch.float32, dev, 4)
+    assert _relerr(hip.colsum_store(xf), xf.double().sum(0)) < 1e-6
+
+
+def test_patch_weight_gradient_from_split_k_partials_equals_zeroed_accumulate():
+    """gemm_tn_partials + patch_wgrad_accum(nslice) == split-K product folded into a zeroed buffer, then re-laid-out."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    M, d, F = 1024, 256, 32
+    de = _mk((M, d), torch.bfloat16, dev, 5)
+    z4 = _mk((M, F * 4), torch.bfloat16, dev, 6)
+    ws, nslice = hip.gemm_tn_partials(de, z4, 8)
+    assert nslice == 8 and ws.shape == (8, d, F * 4)
+    got = torch.ones((d, 4, F, 1), device=dev)
+    hip.patch_wgrad_accum(ws, got, nslice)
+    full = de.float().t() @ z4.float()                                  # [d][f*4+c]
+    ref = 1.0 + full.view(d, F, 4).permute(0, 2, 1).reshape(d, 4, F, 1)
+    assert _relerr(got, ref) < 2e-3

@@ -99,6 +99,7 @@ def main():
     W1 = torch.randn((64, 4), device=dev)
     W4 = torch.randn((4, 64), device=dev)
     group(30, "stem_c1_fwd (4->64 + BN sums)", lambda: hip.stem_c1_fwd(a0, W1, want_stats=True), 0, tb + tb / 16)
+    group(36, "stem_c1_fwd (4->64, no sums)", lambda: hip.stem_c1_fwd(a0, W1), 0, tb + tb / 16)
     group(31, "stem_c4_fwd (BN+ReLU, 64->4)", lambda: hip.stem_c4_fwd(x, W4, sc, sh), 0, tb + tb / 16)
     dy4 = rnd(B, 256, 256, 4)
     group(32, "stem_c4_bwd two-phase (sums + apply)", lambda: hip.stem_c4_bwd_two_phase(x, dy4, W4, aff, True), 0, 3 * tb + 2 * tb / 16)
@@ -138,6 +139,17 @@ def main():
     group(50, "dwglu_fwd d=512 (GLU + depthwise conv + BN sums)", lambda: hip.dwglu_fwd(hh, wdw, B, T, want_stats=True), 0, 3 * eb)
     group(51, "dwglu_bwd d=512 (data gradient + GLU backward)", lambda: hip.dwglu_bwd(dcc, hh, wdw, B, T), 0, 5 * eb)
     group(52, "dwglu_wgrad d=512", lambda: hip.dwglu_wgrad(dcc, hh, gdw, B, T), 0, 3 * eb)
+    # ---- LayerNorm (csrc/elementwise.hip)
+    for tag, d in ((70, 256), (72, 512)):
+        xx, dyy, rr = rnd(Mr, d), rnd(Mr, d), rnd(Mr, d)
+        gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+        gg, gb = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        _, st = hip.layernorm_fwd(xx, gam, bet)
+        group(tag, "layernorm_fwd d=%d (M=16384)" % d, lambda: hip.layernorm_fwd(xx, gam, bet), 0, 2.0 * 2 * Mr * d)
+        group(tag + 1, "layernorm_bwd d=%d (+resid, dgamma/dbeta)" % d, lambda: hip.layernorm_bwd(dyy, xx, gam, st, resid=rr, dgamma=gg, dbeta=gb),
+              0, 2.0 * 4 * Mr * d)
+        group(tag + 4, "layernorm_bwd d=%d (+resid, dgamma/dbeta, dropout output)" % d,
+              lambda: hip.layernorm_bwd(dyy, xx, gam, st, resid=rr, dgamma=gg, dbeta=gb, drop=(0.1, 3, 0.5)), 0, 2.0 * 5 * Mr * d)
     # ---- fp8 GEMM (csrc/gemm_fp8.hip)
     for tag, (M_, N_, K_) in ((60, (Mr, 2048, 512)), (61, (Mr, 1024, 3072))):
         A = rnd(M_, K_); Bm = rnd(N_, K_, scale=0.05)
