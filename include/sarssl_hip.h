@@ -133,6 +133,18 @@ int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb, int F, int
 int sarssl_conv_taps(const float* W, void* fwd, void* dgr, int dtype, void* stream);
 int sarssl_patch_w(const float* W, void* out, int d, int F, int dtype, void* stream);
 int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad, int d, int F, void* stream);
+/* The first stem layer without its 64-channel output (reference: code/model.py:50-64, patch_embed[0:3] = Conv2d(4,64,1) + BatchNorm2d
+ * + ReLU): stem_c1_stats = BatchNorm sums [sum | sum sq] f64[128] of y1 = W1 a0 from the moments of a0 (mom14: f64[16] scratch);
+ * conv3x3_fwd_c1 / conv3x3_wgrad_c1_acc = the following 3x3 convolution (patch_embed[3]) and its weight gradient with the operand
+ * relu(bn1(W1 a0)) formed from a0 (B,F,T,4) bf16 while staging (return 1 = kernel disabled, nothing done);
+ * stem_c1_bwd_a0 = sarssl_stem_c1_bwd with y1 recomputed (npix % 64 == 0, bf16). */
+int sarssl_stem_c1_stats(const void* a0, long npix, const float* W1, double* mom14, double* sums128, int dtype, void* stream);
+int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const float* scale, const float* shift, const void* w, void* out,
+                          int nb, int F, int T, double* stats, void* stream);
+int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const float* W1, int nb, int F, int T, const float* scale,
+                                const float* shift, float* grad_oihw, float* partial, void* stream);
+int sarssl_stem_c1_bwd_a0(const void* dz1, const void* a0, const float* W1, long npix, const float* aff, int use_stats,
+                          double* red, float* dW1, float* dgamma, float* dbeta, void* stream);
 int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
                        int dtype, void* stream);
 int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,

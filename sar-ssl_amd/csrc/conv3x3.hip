@@ -48,10 +48,40 @@ struct ConvArgs {
     // stand-alone normalisation pass (cl_bn_bwd_apply: read 2, write 1 tensor of 537 MB) disappears
     const void* in2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
     int prio;           // != 0: raise the wave's issue priority for its MFMA phase (s_setprio), see sarssl_mfma_prio()
+    // first-layer INPUT mode of the ping-pong kernel (C1IN): `in` is the stem's 4-channel input a0 (B,F,T,4) and the convolution runs
+    // on relu(bn1(W1 a0)) formed while staging (c1_w = W1 f32[64][4], scale / shift = bn1's affine) - the 64-channel output of the
+    // first 1x1 layer is never stored or read (2 x 537 MB per encoder and pass at B = 64)
+    const float* c1_w;
 #ifdef CONV_STAMPS
     unsigned long long* stamps;
 #endif
 };
+
+// C1IN staging: 8 channels of relu(scale * (W1 a) + shift) for one pixel from its packed 4-channel input (lo = channels 0,1; hi = 2,3).
+// wp[c][h] = scale-folded weights of the channel pair h for input channel c, shp[h] = shifts: 16 packed FMAs + 8 max + 4 converts per
+// chunk - the same VALU work as unpack + affine + ReLU of a stored chunk.
+struct C1Const { sarssl_f32x2 wp[4][4], shp[4]; };
+__device__ __forceinline__ void c1_setup(C1Const& k, const float* W1, const float* scale, const float* shift, int c0) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int ch = c0 + 2 * h;
+        k.shp[h] = sarssl_f32x2{shift[ch], shift[ch + 1]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) k.wp[c][h] = sarssl_f32x2{scale[ch] * W1[ch * 4 + c], scale[ch + 1] * W1[(ch + 1) * 4 + c]};
+    }
+}
+__device__ __forceinline__ uint4 c1_chunk(uint32_t lo, uint32_t hi, bool valid, const C1Const& k) {
+    if (!valid) return make_uint4(0, 0, 0, 0);
+    const float a0 = bf16_bits_to_f32(lo & 0xffffu), a1 = __uint_as_float(lo & 0xffff0000u);
+    const float a2 = bf16_bits_to_f32(hi & 0xffffu), a3 = __uint_as_float(hi & 0xffff0000u);
+    uint32_t o[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const sarssl_f32x2 y = k.wp[0][h] * a0 + k.wp[1][h] * a1 + k.wp[2][h] * a2 + k.wp[3][h] * a3 + k.shp[h];
+        o[h] = pack2_bf16(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // per-thread constants of the BatchNorm-backward input transform for channels c0 .. c0+7: dy = cA*g + cB*y + cC
 struct BnInConst { float sc[8], sh[8], cA[8], cB[8], cC[8]; };
@@ -409,7 +439,7 @@ __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int
     asm volatile("" ::: "memory");
 }
 
-template <bool BNRED, bool BNIN = false>
+template <bool BNRED, bool BNIN = false, bool C1IN = false>
 __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     typedef bf16 T;
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
@@ -446,6 +476,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
     BnInConst kin;
     if (BNIN) bnin_setup(kin, a.bnin_aff, a.bnin_red, a.bnin_use_stats, (long)a.nb * F * Tn, cch * 8);
+    C1Const kc1;
+    if (C1IN) c1_setup(kc1, a.c1_w, a.scale, a.shift, cch * 8);
 
     // lane-constant fragment addresses; this wave computes rows 2*hw and 2*hw+1 (32 pixels x 64 channels each)
     int laneW[4], laneX[3][4];
@@ -468,18 +500,23 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     // addresses: row bases are scalar (tile coordinates are wave-uniform), each thread adds ONE byte offset (its clamped frame and chunk)
     auto issue_loads = [&](const TileCoord tc) {
         const int tcl = min(max(tc.t0 - 1 + pc, 0), Tn - 1);
-        const unsigned voff = (unsigned)(tcl * 64 + cch * 8) * 2u;
+        const unsigned voff = C1IN ? (unsigned)tcl * 8u : (unsigned)(tcl * 64 + cch * 8) * 2u;
         const long img = (long)tc.b * F;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int f = min(max(tc.f0 - 1 + i, 0), F - 1);                      // (clamped: unconditional loads, see load_chunk_clamped)
-            const long rowb = (img + f) * (long)Tn * 128;                        // bytes
-            regs[i].u = *(const uint4*)((const char*)in + rowb + voff);
+            const long rowb = (img + f) * (long)Tn * (C1IN ? 8 : 128);           // bytes
+            if (C1IN) { const uint2 q = *(const uint2*)((const char*)in + rowb + voff); regs[i].u.x = q.x; regs[i].u.y = q.y; }
+            else regs[i].u = *(const uint4*)((const char*)in + rowb + voff);
             if (BNIN) regs2[i].u = *(const uint4*)((const char*)in2 + rowb + voff);
         }
         {
             const int hr = pc >> 1, te = tc.t0 + PTC - 1 + (pc & 1);        // (threads >= 160: an unused, harmless extra chunk)
-            regs[HR] = load_chunk_clamped<T>(in, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
+            if (C1IN) {
+                const int f = min(max(tc.f0 - 1 + hr, 0), F - 1), t = min(max(te, 0), Tn - 1);
+                const uint2 q = *(const uint2*)(in + (((long)tc.b * F + f) * Tn + t) * 4);
+                regs[HR].u.x = q.x; regs[HR].u.y = q.y;
+            } else regs[HR] = load_chunk_clamped<T>(in, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
             if (BNIN) regs2[HR] = load_chunk_clamped<T>(in2, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
         }
     };
@@ -491,12 +528,14 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             const int f = tc.f0 - 1 + i;
             const bool ok = tv && f >= 0 && f < F;
             *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = BNIN ? bnin_chunk(regs[i].u, regs2[i].u, ok, kin)
+                                                        : C1IN ? c1_chunk(regs[i].u.x, regs[i].u.y, ok, kc1)
                                                              : xform_chunk<T>(regs[i], ok, a.prologue, sc, sh, 0);
         }
         if (htid < 160) {
             const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
             const bool ok = f >= 0 && f < F && te < Tn;
             *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = BNIN ? bnin_chunk(regs[HR].u, regs2[HR].u, ok, kin)
+                                                                                  : C1IN ? c1_chunk(regs[HR].u.x, regs[HR].u.y, ok, kc1)
                                                                                        : xform_chunk<T>(regs[HR], ok, a.prologue, sc, sh, 0);
         }
     };
@@ -673,6 +712,7 @@ struct WgradArgs {
     int part_dy, part_z;
     // BatchNorm-backward transform of the dy operand (see ConvArgs::in2): dy holds dz, dy2 the pre-BN activations (bf16 only)
     const void* dy2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
+    const float* c1_w;    // first-layer input mode (see ConvArgs::c1_w): zin = a0 (B,F,T,4), the operand relu(bn1(W1 a0)) is formed while staging
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int pix_base, int ch_base, int lane) {
@@ -859,6 +899,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #define WHC (WTC + 2)
 #define WX_ELEMS (HR * WHC * 64)
 #define WY_ELEMS (TR * WTC * 64)
+template <bool C1IN = false>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     typedef bf16 T;
     __shared__ __attribute__((aligned(16))) uint16_t sYb[2][WY_ELEMS];   // dy tiles  [8*32 px][64 co]
@@ -898,6 +939,18 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+    C1Const kc1;
+    if (C1IN) c1_setup(kc1, a.c1_w, a.scale, a.shift, cch * 8);
+    auto load_z = [&](int b, int f, int t) {                    // clamped, unconditional (load_chunk_clamped); C1IN: the pixel's 4 input channels
+        Chunk<T> c;
+        if (C1IN) {
+            f = min(max(f, 0), F - 1); t = min(max(t, 0), Tn - 1);
+            const uint2 q = *(const uint2*)(zin + (((long)b * F + f) * Tn + t) * 4);
+            c.u.x = q.x; c.u.y = q.y;
+        } else c = load_chunk_clamped<T>(zin, b, f, t, F, Tn, cch * 8);
+        return c;
+    };
+    auto xform_z = [&](const Chunk<T>& c, bool ok) { return C1IN ? c1_chunk(c.u.x, c.u.y, ok, kc1) : xform_chunk<T>(c, ok, a.prologue, sc, sh, 0); };
 
     // staging: thread = (row parity pr, pixel column pcol of 32, 8-channel chunk): halo rows pr, pr+2, .. pr+8 and dy rows pr, pr+2, ..
     // pr+6 of its column; threads < 160 also one chunk of halo columns 32 / 33
@@ -906,10 +959,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     auto coord = [&](int tile) { TileCoord c; c.t0 = (tile % tiles_t) * WTC; tile /= tiles_t; c.f0 = (tile % tiles_f) * TR; c.b = tile / tiles_f; return c; };
     auto issue_loads = [&](const TileCoord tc) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) rz[k] = load_chunk_clamped<T>(zin, tc.b, tc.f0 - 1 + pr + 2 * k, tc.t0 - 1 + pcol, F, Tn, cch * 8);
+        for (int k = 0; k < 5; ++k) rz[k] = load_z(tc.b, tc.f0 - 1 + pr + 2 * k, tc.t0 - 1 + pcol);
         {
             const int q = tid >> 3, hr = q >> 1, te = tc.t0 + WTC - 1 + (q & 1);        // (threads >= 160: an unused, harmless extra chunk)
-            rz[5] = load_chunk_clamped<T>(zin, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
+            rz[5] = load_z(tc.b, tc.f0 - 1 + hr, te);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) ry[k] = load_chunk_clamped<T>(dy, tc.b, tc.f0 + pr + 2 * k, tc.t0 + pcol, F, Tn, cch * 8);
@@ -924,11 +977,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
             for (int k = 0; k < 5; ++k) {
                 if ((piece == 0) != (k < 3)) continue;
                 const int i = pr + 2 * k, f = tc.f0 - 1 + i;
-                *(uint4*)&sX[swzc(i * WHC + pcol, pcol, cch)] = xform_chunk<T>(rz[k], tv && f >= 0 && f < F, a.prologue, sc, sh, 0);
+                *(uint4*)&sX[swzc(i * WHC + pcol, pcol, cch)] = xform_z(rz[k], tv && f >= 0 && f < F);
             }
             if (piece == 1 && tid < 160) {
                 const int q = tid >> 3, hr = q >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + WTC - 1 + (q & 1);
-                *(uint4*)&sX[swzc(hr * WHC + WTC + (q & 1), WTC + (q & 1), cch)] = xform_chunk<T>(rz[5], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, 0);
+                *(uint4*)&sX[swzc(hr * WHC + WTC + (q & 1), WTC + (q & 1), cch)] = xform_z(rz[5], f >= 0 && f < F && te < Tn);
             }
         } else {
             const int ty = tc.t0 + pcol;
@@ -1082,6 +1135,30 @@ extern "C" int sarssl_conv3x3_dgrad_bnin(const void* dz_in, const void* w, void*
     return 0;
 }
 
+// 3x3 convolution of relu(bn1(W1 a0)) straight from the stem's 4-channel input a0 (B,F,T,4) bf16: W1 f32[64][4], scale / shift = bn1's
+// affine; out (B,F,T,64) bf16 and, optionally, stats = [sum | sum of squares] of the stored output.  bf16 ping-pong kernel only
+// (returns 1 when that kernel is disabled so the caller can fall back to stem_c1_fwd + sarssl_conv3x3_fwd).
+extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const float* scale, const float* shift, const void* w, void* out,
+                                     int nb, int F, int T, double* stats, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && a0 && W1 && scale && shift, "sarssl_conv3x3_fwd_c1");
+    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
+    if (!use_pp) return 1;
+    if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    ConvArgs a = {};
+#ifdef CONV_STAMPS
+    a.stamps = g_conv_stamps_host;
+#endif
+    a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
+    a.stats = stats;
+    a.in = a0; a.w = w; a.out = out; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
+    a.nb = nb; a.F = F; a.T = T;
+    const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
+    const int ncu = sarssl_cu_count();
+    conv3x3_fwd_pp_kernel<false, false, true><<<npairs < ncu ? npairs : ncu, 512, 0, (hipStream_t)stream>>>(a);
+    SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1in>");
+    return 0;
+}
+
 static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                           const float* scale, const float* shift, int precise, float* ws, double* stats, const void* bn_y,
                           const float* bn_aff, void* stream) {
@@ -1210,7 +1287,7 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
     const int grid = conv_grid(nb, F, T);
     const int rblocks = W_ELEMS / 64;
     if (dtype == SARSSL_BF16) {
-        if (wgrad_db_enabled()) { const int g2 = wgrad_db_grid(nb, F, T); conv3x3_wgrad_db_kernel<<<g2, 512, 0, st>>>(a); wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, g2, dW, 0); }
+        if (wgrad_db_enabled()) { const int g2 = wgrad_db_grid(nb, F, T); conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a); wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, g2, dW, 0); }
         else { conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a); wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid, dW, 0); }
     } else if (dtype == SARSSL_F32) {
         const int npass = precise ? 3 : 1;
@@ -1236,7 +1313,7 @@ extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb,
     hipStream_t st = (hipStream_t)stream;
     if (wgrad_db_enabled()) {
         const int g2 = wgrad_db_grid(nb, F, T);
-        conv3x3_wgrad_db_kernel<<<g2, 512, 0, st>>>(a);
+        conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a);
         wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
     } else {
         const int grid = conv_grid(nb, F, T);
@@ -1244,5 +1321,22 @@ extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb,
         wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, grid, nullptr, 0, grad_oihw);
     }
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel(acc)");
+    return 0;
+}
+// The same with the input operand relu(bn1(W1 a0)) formed from the stem's 4-channel input a0 (B,F,T,4) bf16 while staging (W1 f32[64][4],
+// scale / shift = bn1's affine): the first layer's 64-channel output is not read.  Double-buffered bf16 kernel only (returns 1 when
+// it is disabled: SARSSL_WGRAD_DB=0).
+extern "C" int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const float* W1, int nb, int F, int T, const float* scale,
+                                           const float* shift, float* grad_oihw, float* partial, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && grad_oihw && partial && W1 && scale && shift, "sarssl_conv3x3_wgrad_c1_acc");
+    if (!wgrad_db_enabled()) return 1;
+    WgradArgs a = {};
+    a.dy = dy; a.zin = a0; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
+    a.partial = partial; a.nb = nb; a.F = F; a.T = T;
+    hipStream_t st = (hipStream_t)stream;
+    const int g2 = wgrad_db_grid(nb, F, T);
+    conv3x3_wgrad_db_kernel<true><<<g2, 512, 0, st>>>(a);
+    wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
+    SARSSL_CHECK_LAUNCH("conv3x3_wgrad_db_kernel<c1in>");
     return 0;
 }

@@ -252,9 +252,12 @@ __global__ __launch_bounds__(256) void stem_c1_bwd_kernel(const T* __restrict__ 
 // accumulators instead of 84), 4 waves / SIMD, four pixels (12 8-byte loads) requested before the first is used, packed f32 math, and
 // the accumulators pinned after every pixel so that hipcc does not keep four pixels' worth of intermediates live.  The general kernel
 // had one pixel (40 bytes) in flight per thread at 3 waves / SIMD: 253 us for 1.1 GB (4.4 TB/s) at B = 64.
+// FROM_A0: y1 = W1 a0 is recomputed from the 4-channel input (4 packed FMAs per channel pair) instead of being read - the first
+// stem layer's output is then never stored (engine.stem_fwd: the 3x3 convolution behind it forms it while staging, too).
+template <bool FROM_A0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void stem_c1_bwd16_kernel(const bf16* __restrict__ dz1, const bf16* __restrict__ y1, const bf16* __restrict__ a0, long npix,
-                          const float* __restrict__ aff, double* __restrict__ red) {
+                          const float* __restrict__ aff, double* __restrict__ red, const float* __restrict__ W1) {
     typedef sarssl_f32x2 f2;
     __shared__ float sred[4][16][44];
     const int cq = threadIdx.x & 15, ps = threadIdx.x >> 4;          // channels 4cq..4cq+3; pixel slot 0..15
@@ -270,6 +273,13 @@ void stem_c1_bwd16_kernel(const bf16* __restrict__ dz1, const bf16* __restrict__
         if (sc < 0.f) { t = -t; sgn[e] = 0x80000000u; }
         thr[e] = t;
         if (e & 1) { xa[e >> 1].y = rs; xb[e >> 1].y = -mu * rs; } else { xa[e >> 1].x = rs; xb[e >> 1].x = -mu * rs; }
+    }
+    f2 w1p[4][2];                                                     // FROM_A0: W1[channel pair][c]
+    if (FROM_A0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w1p[c][h] = f2{W1[(cq * 4 + 2 * h) * 4 + c], W1[(cq * 4 + 2 * h + 1) * 4 + c]};
     }
     f2 aG[4][2], aX[4][2], aS1[2], aS2[2], aSa[2];                    // G[c][pair], X[c][pair], s1, s2 [pair], Sa[c pair]
 #pragma unroll
@@ -289,17 +299,18 @@ void stem_c1_bwd16_kernel(const bf16* __restrict__ dz1, const bf16* __restrict__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             d[u] = *(const uint2*)((const char*)(dzb + u * 1024) + yoff);
-            v[u] = *(const uint2*)((const char*)(yb + u * 1024) + yoff);
+            if (!FROM_A0) v[u] = *(const uint2*)((const char*)(yb + u * 1024) + yoff);
             a[u] = *(const uint2*)((const char*)(ab + u * 64) + aoff);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float av[4] = {bf16_bits_to_f32(a[u].x & 0xffffu), __uint_as_float(a[u].x & 0xffff0000u),
                                  bf16_bits_to_f32(a[u].y & 0xffffu), __uint_as_float(a[u].y & 0xffff0000u)};
-            const unsigned yr[2] = {v[u].x, v[u].y}, dr[2] = {d[u].x, d[u].y};
+            const unsigned yr[2] = {FROM_A0 ? 0u : v[u].x, FROM_A0 ? 0u : v[u].y}, dr[2] = {d[u].x, d[u].y};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f2 y = f2{bf16_bits_to_f32(yr[h] & 0xffffu), __uint_as_float(yr[h] & 0xffff0000u)};
+                const f2 y = FROM_A0 ? w1p[0][h] * av[0] + w1p[1][h] * av[1] + w1p[2][h] * av[2] + w1p[3][h] * av[3]
+                                     : f2{bf16_bits_to_f32(yr[h] & 0xffffu), __uint_as_float(yr[h] & 0xffff0000u)};
                 const f2 dd = f2{bf16_bits_to_f32(dr[h] & 0xffffu), __uint_as_float(dr[h] & 0xffff0000u)};
                 const f2 g = f2{__uint_as_float(__float_as_uint(y.x) ^ sgn[2 * h]) > thr[2 * h] ? dd.x : 0.f,
                                 __uint_as_float(__float_as_uint(y.y) ^ sgn[2 * h + 1]) > thr[2 * h + 1] ? dd.y : 0.f};
@@ -976,13 +987,84 @@ extern "C" int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a
     if (fast && dtype == SARSSL_BF16 && (npix & 63) == 0) {
         const long nb64 = npix >> 6;
         static const int cap = grid_cap("SARSSL_GRID_C1B", 1024);
-        stem_c1_bwd16_kernel<<<(int)(nb64 < cap ? nb64 : cap), 256, 0, ST>>>((const bf16*)dz1, (const bf16*)y1, (const bf16*)a0, npix, aff, red);
+        stem_c1_bwd16_kernel<false><<<(int)(nb64 < cap ? nb64 : cap), 256, 0, ST>>>((const bf16*)dz1, (const bf16*)y1, (const bf16*)a0, npix, aff, red, nullptr);
     } else {
         const int nblk = nblocks_for(npix * 8, 256, 1024);
         DISPATCH_T(dtype, (stem_c1_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)y1, (const T*)a0, npix, aff, red)));
     }
     stem_c1_bwd_finalize_kernel<<<1, 256, 0, ST>>>(red, npix, aff, use_stats, dW1, dgamma, dbeta);
     SARSSL_CHECK_LAUNCH("stem_c1_bwd_kernel");
+    return 0;
+}
+
+// The same pass without y1: y1 = W1 a0 is recomputed (bf16 activations, npix % 64 == 0; W1 = the 64 x 4 first-layer weight).
+extern "C" int sarssl_stem_c1_bwd_a0(const void* dz1, const void* a0, const float* W1, long npix, const float* aff, int use_stats,
+                                     double* red, float* dW1, float* dgamma, float* dbeta, void* stream) {
+    SARSSL_REQUIRE(npix > 0 && (npix & 63) == 0 && red && dW1 && dgamma && dbeta && W1, "sarssl_stem_c1_bwd_a0");
+    if (SARSSL_ZERO(red, 644 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    static const int cap = grid_cap("SARSSL_GRID_C1B", 1024);
+    const long nb64 = npix >> 6;
+    stem_c1_bwd16_kernel<true><<<(int)(nb64 < cap ? nb64 : cap), 256, 0, ST>>>((const bf16*)dz1, nullptr, (const bf16*)a0, npix, aff, red, W1);
+    stem_c1_bwd_finalize_kernel<<<1, 256, 0, ST>>>(red, npix, aff, use_stats, dW1, dgamma, dbeta);
+    SARSSL_CHECK_LAUNCH("stem_c1_bwd16_kernel<a0>");
+    return 0;
+}
+
+// BatchNorm(1) statistics of y1 = W1 a0 without forming y1: sum_p y1[co] = W1[co] . Sa and sum_p y1[co]^2 = W1[co]^T Saa W1[co] with
+// Sa = sum_p a0[p] (4) and Saa = sum_p a0[p] a0[p]^T (10 unique entries) - one pass over the 4-channel input (33 MB at B = 64).
+// mom: f64[14] = [Sa | Saa upper triangle, row-major], zeroed by the caller.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_a0_moments_kernel(const T* __restrict__ a0, long npix, double* __restrict__ mom) {
+    __shared__ float sred[4][14];
+    float acc[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) acc[i] = 0.f;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += nthreads) {
+        const float4 a = ld4(a0 + p * 4);
+        const float v[4] = {a.x, a.y, a.z, a.w};
+        int k = 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += v[i];
+#pragma unroll
+            for (int j = i; j < 4; ++j) { acc[k] = fmaf(v[i], v[j], acc[k]); ++k; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 14; ++i) sred[wave][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 14) atomicAdd(&mom[threadIdx.x], (double)(sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x]));
+}
+// sums[co] = W1[co] . Sa, sums[64 + co] = W1[co]^T Saa W1[co]   (f64; the layout bn_finalize / sarssl_bn_train_affine take)
+__global__ void stem_c1_stats_from_moments_kernel(const double* __restrict__ mom, const float* __restrict__ W1, double* __restrict__ sums) {
+    const int co = threadIdx.x;
+    if (co >= 64) return;
+    double w[4];
+    for (int c = 0; c < 4; ++c) w[c] = (double)W1[co * 4 + c];
+    double s = 0.0, q = 0.0;
+    int k = 4;
+    for (int i = 0; i < 4; ++i) {
+        s += w[i] * mom[i];
+        for (int j = i; j < 4; ++j) { q += (i == j ? 1.0 : 2.0) * w[i] * w[j] * mom[k]; ++k; }
+    }
+    sums[co] = s; sums[64 + co] = q;
+}
+extern "C" int sarssl_stem_c1_stats(const void* a0, long npix, const float* W1, double* mom14, double* sums128, int dtype, void* stream) {
+    SARSSL_REQUIRE(npix > 0 && mom14 && sums128 && W1, "sarssl_stem_c1_stats");
+    if (SARSSL_ZERO(mom14, 14 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for(npix, 256 * 4, 512);
+    DISPATCH_T(dtype, (stem_a0_moments_kernel<T><<<nblk, 256, 0, ST>>>((const T*)a0, npix, mom14)));
+    stem_c1_stats_from_moments_kernel<<<1, 64, 0, ST>>>(mom14, W1, sums128);
+    SARSSL_CHECK_LAUNCH("stem_a0_moments_kernel");
     return 0;
 }
 

@@ -220,13 +220,13 @@ def _cached(module, name, builder):
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm plumbing
-def bn_affine(x, C, bn, train, sums=None):
+def bn_affine(x, C, bn, train, sums=None, N=None):
     """BatchNorm{1,2}d affine for channels-last x: batch statistics (+ running-stat update) in train mode, running
     statistics in eval mode.  Returns aff = [scale, shift, mean, rstd] (4, C) f32.  ``sums``: statistics already
-    accumulated by the producing kernel's epilogue (saves one pass over x)."""
+    accumulated by the producing kernel's epilogue (saves one pass over x; x may then be None with the element count N)."""
     if train:
         return hip.bn_train_affine(x, C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
-                                   bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum, sums=sums)
+                                   bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum, sums=sums, N=N)
     return hip.bn_eval_affine(C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, eps=bn.eps)
 
 
@@ -254,10 +254,24 @@ def stem_fwd(a0, pe, train, saved):
     """``patch_embed`` (code/model.py:50-64) on channels-last a0 (B,F,T,4) -> [B*T, d]."""
     B, F, T, _ = a0.shape
     fuse = train and RT.dtype == torch.bfloat16          # BatchNorm sums come out of the producing kernel's epilogue
-    y1, s1 = hip.stem_c1_fwd(a0, pe[0].weight.data.view(64, 4), want_stats=True) if train else (hip.stem_c1_fwd(a0, pe[0].weight.data.view(64, 4)), None)
-    aff1 = bn_affine(y1, 64, pe[1], train, sums=s1)
-    y2, s2 = hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], want_stats=True) if fuse else \
-        (hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], precise=RT.precise), None)
+    W1 = pe[0].weight.data.view(64, 4)
+    y1 = y2 = None
+    if fuse and _C1IN and (B * F * T) % 64 == 0 and not RT.inference:
+        # the first layer's 64-channel output is never stored: its BatchNorm statistics follow from the 4 + 10 moments of the
+        # 4-channel input, the first 3x3 convolution (and, in backward, its weight gradient and the layer's own backward pass) form
+        # relu(bn1(W1 a0)) from a0 while staging - 4 x 537 MB less HBM traffic per encoder and step at B = 64
+        aff1 = bn_affine(None, 64, pe[1], train, sums=hip.stem_c1_stats(a0, W1), N=B * F * T)
+        r = hip.conv3x3_fwd_c1(a0, W1, aff1[0], aff1[1], _taps(pe[3])[0], want_stats=True)
+        if r is not None:
+            y2, s2 = r
+        else:
+            y1 = hip.stem_c1_fwd(a0, W1)
+    else:
+        y1, s1 = hip.stem_c1_fwd(a0, W1, want_stats=True) if train else (hip.stem_c1_fwd(a0, W1), None)
+        aff1 = bn_affine(y1, 64, pe[1], train, sums=s1)
+    if y2 is None:
+        y2, s2 = hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], want_stats=True) if fuse else \
+            (hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], precise=RT.precise), None)
     aff2 = bn_affine(y2, 64, pe[4], train, sums=s2)
     y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
         (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
@@ -279,6 +293,7 @@ _BNIN = os.environ.get("SARSSL_BNIN", "0") != "0"
 _DWGLU = os.environ.get("SARSSL_DWGLU", "1") != "0"             # 0: separate glu / dwconv / cl_stats kernels (A/B runs)
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
+_C1IN = os.environ.get("SARSSL_C1IN", "1") != "0"             # 0: store the first layer's 64-channel output (A/B runs)
 
 
 def patch_bwd(de, pe, saved):
@@ -304,6 +319,10 @@ def stem_bwd(dz4, pe, saved):
     """Backward of the CNN stem below the patch GEMM (``dz4`` = patch_bwd's result)."""
     a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
     B, F, T, _ = a0.shape
+    W1 = pe[0].weight.data.view(64, 4)
+
+    def need_y1():                    # y1 was not stored (stem_fwd, _C1IN) and a fallback path wants it: recompute it
+        return y1 if y1 is not None else hip.stem_c1_fwd(a0, W1)
     red4 = hip.cl_bn_bwd_reduce(dz4, y4, 4, aff4, RELU)
     dy4 = hip.cl_bn_bwd_apply(dz4, y4, 4, aff4, RELU, False, train, red4)
     bn_param_grads(pe[10], red4, 4)
@@ -332,16 +351,23 @@ def stem_bwd(dz4, pe, saved):
     # data gradients): in bf16 both form it while staging their tiles, so it is never written (cl_bn_bwd_apply: 3 x 537 MB at B = 64)
     dz1 = hip.conv3x3_dgrad_bnin(dz2, _taps(pe[3])[1], y2, aff2, red2, train) if (_BNIN and RT.dtype == torch.bfloat16) else None
     if dz1 is not None:
-        dW = hip.conv3x3_wgrad_bnin(dz2, y2, aff2, red2, y1, aff1[0], aff1[1], train)
+        dW = hip.conv3x3_wgrad_bnin(dz2, y2, aff2, red2, need_y1(), aff1[0], aff1[1], train)
     else:
         dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2)
-        dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise, acc_into=gbuf(pe[3].weight))
+        if y1 is None and hip.conv3x3_wgrad_c1(dy2, a0, W1, aff1[0], aff1[1], gbuf(pe[3].weight)):
+            dW = None
+        else:
+            dW = hip.conv3x3_wgrad(dy2, need_y1(), aff1[0], aff1[1], precise=RT.precise, acc_into=gbuf(pe[3].weight))
         dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
     if dW is not None:
         gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
     if _C1_FUSED == 2:      # everything the first layer needs from (dz1, y1, a0) in one pass: BN sums, dgamma/dbeta, dW1
-        hip.stem_c1_bwd(dz1, y1, a0, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
+        if y1 is None:
+            hip.stem_c1_bwd_a0(dz1, a0, W1, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
+        else:
+            hip.stem_c1_bwd(dz1, y1, a0, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
         return None
+    y1 = need_y1()
     red1 = hip.cl_bn_bwd_reduce(dz1, y1, 64, aff1, RELU)
     bn_param_grads(pe[1], red1, 64)
     if _C1_FUSED:           # dy1 feeds nothing but this weight gradient (the stem input is data): normalise it in registers

@@ -354,6 +354,23 @@ def stem_c1_fwd(a0, W1, want_stats=False):
     return (y, sums) if want_stats else y
 
 
+def stem_c1_stats(a0, W1):
+    """BatchNorm sums f64[128] = [sum | sum of squares] of y1 = W1 a0 from the 4 + 10 first / second moments of a0 (y1 is not formed)."""
+    npix = a0.numel() // 4
+    mom, sums = _sums(16, a0.device), _sums(128, a0.device)
+    _lib.call("sarssl_stem_c1_stats", _p(a0), c_long(npix), _p(W1), _p(mom), _p(sums), c_int(dt(a0)), _stream())
+    return sums
+
+
+def stem_c1_bwd_a0(dz1, a0, W1, aff, train, dW1, dgamma, dbeta):
+    """stem_c1_bwd with y1 = W1 a0 recomputed from the input instead of read (bf16, pixel count a multiple of 64)."""
+    npix = a0.numel() // 4
+    assert a0.dtype == torch.bfloat16 and npix % 64 == 0
+    ws = _sums(644, a0.device)
+    _lib.call("sarssl_stem_c1_bwd_a0", _p(dz1), _p(a0), _p(W1), c_long(npix), _p(aff), c_int(1 if train else 0), _p(ws), _p(dW1),
+              _p(dgamma), _p(dbeta), _stream())
+
+
 def stem_c1_wgrad(dy1, a0, grad_out):
     """grad_out (64,4,1,1) f32 += dW1."""
     npix = a0.numel() // 4
@@ -480,6 +497,42 @@ def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False, want_stats=Fals
     return (out, sums) if want_stats else out
 
 
+def conv3x3_fwd_c1(a0, W1, scale, shift, w_tap, want_stats=False):
+    """3x3 convolution of relu(scale * (W1 a0) + shift) straight from the stem's 4-channel input a0 (B,F,T,4) bf16 - the first layer's
+    64-channel output is formed while staging, never stored.  -> out (B,F,T,64) bf16 (or (out, stats f64[128])); None when the
+    ping-pong kernel is disabled."""
+    _need_cuda(a0, W1, scale, shift, w_tap)
+    B, F, T, C = a0.shape
+    assert C == 4 and a0.dtype == torch.bfloat16 and w_tap.dtype == torch.bfloat16 and a0.is_contiguous() and W1.is_contiguous()
+    out = torch.empty((B, F, T, 64), dtype=torch.bfloat16, device=a0.device)
+    stats = _sums(128, a0.device) if want_stats else None
+    fn = _lib.lib().sarssl_conv3x3_fwd_c1
+    with _Timed("conv3x3_fwd_c1"):
+        rc = fn(_p(a0), _p(W1), _p(scale), _p(shift), _p(w_tap), _p(out), c_int(B), c_int(F), c_int(T), _p(stats), _stream())
+    if rc == 1:
+        return None
+    _lib.check(rc, "sarssl_conv3x3_fwd_c1")
+    return (out, stats) if want_stats else out
+
+
+def conv3x3_wgrad_c1(dy, a0, W1, scale, shift, acc_into):
+    """Weight gradient of that convolution, added into the (64,64,3,3) f32 parameter-gradient buffer; the input operand is formed from a0
+    while staging.  False when the double-buffered kernel is disabled (nothing done)."""
+    _need_cuda(dy, a0, W1)
+    B, F, T, _ = a0.shape
+    assert a0.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and acc_into.shape == (64, 64, 3, 3) and acc_into.is_contiguous()
+    nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
+    nbytes.restype = c_long
+    part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), a0.device, "wgrad_part")
+    fn = _lib.lib().sarssl_conv3x3_wgrad_c1_acc
+    with _Timed("conv3x3_wgrad_kernel"):
+        rc = fn(_p(dy), _p(a0), _p(W1), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(acc_into), _p(part), _stream())
+    if rc == 1:
+        return False
+    _lib.check(rc, "sarssl_conv3x3_wgrad_c1_acc")
+    return True
+
+
 def conv3x3_dgrad_bnred(dy, w_tap_dgrad, y, aff):
     """dz = conv3x3(dy, flipped taps) and the BatchNorm-backward sums red f64[128] of the BN+ReLU in front (pre-BN activations
     ``y``, ``aff`` = (4,64) scale|shift|mean|rstd), accumulated in the convolution's epilogue (bf16).  Returns (dz, None) when the
@@ -562,13 +615,13 @@ def cl_stats(x, C):
     return sums, N
 
 
-def bn_train_affine(x, C, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, sums=None):
-    """sums: optional precomputed f64[2C] (sum | sum of squares) from a fused producer epilogue."""
+def bn_train_affine(x, C, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, sums=None, N=None):
+    """sums: optional precomputed f64[2C] (sum | sum of squares) from a fused producer epilogue (then x may be None with N given)."""
     if sums is None:
         sums, N = cl_stats(x, C)
-    else:
+    elif N is None:
         N = x.numel() // C
-    aff = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    aff = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
     _lib.call("sarssl_bn_finalize", _p(sums), c_long(N), c_int(C), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
               _p(running_mean), _p(running_var), _p(nbt), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), _stream())
     return aff

@@ -819,3 +819,82 @@ def test_patch_weight_gradient_from_split_k_partials_equals_zeroed_accumulate():
     full = de.float().t() @ z4.float()                                  # [d][f*4+c]
     ref = 1.0 + full.view(d, F, 4).permute(0, 2, 1).reshape(d, 4, F, 1)
     assert _relerr(got, ref) < 2e-3
+
+
+# ---------------------------------------------------------------- first stem layer without its stored output (engine._C1IN)
+def _c1_case(B, F, T, seed):
+    dev = _dev()
+    g = torch.Generator().manual_seed(seed)
+    a0 = torch.randn((B, F, T, 4), generator=g).bfloat16().to(dev)
+    W1 = (torch.randn((64, 4), generator=g) * 0.5).to(dev)
+    scale = (torch.rand(64, generator=g) + 0.5).to(dev)
+    scale[7] = -scale[7]
+    shift = (torch.randn(64, generator=g) * 0.3).to(dev)
+    return dev, g, a0, W1, scale, shift
+
+
+def test_first_layer_batchnorm_sums_from_input_moments():
+    from sar_ssl_amd import hip
+    dev, g, a0, W1, _, _ = _c1_case(3, 16, 24, 51)
+    hip.sums_arena_reset(dev)
+    got = hip.stem_c1_stats(a0, W1).clone()
+    y = a0.double().view(-1, 4) @ W1.double().t()
+    ref = torch.cat([y.sum(0), (y * y).sum(0)])
+    assert _relerr(got[:64], ref[:64]) < 1e-6 and _relerr(got[64:], ref[64:]) < 1e-6
+    _, s_stored = hip.stem_c1_fwd(a0, W1, want_stats=True)             # sums of the bf16-rounded stored y1: same up to its rounding
+    assert _relerr(s_stored[64:], ref[64:]) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 40), (1, 24, 72)])
+def test_conv3x3_from_the_4_channel_input_matches_the_stored_path(shape):
+    """conv3x3_fwd_c1 / conv3x3_wgrad_c1 (operand relu(bn1(W1 a0)) formed while staging) against an f64 restatement and against the
+    kernels that read a stored y1."""
+    from sar_ssl_amd import hip
+    B, F, T = shape
+    dev, g, a0, W1, scale, shift = _c1_case(B, F, T, 52)
+    w = (torch.randn((9, 64, 64), generator=g) * 0.05).bfloat16().to(dev)
+    hip.sums_arena_reset(dev)
+    r = hip.conv3x3_fwd_c1(a0, W1, scale, shift, w, want_stats=True)
+    assert r is not None
+    out, stats = r
+    z = torch.relu((a0.double().view(-1, 4) @ W1.double().t()) * scale.double() + shift.double()).view(B, F, T, 64)
+    zb = z.float().bfloat16().double()                                          # the operand is rounded to bf16 when staged
+    ref = torch.nn.functional.conv2d(zb.permute(0, 3, 1, 2), w.double().view(3, 3, 64, 64).permute(2, 3, 0, 1), padding=1).permute(0, 2, 3, 1)
+    assert _relerr(out.float(), ref) < 8e-3                                     # bf16 output rounding
+    ob = out.double().view(-1, 64)
+    assert _relerr(stats[:64], ob.sum(0)) < 1e-5 and _relerr(stats[64:], (ob * ob).sum(0)) < 1e-5
+    y1 = hip.stem_c1_fwd(a0, W1)                                                # stored path: y1 rounded to bf16 in between
+    out2 = hip.conv3x3_fwd(y1, w, scale, shift)
+    assert _relerr(out.float(), out2.float()) < 3e-2
+    # weight gradient
+    dy = torch.randn((B, F, T, 64), generator=g).bfloat16().to(dev)
+    gW = torch.zeros((64, 64, 3, 3), device=dev)
+    assert hip.conv3x3_wgrad_c1(dy, a0, W1, scale, shift, gW)
+    zp = torch.nn.functional.pad(zb.permute(0, 3, 1, 2), (1, 1, 1, 1))          # (B,64,F+2,T+2)
+    dyd = dy.double().permute(0, 3, 1, 2)
+    refW = torch.stack([torch.stack([torch.einsum("bofw,bifw->oi", dyd, zp[:, :, kh:kh + F, kw:kw + T]) for kw in range(3)], -1) for kh in range(3)], -2)
+    assert _relerr(gW, refW) < 2e-3
+    gW2 = torch.zeros((64, 64, 3, 3), device=dev)
+    hip.conv3x3_wgrad(dy, y1, scale, shift, acc_into=gW2)
+    assert _relerr(gW, gW2) < 2e-2
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_first_layer_backward_from_the_input_only(train):
+    from sar_ssl_amd import hip
+    dev, g, a0, W1, scale, shift = _c1_case(2, 16, 24, 53)
+    npix = a0.numel() // 4
+    dz1 = torch.randn((npix, 64), generator=g).bfloat16().to(dev)
+    mean = (torch.randn(64, generator=g) * 0.2).to(dev); rstd = (torch.rand(64, generator=g) + 0.5).to(dev)
+    aff = torch.stack([scale, shift, mean, rstd]).contiguous()
+    dW, dga, dbe = torch.zeros((64, 4, 1, 1), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    hip.sums_arena_reset(dev)
+    hip.stem_c1_bwd_a0(dz1, a0, W1, aff, train, dW, dga, dbe)
+    y = a0.double().view(-1, 4) @ W1.double().t()
+    gg = dz1.double() * ((y * scale.double() + shift.double()) > 0)
+    xh = (y - mean.double()) * rstd.double()
+    s1, s2 = gg.sum(0), (gg * xh).sum(0)
+    dy = scale.double() * ((gg - s1 / npix - xh * s2 / npix) if train else gg)
+    ref = dy.t() @ a0.double().view(-1, 4)
+    assert _relerr(dW.view(64, 4), ref) < 2e-5
+    assert _relerr(dbe, s1) < 1e-5 and _relerr(dga, s2) < 1e-5
