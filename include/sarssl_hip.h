@@ -145,6 +145,13 @@ int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const float* W1,
                                 const float* shift, float* grad_oihw, float* partial, void* stream);
 int sarssl_stem_c1_bwd_a0(const void* dz1, const void* a0, const float* W1, long npix, const float* aff, int use_stats,
                           double* red, float* dW1, float* dgamma, float* dbeta, void* stream);
+/* conv3x3_dgrad_c1red: data gradient of patch_embed[3] consumed in its epilogue (masked with relu'(bn1(W1 a0)) and contracted over the
+ * pixels against [a0 | 1] on the matrix cores): red f64[644] gets G at [co*4+c] and s1 at [512+co], nothing is stored;
+ * stem_c1_bwd_finalize_mom completes dW1 / dgamma / dbeta from (red, the input's moments mom14 of sarssl_stem_c1_stats). */
+int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const void* a0, const float* W1, const float* scale, const float* shift,
+                               int nb, int F, int T, double* red, void* stream);
+int sarssl_stem_c1_bwd_finalize_mom(const double* red, const double* mom14, const float* W1, long npix, const float* aff, int use_stats,
+                                    float* dW1, float* dgamma, float* dbeta, void* stream);
 int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
                        int dtype, void* stream);
 int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,

@@ -52,6 +52,12 @@ struct ConvArgs {
     // on relu(bn1(W1 a0)) formed while staging (c1_w = W1 f32[64][4], scale / shift = bn1's affine) - the 64-channel output of the
     // first 1x1 layer is never stored or read (2 x 537 MB per encoder and pass at B = 64)
     const float* c1_w;
+    // first-layer REDUCTION mode of the ping-pong kernel (C1RED): the launch is the data gradient of the first 3x3 convolution and its
+    // result dz1 = dL/d relu(bn1(W1 a0)) is only needed for the first layer's parameter gradients, so it is never stored: the epilogue
+    // masks it with relu'(bn1(W1 a0)) (one MFMA per accumulator tile recomputes the pre-activation from c1_a0 / c1_w / scale / shift)
+    // and contracts it over the pixels against [a0 | 1] on the matrix cores: c1_red (f64[644], sarssl_stem_c1_bwd's layout) receives
+    // G[co][c] = sum_p g a0[c] and s1[co] = sum_p g
+    const void* c1_a0; double* c1_red;
 #ifdef CONV_STAMPS
     unsigned long long* stamps;
 #endif
@@ -428,6 +434,26 @@ extern "C" int sarssl_conv_stamp_buffer(void* p) { g_conv_stamps_host = (unsigne
 #define PHC (PTC + 2)
 #define PX_ELEMS (HR * PHC * 64)                   // 21760 bf16 per half
 
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int pix_base, int ch_base, int lane) {
+    // rows = pixels (contraction), cols = channels: lane gets channel ch_base + (lane&31), 8 consecutive pixels
+    // starting at pix_base + (lane>>5)*8.  Two transpose reads of 4 pixels each.
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const int col = ch_base + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+    const int chunk = col >> 3, within = col & 7;
+    bf16x8 out;
+    s16x4 q[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = pix_base + (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
+        const uint16_t* addr = s + swz(p, chunk) + within;
+        q[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)addr);
+    }
+    union { s16x4 v[2]; bf16x8 b; } u;
+    u.v[0] = q[0]; u.v[1] = q[1];
+    out = u.b;
+    return out;
+}
+
 __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int lane) {
     __builtin_amdgcn_s_waitcnt(0xC07F);            // my LDS traffic has landed (lgkmcnt(0))
     if (lane == 0) atomicAdd(cnt, 1u);
@@ -439,13 +465,16 @@ __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int
     asm volatile("" ::: "memory");
 }
 
-template <bool BNRED, bool BNIN = false, bool C1IN = false>
+template <bool BNRED, bool BNIN = false, bool C1IN = false, bool C1RED = false>
 __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     typedef bf16 T;
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
     __shared__ float sStats[128];
-    __shared__ float sAff[256];
+    __shared__ float sAff[BNRED ? 256 : 1];
+    // C1RED: MFMA "A" fragments of the scale-folded first-layer weights, [co][16 k]: k 0..3 = bf16 high parts of scale*W1[co][c], 4 = of
+    // shift, 8..12 = the low parts (the input fragment repeats [a0 | 1] in both k halves: one MFMA gives the f32-accurate pre-activation)
+    __shared__ __attribute__((aligned(16))) uint16_t sC1[C1RED ? 64 * 16 : 8];
     __shared__ unsigned sSync[2];
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform ids as SCALARS (hipcc cannot prove tid >> 6 uniform): the tile coordinates (two integer divisions), row bases and
@@ -462,6 +491,14 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     if (tid < 128) sStats[tid] = 0.f;
     if (tid < 2) sSync[tid] = 0u;
     if (BNRED && tid < 256) sAff[tid] = a.bn_aff[tid];
+    if (C1RED) {
+        for (int q = tid; q < 64 * 16; q += 512) {
+            const int co = q >> 4, k = q & 15, c = k & 7;
+            const float v = c < 4 ? a.scale[co] * a.c1_w[co * 4 + c] : (c == 4 ? a.shift[co] : 0.f);
+            const uint32_t hi = f32_to_bf16_bits(v);
+            sC1[q] = (uint16_t)(k < 8 ? hi : f32_to_bf16_bits(v - bf16_bits_to_f32(hi)));
+        }
+    }
     const int cch = tid & 7;
     {
         const T* w = (const T*)a.w;
@@ -557,6 +594,11 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             bthr[e] = thr;
         }
     }
+    float gacc[2][4];                              // C1RED: lanes < 32: G[c = r][co = nb*32 + lane]; lanes >= 32: r = 0: s1[co = nb*32 + lane - 32]
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gacc[nb][r] = 0.f;
     const int nrounds = (npairs + gridDim.x - 1) / gridDim.x;
     int tile = tile_of(0);
     TileCoord tc = coord(tile < ntiles ? tile : 0);
@@ -623,9 +665,80 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                 yv[k] = *(const uint4*)((const uint16_t*)a.bn_y + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8);
             }
         }
+        uint2 av[C1RED ? 2 : 1];                               // C1RED: the 4 input channels of this lane's pixel (lane & 31) in both rows
+        bool pv[C1RED ? 2 : 1];
+        if (C1RED) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int f = tc.f0 + 2 * hw + j, t = tc.t0 + (lane & 31);
+                pv[j] = f < F && t < Tn;
+                av[j] = *(const uint2*)((const uint16_t*)a.c1_a0 + (((long)tc.b * F + min(f, F - 1)) * Tn + min(t, Tn - 1)) * 4);
+            }
+        }
         half_barrier(cnt, epoch, lane);                        // the half is done reading its input tile
         STAMP(6);
         uint16_t* stg = sX + hw * (64 * 64);                   // this wave's [64 px][64 co] slice (px = row * 32 + column)
+        if (C1RED) {
+            // (1) mask: pre-activation tile of the first layer in the accumulators' own layout (co x pixel), one MFMA per tile
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // av landed (the next tile's prefetch too: it had the whole MFMA loop)
+            uint16_t* a0t = sX + 4 * (64 * 64) + hw * 256;     // [4 c][64 px] of this wave, in the part of the input tile no slice uses
+            {
+                const int j = lane >> 5;                       // lanes < 32 file row 0, lanes >= 32 row 1 (both hold both rows' pixels)
+                const uint2 q = j ? av[1] : av[0];
+                uint16_t* d = a0t + j * 32 + (lane & 31);
+                d[0] = (uint16_t)(q.x & 0xffffu); d[64] = (uint16_t)(q.x >> 16); d[128] = (uint16_t)(q.y & 0xffffu); d[192] = (uint16_t)(q.y >> 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 wfr = *(const bf16x8*)&sC1[(i * 32 + (lane & 31)) * 16 + (lane >> 5) * 8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    union { uint4 u; bf16x8 b; } bx;
+                    bx.u = make_uint4(av[j].x, av[j].y, 0x00003f80u, 0u);          // [a0_0..a0_3, 1, 0, 0, 0]
+                    f32x16 y;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+                    y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, bx.b, y, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (y[r] > 0.f && pv[j]) ? acc[i][j][r] : 0.f;
+                }
+            }
+            // (2) masked gradient tile, bf16, [64 px][64 co] in the transpose-read layout (swz)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint2 w2;
+                        w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+                        w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                        *(uint2*)(stg + swz(j * 32 + (lane & 31), i * 4 + g) + 4 * (lane >> 5)) = w2;
+                    }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            // (3) G[c'][co] += sum_px [a0 | 1][px][c'] * g[px][co]: 4 k-steps of 16 pixels x 2 channel halves
+            f32x16 d2[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d2[nb][r] = 0.f;
+            const int m = lane & 31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                union { uint4 u; bf16x8 b; } ax;
+                ax.u = *(const uint4*)(a0t + min(m, 3) * 64 + ks * 16 + (lane >> 5) * 8);
+                if (m == 4) ax.u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                else if (m > 4) ax.u = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    d2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax.b, tr_frag(stg, ks * 16, nb * 32, lane), d2[nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[nb][r] += d2[nb][r];
+        } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -675,6 +788,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                 }
             }
         }
+        }
         STAMP(8);
         STAMP(9);
         half_barrier(cnt, epoch, lane);                        // slices drained before the next tile overwrites the buffer
@@ -700,6 +814,21 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     }
     __syncthreads();
     if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
+    if (C1RED) {                                   // fold the 8 waves through LDS (the weight-fragment table is free now), then f64 atomics
+        float* fold = (float*)sC1;                 // [0,256) G[co][c], [256,320) s1[co]
+        for (int q = tid; q < 320; q += 512) fold[q] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int co = nb * 32 + (lane & 31);
+            if (lane < 32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&fold[co * 4 + r], gacc[nb][r]);
+            } else atomicAdd(&fold[256 + co], gacc[nb][0]);
+        }
+        __syncthreads();
+        for (int q = tid; q < 320; q += 512) atomicAdd(&a.c1_red[q < 256 ? q : 512 + (q - 256)], (double)fold[q]);
+    }
 }
 
 // ------------------------------------------------------------------------------------ wgrad
@@ -714,26 +843,6 @@ struct WgradArgs {
     const void* dy2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
     const float* c1_w;    // first-layer input mode (see ConvArgs::c1_w): zin = a0 (B,F,T,4), the operand relu(bn1(W1 a0)) is formed while staging
 };
-
-__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int pix_base, int ch_base, int lane) {
-    // rows = pixels (contraction), cols = channels: lane gets channel ch_base + (lane&31), 8 consecutive pixels
-    // starting at pix_base + (lane>>5)*8.  Two transpose reads of 4 pixels each.
-    typedef __attribute__((ext_vector_type(4))) short s16x4;
-    const int col = ch_base + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
-    const int chunk = col >> 3, within = col & 7;
-    bf16x8 out;
-    s16x4 q[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int p = pix_base + (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
-        const uint16_t* addr = s + swz(p, chunk) + within;
-        q[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)addr);
-    }
-    union { s16x4 v[2]; bf16x8 b; } u;
-    u.v[0] = q[0]; u.v[1] = q[1];
-    out = u.b;
-    return out;
-}
 
 // Weight-gradient tiles use a column-parity swizzle: 16-byte chunk index XOR 4*((column >> 1) & 1).  A 32-lane transpose read
 // touches 4 consecutive pixels x 4 consecutive chunks; pixels x and x+2 share a bank half, and this flips which four chunks of it
@@ -1156,6 +1265,31 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
     const int ncu = sarssl_cu_count();
     conv3x3_fwd_pp_kernel<false, false, true><<<npairs < ncu ? npairs : ncu, 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1in>");
+    return 0;
+}
+
+// Data gradient of the first 3x3 convolution (w = its flipped / transposed taps, dy = the gradient w.r.t. its output) whose result is
+// consumed in the epilogue instead of being stored: red (f64[644], the layout of sarssl_stem_c1_bwd, zeroed here) receives
+// G[co][c] = sum_p g[p][co] a0[p][c] at [co*4 + c] and s1[co] = sum_p g[p][co] at [512 + co], g = dz1 * relu'(scale * (W1 a0) + shift);
+// the remaining entries follow from the input's moments (sarssl_stem_c1_bwd_finalize_mom).  bf16 ping-pong kernel only (returns 1 when
+// it is disabled).
+extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const void* a0, const float* W1, const float* scale,
+                                          const float* shift, int nb, int F, int T, double* red, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && dy && w && a0 && W1 && scale && shift && red, "sarssl_conv3x3_dgrad_c1red");
+    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
+    if (!use_pp) return 1;
+    if (SARSSL_ZERO(red, 644 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    ConvArgs a = {};
+#ifdef CONV_STAMPS
+    a.stamps = g_conv_stamps_host;
+#endif
+    a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
+    a.in = dy; a.w = w; a.out = nullptr; a.scale = scale; a.shift = shift; a.prologue = 0; a.c1_w = W1; a.c1_a0 = a0; a.c1_red = red;
+    a.nb = nb; a.F = F; a.T = T;
+    const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
+    const int ncu = sarssl_cu_count();
+    conv3x3_fwd_pp_kernel<false, false, false, true><<<npairs < ncu ? npairs : ncu, 512, 0, (hipStream_t)stream>>>(a);
+    SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1red>");
     return 0;
 }
 

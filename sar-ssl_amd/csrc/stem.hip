@@ -997,6 +997,40 @@ extern "C" int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a
     return 0;
 }
 
+// Finalize of the first layer's backward when only G and s1 were reduced from the data (sarssl_conv3x3_dgrad_c1red): with
+// y = W1 a0, xhat = (y - mean) * rstd everything else is a function of the input's moments mom = [Sa (4) | Saa (10, upper triangle)]:
+//   X[co][c] = sum_p xhat a0[c] = rstd * (sum_c' W1[co][c'] Saa[c'][c] - mean * Sa[c])
+//   s2[co]   = sum_p g xhat     = rstd * (sum_c W1[co][c] G[co][c] - mean * s1[co])
+__global__ void stem_c1_bwd_finalize_mom_kernel(const double* __restrict__ red, const double* __restrict__ mom, const float* __restrict__ W1,
+                                                long npix, const float* __restrict__ aff, int use_stats,
+                                                float* __restrict__ dW1, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int o = threadIdx.x;                                 // co*4 + c
+    const int co = o >> 2, c = o & 3;
+    const double mean = (double)aff[128 + co], rstd = (double)aff[192 + co];
+    double saa[4][4];
+    {
+        int k = 4;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i; j < 4; ++j) { saa[i][j] = mom[k]; saa[j][i] = mom[k]; ++k; }
+    }
+    double wg = 0.0, wsaa = 0.0;
+    for (int cc = 0; cc < 4; ++cc) { wg += (double)W1[co * 4 + cc] * red[co * 4 + cc]; wsaa += (double)W1[co * 4 + cc] * saa[cc][c]; }
+    const double s1 = red[512 + co];
+    const double s2 = rstd * (wg - mean * s1);
+    const double X = rstd * (wsaa - mean * mom[c]);
+    const double invN = 1.0 / (double)npix;
+    const double m1 = use_stats ? s1 * invN : 0.0, m2 = use_stats ? s2 * invN : 0.0;
+    dW1[o] += (float)((double)aff[co] * (red[o] - m1 * mom[c] - m2 * X));
+    if (c == 0) { dbeta[co] += (float)s1; dgamma[co] += (float)s2; }
+}
+extern "C" int sarssl_stem_c1_bwd_finalize_mom(const double* red, const double* mom14, const float* W1, long npix, const float* aff,
+                                               int use_stats, float* dW1, float* dgamma, float* dbeta, void* stream) {
+    SARSSL_REQUIRE(red && mom14 && W1 && aff && dW1 && dgamma && dbeta && npix > 0, "sarssl_stem_c1_bwd_finalize_mom");
+    stem_c1_bwd_finalize_mom_kernel<<<1, 256, 0, ST>>>(red, mom14, W1, npix, aff, use_stats, dW1, dgamma, dbeta);
+    SARSSL_CHECK_LAUNCH("stem_c1_bwd_finalize_mom_kernel");
+    return 0;
+}
+
 // The same pass without y1: y1 = W1 a0 is recomputed (bf16 activations, npix % 64 == 0; W1 = the 64 x 4 first-layer weight).
 extern "C" int sarssl_stem_c1_bwd_a0(const void* dz1, const void* a0, const float* W1, long npix, const float* aff, int use_stats,
                                      double* red, float* dW1, float* dgamma, float* dbeta, void* stream) {

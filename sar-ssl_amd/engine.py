@@ -255,12 +255,13 @@ def stem_fwd(a0, pe, train, saved):
     B, F, T, _ = a0.shape
     fuse = train and RT.dtype == torch.bfloat16          # BatchNorm sums come out of the producing kernel's epilogue
     W1 = pe[0].weight.data.view(64, 4)
-    y1 = y2 = None
+    y1 = y2 = mom1 = None
     if fuse and _C1IN and (B * F * T) % 64 == 0 and not RT.inference:
         # the first layer's 64-channel output is never stored: its BatchNorm statistics follow from the 4 + 10 moments of the
         # 4-channel input, the first 3x3 convolution (and, in backward, its weight gradient and the layer's own backward pass) form
         # relu(bn1(W1 a0)) from a0 while staging - 4 x 537 MB less HBM traffic per encoder and step at B = 64
-        aff1 = bn_affine(None, 64, pe[1], train, sums=hip.stem_c1_stats(a0, W1), N=B * F * T)
+        s1, mom1 = hip.stem_c1_stats(a0, W1, keep_moments=True)
+        aff1 = bn_affine(None, 64, pe[1], train, sums=s1, N=B * F * T)
         r = hip.conv3x3_fwd_c1(a0, W1, aff1[0], aff1[1], _taps(pe[3])[0], want_stats=True)
         if r is not None:
             y2, s2 = r
@@ -280,7 +281,7 @@ def stem_fwd(a0, pe, train, saved):
     aff4 = bn_affine(y4, 4, pe[10], train)
     z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
     e = mm_nt(z4, _patch_w(pe[12], F), fp8=False)
-    saved.append((a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
+    saved.append((a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
     return e
 
 
@@ -294,6 +295,7 @@ _DWGLU = os.environ.get("SARSSL_DWGLU", "1") != "0"             # 0: separate gl
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 _C1IN = os.environ.get("SARSSL_C1IN", "1") != "0"             # 0: store the first layer's 64-channel output (A/B runs)
+_C1RED = os.environ.get("SARSSL_C1RED", "1") != "0"           # 0: store the gradient w.r.t. that output and reduce it in a pass of its own
 
 
 def patch_bwd(de, pe, saved):
@@ -317,7 +319,7 @@ def patch_bwd(de, pe, saved):
 
 def stem_bwd(dz4, pe, saved):
     """Backward of the CNN stem below the patch GEMM (``dz4`` = patch_bwd's result)."""
-    a0, y1, aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
+    a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
     B, F, T, _ = a0.shape
     W1 = pe[0].weight.data.view(64, 4)
 
@@ -358,6 +360,9 @@ def stem_bwd(dz4, pe, saved):
             dW = None
         else:
             dW = hip.conv3x3_wgrad(dy2, need_y1(), aff1[0], aff1[1], precise=RT.precise, acc_into=gbuf(pe[3].weight))
+        if y1 is None and mom1 is not None and _C1RED and _C1_FUSED == 2 and hip.conv3x3_dgrad_c1red(
+                dy2, _taps(pe[3])[1], a0, W1, aff1, mom1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias)):
+            return None     # the data gradient of the first 3x3 convolution was consumed in its epilogue: the first layer is done
         dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
     if dW is not None:
         gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))

@@ -354,12 +354,33 @@ def stem_c1_fwd(a0, W1, want_stats=False):
     return (y, sums) if want_stats else y
 
 
-def stem_c1_stats(a0, W1):
-    """BatchNorm sums f64[128] = [sum | sum of squares] of y1 = W1 a0 from the 4 + 10 first / second moments of a0 (y1 is not formed)."""
+def stem_c1_stats(a0, W1, keep_moments=False):
+    """BatchNorm sums f64[128] = [sum | sum of squares] of y1 = W1 a0 from the 4 + 10 first / second moments of a0 (y1 is not formed).
+    keep_moments: also return the moments f64[14] in memory of their own (the backward pass reads them, see conv3x3_dgrad_c1red)."""
     npix = a0.numel() // 4
-    mom, sums = _sums(16, a0.device), _sums(128, a0.device)
+    sums = _sums(128, a0.device)
+    mom = torch.zeros(16, dtype=torch.float64, device=a0.device) if keep_moments else _sums(16, a0.device)
     _lib.call("sarssl_stem_c1_stats", _p(a0), c_long(npix), _p(W1), _p(mom), _p(sums), c_int(dt(a0)), _stream())
-    return sums
+    return (sums, mom) if keep_moments else sums
+
+
+def conv3x3_dgrad_c1red(dy, w_tap_dgrad, a0, W1, aff, mom, train, dW1, dgamma, dbeta):
+    """Data gradient of the first 3x3 convolution consumed in its epilogue: dW1 (64,4,1,1) / dgamma / dbeta (64) += the first stem
+    layer's parameter gradients; the 64-channel gradient tensor is never stored (mom = the input's moments from stem_c1_stats).
+    False when the ping-pong kernel is disabled (nothing done)."""
+    _need_cuda(dy, w_tap_dgrad, a0, W1, aff, mom)
+    B, F, T, _ = a0.shape
+    assert dy.dtype == torch.bfloat16 and a0.dtype == torch.bfloat16 and dy.shape == (B, F, T, 64)
+    red = _sums(644, a0.device)
+    fn = _lib.lib().sarssl_conv3x3_dgrad_c1red
+    with _Timed("conv3x3_dgrad_c1red"):
+        rc = fn(_p(dy), _p(w_tap_dgrad), _p(a0), _p(W1), _p(aff[0]), _p(aff[1]), c_int(B), c_int(F), c_int(T), _p(red), _stream())
+    if rc == 1:
+        return False
+    _lib.check(rc, "sarssl_conv3x3_dgrad_c1red")
+    _lib.call("sarssl_stem_c1_bwd_finalize_mom", _p(red), _p(mom), _p(W1), c_long(B * F * T), _p(aff), c_int(1 if train else 0),
+              _p(dW1), _p(dgamma), _p(dbeta), _stream())
+    return True
 
 
 def stem_c1_bwd_a0(dz1, a0, W1, aff, train, dW1, dgamma, dbeta):

@@ -898,3 +898,37 @@ def test_first_layer_backward_from_the_input_only(train):
     ref = dy.t() @ a0.double().view(-1, 4)
     assert _relerr(dW.view(64, 4), ref) < 2e-5
     assert _relerr(dbe, s1) < 1e-5 and _relerr(dga, s2) < 1e-5
+
+
+@pytest.mark.parametrize("shape,train", [((2, 16, 40), True), ((1, 24, 72), False), ((3, 8, 32), True)])
+def test_first_conv_data_gradient_consumed_in_its_epilogue(shape, train):
+    """conv3x3_dgrad_c1red (data gradient masked and contracted against [a0 | 1] on the matrix cores, nothing stored) + the moment-based
+    finalize == data-gradient launch followed by the one-pass first-layer backward, and an f64 restatement."""
+    from sar_ssl_amd import hip
+    B, F, T = shape
+    dev, g, a0, W1, scale, shift = _c1_case(B, F, T, 54)
+    npix = B * F * T
+    w = (torch.randn((9, 64, 64), generator=g) * 0.05).bfloat16().to(dev)         # [tap][ci][co] data-gradient taps
+    dy2 = torch.randn((B, F, T, 64), generator=g).bfloat16().to(dev)
+    hip.sums_arena_reset(dev)
+    sums, mom = hip.stem_c1_stats(a0, W1, keep_moments=True)
+    y = a0.double().view(-1, 4) @ W1.double().t()
+    mean = y.mean(0); var = y.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    aff = torch.stack([scale, shift, mean.float(), rstd.float()]).contiguous()
+    dW, dga, dbe = torch.zeros((64, 4, 1, 1), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    assert hip.conv3x3_dgrad_c1red(dy2, w, a0, W1, aff, mom, train, dW, dga, dbe)
+    # stored path with the same kernels' arithmetic: dz1 (bf16) then the one-pass backward that recomputes y1
+    dz1 = hip.conv3x3_fwd(dy2, w)
+    dW2, dga2, dbe2 = torch.zeros((64, 4, 1, 1), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    if npix % 64 == 0:
+        hip.stem_c1_bwd_a0(dz1, a0, W1, aff, train, dW2, dga2, dbe2)
+        assert _relerr(dW, dW2) < 2e-4 and _relerr(dga, dga2) < 2e-4 and _relerr(dbe, dbe2) < 2e-4
+    # f64 restatement from the stored bf16 gradient
+    gg = dz1.double().view(-1, 64) * ((y * scale.double() + shift.double()) > 0)
+    xh = (y - aff[2].double()) * aff[3].double()
+    s1, s2 = gg.sum(0), (gg * xh).sum(0)
+    dyn = scale.double() * ((gg - s1 / npix - xh * s2 / npix) if train else gg)
+    ref = dyn.t() @ a0.double().view(-1, 4)
+    assert _relerr(dW.view(64, 4), ref) < 2e-4
+    assert _relerr(dbe, s1) < 2e-4 and _relerr(dga, s2) < 2e-4

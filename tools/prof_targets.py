@@ -105,6 +105,11 @@ def main():
     group(32, "stem_c4_bwd two-phase (sums + apply)", lambda: hip.stem_c4_bwd_two_phase(x, dy4, W4, aff, True), 0, 3 * tb + 2 * tb / 16)
     gW, gg, gb = torch.zeros((64, 4), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
     group(33, "stem_c1_bwd (one pass)", lambda: hip.stem_c1_bwd(x, y, a0, aff, True, gW, gg, gb), 0, 2 * tb + tb / 16)
+    group(37, "stem_c1_bwd_a0 (one pass, y1 recomputed from the input)", lambda: hip.stem_c1_bwd_a0(x, a0, W1, aff, True, gW, gg, gb), 0, tb + tb / 16)
+    wt = rnd(9, 64, 64, scale=0.05)
+    group(24, "conv3x3 fwd from the 4-channel input (C1IN, + stats)", lambda: hip.conv3x3_fwd_c1(a0, W1, sc, sh, wt, want_stats=True), cfl, tb + tb / 16)
+    gacc = torch.zeros((64, 64, 3, 3), device=dev)
+    group(25, "conv3x3 wgrad from the 4-channel input (C1IN)", lambda: hip.conv3x3_wgrad_c1(y, a0, W1, sc, sh, gacc), cfl, tb + tb / 16)
     red = torch.zeros(128, dtype=torch.float64, device=dev)
     group(34, "cl_bn_bwd_apply C=64 (in place)", lambda: hip.cl_bn_bwd_apply(x, y, 64, aff, 1, False, True, red, out=x), 0, 3 * tb)
     group(35, "cl_bn_bwd_reduce C=64", lambda: hip.cl_bn_bwd_reduce(x, y, 64, aff, 1), 0, 2 * tb)
