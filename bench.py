@@ -10,8 +10,9 @@ masked MSE -> hand-written backward -> (bucketed RCCL all-reduce overlapped with
 f32 accumulation; dropout active (training mode), nothing cached or skipped.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with events on the launch stream around every BN-prologue launch of the
-dominant kernel (conv3x3_fwd_pp_kernel<false>, the ping-pong schedule of the 3x3 convolution: the 2 forward convolutions per encoder;
-the data-gradient launches of the same kernel are timed under their own labels);
+dominant kernel (conv3x3_fwd_pp_kernel<false>, the ping-pong schedule of the 3x3 convolution: the forward convolution per encoder that
+reads a stored 64-channel input; the other forward convolution forms its input from the 4-channel stem input while staging (C1IN
+variant of the same kernel), and it and the data-gradient launches are timed under their own labels);
 `cpu_baseline` times the CPU oracle (oracle/sarssl_oracle.py, the validated restatement of the reference) on this host.
 """
 import argparse
@@ -199,7 +200,9 @@ def main():
     if rank == 0:
         segs_total = args.batch * world * args.steps
         value = segs_total / elapsed
-        n, ms = prof.get("conv3x3_fwd:bn_prologue", (0, 0.0))          # the 4 forward 3x3 convolutions per step (BN+ReLU prologue)
+        n, ms = prof.get("conv3x3_fwd:bn_prologue", (0, 0.0))          # forward 3x3 convolutions with a stored input (BN+ReLU prologue): 2 per step
+        nc1, msc1 = prof.get("conv3x3_fwd_c1", (0, 0.0))               # the other 2: input formed from the stem's 4-channel input while staging
+        nr1, msr1 = prof.get("conv3x3_dgrad_c1red", (0, 0.0))          # data gradient consumed in its epilogue (nothing stored)
         nd, msd = prof.get("conv3x3_fwd:identity", (0, 0.0))           # plain data-gradient launches of the same kernel
         nb, msb = prof.get("conv3x3_dgrad_bnred", (0, 0.0))            # <true> variant: data gradient + BatchNorm-backward sums
         flop_per_launch = 2.0 * args.batch * 65536 * 64 * 576            # one 3x3 64->64 conv over B x 256 x 256 pixels
@@ -234,6 +237,8 @@ def main():
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic, "mfma_busy": mfma_busy, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
                          "flop_per_launch": flop_per_launch,
+                         "fwd_from_4ch_input_avg_ms": round(msc1 / nc1, 4) if nc1 else None,
+                         "dgrad_consumed_in_epilogue_avg_ms": round(msr1 / nr1, 4) if nr1 else None,
                          "dgrad_identity_avg_ms": round(msd / nd, 4) if nd else None,
                          "dgrad_bnred_avg_ms": round(msb / nb, 4) if nb else None,
                          "wgrad_avg_ms": round(msw / nw, 4) if nw else None,

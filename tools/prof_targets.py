@@ -110,6 +110,9 @@ def main():
     group(24, "conv3x3 fwd from the 4-channel input (C1IN, + stats)", lambda: hip.conv3x3_fwd_c1(a0, W1, sc, sh, wt, want_stats=True), cfl, tb + tb / 16)
     gacc = torch.zeros((64, 64, 3, 3), device=dev)
     group(25, "conv3x3 wgrad from the 4-channel input (C1IN)", lambda: hip.conv3x3_wgrad_c1(y, a0, W1, sc, sh, gacc), cfl, tb + tb / 16)
+    _, mom = hip.stem_c1_stats(a0, W1, keep_moments=True)
+    group(26, "conv3x3 dgrad consumed in its epilogue (C1RED: mask + [a0|1] contraction on MFMA, nothing stored)",
+          lambda: hip.conv3x3_dgrad_c1red(y, wt, a0, W1, aff, mom, True, gW, gg, gb), cfl, tb + tb / 16)
     red = torch.zeros(128, dtype=torch.float64, device=dev)
     group(34, "cl_bn_bwd_apply C=64 (in place)", lambda: hip.cl_bn_bwd_apply(x, y, 64, aff, 1, False, True, red, out=x), 0, 3 * tb)
     group(35, "cl_bn_bwd_reduce C=64", lambda: hip.cl_bn_bwd_reduce(x, y, 64, aff, 1), 0, 2 * tb)
