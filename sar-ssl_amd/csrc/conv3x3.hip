@@ -1190,10 +1190,29 @@ static bool wgrad_db_enabled() {
     static const int v = getenv("SARSSL_WGRAD_DB") ? atoi(getenv("SARSSL_WGRAD_DB")) : 1;       // A/B switch: 0 = single-buffered kernel
     return v != 0;
 }
+// Workgroups of the persistent convolution launches.  kind 0 = forward launches, 1 = data / weight gradients.  One per CU, or
+// SARSSL_CONV_CUS[_FWD | _BWD] of them: a convolution workgroup takes a CU's whole LDS and nearly all of its registers, so while a
+// launch covers every CU the other encoder's stream stands still; a launch that leaves an eighth of the CUs free lets that stream's
+// short latency-bound kernels run next to it (measured on the step).  The grid is then trimmed so that the last
+// round of tiles is as full as the others (a multiple of 8 keeps the XCD-aware tile order).
+static int conv_cus(int kind) {
+    static const int lim[2] = {
+        []() { const char* e = getenv("SARSSL_CONV_CUS_FWD"); if (!e) e = getenv("SARSSL_CONV_CUS"); return e ? atoi(e) : 0; }(),
+        []() { const char* e = getenv("SARSSL_CONV_CUS_BWD"); if (!e) e = getenv("SARSSL_CONV_CUS"); return e ? atoi(e) : 0; }()};
+    const int ncu = sarssl_cu_count();
+    return lim[kind] > 0 && lim[kind] < ncu ? lim[kind] : ncu;
+}
+static int conv_persistent_grid(int nunits, int kind) {
+    const int cus = conv_cus(kind);
+    if (nunits <= cus) return nunits;
+    const int rounds = (nunits + cus - 1) / cus;
+    int g = (nunits + rounds - 1) / rounds;
+    g = (g + 7) & ~7;
+    return g < cus ? g : cus;
+}
 static int wgrad_db_grid(int nb, int F, int T) {
     const int ntiles = nb * ((F + TR - 1) / TR) * ((T + WTC - 1) / WTC);
-    const int ncu = sarssl_cu_count();
-    return ntiles < ncu ? ntiles : ncu;
+    return conv_persistent_grid(ntiles, 1);
 }
 static int conv_grid(int nb, int F, int T) {
     int ntiles = nb * ((F + TR - 1) / TR) * ((T + TCOL - 1) / TCOL);
@@ -1238,8 +1257,7 @@ extern "C" int sarssl_conv3x3_dgrad_bnin(const void* dz_in, const void* w, void*
     a.in = dz_in; a.w = w; a.out = out; a.nb = nb; a.F = F; a.T = T;
     a.in2 = y; a.bnin_aff = aff; a.bnin_red = red; a.bnin_use_stats = use_stats;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    const int ncu = sarssl_cu_count();
-    conv3x3_fwd_pp_kernel<false, true><<<npairs < ncu ? npairs : ncu, 512, 0, (hipStream_t)stream>>>(a);
+    conv3x3_fwd_pp_kernel<false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<bnin>");
     return 0;
 }
@@ -1262,8 +1280,7 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
     a.in = a0; a.w = w; a.out = out; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    const int ncu = sarssl_cu_count();
-    conv3x3_fwd_pp_kernel<false, false, true><<<npairs < ncu ? npairs : ncu, 512, 0, (hipStream_t)stream>>>(a);
+    conv3x3_fwd_pp_kernel<false, false, true><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1in>");
     return 0;
 }
@@ -1287,8 +1304,7 @@ extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const v
     a.in = dy; a.w = w; a.out = nullptr; a.scale = scale; a.shift = shift; a.prologue = 0; a.c1_w = W1; a.c1_a0 = a0; a.c1_red = red;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    const int ncu = sarssl_cu_count();
-    conv3x3_fwd_pp_kernel<false, false, false, true><<<npairs < ncu ? npairs : ncu, 512, 0, (hipStream_t)stream>>>(a);
+    conv3x3_fwd_pp_kernel<false, false, false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1red>");
     return 0;
 }
@@ -1315,9 +1331,9 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
         static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
         if (use_pp) {
             const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-            const int ncu = sarssl_cu_count();
-            if (bn_y) conv3x3_fwd_pp_kernel<true><<<npairs < ncu ? npairs : ncu, 512, 0, st>>>(a);
-            else conv3x3_fwd_pp_kernel<false><<<npairs < ncu ? npairs : ncu, 512, 0, st>>>(a);
+            const int g = conv_persistent_grid(npairs, scale != nullptr ? 0 : 1);      // (no prologue = a data-gradient launch)
+            if (bn_y) conv3x3_fwd_pp_kernel<true><<<g, 512, 0, st>>>(a);
+            else conv3x3_fwd_pp_kernel<false><<<g, 512, 0, st>>>(a);
         } else conv3x3_fwd_kernel<bf16, bf16><<<grid, 512, 0, st>>>(a);
     } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
         if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);
