@@ -1,0 +1,33 @@
+"""Model-level A/B of engine._C1IN / _C1RED: same weights / masks, dropout off; loss, gradients and BatchNorm running
+statistics with and without the stored first-layer tensors, next to the run-to-run noise of the stored path itself."""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sarssl_boot, numpy as np, torch
+from sar_ssl_amd import hip, model, runtime, synth, engine
+dev = torch.device("cuda:0")
+runtime.set_precision("bf16")
+T, B = 16, 4
+sig = torch.from_numpy(synth.make_batch(7, B, nsample=512 + 256 * (T - 1))).to(dev)
+x = hip.stft_frontend(sig)
+res = {}
+for flag in (True, False, 'again'):
+    engine._C1IN = engine._C1RED = flag is True
+    torch.manual_seed(3)
+    net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout): m.p = 0.0
+    net.to(dev).train()
+    flat = runtime.FlatParams(net)
+    random.seed(5)
+    loss, _, _ = net(x)
+    loss.backward()
+    torch.cuda.synchronize()
+    res[flag] = (float(loss.detach()), flat.grad.clone(), {n: b.clone() for n, b in net.named_buffers() if "running" in n})
+for a, b in ((True, False), ('again', False)):
+  l1, g1, b1 = res[a]; l0, g0, b0 = res[b]
+  print("==", {True: "first-layer tensors not stored", 'again': "stored path, second run"}[a], "vs stored path")
+  print("loss %.6f vs %.6f  rel %.2e" % (l1, l0, abs(l1 - l0) / abs(l0)))
+  print("grad rel diff (max abs / max abs) %.3e   cos %.6f" % (((g1 - g0).abs().max() / g0.abs().max()).item(), torch.nn.functional.cosine_similarity(g1, g0, dim=0).item()))
+  for k in b1:
+    d = ((b1[k] - b0[k]).abs().max() / (b0[k].abs().max() + 1e-9)).item()
+    if d > 1e-3: print("   ", k, "%.3e" % d)
