@@ -164,6 +164,11 @@ int sarssl_stem_c4_bwd_sums(const void* y3, const void* dy4, const float* W4, co
 int sarssl_stem_c4_bwd_apply(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
                              const float* mean, const float* rstd, int nb, int F, int Tn, const double* red, int use_stats,
                              void* dy3, int dtype, void* stream);
+/* the same pass; workgroup 0 also adds the parameter gradients from the finished sums: gW4 (4,64) += red[0:256], dbeta += red[256:320],
+ * dgamma += red[320:384] */
+int sarssl_stem_c4_bwd_apply_pg(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
+                                const float* mean, const float* rstd, int nb, int F, int Tn, const double* red, int use_stats, void* dy3,
+                                float* gW4, float* dgamma, float* dbeta, int dtype, void* stream);
 
 /* ---- BatchNorm{1,2}d on channels-last [N][C] tensors (training statistics, running-stat update, backward):
  *      nn.BatchNorm2d in code/model.py:52-61, nn.BatchNorm1d in code/common/conformer/convolution.py:142 */
@@ -180,6 +185,10 @@ int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, int C, const 
 int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
                            const float* mean, const float* rstd, int act, int g_is_masked, int use_stats, const double* red,
                            void* dy, int dtype, void* stream);
+/* the same pass; workgroup 0 also adds the BatchNorm parameter gradients dbeta += red[0:C], dgamma += red[C:2C] */
+int sarssl_cl_bn_bwd_apply_pg(const void* dz, const void* y, long N, int C, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, int act, int g_is_masked, int use_stats, const double* red, void* dy, float* dgamma,
+                              float* dbeta, int dtype, void* stream);
 
 /* ---- depthwise-conv part of the Conformer convolution module as LDS tiles (convolution.py:139-143 and its backward): GLU fused
  *      into the tile load, BatchNorm1d batch sums in the epilogue; the data gradient fused with the GLU backward; the weight gradient

@@ -428,7 +428,12 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict__ dy4, const float* __restrict__ W4,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                   int nb, int F, int Tn, T* __restrict__ g3, double* __restrict__ red, int use_stats) {
+                                   int nb, int F, int Tn, T* __restrict__ g3, double* __restrict__ red, int use_stats,
+                                   float* __restrict__ gW4 = nullptr, float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
+    if (MODE == 2 && gW4 && blockIdx.x == 0) {   // parameter gradients from the finished sums (were two launches of their own)
+        for (int o = threadIdx.x; o < 256; o += blockDim.x) gW4[o] += (float)red[o];
+        for (int c = threadIdx.x; c < 64; c += blockDim.x) { dbeta[c] += (float)red[256 + c]; dgamma[c] += (float)red[320 + c]; }
+    }
     __shared__ float sred[4][8][48];
     const int cg = threadIdx.x & 7;
     float w[4][8], sc[8], sh[8], mu[8], rs[8];
@@ -850,7 +855,11 @@ template <typename T>
 __global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, long rows, int L, int C, long N,
                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                        const float* __restrict__ mean, const float* __restrict__ rstd, int act,
-                                       int g_is_masked, int use_stats, const double* __restrict__ red, T* __restrict__ dy) {
+                                       int g_is_masked, int use_stats, const double* __restrict__ red, T* __restrict__ dy,
+                                       float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
+    if (dgamma && blockIdx.x == 0) {        // BatchNorm parameter gradients from the same sums: dbeta += s1, dgamma += s2 (was a launch of its own)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += (float)red[c]; dgamma[c] += (float)red[C + c]; }
+    }
     const int gpr = L >> 3, cg = threadIdx.x % gpr, rslot = threadIdx.x / gpr, rpb = 256 / gpr;
     const int col = cg * 8;
     const float invN = 1.0f / (float)N;
@@ -1145,13 +1154,23 @@ extern "C" int sarssl_stem_c4_bwd_sums(const void* y3, const void* dy4, const fl
     SARSSL_CHECK_LAUNCH("stem_c4_bwd_kernel<sums>");
     return 0;
 }
+extern "C" int sarssl_stem_c4_bwd_apply_pg(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
+                                           const float* mean, const float* rstd, int nb, int F, int Tn, const double* red,
+                                           int use_stats, void* dy3, float* gW4, float* dgamma, float* dbeta, int dtype, void* stream);
 extern "C" int sarssl_stem_c4_bwd_apply(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
                                         const float* mean, const float* rstd, int nb, int F, int Tn, const double* red,
                                         int use_stats, void* dy3, int dtype, void* stream) {
+    return sarssl_stem_c4_bwd_apply_pg(y3, dy4, W4, scale, shift, mean, rstd, nb, F, Tn, red, use_stats, dy3, nullptr, nullptr, nullptr, dtype, stream);
+}
+// The same pass; workgroup 0 also adds gW4 (4 x 64) += red[0:256], dbeta += red[256:320], dgamma += red[320:384] (all three or none).
+extern "C" int sarssl_stem_c4_bwd_apply_pg(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
+                                           const float* mean, const float* rstd, int nb, int F, int Tn, const double* red,
+                                           int use_stats, void* dy3, float* gW4, float* dgamma, float* dbeta, int dtype, void* stream) {
+    SARSSL_REQUIRE((gW4 == nullptr) == (dgamma == nullptr) && (gW4 == nullptr) == (dbeta == nullptr), "sarssl_stem_c4_bwd_apply_pg");
     static const int cap = grid_cap("SARSSL_GRID_C4A", 4096);
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
     DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 2><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
-                                                                     nb, F, Tn, (T*)dy3, (double*)red, use_stats)));
+                                                                     nb, F, Tn, (T*)dy3, (double*)red, use_stats, gW4, dgamma, dbeta)));
     SARSSL_CHECK_LAUNCH("stem_c4_bwd_kernel<apply>");
     return 0;
 }
@@ -1227,9 +1246,19 @@ extern "C" int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, in
     return 0;
 }
 
+extern "C" int sarssl_cl_bn_bwd_apply_pg(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
+                                         const float* mean, const float* rstd, int act, int g_is_masked, int use_stats,
+                                         const double* red, void* dy, float* dgamma, float* dbeta, int dtype, void* stream);
 extern "C" int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
                                       const float* mean, const float* rstd, int act, int g_is_masked, int use_stats,
                                       const double* red, void* dy, int dtype, void* stream) {
+    return sarssl_cl_bn_bwd_apply_pg(dz, y, N, C, scale, shift, mean, rstd, act, g_is_masked, use_stats, red, dy, nullptr, nullptr, dtype, stream);
+}
+// The same pass; workgroup 0 also adds the BatchNorm parameter gradients dbeta += red[0:C], dgamma += red[C:2C] (f32 buffers; both or neither).
+extern "C" int sarssl_cl_bn_bwd_apply_pg(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
+                                         const float* mean, const float* rstd, int act, int g_is_masked, int use_stats,
+                                         const double* red, void* dy, float* dgamma, float* dbeta, int dtype, void* stream) {
+    SARSSL_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "sarssl_cl_bn_bwd_apply_pg");
     long rows; int L;
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L) && cl_rowthreads_ok(L), "sarssl_cl_bn_bwd_apply");
     static const int cap = grid_cap("SARSSL_GRID_BNA", 1024);       // one resident round (4 workgroups per CU): every further round repeats the per-channel prologue and adds a tail (4096: 378 us, 1024: 321 us at B = 64)
@@ -1238,7 +1267,7 @@ extern "C" int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int
     const int grid_ = (int)(nb_ > cap ? cap : nb_);
     DISPATCH_T(dtype, (cl_bn_bwd_apply_kernel<T><<<grid_, 256, 0, ST>>>((const T*)dz, (const T*)y, rows, L, C, N, scale,
                                                                                      shift, mean, rstd, act, g_is_masked,
-                                                                                     use_stats, red, (T*)dy)));
+                                                                                     use_stats, red, (T*)dy, dgamma, dbeta)));
     SARSSL_CHECK_LAUNCH("cl_bn_bwd_apply_kernel");
     return 0;
 }

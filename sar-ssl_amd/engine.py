@@ -326,17 +326,16 @@ def stem_bwd(dz4, pe, saved):
     def need_y1():                    # y1 was not stored (stem_fwd, _C1IN) and a fallback path wants it: recompute it
         return y1 if y1 is not None else hip.stem_c1_fwd(a0, W1)
     red4 = hip.cl_bn_bwd_reduce(dz4, y4, 4, aff4, RELU)
-    dy4 = hip.cl_bn_bwd_apply(dz4, y4, 4, aff4, RELU, False, train, red4)
-    bn_param_grads(pe[10], red4, 4)
+    # (BatchNorm / 1x1-conv parameter gradients are added from the finished sums by workgroup 0 of the pass that consumes them)
+    dy4 = hip.cl_bn_bwd_apply(dz4, y4, 4, aff4, RELU, False, train, red4, pgrads=(gbuf(pe[10].weight), gbuf(pe[10].bias)))
     # 64->4 conv + BN3/ReLU backward reductions in one pass over y3
     if _C4_TWO_PHASE:       # sums pass + direct dy3 pass: 1.7 GB per encoder instead of 2.7 GB (c4_bwd + in-place BatchNorm apply)
-        dy3, red = hip.stem_c4_bwd_two_phase(y3, dy4, pe[9].weight.data.view(4, 64), aff3, train)
-        hip.f64_accum(red[:256], gbuf(pe[9].weight))
+        dy3, red = hip.stem_c4_bwd_two_phase(y3, dy4, pe[9].weight.data.view(4, 64), aff3, train,
+                                             pgrads=(gbuf(pe[9].weight), gbuf(pe[7].weight), gbuf(pe[7].bias)))
     else:
         g3, red = hip.stem_c4_bwd(y3, dy4, pe[9].weight.data.view(4, 64), aff3)
         hip.f64_accum(red[:256], gbuf(pe[9].weight))
-        dy3 = hip.cl_bn_bwd_apply(g3, y3, 64, aff3, RELU, True, train, red[256:], out=g3)
-    bn_param_grads(pe[7], red[256:], 64)
+        dy3 = hip.cl_bn_bwd_apply(g3, y3, 64, aff3, RELU, True, train, red[256:], out=g3, pgrads=(gbuf(pe[7].weight), gbuf(pe[7].bias)))
     # second 3x3 conv
     dW = hip.conv3x3_wgrad(dy3, y2, aff2[0], aff2[1], precise=RT.precise, acc_into=gbuf(pe[6].weight))
     if dW is not None:
@@ -348,14 +347,14 @@ def stem_bwd(dz4, pe, saved):
         dz2 = hip.conv3x3_fwd(dy3, _taps(pe[6])[1], precise=RT.precise)
     if red2 is None:
         red2 = hip.cl_bn_bwd_reduce(dz2, y2, 64, aff2, RELU)
-    bn_param_grads(pe[4], red2, 64)
     # first 3x3 conv.  The normalised gradient dy2 = BatchNorm/ReLU backward of (dz2, y2) has two consumers (this layer's weight and
     # data gradients): in bf16 both form it while staging their tiles, so it is never written (cl_bn_bwd_apply: 3 x 537 MB at B = 64)
     dz1 = hip.conv3x3_dgrad_bnin(dz2, _taps(pe[3])[1], y2, aff2, red2, train) if (_BNIN and RT.dtype == torch.bfloat16) else None
     if dz1 is not None:
+        bn_param_grads(pe[4], red2, 64)
         dW = hip.conv3x3_wgrad_bnin(dz2, y2, aff2, red2, need_y1(), aff1[0], aff1[1], train)
     else:
-        dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2)
+        dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2, pgrads=(gbuf(pe[4].weight), gbuf(pe[4].bias)))
         if y1 is None and hip.conv3x3_wgrad_c1(dy2, a0, W1, aff1[0], aff1[1], gbuf(pe[3].weight)):
             dW = None
         else:
@@ -709,8 +708,7 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
     hip.colsum(dout, gbuf(pw2.bias))
     ds = mm_nn(dout, wt(pw2.weight).view(d, d))
     red = hip.cl_bn_bwd_reduce(ds, c, d, aff, SWISH)
-    dc = hip.cl_bn_bwd_apply(ds, c, d, aff, SWISH, False, train, red, out=ds).view(B, T, d)
-    bn_param_grads(bn, red, d)
+    dc = hip.cl_bn_bwd_apply(ds, c, d, aff, SWISH, False, train, red, out=ds, pgrads=(gbuf(bn.weight), gbuf(bn.bias))).view(B, T, d)
     if g is None:                        # fused forward: the GLU output was never stored
         dh = hip.dwglu_bwd(dc.view(B * T, d), h, dw.weight.data.view(d, -1), B, T)
         hip.dwglu_wgrad(dc.view(B * T, d), h, gbuf(dw.weight).view(d, -1), B, T)

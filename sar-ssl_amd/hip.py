@@ -435,16 +435,18 @@ def stem_c4_bwd(y3, dy4, W4, aff):
     return g3, red
 
 
-def stem_c4_bwd_two_phase(y3, dy4, W4, aff, train):
+def stem_c4_bwd_two_phase(y3, dy4, W4, aff, train, pgrads=None):
     """-> dy3 (B,F,T,64) = gradient w.r.t. the third BatchNorm's input, red f64[384] = [dW4 | s1 | s2]; two kernels, no
-    intermediate 64-channel tensor."""
+    intermediate 64-channel tensor.  pgrads = (gW4 (4,64), dgamma, dbeta) f32 gradient buffers: accumulated from red by the second
+    kernel."""
     B, F, T, _ = y3.shape
     red = _sums(384, y3.device)
     _lib.call("sarssl_stem_c4_bwd_sums", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
               c_int(T), _p(red), c_int(dt(y3)), _stream())
     dy3 = torch.empty_like(y3)
-    _lib.call("sarssl_stem_c4_bwd_apply", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
-              c_int(T), _p(red), c_int(1 if train else 0), _p(dy3), c_int(dt(y3)), _stream())
+    gw, dg, db = pgrads if pgrads is not None else (None, None, None)
+    _lib.call("sarssl_stem_c4_bwd_apply_pg", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
+              c_int(T), _p(red), c_int(1 if train else 0), _p(dy3), _p(gw), _p(dg), _p(db), c_int(dt(y3)), _stream())
     return dy3, red
 
 
@@ -669,11 +671,13 @@ def cl_bn_bwd_reduce(dz, y, C, aff, act):
     return red
 
 
-def cl_bn_bwd_apply(dz, y, C, aff, act, g_is_masked, use_stats, red, out=None):
+def cl_bn_bwd_apply(dz, y, C, aff, act, g_is_masked, use_stats, red, out=None, pgrads=None):
+    """pgrads = (dgamma, dbeta) f32 [C] gradient buffers: dbeta += red[:C], dgamma += red[C:] in the same launch."""
     if out is None:
         out = torch.empty_like(y)
-    _lib.call("sarssl_cl_bn_bwd_apply", _p(dz), _p(y), c_long(y.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), _p(aff[2]),
-              _p(aff[3]), c_int(act), c_int(1 if g_is_masked else 0), c_int(1 if use_stats else 0), _p(red), _p(out),
+    dg, db = pgrads if pgrads is not None else (None, None)
+    _lib.call("sarssl_cl_bn_bwd_apply_pg", _p(dz), _p(y), c_long(y.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), _p(aff[2]),
+              _p(aff[3]), c_int(act), c_int(1 if g_is_masked else 0), c_int(1 if use_stats else 0), _p(red), _p(out), _p(dg), _p(db),
               c_int(dt(y)), _stream())
     return out
 
