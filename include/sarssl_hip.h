@@ -139,6 +139,11 @@ int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad, int d, int
  * relu(bn1(W1 a0)) formed from a0 (B,F,T,4) bf16 while staging (return 1 = kernel disabled, nothing done);
  * stem_c1_bwd_a0 = sarssl_stem_c1_bwd with y1 recomputed (npix % 64 == 0, bf16). */
 int sarssl_stem_c1_stats(const void* a0, long npix, const float* W1, double* mom14, double* sums128, int dtype, void* stream);
+/* sarssl_stem_c1_stats followed by sarssl_bn_finalize (C = 64, N = npix) in two launches instead of three: aff (4 x 64) = scale | shift |
+ * mean | rstd of BatchNorm(1), running statistics and the batch counter updated (pass null for eval-style use) */
+int sarssl_stem_c1_stats_affine(const void* a0, long npix, const float* W1, double* mom14, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* aff,
+                                int dtype, void* stream);
 int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const float* scale, const float* shift, const void* w, void* out,
                           int nb, int F, int T, double* stats, void* stream);
 int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const float* W1, int nb, int F, int T, const float* scale,

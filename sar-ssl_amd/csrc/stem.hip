@@ -1110,6 +1110,45 @@ extern "C" int sarssl_stem_c1_stats(const void* a0, long npix, const float* W1, 
     SARSSL_CHECK_LAUNCH("stem_a0_moments_kernel");
     return 0;
 }
+// sarssl_stem_c1_stats + sarssl_bn_finalize (C = 64, N = npix) with the sums -> affine step done by the same one-workgroup kernel that
+// forms the sums from the moments: aff = [scale | shift | mean | rstd] (4 x 64), running statistics / batch counter updated.
+__global__ void stem_c1_affine_from_moments_kernel(const double* __restrict__ mom, const float* __restrict__ W1, long N,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                   float* __restrict__ running_mean, float* __restrict__ running_var, long* __restrict__ nbt,
+                                                   float* __restrict__ aff) {
+    const int co = threadIdx.x;
+    if (co == 0 && nbt) *nbt += 1;
+    if (co >= 64) return;
+    double w[4];
+    for (int c = 0; c < 4; ++c) w[c] = (double)W1[co * 4 + c];
+    double s = 0.0, q = 0.0;
+    int k = 4;
+    for (int i = 0; i < 4; ++i) {
+        s += w[i] * mom[i];
+        for (int j = i; j < 4; ++j) { q += (i == j ? 1.0 : 2.0) * w[i] * w[j] * mom[k]; ++k; }
+    }
+    const double m = s / (double)N;
+    double var = q / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    aff[co] = gamma[co] * r; aff[64 + co] = beta[co] - (float)m * gamma[co] * r; aff[128 + co] = (float)m; aff[192 + co] = r;
+    if (running_mean) {
+        const double unb = (N > 1) ? var * (double)N / (double)(N - 1) : var;
+        running_mean[co] = (1.f - momentum) * running_mean[co] + momentum * (float)m;
+        running_var[co] = (1.f - momentum) * running_var[co] + momentum * (float)unb;
+    }
+}
+extern "C" int sarssl_stem_c1_stats_affine(const void* a0, long npix, const float* W1, double* mom14, const float* gamma, const float* beta,
+                                           float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* aff,
+                                           int dtype, void* stream) {
+    SARSSL_REQUIRE(npix > 0 && mom14 && W1 && gamma && beta && aff, "sarssl_stem_c1_stats_affine");
+    if (SARSSL_ZERO(mom14, 14 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for(npix, 256 * 4, 512);
+    DISPATCH_T(dtype, (stem_a0_moments_kernel<T><<<nblk, 256, 0, ST>>>((const T*)a0, npix, mom14)));
+    stem_c1_affine_from_moments_kernel<<<1, 64, 0, ST>>>(mom14, W1, npix, gamma, beta, eps, momentum, running_mean, running_var, nbt, aff);
+    SARSSL_CHECK_LAUNCH("stem_c1_affine_from_moments_kernel");
+    return 0;
+}
 
 extern "C" int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F,
                                   int Tn, void* y4, int dtype, void* stream) {

@@ -260,8 +260,9 @@ def stem_fwd(a0, pe, train, saved):
         # the first layer's 64-channel output is never stored: its BatchNorm statistics follow from the 4 + 10 moments of the
         # 4-channel input, the first 3x3 convolution (and, in backward, its weight gradient and the layer's own backward pass) form
         # relu(bn1(W1 a0)) from a0 while staging - 4 x 537 MB less HBM traffic per encoder and step at B = 64
-        s1, mom1 = hip.stem_c1_stats(a0, W1, keep_moments=True)
-        aff1 = bn_affine(None, 64, pe[1], train, sums=s1, N=B * F * T)
+        bn1 = pe[1]
+        aff1, mom1 = hip.stem_c1_bn_affine(a0, W1, bn1.weight.data, bn1.bias.data, bn1.running_mean, bn1.running_var,
+                                           bn1.num_batches_tracked, eps=bn1.eps, momentum=bn1.momentum)
         r = hip.conv3x3_fwd_c1(a0, W1, aff1[0], aff1[1], _taps(pe[3])[0], want_stats=True)
         if r is not None:
             y2, s2 = r

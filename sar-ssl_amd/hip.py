@@ -364,6 +364,17 @@ def stem_c1_stats(a0, W1, keep_moments=False):
     return (sums, mom) if keep_moments else sums
 
 
+def stem_c1_bn_affine(a0, W1, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
+    """Training-mode BatchNorm(1) affine of y1 = W1 a0 from the input's moments: -> (aff (4,64) f32 = scale | shift | mean | rstd, moments
+    f64[14]); running statistics and the batch counter are updated like sarssl_bn_finalize does."""
+    npix = a0.numel() // 4
+    mom = torch.zeros(16, dtype=torch.float64, device=a0.device)
+    aff = torch.empty((4, 64), dtype=torch.float32, device=a0.device)
+    _lib.call("sarssl_stem_c1_stats_affine", _p(a0), c_long(npix), _p(W1), _p(mom), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
+              _p(running_mean), _p(running_var), _p(nbt), _p(aff), c_int(dt(a0)), _stream())
+    return aff, mom
+
+
 def conv3x3_dgrad_c1red(dy, w_tap_dgrad, a0, W1, aff, mom, train, dW1, dgamma, dbeta):
     """Data gradient of the first 3x3 convolution consumed in its epilogue: dW1 (64,4,1,1) / dgamma / dbeta (64) += the first stem
     layer's parameter gradients; the 64-channel gradient tensor is never stored (mom = the input's moments from stem_c1_stats).

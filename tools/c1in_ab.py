@@ -23,6 +23,23 @@ for flag in (True, False, 'again'):
     loss.backward()
     torch.cuda.synchronize()
     res[flag] = (float(loss.detach()), flat.grad.clone(), {n: b.clone() for n, b in net.named_buffers() if "running" in n})
+# fp32 mode (split-bf16 MFMA, the mode that meets 1e-3 against the reference) as the yardstick for both bf16 variants
+runtime.set_precision("fp32")
+torch.manual_seed(3)
+net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev)
+for m in net.modules():
+    if isinstance(m, torch.nn.Dropout): m.p = 0.0
+net.to(dev).train()
+flat = runtime.FlatParams(net)
+random.seed(5)
+loss, _, _ = net(x)
+loss.backward()
+torch.cuda.synchronize()
+g32 = flat.grad.clone()
+for k, name in ((True, "first-layer tensors not stored"), (False, "stored path")):
+    g = res[k][1]
+    print("bf16 %-32s vs fp32 mode: loss rel %.2e  grad max-abs rel %.3e  cos %.6f" % (name, abs(res[k][0] - float(loss.detach())) / abs(float(loss.detach())),
+          ((g - g32).abs().max() / g32.abs().max()).item(), torch.nn.functional.cosine_similarity(g, g32, dim=0).item()))
 for a, b in ((True, False), ('again', False)):
   l1, g1, b1 = res[a]; l0, g0, b0 = res[b]
   print("==", {True: "first-layer tensors not stored", 'again': "stored path, second run"}[a], "vs stored path")
