@@ -139,6 +139,19 @@ int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad, int d, int
  * relu(bn1(W1 a0)) formed from a0 (B,F,T,4) bf16 while staging (return 1 = kernel disabled, nothing done);
  * stem_c1_bwd_a0 = sarssl_stem_c1_bwd with y1 recomputed (npix % 64 == 0, bf16). */
 int sarssl_stem_c1_stats(const void* a0, long npix, const float* W1, double* mom14, double* sums128, int dtype, void* stream);
+/* Training-mode BatchNorm finalize done by the consumer of the affine (reference: nn.BatchNorm2d / BatchNorm1d in train mode,
+ * code/model.py:50-64 and code/common/conformer/convolution.py:140-143): the `_fin` launches derive scale / shift from the producer's sums
+ * themselves; workgroup 0 writes aff = [scale | shift | mean | rstd] (4 x C) and updates running_mean / running_var / nbt exactly like
+ * sarssl_bn_finalize - which then is not launched. */
+typedef struct SarsslBnFin {
+    const double* sums; long N; int C;
+    const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; long* nbt;
+    float* aff;
+} SarsslBnFin;
+int sarssl_conv3x3_fwd_fin(const void* in, const void* w, void* out, int nb, int F, int T, const SarsslBnFin* fin, double* stats, void* stream);
+int sarssl_stem_c4_fwd_fin(const void* y3, const float* W4, const SarsslBnFin* fin, int nb, int F, int Tn, void* y4, int dtype, void* stream);
+int sarssl_cl_affine_act_fin(const void* x, long N, int C, const SarsslBnFin* fin, int act, void* z, int dtype, void* stream);
 /* sarssl_stem_c1_stats followed by sarssl_bn_finalize (C = 64, N = npix) in two launches instead of three: aff (4 x 64) = scale | shift |
  * mean | rstd of BatchNorm(1), running statistics and the batch counter updated (pass null for eval-style use) */
 int sarssl_stem_c1_stats_affine(const void* a0, long npix, const float* W1, double* mom14, const float* gamma, const float* beta,

@@ -58,6 +58,7 @@ struct ConvArgs {
     // and contracts it over the pixels against [a0 | 1] on the matrix cores: c1_red (f64[644], sarssl_stem_c1_bwd's layout) receives
     // G[co][c] = sum_p g a0[c] and s1[co] = sum_p g
     const void* c1_a0; double* c1_red;
+    SarsslBnFin fin;    // fin.sums != null: the prologue's scale / shift come from the producer's sums and workgroup 0 publishes the affine (common.h)
 #ifdef CONV_STAMPS
     unsigned long long* stamps;
 #endif
@@ -468,6 +469,7 @@ __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int
 template <bool BNRED, bool BNIN = false, bool C1IN = false, bool C1RED = false>
 __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     typedef bf16 T;
+    constexpr bool FIN_OK = !BNRED && !BNIN && !C1IN && !C1RED;      // consumer-side BatchNorm finalize: the plain forward variant only
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
     __shared__ float sStats[128];
@@ -510,7 +512,11 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     __syncthreads();                                // weights, counters (the only workgroup-wide barrier before the end)
     float sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+    for (int e = 0; e < 8; ++e) {
+        if (FIN_OK && a.fin.sums) bn_fin_channel(a.fin, cch * 8 + e, sc[e], sh[e]);
+        else { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+    }
+    if (FIN_OK && a.fin.sums && blockIdx.x == 0) bn_fin_publish(a.fin, tid, 512);
     BnInConst kin;
     if (BNIN) bnin_setup(kin, a.bnin_aff, a.bnin_red, a.bnin_use_stats, (long)a.nb * F * Tn, cch * 8);
     C1Const kc1;
@@ -1262,6 +1268,28 @@ extern "C" int sarssl_conv3x3_dgrad_bnin(const void* dz_in, const void* w, void*
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
     conv3x3_fwd_pp_kernel<false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<bnin>");
+    return 0;
+}
+
+// sarssl_conv3x3_fwd (bf16, BN+ReLU prologue, optional statistics epilogue) with the prologue BatchNorm's training-mode finalize done by
+// this launch (see SarsslBnFin; fin->sums = the sums of `in`, C = 64).  bf16 ping-pong kernel only (returns 1 when it is disabled).
+extern "C" int sarssl_conv3x3_fwd_fin(const void* in, const void* w, void* out, int nb, int F, int T, const SarsslBnFin* fin, double* stats,
+                                      void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && fin && fin->sums && fin->aff && fin->C == 64, "sarssl_conv3x3_fwd_fin");
+    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
+    if (!use_pp) return 1;
+    if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    ConvArgs a = {};
+#ifdef CONV_STAMPS
+    a.stamps = g_conv_stamps_host;
+#endif
+    a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
+    a.stats = stats;
+    a.in = in; a.w = w; a.out = out; a.prologue = 1; a.fin = *fin;
+    a.nb = nb; a.F = F; a.T = T;
+    const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
+    conv3x3_fwd_pp_kernel<false><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
+    SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<fin>");
     return 0;
 }
 

@@ -230,6 +230,12 @@ def bn_affine(x, C, bn, train, sums=None, N=None):
     return hip.bn_eval_affine(C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, eps=bn.eps)
 
 
+def bn_pending(bn, sums, N, C):
+    """Training-mode BatchNorm with finished sums whose finalize is left to the launch that applies the affine (hip.BnPending)."""
+    return hip.BnPending(sums, N, C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                         bn.momentum)
+
+
 def bn_param_grads(bn, red, C):
     """red = [sum g | sum g*xhat] (f64, 2C) -> dbeta, dgamma."""
     hip.f64_accum2(red, gbuf(bn.bias), gbuf(bn.weight))
@@ -274,13 +280,31 @@ def stem_fwd(a0, pe, train, saved):
     if y2 is None:
         y2, s2 = hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], want_stats=True) if fuse else \
             (hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], precise=RT.precise), None)
-    aff2 = bn_affine(y2, 64, pe[4], train, sums=s2)
-    y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
-        (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
-    aff3 = bn_affine(y3, 64, pe[7], train, sums=s3)
-    y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])           # (B,T,F,4)
-    aff4 = bn_affine(y4, 4, pe[10], train)
-    z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
+    if fuse and _BNFIN:
+        # the launch that applies a BatchNorm affine derives it from the producer's sums itself and publishes aff / running statistics
+        # (hip.BnPending): no one-workgroup finalize launch between producer and consumer on the stem's chain
+        npix = B * F * T
+        p2 = bn_pending(pe[4], s2, npix, 64)
+        r = hip.conv3x3_fwd_fin(y2, _taps(pe[6])[0], p2, want_stats=True)
+        if r is None:
+            aff2 = p2.affine()
+            r = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True)
+        y3, s3 = r
+        aff2 = p2.aff
+        p3 = bn_pending(pe[7], s3, npix, 64)
+        y4 = hip.stem_c4_fwd_fin(y3, pe[9].weight.data.view(4, 64), p3)                    # (B,T,F,4)
+        aff3 = p3.aff
+        p4 = bn_pending(pe[10], hip.cl_stats(y4, 4)[0], npix, 4)
+        z4 = hip.cl_affine_act_fin(y4, 4, p4, RELU).view(B * T, F * 4)
+        aff4 = p4.aff
+    else:
+        aff2 = bn_affine(y2, 64, pe[4], train, sums=s2)
+        y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
+            (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
+        aff3 = bn_affine(y3, 64, pe[7], train, sums=s3)
+        y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])           # (B,T,F,4)
+        aff4 = bn_affine(y4, 4, pe[10], train)
+        z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
     e = mm_nt(z4, _patch_w(pe[12], F), fp8=False)
     saved.append((a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
     return e
@@ -296,6 +320,7 @@ _DWGLU = os.environ.get("SARSSL_DWGLU", "1") != "0"             # 0: separate gl
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 _C1IN = os.environ.get("SARSSL_C1IN", "1") != "0"             # 0: store the first layer's 64-channel output (A/B runs)
+_BNFIN = os.environ.get("SARSSL_BNFIN", "0") != "0"           # 1: BatchNorm finalize inside the launch that applies the affine (10 launches fewer; measured: no gain)
 _C1RED = os.environ.get("SARSSL_C1RED", "1") != "0"           # 0: store the gradient w.r.t. that output and reduce it in a pass of its own
 
 
@@ -676,12 +701,17 @@ def convmod_fwd(x, cm, B, T, train, saved):
     if _DWGLU and d % 8 == 0:            # GLU + depthwise conv + BatchNorm batch sums in one LDS-tiled pass (csrc/dwconv.hip)
         c, sums = hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T, want_stats=True) if train else \
             (hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T), None)
-        aff = bn_affine(c, d, bn, train, sums=sums)
+        aff = None if (train and _BNFIN) else bn_affine(c, d, bn, train, sums=sums)
     else:
         g = hip.glu_fwd(h)
         c = hip.dwconv(g.view(B, T, d), dw.weight.data.view(d, -1))
         aff = bn_affine(c, d, bn, train)
-    s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
+    if aff is None:                      # BatchNorm finalize inside the launch that applies it (hip.BnPending)
+        pend = bn_pending(bn, sums, B * T, d)
+        s = hip.cl_affine_act_fin(c, d, pend, SWISH).view(B * T, d)
+        aff = pend.aff
+    else:
+        s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
     po = _p(seq[8], train)
     if _replaying(train) and po > 0:                       # the reference draws this mask on the (B, d, T) conv output
         y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data)

@@ -3,6 +3,9 @@
 PyTorch is used for device memory and streams only: every wrapper passes ``data_ptr()``s and the
 current HIP stream to ``libsarssl_hip.so``.
 """
+import ctypes
+import os
+
 import torch
 
 from . import _lib
@@ -659,6 +662,68 @@ def bn_train_affine(x, C, gamma, beta, running_mean, running_var, nbt, eps=1e-5,
     _lib.call("sarssl_bn_finalize", _p(sums), c_long(N), c_int(C), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
               _p(running_mean), _p(running_var), _p(nbt), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), _stream())
     return aff
+
+
+class _BnFinStruct(ctypes.Structure):
+    _fields_ = [("sums", ctypes.c_void_p), ("N", ctypes.c_long), ("C", ctypes.c_int), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
+                ("nbt", ctypes.c_void_p), ("aff", ctypes.c_void_p)]
+
+
+class BnPending:
+    """Training-mode BatchNorm whose sums exist but whose affine has not been formed yet.  The launch that applies the affine can do
+    the finalize itself (`fin()` -> SarsslBnFin for the `_fin` entry points: that launch also writes `aff` and the running statistics);
+    anything else asks for `affine()`, which runs the stand-alone finalize once."""
+
+    def __init__(self, sums, N, C, gamma, beta, running_mean, running_var, nbt, eps, momentum):
+        self.sums, self.N, self.C = sums, N, C
+        self.p = (gamma, beta, running_mean, running_var, nbt, eps, momentum)
+        self.aff = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+        self.done = False
+
+    def fin(self):
+        assert not self.done
+        self.done = True
+        g, b, rm, rv, nbt, eps, mom = self.p
+        self._st = _BnFinStruct(self.sums.data_ptr(), self.N, self.C, g.data_ptr(), b.data_ptr(), eps, mom, rm.data_ptr(), rv.data_ptr(),
+                                nbt.data_ptr(), self.aff.data_ptr())
+        return ctypes.byref(self._st)
+
+    def affine(self):
+        if not self.done:
+            self.done = True
+            g, b, rm, rv, nbt, eps, mom = self.p
+            _lib.call("sarssl_bn_finalize", _p(self.sums), c_long(self.N), c_int(self.C), _p(g), _p(b), c_float(eps), c_float(mom),
+                      _p(rm), _p(rv), _p(nbt), _p(self.aff[0]), _p(self.aff[1]), _p(self.aff[2]), _p(self.aff[3]), _stream())
+        return self.aff
+
+
+def conv3x3_fwd_fin(x, w_tap, pend, want_stats=False):
+    """conv3x3_fwd with BN+ReLU prologue whose BatchNorm finalize happens inside the launch (pend: BnPending of x's BatchNorm).
+    None when the ping-pong kernel is disabled (pend untouched)."""
+    _need_cuda(x, w_tap)
+    B, F, T, C = x.shape
+    assert C == 64 and x.dtype == torch.bfloat16 and w_tap.dtype == torch.bfloat16 and x.is_contiguous() and pend.C == 64
+    if os.environ.get("SARSSL_CONV_PP", "1") == "0":
+        return None
+    out = torch.empty_like(x)
+    stats = _sums(128, x.device) if want_stats else None
+    with _Timed("conv3x3_fwd:bn_prologue"):
+        _lib.call("sarssl_conv3x3_fwd_fin", _p(x), _p(w_tap), _p(out), c_int(B), c_int(F), c_int(T), pend.fin(), _p(stats), _stream())
+    return (out, stats) if want_stats else out
+
+
+def stem_c4_fwd_fin(y3, W4, pend):
+    B, F, T, _ = y3.shape
+    y4 = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)
+    _lib.call("sarssl_stem_c4_fwd_fin", _p(y3), _p(W4), pend.fin(), c_int(B), c_int(F), c_int(T), _p(y4), c_int(dt(y3)), _stream())
+    return y4
+
+
+def cl_affine_act_fin(x, C, pend, act):
+    z = torch.empty_like(x)
+    _lib.call("sarssl_cl_affine_act_fin", _p(x), c_long(x.numel() // C), c_int(C), pend.fin(), c_int(act), _p(z), c_int(dt(x)), _stream())
+    return z
 
 
 def bn_eval_affine(C, gamma, beta, running_mean, running_var, eps=1e-5):

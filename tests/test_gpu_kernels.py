@@ -932,3 +932,41 @@ def test_first_conv_data_gradient_consumed_in_its_epilogue(shape, train):
     ref = dyn.t() @ a0.double().view(-1, 4)
     assert _relerr(dW.view(64, 4), ref) < 2e-4
     assert _relerr(dbe, s1) < 2e-4 and _relerr(dga, s2) < 2e-4
+
+
+def test_batchnorm_finalize_inside_the_consuming_launch():
+    """The `_fin` entry points (scale / shift derived from the producer's sums inside the launch that applies them, affine and running
+    statistics published by its workgroup 0) against stand-alone bn_finalize + the plain launches: identical outputs and state."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(61)
+
+    def bn_state(C):
+        return [(torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev), torch.zeros(C, device=dev),
+                torch.ones(C, device=dev), torch.zeros((), dtype=torch.long, device=dev)]
+
+    def both(C, x, run_ref, run_fin):
+        hip.sums_arena_reset(dev)
+        sums, N = hip.cl_stats(x, C)
+        st_a, st_b = bn_state(C), None
+        st_b = [t.clone() for t in st_a]
+        aff = hip.bn_train_affine(x, C, *st_a, eps=1e-5, momentum=0.1, sums=sums)
+        ref = run_ref(aff)
+        pend = hip.BnPending(sums, N, C, *st_b, 1e-5, 0.1)
+        got = run_fin(pend)
+        assert torch.equal(pend.aff, aff)
+        for a, b in zip(st_a[2:], st_b[2:]):
+            assert torch.equal(a, b)
+        return ref, got
+
+    x = torch.randn((2, 16, 40, 64), generator=g).bfloat16().to(dev)
+    w = (torch.randn((9, 64, 64), generator=g) * 0.05).bfloat16().to(dev)
+    ref, got = both(64, x, lambda aff: hip.conv3x3_fwd(x, w, aff[0], aff[1]), lambda p: hip.conv3x3_fwd_fin(x, w, p))
+    assert got is not None and torch.equal(ref, got)
+    W4 = (torch.randn((4, 64), generator=g) * 0.2).to(dev)
+    ref, got = both(64, x, lambda aff: hip.stem_c4_fwd(x, W4, aff[0], aff[1]), lambda p: hip.stem_c4_fwd_fin(x, W4, p))
+    assert torch.equal(ref, got)
+    for dtp, C, shape in ((torch.bfloat16, 256, (64, 256)), (torch.float32, 4, (2, 24, 16, 4))):
+        xx = torch.randn(shape, generator=g).to(dtp).to(dev)
+        ref, got = both(C, xx, lambda aff: hip.cl_affine_act(xx, C, aff, 2), lambda p: hip.cl_affine_act_fin(xx, C, p, 2))
+        assert torch.equal(ref, got)
