@@ -119,7 +119,7 @@ def test_backward_stage_hooks_fire_before_the_stem_backward(monkeypatch):
     monkeypatch.setattr(engine, "block_bwd", lambda d, blk, saved: (log.append("block"), d)[1])
     monkeypatch.setattr(engine, "patch_bwd", lambda d, pe, saved: (log.append("patch"), d)[1])
     monkeypatch.setattr(engine, "stem_bwd", lambda d, pe, saved: log.append("stem"))
-    monkeypatch.setattr(engine, "decoder_bwd", lambda d, dec, saved: (log.append("decoder"), torch.zeros(16, 768))[1])
+    monkeypatch.setattr(engine, "decoder_bwd", lambda d, dec, saved, after_dx=None: (log.append("decoder"), torch.zeros(16, 768))[1])
     monkeypatch.setattr(hip, "masked_mse_bwd", lambda *a, **k: torch.zeros(1))
     monkeypatch.setattr(net, "_side_stream", lambda dev: None)
     red = sdist.FlatGradAllReduce(net, flat)
