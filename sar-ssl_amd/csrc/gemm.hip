@@ -198,17 +198,32 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
         uint4 ra[BM / 32], rb[BN / 32];
         tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
         tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
+#ifdef GEMM_STAMPS
+#define GSTAMP(k) do { if (g.stamps && bid_x == 0 && bid_y == 0 && bid_z == 0 && lane == 0 && kt < 16) g.stamps[((tid >> 6) * 16 + kt) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+        int kt = 0;
+#else
+#define GSTAMP(k) do {} while (0)
+#endif
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            GSTAMP(0);
             tile_store<AKC, BM>(sA, tid, ra);
             tile_store<BKC, BN>(sB, tid, rb);
+            GSTAMP(1);
             __syncthreads();
+            GSTAMP(2);
             if (k0 + BK < k_end) {                           // next K-tile in flight behind the MFMAs
                 pa += stepA; pb += stepB;
                 tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
                 tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
             }
+            GSTAMP(3);
             mfma_phase(sA, sB);
+            GSTAMP(4);
             __syncthreads();
+            GSTAMP(5);
+#ifdef GEMM_STAMPS
+            ++kt;
+#endif
         }
     }
 
@@ -272,6 +287,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     if constexpr (FM >= 4) { slice(2, exa, exb); slice(3, exb, exa); }
 }
 
+#ifdef GEMM_STAMPS
+static unsigned long long* g_gemm_stamps_host = nullptr;
+extern "C" int sarssl_gemm_stamp_buffer(void* p) { g_gemm_stamps_host = (unsigned long long*)p; return 0; }
+#endif
 template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_kernel(GemmArgs g) {
     gemm_body<TA, TB, TC, AKC, BKC, FM, EDGE>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
@@ -442,6 +461,9 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K;
     g.row_shift = 0;
+#ifdef GEMM_STAMPS
+    g.stamps = g_gemm_stamps_host;
+#endif
     if (c_row_shift) {
         SARSSL_REQUIRE(M == N && ldc == N && split_k <= 0 && !precise && !resid && !preact && !aux, "sarssl_gemm(c_row_shift)");
         g.row_shift = N;

@@ -22,6 +22,9 @@ struct GemmArgs {
     int row_shift;              // != 0 (= T, with M = N = ldc = T): row m of every batch matrix is stored m + 1 - T elements further
                                 // (elements falling before the matrix are dropped): the relative-position shift of the reference
                                 // (attention.py:105-113: pad one zero column, reinterpret (T, T+1) as (T+1, T), drop the first row)
+#ifdef GEMM_STAMPS
+    unsigned long long* stamps;     // probe build only (tools/gemm_stamps.py): s_memtime per K-loop phase of workgroup (0,0,0)
+#endif
 };
 
 // ---- fused epilogue on one 8-wide piece of one output row (v = alpha * accumulator) -------------------------------------------------
