@@ -76,10 +76,11 @@ def main():
     args = ap.parse_args()
 
     from sar_ssl_amd import dist as sdist, hip, model, runtime, synth, _lib
-    rank, world, local = sdist.init_from_env()
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
-    local = local % max(torch.cuda.device_count(), 1)      # (single-GPU functional tests run 2 ranks on one device over gloo)
+    # the rank's GPU is selected BEFORE the process group exists (RCCL binds a communicator to the current device at its first collective)
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)      # (single-GPU functional tests run 2 ranks on one device over gloo)
     torch.cuda.set_device(local)
+    rank, world, _ = sdist.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
     dev = torch.device("cuda", local)
     runtime.set_precision(args.precision)
     torch.manual_seed(1234)
