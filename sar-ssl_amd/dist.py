@@ -20,6 +20,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        # select this rank's GPU before the process group exists: RCCL binds a communicator to the current device at its first collective
+        torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
