@@ -172,6 +172,9 @@ int sarssl_stem_c1_bwd_finalize_mom(const double* red, const double* mom14, cons
                                     float* dW1, float* dgamma, float* dbeta, void* stream);
 int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
                        int dtype, void* stream);
+/* sarssl_stem_c4_fwd that also returns the BatchNorm sums of its stored output: stats8 f64[8] = [sum (4) | sum of squares (4)] */
+int sarssl_stem_c4_fwd_stats(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
+                             double* stats8, int dtype, void* stream);
 int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* W4, const float* scale, const float* shift,
                        const float* mean, const float* rstd, int nb, int F, int Tn, void* g3, double* red, int dtype,
                        void* stream);

@@ -372,8 +372,9 @@ __global__ void stem_c1_bwd_finalize_kernel(const double* __restrict__ red, long
 template <typename T>
 __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __restrict__ W4, const float* __restrict__ scale,
                                    const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4, int nstream,
-                                   SarsslBnFin fin = SarsslBnFin()) {
+                                   SarsslBnFin fin = SarsslBnFin(), double* __restrict__ stats = nullptr) {
     const int cg = threadIdx.x & 7;
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};      // stats: sum / sum of squares of the STORED y4 (BatchNorm(4) statistics)
     float w[4][8], sc[8], sh[8];
     if (fin.sums && blockIdx.x == 0) bn_fin_publish(fin, threadIdx.x, blockDim.x);
 #pragma unroll
@@ -414,7 +415,29 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
             const long bf = p / Tn;
             const int f = (int)(bf % F), b = (int)(bf / F);
             st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
+            if (stats) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float r = (sizeof(T) == 2) ? bf16_bits_to_f32(f32_to_bf16_bits(o[c])) : o[c];
+                    ssum[c] += r; ssq[c] = fmaf(r, r, ssq[c]);
+                }
+            }
         }
+    }
+    if (stats) {                    // lanes 0, 8, 16, ... hold the pixels: fold over lane bits 3..5, then the 4 waves through LDS, 8 atomics per workgroup
+        __shared__ float sfold[4][8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ssum[c] += __shfl_xor(ssum[c], 8, 64); ssum[c] += __shfl_xor(ssum[c], 16, 64); ssum[c] += __shfl_xor(ssum[c], 32, 64);
+            ssq[c] += __shfl_xor(ssq[c], 8, 64); ssq[c] += __shfl_xor(ssq[c], 16, 64); ssq[c] += __shfl_xor(ssq[c], 32, 64);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { sfold[wave][c] = ssum[c]; sfold[wave][4 + c] = ssq[c]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) atomicAdd(&stats[threadIdx.x], (double)(sfold[0][threadIdx.x] + sfold[1][threadIdx.x] + sfold[2][threadIdx.x] + sfold[3][threadIdx.x]));
     }
 }
 
@@ -1166,6 +1189,19 @@ extern "C" int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* 
     static const int nstream = grid_cap("SARSSL_C4F_STREAMS", 1);
     DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, nstream)));
     SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel");
+    return 0;
+}
+// The same, also returning the BatchNorm(4) sums of the stored output: stats8 f64[8] = [sum (4) | sum of squares (4)] (zeroed here) - the
+// separate statistics pass over y4 is not needed.
+extern "C" int sarssl_stem_c4_fwd_stats(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn,
+                                        void* y4, double* stats8, int dtype, void* stream) {
+    SARSSL_REQUIRE(stats8 != nullptr, "sarssl_stem_c4_fwd_stats");
+    if (SARSSL_ZERO(stats8, 8 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    static const int cap = grid_cap("SARSSL_GRID_C4F", 8192);
+    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
+    static const int nstream = grid_cap("SARSSL_C4F_STREAMS", 1);
+    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, nstream, SarsslBnFin(), stats8)));
+    SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel<stats>");
     return 0;
 }
 // The same with BatchNorm(3)'s training-mode finalize done here (see SarsslBnFin): fin->sums = the sums of y3 (C = 64).

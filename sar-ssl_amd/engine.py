@@ -302,8 +302,12 @@ def stem_fwd(a0, pe, train, saved):
         y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
             (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
         aff3 = bn_affine(y3, 64, pe[7], train, sums=s3)
-        y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])           # (B,T,F,4)
-        aff4 = bn_affine(y4, 4, pe[10], train)
+        if train:                       # BatchNorm(4) sums ride in the 64->4 pass (no statistics pass over y4)
+            y4, s4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1], want_stats=True)        # (B,T,F,4)
+            aff4 = bn_affine(y4, 4, pe[10], train, sums=s4)
+        else:
+            y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])
+            aff4 = bn_affine(y4, 4, pe[10], train)
         z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
     e = mm_nt(z4, _patch_w(pe[12], F), fp8=False)
     saved.append((a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))

@@ -432,9 +432,15 @@ def stem_c1_bwd(dz1, y1, a0, aff, train, dW1, dgamma, dbeta):
               _p(dgamma), _p(dbeta), c_int(dt(a0)), _stream())
 
 
-def stem_c4_fwd(y3, W4, scale, shift):
+def stem_c4_fwd(y3, W4, scale, shift, want_stats=False):
+    """-> y4 (B,T,F,4), or (y4, sums f64[8]) with the BatchNorm sums of the stored y4 accumulated in the same pass."""
     B, F, T, _ = y3.shape
     y4 = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)
+    if want_stats:
+        sums = _sums(8, y3.device)
+        _lib.call("sarssl_stem_c4_fwd_stats", _p(y3), _p(W4), _p(scale), _p(shift), c_int(B), c_int(F), c_int(T), _p(y4), _p(sums),
+                  c_int(dt(y3)), _stream())
+        return y4, sums
     _lib.call("sarssl_stem_c4_fwd", _p(y3), _p(W4), _p(scale), _p(shift), c_int(B), c_int(F), c_int(T), _p(y4), c_int(dt(y3)), _stream())
     return y4
 

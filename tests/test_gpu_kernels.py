@@ -970,3 +970,20 @@ def test_batchnorm_finalize_inside_the_consuming_launch():
         xx = torch.randn(shape, generator=g).to(dtp).to(dev)
         ref, got = both(C, xx, lambda aff: hip.cl_affine_act(xx, C, aff, 2), lambda p: hip.cl_affine_act_fin(xx, C, p, 2))
         assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
+def test_stem_c4_forward_statistics_epilogue(dtp):
+    """stem_c4_fwd(want_stats) == stem_c4_fwd followed by the statistics pass over its stored output."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(81)
+    y3 = torch.randn((3, 24, 40, 64), generator=g).to(dtp).to(dev)
+    W4 = (torch.randn((4, 64), generator=g) * 0.2).to(dev)
+    sc = (torch.rand(64, generator=g) + 0.5).to(dev); sh = (torch.randn(64, generator=g) * 0.3).to(dev)
+    hip.sums_arena_reset(dev)
+    ref = hip.stem_c4_fwd(y3, W4, sc, sh)
+    sums_ref, _ = hip.cl_stats(ref, 4)
+    y4, sums = hip.stem_c4_fwd(y3, W4, sc, sh, want_stats=True)
+    assert torch.equal(y4, ref)
+    assert _relerr(sums[:4], sums_ref[:4]) < 1e-5 and _relerr(sums[4:], sums_ref[4:]) < 1e-5
