@@ -9,17 +9,27 @@ One step = one pass of the whole hot path over one batch of synthetic input that
 masked MSE -> hand-written backward -> (bucketed RCCL all-reduce overlapped with backward) -> fused Adam.  bf16 storage/MFMA,
 f32 accumulation; dropout active (training mode), nothing cached or skipped.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with events on the launch stream around every BN-prologue launch of the
-dominant kernel (conv3x3_fwd_pp_kernel<false>, the ping-pong schedule of the 3x3 convolution: the forward convolution per encoder that
-reads a stored 64-channel input; the other forward convolution forms its input from the 4-channel stem input while staging (C1IN
-variant of the same kernel), and it and the data-gradient launches are timed under their own labels);
-`cpu_baseline` times the CPU oracle (oracle/sarssl_oracle.py, the validated restatement of the reference) on this host.
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
+  * `roofline`: measured live with events on the launch stream around every BN-prologue launch of the dominant kernel
+    (conv3x3_fwd_pp_kernel<false>, the forward 3x3 convolution with a stored 64-channel input), the effective shader clock of those
+    launches (in-kernel s_memtime / s_memrealtime probe), and the sibling launches under their own labels;
+  * `cpu_baseline`: the CPU oracle (oracle/sarssl_oracle.py, the validated restatement of the reference) timed on this host;
+  * `knobs`: the resolved state of every environment switch that selects a compute path (a line is only comparable with another one
+    under the same knobs; ablation switches that skip work do not exist in the product and any SARSSL_ABLATE* variable is refused);
+  * `parity_class`: what the timed numeric mode is pinned to against the reference (tests/, DESIGN.md section 2);
+  * `product_loop` (N = 1): the same step driven the way run_pretrain.py drives it - PCM-16 WAV files -> dataset.PcmSegmentLoader
+    (native reader thread + pinned upload) -> STFTLearner.pretrain_epoch (captured step, STFT inside the replay);
+  * `dist` (N > 1): backend, RCCL version, ranks, bytes per gradient bucket and the event-timed all-reduce of each bucket.
+`--via-learner` makes the product loop the line's primary value; `--workload config5` times BASELINE config 5 (4-microphone 10 s
+segments: 3 microphone pairs per segment, T = 624 frames).
 """
 import argparse
 import json
 import os
 import random
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,38 +40,107 @@ sys.path.insert(0, ROOT)
 import sarssl_boot  # noqa: E402,F401
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-FLOP_PER_SEG_STEP = 86.5e9         # 3 x 28.84 GFLOP forward contractions
+FLOP_PER_SEG_STEP = 86.5e9         # 3 x 28.84 GFLOP forward contractions (2-ch segment, T = 256)
+ATTN_CORE_FLOP = 1.51e9            # of which the score / PV products (quadratic in T): 3 x (0.201 + 3 x 0.101) GFLOP
 NSAMPLE = 65792
+WORKLOADS = {
+    # name: (samples per segment, microphones, frames T, pairs per segment)
+    "config2": (65792, 2, 256, 1),
+    "config5": (160000, 4, 624, 3),
+}
 
 
-def cpu_baseline(nwarm=3, nstep=8, B=8):
-    """CPU oracle train step (fp32, B=8: the reference's own CPU-runnable shape) on this host's cores: 3 warm-up + 8 timed full
-    steps, median.  8 intra-op threads = the reference's own cap (code/run_pretrain.py:19-24)."""
+def flop_per_segment(workload):
+    _, _, T, pairs = WORKLOADS[workload]
+    r = T / 256.0
+    return pairs * ((FLOP_PER_SEG_STEP - ATTN_CORE_FLOP) * r + ATTN_CORE_FLOP * r * r)
+
+
+def cpu_baseline(B=8):
+    """CPU oracle train step (fp32, B=8: the reference's own CPU-runnable shape) on this host's cores: 3 warm-up + 8
+    timed full steps at 8 intra-op threads = the reference's own cap (code/run_pretrain.py:19-24), median; and a second, shorter
+    sample at min(32, physical cores) threads when the host has more than 8."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import recipes
     import sarssl_oracle as orc
     from sar_ssl_amd import synth
     man = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_manifest.json")))["pretrain"]
     sig = torch.from_numpy(synth.make_batch(0, B))
-    ncore = os.cpu_count() or 8
-    nthr = min(8, ncore)
-    torch.set_num_threads(nthr)
-    sd = recipes.recipe_state_dict(man, 0)
-    state = {}
-    random.seed(1)
-    for _ in range(nwarm):                                     # oneDNN primitive creation, allocator warm-up
-        orc.train_step(sig, sd, state, 1e-3)
-    times = []
-    for _ in range(nstep):
-        t0 = time.time()
-        orc.train_step(sig, sd, state, 1e-3)
-        times.append(time.time() - t0)
-    med = float(np.median(times))
-    # (one intra-op thread per core of a 256-core host was measured at 0.04 segments/s - oversubscribed oneDNN/OpenMP - and took
-    #  ten minutes; the bounded sample is the 8-thread run only)
-    return {"value": round(B / med, 3), "unit": "segments/s", "cores": nthr, "kind": "port",
-            "sample": "median of %d full train steps (STFT+fwd+bwd+Adam) of the CPU oracle, fp32, batch %d, after %d warm-up steps; "
-                      "min %.2f / max %.2f s per step" % (nstep, B, nwarm, min(times), max(times))}
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 8
+    except Exception:
+        phys = os.cpu_count() or 8
+
+    def sample(nthr, nwarm, nstep):
+        torch.set_num_threads(nthr)
+        sd = recipes.recipe_state_dict(man, 0)
+        state = {}
+        random.seed(1)
+        for _ in range(nwarm):                                     # oneDNN primitive creation, allocator warm-up
+            orc.train_step(sig, sd, state, 1e-3)
+        times = []
+        for _ in range(nstep):
+            t0 = time.time()
+            orc.train_step(sig, sd, state, 1e-3)
+            times.append(time.time() - t0)
+        return float(np.median(times)), min(times), max(times)
+
+    nthr = min(8, os.cpu_count() or 8)
+    med, lo, hi = sample(nthr, 3, 8)
+    out = {"value": round(B / med, 3), "unit": "segments/s", "cores": nthr, "kind": "port",
+           "sample": "median of 8 full train steps (STFT+fwd+bwd+Adam) of the CPU oracle, fp32, batch %d, after 3 warm-up steps; "
+                     "min %.2f / max %.2f s per step" % (B, lo, hi), "host_physical_cores": phys}
+    more = min(32, phys)
+    if more > nthr:
+        # (one intra-op thread per core of a 256-core host was measured at 0.04 segments/s - oversubscribed oneDNN/OpenMP; the second
+        #  sample is bounded to 32 threads)
+        med2, lo2, hi2 = sample(more, 2, 5)
+        out["more_threads"] = {"value": round(B / med2, 3), "cores": more,
+                               "sample": "median of 5 steps after 2 warm-up steps, same workload; min %.2f / max %.2f s per step" % (lo2, hi2)}
+    return out
+
+
+def product_loop(dev, batch, precision, nseg=512, epochs=3):
+    """The step as run_pretrain.py drives it: `nseg` PCM-16 WAV segments on /dev/shm -> dataset.PcmSegmentLoader (native reader thread,
+    pinned int16 batches uploaded on a copy stream) -> STFTLearner.pretrain_epoch (captured step, STFT front-end inside the replay, Adam
+    re-created per epoch).  One untimed epoch (graph capture), then `epochs` timed epochs incl. their end-of-epoch synchronisation."""
+    from sar_ssl_amd import dataset, learner as L, model, runtime, synth
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="sarssl_bench_", dir=base)
+    try:
+        uniq = synth.to_pcm16(synth.make_batch(7000, 16))
+        for i in range(nseg):
+            dataset.write_wav_pcm16(os.path.join(d, "%d.wav" % i), np.roll(uniq[i % 16], 997 * (i // 16), axis=0))
+        files = dataset.segment_files(d)
+        loader = dataset.PcmSegmentLoader(files, batch, NSAMPLE, 2, shuffle=True, seed=3, device=dev, nthreads=8, drop_last=True)
+        torch.manual_seed(4321)
+        net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev)
+        lrn = L.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+        lrn.cuda()
+        if precision != "fp32":
+            lrn.amp()
+        runtime.set_precision(precision)
+        random.seed(99)
+        loader.set_epoch(0)
+        lrn.pretrain_epoch(loader, lr=1e-3, epoch=0)                # capture + first replays
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for ep in range(1, epochs + 1):
+            loader.set_epoch(ep)
+            last = lrn.pretrain_epoch(loader, lr=1e-3, epoch=ep)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nstep = epochs * len(loader)
+        g = lrn.__dict__.get("_step_graph")
+        return {"value": round(nstep * batch / dt, 2), "unit": "segments/s", "ms_per_step": round(1e3 * dt / nstep, 3), "steps": nstep,
+                "epochs": epochs, "segments_on_disk": nseg, "final_epoch_loss": round(float(last[0]), 5),
+                "step_mode": "hipGraph replay, STFT inside the replay" if g is not None and g._plan is not None else "eager launches",
+                "path": "PCM-16 WAV files (%s) -> dataset.PcmSegmentLoader (8 reader threads, pinned upload) -> "
+                        "STFTLearner.pretrain_epoch" % ("/dev/shm" if base else "tmp dir")}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -69,13 +148,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="segments per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="segments per GPU (default 64; config5: 16 four-microphone segments = 48 pairs)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-product-loop", action="store_true")
+    ap.add_argument("--via-learner", action="store_true", help="primary value = the product loop (WAV files -> loader -> Learner.pretrain_epoch)")
     ap.add_argument("--eager", action="store_true", help="enqueue the step launch by launch instead of replaying the captured HIP graph")
+    ap.add_argument("--graph", action="store_true", help="replay the captured step also when data-parallel (default there: eager launches)")
     args = ap.parse_args()
 
-    from sar_ssl_amd import dist as sdist, hip, model, runtime, synth, _lib
+    bad = sorted(k for k in os.environ if k.startswith("SARSSL_ABLATE"))
+    if bad:
+        sys.exit("bench.py: refusing to run with %s set - a step with work switched off is not a benchmark" % ", ".join(bad))
+
+    from sar_ssl_amd import dist as sdist, engine, hip, model, runtime, synth, _lib
+    nsample, nmic, T, pairs = WORKLOADS[args.workload]
+    batch = args.batch if args.batch is not None else (64 if args.workload == "config2" else 16)
     # the rank's GPU is selected BEFORE the process group exists (RCCL binds a communicator to the current device at its first collective)
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)      # (single-GPU functional tests run 2 ranks on one device over gloo)
     torch.cuda.set_device(local)
@@ -87,7 +176,7 @@ def main():
     random.seed(1234 + rank)
     runtime.RT.manual_seed(1234 + rank)
 
-    net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev).to(dev).train()
+    net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev).to(dev).train()
     flat = runtime.FlatParams(net)
     sdist.broadcast_parameters(flat)
     reducer = sdist.FlatGradAllReduce(net, flat)
@@ -95,9 +184,10 @@ def main():
     opt.zero_grad()
 
     # synthetic structured segments, int16 PCM resident in HBM (16 unique segments per rank, circularly shifted copies)
-    uniq = synth.make_batch(1000 * rank, 16)
-    segs = np.stack([np.roll(uniq[i % 16], 997 * (i // 16), axis=0) for i in range(args.batch)], axis=0)
+    uniq = synth.make_batch(1000 * rank, min(16, batch), nsample=nsample, nch=nmic)
+    segs = np.stack([np.roll(uniq[i % len(uniq)], 997 * (i // len(uniq)), axis=0) for i in range(batch)], axis=0)
     pcm = torch.from_numpy(synth.to_pcm16(segs)).to(dev)
+    from_pcm_in_graph = nmic == 2                                   # (the captured step runs the 2-microphone front-end itself)
 
     def step_eager():
         x = hip.stft_frontend(pcm)
@@ -109,10 +199,12 @@ def main():
         return loss
 
     # the training step of the product path (learner.pretrain_epoch): STFT front-end + masks + forward + backward + (all-reduce) + Adam
-    # captured into HIP graph(s) and replayed - same kernels, same order, one graph launch per step (per bucket boundary when
-    # data-parallel) instead of ~450 launches from Python
+    # captured into HIP graph(s) and replayed - same kernels, same order, one graph launch per step instead of ~450 launches from Python.
+    # Data parallel: the segmented replay (four graphs with the RCCL collectives in between) has never run on a multi-GPU node, so the
+    # default there is the launch-by-launch step with the overlapped bucket all-reduce (--graph opts in).
+    use_graph = (not args.eager) and (world == 1 or args.graph)
     graph = None
-    if not args.eager:
+    if use_graph:
         from sar_ssl_amd.graph import PretrainStepGraph
         graph = PretrainStepGraph(net, flat, reducer, lr=1e-3)
 
@@ -123,7 +215,9 @@ def main():
         if g is None:
             return step_eager()
         try:
-            return g.step(pcm=pcm, static=True)[0]      # the resident batch IS the graph's input buffer: no per-step copy
+            if from_pcm_in_graph:
+                return g.step(pcm=pcm, static=True)[0]  # the resident batch IS the graph's input buffer: no per-step copy
+            return g.step(x=hip.stft_frontend(pcm))[0]  # >2 microphones: pairing front-end launched in front of the replay
         except Exception as e:                          # (never seen; a failed capture must not cost the whole run its number)
             if g._plan is not None:
                 raise
@@ -140,6 +234,7 @@ def main():
         step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     graph = state["graph"]
+    clk = torch.zeros(20, dtype=torch.int64, device=dev)       # clock probe of the convolution launches (csrc/conv3x3.hip)
     if graph is None:
         hip.profile_start()
     n0 = _lib.ncalls
@@ -150,8 +245,12 @@ def main():
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     calls_per_step = (_lib.ncalls - n0) / max(args.steps, 1)
+    prof2 = {}
+    _lib.call("sarssl_conv_clock_probe", _lib.c_void_p(clk.data_ptr()))
     if graph is None:
         prof = hip.profile_stop()
+        step_eager()                                           # (one more step with the clock probe attached)
+        torch.cuda.synchronize()
     else:
         # per-kernel durations: a graph replay offers no host-side events around single launches, so the event-bracketed launches
         # are taken from eager steps of the SAME training run right after the timed region (same shapes, same kernels, the two
@@ -172,6 +271,8 @@ def main():
             step_eager()
         prof = hip.profile_stop()
         os.environ["SARSSL_TWO_STREAMS"] = "1"
+    wall_khz = _lib.lib().sarssl_wall_clock_khz()
+    clk_step = clk.cpu().numpy().reshape(5, 4).copy()
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -179,11 +280,31 @@ def main():
     loss_val = float(last.detach())
     assert np.isfinite(loss_val), "non-finite loss"
 
+    def eff_ghz(slot):
+        """effective shader clock of the last probed launch of a variant: shader-clock ticks / constant-rate ticks x that rate"""
+        s0, r0, s1, r1 = (int(v) for v in slot)
+        if wall_khz <= 0 or r1 <= r0 or s1 <= s0:
+            return None
+        return round((s1 - s0) / (r1 - r0) * wall_khz * 1e-6, 3)
+
+    dist_info = None
+    if world > 1:
+        dist_info = reducer.describe()
+        ms = reducer.time_buckets(iters=5)
+        t = torch.tensor([ms.get(b["name"], 0.0) for b in dist_info["buckets"]], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        for b, v in zip(dist_info["buckets"], t.cpu().tolist()):
+            b["allreduce_ms_alone"] = round(v, 4)
+            b["bus_GBps_alone"] = round(2.0 * (world - 1) / world * b["bytes"] / (v * 1e-3) / 1e9, 1) if v > 0 else None
+        dist_info["steps_seen_by_reducer"] = reducer.nsteps
+        dist_info["overlap"] = "buckets issued from backward-stage hooks (decoder -> spat -> spec before the CNN-stem backward, stems after it)"
+
     # the same kernel on the same shape with nothing else on the GPU (in the step its launches share the device with the other
     # encoder's stream, which stretches the event-bracketed durations used for `roofline.achieved`)
-    iso_ms = None
+    iso_ms, iso_ghz = None, None
+    npix_b = batch * pairs
     if rank == 0 and args.precision != "fp32":
-        xi = torch.randn((args.batch, 256, 256, 64), device=dev).to(torch.bfloat16)
+        xi = torch.randn((npix_b, 256, T, 64), device=dev).to(torch.bfloat16)
         wi = (torch.randn((9, 64, 64), device=dev) * 0.05).to(torch.bfloat16)
         sci, shi = torch.ones(64, device=dev), torch.zeros(64, device=dev)
         for _ in range(3):
@@ -196,28 +317,34 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         iso_ms = e0.elapsed_time(e1) / 10
+        iso_ghz = eff_ghz(clk.cpu().numpy().reshape(5, 4)[0])
         del xi
+    _lib.call("sarssl_conv_clock_probe", _lib.c_void_p(0))
 
+    out = None
     if rank == 0:
-        segs_total = args.batch * world * args.steps
+        segs_total = batch * world * args.steps
         value = segs_total / elapsed
         n, ms = prof.get("conv3x3_fwd:bn_prologue", (0, 0.0))          # forward 3x3 convolutions with a stored input (BN+ReLU prologue): 2 per step
         nc1, msc1 = prof.get("conv3x3_fwd_c1", (0, 0.0))               # the other 2: input formed from the stem's 4-channel input while staging
         nr1, msr1 = prof.get("conv3x3_dgrad_c1red", (0, 0.0))          # data gradient consumed in its epilogue (nothing stored)
         nd, msd = prof.get("conv3x3_fwd:identity", (0, 0.0))           # plain data-gradient launches of the same kernel
         nb, msb = prof.get("conv3x3_dgrad_bnred", (0, 0.0))            # <true> variant: data gradient + BatchNorm-backward sums
-        flop_per_launch = 2.0 * args.batch * 65536 * 64 * 576            # one 3x3 64->64 conv over B x 256 x 256 pixels
+        flop_per_launch = 2.0 * npix_b * 256 * T * 64 * 576              # one 3x3 64->64 conv over B' x 256 x T pixels
         achieved = (flop_per_launch / (ms / n * 1e-3)) / 1e12 if n else 0.0
         nw, msw = prof.get("conv3x3_wgrad_kernel", (0, 0.0))
-        traffic, mfma_busy = None, None      # per launch, from the committed PMC passes (same kernel, same shape; tools/prof_counters.py)
-        for name in ("r02_kernel_counters.json",):
+        traffic, mfma_busy, pmc_file = None, None, None  # per launch, from the committed PMC passes (same kernel, same shape; tools/prof_counters.py)
+        for name in ("r03_kernel_counters.json", "r02_kernel_counters.json"):
             pmc = os.path.join(ROOT, "profiles", name)
-            if args.batch == 64 and os.path.exists(pmc):
+            if traffic is None and args.workload == "config2" and batch == 64 and os.path.exists(pmc):
                 for e in json.load(open(pmc)).get("kernels", []):
                     if e.get("tag") == 20 and e.get("kernel", "").startswith("conv3x3_fwd_pp_kernel"):
                         if "hbm_read_mb" in e and "hbm_write_mb" in e:
                             traffic = (e["hbm_read_mb"] + e["hbm_write_mb"]) * 1e6
+                            pmc_file = name
                         mfma_busy = e.get("mfma_busy")
+        fps = flop_per_segment(args.workload)
+        seg_desc = "%dch %.3fs@16kHz segments (%d microphone pair%s, T = %d frames)" % (nmic, nsample / 16000.0, pairs, "" if pairs == 1 else "s", T)
         out = {
             "metric": "pretrain_segments_per_sec", "value": round(value, 2), "unit": "segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -226,8 +353,8 @@ def main():
             "dtype": {"bf16": "bf16", "fp32": "f32(split-bf16 MFMA)", "fp8": "bf16 storage, fp8(e4m3) Linear GEMMs"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "SAR-SSL MC-Conformer cross-channel-reconstruction pretrain step (STFT+mask+fwd+bwd+Adam), "
-                                   "2ch 4.112s@16kHz segments, batch %d per GPU, dropout on" % args.batch,
-                       "global_batch": args.batch * world, "segment_samples": NSAMPLE, "parallelism": "dp%d" % world},
+                                   "%s, batch %d per GPU, dropout on" % (seg_desc, batch),
+                       "baseline_config": args.workload, "global_batch": batch * world, "segment_samples": nsample, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma",
                          "kernel": "conv3x3_fwd_pp_kernel<false>, BN+ReLU-prologue launches (the forward 3x3 convolutions; events around "
                                    "exactly these launches inside training steps" +
@@ -236,25 +363,56 @@ def main():
                                     "right after the timed replays - two_stream_avg_ms = the same with both encoder streams") + ")",
                          "achieved": round(achieved, 1),
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic, "mfma_busy": mfma_busy, "launches": n, "avg_ms": round(ms / n, 4) if n else None,
+                         "traffic": traffic, "traffic_source": pmc_file, "mfma_busy": mfma_busy, "launches": n,
+                         "avg_ms": round(ms / n, 4) if n else None, "effective_clock_ghz": eff_ghz(clk_step[0]),
                          "flop_per_launch": flop_per_launch,
-                         "fwd_from_4ch_input_avg_ms": round(msc1 / nc1, 4) if nc1 else None,
+                         "fwd_from_4ch_input_avg_ms": round(msc1 / nc1, 4) if nc1 else None, "fwd_from_4ch_input_clock_ghz": eff_ghz(clk_step[3]),
                          "dgrad_consumed_in_epilogue_avg_ms": round(msr1 / nr1, 4) if nr1 else None,
-                         "dgrad_identity_avg_ms": round(msd / nd, 4) if nd else None,
-                         "dgrad_bnred_avg_ms": round(msb / nb, 4) if nb else None,
+                         "dgrad_consumed_in_epilogue_clock_ghz": eff_ghz(clk_step[4]),
+                         "dgrad_identity_avg_ms": round(msd / nd, 4) if nd else None, "dgrad_identity_clock_ghz": eff_ghz(clk_step[1]),
+                         "dgrad_bnred_avg_ms": round(msb / nb, 4) if nb else None, "dgrad_bnred_clock_ghz": eff_ghz(clk_step[2]),
                          "wgrad_avg_ms": round(msw / nw, 4) if nw else None,
                          "two_stream_avg_ms": (round(prof2["conv3x3_fwd:bn_prologue"][1] / prof2["conv3x3_fwd:bn_prologue"][0], 4)
-                                               if graph is not None and prof2.get("conv3x3_fwd:bn_prologue", (0, 0))[0] else None),
-                         "isolated_avg_ms": round(iso_ms, 4) if iso_ms else None,
+                                               if prof2.get("conv3x3_fwd:bn_prologue", (0, 0))[0] else None),
+                         "isolated_avg_ms": round(iso_ms, 4) if iso_ms else None, "isolated_clock_ghz": iso_ghz,
                          "isolated_achieved": round(flop_per_launch / (iso_ms * 1e-3) / 1e12, 1) if iso_ms else None,
-                         "end_to_end_frac": round(value / world * FLOP_PER_SEG_STEP / (PEAK_BF16_TFLOPS * 1e12), 4)},
+                         "nominal_clock_ghz": 2.4,
+                         "flop_per_segment_step": fps,
+                         "end_to_end_frac": round(value / world * fps / (PEAK_BF16_TFLOPS * 1e12), 4)},
             "final_loss": round(loss_val, 5),
             "step_mode": "eager launches" if graph is None else "hipGraph replay (%d graph(s) per step)" % sum(1 for k, _ in graph._plan if k == "graph"),
             "host_ms_per_step": round(1e3 * t_host / args.steps, 3),
             "host_calls_per_step": round(calls_per_step, 1),
+            "knobs": engine.knobs(),
+            "parity_class": {
+                "bf16": {"loss_vs_reference": 1e-3, "loss_curve_100_steps": 1e-3, "per_bin_pred_of_range": 1e-2, "per_parameter_grad_norm": 6e-2,
+                         "pinned_by": "tests/test_gpu_model.py (F3), test_gpu_train.py (F5, F12), test_gpu_graph.py (B = 64 vs fp32 mode)"},
+                "fp32": {"loss_vs_reference": 1e-3, "loss_curve_100_steps": 1e-3, "per_bin_pred_of_range": 1e-3, "per_parameter_grad_norm": 5e-3,
+                         "pinned_by": "tests/test_gpu_model.py (F3), test_gpu_train.py (F5, F12)"},
+                "fp8": {"loss_vs_bf16_path": 2e-3, "per_bin_pred_of_range": 0.15, "pinned_by": "tests/test_gpu_fp8.py (against the bf16 path)"},
+            }[args.precision],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if dist_info is not None:
+            out["dist"] = dist_info
+    del graph, state
+    if world == 1:
+        want_loop = (not args.no_product_loop or args.via_learner) and args.workload == "config2"
+        if want_loop:
+            opt = None
+            net._stage_hook = None
+            del net, flat, reducer, pcm
+            torch.cuda.empty_cache()
+            loop = product_loop(dev, batch, args.precision, nseg=max(512, 8 * batch), epochs=3 if not args.via_learner else max(3, args.steps // 8))
+            out["product_loop"] = loop
+            if args.via_learner:
+                out["resident_batch_replay"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": out["steps"]}
+                out["value"], out["ms_per_step"], out["steps"] = loop["value"], loop["ms_per_step"], loop["steps"]
+                out["step_mode"] = loop["step_mode"]
+                out["config"]["workload"] += "; driven through " + loop["path"]
+                out["roofline"]["end_to_end_frac"] = round(loop["value"] * flop_per_segment(args.workload) / (PEAK_BF16_TFLOPS * 1e12), 4)
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()                 # rank 0 may still be printing / timing the isolated kernel

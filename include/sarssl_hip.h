@@ -108,18 +108,15 @@ int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int 
                        const float* scale, const float* shift, int precise, float* ws, double* stats, void* stream);
 /*      data gradient (w = flipped/transposed taps) that also accumulates the BatchNorm-backward sums of the layer in front:
  *      red = f64[128] = [sum g | sum g*xhat], g = dz * relu'(bn(y)); aff = [scale|shift|mean|rstd] (4 x 64 f32); bf16 only.
- *      Returns 1 without launching when the ping-pong kernel is disabled (caller falls back to sarssl_cl_bn_bwd_reduce). */
+ */
 int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, int F, int T, const void* y, const float* aff,
                                double* red, void* stream);
-/* ---- the same two convolution launches with the BatchNorm + ReLU backward of the layer BEHIND them applied to the incoming gradient
- *      while staging: dz_in = dL/d relu(bn(y)), (y, aff, red) = that BatchNorm's pre-activations / affine / backward sums; the
- *      normalised gradient dy = gamma*rstd*(g - s1/N - xhat*s2/N) is never stored (replaces sarssl_cl_bn_bwd_apply + the plain
- *      launches; code/model.py:53-58 backward).  bf16; sarssl_conv3x3_dgrad_bnin returns 1 when the ping-pong kernel is disabled. */
-int sarssl_conv3x3_dgrad_bnin(const void* dz_in, const void* w, void* out, int nb, int F, int T, const void* y, const float* aff,
-                              const double* red, int use_stats, void* stream);
-int sarssl_conv3x3_wgrad_bnin(const void* dz_in, const void* y_bn, const float* aff_bn, const double* red_bn, int use_stats,
-                              const void* zin, int nb, int F, int T, const float* scale, const float* shift, float* dW, float* partial,
-                              void* stream);
+/*      measurement aid (no reference counterpart): buf = device memory, 5 slots x 4 u64; thread 0 of workgroup 0 of every bf16 3x3
+ *      forward / data-gradient launch stores {s_memtime, s_memrealtime} at kernel entry and exit into the slot of its variant (0 forward
+ *      with BN prologue, 1 data gradient, 2 data gradient + BN sums, 3 forward from the 4-channel input, 4 data gradient consumed in its
+ *      epilogue): effective shader clock = d(memtime) / d(memrealtime) * sarssl_wall_clock_khz().  null switches it off. */
+int sarssl_conv_clock_probe(void* buf);
+long sarssl_wall_clock_khz();
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
                          const float* shift, float* dW, float* partial, int precise, void* stream);
@@ -136,22 +133,9 @@ int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad, int d, int
 /* The first stem layer without its 64-channel output (reference: code/model.py:50-64, patch_embed[0:3] = Conv2d(4,64,1) + BatchNorm2d
  * + ReLU): stem_c1_stats = BatchNorm sums [sum | sum sq] f64[128] of y1 = W1 a0 from the moments of a0 (mom14: f64[16] scratch);
  * conv3x3_fwd_c1 / conv3x3_wgrad_c1_acc = the following 3x3 convolution (patch_embed[3]) and its weight gradient with the operand
- * relu(bn1(W1 a0)) formed from a0 (B,F,T,4) bf16 while staging (return 1 = kernel disabled, nothing done);
+ * relu(bn1(W1 a0)) formed from a0 (B,F,T,4) bf16 while staging;
  * stem_c1_bwd_a0 = sarssl_stem_c1_bwd with y1 recomputed (npix % 64 == 0, bf16). */
 int sarssl_stem_c1_stats(const void* a0, long npix, const float* W1, double* mom14, double* sums128, int dtype, void* stream);
-/* Training-mode BatchNorm finalize done by the consumer of the affine (reference: nn.BatchNorm2d / BatchNorm1d in train mode,
- * code/model.py:50-64 and code/common/conformer/convolution.py:140-143): the `_fin` launches derive scale / shift from the producer's sums
- * themselves; workgroup 0 writes aff = [scale | shift | mean | rstd] (4 x C) and updates running_mean / running_var / nbt exactly like
- * sarssl_bn_finalize - which then is not launched. */
-typedef struct SarsslBnFin {
-    const double* sums; long N; int C;
-    const float* gamma; const float* beta; float eps, momentum;
-    float* running_mean; float* running_var; long* nbt;
-    float* aff;
-} SarsslBnFin;
-int sarssl_conv3x3_fwd_fin(const void* in, const void* w, void* out, int nb, int F, int T, const SarsslBnFin* fin, double* stats, void* stream);
-int sarssl_stem_c4_fwd_fin(const void* y3, const float* W4, const SarsslBnFin* fin, int nb, int F, int Tn, void* y4, int dtype, void* stream);
-int sarssl_cl_affine_act_fin(const void* x, long N, int C, const SarsslBnFin* fin, int act, void* z, int dtype, void* stream);
 /* sarssl_stem_c1_stats followed by sarssl_bn_finalize (C = 64, N = npix) in two launches instead of three: aff (4 x 64) = scale | shift |
  * mean | rstd of BatchNorm(1), running statistics and the batch counter updated (pass null for eval-style use) */
 int sarssl_stem_c1_stats_affine(const void* a0, long npix, const float* W1, double* mom14, const float* gamma, const float* beta,
@@ -257,12 +241,15 @@ int sarssl_bias2(const void* q, long ldq, long M, int d, const float* u, const f
 int sarssl_axpby(const void* x, const void* y, float a, float b, long n, void* out, int dtype, void* stream);
 int sarssl_axpby2d(const void* x, long ldx, const void* y, long ldy, float a, float b, long M, int N, void* out, long ldo,
                    int dtype, void* stream);
-int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream);
 /* out[n] (x's dtype) = sum_m x[m][n]: few rows, many columns (batch sum of the positional-score gradient, model.py:RelPositionMultiHeadAttention) */
 int sarssl_colsum_store(const void* x, long ldx, long M, int N, void* out, int dtype, void* stream);
-/* up to 24 independent column sums in one launch (bias gradients of one backward stage): outs[q][n] += sum_m xs[q][m][n] */
-int sarssl_colsum_multi(const void* const* xs, const long* ldxs, const long* Ms, const int* Ns, float* const* outs, int n, int dtype,
-                        void* stream);
+/* up to 24 independent column sums in one launch (the bias gradients of one backward stage; autograd of nn.Linear / Conv1d biases,
+   conformer/modules.py:35-48): parts[q][s][n] = sum over row slice s of xs[q][m][n], s < sarssl_colsum_slices(Ms[q], Ns[q]); every
+   element is written (no atomics: run-to-run reproducible), sarssl_splitk_reduce_multi (M = 1, nsplit = slices) adds them to the
+   gradient in slice order */
+int sarssl_colsum_slices(long M, int N);
+int sarssl_colsum_multi_partials(const void* const* xs, const long* ldxs, const long* Ms, const int* Ns, float* const* parts, int n,
+                                 int dtype, void* stream);
 int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,
                    void* dh, int dtype, void* stream);
 int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);

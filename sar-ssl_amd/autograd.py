@@ -28,8 +28,6 @@ class _TapeFn(torch.autograd.Function):
     def backward(ctx, dy):
         hip.sums_arena_reset(dy.device)
         dx = ctx.bwd(_to_rt(dy.contiguous()), ctx.saved)
-        from .engine import wgrad_join
-        wgrad_join()                              # weight-gradient side stream (engine._WgradSide): gradients are read after this node
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = hip.cast(dx.contiguous(), ctx.in_dtype)
         return (None, None, dx) + (None,) * ctx.nparams

@@ -24,45 +24,6 @@ struct SarsslStepState {
     float step_size;             // lr / (1 - beta1^step)
     float inv_bc2_sqrt;          // 1 / sqrt(1 - beta2^step)
 };
-// Training-mode BatchNorm finalize done by the CONSUMER of the affine (csrc/stem.hip, conv3x3.hip `_fin` entry points): the launch that
-// applies scale / shift derives them itself from the producer's sums, and its workgroup 0 also publishes aff = [scale | shift | mean |
-// rstd] (4 x C, what the backward pass reads later) and updates the running statistics - the one-workgroup bn_finalize launch that sat
-// between every producer and consumer on the stem's and the convolution modules' chains is gone.  Same arithmetic as bn_finalize_kernel.
-struct SarsslBnFin {
-    const double* sums;          // [2C] sum | sum of squares (complete: written by an earlier launch on the stream)
-    long N; int C;
-    const float* gamma; const float* beta; float eps, momentum;
-    float* running_mean; float* running_var; long* nbt;      // may be null
-    float* aff;                  // [4][C]
-};
-#ifdef __HIPCC__
-__device__ __forceinline__ void bn_fin_channel(const SarsslBnFin& f, int c, float& scale, float& shift, float* mean_out = nullptr,
-                                               float* rstd_out = nullptr, double* var_out = nullptr) {
-    const double m = f.sums[c] / (double)f.N;
-    double var = f.sums[f.C + c] / (double)f.N - m * m;
-    if (var < 0.0) var = 0.0;
-    const float r = (float)(1.0 / sqrt(var + (double)f.eps));
-    scale = f.gamma[c] * r;
-    shift = f.beta[c] - (float)m * f.gamma[c] * r;
-    if (mean_out) *mean_out = (float)m;
-    if (rstd_out) *rstd_out = r;
-    if (var_out) *var_out = var;
-}
-// every thread of ONE workgroup (the caller picks it, e.g. blockIdx 0) calls this once
-__device__ __forceinline__ void bn_fin_publish(const SarsslBnFin& f, int tid, int nthreads) {
-    if (tid == 0 && f.nbt) *f.nbt += 1;
-    for (int c = tid; c < f.C; c += nthreads) {
-        float sc, sh, m, r; double var;
-        bn_fin_channel(f, c, sc, sh, &m, &r, &var);
-        f.aff[c] = sc; f.aff[f.C + c] = sh; f.aff[2 * f.C + c] = m; f.aff[3 * f.C + c] = r;
-        if (f.running_mean) {
-            const double unb = (f.N > 1) ? var * (double)f.N / (double)(f.N - 1) : var;
-            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m;
-            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
-        }
-    }
-}
-#endif
 int sarssl_mfma_prio();         // SARSSL_MFMA_PRIO: waves raise their issue priority (s_setprio) during MFMA phases - 0 nowhere, 1 convolution
                                 // and GEMM, 2 (default) ping-pong convolution only (-2.4 ... -3.5 % alone; GEMM: no effect), 3 GEMM only
 bool sarssl_prezeroed(const void* p);               // pointer inside the host-zeroed arena (api.hip): its memset can be skipped

@@ -43,10 +43,6 @@ struct ConvArgs {
     // stats instead receives that BatchNorm's backward sums [sum g | sum g*xhat], g = dz * relu'(bn(y)) (the cl_bn_bwd_reduce pass)
     const void* bn_y;   // (B,F,T,64) pre-BN activations of the layer whose input gradient this launch produces
     const float* bn_aff;    // [4][64]: scale, shift, mean, rstd
-    // BatchNorm-backward INPUT transform of the ping-pong kernel (BNIN): `in` holds dz = dL/d relu(bn(y)) and the convolution
-    // runs on dy = gamma*rstd*(g - s1/N - xhat*s2/N), g = dz*relu'(bn(y)), formed while staging from (dz, in2 = y) - the
-    // stand-alone normalisation pass (cl_bn_bwd_apply: read 2, write 1 tensor of 537 MB) disappears
-    const void* in2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
     int prio;           // != 0: raise the wave's issue priority for its MFMA phase (s_setprio), see sarssl_mfma_prio()
     // first-layer INPUT mode of the ping-pong kernel (C1IN): `in` is the stem's 4-channel input a0 (B,F,T,4) and the convolution runs
     // on relu(bn1(W1 a0)) formed while staging (c1_w = W1 f32[64][4], scale / shift = bn1's affine) - the 64-channel output of the
@@ -58,7 +54,10 @@ struct ConvArgs {
     // and contracts it over the pixels against [a0 | 1] on the matrix cores: c1_red (f64[644], sarssl_stem_c1_bwd's layout) receives
     // G[co][c] = sum_p g a0[c] and s1[co] = sum_p g
     const void* c1_a0; double* c1_red;
-    SarsslBnFin fin;    // fin.sums != null: the prologue's scale / shift come from the producer's sums and workgroup 0 publishes the affine (common.h)
+    // optional clock probe (sarssl_conv_clock_probe): thread 0 of workgroup 0 stores {s_memtime, s_memrealtime} at kernel entry and
+    // exit - shader-clock ticks over constant-rate ticks = the effective shader clock this launch ran at (bench.py reports it next to
+    // the launch durations: the chip clocks down under matrix load)
+    unsigned long long* clk;
 #ifdef CONV_STAMPS
     unsigned long long* stamps;
 #endif
@@ -88,39 +87,6 @@ __device__ __forceinline__ uint4 c1_chunk(uint32_t lo, uint32_t hi, bool valid, 
         o[h] = pack2_bf16(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f));
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-// per-thread constants of the BatchNorm-backward input transform for channels c0 .. c0+7: dy = cA*g + cB*y + cC
-struct BnInConst { float sc[8], sh[8], cA[8], cB[8], cC[8]; };
-__device__ __forceinline__ void bnin_setup(BnInConst& k, const float* aff, const double* red, int use_stats, long npix, int c0) {
-    const float invN = 1.0f / (float)npix;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = c0 + e;
-        const float scale = aff[c], shift = aff[64 + c], mean = aff[128 + c], rstd = aff[192 + c];
-        const float m1 = use_stats ? (float)red[c] * invN : 0.f, m2 = use_stats ? (float)red[64 + c] * invN : 0.f;
-        k.sc[e] = scale; k.sh[e] = shift;
-        k.cA[e] = scale; k.cB[e] = -scale * m2 * rstd; k.cC[e] = -scale * m1 - k.cB[e] * mean;
-    }
-}
-__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
-    v[0] = bf16_bits_to_f32(u.x & 0xffffu); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = bf16_bits_to_f32(u.y & 0xffffu); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    v[4] = bf16_bits_to_f32(u.z & 0xffffu); v[5] = __uint_as_float(u.z & 0xffff0000u);
-    v[6] = bf16_bits_to_f32(u.w & 0xffffu); v[7] = __uint_as_float(u.w & 0xffff0000u);
-}
-// 8 channels of one pixel: (dz, y) -> bf16 dy
-__device__ __forceinline__ uint4 bnin_chunk(const uint4& dz, const uint4& y, bool valid, const BnInConst& k) {
-    if (!valid) return make_uint4(0, 0, 0, 0);
-    float g[8], v[8];
-    unpack8(dz, g); unpack8(y, v);
-    f8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float gi = fmaf(v[e], k.sc[e], k.sh[e]) > 0.f ? g[e] : 0.f;
-        o.v[e] = fmaf(k.cA[e], gi, fmaf(k.cB[e], v[e], k.cC[e]));
-    }
-    return pack8_part(o, 0);
 }
 
 __device__ __forceinline__ int swz(int p, int chunk) { return (p * 8 + (chunk ^ ((p >> 1) & 7))) * 8; }
@@ -204,13 +170,13 @@ template <typename T, typename TW>
 __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sX[X_ELEMS];
-    __shared__ float sStats[128];
+    __shared__ float sStats[8][128];               // per-wave partial statistics, folded in wave order at the end (deterministic)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int F = a.F, Tn = a.T;
     const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + TCOL - 1) / TCOL;
     const int ntiles = a.nb * tiles_f * tiles_t;
     const T* in = (const T*)a.in;
-    if (tid < 128) sStats[tid] = 0.f;
+    for (int q = tid; q < 8 * 128; q += 512) (&sStats[0][0])[q] = 0.f;
     const int cch = tid & 7;                        // this thread's 8-channel chunk (fixed: 512 % 8 == 0)
 
     // weights -> LDS once ([tap][co][ci], ci contiguous)
@@ -380,7 +346,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
                 }
                 if (lane < 8) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], ssq[e]); }
+                    for (int e = 0; e < 8; ++e) { sStats[wave][lane * 8 + e] += ssum[e]; sStats[wave][64 + lane * 8 + e] += ssq[e]; }   // this wave's own slot: no race
                 }
             }
         } else if (f < F) {
@@ -408,7 +374,12 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_kernel(ConvArgs a) {
         }
         __syncthreads();
     }
-    if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
+    if (a.stats && tid < 128) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += sStats[w][tid];
+        atomicAdd(&a.stats[tid], (double)s);
+    }
 }
 
 
@@ -466,13 +437,11 @@ __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int
     asm volatile("" ::: "memory");
 }
 
-template <bool BNRED, bool BNIN = false, bool C1IN = false, bool C1RED = false>
+template <bool BNRED, bool C1IN = false, bool C1RED = false>
 __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     typedef bf16 T;
-    constexpr bool FIN_OK = !BNRED && !BNIN && !C1IN && !C1RED;      // consumer-side BatchNorm finalize: the plain forward variant only
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
-    __shared__ float sStats[128];
     __shared__ float sAff[BNRED ? 256 : 1];
     // C1RED: MFMA "A" fragments of the scale-folded first-layer weights, [co][16 k]: k 0..3 = bf16 high parts of scale*W1[co][c], 4 = of
     // shift, 8..12 = the low parts (the input fragment repeats [a0 | 1] in both k halves: one MFMA gives the f32-accurate pre-activation)
@@ -488,9 +457,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     const int ntiles = a.nb * tiles_f * tiles_t;
     const int npairs = (ntiles + 1) >> 1;
     const T* in = (const T*)a.in;
-    const T* in2 = (const T*)a.in2;
     uint16_t* sX = sXh[half];
-    if (tid < 128) sStats[tid] = 0.f;
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = __builtin_amdgcn_s_memtime(); a.clk[1] = __builtin_amdgcn_s_memrealtime(); }
     if (tid < 2) sSync[tid] = 0u;
     if (BNRED && tid < 256) sAff[tid] = a.bn_aff[tid];
     if (C1RED) {
@@ -513,12 +481,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        if (FIN_OK && a.fin.sums) bn_fin_channel(a.fin, cch * 8 + e, sc[e], sh[e]);
-        else { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+        sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f;
     }
-    if (FIN_OK && a.fin.sums && blockIdx.x == 0) bn_fin_publish(a.fin, tid, 512);
-    BnInConst kin;
-    if (BNIN) bnin_setup(kin, a.bnin_aff, a.bnin_red, a.bnin_use_stats, (long)a.nb * F * Tn, cch * 8);
     C1Const kc1;
     if (C1IN) c1_setup(kc1, a.c1_w, a.scale, a.shift, cch * 8);
 
@@ -538,7 +502,6 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 
     // staging: thread of the half = (pixel column pc = htid >> 3 of 32, chunk): halo rows 0..9 + one chunk of halo columns 32 / 33
     Chunk<T> regs[X_ITERS];
-    Chunk<T> regs2[BNIN ? X_ITERS : 1];            // BNIN: the matching pre-BatchNorm activations
     const int pc = htid >> 3;
     // addresses: row bases are scalar (tile coordinates are wave-uniform), each thread adds ONE byte offset (its clamped frame and chunk)
     auto issue_loads = [&](const TileCoord tc) {
@@ -551,7 +514,6 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             const long rowb = (img + f) * (long)Tn * (C1IN ? 8 : 128);           // bytes
             if (C1IN) { const uint2 q = *(const uint2*)((const char*)in + rowb + voff); regs[i].u.x = q.x; regs[i].u.y = q.y; }
             else regs[i].u = *(const uint4*)((const char*)in + rowb + voff);
-            if (BNIN) regs2[i].u = *(const uint4*)((const char*)in2 + rowb + voff);
         }
         {
             const int hr = pc >> 1, te = tc.t0 + PTC - 1 + (pc & 1);        // (threads >= 160: an unused, harmless extra chunk)
@@ -560,7 +522,6 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                 const uint2 q = *(const uint2*)(in + (((long)tc.b * F + f) * Tn + t) * 4);
                 regs[HR].u.x = q.x; regs[HR].u.y = q.y;
             } else regs[HR] = load_chunk_clamped<T>(in, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
-            if (BNIN) regs2[HR] = load_chunk_clamped<T>(in2, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
         }
     };
     auto write_tile = [&](const TileCoord tc) {
@@ -570,15 +531,13 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         for (int i = 0; i < HR; ++i) {
             const int f = tc.f0 - 1 + i;
             const bool ok = tv && f >= 0 && f < F;
-            *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = BNIN ? bnin_chunk(regs[i].u, regs2[i].u, ok, kin)
-                                                        : C1IN ? c1_chunk(regs[i].u.x, regs[i].u.y, ok, kc1)
+            *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = C1IN ? c1_chunk(regs[i].u.x, regs[i].u.y, ok, kc1)
                                                              : xform_chunk<T>(regs[i], ok, a.prologue, sc, sh, 0);
         }
         if (htid < 160) {
             const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
             const bool ok = f >= 0 && f < F && te < Tn;
-            *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = BNIN ? bnin_chunk(regs[HR].u, regs2[HR].u, ok, kin)
-                                                                                  : C1IN ? c1_chunk(regs[HR].u.x, regs[HR].u.y, ok, kc1)
+            *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = C1IN ? c1_chunk(regs[HR].u.x, regs[HR].u.y, ok, kc1)
                                                                                        : xform_chunk<T>(regs[HR], ok, a.prologue, sc, sh, 0);
         }
     };
@@ -802,7 +761,14 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         tile = next; tc = tcn;
     }
     // per-channel sums: the thread's 8 channels were accumulated over ALL its tiles in registers (folding them per tile - 48 lane
-    // exchanges + 16 LDS atomics - showed as ~2.5 k of a half-tile's ~22 k cycles in the stamps); one fold per launch
+    // exchanges + 16 LDS atomics - showed as ~2.5 k of a half-tile's ~22 k cycles in the stamps); one fold per launch.
+    // The fold is ORDERED (round 3): every wave parks its 128 partial sums in a slot of its own (the weight table is free once all
+    // eight waves are past their last tile) and thread c adds the eight slots in wave order - the round-2 f32 LDS atomics summed them
+    // in arrival order, which flipped bf16 roundings downstream from run to run.  What leaves the workgroup is one f64 atomic per
+    // channel of f32-valued terms: exact (order-free) as long as the terms' exponents span < 2^20.
+    __syncthreads();                               // every wave is done with sW
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = __builtin_amdgcn_s_memtime(); a.clk[3] = __builtin_amdgcn_s_memrealtime(); }
+    float* part = (float*)sW;                      // [8 waves][128] statistics, then [8][320] first-layer sums (C1RED)
     if (BNRED || a.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -814,26 +780,34 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
             for (int e = 0; e < 8; ++e) {
                 float s2 = ssq[e];
                 if (BNRED) s2 = sAff[192 + lane * 8 + e] * (s2 - sAff[128 + lane * 8 + e] * ssum[e]);     // rstd * (sum g*y - mean * sum g)
-                atomicAdd(&sStats[lane * 8 + e], ssum[e]); atomicAdd(&sStats[64 + lane * 8 + e], s2);
+                part[wave * 128 + lane * 8 + e] = ssum[e]; part[wave * 128 + 64 + lane * 8 + e] = s2;
             }
         }
-    }
-    __syncthreads();
-    if (a.stats && tid < 128) atomicAdd(&a.stats[tid], (double)sStats[tid]);
-    if (C1RED) {                                   // fold the 8 waves through LDS (the weight-fragment table is free now), then f64 atomics
-        float* fold = (float*)sC1;                 // [0,256) G[co][c], [256,320) s1[co]
-        for (int q = tid; q < 320; q += 512) fold[q] = 0.f;
         __syncthreads();
+        if (a.stats && tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += part[w * 128 + tid];
+            atomicAdd(&a.stats[tid], (double)s);
+        }
+    }
+    if (C1RED) {                                   // fold the 8 waves through LDS in wave order, then f64 atomics
+        float* fold = part + 1024;                 // [8][320]: [0,256) G[co][c], [256,320) s1[co]
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const int co = nb * 32 + (lane & 31);
             if (lane < 32) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&fold[co * 4 + r], gacc[nb][r]);
-            } else atomicAdd(&fold[256 + co], gacc[nb][0]);
+                for (int r = 0; r < 4; ++r) fold[wave * 320 + co * 4 + r] = gacc[nb][r];
+            } else fold[wave * 320 + 256 + co] = gacc[nb][0];
         }
         __syncthreads();
-        for (int q = tid; q < 320; q += 512) atomicAdd(&a.c1_red[q < 256 ? q : 512 + (q - 256)], (double)fold[q]);
+        for (int q = tid; q < 320; q += 512) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += fold[w * 320 + q];
+            atomicAdd(&a.c1_red[q < 256 ? q : 512 + (q - 256)], (double)s);
+        }
     }
 }
 
@@ -845,8 +819,6 @@ struct WgradArgs {
     float* partial;       // [gridDim.x * 2][9][64][64] f32
     int nb, F, T;
     int part_dy, part_z;
-    // BatchNorm-backward transform of the dy operand (see ConvArgs::in2): dy holds dz, dy2 the pre-BN activations (bf16 only)
-    const void* dy2; const float* bnin_aff; const double* bnin_red; int bnin_use_stats;
     const float* c1_w;    // first-layer input mode (see ConvArgs::c1_w): zin = a0 (B,F,T,4), the operand relu(bn1(W1 a0)) is formed while staging
 };
 
@@ -866,7 +838,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const uint16_t* p0, const uint16_t* p1
 // 8 waves = (co half) x (ci half) x (tap group: taps 0-4 | taps 5-8).  Every wave walks ALL pixels of the tile, so it only
 // needs 5 (4) accumulator fragments = 80 VGPRs; the registers that frees hold the NEXT tile (z halo + dy, 19 x 16 B per
 // thread) which is fetched from HBM while the current tile is on the matrix cores.
-template <typename T, bool BNIN = false>
+template <typename T>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t sY[Y_ELEMS];     // dy tile  [8*64 px][64 co]
     __shared__ __attribute__((aligned(16))) uint16_t sX[X_ELEMS];     // z halo tile [660 px][64 ci]
@@ -878,7 +850,6 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
     const int ntiles = a.nb * tiles_f * tiles_t;
     const T* zin = (const T*)a.zin;
     const T* dy = (const T*)a.dy;
-    const T* dy2 = (const T*)a.dy2;
     const int cch = tid & 7;
 
     f32x16 acc[5];
@@ -907,7 +878,6 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 
     // staging as in the forward kernel: thread = (pixel column pc, 8-channel chunk), halo rows 0..9 + one chunk of columns 64/65
     Chunk<T> rz[X_ITERS], ry[8];
-    Chunk<T> ry2[BNIN ? 8 : 1];
     const int pc = tid >> 3;
     auto issue_loads = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
@@ -920,10 +890,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
         }
         const int ty = tc.t0 + pc;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ry[i] = load_chunk_clamped<T>(dy, tc.b, tc.f0 + i, ty, F, Tn, cch * 8);
-            if (BNIN) ry2[i] = load_chunk_clamped<T>(dy2, tc.b, tc.f0 + i, ty, F, Tn, cch * 8);
-        }
+        for (int i = 0; i < 8; ++i) ry[i] = load_chunk_clamped<T>(dy, tc.b, tc.f0 + i, ty, F, Tn, cch * 8);
     };
     auto write_tile = [&](int tile) {
         const TileCoord tc = tile_coord(tile, tiles_f, tiles_t);
@@ -942,17 +909,9 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
             *(uint4*)&sX[swzc(hr * HC + TCOL + (pc & 1), TCOL + (pc & 1), cch)] = xform_chunk<T>(rz[HR], f >= 0 && f < F && te < Tn, a.prologue, sc, sh, a.part_z);
         }
         const int ty = tc.t0 + pc;
-        if constexpr (BNIN && sizeof(T) == 2) {
-            BnInConst kin;                                     // (live only while staging, like sc / sh)
-            bnin_setup(kin, a.bnin_aff, a.bnin_red, a.bnin_use_stats, (long)a.nb * F * Tn, cch * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *(uint4*)&sY[swzc(i * 64 + pc, pc, cch)] = bnin_chunk(ry[i].u, ry2[i].u, tc.f0 + i < F && ty < Tn, kin);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *(uint4*)&sY[swzc(i * 64 + pc, pc, cch)] = xform_chunk<T>(ry[i], tc.f0 + i < F && ty < Tn, 0, sc, sh, a.part_dy);
-        }
+        for (int i = 0; i < 8; ++i)
+            *(uint4*)&sY[swzc(i * 64 + pc, pc, cch)] = xform_chunk<T>(ry[i], tc.f0 + i < F && ty < Tn, 0, sc, sh, a.part_dy);
     };
 
     const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -1192,10 +1151,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-static bool wgrad_db_enabled() {
-    static const int v = getenv("SARSSL_WGRAD_DB") ? atoi(getenv("SARSSL_WGRAD_DB")) : 1;       // A/B switch: 0 = single-buffered kernel
-    return v != 0;
-}
 // Workgroups of the persistent convolution launches.  kind 0 = forward launches, 1 = data / weight gradients.  One per CU, or
 // SARSSL_CONV_CUS[_FWD | _BWD] of them: a convolution workgroup takes a CU's whole LDS and nearly all of its registers, so while a
 // launch covers every CU the other encoder's stream stands still; a launch that leaves an eighth of the CUs free lets that stream's
@@ -1210,6 +1165,15 @@ static int conv_cus(int kind) {
     // default: forward launches on every CU, gradient launches on 7/8 of them (same-box A/B at B = 64, three rounds: 5 510 - 5 750
     // segments/s with 256 of 256, 5 736 - 5 750 with 224 - the step gains ~2 % although each gradient launch alone is ~12 % slower)
     return kind == 1 && ncu >= 64 ? (ncu * 7 / 8) & ~7 : ncu;
+}
+// Clock probe buffer (device memory, 5 slots x 4 u64: forward with BN prologue | data gradient | data gradient + BN sums | forward from
+// the 4-channel input | data gradient consumed in its epilogue); null = off.  Set by bench.py around its event-timed launches.
+static unsigned long long* g_conv_clk = nullptr;
+extern "C" int sarssl_conv_clock_probe(void* buf) { g_conv_clk = (unsigned long long*)buf; return 0; }
+extern "C" long sarssl_wall_clock_khz() {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) != hipSuccess) return 0;
+    return (long)khz;
 }
 static int conv_persistent_grid(int nunits, int kind) {
     const int cus = conv_cus(kind);
@@ -1243,75 +1207,30 @@ extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int 
 
 // Data gradient of a 3x3 convolution (w = flipped / transposed taps, no prologue) that also returns, in red = f64[128], the
 // backward sums [sum g | sum g*xhat] of the BatchNorm + ReLU in front of that convolution (g = dz * relu'(bn(y)), y = its pre-BN
-// activations, aff = [scale | shift | mean | rstd], 4 x 64 f32).  bf16, ping-pong kernel only; returns 1 (and does nothing) when that
-// kernel is disabled so the caller can fall back to the separate reduction pass.
+// activations, aff = [scale | shift | mean | rstd], 4 x 64 f32).  bf16 (ping-pong kernel).
 extern "C" int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, int F, int T, const void* y,
                                           const float* aff, double* red, void* stream) {
     SARSSL_REQUIRE(y != nullptr && aff != nullptr && red != nullptr, "sarssl_conv3x3_dgrad_bnred");
-    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
-    if (!use_pp) return 1;
     return conv3x3_launch(dy, w, dz, SARSSL_BF16, SARSSL_BF16, nb, F, T, nullptr, nullptr, 0, nullptr, red, y, aff, stream);
 }
 
-// Data gradient of a 3x3 convolution whose incoming gradient still needs the BatchNorm + ReLU backward of the layer behind it:
-// dz_in = dL/d relu(bn(y)) (the previous data-gradient launch's output), y / aff / red = that BatchNorm's pre-activations, affine
-// [scale | shift | mean | rstd] and backward sums [s1 | s2] (sarssl_conv3x3_dgrad_bnred / sarssl_cl_bn_bwd_reduce); the normalised
-// gradient is formed while staging, never stored.  bf16, ping-pong kernel only (returns 1 when that kernel is disabled).
-extern "C" int sarssl_conv3x3_dgrad_bnin(const void* dz_in, const void* w, void* out, int nb, int F, int T, const void* y,
-                                         const float* aff, const double* red, int use_stats, void* stream) {
-    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && y && aff && red, "sarssl_conv3x3_dgrad_bnin");
-    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
-    if (!use_pp) return 1;
-    ConvArgs a = {};
-    a.in = dz_in; a.w = w; a.out = out; a.nb = nb; a.F = F; a.T = T;
-    a.in2 = y; a.bnin_aff = aff; a.bnin_red = red; a.bnin_use_stats = use_stats;
-    const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    conv3x3_fwd_pp_kernel<false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
-    SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<bnin>");
-    return 0;
-}
-
-// sarssl_conv3x3_fwd (bf16, BN+ReLU prologue, optional statistics epilogue) with the prologue BatchNorm's training-mode finalize done by
-// this launch (see SarsslBnFin; fin->sums = the sums of `in`, C = 64).  bf16 ping-pong kernel only (returns 1 when it is disabled).
-extern "C" int sarssl_conv3x3_fwd_fin(const void* in, const void* w, void* out, int nb, int F, int T, const SarsslBnFin* fin, double* stats,
-                                      void* stream) {
-    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && fin && fin->sums && fin->aff && fin->C == 64, "sarssl_conv3x3_fwd_fin");
-    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
-    if (!use_pp) return 1;
-    if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    ConvArgs a = {};
-#ifdef CONV_STAMPS
-    a.stamps = g_conv_stamps_host;
-#endif
-    a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
-    a.stats = stats;
-    a.in = in; a.w = w; a.out = out; a.prologue = 1; a.fin = *fin;
-    a.nb = nb; a.F = F; a.T = T;
-    const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    conv3x3_fwd_pp_kernel<false><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
-    SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<fin>");
-    return 0;
-}
-
 // 3x3 convolution of relu(bn1(W1 a0)) straight from the stem's 4-channel input a0 (B,F,T,4) bf16: W1 f32[64][4], scale / shift = bn1's
-// affine; out (B,F,T,64) bf16 and, optionally, stats = [sum | sum of squares] of the stored output.  bf16 ping-pong kernel only
-// (returns 1 when that kernel is disabled so the caller can fall back to stem_c1_fwd + sarssl_conv3x3_fwd).
+// affine; out (B,F,T,64) bf16 and, optionally, stats = [sum | sum of squares] of the stored output.  bf16 (ping-pong kernel).
 extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const float* scale, const float* shift, const void* w, void* out,
                                      int nb, int F, int T, double* stats, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && a0 && W1 && scale && shift, "sarssl_conv3x3_fwd_c1");
-    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
-    if (!use_pp) return 1;
     if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
 #ifdef CONV_STAMPS
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
+    a.clk = g_conv_clk ? g_conv_clk + 4 * 3 : nullptr;
     a.stats = stats;
     a.in = a0; a.w = w; a.out = out; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    conv3x3_fwd_pp_kernel<false, false, true><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
+    conv3x3_fwd_pp_kernel<false, true><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1in>");
     return 0;
 }
@@ -1319,23 +1238,21 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
 // Data gradient of the first 3x3 convolution (w = its flipped / transposed taps, dy = the gradient w.r.t. its output) whose result is
 // consumed in the epilogue instead of being stored: red (f64[644], the layout of sarssl_stem_c1_bwd, zeroed here) receives
 // G[co][c] = sum_p g[p][co] a0[p][c] at [co*4 + c] and s1[co] = sum_p g[p][co] at [512 + co], g = dz1 * relu'(scale * (W1 a0) + shift);
-// the remaining entries follow from the input's moments (sarssl_stem_c1_bwd_finalize_mom).  bf16 ping-pong kernel only (returns 1 when
-// it is disabled).
+// the remaining entries follow from the input's moments (sarssl_stem_c1_bwd_finalize_mom).  bf16 (ping-pong kernel).
 extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const void* a0, const float* W1, const float* scale,
                                           const float* shift, int nb, int F, int T, double* red, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && dy && w && a0 && W1 && scale && shift && red, "sarssl_conv3x3_dgrad_c1red");
-    static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
-    if (!use_pp) return 1;
     if (SARSSL_ZERO(red, 644 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
 #ifdef CONV_STAMPS
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
+    a.clk = g_conv_clk ? g_conv_clk + 4 * 4 : nullptr;
     a.in = dy; a.w = w; a.out = nullptr; a.scale = scale; a.shift = shift; a.prologue = 0; a.c1_w = W1; a.c1_a0 = a0; a.c1_red = red;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    conv3x3_fwd_pp_kernel<false, false, false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
+    conv3x3_fwd_pp_kernel<false, false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1red>");
     return 0;
 }
@@ -1351,6 +1268,7 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
+    a.clk = g_conv_clk ? g_conv_clk + 4 * (bn_y ? 2 : (scale != nullptr ? 0 : 1)) : nullptr;
     a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
     a.in = in; a.w = w; a.out = out; a.acc_ws = nullptr; a.acc_in = 0; a.acc_out = 0;
@@ -1359,13 +1277,10 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     hipStream_t st = (hipStream_t)stream;
     const int grid = conv_grid(nb, F, T);
     if (dtype == SARSSL_BF16 && w_dtype == SARSSL_BF16) {
-        static const int use_pp = getenv("SARSSL_CONV_PP") ? atoi(getenv("SARSSL_CONV_PP")) : 1;
-        if (use_pp) {
-            const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-            const int g = conv_persistent_grid(npairs, scale != nullptr ? 0 : 1);      // (no prologue = a data-gradient launch)
-            if (bn_y) conv3x3_fwd_pp_kernel<true><<<g, 512, 0, st>>>(a);
-            else conv3x3_fwd_pp_kernel<false><<<g, 512, 0, st>>>(a);
-        } else conv3x3_fwd_kernel<bf16, bf16><<<grid, 512, 0, st>>>(a);
+        const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
+        const int g = conv_persistent_grid(npairs, scale != nullptr ? 0 : 1);      // (no prologue = a data-gradient launch)
+        if (bn_y) conv3x3_fwd_pp_kernel<true><<<g, 512, 0, st>>>(a);
+        else conv3x3_fwd_pp_kernel<false><<<g, 512, 0, st>>>(a);
     } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
         if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);
         else {
@@ -1387,23 +1302,6 @@ extern "C" long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T) {
 }
 
 // dW: f32 [9][64][64] ([tap][co][ci]).  partial: workspace of sarssl_conv3x3_wgrad_workspace_bytes.
-// Weight gradient with the BatchNorm-backward transform on the dy operand (see sarssl_conv3x3_dgrad_bnin): dz_in, y_bn bf16.
-extern "C" int sarssl_conv3x3_wgrad_bnin(const void* dz_in, const void* y_bn, const float* aff_bn, const double* red_bn, int use_stats,
-                                         const void* zin, int nb, int F, int T, const float* scale, const float* shift, float* dW,
-                                         float* partial, void* stream) {
-    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && y_bn && aff_bn && red_bn, "sarssl_conv3x3_wgrad_bnin");
-    WgradArgs a = {};
-    a.dy = dz_in; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
-    a.partial = partial; a.nb = nb; a.F = F; a.T = T;
-    a.dy2 = y_bn; a.bnin_aff = aff_bn; a.bnin_red = red_bn; a.bnin_use_stats = use_stats;
-    hipStream_t st = (hipStream_t)stream;
-    const int grid = conv_grid(nb, F, T);
-    conv3x3_wgrad_kernel<bf16, true><<<grid, 512, 0, st>>>(a);
-    wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, grid, dW, 0);
-    SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel<bnin>");
-    return 0;
-}
-
 // Re-laid-out taps of a (64, 64, 3, 3) f32 convolution weight in ONE launch (a permute + flip + 2 casts = 5 torch launches per
 // convolution otherwise, redone every step because the weights move): fwd [9][co][ci] and dgr [9][ci][co] with flipped taps
 // (= W.flip(2,3).permute(2,3,1,0)), as f32 (dtype 0) or bf16 (dtype 1).
@@ -1468,8 +1366,9 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
     const int grid = conv_grid(nb, F, T);
     const int rblocks = W_ELEMS / 64;
     if (dtype == SARSSL_BF16) {
-        if (wgrad_db_enabled()) { const int g2 = wgrad_db_grid(nb, F, T); conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a); wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, g2, dW, 0); }
-        else { conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a); wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, grid, dW, 0); }
+        const int g2 = wgrad_db_grid(nb, F, T);
+        conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a);
+        wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, g2, dW, 0);
     } else if (dtype == SARSSL_F32) {
         const int npass = precise ? 3 : 1;
         for (int pass = 0; pass < npass; ++pass) {
@@ -1492,25 +1391,17 @@ extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb,
     a.dy = dy; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
     a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (wgrad_db_enabled()) {
-        const int g2 = wgrad_db_grid(nb, F, T);
-        conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a);
-        wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
-    } else {
-        const int grid = conv_grid(nb, F, T);
-        conv3x3_wgrad_kernel<bf16><<<grid, 512, 0, st>>>(a);
-        wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, grid, nullptr, 0, grad_oihw);
-    }
+    const int g2 = wgrad_db_grid(nb, F, T);
+    conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a);
+    wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel(acc)");
     return 0;
 }
 // The same with the input operand relu(bn1(W1 a0)) formed from the stem's 4-channel input a0 (B,F,T,4) bf16 while staging (W1 f32[64][4],
-// scale / shift = bn1's affine): the first layer's 64-channel output is not read.  Double-buffered bf16 kernel only (returns 1 when
-// it is disabled: SARSSL_WGRAD_DB=0).
+// scale / shift = bn1's affine): the first layer's 64-channel output is not read.  Double-buffered bf16 kernel.
 extern "C" int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const float* W1, int nb, int F, int T, const float* scale,
                                            const float* shift, float* grad_oihw, float* partial, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && grad_oihw && partial && W1 && scale && shift, "sarssl_conv3x3_wgrad_c1_acc");
-    if (!wgrad_db_enabled()) return 1;
     WgradArgs a = {};
     a.dy = dy; a.zin = a0; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
     a.partial = partial; a.nb = nb; a.F = F; a.T = T;

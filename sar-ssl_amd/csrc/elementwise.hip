@@ -499,29 +499,6 @@ __global__ void axpby2d_kernel(const T* __restrict__ x, long ldx, const T* __res
         st4(out + row * ldo + c, make_float4(a * xv.x + b * yv.x, a * xv.y + b * yv.y, a * xv.z + b * yv.z, a * xv.w + b * yv.w));
     }
 }
-// out[n] += sum_m x[m][n]    (column tiles of 64, f32 atomics: bias / u,v-bias gradients)
-template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, long ldx, long M, int N, float* __restrict__ out) {
-    __shared__ float sred[256][5];
-    const int cgp = threadIdx.x & 15, rslot = threadIdx.x >> 4;
-    const int col0 = blockIdx.x * 64, col = col0 + cgp * 4;
-    float s[4] = {0, 0, 0, 0};
-    if (col < N) {
-        for (long m = (long)blockIdx.y * 16 + rslot; m < M; m += (long)gridDim.y * 16) {
-            const float4 v = ld4(x + m * ldx + col);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sred[threadIdx.x][e] = s[e];
-    __syncthreads();
-    if (threadIdx.x < 64 && col0 + threadIdx.x < N) {
-        const int c = threadIdx.x;
-        float acc = 0.f;
-        for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][c & 3];
-        atomicAdd(&out[col0 + c], acc);
-    }
-}
 // out[n] = sum_m x[m][n] written in the activation dtype (few rows, many columns: the batch sum of the positional-score gradient that
 // feeds the positional projection's weight-gradient GEMM - was memset + colsum_kernel + cast_kernel).  One workgroup per 64 columns.
 template <typename T>
@@ -547,7 +524,9 @@ __global__ void colsum_store_kernel(const T* __restrict__ x, long ldx, long M, i
     }
 }
 // Several independent column sums in ONE launch (the ~46 bias-gradient reductions of a backward pass were 8 us launches each):
-// problem q: out_q[n] += sum_m x_q[m][n].  Workgroups are numbered through the problems' (column tile, row slice) grids.
+// problem q: part_q[row slice][n] = sum over the slice's rows of x_q[m][n].  Workgroups are numbered through the problems'
+// (column tile, row slice) grids.  Round 3: the slices' sums are WRITTEN (round 2 added them to the gradient with f32 atomics, in
+// arrival order - bias gradients differed in the last bits from run to run); sarssl_splitk_reduce_multi folds them in slice order.
 #define COLSUM_MAXP 24
 struct ColsumMulti {
     const void* x[COLSUM_MAXP]; long ld[COLSUM_MAXP]; long M[COLSUM_MAXP]; int N[COLSUM_MAXP]; float* out[COLSUM_MAXP];
@@ -580,7 +559,7 @@ __global__ void colsum_multi_kernel(ColsumMulti a) {
         const int c = threadIdx.x;
         float acc = 0.f;
         for (int r = 0; r < 16; ++r) acc += sred[r * 16 + (c >> 2)][c & 3];
-        atomicAdd(&a.out[q][col0 + c], acc);
+        a.out[q][(long)by * N + col0 + c] = acc;
     }
 }
 // dh = dz * act'(h) * dropout_mask(seed, idx) * gscale
@@ -893,16 +872,6 @@ extern "C" int sarssl_axpby2d(const void* x, long ldx, const void* y, long ldy, 
     SARSSL_CHECK_LAUNCH("axpby2d_kernel");
     return 0;
 }
-extern "C" int sarssl_colsum(const void* x, long ldx, long M, int N, float* out, int dtype, void* stream) {
-    SARSSL_REQUIRE((N & 3) == 0 && (ldx & 3) == 0 && M > 0, "sarssl_colsum");
-    int gx = (N + 63) / 64;
-    long gy = (M + 255) / 256; if (gy < 1) gy = 1;
-    long cap = 1024 / gx; if (cap < 1) cap = 1;
-    if (gy > cap) gy = cap;
-    DISPATCH_T(dtype, (colsum_kernel<T><<<dim3(gx, (unsigned)gy), 256, 0, ST>>>((const T*)x, ldx, M, N, out)));
-    SARSSL_CHECK_LAUNCH("colsum_kernel");
-    return 0;
-}
 // out[n] (same dtype as x) = sum_m x[m][n]; N % 4 == 0
 extern "C" int sarssl_colsum_store(const void* x, long ldx, long M, int N, void* out, int dtype, void* stream) {
     SARSSL_REQUIRE((N & 3) == 0 && (ldx & 3) == 0 && M > 0, "sarssl_colsum_store(shape)");
@@ -910,22 +879,29 @@ extern "C" int sarssl_colsum_store(const void* x, long ldx, long M, int N, void*
     SARSSL_CHECK_LAUNCH("colsum_store_kernel");
     return 0;
 }
-// n <= 24 problems: xs[q] (dtype, row stride ldxs[q], Ms[q] x Ns[q], Ns[q] % 4 == 0) -> outs[q][Ns[q]] += column sums
-extern "C" int sarssl_colsum_multi(const void* const* xs, const long* ldxs, const long* Ms, const int* Ns, float* const* outs, int n,
-                                   int dtype, void* stream) {
-    SARSSL_REQUIRE(n > 0 && n <= COLSUM_MAXP, "sarssl_colsum_multi");
+// Row slices the column sums of an M x N problem are split into (the caller sizes the partial buffer [slices][N] with it)
+static int colsum_slices(long M, int N) {
+    const int gx = (N + 63) / 64;
+    long gy = (M + 255) / 256; if (gy < 1) gy = 1;
+    long cap = 512 / gx; if (cap < 1) cap = 1;
+    if (gy > cap) gy = cap;
+    return (int)gy;
+}
+extern "C" int sarssl_colsum_slices(long M, int N) { return colsum_slices(M, N); }
+// n <= 24 problems: xs[q] (dtype, row stride ldxs[q], Ms[q] x Ns[q], Ns[q] % 4 == 0) -> parts[q][sarssl_colsum_slices(Ms[q], Ns[q])][Ns[q]]
+// per-slice column sums (f32, every element written); fold them with sarssl_splitk_reduce_multi (M = 1, nsplit = slices)
+extern "C" int sarssl_colsum_multi_partials(const void* const* xs, const long* ldxs, const long* Ms, const int* Ns, float* const* parts, int n,
+                                            int dtype, void* stream) {
+    SARSSL_REQUIRE(n > 0 && n <= COLSUM_MAXP, "sarssl_colsum_multi_partials");
     ColsumMulti a;
     a.n = n;
     int total = 0;
     for (int q = 0; q < n; ++q) {
-        SARSSL_REQUIRE((Ns[q] & 3) == 0 && (ldxs[q] & 3) == 0 && Ms[q] > 0, "sarssl_colsum_multi(shape)");
-        a.x[q] = xs[q]; a.ld[q] = ldxs[q]; a.M[q] = Ms[q]; a.N[q] = Ns[q]; a.out[q] = outs[q];
+        SARSSL_REQUIRE((Ns[q] & 3) == 0 && (ldxs[q] & 3) == 0 && Ms[q] > 0, "sarssl_colsum_multi_partials(shape)");
+        a.x[q] = xs[q]; a.ld[q] = ldxs[q]; a.M[q] = Ms[q]; a.N[q] = Ns[q]; a.out[q] = parts[q];
         const int gx = (Ns[q] + 63) / 64;
-        long gy = (Ms[q] + 255) / 256; if (gy < 1) gy = 1;
-        long cap = 512 / gx; if (cap < 1) cap = 1;
-        if (gy > cap) gy = cap;
-        a.gx[q] = gx; a.gy[q] = (int)gy; a.first[q] = total;
-        total += gx * (int)gy;
+        a.gx[q] = gx; a.gy[q] = colsum_slices(Ms[q], Ns[q]); a.first[q] = total;
+        total += gx * a.gy[q];
     }
     a.first[n] = total;
     DISPATCH_T(dtype, (colsum_multi_kernel<T><<<total, 256, 0, ST>>>(a)));

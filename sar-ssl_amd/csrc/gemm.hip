@@ -334,7 +334,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, i
 
 // The same reduction for several split-K products in one launch (the weight-gradient GEMMs of one backward stage are reduced
 // together when the stage ends: 40 launches of ~12 us per step otherwise).
-#define SPLITK_MAXP 16
+#define SPLITK_MAXP 32
 struct SplitKMulti {
     const float* ws[SPLITK_MAXP]; float* C[SPLITK_MAXP]; long ldc[SPLITK_MAXP];
     int nsplit[SPLITK_MAXP], M[SPLITK_MAXP], N[SPLITK_MAXP], first[SPLITK_MAXP + 1];
@@ -362,7 +362,7 @@ __global__ void splitk_reduce_multi_kernel(SplitKMulti a) {
         *dst = c;
     }
 }
-// C_q[m][n] += sum_s ws_q[s][m][n] for n_prob <= 16 products (N_q % 4 == 0, ldc_q % 4 == 0)
+// C_q[m][n] += sum_s ws_q[s][m][n] for n_prob <= 32 products (also the bias-gradient column sums' slices: M = 1) (N_q % 4 == 0, ldc_q % 4 == 0)
 extern "C" int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsplit, const int* M, const int* N, float* const* C,
                                           const long* ldc, int n_prob, void* stream) {
     SARSSL_REQUIRE(n_prob > 0 && n_prob <= SPLITK_MAXP, "sarssl_splitk_reduce_multi");

@@ -372,15 +372,13 @@ __global__ void stem_c1_bwd_finalize_kernel(const double* __restrict__ red, long
 template <typename T>
 __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __restrict__ W4, const float* __restrict__ scale,
                                    const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4, int nstream,
-                                   SarsslBnFin fin = SarsslBnFin(), double* __restrict__ stats = nullptr) {
+                                   double* __restrict__ stats = nullptr) {
     const int cg = threadIdx.x & 7;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};      // stats: sum / sum of squares of the STORED y4 (BatchNorm(4) statistics)
     float w[4][8], sc[8], sh[8];
-    if (fin.sums && blockIdx.x == 0) bn_fin_publish(fin, threadIdx.x, blockDim.x);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        if (fin.sums) bn_fin_channel(fin, cg * 8 + e, sc[e], sh[e]);
-        else { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
+        sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e];
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[c][e] = W4[c * 64 + cg * 8 + e];
     }
@@ -803,18 +801,12 @@ __device__ __forceinline__ float act_bwd(float u, int act) {   // d act / d u
 // z = act(x*scale[c] + shift[c]);  x viewed as [rows][L], thread = fixed 8-channel group
 template <typename T>
 __global__ void cl_affine_act_kernel(const T* __restrict__ x, long rows, int L, int C, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, int act, T* __restrict__ z, SarsslBnFin fin = SarsslBnFin()) {
+                                     const float* __restrict__ shift, int act, T* __restrict__ z) {
     const int gpr = L >> 3, cg = threadIdx.x % gpr, rslot = threadIdx.x / gpr, rpb = 256 / gpr;
     const int col = cg * 8;
     float sc[8], sh[8];
-    if (fin.sums) {                              // scale / shift from the producer's sums (see SarsslBnFin)
-        if (blockIdx.x == 0) bn_fin_publish(fin, threadIdx.x, blockDim.x);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bn_fin_channel(fin, (col + e) % C, sc[e], sh[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const int ch = (col + e) % C; sc[e] = scale[ch]; sh[e] = shift[ch]; }
-    }
+    for (int e = 0; e < 8; ++e) { const int ch = (col + e) % C; sc[e] = scale[ch]; sh[e] = shift[ch]; }
     for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
         f8 v = ld8(x + n * L + col);
 #pragma unroll
@@ -1200,19 +1192,8 @@ extern "C" int sarssl_stem_c4_fwd_stats(const void* y3, const float* W4, const f
     static const int cap = grid_cap("SARSSL_GRID_C4F", 8192);
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
     static const int nstream = grid_cap("SARSSL_C4F_STREAMS", 1);
-    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, nstream, SarsslBnFin(), stats8)));
+    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, nstream, stats8)));
     SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel<stats>");
-    return 0;
-}
-// The same with BatchNorm(3)'s training-mode finalize done here (see SarsslBnFin): fin->sums = the sums of y3 (C = 64).
-extern "C" int sarssl_stem_c4_fwd_fin(const void* y3, const float* W4, const SarsslBnFin* fin, int nb, int F, int Tn, void* y4, int dtype,
-                                      void* stream) {
-    SARSSL_REQUIRE(fin && fin->sums && fin->aff && fin->C == 64, "sarssl_stem_c4_fwd_fin");
-    static const int cap = grid_cap("SARSSL_GRID_C4F", 8192);
-    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
-    static const int nstream = grid_cap("SARSSL_C4F_STREAMS", 1);
-    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, nullptr, nullptr, nb, F, Tn, (T*)y4, nstream, *fin)));
-    SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel<fin>");
     return 0;
 }
 
@@ -1325,14 +1306,6 @@ extern "C" int sarssl_cl_affine_act(const void* x, long N, int C, const float* s
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L) && cl_rowthreads_ok(L), "sarssl_cl_affine_act");
     DISPATCH_T(dtype, (cl_affine_act_kernel<T><<<cl_rowgrid(rows, L), 256, 0, ST>>>((const T*)x, rows, L, C, scale, shift, act, (T*)z)));
     SARSSL_CHECK_LAUNCH("cl_affine_act_kernel");
-    return 0;
-}
-// z = act(bn(x)) with the training-mode BatchNorm finalize done here (see SarsslBnFin): fin->sums = the sums of x, fin->C == C.
-extern "C" int sarssl_cl_affine_act_fin(const void* x, long N, int C, const SarsslBnFin* fin, int act, void* z, int dtype, void* stream) {
-    long rows; int L;
-    SARSSL_REQUIRE(fin && fin->sums && fin->aff && fin->C == C && cl_view(N, C, &rows, &L) && cl_rowthreads_ok(L), "sarssl_cl_affine_act_fin");
-    DISPATCH_T(dtype, (cl_affine_act_kernel<T><<<cl_rowgrid(rows, L), 256, 0, ST>>>((const T*)x, rows, L, C, nullptr, nullptr, act, (T*)z, *fin)));
-    SARSSL_CHECK_LAUNCH("cl_affine_act_kernel<fin>");
     return 0;
 }
 

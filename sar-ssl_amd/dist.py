@@ -63,7 +63,7 @@ def stage_slices(net, flat):
 class FlatGradAllReduce:
     """Bucketed, overlapped gradient all-reduce driven by the model's backward-stage hooks."""
 
-    def __init__(self, net, flat, process_group=None):
+    def __init__(self, net, flat, process_group=None, strict=None):
         self.net, self.flat, self.pg = net, flat, process_group
         self.spans = stage_slices(net, flat)
         covered = sorted(self.spans.values())
@@ -72,12 +72,25 @@ class FlatGradAllReduce:
             assert a1 == b0, "stage spans must be contiguous"
         self.handles = []
         self._fired = set()
-        self.order = []                                   # stage names in the order their all-reduce was issued (tests)
+        self._calls = {}                                  # stage name -> hook calls since the last finish()
+        self._closed = True                               # finish() ran: the next hook call starts a new step's record
+        self.order = []                                   # stage names in the order their all-reduce was issued in the LAST step (tests)
         self.world = world_size()
+        # strict: the pretraining backward (model._PretrainFn) reports every stage exactly once per step; anything else means a bucket
+        # was exchanged before its gradients were final (or twice) - fail loudly instead of training on a wrong average
+        self.strict = bool(getattr(net, "pretrain", False)) if strict is None else bool(strict)
+        self.nsteps = 0
         net.set_backward_stage_hook(self._on_stage)
 
     def _on_stage(self, name):
-        if name not in self.spans or name in self._fired:
+        if name not in self.spans:
+            return
+        if self._closed:
+            self._closed = False
+            self.order = []
+            self._calls = {}
+        self._calls[name] = self._calls.get(name, 0) + 1
+        if name in self._fired:
             return
         self.order.append(name)
         if self.world <= 1:
@@ -89,6 +102,9 @@ class FlatGradAllReduce:
     def finish(self):
         """Wait for all outstanding buckets (also reduces every span no stage hook fired for in this step, e.g. 'other' parameters
         not owned by a stage).  Returns the gradient scale (1/world) to fold into the optimizer step."""
+        if self.strict and not self._closed:
+            bad = {n: self._calls.get(n, 0) for n in self.spans if n in STAGES and self._calls.get(n, 0) != 1}
+            assert not bad, "gradient buckets must be reported exactly once per step, got %r" % (bad,)
         if self.world > 1:
             for name, (s, e) in sorted(self.spans.items(), key=lambda kv: kv[1]):
                 if name not in self._fired:
@@ -97,7 +113,49 @@ class FlatGradAllReduce:
             h.wait()
         self.handles = []
         self._fired = set()
+        self._closed = True
+        self.nsteps += 1
         return 1.0 / self.world
+
+    def describe(self):
+        """What a benchmark line needs to prove which exchange ran: backend, library version, ranks, bucket sizes in issue order."""
+        info = {"world": self.world, "backend": (dist.get_backend(self.pg) if self.world > 1 else None),
+                "buckets": [{"name": n, "bytes": 4 * (self.spans[n][1] - self.spans[n][0])} for n in STAGES if n in self.spans]}
+        if self.world > 1 and info["backend"] == "nccl":
+            try:
+                info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:                        # (version query is informational only)
+                info["rccl_version"] = "unknown (%s)" % type(e).__name__
+        return info
+
+    def time_buckets(self, iters=5):
+        """Event-timed all-reduce of every bucket's slice on its own (ms per bucket, max over ranks is the caller's business):
+        the exchange a step issues, without the backward it normally hides under.  Scratch copies: gradients are not touched."""
+        out = {}
+        if self.world <= 1:
+            return out
+        for n in STAGES:
+            if n not in self.spans:
+                continue
+            s, e = self.spans[n]
+            buf = torch.zeros(e - s, dtype=torch.float32, device=self.flat.grad.device)
+            dist.all_reduce(buf, group=self.pg)                       # warm-up (communicator / channel setup)
+            if buf.is_cuda:
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(iters):
+                    dist.all_reduce(buf, group=self.pg)
+                b.record()
+                torch.cuda.synchronize()
+                out[n] = a.elapsed_time(b) / iters
+            else:
+                import time
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    dist.all_reduce(buf, group=self.pg)
+                out[n] = 1e3 * (time.perf_counter() - t0) / iters
+        return out
 
 
 def broadcast_parameters(flat, src=0):

@@ -64,84 +64,19 @@ def mm_nn(dy, W, fp8=True, **kw):
                     precise=RT.precise, **kw)
 
 
-_ABLATE_WGRAD = os.environ.get("SARSSL_ABLATE_WGRAD", "0") == "1"     # timing experiment only (tools/): skips the Linear weight-gradient products
-
-
-# Weight-gradient side stream.  The weight-gradient products (and the bias-gradient column sums / split-K folds batched per block)
-# feed nothing but the gradient buffer, so they need not sit on the input-gradient chain.  SARSSL_WGRAD_MODE:
-#   "off" (default)    everything on the chain's own stream;
-#   "block"            the products of one Conformer block / the decoder are collected and enqueued together at the end of that
-#                      block's backward on a companion stream of the stream running the chain - ONE fork per block - so they run
-#                      underneath the next block's (or the CNN stem's) backward;
-#   "fork"             every product forks to the companion stream as soon as its operands exist.
-# Measured on MI355X (same box, B = 64): without the products the step is 1.4 ms shorter (SARSSL_ABLATE_WGRAD), but neither schedule
-# recovers it - "block" 13.67 vs "off" 13.70 ms in the captured step, and a captured graph with the many cross-stream edges of
-# "fork" replays SLOWER than the plain two-stream graph (14.69 ms; eager 13.67).  The two encoder streams already fill the CUs.
-# Joined (wgrad_join) only where gradients are consumed: bucket all-reduce hooks, Adam.
-_WGRAD_MODE = os.environ.get("SARSSL_WGRAD_MODE", "off")
-# Grouped launch: independently of the stream schedule, the weight-gradient products of one block (bf16) are collected and issued as
-# ONE launch when the block's backward ends (hip.gemm_group_tn); SARSSL_WGRAD_GROUP=0 issues them one by one where they occur.
+# Grouped launch: the weight-gradient products of one block (bf16) are collected while its backward runs and issued as ONE launch when
+# it ends (hip.gemm_group_tn); SARSSL_WGRAD_GROUP=0 issues them one by one where they occur (A/B runs).  (Round 2 also measured
+# companion-stream schedules for these products - per product and per block; neither beat keeping them on the chain, and a stream
+# forked off a forked stream crashes hipStreamEndCapture on ROCm 7.2 (tools/capture_nested_fork_repro.py).  Removed in round 3.)
 _WGRAD_GROUP = os.environ.get("SARSSL_WGRAD_GROUP", "1") != "0"
-_wg_streams = {}
-_wg_hold = {}
-_wg_nofork = set()           # stream handles that must not fork a companion (see wgrad_no_fork)
-_wg_nest = [0]
 _wg_blocks = []              # stack of pending-product lists (wgrad_block)
 
 
-def wgrad_no_fork(stream):
-    """No companion stream for ``stream``: its weight-gradient work stays on it.  Needed for the second encoder's stream - a stream
-    forked off a FORKED stream (i.e. waiting on an event recorded on a non-origin stream) crashes hipStreamEndCapture on ROCm 7.2
-    (tools/capture_nested_fork_repro.py), so inside a capture only the origin stream gets a companion."""
-    _wg_nofork.add(stream.cuda_stream)
-
-
-class _WgradSide:
-    """``with _WgradSide(t1, t2, ...):`` - enqueue on the companion stream of the current stream, after everything enqueued so far;
-    the tensors are kept alive until the join (their memory is not recycled under the other stream's pending reads)."""
-
-    def __init__(self, *tensors):
-        self.tensors = tensors
-
-    def __enter__(self):
-        self.ctx = None
-        if _WGRAD_MODE == "off" or RT.replay is not None or _wg_nest[0]:
-            return self
-        cur = torch.cuda.current_stream()
-        if cur.cuda_stream in _wg_nofork:
-            return self
-        ws = _wg_streams.get(cur.cuda_stream)
-        if ws is None:
-            ws = _wg_streams[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
-        ws.wait_stream(cur)
-        _wg_hold.setdefault(cur.cuda_stream, []).extend(t for t in self.tensors if t is not None)
-        self.ctx = torch.cuda.stream(ws)
-        self.ctx.__enter__()
-        _wg_nest[0] += 1
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            _wg_nest[0] -= 1
-            self.ctx.__exit__(*exc)
-        return False
-
-
-def wgrad_join():
-    """The current stream waits for its companion weight-gradient stream (call before gradients are read)."""
-    if not _wg_streams:
-        return
-    cur = torch.cuda.current_stream()
-    ws = _wg_streams.get(cur.cuda_stream)
-    if ws is not None:
-        cur.wait_stream(ws)
-        _wg_hold.pop(cur.cuda_stream, None)
-
-
 class wgrad_block:
-    """Backward of one block: weight-gradient products issued inside are collected ("block" mode) and enqueued at exit, together
-    with the block's batched split-K folds and bias-gradient column sums, under one fork to the companion stream.  Their operands
-    must stay unmodified until then (true for every product in this file: operands are saved activations or fresh gradients)."""
+    """Backward of one block: weight-gradient products issued inside are collected and enqueued at exit as one grouped launch,
+    followed by the block's bias-gradient column sums (one launch of per-slice partials) and ONE fold launch for both.  Their
+    operands must stay unmodified until then (true for every product in this file: operands are saved activations or fresh
+    gradients)."""
 
     def __enter__(self):
         _wg_blocks.append([])
@@ -151,15 +86,13 @@ class wgrad_block:
         items = _wg_blocks.pop()
         if exc[0] is not None:
             return False
-        held = [t for it in items for t in it[:2]] + [x for x, _ in (hip._colsum_batch or [])]
-        with _WgradSide(*held):
-            for i in range(0, len(items), 12):                 # one grouped launch per <= 12 products (csrc/gemm.hip)
-                chunk = items[i:i + 12]
-                if not (_WGRAD_GROUP and len(chunk) > 1 and hip.gemm_group_tn(chunk)):
-                    for dy, x, g2, split in chunk:
-                        _wgrad_gemm(dy, x, g2, split)
-            hip.splitk_flush()
-            hip.colsum_flush()
+        for i in range(0, len(items), 12):                 # one grouped launch per <= 12 products (csrc/gemm.hip)
+            chunk = items[i:i + 12]
+            if not (_WGRAD_GROUP and len(chunk) > 1 and hip.gemm_group_tn(chunk)):
+                for dy, x, g2, split in chunk:
+                    _wgrad_gemm(dy, x, g2, split)
+        hip.colsum_flush()                                 # partial sums join the split-K batch ...
+        hip.splitk_flush()                                 # ... and are folded with the products' partials in one launch
         return False
 
 
@@ -183,20 +116,15 @@ def _wgrad_split(M, N, K, grouped):
     return split // 8 * 8 if split >= 8 else split
 
 
-def mm_tn_acc(dy, x, gW, side=True):
+def mm_tn_acc(dy, x, gW, group=True):
     """gW[N,K] += dy[M,N]^T @ x[M,K]   (weight gradient of nn.Linear, f32 accumulate into the grad buffer)."""
     M, N = dy.shape
     K = x.shape[1]
-    if _ABLATE_WGRAD:
-        return
     g2 = gW.view(N, K)
-    grouped = side and _wg_blocks and RT.replay is None and (_WGRAD_MODE == "block" or (_WGRAD_GROUP and RT.dtype == torch.bfloat16))
+    grouped = bool(group and _wg_blocks and RT.replay is None and _WGRAD_GROUP and RT.dtype == torch.bfloat16)
     split = _wgrad_split(M, N, K, grouped)
     if grouped:
         _wg_blocks[-1].append((dy, x, g2, split))            # enqueued when the block's backward ends (wgrad_block)
-    elif side and _WGRAD_MODE == "fork":
-        with _WgradSide(dy, x):
-            _wgrad_gemm(dy, x, g2, split)
     else:
         _wgrad_gemm(dy, x, g2, split)
 
@@ -228,12 +156,6 @@ def bn_affine(x, C, bn, train, sums=None, N=None):
         return hip.bn_train_affine(x, C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
                                    bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum, sums=sums, N=N)
     return hip.bn_eval_affine(C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, eps=bn.eps)
-
-
-def bn_pending(bn, sums, N, C):
-    """Training-mode BatchNorm with finished sums whose finalize is left to the launch that applies the affine (hip.BnPending)."""
-    return hip.BnPending(sums, N, C, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
-                         bn.momentum)
 
 
 def bn_param_grads(bn, red, C):
@@ -269,63 +191,49 @@ def stem_fwd(a0, pe, train, saved):
         bn1 = pe[1]
         aff1, mom1 = hip.stem_c1_bn_affine(a0, W1, bn1.weight.data, bn1.bias.data, bn1.running_mean, bn1.running_var,
                                            bn1.num_batches_tracked, eps=bn1.eps, momentum=bn1.momentum)
-        r = hip.conv3x3_fwd_c1(a0, W1, aff1[0], aff1[1], _taps(pe[3])[0], want_stats=True)
-        if r is not None:
-            y2, s2 = r
-        else:
-            y1 = hip.stem_c1_fwd(a0, W1)
+        y2, s2 = hip.conv3x3_fwd_c1(a0, W1, aff1[0], aff1[1], _taps(pe[3])[0], want_stats=True)
     else:
         y1, s1 = hip.stem_c1_fwd(a0, W1, want_stats=True) if train else (hip.stem_c1_fwd(a0, W1), None)
         aff1 = bn_affine(y1, 64, pe[1], train, sums=s1)
-    if y2 is None:
         y2, s2 = hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], want_stats=True) if fuse else \
             (hip.conv3x3_fwd(y1, _taps(pe[3])[0], aff1[0], aff1[1], precise=RT.precise), None)
-    if fuse and _BNFIN:
-        # the launch that applies a BatchNorm affine derives it from the producer's sums itself and publishes aff / running statistics
-        # (hip.BnPending): no one-workgroup finalize launch between producer and consumer on the stem's chain
-        npix = B * F * T
-        p2 = bn_pending(pe[4], s2, npix, 64)
-        r = hip.conv3x3_fwd_fin(y2, _taps(pe[6])[0], p2, want_stats=True)
-        if r is None:
-            aff2 = p2.affine()
-            r = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True)
-        y3, s3 = r
-        aff2 = p2.aff
-        p3 = bn_pending(pe[7], s3, npix, 64)
-        y4 = hip.stem_c4_fwd_fin(y3, pe[9].weight.data.view(4, 64), p3)                    # (B,T,F,4)
-        aff3 = p3.aff
-        p4 = bn_pending(pe[10], hip.cl_stats(y4, 4)[0], npix, 4)
-        z4 = hip.cl_affine_act_fin(y4, 4, p4, RELU).view(B * T, F * 4)
-        aff4 = p4.aff
+    aff2 = bn_affine(y2, 64, pe[4], train, sums=s2)
+    y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
+        (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
+    aff3 = bn_affine(y3, 64, pe[7], train, sums=s3)
+    if train:                       # BatchNorm(4) sums ride in the 64->4 pass (no statistics pass over y4)
+        y4, s4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1], want_stats=True)        # (B,T,F,4)
+        aff4 = bn_affine(y4, 4, pe[10], train, sums=s4)
     else:
-        aff2 = bn_affine(y2, 64, pe[4], train, sums=s2)
-        y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
-            (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
-        aff3 = bn_affine(y3, 64, pe[7], train, sums=s3)
-        if train:                       # BatchNorm(4) sums ride in the 64->4 pass (no statistics pass over y4)
-            y4, s4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1], want_stats=True)        # (B,T,F,4)
-            aff4 = bn_affine(y4, 4, pe[10], train, sums=s4)
-        else:
-            y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])
-            aff4 = bn_affine(y4, 4, pe[10], train)
-        z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
+        y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])
+        aff4 = bn_affine(y4, 4, pe[10], train)
+    z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
     e = mm_nt(z4, _patch_w(pe[12], F), fp8=False)
     saved.append((a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
     return e
 
 
-_C4_TWO_PHASE = os.environ.get("SARSSL_C4_TWO_PHASE", "1") != "0"
+# A/B switches of the round-2 work-removal passes; bench.py prints their resolved state.  The paths measured
+# slower in round 2 (BatchNorm-backward transform inside the convolution staging, consumer-side BatchNorm finalize, one-pass 64->4
+# backward, the separate / half-fused first-layer backward) were removed from the engine in round 3.
 _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
-# layer-2 BatchNorm-backward normalisation folded into the conv staging: built and measured in round 2 - the fused pair costs 558 + 687 us
-# against 352 (cl_bn_bwd_apply) + 360 + 414 us (both consumers re-read y2, and the extra arithmetic lands in the VALU-bound staging
-# phase of the convolution kernels): 15.2 vs 14.8 ms/step.  Off by default; kept for the next attempt (tests cover it).
-_BNIN = os.environ.get("SARSSL_BNIN", "0") != "0"
 _DWGLU = os.environ.get("SARSSL_DWGLU", "1") != "0"             # 0: separate glu / dwconv / cl_stats kernels (A/B runs)
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
-_C1_FUSED = int(os.environ.get("SARSSL_C1_FUSED", "2"))       # 2: one-pass first-layer backward, 1: fused normalise+wgrad, 0: separate
 _C1IN = os.environ.get("SARSSL_C1IN", "1") != "0"             # 0: store the first layer's 64-channel output (A/B runs)
-_BNFIN = os.environ.get("SARSSL_BNFIN", "0") != "0"           # 1: BatchNorm finalize inside the launch that applies the affine (10 launches fewer; measured: no gain)
 _C1RED = os.environ.get("SARSSL_C1RED", "1") != "0"           # 0: store the gradient w.r.t. that output and reduce it in a pass of its own
+
+
+def knobs():
+    """Resolved state of every environment switch that selects a compute path (bench.py prints it; a benchmark line is only
+    comparable with another one under the same knobs)."""
+    from . import runtime
+    return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
+            "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
+            "SARSSL_CONV_CUS_BWD": os.environ.get("SARSSL_CONV_CUS_BWD", os.environ.get("SARSSL_CONV_CUS", "default(224)")),
+            "SARSSL_GRAPH": os.environ.get("SARSSL_GRAPH", "default"), "SARSSL_MFMA_PRIO": os.environ.get("SARSSL_MFMA_PRIO", "default(2)"),
+            "precision": runtime.get_precision()}
 
 
 def patch_bwd(de, pe, saved):
@@ -335,14 +243,12 @@ def patch_bwd(de, pe, saved):
     a0, z4 = saved[-1][0], saved[-1][9]
     B, F, T, _ = a0.shape
     d = de.shape[1]
-    if _ABLATE_WGRAD:
-        pass
-    elif RT.dtype == torch.bfloat16 and RT.replay is None:   # split-K partials folded and re-laid-out in one pass (nothing zeroed)
+    if RT.dtype == torch.bfloat16 and RT.replay is None:   # split-K partials folded and re-laid-out in one pass (nothing zeroed)
         ws, nslice = hip.gemm_tn_partials(de, z4, _wgrad_split(de.shape[0], d, F * 4, False))
         hip.patch_wgrad_accum(ws, gbuf(pe[12].weight), nslice)
     else:
         gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
-        mm_tn_acc(de, z4, gtmp, side=False)
+        mm_tn_acc(de, z4, gtmp, group=False)
         hip.patch_wgrad_accum(gtmp, gbuf(pe[12].weight))
     return mm_nn(de, _patch_w(pe[12], F), fp8=False)                                       # (B,T,F,4)
 
@@ -352,20 +258,12 @@ def stem_bwd(dz4, pe, saved):
     a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train = saved.pop()
     B, F, T, _ = a0.shape
     W1 = pe[0].weight.data.view(64, 4)
-
-    def need_y1():                    # y1 was not stored (stem_fwd, _C1IN) and a fallback path wants it: recompute it
-        return y1 if y1 is not None else hip.stem_c1_fwd(a0, W1)
     red4 = hip.cl_bn_bwd_reduce(dz4, y4, 4, aff4, RELU)
     # (BatchNorm / 1x1-conv parameter gradients are added from the finished sums by workgroup 0 of the pass that consumes them)
     dy4 = hip.cl_bn_bwd_apply(dz4, y4, 4, aff4, RELU, False, train, red4, pgrads=(gbuf(pe[10].weight), gbuf(pe[10].bias)))
-    # 64->4 conv + BN3/ReLU backward reductions in one pass over y3
-    if _C4_TWO_PHASE:       # sums pass + direct dy3 pass: 1.7 GB per encoder instead of 2.7 GB (c4_bwd + in-place BatchNorm apply)
-        dy3, red = hip.stem_c4_bwd_two_phase(y3, dy4, pe[9].weight.data.view(4, 64), aff3, train,
-                                             pgrads=(gbuf(pe[9].weight), gbuf(pe[7].weight), gbuf(pe[7].bias)))
-    else:
-        g3, red = hip.stem_c4_bwd(y3, dy4, pe[9].weight.data.view(4, 64), aff3)
-        hip.f64_accum(red[:256], gbuf(pe[9].weight))
-        dy3 = hip.cl_bn_bwd_apply(g3, y3, 64, aff3, RELU, True, train, red[256:], out=g3, pgrads=(gbuf(pe[7].weight), gbuf(pe[7].bias)))
+    # 64->4 conv + BN3/ReLU backward: sums pass + direct dy3 pass over y3 (1.7 GB per encoder)
+    dy3, red = hip.stem_c4_bwd_two_phase(y3, dy4, pe[9].weight.data.view(4, 64), aff3, train,
+                                         pgrads=(gbuf(pe[9].weight), gbuf(pe[7].weight), gbuf(pe[7].bias)))
     # second 3x3 conv
     dW = hip.conv3x3_wgrad(dy3, y2, aff2[0], aff2[1], precise=RT.precise, acc_into=gbuf(pe[6].weight))
     if dW is not None:
@@ -375,40 +273,24 @@ def stem_bwd(dz4, pe, saved):
         dz2, red2 = hip.conv3x3_dgrad_bnred(dy3, _taps(pe[6])[1], y2, aff2)
     else:
         dz2 = hip.conv3x3_fwd(dy3, _taps(pe[6])[1], precise=RT.precise)
-    if red2 is None:
         red2 = hip.cl_bn_bwd_reduce(dz2, y2, 64, aff2, RELU)
-    # first 3x3 conv.  The normalised gradient dy2 = BatchNorm/ReLU backward of (dz2, y2) has two consumers (this layer's weight and
-    # data gradients): in bf16 both form it while staging their tiles, so it is never written (cl_bn_bwd_apply: 3 x 537 MB at B = 64)
-    dz1 = hip.conv3x3_dgrad_bnin(dz2, _taps(pe[3])[1], y2, aff2, red2, train) if (_BNIN and RT.dtype == torch.bfloat16) else None
-    if dz1 is not None:
-        bn_param_grads(pe[4], red2, 64)
-        dW = hip.conv3x3_wgrad_bnin(dz2, y2, aff2, red2, need_y1(), aff1[0], aff1[1], train)
-    else:
-        dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2, pgrads=(gbuf(pe[4].weight), gbuf(pe[4].bias)))
-        if y1 is None and hip.conv3x3_wgrad_c1(dy2, a0, W1, aff1[0], aff1[1], gbuf(pe[3].weight)):
-            dW = None
-        else:
-            dW = hip.conv3x3_wgrad(dy2, need_y1(), aff1[0], aff1[1], precise=RT.precise, acc_into=gbuf(pe[3].weight))
-        if y1 is None and mom1 is not None and _C1RED and _C1_FUSED == 2 and hip.conv3x3_dgrad_c1red(
-                dy2, _taps(pe[3])[1], a0, W1, aff1, mom1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias)):
+    # first 3x3 conv
+    dy2 = hip.cl_bn_bwd_apply(dz2, y2, 64, aff2, RELU, False, train, red2, out=dz2, pgrads=(gbuf(pe[4].weight), gbuf(pe[4].bias)))
+    if y1 is None:                     # first layer never stored (stem_fwd): its operand is formed from a0 while staging
+        hip.conv3x3_wgrad_c1(dy2, a0, W1, aff1[0], aff1[1], gbuf(pe[3].weight))
+        if _C1RED and hip.conv3x3_dgrad_c1red(dy2, _taps(pe[3])[1], a0, W1, aff1, mom1, train, gbuf(pe[0].weight),
+                                              gbuf(pe[1].weight), gbuf(pe[1].bias)):
             return None     # the data gradient of the first 3x3 convolution was consumed in its epilogue: the first layer is done
-        dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
-    if dW is not None:
-        gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
-    if _C1_FUSED == 2:      # everything the first layer needs from (dz1, y1, a0) in one pass: BN sums, dgamma/dbeta, dW1
-        if y1 is None:
-            hip.stem_c1_bwd_a0(dz1, a0, W1, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
-        else:
-            hip.stem_c1_bwd(dz1, y1, a0, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
-        return None
-    y1 = need_y1()
-    red1 = hip.cl_bn_bwd_reduce(dz1, y1, 64, aff1, RELU)
-    bn_param_grads(pe[1], red1, 64)
-    if _C1_FUSED:           # dy1 feeds nothing but this weight gradient (the stem input is data): normalise it in registers
-        hip.stem_c1_wgrad_bn(dz1, y1, a0, aff1, red1, train, gbuf(pe[0].weight))
     else:
-        dy1 = hip.cl_bn_bwd_apply(dz1, y1, 64, aff1, RELU, False, train, red1, out=dz1)
-        hip.stem_c1_wgrad(dy1, a0, gbuf(pe[0].weight))
+        dW = hip.conv3x3_wgrad(dy2, y1, aff1[0], aff1[1], precise=RT.precise, acc_into=gbuf(pe[3].weight))
+        if dW is not None:
+            gbuf(pe[3].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
+    dz1 = hip.conv3x3_fwd(dy2, _taps(pe[3])[1], precise=RT.precise)
+    # everything the first layer needs from (dz1, y1, a0) in one pass: BN sums, dgamma/dbeta, dW1
+    if y1 is None:
+        hip.stem_c1_bwd_a0(dz1, a0, W1, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
+    else:
+        hip.stem_c1_bwd(dz1, y1, a0, aff1, train, gbuf(pe[0].weight), gbuf(pe[1].weight), gbuf(pe[1].bias))
     return None        # the stem input is data
 
 
@@ -530,8 +412,11 @@ def _qkv_views(att):
 def mhsa_fwd(x, mod, B, T, train, saved):
     """x + MultiHeadedSelfAttentionModule(x)  (conformer/attention.py:143-151, 72-113).
 
-    Attention core = batched MFMA GEMMs over (b, head) + one fused scale/relative-shift/softmax/dropout kernel;
-    the positional projection is computed once per call (it is batch-invariant)."""
+    bf16: the positional-score GEMM writes (q+v)P^T directly in the reference's relative-shift layout and ONE flash-style kernel
+    (csrc/attention.hip) does content score + shifted positional score + 1/sqrt(d_model) + softmax + dropout + PV - no (B,H,T,T)
+    score / probability tensor.  f32 mode, replayed dropout masks and shapes the fused kernel does not take: batched MFMA GEMMs over
+    (b, head) + one scale/relative-shift/softmax/dropout kernel.  The positional projection is computed once per call (it is
+    batch-invariant)."""
     att = mod.attention
     H, dh, d = att.num_heads, att.d_head, att.d_model
     M = B * T
@@ -705,17 +590,12 @@ def convmod_fwd(x, cm, B, T, train, saved):
     if _DWGLU and d % 8 == 0:            # GLU + depthwise conv + BatchNorm batch sums in one LDS-tiled pass (csrc/dwconv.hip)
         c, sums = hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T, want_stats=True) if train else \
             (hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T), None)
-        aff = None if (train and _BNFIN) else bn_affine(c, d, bn, train, sums=sums)
+        aff = bn_affine(c, d, bn, train, sums=sums)
     else:
         g = hip.glu_fwd(h)
         c = hip.dwconv(g.view(B, T, d), dw.weight.data.view(d, -1))
         aff = bn_affine(c, d, bn, train)
-    if aff is None:                      # BatchNorm finalize inside the launch that applies it (hip.BnPending)
-        pend = bn_pending(bn, sums, B * T, d)
-        s = hip.cl_affine_act_fin(c, d, pend, SWISH).view(B * T, d)
-        aff = pend.aff
-    else:
-        s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
+    s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
     po = _p(seq[8], train)
     if _replaying(train) and po > 0:                       # the reference draws this mask on the (B, d, T) conv output
         y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data)
@@ -774,7 +654,7 @@ def block_bwd(dy, blk, saved):
     seq = blk.sequential
     x, stats = saved.pop()
     # the block's ~9 bias-gradient column sums and the reductions of its 9 split-K weight-gradient products: one launch each, at the end
-    with hip.colsum_batched(flush_ctx=_WgradSide), hip.splitk_batched(flush_ctx=_WgradSide), hip.ln_reduce_batched(), wgrad_block():
+    with hip.colsum_batched(), hip.splitk_batched(), hip.ln_reduce_batched(), wgrad_block():
         # each module's backward starts with the dropout backward of its incoming gradient: the LayerNorm backward that produces
         # that gradient writes the dropped copy as a second output (d = (gradient, dropped gradient) where a mask applies)
         pair = lambda r: r if isinstance(r, tuple) else (r, None)
@@ -815,7 +695,7 @@ def decoder_fwd(e, dec, saved):
 def decoder_bwd(dpred, dec, saved):
     e, h = saved.pop()
     l1, l2 = dec.proj[0], dec.proj[2]
-    with hip.colsum_batched(flush_ctx=_WgradSide), hip.splitk_batched(flush_ctx=_WgradSide), wgrad_block():
+    with hip.colsum_batched(), hip.splitk_batched(), wgrad_block():
         mm_tn_acc(dpred, h, gbuf(l2.weight))
         hip.colsum(dpred, gbuf(l2.bias))
         dh = mm_nn(dpred, wt(l2.weight), fp8=False, aux=h, aux_act=RELU)

@@ -118,11 +118,11 @@ class PretrainStepGraph:
         if not with_adam:
             return
         world = self.reducer.world if self.reducer is not None else 1
-        if world > 1:
-            if seg is not None:
+        if seg is not None:
+            if world > 1:
                 seg.cut(("finish", None))
-            else:
-                self.reducer.finish()
+        elif self.reducer is not None:
+            self.reducer.finish()                          # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
                           zero_grad=self.zero_grad_in_adam)
 
@@ -237,9 +237,10 @@ class PretrainStepGraph:
         return self.out
 
     def vis(self):
-        """vis dict of the last step (same keys as SARSSL.forward's third result)."""
+        """vis dict of the last step (same keys as SARSSL.forward's third result).  Copies: the graph's pool tensors are overwritten
+        by the next replay, a vis dict of the eager path keeps its contents."""
         from .model import LazyVis
-        return LazyVis(self.pred, self.xin, self.vis_masks[0], self.vis_masks[1])
+        return LazyVis(self.pred.clone(), self.xin.clone(), self.vis_masks[0].clone(), self.vis_masks[1].clone())
 
 
 class _Segments:

@@ -1,4 +1,4 @@
-"""Tensor-level wrappers over the C-ABI kernels (raw ops; autograd lives in ops.py).
+"""Tensor-level wrappers over the C-ABI kernels (raw ops; the autograd anchor is model._PretrainFn / autograd.py, orchestration engine.py).
 
 PyTorch is used for device memory and streams only: every wrapper passes ``data_ptr()``s and the
 current HIP stream to ``libsarssl_hip.so``.
@@ -159,7 +159,7 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
               _p(ws), c_int(split_k), c_int(1 if c_row_shift else 0), _stream())
     if deferred is not None:
         _splitk_batch.append(deferred)
-        if len(_splitk_batch) == 16:
+        if len(_splitk_batch) == 32:
             splitk_flush()
     return out
 
@@ -196,7 +196,7 @@ def gemm_group_tn(items):
     _lib.check(rc, "sarssl_gemm_group_tn")
     for q, (dy, x, out, split) in enumerate(items):
         _splitk_batch.append((ws[q], int(split_out[q]), dy.shape[1], x.shape[1], out, out.stride(0)))
-        if len(_splitk_batch) == 16:
+        if len(_splitk_batch) == 32:
             splitk_flush()
     return True
 
@@ -380,18 +380,14 @@ def stem_c1_bn_affine(a0, W1, gamma, beta, running_mean, running_var, nbt, eps=1
 
 def conv3x3_dgrad_c1red(dy, w_tap_dgrad, a0, W1, aff, mom, train, dW1, dgamma, dbeta):
     """Data gradient of the first 3x3 convolution consumed in its epilogue: dW1 (64,4,1,1) / dgamma / dbeta (64) += the first stem
-    layer's parameter gradients; the 64-channel gradient tensor is never stored (mom = the input's moments from stem_c1_stats).
-    False when the ping-pong kernel is disabled (nothing done)."""
+    layer's parameter gradients; the 64-channel gradient tensor is never stored (mom = the input's moments from stem_c1_stats)."""
     _need_cuda(dy, w_tap_dgrad, a0, W1, aff, mom)
     B, F, T, _ = a0.shape
     assert dy.dtype == torch.bfloat16 and a0.dtype == torch.bfloat16 and dy.shape == (B, F, T, 64)
     red = _sums(644, a0.device)
-    fn = _lib.lib().sarssl_conv3x3_dgrad_c1red
     with _Timed("conv3x3_dgrad_c1red"):
-        rc = fn(_p(dy), _p(w_tap_dgrad), _p(a0), _p(W1), _p(aff[0]), _p(aff[1]), c_int(B), c_int(F), c_int(T), _p(red), _stream())
-    if rc == 1:
-        return False
-    _lib.check(rc, "sarssl_conv3x3_dgrad_c1red")
+        _lib.call("sarssl_conv3x3_dgrad_c1red", _p(dy), _p(w_tap_dgrad), _p(a0), _p(W1), _p(aff[0]), _p(aff[1]), c_int(B), c_int(F), c_int(T),
+                  _p(red), _stream())
     _lib.call("sarssl_stem_c1_bwd_finalize_mom", _p(red), _p(mom), _p(W1), c_long(B * F * T), _p(aff), c_int(1 if train else 0),
               _p(dW1), _p(dgamma), _p(dbeta), _stream())
     return True
@@ -542,90 +538,46 @@ def conv3x3_fwd(x, w_tap, scale=None, shift=None, precise=False, want_stats=Fals
 
 def conv3x3_fwd_c1(a0, W1, scale, shift, w_tap, want_stats=False):
     """3x3 convolution of relu(scale * (W1 a0) + shift) straight from the stem's 4-channel input a0 (B,F,T,4) bf16 - the first layer's
-    64-channel output is formed while staging, never stored.  -> out (B,F,T,64) bf16 (or (out, stats f64[128])); None when the
-    ping-pong kernel is disabled."""
+    64-channel output is formed while staging, never stored.  -> out (B,F,T,64) bf16 (or (out, stats f64[128]))."""
     _need_cuda(a0, W1, scale, shift, w_tap)
     B, F, T, C = a0.shape
     assert C == 4 and a0.dtype == torch.bfloat16 and w_tap.dtype == torch.bfloat16 and a0.is_contiguous() and W1.is_contiguous()
     out = torch.empty((B, F, T, 64), dtype=torch.bfloat16, device=a0.device)
     stats = _sums(128, a0.device) if want_stats else None
-    fn = _lib.lib().sarssl_conv3x3_fwd_c1
     with _Timed("conv3x3_fwd_c1"):
-        rc = fn(_p(a0), _p(W1), _p(scale), _p(shift), _p(w_tap), _p(out), c_int(B), c_int(F), c_int(T), _p(stats), _stream())
-    if rc == 1:
-        return None
-    _lib.check(rc, "sarssl_conv3x3_fwd_c1")
+        _lib.call("sarssl_conv3x3_fwd_c1", _p(a0), _p(W1), _p(scale), _p(shift), _p(w_tap), _p(out), c_int(B), c_int(F), c_int(T), _p(stats),
+                  _stream())
     return (out, stats) if want_stats else out
 
 
 def conv3x3_wgrad_c1(dy, a0, W1, scale, shift, acc_into):
     """Weight gradient of that convolution, added into the (64,64,3,3) f32 parameter-gradient buffer; the input operand is formed from a0
-    while staging.  False when the double-buffered kernel is disabled (nothing done)."""
+    while staging."""
     _need_cuda(dy, a0, W1)
     B, F, T, _ = a0.shape
     assert a0.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and acc_into.shape == (64, 64, 3, 3) and acc_into.is_contiguous()
     nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
     nbytes.restype = c_long
     part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), a0.device, "wgrad_part")
-    fn = _lib.lib().sarssl_conv3x3_wgrad_c1_acc
     with _Timed("conv3x3_wgrad_kernel"):
-        rc = fn(_p(dy), _p(a0), _p(W1), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(acc_into), _p(part), _stream())
-    if rc == 1:
-        return False
-    _lib.check(rc, "sarssl_conv3x3_wgrad_c1_acc")
+        _lib.call("sarssl_conv3x3_wgrad_c1_acc", _p(dy), _p(a0), _p(W1), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(acc_into),
+                  _p(part), _stream())
     return True
 
 
 def conv3x3_dgrad_bnred(dy, w_tap_dgrad, y, aff):
     """dz = conv3x3(dy, flipped taps) and the BatchNorm-backward sums red f64[128] of the BN+ReLU in front (pre-BN activations
-    ``y``, ``aff`` = (4,64) scale|shift|mean|rstd), accumulated in the convolution's epilogue (bf16).  Returns (dz, None) when the
-    fused kernel is disabled - the caller then runs cl_bn_bwd_reduce."""
+    ``y``, ``aff`` = (4,64) scale|shift|mean|rstd), accumulated in the convolution's epilogue (bf16)."""
     _need_cuda(dy, w_tap_dgrad, y, aff)
     B, F, T, C = dy.shape
     assert C == 64 and dy.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.shape == dy.shape
     assert aff.dtype == torch.float32 and aff.is_contiguous() and aff.numel() == 256 and dy.is_contiguous() and y.is_contiguous()
     dz = torch.empty_like(dy)
     red = _sums(128, dy.device)
-    fn = _lib.lib().sarssl_conv3x3_dgrad_bnred
     with _Timed("conv3x3_dgrad_bnred"):          # (its own label: this launch also reads y and reduces)
-        rc = fn(_p(dy), _p(w_tap_dgrad), _p(dz), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red), _stream())
-    if rc == 1:
-        return conv3x3_fwd(dy, w_tap_dgrad), None
-    _lib.check(rc, "sarssl_conv3x3_dgrad_bnred")
+        _lib.call("sarssl_conv3x3_dgrad_bnred", _p(dy), _p(w_tap_dgrad), _p(dz), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red),
+                  _stream())
     return dz, red
-
-
-def conv3x3_dgrad_bnin(dz_in, w_tap_dgrad, y, aff, red, use_stats=True):
-    """Data gradient conv3x3(dy, flipped taps) with dy = BatchNorm+ReLU backward of (dz_in, y, aff, red) formed while staging (bf16).
-    Returns None when the fused kernel is disabled (the caller then runs cl_bn_bwd_apply + conv3x3_fwd)."""
-    _need_cuda(dz_in, w_tap_dgrad, y, aff, red)
-    B, F, T, C = dz_in.shape
-    assert C == 64 and dz_in.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.shape == dz_in.shape
-    assert dz_in.is_contiguous() and y.is_contiguous() and aff.is_contiguous() and aff.numel() == 256 and red.dtype == torch.float64
-    out = torch.empty_like(dz_in)
-    fn = _lib.lib().sarssl_conv3x3_dgrad_bnin
-    with _Timed("conv3x3_dgrad_bnin"):
-        rc = fn(_p(dz_in), _p(w_tap_dgrad), _p(out), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red), c_int(1 if use_stats else 0),
-                _stream())
-    if rc == 1:
-        return None
-    _lib.check(rc, "sarssl_conv3x3_dgrad_bnin")
-    return out
-
-
-def conv3x3_wgrad_bnin(dz_in, y_bn, aff_bn, red_bn, zin, scale=None, shift=None, use_stats=True):
-    """Weight gradient [9][64][64] f32 with the same BatchNorm-backward transform on the gradient operand (bf16)."""
-    _need_cuda(dz_in, y_bn, zin)
-    B, F, T, C = zin.shape
-    assert dz_in.dtype == torch.bfloat16 and y_bn.dtype == torch.bfloat16 and zin.dtype == torch.bfloat16
-    nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
-    nbytes.restype = c_long
-    part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), zin.device, "wgrad_part")
-    dW = torch.empty((9, 64, 64), dtype=torch.float32, device=zin.device)
-    with _Timed("conv3x3_wgrad_bnin"):
-        _lib.call("sarssl_conv3x3_wgrad_bnin", _p(dz_in), _p(y_bn), _p(aff_bn), _p(red_bn), c_int(1 if use_stats else 0), _p(zin),
-                  c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW), _p(part), _stream())
-    return dW
 
 
 def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False, acc_into=None):
@@ -668,68 +620,6 @@ def bn_train_affine(x, C, gamma, beta, running_mean, running_var, nbt, eps=1e-5,
     _lib.call("sarssl_bn_finalize", _p(sums), c_long(N), c_int(C), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
               _p(running_mean), _p(running_var), _p(nbt), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), _stream())
     return aff
-
-
-class _BnFinStruct(ctypes.Structure):
-    _fields_ = [("sums", ctypes.c_void_p), ("N", ctypes.c_long), ("C", ctypes.c_int), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
-                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
-                ("nbt", ctypes.c_void_p), ("aff", ctypes.c_void_p)]
-
-
-class BnPending:
-    """Training-mode BatchNorm whose sums exist but whose affine has not been formed yet.  The launch that applies the affine can do
-    the finalize itself (`fin()` -> SarsslBnFin for the `_fin` entry points: that launch also writes `aff` and the running statistics);
-    anything else asks for `affine()`, which runs the stand-alone finalize once."""
-
-    def __init__(self, sums, N, C, gamma, beta, running_mean, running_var, nbt, eps, momentum):
-        self.sums, self.N, self.C = sums, N, C
-        self.p = (gamma, beta, running_mean, running_var, nbt, eps, momentum)
-        self.aff = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
-        self.done = False
-
-    def fin(self):
-        assert not self.done
-        self.done = True
-        g, b, rm, rv, nbt, eps, mom = self.p
-        self._st = _BnFinStruct(self.sums.data_ptr(), self.N, self.C, g.data_ptr(), b.data_ptr(), eps, mom, rm.data_ptr(), rv.data_ptr(),
-                                nbt.data_ptr(), self.aff.data_ptr())
-        return ctypes.byref(self._st)
-
-    def affine(self):
-        if not self.done:
-            self.done = True
-            g, b, rm, rv, nbt, eps, mom = self.p
-            _lib.call("sarssl_bn_finalize", _p(self.sums), c_long(self.N), c_int(self.C), _p(g), _p(b), c_float(eps), c_float(mom),
-                      _p(rm), _p(rv), _p(nbt), _p(self.aff[0]), _p(self.aff[1]), _p(self.aff[2]), _p(self.aff[3]), _stream())
-        return self.aff
-
-
-def conv3x3_fwd_fin(x, w_tap, pend, want_stats=False):
-    """conv3x3_fwd with BN+ReLU prologue whose BatchNorm finalize happens inside the launch (pend: BnPending of x's BatchNorm).
-    None when the ping-pong kernel is disabled (pend untouched)."""
-    _need_cuda(x, w_tap)
-    B, F, T, C = x.shape
-    assert C == 64 and x.dtype == torch.bfloat16 and w_tap.dtype == torch.bfloat16 and x.is_contiguous() and pend.C == 64
-    if os.environ.get("SARSSL_CONV_PP", "1") == "0":
-        return None
-    out = torch.empty_like(x)
-    stats = _sums(128, x.device) if want_stats else None
-    with _Timed("conv3x3_fwd:bn_prologue"):
-        _lib.call("sarssl_conv3x3_fwd_fin", _p(x), _p(w_tap), _p(out), c_int(B), c_int(F), c_int(T), pend.fin(), _p(stats), _stream())
-    return (out, stats) if want_stats else out
-
-
-def stem_c4_fwd_fin(y3, W4, pend):
-    B, F, T, _ = y3.shape
-    y4 = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)
-    _lib.call("sarssl_stem_c4_fwd_fin", _p(y3), _p(W4), pend.fin(), c_int(B), c_int(F), c_int(T), _p(y4), c_int(dt(y3)), _stream())
-    return y4
-
-
-def cl_affine_act_fin(x, C, pend, act):
-    z = torch.empty_like(x)
-    _lib.call("sarssl_cl_affine_act_fin", _p(x), c_long(x.numel() // C), c_int(C), pend.fin(), c_int(act), _p(z), c_int(dt(x)), _stream())
-    return z
 
 
 def bn_eval_affine(C, gamma, beta, running_mean, running_var, eps=1e-5):
@@ -996,14 +886,14 @@ _colsum_batch = None          # list of (x2d, out) while a batch is open
 
 def colsum(x2d, out_f32, now=False):
     """out_f32[n] += sum_m x2d[m][n].  Inside ``colsum_batched()`` the request is queued and executed with the others in one
-    launch when the batch closes: x2d must stay unmodified and out_f32 unread until then; ``now=True`` opts out."""
+    launch when the batch closes: x2d must stay unmodified and out_f32 unread until then; ``now=True`` opts out.
+    Deterministic: per-row-slice partial sums are written and folded in slice order (no floating-point atomics)."""
     if _colsum_batch is not None and not now and x2d.dtype == torch.bfloat16:
         _colsum_batch.append((x2d, out_f32))
         if len(_colsum_batch) == 24:
             colsum_flush()
         return
-    M, N = x2d.shape
-    _lib.call("sarssl_colsum", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(N), _p(out_f32), c_int(dt(x2d)), _stream())
+    _colsum_flush_items([(x2d, out_f32)], 1, fold_now=True)
 
 
 _colsum_ctx = None
@@ -1032,14 +922,32 @@ def colsum_flush():
         _colsum_flush_items(items, n)
 
 
-def _colsum_flush_items(items, n):
+def _colsum_flush_items(items, n, fold_now=False):
+    """One launch writes every problem's per-row-slice column sums; the fold into the gradient buffers joins the open split-K batch
+    (one reduce launch per backward stage for weight AND bias gradients) or, outside a batch / fold_now, runs right away."""
     import ctypes
+    _need_cuda(*[t for it in items for t in it])
+    nsl = [_lib.lib().sarssl_colsum_slices(c_long(x.shape[0]), c_int(x.shape[1])) for x, _ in items]
+    offs, tot = [], 0
+    for (x, _), g in zip(items, nsl):
+        offs.append(tot)
+        tot += g * x.shape[1]
+    part = torch.empty((tot,), dtype=torch.float32, device=items[0][0].device)
     xs = (ctypes.c_void_p * n)(*[x.data_ptr() for x, _ in items])
-    outs = (ctypes.c_void_p * n)(*[o.data_ptr() for _, o in items])
+    parts = (ctypes.c_void_p * n)(*[part.data_ptr() + 4 * o for o in offs])
     lds = (ctypes.c_long * n)(*[x.stride(0) for x, _ in items])
     Ms = (ctypes.c_long * n)(*[x.shape[0] for x, _ in items])
     Ns = (ctypes.c_int * n)(*[x.shape[1] for x, _ in items])
-    _lib.call("sarssl_colsum_multi", xs, lds, Ms, Ns, outs, c_int(n), c_int(BF16), _stream())
+    _lib.call("sarssl_colsum_multi_partials", xs, lds, Ms, Ns, parts, c_int(n), c_int(dt(items[0][0])), _stream())
+    folds = [(part[o:o + g * x.shape[1]], g, 1, x.shape[1], out, x.shape[1]) for (x, out), g, o in zip(items, nsl, offs)]
+    if _splitk_batch is not None and not fold_now:
+        for f in folds:
+            _splitk_batch.append(f)
+            if len(_splitk_batch) == 32:
+                splitk_flush()
+    else:
+        for i in range(0, len(folds), 32):
+            _splitk_flush_items(folds[i:i + 32], len(folds[i:i + 32]))
 
 
 class colsum_batched:

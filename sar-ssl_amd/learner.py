@@ -40,6 +40,7 @@ class Learner(ABC):
         self.model.cuda()
         self.device = "cuda"
         self._flat = runtime.FlatParams(self.model)
+        self.__dict__.pop("_step_graph", None)           # a captured step holds the OLD flat buffers' addresses: never reuse it
         if sdist.world_size() > 1:
             sdist.broadcast_parameters(self._flat)
         if hasattr(self.model, "set_backward_stage_hook"):
@@ -90,22 +91,46 @@ class Learner(ABC):
         return (loss, diff, vis_batch) if return_diff else loss
 
     def _use_step_graph(self):
-        """The captured step (graph.py) is the default training step; SARSSL_GRAPH=0, replayed dropout masks (parity fixtures that
-        need the reference's draw order) and models without the pretraining node fall back to the launch-by-launch step."""
-        return (os.environ.get("SARSSL_GRAPH", "1") != "0" and runtime.RT.replay is None and getattr(self.model, "pretrain", False)
-                and self._flat is not None and self._flat.on_gpu)
+        """The captured step (graph.py) is the default training step on one GPU; SARSSL_GRAPH=0, replayed dropout masks (parity
+        fixtures that need the reference's draw order), models without the pretraining node and models with frozen parameters (the
+        captured Adam pass updates the whole flat buffer) fall back to the launch-by-launch step.  Data parallel (world > 1): the
+        segmented replay with RCCL collectives between the graph launches has only ever run over gloo with two ranks on one GPU
+        (tests/test_gpu_graph.py) - until it has run on a multi-GPU node it is opt-in (SARSSL_GRAPH=1), the default there is the
+        launch-by-launch step with the overlapped bucket all-reduce."""
+        default = "1" if sdist.world_size() == 1 else "0"
+        return (os.environ.get("SARSSL_GRAPH", default) != "0" and runtime.RT.replay is None and getattr(self.model, "pretrain", False)
+                and self._flat is not None and self._flat.on_gpu and all(p.requires_grad for p in self._flat.params))
+
+    def _graph_takes_raw_batch(self, sig):
+        """The captured step can run the STFT front-end itself (as bench.py's does) when the batch is the plain 2-microphone case
+        of the default front-end: no per-step STFT launch + 67 MB copy into the graph's input buffer, only the 17 MB int16 /
+        34 MB f32 batch."""
+        return (torch.is_tensor(sig) and sig.dim() == 3 and sig.shape[2] == 2 and sig.dtype in (torch.float32, torch.int16)
+                and getattr(self, "ch_mode", None) == "M" and getattr(self, "win_len", None) == 512 and getattr(self, "nfft", None) == 512
+                and getattr(self, "win_shift_ratio", None) == 0.5)
 
     def _pretrain_epoch_graph(self, dataset, lr, return_diff):
         """Same epoch with every full-size batch replayed from the captured HIP graph(s); batches of another shape (a ragged last
         batch) take the same step eagerly and share the optimizer state."""
         from .graph import PretrainStepGraph
         g = self.__dict__.get("_step_graph")
+        if g is not None and g.flat is not self._flat:                                      # (flat buffers rebuilt since the capture)
+            g = None
         if g is None:
             g = self.__dict__["_step_graph"] = PretrainStepGraph(self.model, self._flat, self._reducer, lr=float(lr), betas=(0.9, 0.999))
         g.reset_epoch(float(lr))                                                            # "Adam re-created every epoch" (learner.py:83)
         self._flat.grad.zero_()
         for batch in dataset:
             mic_sig_batch = batch[0] if isinstance(batch, (list, tuple)) else batch
+            if not torch.is_tensor(mic_sig_batch):
+                mic_sig_batch = torch.as_tensor(mic_sig_batch)
+            if self._graph_takes_raw_batch(mic_sig_batch):                                  # STFT front-end inside the replay
+                sig = mic_sig_batch.to(self.device, non_blocking=True).contiguous()
+                if g.matches(pcm=sig):
+                    g.step(pcm=sig)
+                else:
+                    g.step_eager(pcm=sig)
+                continue
             in_batch, = self.data_preprocess(mic_sig_batch, None)
             in_batch = in_batch.contiguous().float()
             if g.matches(x=in_batch):
@@ -265,6 +290,7 @@ class Learner(ABC):
             self.model.load_state_dict(all_state_dict)
         if self._flat is not None:
             self._flat.ensure_shadow()
+        self.__dict__.pop("_step_graph", None)           # (requires_grad / buffers may change with a checkpoint: capture again)
         return sd
 
     def resume_checkpoint(self, checkpoints_dir, from_latest=True, as_all_state=True, ex_key=""):

@@ -187,7 +187,6 @@ class _PretrainFn(torch.autograd.Function):
         hip.sums_arena_reset(x.device)
         dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
         decat = engine.decoder_bwd(dpred, net.decoder, saved)
-        engine.wgrad_join()                                    # (weight-gradient side stream: the bucket is about to be read)
         net._after_backward_stage("decoder")
         saved_spat = saved.pop()
         # encoder backward takes column slices of the concatenated decoder-input gradient (row stride 768).  Schedule: all
@@ -199,7 +198,6 @@ class _PretrainFn(torch.autograd.Function):
         if side is not None:
             side.wait_stream(main)
             decat.record_stream(side)
-            engine.wgrad_no_fork(side)                         # (no stream forked off the side stream: engine.wgrad_no_fork)
         spe, spa = net.spec_encoder, net.spat_encoder
         nl = len(spa.embed.layers)
         with on_side():                                         # the host enqueues the two streams in alternating chunks, see forward
@@ -213,11 +211,9 @@ class _PretrainFn(torch.autograd.Function):
         with on_side():                                               # needs both streams joined, so the two hooks fire after the join
             d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat)
             dz_spat = engine.patch_bwd(d_spat, spa.patch_embed, saved_spat)
-            engine.wgrad_join()
             if not cut:
                 net._after_backward_stage("spat_encoder")      # its bucket is reduced behind the side stream
         dz_spec = engine.patch_bwd(d_spec, spe.patch_embed, saved)
-        engine.wgrad_join()
         if cut:
             main.wait_stream(side)
             net._after_backward_stage("spat_encoder")

@@ -64,7 +64,7 @@ def _worker(rank, world, port, q):
             net2._hook(stage)
         red2.finish()
         ok2 = ok2 and float(flat2.grad.min()) == float(flat2.grad.max()) == 3.0
-    ok2 = ok2 and red2.order == ["decoder", "spat_encoder", "spec_encoder"] * 2
+    ok2 = ok2 and red2.order == ["decoder", "spat_encoder", "spec_encoder"] and red2.nsteps == 2      # (order: the last step's)
     # BatchNorm buffers / validation scalars follow rank 0 (run_pretrain.py)
     bn = torch.nn.BatchNorm1d(3)
     bn.running_mean.fill_(float(rank + 1)); bn.num_batches_tracked.fill_(rank + 5)
@@ -93,6 +93,64 @@ def test_flat_grad_allreduce_two_ranks():
     assert set(spans) == {"spec_encoder", "spat_encoder", "decoder"}
     assert spans["spec_encoder"][0] == 0 and spans["spec_encoder"][1] == spans["spat_encoder"][0]
     assert spans["spat_encoder"][1] == spans["decoder"][0]
+
+
+def _worker4(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank)})
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import sarssl_boot  # noqa: F401
+    from sar_ssl_amd import dist as sdist, runtime
+    sdist.init_from_env(backend="gloo")
+    torch.manual_seed(7)
+    net = _NetGrouped()
+    flat = runtime.FlatParams(net)
+    red = sdist.FlatGradAllReduce(net, flat, strict=True)      # strict: what the pretraining model gets by default
+    ok = True
+    for step in range(3):
+        flat.grad.fill_(float(rank + 1))
+        for stage in ("decoder", "spat_encoder", "spec_encoder", "stem_bwd_begin", "stems"):
+            net._hook(stage)
+        scale = red.finish()
+        ok = ok and scale == 0.25 and float(flat.grad.min()) == float(flat.grad.max()) == 10.0 and \
+            red.order == ["decoder", "spat_encoder", "spec_encoder", "stems"]
+    # a bucket reported twice (exchanged before its gradient was final) or never must fail loudly
+    caught = 0
+    for stages in (("decoder", "decoder", "spat_encoder", "spec_encoder", "stems"), ("decoder", "spat_encoder", "spec_encoder")):
+        flat.grad.fill_(1.0)
+        for stage in stages:
+            net._hook(stage)
+        try:
+            red.finish()
+        except AssertionError:
+            caught += 1
+            red.strict = False                             # drain the collectives every rank has issued, then re-arm
+            red.finish()
+            red.strict = True
+    desc = red.describe()
+    ms = red.time_buckets(iters=1)
+    ok = ok and caught == 2 and desc["world"] == 4 and desc["backend"] == "gloo" and [b["name"] for b in desc["buckets"]] == \
+        ["decoder", "spat_encoder", "spec_encoder", "stems"] and sum(b["bytes"] for b in desc["buckets"]) == 4 * flat.numel and \
+        set(ms) == {"decoder", "spat_encoder", "spec_encoder", "stems"} and all(v > 0 for v in ms.values())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_four_ranks_strict_bucket_accounting():
+    """4 ranks over gloo: every bucket exactly once per step (asserted by the reducer itself in strict mode), 1/world scaling, and the
+    self-description / per-bucket timing bench.py prints for a multi-GPU line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1, 2, 3] and all(ok for _, ok in res)
 
 
 def test_backward_stage_hooks_fire_before_the_stem_backward(monkeypatch):

@@ -275,7 +275,12 @@ def test_two_rank_bench_path_over_gloo():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak" and out["value"] > 0
-    assert np.isfinite(out["final_loss"]) and "cpu_baseline" not in out
+    assert np.isfinite(out["final_loss"]) and "cpu_baseline" not in out and "product_loop" not in out
+    assert out["step_mode"] == "eager launches"                      # data parallel: the captured step is opt-in (--graph)
+    d = out["dist"]
+    assert d["world"] == 2 and d["backend"] == "gloo" and [b["name"] for b in d["buckets"]] == ["decoder", "spat_encoder", "spec_encoder", "stems"]
+    assert sum(b["bytes"] for b in d["buckets"]) > 70e6 and all(b["allreduce_ms_alone"] > 0 for b in d["buckets"])
+    assert d["steps_seen_by_reducer"] >= 3 and out["knobs"]["SARSSL_C1IN"] == 1
 
 
 @pytest.mark.parametrize("two_streams", ["0", "1"])

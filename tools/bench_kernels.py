@@ -83,6 +83,4 @@ if __name__ == "__main__":
     y2 = torch.randn((64, 256, 256, 64), device=dev).to(torch.bfloat16)
     red = hip.cl_bn_bwd_reduce(x, y2, 64, aff, 1)
     t0 = timeit(lambda: hip.cl_bn_bwd_apply(x, y2, 64, aff, 1, False, True, red), n=10)
-    t1 = timeit(lambda: hip.conv3x3_dgrad_bnin(x, w, y2, aff, red, True), n=10)
-    t2 = timeit(lambda: hip.conv3x3_wgrad_bnin(x, y2, aff, red, x, sc, sh, True), n=10)
-    print("cl_bn_bwd_apply %6.1f us | conv3x3_dgrad_bnin %6.1f us | conv3x3_wgrad_bnin %6.1f us  (fused pair vs apply + plain pair)" % (t0 * 1e6, t1 * 1e6, t2 * 1e6))
+    print("cl_bn_bwd_apply %6.1f us" % (t0 * 1e6))

@@ -44,6 +44,18 @@ def short(name):
     return name.split("(")[0][:90]
 
 
+def build_marker():
+    """tools/libprofmarker.so (marker kernel whose grid size tags the next group of launches), compiled HERE, in the un-profiled
+    driver process and with the profiler's preload variables stripped - never from tools/prof_targets.py, which runs under rocprofv3
+    with the GPU already initialised."""
+    src, lib = os.path.join(HERE, "prof_marker.hip"), os.path.join(HERE, "libprofmarker.so")
+    if os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(src):
+        return lib
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",) and not k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "HSA_TOOLS"))}
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", lib, src], env=env)
+    return lib
+
+
 def run_pass(pname, counters, outdir, env):
     d = os.path.join(outdir, pname)
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "-f", "csv", "-d", d, "-o", "r", "--",
@@ -90,11 +102,15 @@ def aggregate(rows):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_kernel_counters.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_kernel_counters.json"))
+    ap.add_argument("--build-marker", action="store_true", help="only compile tools/libprofmarker.so (no GPU needed) and exit")
     ap.add_argument("--only", default="")
     ap.add_argument("--passes", default="mfma,lds,fetch,write")
-    ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "pmc_r02"))
+    ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "pmc_r03"))
     args = ap.parse_args()
+    build_marker()                                           # before any rocprofv3 pass starts the target
+    if args.build_marker:
+        return
     env = dict(os.environ, PROF_ONLY=args.only, TMPDIR="/tmp")
     merged, tags = {}, {}
     for p in args.passes.split(","):

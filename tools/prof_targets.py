@@ -3,7 +3,6 @@ launch (tools/prof_marker.hip, grid = tag) - the target of tools/prof_counters.p
 PROF_TIME=1: no markers, each group timed with events (median / min over >= 15 calls; PROF_ONLY=30,31 selects groups)."""
 import ctypes
 import os
-import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -13,13 +12,17 @@ import torch
 from sar_ssl_amd import hip
 
 MARK = os.path.join(HERE, "libprofmarker.so")
-if not os.path.exists(MARK) or os.path.getmtime(MARK) < os.path.getmtime(os.path.join(HERE, "prof_marker.hip")):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", MARK,
-                           os.path.join(HERE, "prof_marker.hip")])
-_mk = ctypes.CDLL(MARK)
+TIME = os.environ.get("PROF_TIME", "0") != "0"
+# The marker library is built BEFORE the profiler starts this program (tools/prof_counters.py build_marker(), or
+# `python tools/prof_counters.py --build-marker`): under rocprofv3 the profiler's preloaded library has already initialised the GPU
+# when this module runs, and hipcc's clang / lld children would be exec'd from such a process - forbidden on this pool.
+if not TIME:
+    if not os.path.exists(MARK) or os.path.getmtime(MARK) < os.path.getmtime(os.path.join(HERE, "prof_marker.hip")):
+        raise SystemExit("tools/libprofmarker.so is missing or older than prof_marker.hip: run `python tools/prof_counters.py "
+                         "--build-marker` first (it is never compiled from inside the profiled process)")
+    _mk = ctypes.CDLL(MARK)
 dev = torch.device("cuda:0")
 NREP = int(os.environ.get("PROF_NREP", "3"))
-TIME = os.environ.get("PROF_TIME", "0") != "0"
 ONLY = set(int(t) for t in os.environ.get("PROF_ONLY", "").split(",") if t)
 
 TAGS = {}          # tag -> (label, algorithmic flop per launch, algorithmic bytes per launch)
