@@ -68,12 +68,17 @@ def set_precision(mode):
         RT.dtype, RT.precise, RT.fp8 = torch.float32, True, False
     elif mode == "fp8":
         RT.dtype, RT.precise, RT.fp8 = torch.bfloat16, False, True
+    elif mode == "fp32_1pass":
+        # intermediate mode (round 3): f32 STORAGE of every activation / gradient (no rounding of the residual stream, the stem
+        # tensors or the prediction to bf16), each MFMA contraction as ONE bf16 pass (operands rounded to bf16 while staged) instead
+        # of the three split passes of 'fp32'
+        RT.dtype, RT.precise, RT.fp8 = torch.float32, False, False
     else:
-        raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
+        raise ValueError("precision must be 'bf16', 'fp32', 'fp32_1pass' or 'fp8'")
 
 
 def get_precision():
-    return "fp8" if RT.fp8 else ("bf16" if RT.dtype == torch.bfloat16 else "fp32")
+    return "fp8" if RT.fp8 else ("bf16" if RT.dtype == torch.bfloat16 else ("fp32" if RT.precise else "fp32_1pass"))
 
 
 _GLOBAL_VERSION = [0]

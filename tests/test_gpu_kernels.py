@@ -313,17 +313,36 @@ def test_first_layer_conv_variants_at_the_full_batch_shape():
     mean = (sums[:64] / npix).float()
     var = (sums[64:] / npix - (sums[:64] / npix) ** 2).clamp_min(0).float()
     aff = torch.stack([scale, shift, mean, 1.0 / torch.sqrt(var + 1e-5)]).contiguous()
+    # reference: the UNROUNDED data gradient (three-pass f32 kernel over all 64 images) reduced in f64.  Both device paths round the
+    # masked gradient to bf16 before they reduce it (the stored path when it stores dz1, the fused path when it hands the masked tile
+    # to the matrix cores), and on random data the reduced sums are random-walk sums - of the size of their own rounding noise times
+    # sqrt(N) - so a relative deviation of the order of the bf16 epsilon is what BOTH must show; the gate is that the fused path is
+    # in the same class as the stored one (measured: 2.1e-3 vs 1.2e-3 on dW1) and within 5e-3.
+    dz1_32 = hip.conv3x3_fwd(dy16.float(), w16.float(), precise=True).view(-1, 64)
+    y = a0.float().view(-1, 4) @ W1.t()
+    mask = (y * scale + shift) > 0
+    xh = ((y - aff[2]) * aff[3]).double()
+    gg = torch.where(mask, dz1_32, torch.zeros_like(dz1_32)).double()
+    del dz1_32, y, mask
+    s1, s2 = gg.sum(0), (gg * xh).sum(0)
+    a0d = a0.double().view(-1, 4)
+    G = gg.t() @ a0d                                                                  # sum_p g a0
+    X = xh.t() @ a0d                                                                  # sum_p xhat a0
+    Sa = a0d.sum(0)
+    del gg, xh
+    dz1 = hip.conv3x3_fwd(dy16, w16)                                                 # stored path: dz1 (bf16), then the one-pass backward
     for train in (True, False):
+        ref = scale.double()[:, None] * ((G - s1[:, None] * Sa[None, :] / npix - s2[:, None] * X / npix) if train else G)
         dW, dga, dbe = torch.zeros((64, 4, 1, 1), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
         assert hip.conv3x3_dgrad_c1red(dy16, w16, a0, W1, aff, mom, train, dW, dga, dbe)
-        dz1 = hip.conv3x3_fwd(dy16, w16)                                             # stored path: dz1 (bf16), then the one-pass backward
         dW2, dga2, dbe2 = torch.zeros((64, 4, 1, 1), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
         hip.stem_c1_bwd_a0(dz1, a0, W1, aff, train, dW2, dga2, dbe2)
-        # (the stored path rounds dz1 to bf16 before reducing it over 4.2 M pixels; the fused path reduces the unrounded accumulators)
-        check("c1_full.c1red.dW1[train=%d]" % train, _relerr(dW, dW2), 1e-3)
-        check("c1_full.c1red.dgamma[train=%d]" % train, _relerr(dga, dga2), 1e-3)
-        check("c1_full.c1red.dbeta[train=%d]" % train, _relerr(dbe, dbe2), 1e-3)
-        del dz1
+        for name, got, got2, want in (("dW1", dW.view(64, 4), dW2.view(64, 4), ref), ("dgamma", dga, dga2, s2), ("dbeta", dbe, dbe2, s1)):
+            e_fused, e_stored = _relerr(got, want), _relerr(got2, want)
+            check("c1_full.c1red.%s[train=%d]" % (name, train), e_fused, 5e-3)
+            check("c1_full.c1red.%s[train=%d].stored_path" % (name, train), e_stored, 5e-3)
+            assert e_fused <= 3.0 * e_stored + 1e-3, (name, e_fused, e_stored)      # (same rounding class; the max over 64-256 random-walk sums varies ~2x)
+    del dz1
 
 
 def test_statistics_epilogues_and_bias_gradients_are_run_to_run_reproducible():

@@ -170,10 +170,12 @@ def _fullsize(prec, mode):
 # Full-size tolerances.  fp32 (split-bf16 MFMA) path: the north_star's 1e-3.  bf16 path (what bench.py times): 2.5-5x the deviation
 # measured on MI355X (round 2: loss 3.6e-4, sampled pred 9.6e-3 of range, worst per-parameter gradient norm 2.6e-2, BN running
 # stats 9.6e-4; recorded by conftest.check in gpurun_out/parity_measured.jsonl).
-FULL_TOL = {"fp32": dict(loss=1e-3, pred=1e-3, grad=5e-3, bn=1e-4), "bf16": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3)}
+FULL_TOL = {"fp32": dict(loss=1e-3, pred=1e-3, grad=5e-3, bn=1e-4), "bf16": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3),
+            # f32 storage + single-pass bf16 MFMA (runtime.set_precision("fp32_1pass")): first measured in round 3
+            "fp32_1pass": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3)}
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_1pass"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_fullsize_forward_backward(mode, prec):
     """north_star gate: loss and per-bin outputs within 1e-3 relative of the reference CPU path (fp32 mode); the bf16 fast path is
