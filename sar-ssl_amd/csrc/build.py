@@ -6,9 +6,12 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_nt.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip"]
 LIB = os.path.join(HERE, "libsarssl_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wno-unused-result"]
+# per-file extras.  gemm_nt.hip: hipcc 7.2's simplifycfg crashes (segfault in llvm::simplifyCFG) when it sinks "common" instructions out
+# of branches that hold LDS-DMA intrinsic calls (llvm.amdgcn.raw.ptr.buffer.load.lds has immediate operands); sinking is switched off there
+EXTRA_FLAGS = {"gemm_nt.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def _hipcc():
@@ -35,7 +38,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([_hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -485,6 +485,10 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
         SARSSL_CHECK_LAUNCH("splitk_reduce_kernel");
         return 0;
     };
+    if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && a_kc && b_kc && nbatch == 1 && g.split_k <= 0 && !c_row_shift) {
+        const int rc = sarssl_gemm_nt_try(g, dtC, stream);        // direct-to-LDS pipelined kernel (gemm_nt.hip) for the plain large shapes
+        if (rc <= 0) return rc;
+    }
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_BF16)
         return launch_layout<bf16, bf16, bf16, true>(g, a_kc, b_kc, nbatch, st);
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_F32) {

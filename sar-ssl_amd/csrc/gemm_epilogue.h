@@ -27,6 +27,9 @@ struct GemmArgs {
 #endif
 };
 
+// fast path of sarssl_gemm for bf16 NT products without ragged edges (gemm_nt.hip): 0 = launched, 1 = not this kernel's shape
+int sarssl_gemm_nt_try(const GemmArgs& g, int dtC, void* stream);
+
 // ---- fused epilogue on one 8-wide piece of one output row (v = alpha * accumulator) -------------------------------------------------
 template <typename TC, bool EDGE>
 __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m, int n, TC* __restrict__ C, const TC* __restrict__ Rz,
