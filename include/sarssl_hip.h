@@ -63,9 +63,12 @@ int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsplit, const 
 /* up to 12 independent weight-gradient products dY_q^T X_q (the nn.Linear weight gradients autograd computes one by one for the
  * layers of a Conformer block, code/common/conformer/*.py) as ONE launch: A_q = dY [K_q][M_q], B_q = X [K_q][N_q], bf16, row strides
  * lda / ldb; f32 partial sums of split_out[q] K-slices to ws[q] (size it for split_k[q] slices), folded by
- * sarssl_splitk_reduce_multi.  Returns 1 without launching when a shape is ragged (M, N % 128 or a K slice % 64). */
+ * sarssl_splitk_reduce_multi.  csum_ws (may be null, entries may be null): csum_ws[q] = f32 [split_k[q]][M_q] receives the per-slice
+ * column sums of dY_q - the layer's bias gradient, folded by the same sarssl_splitk_reduce_multi launch (M = 1, N = M_q).
+ * Returns 1 without launching when a shape is ragged (M, N % 128 or a K slice % 64). */
 int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* const* ws, const int* M, const int* N, const int* K,
-                         const long* lda, const long* ldb, const int* split_k, int* split_out, int n_prob, void* stream);
+                         const long* lda, const long* ldb, const int* split_k, int* split_out, float* const* csum_ws, int n_prob,
+                         void* stream);
 
 /* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
  *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as

@@ -6,12 +6,10 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "gemm_nt.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip"]
 LIB = os.path.join(HERE, "libsarssl_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wno-unused-result"]
-# per-file extras.  gemm_nt.hip: hipcc 7.2's simplifycfg crashes (segfault in llvm::simplifyCFG) when it sinks "common" instructions out
-# of branches that hold LDS-DMA intrinsic calls (llvm.amdgcn.raw.ptr.buffer.load.lds has immediate operands); sinking is switched off there
-EXTRA_FLAGS = {"gemm_nt.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+EXTRA_FLAGS = {}             # per-file extras (none in the product build; tools/gemm_nt/ documents one hipcc 7.2 workaround)
 
 
 def _hipcc():

@@ -81,7 +81,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
     return u.b;
 }
 
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE>
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool CSUM = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, const int bid_y, const int bid_z, const int grid_x,
                                           const int grid_y, const int grid_z) {
     constexpr int BM = 64 * FM;
@@ -140,6 +140,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // CSUM (grouped weight-gradient launch): the column sums of the A operand over this K-slice - the bias gradient that autograd
+    // computes next to every nn.Linear weight gradient - ride on the matrix cores: one extra MFMA per A fragment against an all-ones
+    // fragment (every row of the 32 x 32 result then holds sum_k A[m][k]), in the workgroups of column tile 0 only.  Round 2 read every dY
+    // a second time for these sums (colsum_multi: 235 us per step inside the graph).
+    // ONE extra accumulator for both A fragments (FM = 2): the ones sit in rows 0-15 of the selector fragment used with fragment 0 and in
+    // rows 16-31 of the one used with fragment 1, so rows 0-15 of the result collect fragment 0's sums and rows 16-31 fragment 1's
+    // (two accumulators did not fit next to the 3-waves-per-SIMD register cap: 108 bytes of scratch per lane).
+    static_assert(!CSUM || FM == 2, "column-sum epilogue: two A fragments share one accumulator");
+    const bool do_cs = CSUM && g.csum_ws != nullptr && bx == 0 && wn == 0;
+    f32x16 accs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accs[r] = 0.f;
+    // lane = row (lane & 31) of the selector: all ones (0x3F80 pairs) or all zeros; fragment 1's selector is its complement
+    const uint32_t selw = ((lane & 31) < 16) ? 0x3F803F80u : 0u;
 
     // epilogue operands that do not depend on the accumulators are requested early: a thread keeps the same 8 output columns in
     // every epilogue slice, so its 8 bias values are loaded here, behind the whole K loop
@@ -176,6 +190,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if constexpr (CSUM) {
+                if (do_cs) {
+                    union { uint32_t w[4]; bf16x8 b; } s0, s1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s0.w[e] = selw; s1.w[e] = selw ^ 0x3F803F80u; }
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.b, fa[0], accs, 0, 0, 0);
+                    accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.b, fa[FM - 1], accs, 0, 0, 0);
+                }
+            }
         };
         bf16x8 fa0[FM], fb0[2], fa1[FM], fb1[2];
         if (g.prio) __builtin_amdgcn_s_setprio(2);      // over the co-resident workgroups' waves that are staging / storing
@@ -227,6 +250,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
         }
     }
 
+    if constexpr (CSUM) {
+        if (do_cs && lane < 32) {                       // column lane of the result = row m of A; register 0 = result row 0 (fragment 0's
+            float* q = g.csum_ws + (long)ks * g.M + m0 + wm * (FM * 32) + lane;     // sums), register 8 = result row 16 (fragment 1's)
+            q[0] = accs[0];
+            q[32] = accs[8];
+        }
+    }
     // ---- epilogue.  The MFMA leaves each lane with 4 consecutive n for ONE row m (32 different rows per wave instruction):
     // storing that directly is store-issue bound (every instruction touches 32 cache lines).  Instead the f32 accumulators are
     // transposed through LDS, 64 rows at a time (fragment row i of both wave rows), so each thread owns 8 consecutive columns of
@@ -314,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     const int gx = a.gx[q], gy = a.gy[q], ns = a.p[q].split_k;
     if (local >= gx * gy * ns) return;               // (first[] is padded to multiples of 8: linear id % 8 stays the XCD inside a product)
     const int bz = local / (gx * gy), rem = local - bz * (gx * gy);
-    gemm_body<bf16, bf16, float, false, false, 2, false>(a.p[q], rem % gx, rem / gx, bz, gx, gy, ns);
+    gemm_body<bf16, bf16, float, false, false, 2, false, true>(a.p[q], rem % gx, rem / gx, bz, gx, gy, ns);
 }
 
 // C[z][m][n] += sum_s ws[z][s][m][n]   (second stage of split-K weight-gradient GEMMs; C is f32)
@@ -460,7 +490,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
     g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K;
-    g.row_shift = 0;
+    g.row_shift = 0; g.csum_ws = nullptr;
 #ifdef GEMM_STAMPS
     g.stamps = g_gemm_stamps_host;
 #endif
@@ -485,10 +515,15 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
         SARSSL_CHECK_LAUNCH("splitk_reduce_kernel");
         return 0;
     };
+#ifdef SARSSL_WITH_GEMM_NT
+    // probe builds only (tools/gemm_nt/): the direct-to-LDS pipelined NT kernel measured in round 3 - faster than this file's kernel on
+    // long-K products alone (dec2 105 -> 96 us), neutral inside the step (its 128-144 KiB of LDS keep the other encoder's stream off the
+    // CU), so it is not part of the product library
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && a_kc && b_kc && nbatch == 1 && g.split_k <= 0 && !c_row_shift) {
-        const int rc = sarssl_gemm_nt_try(g, dtC, stream);        // direct-to-LDS pipelined kernel (gemm_nt.hip) for the plain large shapes
+        const int rc = sarssl_gemm_nt_try(g, dtC, stream);
         if (rc <= 0) return rc;
     }
+#endif
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_BF16)
         return launch_layout<bf16, bf16, bf16, true>(g, a_kc, b_kc, nbatch, st);
     if (dtA == SARSSL_BF16 && dtB == SARSSL_BF16 && dtC == SARSSL_F32) {
@@ -528,8 +563,8 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
 // multiple of 64) is returned in split_out[q] - size ws[q] for split_k[q] slices.  Returns 1 without launching when any shape is
 // ragged (M % 128, N % 128 or the K slices % 64).
 extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* const* ws, const int* M, const int* N,
-                                    const int* K, const long* lda, const long* ldb, const int* split_k, int* split_out, int n_prob,
-                                    void* stream) {
+                                    const int* K, const long* lda, const long* ldb, const int* split_k, int* split_out,
+                                    float* const* csum_ws, int n_prob, void* stream) {
     SARSSL_REQUIRE(n_prob > 0 && n_prob <= GROUP_MAXP, "sarssl_gemm_group_tn");
     GemmGroup a;
     a.n = n_prob;
@@ -548,6 +583,7 @@ extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, 
         g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
         g.p_drop = 0.f; g.seed = 0; g.salt = nullptr; g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
         g.split_k = ns; g.k_per_split = per; g.row_shift = 0;
+        g.csum_ws = csum_ws ? csum_ws[q] : nullptr;
         a.gx[q] = (N[q] + BN - 1) / BN; a.gy[q] = (M[q] + 127) / 128;
         a.first[q] = total; total += (a.gx[q] * a.gy[q] * ns + 7) / 8 * 8;
         split_out[q] = ns;

@@ -19,6 +19,8 @@ struct GemmArgs {
     float p_drop; unsigned long long seed; const unsigned long long* salt;   // salt: device-resident seed addend (graph replay) or null
     int prio;                   // != 0: waves raise their issue priority during the MFMA phase of a K-tile (s_setprio)
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
+    float* csum_ws;             // grouped weight-gradient launch only: f32 [split_k][M] partial column sums of the A operand (= the bias
+                                // gradient of the layer whose weight gradient this product is), written by the workgroups of column tile 0
     int row_shift;              // != 0 (= T, with M = N = ldc = T): row m of every batch matrix is stored m + 1 - T elements further
                                 // (elements falling before the matrix are dropped): the relative-position shift of the reference
                                 // (attention.py:105-113: pad one zero column, reinterpret (T, T+1) as (T+1, T), drop the first row)

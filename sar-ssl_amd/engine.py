@@ -69,6 +69,7 @@ def mm_nn(dy, W, fp8=True, **kw):
 # companion-stream schedules for these products - per product and per block; neither beat keeping them on the chain, and a stream
 # forked off a forked stream crashes hipStreamEndCapture on ROCm 7.2 (tools/capture_nested_fork_repro.py).  Removed in round 3.)
 _WGRAD_GROUP = os.environ.get("SARSSL_WGRAD_GROUP", "1") != "0"
+_WGRAD_CSUM = os.environ.get("SARSSL_WGRAD_CSUM", "1") != "0"   # bias gradients from the grouped weight-gradient launch (0: separate column-sum launch)
 _wg_blocks = []              # stack of pending-product lists (wgrad_block)
 
 
@@ -89,8 +90,10 @@ class wgrad_block:
         for i in range(0, len(items), 12):                 # one grouped launch per <= 12 products (csrc/gemm.hip)
             chunk = items[i:i + 12]
             if not (_WGRAD_GROUP and len(chunk) > 1 and hip.gemm_group_tn(chunk)):
-                for dy, x, g2, split in chunk:
+                for dy, x, g2, split, bias in chunk:
                     _wgrad_gemm(dy, x, g2, split)
+                    if bias is not None:
+                        hip.colsum(dy, bias)
         hip.colsum_flush()                                 # partial sums join the split-K batch ...
         hip.splitk_flush()                                 # ... and are folded with the products' partials in one launch
         return False
@@ -116,17 +119,24 @@ def _wgrad_split(M, N, K, grouped):
     return split // 8 * 8 if split >= 8 else split
 
 
-def mm_tn_acc(dy, x, gW, group=True):
-    """gW[N,K] += dy[M,N]^T @ x[M,K]   (weight gradient of nn.Linear, f32 accumulate into the grad buffer)."""
+def mm_tn_acc(dy, x, gW, group=True, bias=None):
+    """gW[N,K] += dy[M,N]^T @ x[M,K]   (weight gradient of nn.Linear, f32 accumulate into the grad buffer) and, with ``bias``,
+    bias[N] += column sums of dy (the layer's bias gradient): inside a grouped launch they come out of the same kernel (one extra MFMA
+    per dy fragment against a ones fragment) instead of a second pass over dy."""
     M, N = dy.shape
     K = x.shape[1]
     g2 = gW.view(N, K)
     grouped = bool(group and _wg_blocks and RT.replay is None and _WGRAD_GROUP and RT.dtype == torch.bfloat16)
     split = _wgrad_split(M, N, K, grouped)
     if grouped:
-        _wg_blocks[-1].append((dy, x, g2, split))            # enqueued when the block's backward ends (wgrad_block)
+        if bias is not None and not _WGRAD_CSUM:             # A/B: bias gradient by the stand-alone column-sum launch
+            hip.colsum(dy, bias)
+            bias = None
+        _wg_blocks[-1].append((dy, x, g2, split, bias))      # enqueued when the block's backward ends (wgrad_block)
     else:
         _wgrad_gemm(dy, x, g2, split)
+        if bias is not None:
+            hip.colsum(dy, bias)
 
 
 def to_rt(x):
@@ -227,12 +237,12 @@ def knobs():
     """Resolved state of every environment switch that selects a compute path (bench.py prints it; a benchmark line is only
     comparable with another one under the same knobs)."""
     from . import runtime
-    return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
+    return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
             "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
             "SARSSL_CONV_CUS_BWD": os.environ.get("SARSSL_CONV_CUS_BWD", os.environ.get("SARSSL_CONV_CUS", "default(224)")),
-            "SARSSL_GRAPH": os.environ.get("SARSSL_GRAPH", "default"), "SARSSL_GEMM_NT": os.environ.get("SARSSL_GEMM_NT", "default(1)"), "SARSSL_MFMA_PRIO": os.environ.get("SARSSL_MFMA_PRIO", "default(2)"),
+            "SARSSL_GRAPH": os.environ.get("SARSSL_GRAPH", "default"), "SARSSL_MFMA_PRIO": os.environ.get("SARSSL_MFMA_PRIO", "default(2)"),
             "precision": runtime.get_precision()}
 
 
@@ -357,8 +367,7 @@ def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
     seq = ff.sequential
     if torch.is_tensor(s1) or torch.is_tensor(s2):        # replayed masks (see ffn_fwd)
         dz2 = (dy * s2 if torch.is_tensor(s2) else dy) * factor
-        mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
-        hip.colsum(dz2, gbuf(seq[4].linear.bias))
+        mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight), bias=gbuf(seq[4].linear.bias))
         dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH)
         if torch.is_tensor(s1):
             dh = dh * s1
@@ -367,12 +376,10 @@ def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
             dz2 = dy_dropped                                  # written by the previous LayerNorm backward (see _next_drop)
         else:
             dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
-        mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight))
-        hip.colsum(dz2, gbuf(seq[4].linear.bias))
+        mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight), bias=gbuf(seq[4].linear.bias))
         # dh = (dz2 @ W2) * dropout_mask1 * swish'(hpre): activation backward fused into the GEMM epilogue
         dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
-    mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight))
-    hip.colsum(dh, gbuf(seq[1].linear.bias))
+    mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight), bias=gbuf(seq[1].linear.bias))
     dln = mm_nn(dh, wt(seq[1].linear.weight))
     return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
                              drop=_next_drop(next_kind, saved))
@@ -492,8 +499,7 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
         dout = dy_dropped
     else:
         dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
-    mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight))
-    hip.colsum(dout, gbuf(att.out_proj.linear.bias))
+    mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight), bias=gbuf(att.out_proj.linear.bias))
     dctx = mm_nn(dout, wt(att.out_proj.linear.weight))
     fused = _qkv_views(att)
     ldk = k.stride(0)
@@ -565,13 +571,11 @@ def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb
     hip.colsum(dqv, gbuf(att.v_bias).view(-1))
     dq = hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dq_out)
     if fused is not None:
-        mm_tn_acc(dqkv, ln, fused[2])
-        hip.colsum(dqkv, fused[3])
+        mm_tn_acc(dqkv, ln, fused[2], bias=fused[3])
         dln = mm_nn(dqkv, fused[0])
     else:
         for proj, g in ((att.query_proj, dq), (att.key_proj, dk), (att.value_proj, dv)):
-            mm_tn_acc(g, ln, gbuf(proj.linear.weight))
-            hip.colsum(g, gbuf(proj.linear.bias))
+            mm_tn_acc(g, ln, gbuf(proj.linear.weight), bias=gbuf(proj.linear.bias))
         dln = mm_nn(dq, wt(att.query_proj.linear.weight))
         dln = mm_nn(dk, wt(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
         dln = mm_nn(dv, wt(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
@@ -619,8 +623,7 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
         dout = dy_dropped
     else:
         dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
-    mm_tn_acc(dout, s, gbuf(pw2.weight))
-    hip.colsum(dout, gbuf(pw2.bias))
+    mm_tn_acc(dout, s, gbuf(pw2.weight), bias=gbuf(pw2.bias))
     ds = mm_nn(dout, wt(pw2.weight).view(d, d))
     red = hip.cl_bn_bwd_reduce(ds, c, d, aff, SWISH)
     dc = hip.cl_bn_bwd_apply(ds, c, d, aff, SWISH, False, train, red, out=ds, pgrads=(gbuf(bn.weight), gbuf(bn.bias))).view(B, T, d)
@@ -631,8 +634,7 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
         dg = hip.dwconv(dc, dw.weight.data.view(d, -1), flip=True)
         hip.dwconv_wgrad(dc, g.view(B, T, d), gbuf(dw.weight).view(d, -1))
         dh = hip.glu_bwd(dg.view(B * T, d), h)
-    mm_tn_acc(dh, ln, gbuf(pw1.weight))
-    hip.colsum(dh, gbuf(pw1.bias))
+    mm_tn_acc(dh, ln, gbuf(pw1.weight), bias=gbuf(pw1.bias))
     dln = mm_nn(dh, wt(pw1.weight).view(2 * d, d))
     return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
                              drop=_next_drop(next_kind, saved))
@@ -696,9 +698,7 @@ def decoder_bwd(dpred, dec, saved):
     e, h = saved.pop()
     l1, l2 = dec.proj[0], dec.proj[2]
     with hip.colsum_batched(), hip.splitk_batched(), wgrad_block():
-        mm_tn_acc(dpred, h, gbuf(l2.weight))
-        hip.colsum(dpred, gbuf(l2.bias))
+        mm_tn_acc(dpred, h, gbuf(l2.weight), bias=gbuf(l2.bias))
         dh = mm_nn(dpred, wt(l2.weight), fp8=False, aux=h, aux_act=RELU)
-        mm_tn_acc(dh, e, gbuf(l1.weight))
-        hip.colsum(dh, gbuf(l1.bias))
+        mm_tn_acc(dh, e, gbuf(l1.weight), bias=gbuf(l1.bias))
         return mm_nn(dh, wt(l1.weight), fp8=False)

@@ -168,20 +168,22 @@ _splitk_batch = None
 
 
 def gemm_group_tn(items):
-    """items: [(dy [K,M] bf16, x [K,N] bf16, out f32 [M,N] view, split)] - the split-K partial sums of every out_q += dy_q^T x_q in ONE
-    launch (csrc/gemm.hip, gemm_group_tn_kernel); the partials join the open splitk_batched() batch and are folded into the
+    """items: [(dy [K,M] bf16, x [K,N] bf16, out f32 [M,N] view, split, bias_out f32 [M] or None)] - the split-K partial sums of every
+    out_q += dy_q^T x_q in ONE launch (csrc/gemm.hip, gemm_group_tn_kernel) and, where bias_out is given, the per-slice column sums of
+    dy_q (the layer's bias gradient) from the same launch; the partials join the open splitk_batched() batch and are folded into the
     gradient buffers when it closes.  Returns False (nothing launched) when a shape is ragged or no batch is open."""
     import ctypes
     n = len(items)
     if _splitk_batch is None or n == 0 or n > 12:
         return False
-    for dy, x, out, split in items:
+    for dy, x, out, split, _ in items:
         if not (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and out.dtype == torch.float32 and dy.stride(1) == 1
                 and x.stride(1) == 1 and out.shape[1] % 4 == 0 and out.stride(0) % 4 == 0 and dy.shape[1] % 128 == 0
                 and x.shape[1] % 128 == 0):
             return False
     _need_cuda(*[t for it in items for t in it[:3]])
     ws = [torch.empty((it[3] * it[0].shape[1] * it[1].shape[1],), dtype=torch.float32, device=it[0].device) for it in items]
+    cs = [torch.empty((it[3] * it[0].shape[1],), dtype=torch.float32, device=it[0].device) if it[4] is not None else None for it in items]
     arr = lambda ty, vals: (ty * n)(*vals)
     split_out = (ctypes.c_int * n)()
     rc = _lib.lib().sarssl_gemm_group_tn(
@@ -189,16 +191,27 @@ def gemm_group_tn(items):
         arr(ctypes.c_void_p, [w.data_ptr() for w in ws]), arr(ctypes.c_int, [it[0].shape[1] for it in items]),
         arr(ctypes.c_int, [it[1].shape[1] for it in items]), arr(ctypes.c_int, [it[0].shape[0] for it in items]),
         arr(ctypes.c_long, [it[0].stride(0) for it in items]), arr(ctypes.c_long, [it[1].stride(0) for it in items]),
-        arr(ctypes.c_int, [it[3] for it in items]), split_out, c_int(n), _stream())
+        arr(ctypes.c_int, [it[3] for it in items]), split_out, arr(ctypes.c_void_p, [c.data_ptr() if c is not None else None for c in cs]),
+        c_int(n), _stream())
     _lib.ncalls += 1
     if rc == 1:
         return False
     _lib.check(rc, "sarssl_gemm_group_tn")
-    for q, (dy, x, out, split) in enumerate(items):
-        _splitk_batch.append((ws[q], int(split_out[q]), dy.shape[1], x.shape[1], out, out.stride(0)))
-        if len(_splitk_batch) == 32:
-            splitk_flush()
+    for q, (dy, x, out, split, bias_out) in enumerate(items):
+        ns, Mq = int(split_out[q]), dy.shape[1]
+        _splitk_batch.append((ws[q], ns, Mq, x.shape[1], out, out.stride(0)))
+        if bias_out is not None:
+            _splitk_batch.append((cs[q][:ns * Mq], ns, 1, Mq, bias_out, Mq))
+    while len(_splitk_batch) > 32:
+        splitk_flush_first(32)
     return True
+
+
+def splitk_flush_first(k):
+    """Fold the first k queued partial-sum buffers now (the reduce launch takes at most 32 problems)."""
+    global _splitk_batch
+    head, _splitk_batch = _splitk_batch[:k], _splitk_batch[k:]
+    _splitk_flush_items(head, len(head))
 
 
 _splitk_ctx = None            # optional context-manager factory (tensors...) the flush launch runs under (engine._WgradSide)
@@ -208,13 +221,15 @@ def splitk_flush():
     global _splitk_batch
     if not _splitk_batch:
         return
-    items, n = _splitk_batch, len(_splitk_batch)
+    items = _splitk_batch
     _splitk_batch = []
-    if _splitk_ctx is not None:
-        with _splitk_ctx(*[it[0] for it in items]):
-            _splitk_flush_items(items, n)
-    else:
-        _splitk_flush_items(items, n)
+    for i in range(0, len(items), 32):
+        chunk = items[i:i + 32]
+        if _splitk_ctx is not None:
+            with _splitk_ctx(*[it[0] for it in chunk]):
+                _splitk_flush_items(chunk, len(chunk))
+        else:
+            _splitk_flush_items(chunk, len(chunk))
 
 
 def _splitk_flush_items(items, n):

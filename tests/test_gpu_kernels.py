@@ -825,23 +825,27 @@ def test_dwglu_fused_kernels(B, T, d, dtp):
 
 
 def test_gemm_group_tn_equals_separate_products():
-    """Grouped weight-gradient launch (csrc/gemm.hip gemm_group_tn_kernel) vs the same products issued one by one and vs f64."""
+    """Grouped weight-gradient launch (csrc/gemm.hip gemm_group_tn_kernel) vs the same products issued one by one and vs f64; the bias
+    gradients (column sums of dy) that ride on the same launch vs f64 and vs the stand-alone column-sum kernel."""
     from sar_ssl_amd import hip
     torch.manual_seed(3)
     K = 1024
     shapes = [(512, 256), (256, 256), (2048, 512), (128, 128), (768, 256)]
-    items, refs, outs = [], [], []
-    for M, N in shapes:
+    items, refs, outs, brefs, bouts = [], [], [], [], []
+    for q, (M, N) in enumerate(shapes):
         dy = (torch.randn(K, M, device="cuda") * 0.1).to(torch.bfloat16)
         x = torch.randn(K, N, device="cuda").to(torch.bfloat16)
         out = torch.zeros(M, N, device="cuda") + 1.0                    # (+= semantics: starts non-zero)
-        items.append((dy, x, out, 4))
+        bias = (torch.zeros(M, device="cuda") + 2.0) if q != 1 else None    # (one product without a bias gradient)
+        items.append((dy, x, out, 4, bias))
         refs.append(1.0 + dy.double().t() @ x.double())
         outs.append(out)
+        brefs.append(2.0 + dy.double().sum(0))
+        bouts.append(bias)
     with hip.splitk_batched():
         assert hip.gemm_group_tn(items)
     sep = []
-    for dy, x, _, split in items:
+    for dy, x, _, split, _b in items:
         o = torch.zeros(dy.shape[1], x.shape[1], device="cuda") + 1.0
         hip.gemm(dy, x, a_kc=False, b_kc=False, M=dy.shape[1], N=x.shape[1], K=K, lda=dy.stride(0), ldb=x.stride(0), out=o, ldc=x.shape[1],
                  split_k=split)
@@ -849,10 +853,17 @@ def test_gemm_group_tn_equals_separate_products():
     for o, r, s_ in zip(outs, refs, sep):
         assert float((o.double() - r).abs().max() / r.abs().max()) < 2e-3
         assert torch.equal(o, s_)                                        # same tiles, same split, same fold order
+    for (dy, _x, _o, _s, _b), b, r in zip(items, bouts, brefs):
+        if b is None:
+            continue
+        assert float((b.double() - r).abs().max() / r.abs().max()) < 1e-5    # exact bf16 terms, f32 accumulation
+        alone = torch.zeros_like(b) + 2.0
+        hip.colsum(dy, alone)
+        assert float((b - alone).abs().max() / alone.abs().max()) < 1e-5
     # ragged shape: refused, nothing launched
     dy = torch.randn(K, 192, device="cuda").to(torch.bfloat16)
     with hip.splitk_batched():
-        assert not hip.gemm_group_tn([(dy, dy, torch.zeros(192, 192, device="cuda"), 2), items[0]])
+        assert not hip.gemm_group_tn([(dy, dy, torch.zeros(192, 192, device="cuda"), 2, None), items[0]])
 
 
 @pytest.mark.parametrize("dtp", [torch.bfloat16, torch.float32])

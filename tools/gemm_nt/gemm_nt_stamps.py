@@ -1,19 +1,15 @@
-"""Per-phase cycle stamps of the pipelined NT GEMM's K loop (csrc/gemm_nt.hip; workgroup (0,0), all waves, first 24 K-tiles): builds a probe
-copy of the library with -DGEMM_STAMPS into gpurun_out/ and prints where a K-tile's cycles go.   python tools/gemm_nt_stamps.py [cfg ...]"""
-import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-C = os.path.join(ROOT, "sar-ssl_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "libgemmntprobe.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wno-unused-result", "-DGEMM_STAMPS"]
-if not os.path.exists(out) or os.environ.get("PROBE_REBUILD", "1") != "0":
-    objs = [os.path.join(C, f) for f in os.listdir(C) if f.endswith(".o") and f not in ("gemm.o", "gemm_nt.o", "gemm_fp8.o")]
-    for f, extra in (("gemm.hip", []), ("gemm_fp8.hip", []), ("gemm_nt.hip", ["-mllvm", "-simplifycfg-sink-common=false"])):
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + extra + ["-c", os.path.join(C, f), "-o", "/tmp/probe_%s.o" % f[:-4]])
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, "/tmp/probe_gemm.o", "/tmp/probe_gemm_fp8.o",
-                           "/tmp/probe_gemm_nt.o"] + objs + ["-lpthread"])
-if "--build-only" in sys.argv:
-    sys.exit(0)
+"""Per-phase cycle stamps of the pipelined NT GEMM's K loop (tools/gemm_nt/gemm_nt.hip, round-3 experiment; workgroup (0,0), all waves, first 24 K-tiles): builds a probe
+copy of the library with -DGEMM_STAMPS into tmp_ab/ and prints where a K-tile's cycles go.   SARSSL_GEMM_NT_CFG=<n> python tools/gemm_nt/gemm_nt_stamps.py"""
+import os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+out = os.path.join(ROOT, "tmp_ab", "libgemmntstamps.so")
+if "--build-only" in sys.argv or not os.path.exists(out):
+    sys.path.insert(0, HERE)
+    import build_probe
+    build_probe.build(out, stamps=True)
+    if "--build-only" in sys.argv:
+        sys.exit(0)
 cfg = os.environ.get("SARSSL_GEMM_NT_CFG", "auto")
 os.environ["SARSSL_HIP_LIB"] = out
 sys.path.insert(0, ROOT)

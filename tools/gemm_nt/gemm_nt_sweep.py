@@ -1,10 +1,10 @@
-"""NT GEMM sweep at the step's shapes (M = 16384): the direct-to-LDS pipelined kernel (csrc/gemm_nt.hip) in each of its tile
-configurations against the general register-staged kernel (csrc/gemm.hip) and the library (torch.matmul -> hipBLASLt), plain and with
-the step's epilogues; every configuration is first checked against an f64 product of the same bf16 operands.  Each variant runs in a
-child process (the configuration switches are read once per process).
+"""NT GEMM sweep at the step's shapes (M = 16384): the direct-to-LDS pipelined kernel (tools/gemm_nt/gemm_nt.hip, a round-3 experiment
+that is NOT in the product library) in each of its tile configurations against the product's register-staged kernel (csrc/gemm.hip) and the
+library (torch.matmul -> hipBLASLt), plain and with the step's epilogues; every configuration is first checked against an f64 product of
+the same bf16 operands.  Each variant runs in a child process (the configuration switches are read once per process).
 
-    python tools/gemm_nt_sweep.py            # all shapes
-    python tools/gemm_nt_sweep.py --child    # (internal)
+    python tools/gemm_nt/gemm_nt_sweep.py --build-only     # (here: compiles tmp_ab/libgemmnt.so, which travels to the GPU box)
+    python tools/gemm_nt/gemm_nt_sweep.py                  # all shapes
 """
 import json
 import os
@@ -12,7 +12,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ROOT = os.path.dirname(os.path.dirname(HERE))
+PROBE = os.path.join(ROOT, "tmp_ab", "libgemmnt.so")
 SHAPES = [("ffn1 d512", 2048, 512), ("ffn2 d512", 512, 2048), ("qkv d512", 1536, 512), ("pw1 d512", 1024, 512), ("out d512", 512, 512),
           ("dec1", 3072, 768), ("dec1 dX", 768, 3072), ("dec2", 1024, 3072), ("dec2 dX", 3072, 1024), ("patch d512", 512, 1024),
           ("ffn1 d256", 1024, 256), ("ffn2 d256", 256, 1024), ("proj d256", 256, 256), ("qkv d256", 768, 256), ("pw1 d256", 512, 256),
@@ -20,6 +21,7 @@ SHAPES = [("ffn1 d512", 2048, 512), ("ffn2 d512", 512, 2048), ("qkv d512", 1536,
 
 
 def child():
+    os.environ["SARSSL_HIP_LIB"] = PROBE
     sys.path.insert(0, ROOT)
     import sarssl_boot  # noqa
     import torch
@@ -77,6 +79,12 @@ def run(env_extra):
 
 
 def main():
+    if "--build-only" in sys.argv or not os.path.exists(PROBE):
+        sys.path.insert(0, HERE)
+        import build_probe
+        build_probe.build(PROBE)
+        if "--build-only" in sys.argv:
+            return
     variants = [("lib", dict(SWEEP_LIB="1")), ("old", dict(SARSSL_GEMM_NT="0")), ("auto", {})]
     variants += [("cfg%d" % c, dict(SARSSL_GEMM_NT_CFG=str(c))) for c in (0, 2, 3, 6)]
     modes = os.environ.get("SWEEP_MODES", "plain,epi,resid").split(",")
