@@ -507,13 +507,17 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     auto issue_loads = [&](const TileCoord tc) {
         const int tcl = min(max(tc.t0 - 1 + pc, 0), Tn - 1);
         const unsigned voff = C1IN ? (unsigned)tcl * 8u : (unsigned)(tcl * 64 + cch * 8) * 2u;
-        const long img = (long)tc.b * F;
+        // one 64-bit base per tile (the image), 32-bit row offsets inside it (an image is < 4 GB): round-3 stamps showed this phase at
+        // 2.8 k cycles per half tile for 12 loads - ~14 scalar instructions of 64-bit multiply / add per row sat in front of every load
+        constexpr unsigned PXB = C1IN ? 8u : 128u;                               // bytes per pixel
+        const char* pimg = (const char*)in + (long)tc.b * F * (long)Tn * PXB;
+        const unsigned rowbytes = (unsigned)Tn * PXB;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int f = min(max(tc.f0 - 1 + i, 0), F - 1);                      // (clamped: unconditional loads, see load_chunk_clamped)
-            const long rowb = (img + f) * (long)Tn * (C1IN ? 8 : 128);           // bytes
-            if (C1IN) { const uint2 q = *(const uint2*)((const char*)in + rowb + voff); regs[i].u.x = q.x; regs[i].u.y = q.y; }
-            else regs[i].u = *(const uint4*)((const char*)in + rowb + voff);
+            const char* prow = pimg + (unsigned)f * rowbytes;
+            if (C1IN) { const uint2 q = *(const uint2*)(prow + voff); regs[i].u.x = q.x; regs[i].u.y = q.y; }
+            else regs[i].u = *(const uint4*)(prow + voff);
         }
         {
             const int hr = pc >> 1, te = tc.t0 + PTC - 1 + (pc & 1);        // (threads >= 160: an unused, harmless extra chunk)
@@ -722,6 +726,30 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         __builtin_amdgcn_wave_barrier();
         if (BNRED) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         STAMP(7);
+        // Interior tiles (every tile of a 256-multiple image): branch-free drain - all eight LDS reads in flight at once, one scalar base
+        // per wave, lane-constant byte offset, the row / column-block offsets immediate or scalar.  Round-3 stamps: the per-chunk validity
+        // branches (s_and_saveexec + branch around every store) made this phase a chain of eight LDS round trips, 2.4-4.5 k cycles per tile.
+        const bool interior = !BNRED && (tc.f0 + TR <= F) && (tc.t0 + PTC <= Tn);
+        if (interior) {
+            uint4 o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = *(const uint4*)&stg[((lane >> 3) + 8 * k) * 64 + (((lane & 7) ^ (lane >> 3)) << 3)];
+            char* obase = (char*)a.out + (((long)tc.b * F + tc.f0 + 2 * hw) * Tn + tc.t0) * 128;
+            const unsigned loff = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16), rowb = (unsigned)Tn * 128u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *(uint4*)(obase + loff + (k & 3) * (8 * 128) + (k >> 2) * rowb) = o[k];
+            if (a.stats) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t w[4] = {o[k].x, o[k].y, o[k].z, o[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int px = (lane >> 3) + 8 * k;

@@ -3,12 +3,13 @@ with -DCONV_STAMPS into gpurun_out/ and prints where a half-tile's cycles go.   
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C = os.path.join(ROOT, "sar-ssl_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "libconvprobe.so")
+out = os.path.join(ROOT, "tmp_ab", "libconvprobe.so")        # (tmp_ab/ travels to the GPU box, gpurun_out/ does not)
 os.makedirs(os.path.dirname(out), exist_ok=True)
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wno-unused-result"]
 objs = [os.path.join(C, f) for f in os.listdir(C) if f.endswith(".o") and f != "conv3x3.o"]
-subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DCONV_STAMPS", "-c", os.path.join(C, "conv3x3.hip"), "-o", "/tmp/conv_probe.o"])
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, "/tmp/conv_probe.o"] + objs + ["-lpthread"])
+REBUILD = os.environ.get("PROBE_REBUILD", "1") != "0" or not os.path.exists(out)
+if REBUILD: subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DCONV_STAMPS", "-c", os.path.join(C, "conv3x3.hip"), "-o", "/tmp/conv_probe.o"])
+if REBUILD: subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, "/tmp/conv_probe.o"] + objs + ["-lpthread"])
 os.environ["SARSSL_HIP_LIB"] = out
 sys.path.insert(0, ROOT)
 import sarssl_boot  # noqa
