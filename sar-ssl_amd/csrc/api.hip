@@ -39,7 +39,9 @@ int sarssl_cu_count() {
 // ---- device-resident step state ----------------------------------------------------------------------------------------------------
 // A training step captured into a hipGraph replays with frozen kernel arguments, so everything that changes from step to step lives
 // in device memory: the dropout salt (added to each launch's static seed) and the Adam step count / bias corrections.
-static const unsigned long long* g_salt = nullptr;
+// (thread_local: the pointer is attached by the thread that captures a step and must only reach the launches THAT thread issues - a loader
+//  or validation thread launching kernels at the same time keeps seeing "no salt")
+static thread_local const unsigned long long* g_salt = nullptr;
 const unsigned long long* sarssl_dropout_salt() { return g_salt; }
 // state: device pointer to a SarsslStepState (or null to detach).  While attached, every launch that draws dropout masks reads the
 // salt through this pointer - attach only around graph capture: the pointer is baked into the captured launches.
@@ -86,15 +88,25 @@ extern "C" int sarssl_step_tick(void* state, void* stream) {
 // The f64 accumulators of the reductions (BatchNorm sums, backward sums, loss sums) are zeroed by a hipMemsetAsync in front of every
 // launch: ~26 memset nodes per training step.  The host side can instead hand out slices of ONE arena it zeroes once per forward /
 // backward pass (hip.py: sums_zeroed); a pointer inside the registered range is taken as already zero and its memset is skipped.
-static const char* g_zero_lo = nullptr;
-static const char* g_zero_hi = nullptr;
+// One range per device (the host keeps one arena per GPU; with a single process-global range the second device's arena used to evict the
+// first one's, whose slices then silently got all their memsets back).  base == null clears the table.
+#define ZERO_ARENA_MAX 16
+static struct { const char* lo; const char* hi; } g_zero[ZERO_ARENA_MAX];
+static int g_nzero = 0;
 extern "C" int sarssl_zero_arena(const void* base, long bytes) {
-    g_zero_lo = (const char*)base; g_zero_hi = base ? (const char*)base + bytes : nullptr;
+    if (!base) { g_nzero = 0; return 0; }
+    for (int i = 0; i < g_nzero; ++i)
+        if (g_zero[i].lo == (const char*)base) { g_zero[i].hi = (const char*)base + bytes; return 0; }
+    SARSSL_REQUIRE(g_nzero < ZERO_ARENA_MAX, "sarssl_zero_arena(table full)");
+    g_zero[g_nzero].lo = (const char*)base; g_zero[g_nzero].hi = (const char*)base + bytes; ++g_nzero;
     return 0;
 }
-bool sarssl_prezeroed(const void* p) { return p && (const char*)p >= g_zero_lo && (const char*)p < g_zero_hi; }
-
-int sarssl_mfma_prio() {
-    static const int v = getenv("SARSSL_MFMA_PRIO") ? atoi(getenv("SARSSL_MFMA_PRIO")) : 2;
-    return v;
+bool sarssl_prezeroed(const void* p) {
+    for (int i = 0; i < g_nzero; ++i)
+        if ((const char*)p >= g_zero[i].lo && (const char*)p < g_zero[i].hi) return true;
+    return false;
 }
+
+// waves raise their issue priority (s_setprio) during MFMA phases: 2 = the ping-pong convolution only (measured in round 2: -2.4 ... -3.5 %
+// on those launches alone; no effect on the GEMM kernels)
+int sarssl_mfma_prio() { return 2; }

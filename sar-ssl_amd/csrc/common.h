@@ -24,8 +24,7 @@ struct SarsslStepState {
     float step_size;             // lr / (1 - beta1^step)
     float inv_bc2_sqrt;          // 1 / sqrt(1 - beta2^step)
 };
-int sarssl_mfma_prio();         // SARSSL_MFMA_PRIO: waves raise their issue priority (s_setprio) during MFMA phases - 0 nowhere, 1 convolution
-                                // and GEMM, 2 (default) ping-pong convolution only (-2.4 ... -3.5 % alone; GEMM: no effect), 3 GEMM only
+int sarssl_mfma_prio();         // where waves raise their issue priority (s_setprio) during MFMA phases: 2 = the ping-pong convolution only
 bool sarssl_prezeroed(const void* p);               // pointer inside the host-zeroed arena (api.hip): its memset can be skipped
 // zero `bytes` at p on `st` unless p is a slice of the pre-zeroed arena
 #define SARSSL_ZERO(p, bytes, st) (sarssl_prezeroed(p) ? hipSuccess : hipMemsetAsync((p), 0, (bytes), (st)))

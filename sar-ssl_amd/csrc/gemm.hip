@@ -423,16 +423,14 @@ static void launch_fm(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStrea
 // Tile choice: 256 x 128 tiles (FM = 4) halve the staged bytes and barriers per MFMA but also the number of workgroups; they are
 // used when the grid still has at least ~one workgroup per CU, otherwise 128 x 128 (FM = 2).  big = allowed for this dtype combo.
 static int pick_fm(const GemmArgs& g, int nbatch, bool big) {
-    static const int force = getenv("SARSSL_GEMM_FM") ? atoi(getenv("SARSSL_GEMM_FM")) : 0;        // A/B experiments only (-1: never FM = 1)
     if (!big) return 2;
-    if (force == 1 || force == 2 || force == 4) return force;
     const long nsplit = g.split_k > 0 ? g.split_k : 1;
     const long wg4 = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN) * nbatch * nsplit;
     // 64 x 128 tiles (FM = 1) when 128 x 128 tiles give at most ~one workgroup per CU (N <= 256 at M = 16384): nothing else on the
     // CU hides a K-tile's memory round trip then (0.7-0.8 us per K-tile measured against 0.25 us of MFMA)
     const long wg2 = (long)((g.M + 127) / 128) * ((g.N + BN - 1) / BN) * nbatch * nsplit;
-    static const int fm1_pct = getenv("SARSSL_GEMM_FM1_PCT") ? atoi(getenv("SARSSL_GEMM_FM1_PCT")) : 112;      // A/B experiments only
-    if (force != -1 && g.split_k <= 0 && g.M >= 128 && wg2 * 100 <= (long)sarssl_cu_count() * fm1_pct) return 1;
+    constexpr int fm1_pct = 112;
+    if (g.split_k <= 0 && g.M >= 128 && wg2 * 100 <= (long)sarssl_cu_count() * fm1_pct) return 1;
     const int k_len = g.split_k > 0 ? g.k_per_split : g.K;
     // measured on MI355X (tools/bench_kernels.py, tools/gemm_diag.py, M = 16384): the large tile wins from ~2 workgroups per CU and
     // K >= 768 on (decoder 3072 x 768 / 1024 x 3072: -4 ... -15 %); with one workgroup per CU (N = 512) or short K it loses 5-20 %

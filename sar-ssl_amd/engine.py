@@ -242,7 +242,7 @@ def knobs():
             "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
             "SARSSL_CONV_CUS_BWD": os.environ.get("SARSSL_CONV_CUS_BWD", os.environ.get("SARSSL_CONV_CUS", "default(224)")),
-            "SARSSL_GRAPH": os.environ.get("SARSSL_GRAPH", "default"), "SARSSL_MFMA_PRIO": os.environ.get("SARSSL_MFMA_PRIO", "default(2)"),
+            "SARSSL_GRAPH": os.environ.get("SARSSL_GRAPH", "default"),
             "precision": runtime.get_precision()}
 
 
