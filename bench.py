@@ -101,7 +101,7 @@ def cpu_baseline(B=8):
     return out
 
 
-def product_loop(dev, batch, precision, nseg=512, epochs=3):
+def product_loop(dev, batch, precision, nseg=2048, epochs=2):
     """The step as run_pretrain.py drives it: `nseg` PCM-16 WAV segments on /dev/shm -> dataset.PcmSegmentLoader (native reader thread,
     pinned int16 batches uploaded on a copy stream) -> STFTLearner.pretrain_epoch (captured step, STFT front-end inside the replay, Adam
     re-created per epoch).  One untimed epoch (graph capture), then `epochs` timed epochs incl. their end-of-epoch synchronisation."""
@@ -404,7 +404,7 @@ def main():
             net._stage_hook = None
             del net, flat, reducer, pcm
             torch.cuda.empty_cache()
-            loop = product_loop(dev, batch, args.precision, nseg=max(512, 8 * batch), epochs=3 if not args.via_learner else max(3, args.steps // 8))
+            loop = product_loop(dev, batch, args.precision, nseg=32 * batch, epochs=2 if not args.via_learner else max(2, args.steps // 32))
             out["product_loop"] = loop
             if args.via_learner:
                 out["resident_batch_replay"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "steps": out["steps"]}
