@@ -1,0 +1,63 @@
+"""Isolated timings of the fused relative-position attention kernels (csrc/attention.hip) at the shapes of the timed step:
+B = 64 segments, H = 4, T = 256, d_head = 128 (spectral encoder, 1 layer) and 64 (spatial encoder, 3 layers).
+Forward and backward are timed as whole C-ABI calls (backward = dsum + bwd_q + bwd_kv launches); per-kernel splits come from
+`rocprofv3 --kernel-trace --stats -- python3 tools/bench_attn.py`.
+
+    python tools/bench_attn.py [--iters 50] [--drop 0.1]
+"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sar_ssl_amd import hip  # noqa: E402
+
+
+def run(B, H, T, dh, p_drop, iters):
+    dev = torch.device("cuda:0")
+    d = H * dh
+    g = torch.Generator(device=dev).manual_seed(3)
+    qkv = (torch.randn((B * T, 3 * d), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    qu, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    bias = (torch.randn((B, H, T, T), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    dctx = (torch.randn((B * T, d), device=dev, generator=g) * 0.1).to(torch.bfloat16)
+    dqkv = torch.empty_like(qkv)
+    scale = 1.0 / math.sqrt(d)
+    ctx, aux = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, 11)
+
+    def fwd():
+        hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, 11)
+
+    def bwd():
+        hip.relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, scale, p_drop, 11)
+
+    out = {}
+    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) / iters * 1e3
+    fl_f = 2 * 2 * T * T * dh * B * H          # S and PV
+    fl_b = 5 * 2 * T * T * dh * B * H * 1.0 + 2 * 2 * T * T * dh * B * H   # dQ, dK, dV, + recomputed S and dP twice
+    print(f"B={B} H={H} T={T} dh={dh} drop={p_drop}:  fwd {out['fwd']:8.1f} us ({fl_f / out['fwd'] / 1e6:6.1f} TFLOP/s)   "
+          f"bwd {out['bwd']:8.1f} us ({fl_b / out['bwd'] / 1e6:6.1f} TFLOP/s)", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--drop", type=float, default=0.1)
+    ap.add_argument("--batch", type=int, default=64)
+    a = ap.parse_args()
+    for dh in (128, 64):
+        run(a.batch, 4, 256, dh, a.drop, a.iters)
+        run(a.batch, 4, 256, dh, 0.0, a.iters)
