@@ -369,9 +369,9 @@ __global__ void stem_c1_bwd_finalize_kernel(const double* __restrict__ red, long
 // ------------------------------------------------------------------------------------------------
 // y4[b][t][f][c] = sum_ci W4[c][ci] * relu(y3[b][f][t][ci]*scale[ci] + shift[ci])
 // 8 lanes per pixel (one 16-byte chunk each), shuffle-reduced.
-template <typename T>
+template <typename T, int U>
 __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __restrict__ W4, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4, int nstream,
+                                   const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4,
                                    double* __restrict__ stats = nullptr) {
     const int cg = threadIdx.x & 7;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};      // stats: sum / sum of squares of the STORED y4 (BatchNorm(4) statistics)
@@ -385,18 +385,14 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
     // (measured and rejected in round 2, B = 64: a (bin, frame)-tiled variant writing the (B,T,F,4) output in 128-byte rows through
     //  LDS - 182 us, two barriers per tile cost more than the scattered 8-byte stores of this 33 MB tensor; four loads in flight per
     //  thread - 162 us; this one-chunk-per-iteration loop at 16 waves / CU: 146 us)
+    //  Round 3: the output is (B,T,F,4) - bins contiguous - while y3 is (B,F,T,64): walking the pixels in y3's order made every 8-byte
+    //  store land in a different 2 KB-strided line (4.2 M partial-line writes for a 33 MB tensor), and one 16-byte load in flight per
+    //  thread at ~7 waves / SIMD is ~28 KB per CU - 189 us = 3.0 TB/s for the pass.  Now a workgroup takes an (8 bins x 16 frames) item:
+    //  the 8 pixels of a wave are 8 consecutive BINS of one frame (one 64-byte store per wave), every thread has the U frames
+    //  tl, tl+4, ... of its bin in flight at once (each bin row of the item is U * 512 contiguous bytes), reads stay whole 128-byte
+    //  lines.  B = 64: 189 -> 147 us (U = 4) -> 121 us (U = 8, one resident round of workgroups) = 4.7 TB/s.
     const long npix = (long)nb * F * Tn;
-    const long nthreads = (long)gridDim.x * blockDim.x;
-    // nstream > 1: the 256-thread chunks are dealt round-robin to nstream equal address ranges, so the chip reads nstream moving
-    // windows instead of one (a single sequential read stream tops out near 3.8 TB/s on this part, two reach 5+)
-    const long nq = npix * 8 / 256;
-    const bool split = nstream > 1 && (npix * 8) % 256 == 0 && nq % nstream == 0;
-    const long qper = split ? nq / nstream : 0;
-    for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads) {
-        long g = g0;
-        if (split) { const long q = g0 >> 8; g = ((q % nstream) * qper + q / nstream) * 256 + (g0 & 255); }
-        const long p = g >> 3;
-        const f8 v = ld8(y3 + p * 64 + cg * 8);
+    auto pixel = [&](const f8& v, int b, int f, int t) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -409,9 +405,6 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
             o[c] += __shfl_xor(o[c], 1, 64); o[c] += __shfl_xor(o[c], 2, 64); o[c] += __shfl_xor(o[c], 4, 64);
         }
         if (cg == 0) {
-            const int t = (int)(p % Tn);
-            const long bf = p / Tn;
-            const int f = (int)(bf % F), b = (int)(bf / F);
             st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
             if (stats) {
 #pragma unroll
@@ -420,6 +413,29 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
                     ssum[c] += r; ssq[c] = fmaf(r, r, ssq[c]);
                 }
             }
+        }
+    };
+    if constexpr (U > 0) {                              // host: F % 8 == 0 and Tn % (4 U) == 0
+        const int fblocks = F >> 3, tblocks = Tn / (4 * U);
+        const int nitem = nb * fblocks * tblocks;
+        const int fi = (threadIdx.x >> 3) & 7, tl = threadIdx.x >> 6;
+        for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
+            const int tb = item % tblocks, r = item / tblocks;
+            const int f = (r % fblocks) * 8 + fi, b = r / fblocks, t0 = tb * (4 * U) + tl;
+            const T* src = y3 + (((long)b * F + f) * Tn + t0) * 64 + cg * 8;
+            Raw8<T> v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = raw8_load(src + (long)u * 4 * 64);
+#pragma unroll
+            for (int u = 0; u < U; ++u) pixel(raw8_unpack(v[u]), b, f, t0 + 4 * u);
+        }
+    } else {
+        const long nthreads = (long)gridDim.x * blockDim.x;
+        for (long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x; g0 < npix * 8; g0 += nthreads) {
+            const long p = g0 >> 3;
+            const int t = (int)(p % Tn);
+            const long bf = p / Tn;
+            pixel(ld8(y3 + p * 64 + cg * 8), (int)(bf / F), (int)(bf % F), t);
         }
     }
     if (stats) {                    // lanes 0, 8, 16, ... hold the pixels: fold over lane bits 3..5, then the 4 waves through LDS, 8 atomics per workgroup
@@ -957,7 +973,11 @@ __global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __rest
 
 // ================================================================================================ C ABI
 // grid caps of the stem passes: tuning knobs (A/B runs), e.g. SARSSL_GRID_C1F=2048
+#ifdef SARSSL_PROBE_ENV      // tools/bench_stem.py probe build: caps / read-stream counts from the environment
+static inline int grid_cap(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
 static inline int grid_cap(const char*, int dflt) { return dflt; }      // (workgroup caps measured in round 2: fixed; the name documents which pass)
+#endif
 static inline int nblocks_for(long work, int per_block, int cap = 2048) {
     long b = (work + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -1170,14 +1190,27 @@ extern "C" int sarssl_stem_c1_stats_affine(const void* a0, long npix, const floa
     return 0;
 }
 
-extern "C" int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F,
-                                  int Tn, void* y4, int dtype, void* stream) {
-    static const int cap = grid_cap("SARSSL_GRID_C4F", 8192);
-    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
-    static const int nstream = grid_cap("SARSSL_C4F_STREAMS", 1);
-    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, nstream)));
+// (8 bins x 4U frames) items, U loads in flight per thread; 2048 workgroups = one resident round at B = 64 (sweep 1024 / 2048 / 4096 /
+// 8192 with U = 8: 125 / 121 / 126 / 141 us); frame counts that are no multiple of 16 (or bin counts of 8) take the pixel-order loop
+static int stem_c4_fwd_launch(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
+                              double* stats8, int dtype, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && Tn > 0 && (long)nb * F * Tn < (1L << 31), "sarssl_stem_c4_fwd");
+    static const int cap = grid_cap("SARSSL_GRID_C4F", 2048);
+    const int u = (F % 8 == 0) ? (Tn % 32 == 0 ? 8 : (Tn % 16 == 0 ? 4 : 0)) : 0;
+    if (u == 0) {
+        const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 8192);
+        DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 0><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8)));
+    } else {
+        const int nblk = nblocks_for((long)nb * (F / 8) * (Tn / (4 * u)), 1, cap);
+        if (u == 8) { DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 8><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8))); }
+        else { DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 4><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8))); }
+    }
     SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel");
     return 0;
+}
+extern "C" int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F,
+                                  int Tn, void* y4, int dtype, void* stream) {
+    return stem_c4_fwd_launch(y3, W4, scale, shift, nb, F, Tn, y4, nullptr, dtype, stream);
 }
 // The same, also returning the BatchNorm(4) sums of the stored output: stats8 f64[8] = [sum (4) | sum of squares (4)] (zeroed here) - the
 // separate statistics pass over y4 is not needed.
@@ -1185,12 +1218,7 @@ extern "C" int sarssl_stem_c4_fwd_stats(const void* y3, const float* W4, const f
                                         void* y4, double* stats8, int dtype, void* stream) {
     SARSSL_REQUIRE(stats8 != nullptr, "sarssl_stem_c4_fwd_stats");
     if (SARSSL_ZERO(stats8, 8 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    static const int cap = grid_cap("SARSSL_GRID_C4F", 8192);
-    const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
-    static const int nstream = grid_cap("SARSSL_C4F_STREAMS", 1);
-    DISPATCH_T(dtype, (stem_c4_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, nstream, stats8)));
-    SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel<stats>");
-    return 0;
+    return stem_c4_fwd_launch(y3, W4, scale, shift, nb, F, Tn, y4, stats8, dtype, stream);
 }
 
 // red: f64[384] (zeroed here): [0,256) dW4[c][ci], [256,320) s1, [320,384) s2

@@ -1031,17 +1031,25 @@ def test_first_conv_data_gradient_consumed_in_its_epilogue(shape, train):
     assert _relerr(dbe, s1) < 2e-4 and _relerr(dga, s2) < 2e-4
 
 
+# frame counts: 40 -> pixel-order loop, 48 -> (8 bins x 16 frames) items, 64 / 96 -> (8 x 32) items (several items per workgroup row);
+# 20 bins -> pixel-order loop whatever the frame count
+@pytest.mark.parametrize("shape", [(3, 24, 40), (2, 24, 48), (3, 16, 64), (2, 40, 96), (2, 20, 64)])
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
-def test_stem_c4_forward_statistics_epilogue(dtp):
-    """stem_c4_fwd(want_stats) == stem_c4_fwd followed by the statistics pass over its stored output."""
+def test_stem_c4_forward_statistics_epilogue(dtp, shape):
+    """stem_c4_fwd against an f64 restatement (code/model.py:60-62: BatchNorm + ReLU, then Conv2d(64, 4, 1), stored (B,T,F,4)) for every
+    loop variant of the kernel, and stem_c4_fwd(want_stats) == stem_c4_fwd followed by the statistics pass over its stored output."""
     from sar_ssl_amd import hip
     dev = _dev()
     g = torch.Generator().manual_seed(81)
-    y3 = torch.randn((3, 24, 40, 64), generator=g).to(dtp).to(dev)
+    B, F, T = shape
+    y3 = torch.randn((B, F, T, 64), generator=g).to(dtp).to(dev)
     W4 = (torch.randn((4, 64), generator=g) * 0.2).to(dev)
     sc = (torch.rand(64, generator=g) + 0.5).to(dev); sh = (torch.randn(64, generator=g) * 0.3).to(dev)
     hip.sums_arena_reset(dev)
     ref = hip.stem_c4_fwd(y3, W4, sc, sh)
+    want = (torch.relu(y3.double() * sc.double() + sh.double()) @ W4.double().t()).permute(0, 2, 1, 3)     # (B,T,F,4)
+    assert ref.shape == (B, T, F, 4)
+    assert _relerr(ref.double(), want) < (1e-5 if dtp == torch.float32 else 6e-3)
     sums_ref, _ = hip.cl_stats(ref, 4)
     y4, sums = hip.stem_c4_fwd(y3, W4, sc, sh, want_stats=True)
     assert torch.equal(y4, ref)
