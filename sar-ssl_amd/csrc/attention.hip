@@ -77,6 +77,32 @@ __device__ __forceinline__ float half_swap_f(float v) { return __shfl_xor(v, 32,
 __device__ __forceinline__ float attn_keep(const AttnArgs& a, unsigned long long rowbase, int j, float inv_keep) {
     return dropout_scale(salted_seed(a.seed, a.salt), rowbase + (unsigned long long)j, a.p_drop, inv_keep);
 }
+// The same decisions (dropout_scale's hash, common.h) for the way these kernels walk the score matrix.  dropout_scale pays two hashes
+// per element - the key of the index's high word and the pair hash - although one pair hash decides two neighbouring elements and
+// the key only changes every 2^33 elements: with dropout on, the three attention kernels spent 170 us per step on it (tools/bench_attn.py).
+struct AttnDrop {
+    uint64_t seed; uint32_t thr, hi0, key0; float inv_keep;
+    __device__ __forceinline__ void init(const AttnArgs& a, uint64_t idx0, float ik) {
+        seed = salted_seed(a.seed, a.salt); thr = dropout_thr16(a.p_drop); inv_keep = ik;
+        hi0 = (uint32_t)(idx0 >> 33); key0 = dropout_key(seed, hi0);
+    }
+    __device__ __forceinline__ uint32_t key(uint64_t idx) const {
+        const uint32_t hi = (uint32_t)(idx >> 33);
+        return hi == hi0 ? key0 : dropout_key(seed, hi);
+    }
+    // 4 consecutive elements from idx (a multiple of 4): two pair hashes
+    __device__ __forceinline__ void keep4(uint64_t idx, float (&k)[4]) const {
+        const uint32_t ky = key(idx), pair = (uint32_t)(idx >> 1);
+        const uint32_t h0 = hash_u32(pair ^ ky), h1 = hash_u32((pair + 1u) ^ ky);
+        k[0] = (h0 & 0xffffu) >= thr ? inv_keep : 0.f; k[1] = (h0 >> 16) >= thr ? inv_keep : 0.f;
+        k[2] = (h1 & 0xffffu) >= thr ? inv_keep : 0.f; k[3] = (h1 >> 16) >= thr ? inv_keep : 0.f;
+    }
+    // one element: one hash
+    __device__ __forceinline__ float keep1(uint64_t idx) const {
+        const uint32_t h = hash_u32((uint32_t)(idx >> 1) ^ key(idx));
+        return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= thr ? inv_keep : 0.f;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------------------------- forward
 // (d_head <= 64: capped at 256 registers - 243 used, no spills - so that TWO workgroups share a CU: the kernel is a chain of
@@ -116,6 +142,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const float sc2 = a.scale * LOG2E;
     const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned long long)(row_ok ? i : 0)) * (unsigned long long)T;
+    AttnDrop drop;
+    drop.init(a, rowbase, inv_keep);
 
     // K, V (64 keys x DH) and the bias tile (128 rows x 64 keys) go through registers: the next tile's loads are in flight while
     // this one is on the matrix cores
@@ -207,9 +235,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = j0 + f * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                    s[f][r] *= attn_keep(a, rowbase, j, inv_keep);
+                for (int g = 0; g < 4; ++g) {
+                    float kp[4];
+                    drop.keep4(rowbase + (unsigned long long)(j0 + f * 32 + 8 * g + 4 * half), kp);     // (T % 8 == 0: rowbase is a multiple of 8)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[f][4 * g + e] *= kp[e];
                 }
         }
         // ---- O^T += V^T P^T: lane = query row, registers = head channels
@@ -306,6 +336,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const float sc2 = a.scale * LOG2E;
     const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const unsigned long long rowbase = ((unsigned long long)bh * T + (unsigned long long)(row_ok ? i : 0)) * (unsigned long long)T;
+    AttnDrop drop;
+    drop.init(a, rowbase, inv_keep);
 
     constexpr int NKV = TK * CPR / 256, NBI = TQ * (TK / 8) / 256;
     uint4 rk[NKV], rv[NKV], rbi[NBI];
@@ -367,12 +399,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                 const float bv[4] = {bf16_bits_to_f32(bu.x & 0xffffu), __uint_as_float(bu.x & 0xffff0000u),
                                      bf16_bits_to_f32(bu.y & 0xffffu), __uint_as_float(bu.y & 0xffff0000u)};
                 float ds[4];
+                float kp[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (a.p_drop > 0.f) drop.keep4(rowbase + (unsigned long long)(j0 + jl), kp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int j = j0 + jl + e;
                     const float x = (s[f][4 * g + e] + (j == i + 1 ? 0.f : bv[e])) * sc2;
                     const float p = j < T ? exp2f(x - lse) : 0.f;
-                    const float keep = a.p_drop > 0.f ? attn_keep(a, rowbase, j, inv_keep) : 1.0f;
+                    const float keep = kp[e];
                     ds[e] = a.scale * p * (keep * dp[f][4 * g + e] - dsum);
                     s[f][4 * g + e] = ds[e];
                 }
@@ -457,6 +491,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { dk[c][r] = 0.f; dv[c][r] = 0.f; }
     const float sc2 = a.scale * LOG2E;
     const float inv_keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    AttnDrop drop;
+    drop.init(a, (unsigned long long)bh * T * (unsigned long long)T, inv_keep);
 
     constexpr int NQD = TQ * CPR / 256, NBI = TQ * (TKB / 8) / 256;
     uint4 rq[NQD], rd[NQD], rbi[NBI];
@@ -528,8 +564,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
                 const float p = (i < T && key_ok) ? exp2f(x - sStat[il]) : 0.f;
                 float keep = 1.0f;
                 if (a.p_drop > 0.f)
-                    keep = dropout_scale(salted_seed(a.seed, a.salt), ((unsigned long long)bh * T + (unsigned long long)(i < T ? i : 0)) * (unsigned long long)T + (unsigned long long)(key_ok ? j : 0),
-                                         a.p_drop, inv_keep);
+                    keep = drop.keep1(((unsigned long long)bh * T + (unsigned long long)(i < T ? i : 0)) * (unsigned long long)T + (unsigned long long)(key_ok ? j : 0));
                 s[f][r] = a.scale * p * (keep * dp[f][r] - sStat[TQ + il]);       // dScore^T
                 dp[f][r] = p * keep;                                               // dropped probability
             }
