@@ -34,6 +34,9 @@ struct AttnArgs {
 };
 
 #define LOG2E 1.4426950408889634f
+// v_exp_f32 as is: exp2f() wraps it in a denormal-range rescue (compare, two selects, add, ldexp: 7 instructions per probability);
+// a probability below 2^-126 is zero for every purpose here
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int PT>
 __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int kbase, int r0, int lane) {      // as gemm.hip: [k][row] tile
@@ -215,14 +218,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
             }
         mx = fmaxf(mx, half_swap_f(mx));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = exp2_raw(m_run - m_new);
         m_run = m_new;
         float rs = 0.f;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[f][r] - m_new);
+                const float p = exp2_raw(s[f][r] - m_new);
                 rs += p;
                 s[f][r] = p;
             }
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                 for (int e = 0; e < 4; ++e) {
                     const int j = j0 + jl + e;
                     const float x = (s[f][4 * g + e] + (j == i + 1 ? 0.f : bv[e])) * sc2;
-                    const float p = j < T ? exp2f(x - lse) : 0.f;
+                    const float p = j < T ? exp2_raw(x - lse) : 0.f;
                     const float keep = kp[e];
                     ds[e] = a.scale * p * (keep * dp[f][4 * g + e] - dsum);
                     s[f][4 * g + e] = ds[e];
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
                 const int i = i0 + il;
                 const float bv = bf16_bits_to_f32(sB[il * PB + wave * 32 + (lane & 31)]);
                 const float x = (s[f][r] + (j == i + 1 ? 0.f : bv)) * sc2;
-                const float p = (i < T && key_ok) ? exp2f(x - sStat[il]) : 0.f;
+                const float p = (i < T && key_ok) ? exp2_raw(x - sStat[il]) : 0.f;
                 float keep = 1.0f;
                 if (a.p_drop > 0.f)
                     keep = drop.keep1(((unsigned long long)bh * T + (unsigned long long)(i < T ? i : 0)) * (unsigned long long)T + (unsigned long long)(key_ok ? j : 0));

@@ -125,7 +125,9 @@ __device__ __forceinline__ uint4 pack8_part(const f8& r, int part) {
     return u;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each).  `1.0f / (...)` is an IEEE division here (no fast-math: two v_div_scale, v_rcp, four FMAs,
+// v_div_fmas, v_div_fixup): the Swish / Swish' / GLU epilogues evaluate ~400 M sigmoids per step, 8 400 division sequences in gemm.o
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // counter-based dropout RNG: keep-decision for element `idx` of stream `seed`
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
@@ -144,6 +146,13 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
     const uint32_t h = hash_u32((uint32_t)(idx >> 1) ^ dropout_key(seed, (uint32_t)(idx >> 33)));
     const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
     return bits >= dropout_thr16(p_drop) ? inv_keep : 0.0f;
+}
+// keep-scales of the 4 consecutive elements from idx (a multiple of 4): one key + two pair hashes (dropout_scale: two hashes per element)
+__device__ __forceinline__ void dropout_scale4(uint64_t seed, uint64_t idx, float p_drop, float inv_keep, float (&k)[4]) {
+    const uint32_t thr = dropout_thr16(p_drop), key = dropout_key(seed, (uint32_t)(idx >> 33)), pair = (uint32_t)(idx >> 1);
+    const uint32_t h0 = hash_u32(pair ^ key), h1 = hash_u32((pair + 1u) ^ key);
+    k[0] = (h0 & 0xffffu) >= thr ? inv_keep : 0.0f; k[1] = (h0 >> 16) >= thr ? inv_keep : 0.0f;
+    k[2] = (h1 & 0xffffu) >= thr ? inv_keep : 0.0f; k[3] = (h1 >> 16) >= thr ? inv_keep : 0.0f;
 }
 // v[e] *= keep(seed, base + e) * inv_keep for e = 0..7; base must be even
 __device__ __forceinline__ void dropout_apply8(float (&v)[8], uint64_t seed, uint64_t base, float p_drop, float inv_keep) {

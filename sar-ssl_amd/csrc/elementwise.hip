@@ -139,9 +139,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     if (dx2) {
                         const unsigned long long idx = (unsigned long long)row * d + c4 * 4;
                         float4 q = o;
-                        if (p_drop > 0.f) {
-                            q.x *= dropout_scale(seed, idx, p_drop, inv_keep); q.y *= dropout_scale(seed, idx + 1, p_drop, inv_keep);
-                            q.z *= dropout_scale(seed, idx + 2, p_drop, inv_keep); q.w *= dropout_scale(seed, idx + 3, p_drop, inv_keep);
+                        if (p_drop > 0.f) {             // (d % 4 == 0: idx is a multiple of 4)
+                            float kp[4];
+                            dropout_scale4(seed, idx, p_drop, inv_keep, kp);
+                            q.x *= kp[0]; q.y *= kp[1]; q.z *= kp[2]; q.w *= kp[3];
                         }
                         q.x *= gscale; q.y *= gscale; q.z *= gscale; q.w *= gscale;
                         st4(dx2 + row * d + c4 * 4, q);
@@ -573,10 +574,11 @@ __global__ void act_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ h
         const float4 d = ld4(dz + i * 4);
         float dv[4] = {d.x, d.y, d.z, d.w}, hv[4] = {0, 0, 0, 0};
         if (act) { const float4 hh = ld4(h + i * 4); hv[0] = hh.x; hv[1] = hh.y; hv[2] = hh.z; hv[3] = hh.w; }
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p_drop > 0.f) dropout_scale4(seed, (unsigned long long)(i * 4), p_drop, inv_keep, kp);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float g = dv[e] * gscale;
-            if (p_drop > 0.f) g *= dropout_scale(seed, (unsigned long long)(i * 4 + e), p_drop, inv_keep);
+            float g = dv[e] * gscale * kp[e];
             if (act == 1) g = hv[e] > 0.f ? g : 0.f;
             else if (act == 2) { const float s = sigmoidf_(hv[e]); g *= s * (1.f + hv[e] * (1.f - s)); }
             dv[e] = g;
