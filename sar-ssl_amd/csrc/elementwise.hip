@@ -449,7 +449,9 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
         }
     }
 }
-// dpos[r][m] gathered from dscore through the inverse of the relative shift
+// dpos[r][m] gathered from dscore through the inverse of the relative shift.  In the flat (T x T) layout the shift is a per-row offset:
+// dpos_flat[r T + m] = dscore_flat[r T + m - (T - 1 - r)] (both branches of attention.py:105-113's inverse), zero where that falls before
+// the matrix (row 0, m < T - 1).
 template <typename T>
 __global__ void relshift_bwd_kernel(const T* __restrict__ dscore, long nmat, int Tn, T* __restrict__ dpos) {
     const long total = nmat * Tn * Tn;
@@ -462,6 +464,28 @@ __global__ void relshift_bwd_kernel(const T* __restrict__ dscore, long nmat, int
         if (m >= Tn - 1 - r) v = ld_f(dscore + (mat * Tn + r) * Tn + (m - Tn + 1 + r));
         else if (r >= 1 && m <= Tn - 2 - r) v = ld_f(dscore + (mat * Tn + r - 1) * Tn + (m + r + 1));
         st_f(dpos + idx, v);
+    }
+}
+// bf16, T % 8 == 0: a thread owns 8 consecutive outputs of one row (one 16-byte store; the 8 source elements are 2-byte loads at the
+// row's offset - neighbouring lanes share their cache lines).  The element-per-thread kernel above spent its time on three 64-bit
+// divisions per element: 33 us per layer at (B, H, T) = (64, 4, 256).
+__global__ __launch_bounds__(256) void relshift_bwd8_kernel(const uint16_t* __restrict__ dscore, long nrows, int Tn, uint16_t* __restrict__ dpos) {
+    const unsigned cpr = (unsigned)Tn >> 3;
+    const long nchunk = nrows * cpr;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nchunk; q += (long)gridDim.x * blockDim.x) {
+        const long row = q / cpr;                              // mat * T + r
+        const int c8 = (int)(q - row * cpr) << 3;
+        const int r = (int)(row % Tn);
+        const long mat0 = (row - r) * Tn;                      // first element of this matrix
+        const long src = row * Tn + c8 - (Tn - 1 - r);         // flat source index of output element c8
+        const uint16_t* sp = dscore + src;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = (src + 2 * e >= mat0) ? sp[2 * e] : 0u, hi = (src + 2 * e + 1 >= mat0) ? sp[2 * e + 1] : 0u;
+            w[e] = lo | (hi << 16);
+        }
+        *(uint4*)(dpos + row * Tn + c8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -850,6 +874,12 @@ extern "C" int sarssl_softmax_bwd(const float* dpd, const void* p, long nmat, in
     return 0;
 }
 extern "C" int sarssl_relshift_bwd(const void* dscore, long nmat, int Tn, void* dpos, int dtype, void* stream) {
+    if (dtype == SARSSL_BF16 && (Tn & 7) == 0) {
+        const long nrows = nmat * Tn;
+        relshift_bwd8_kernel<<<nblocks_for(nrows * (Tn >> 3), 256, 8192), 256, 0, ST>>>((const uint16_t*)dscore, nrows, Tn, (uint16_t*)dpos);
+        SARSSL_CHECK_LAUNCH("relshift_bwd8_kernel");
+        return 0;
+    }
     DISPATCH_T(dtype, (relshift_bwd_kernel<T><<<nblocks_for(nmat * Tn * Tn, 256, 8192), 256, 0, ST>>>((const T*)dscore, nmat, Tn, (T*)dpos)));
     SARSSL_CHECK_LAUNCH("relshift_bwd_kernel");
     return 0;

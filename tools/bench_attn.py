@@ -61,3 +61,15 @@ if __name__ == "__main__":
     for dh in (128, 64):
         run(a.batch, 4, 256, dh, a.drop, a.iters)
         run(a.batch, 4, 256, dh, 0.0, a.iters)
+    # the unshift of d(bias) that follows every backward (elementwise.hip: relshift_bwd)
+    db = torch.randn((a.batch, 4, 256, 256), device="cuda").to(torch.bfloat16)
+    for _ in range(3):
+        hip.relshift_bwd(db)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        hip.relshift_bwd(db)
+    e1.record()
+    torch.cuda.synchronize()
+    print("relshift_bwd (B,4,256,256) bf16: %.1f us" % (e0.elapsed_time(e1) / a.iters * 1e3))
