@@ -269,7 +269,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     float* W = g.acc_ws ? g.acc_ws + (long)z * g.M * g.N : nullptr;
     float* Wp = (g.split_k > 0) ? g.acc_ws + ((long)z * nsplit + ks) * g.M * g.N : nullptr;
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
-    const float inv_keep = g.p_drop > 0.f ? 1.0f / (1.0f - g.p_drop) : 1.0f;
+    DropCtx dc;
+    dc.init(g);
     float* sC = (float*)smem;
     // residual (forward GEMMs) or saved pre-activation (activation-backward GEMMs) rows of a slice are requested one slice ahead, so
     // their latency hides behind the LDS transposition and the arithmetic of the previous slice instead of stalling every tile
@@ -308,7 +309,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             const float4 a0 = *(const float4*)&sC[r * PC + ch * 8], a1 = *(const float4*)&sC[r * PC + ch * 8 + 4];
             v.v[0] = g.alpha * a0.x; v.v[1] = g.alpha * a0.y; v.v[2] = g.alpha * a0.z; v.v[3] = g.alpha * a0.w;
             v.v[4] = g.alpha * a1.x; v.v[5] = g.alpha * a1.y; v.v[6] = g.alpha * a1.z; v.v[7] = g.alpha * a1.w;
-            epilogue8<TC, EDGE>(g, v, z, m, n, C, Rz, P, Xa, W, Wp, bias8, vec_ok, inv_keep, has_ex, cur[k]);
+            epilogue8<TC, EDGE>(g, v, z, m, n, C, Rz, P, Xa, W, Wp, bias8, vec_ok, dc, has_ex, cur[k]);
         }
         if (i + 1 < FM) __syncthreads();
     };

@@ -32,11 +32,23 @@ struct GemmArgs {
 // fast path of sarssl_gemm for bf16 NT products without ragged edges (gemm_nt.hip): 0 = launched, 1 = not this kernel's shape
 int sarssl_gemm_nt_try(const GemmArgs& g, int dtC, void* stream);
 
+// per-thread dropout state of an epilogue: the salted seed, the hash key of index word 0 (dropout_key recomputed it - one of five hashes -
+// for every 8-wide piece although it only changes every 2^33 elements), threshold and keep scale
+struct DropCtx {
+    unsigned long long seed; uint32_t key0, thr; float inv_keep;
+    __device__ __forceinline__ void init(const GemmArgs& g) {
+        inv_keep = g.p_drop > 0.f ? 1.0f / (1.0f - g.p_drop) : 1.0f;
+        seed = 0; key0 = 0; thr = 0;
+        if (g.p_drop > 0.f) { seed = salted_seed(g.seed, g.salt); key0 = dropout_key(seed, 0u); thr = dropout_thr16(g.p_drop); }
+    }
+};
+
 // ---- fused epilogue on one 8-wide piece of one output row (v = alpha * accumulator) -------------------------------------------------
 template <typename TC, bool EDGE>
 __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m, int n, TC* __restrict__ C, const TC* __restrict__ Rz,
                                           TC* __restrict__ P, const TC* __restrict__ Xa, float* __restrict__ W, float* __restrict__ Wp,
-                                          const float (&bias8)[8], bool vec_ok, float inv_keep, const bool has_pre, const f8& pre) {
+                                          const float (&bias8)[8], bool vec_ok, const DropCtx& dc, const bool has_pre, const f8& pre) {
+    const float inv_keep = dc.inv_keep;
     const int nvalid = EDGE ? min(8, g.N - n) : 8;
     const bool vec = EDGE ? (vec_ok && nvalid == 8) : true;
     if (g.split_k > 0) {                                 // raw partial for the split-K second stage
@@ -95,8 +107,16 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m,
     }
     if (g.p_drop > 0.f) {
         const unsigned long long base = ((unsigned long long)z * g.M + m) * (unsigned long long)g.N + n;
-        const unsigned long long seed = salted_seed(g.seed, g.salt);
-        if ((base & 1ull) == 0 && (((base + 7) >> 33) == (base >> 33))) dropout_apply8(v.v, seed, base, g.p_drop, inv_keep);
+        const unsigned long long seed = dc.seed;
+        if ((base & 1ull) == 0 && ((base + 7) >> 33) == 0) {          // the usual case: four pair hashes with the hoisted key
+            const uint32_t pair = (uint32_t)(base >> 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t h = hash_u32((pair + q) ^ dc.key0);
+                v.v[2 * q] *= (h & 0xffffu) >= dc.thr ? inv_keep : 0.0f;
+                v.v[2 * q + 1] *= (h >> 16) >= dc.thr ? inv_keep : 0.0f;
+            }
+        } else if ((base & 1ull) == 0 && (((base + 7) >> 33) == (base >> 33))) dropout_apply8(v.v, seed, base, g.p_drop, inv_keep);
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] *= dropout_scale(seed, base + e, g.p_drop, inv_keep);

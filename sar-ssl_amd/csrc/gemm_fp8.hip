@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     TC* P = (TC*)g.preact;
     const TC* Xa = (const TC*)g.aux;
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
-    const float inv_keep = g.p_drop > 0.f ? 1.0f / (1.0f - g.p_drop) : 1.0f;
+    DropCtx dc;
+    dc.init(g);
     float* sC = (float*)smem;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             v.v[0] = alpha_q * a0.x; v.v[1] = alpha_q * a0.y; v.v[2] = alpha_q * a0.z; v.v[3] = alpha_q * a0.w;
             v.v[4] = alpha_q * a1.x; v.v[5] = alpha_q * a1.y; v.v[6] = alpha_q * a1.z; v.v[7] = alpha_q * a1.w;
             // (workspace pointers passed as runtime values: literal nullptrs here crash hipcc 7.2's SimplifyCFG at -O2 and above)
-            epilogue8<TC, EDGE>(g, v, 0, m, n, C, Rz, P, Xa, g.acc_ws, g.acc_ws, bias8, vec_ok, inv_keep, false, v);
+            epilogue8<TC, EDGE>(g, v, 0, m, n, C, Rz, P, Xa, g.acc_ws, g.acc_ws, bias8, vec_ok, dc, false, v);
         }
         if (i == 0) __syncthreads();
     }

@@ -58,7 +58,9 @@ if __name__ == "__main__":
     bias = torch.zeros(4096, device=dev)
     for d in (512, 256):
         gemm_case("ffn1 NT d=%d (+bias,swish,preact)" % d, Mr, 4 * d, d, bias=bias[:4 * d], act=2)
+        gemm_case("ffn1 NT d=%d (... + dropout 0.1)" % d, Mr, 4 * d, d, bias=bias[:4 * d], act=2, p_drop=0.1, seed=7)
         gemm_case("ffn2 NT d=%d" % d, Mr, d, 4 * d, bias=bias[:d])
+        gemm_case("ffn2 NT d=%d (+ dropout 0.1)" % d, Mr, d, 4 * d, bias=bias[:d], p_drop=0.1, seed=7)
         gemm_case("qkv NT d=%d" % d, Mr, d, d, bias=bias[:d])
         gemm_case("ffn1 dX NN d=%d" % d, Mr, d, 4 * d, b_kc=False)
         gemm_case("ffn2 dX NN d=%d" % d, Mr, 4 * d, d, b_kc=False)
