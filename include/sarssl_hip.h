@@ -119,6 +119,9 @@ int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, 
  *      with BN prologue, 1 data gradient, 2 data gradient + BN sums, 3 forward from the 4-channel input, 4 data gradient consumed in its
  *      epilogue): effective shader clock = d(memtime) / d(memrealtime) * sarssl_wall_clock_khz().  null switches it off. */
 int sarssl_conv_clock_probe(void* buf);
+/*      scheduling aid (no reference counterpart): workgroup count of the 3x3 gradient launches (data and weight gradients) that follow on
+ *      this host thread; 0 = the default rule (7/8 of the CUs, leaving room for the other encoder's stream). */
+int sarssl_conv_cus_override(int ncus);
 long sarssl_wall_clock_khz();
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,

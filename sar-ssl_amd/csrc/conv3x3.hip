@@ -1184,11 +1184,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // launch covers every CU the other encoder's stream stands still; a launch that leaves an eighth of the CUs free lets that stream's
 // short latency-bound kernels run next to it (measured on the step).  The grid is then trimmed so that the last
 // round of tiles is as full as the others (a multiple of 8 keeps the XCD-aware tile order).
+// Host-side override of the workgroup count of the following gradient launches (0 = the default rule below): the engine uses it to give
+// the stem backward that runs LAST - alone on the chip, the other encoder's stream has drained - all CUs (sarssl_conv_cus_override).
+static thread_local int g_conv_cus_override = 0;
+extern "C" int sarssl_conv_cus_override(int ncus) { g_conv_cus_override = ncus > 0 ? ncus : 0; return 0; }
 static int conv_cus(int kind) {
     static const int lim[2] = {
         []() { const char* e = getenv("SARSSL_CONV_CUS_FWD"); if (!e) e = getenv("SARSSL_CONV_CUS"); return e ? atoi(e) : 0; }(),
         []() { const char* e = getenv("SARSSL_CONV_CUS_BWD"); if (!e) e = getenv("SARSSL_CONV_CUS"); return e ? atoi(e) : 0; }()};
     const int ncu = sarssl_cu_count();
+    if (kind == 1 && g_conv_cus_override > 0) return g_conv_cus_override < ncu ? g_conv_cus_override : ncu;
     if (lim[kind] > 0) return lim[kind] < ncu ? lim[kind] : ncu;
     // default: forward launches on every CU, gradient launches on 7/8 of them (same-box A/B at B = 64, three rounds: 5 510 - 5 750
     // segments/s with 256 of 256, 5 736 - 5 750 with 224 - the step gains ~2 % although each gradient launch alone is ~12 % slower)

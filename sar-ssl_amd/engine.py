@@ -70,6 +70,7 @@ def mm_nn(dy, W, fp8=True, **kw):
 # forked off a forked stream crashes hipStreamEndCapture on ROCm 7.2 (tools/capture_nested_fork_repro.py).  Removed in round 3.)
 _WGRAD_GROUP = os.environ.get("SARSSL_WGRAD_GROUP", "1") != "0"
 _WGRAD_CSUM = os.environ.get("SARSSL_WGRAD_CSUM", "1") != "0"   # bias gradients from the grouped weight-gradient launch (0: separate column-sum launch)
+_STEM_LAST_ALL_CUS = os.environ.get("SARSSL_STEM_LAST_ALL_CUS", "1") != "0"   # gradient convolutions of the stem that runs last (spat) on every CU (model.py)
 _wg_blocks = []              # stack of pending-product lists (wgrad_block)
 
 
@@ -240,6 +241,7 @@ def knobs():
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
             "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
             "SARSSL_CONV_CUS_BWD": os.environ.get("SARSSL_CONV_CUS_BWD", os.environ.get("SARSSL_CONV_CUS", "default(224)")),
             "SARSSL_GRAPH": os.environ.get("SARSSL_GRAPH", "default"),

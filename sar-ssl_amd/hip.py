@@ -565,6 +565,11 @@ def conv3x3_fwd_c1(a0, W1, scale, shift, w_tap, want_stats=False):
     return (out, stats) if want_stats else out
 
 
+def conv_cus_override(ncus):
+    """Workgroup count of the 3x3 gradient launches that follow (0: the library's default rule)."""
+    _lib.call("sarssl_conv_cus_override", c_int(int(ncus)))
+
+
 def conv3x3_wgrad_c1(dy, a0, W1, scale, shift, acc_into):
     """Weight gradient of that convolution, added into the (64,64,3,3) f32 parameter-gradient buffer; the input operand is formed from a0
     while staging."""

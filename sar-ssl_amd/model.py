@@ -221,9 +221,17 @@ class _PretrainFn(torch.autograd.Function):
         if cut:
             side.wait_stream(main)
         net._after_backward_stage("stem_bwd_begin")            # (not a bucket: a marker for tests / tracing)
+        # CUs of the persistent 3x3 gradient launches: the library's default leaves 1/8 of the chip to the other encoder's stream
+        # (csrc/conv3x3.hip: conv_cus).  That pays for the spec stem, which starts while the spat stream is still in its three
+        # Conformer blocks - and costs 1/8 of the chip for the spat stem, which runs last and alone (same-box A/B, three interleaved
+        # rounds: 10.97 -> 10.84 ms with spec 7/8 + spat all, 11.08 ms the other way round).  One stream: every launch runs alone.
+        all_cus = 1 << 16 if engine._STEM_LAST_ALL_CUS else 0
+        hip.conv_cus_override(all_cus if side is None else 0)
         engine.stem_bwd(dz_spec, spe.patch_embed, saved)
+        hip.conv_cus_override(all_cus)
         with on_side():
             engine.stem_bwd(dz_spat, spa.patch_embed, saved_spat)
+        hip.conv_cus_override(0)
         if side is not None:
             main.wait_stream(side)
         net._after_backward_stage("stems")
