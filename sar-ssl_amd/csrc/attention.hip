@@ -27,7 +27,7 @@ struct AttnArgs {
     bf16* dqu; long lddq;              // backward outputs
     bf16* dk; bf16* dv; long lddk;
     bf16* dbias;                       // (B,H,T,T): gradient of the shifted positional score
-    float* dsum;                       // (B,H,T): sum_c dctx * ctx
+    float* dsum;                       // (B,H,T): D_i = sum_c dctx * ctx, written by the dQ kernel, read by the dK / dV kernel
     int B, H, T;
     float scale, p_drop; unsigned long long seed;
     const unsigned long long* salt;    // device-resident addend of the seed (graph replay), or null
@@ -280,26 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     }
 }
 
-// --------------------------------------------------------------------------------------------- backward, part 0: D_i = dctx_i . ctx_i
-__global__ void relpos_attn_dsum_kernel(AttnArgs a, int dh) {
-    // one wave per (b, i, h) row slice
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);          // over B*T*H
-    const int lane = threadIdx.x & 63;
-    const long nrow = (long)a.B * a.T * a.H;
-    if (row >= nrow) return;
-    const long bt = row / a.H; const int h = (int)(row % a.H);
-    const bf16* x = a.dctx + bt * a.lddc + h * dh;
-    const float* y = a.ctx32 + bt * ((long)a.H * dh) + h * dh;
-    float s = 0.f;
-    for (int c = lane; c < dh; c += 64) s += ld_f(x + c) * y[c];
-    s = wave_sum(s);
-    if (lane == 0) {
-        const long b = bt / a.T, i = bt % a.T;
-        a.dsum[(b * a.H + h) * a.T + i] = s;
-    }
-}
-
-// ---------------------------------------------------------------------------- backward, part 1: dQ and d(bias), per query tile
+// ---------------------------------------------------------------------------- backward, part 1: D, dQ and d(bias), per query tile
 template <int DH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 2 : 1))) void relpos_attn_bwd_q_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
@@ -320,17 +301,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const bf16* Bi = a.bias + (long)bh * T * T;
     bf16* dBi = a.dbias + (long)bh * T * T;
     bf16x8 fq[DH / 16], fdo[DH / 16];
+    float dpart = 0.f;
     {
         const bf16* q = a.qu + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
         const bf16* d = a.dctx + ((long)b * T + (row_ok ? i : 0)) * a.lddc + h * DH + half * 8;
+        // D_i = dctx_i . ctx_i (the unrounded f32 context): this lane holds half of the row's dctx chunks anyway - the stand-alone
+        // pass over dctx / ctx32 (17-19 us per layer) is gone; the row's value is stored for the dK / dV kernel that follows
+        const float* c32 = a.ctx32 + ((long)b * T + (row_ok ? i : 0)) * ((long)a.H * DH) + h * DH + half * 8;
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
             fq[s] = __builtin_bit_cast(bf16x8, row_ok ? *(const uint4*)(q + s * 16) : make_uint4(0, 0, 0, 0));
-            fdo[s] = __builtin_bit_cast(bf16x8, row_ok ? *(const uint4*)(d + s * 16) : make_uint4(0, 0, 0, 0));
+            const uint4 du = row_ok ? *(const uint4*)(d + s * 16) : make_uint4(0, 0, 0, 0);
+            fdo[s] = __builtin_bit_cast(bf16x8, du);
+            const float4 c0 = *(const float4*)(c32 + s * 16), c1 = *(const float4*)(c32 + s * 16 + 4);
+            dpart += bf16_bits_to_f32(du.x & 0xffffu) * c0.x + __uint_as_float(du.x & 0xffff0000u) * c0.y +
+                     bf16_bits_to_f32(du.y & 0xffffu) * c0.z + __uint_as_float(du.y & 0xffff0000u) * c0.w +
+                     bf16_bits_to_f32(du.z & 0xffffu) * c1.x + __uint_as_float(du.z & 0xffff0000u) * c1.y +
+                     bf16_bits_to_f32(du.w & 0xffffu) * c1.z + __uint_as_float(du.w & 0xffff0000u) * c1.w;
         }
     }
     const float lse = row_ok ? a.lse[(long)bh * T + i] : 0.f;
-    const float dsum = row_ok ? a.dsum[(long)bh * T + i] : 0.f;
+    const float dsum = dpart + half_swap_f(dpart);
+    if (row_ok && half == 0) a.dsum[(long)bh * T + i] = dsum;
     f32x16 dq[DH / 32];
 #pragma unroll
     for (int c = 0; c < DH / 32; ++c)
@@ -650,8 +642,6 @@ extern "C" int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, c
     a.dqu = (bf16*)dqu; a.lddq = lddq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddk = lddk; a.dbias = (bf16*)dbias; a.dsum = dsum;
     a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     hipStream_t st = (hipStream_t)stream;
-    const long nrow = (long)B * T * H;
-    relpos_attn_dsum_kernel<<<(unsigned)((nrow + 3) / 4), 256, 0, st>>>(a, dh);
     dim3 gq((T + 127) / 128, B * H), gk((T + 127) / 128, B * H);
     if (dh == 128) { relpos_attn_bwd_q_kernel<128><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<128><<<gk, 256, 0, st>>>(a); }
     else if (dh == 64) { relpos_attn_bwd_q_kernel<64><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<64><<<gk, 256, 0, st>>>(a); }

@@ -138,7 +138,7 @@ def main():
         group(tag, "relpos_attn_fwd dh=%d (B=64,H=4,T=256)" % dh, lambda: hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5), aflop, abytes)
         ctx, aux = hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5)
         dqkv = torch.empty_like(qkv)
-        group(tag + 1, "relpos_attn_bwd dh=%d (dsum + dQ/dbias + dK/dV kernels)" % dh,
+        group(tag + 1, "relpos_attn_bwd dh=%d (dQ/dbias (+ D) + dK/dV kernels)" % dh,
               lambda: hip.relpos_attn_bwd(qu, k_, v_, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, 0.044, 0.1, 5),
               3.5 * aflop, 2.0 * (8 * B * T * d + 2 * B * H * T * T))
     # ---- convolution-module tiles (csrc/dwconv.hip)
