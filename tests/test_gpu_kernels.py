@@ -382,6 +382,35 @@ def test_statistics_epilogues_and_bias_gradients_are_run_to_run_reproducible():
     assert _relerr(first[-1], ref) < 1e-5
 
 
+def test_gradient_convolutions_do_not_depend_on_the_workgroup_count():
+    """sarssl_conv_cus_override (model.py: every CU for the stem that runs last, 7/8 for the other) only changes which persistent
+    workgroup takes which tile: the stored data gradient is bit-identical, the per-workgroup partial sums of the weight gradient and of
+    the BatchNorm-backward epilogue agree to f32 summation order."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    B, F, T = 6, 64, 96                                       # 1152 tiles of 8 x 32: several rounds on any grid
+    dy = _cl(torch.randn((B, 64, F, T), generator=g)).to(torch.bfloat16).to(dev)
+    y = _cl(torch.randn((B, 64, F, T), generator=g)).to(torch.bfloat16).to(dev)
+    w = (torch.randn((9, 64, 64), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    sc, sh = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    aff = torch.stack([sc, sh, torch.zeros(64, device=dev), torch.ones(64, device=dev)]).contiguous()
+    out = {}
+    try:
+        for ncus in (0, 1 << 16, 40):                         # the default rule, every CU, an odd small grid
+            hip.conv_cus_override(ncus)
+            dz, red = hip.conv3x3_dgrad_bnred(dy, w, y, aff)
+            gw = torch.zeros((64, 64, 3, 3), device=dev)
+            hip.conv3x3_wgrad(dy, y, sc, sh, acc_into=gw)
+            out[ncus] = (dz, red.clone(), gw)
+    finally:
+        hip.conv_cus_override(0)
+    for ncus in (1 << 16, 40):
+        assert torch.equal(out[ncus][0], out[0][0])
+        assert _relerr(out[ncus][1], out[0][1]) < 1e-5
+        assert _relerr(out[ncus][2], out[0][2]) < 1e-5
+
+
 @pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64)])
 def test_conv3x3_dgrad_with_fused_bn_backward_sums(B, F, T):
     """The data-gradient launch that also accumulates the BatchNorm-backward sums of the layer in front must store exactly the
