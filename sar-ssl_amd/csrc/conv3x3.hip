@@ -1056,18 +1056,39 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
 
     // staging: thread = (row parity pr, pixel column pcol of 32, 8-channel chunk): halo rows pr, pr+2, .. pr+8 and dy rows pr, pr+2, ..
     // pr+6 of its column; threads < 160 also one chunk of halo columns 32 / 33
+    // (round 3: ~1100 vector instructions per wave and tile, a third of them addresses - 64-bit products per load, the LDS swizzle per
+    //  store.  The row parity is wave-uniform, so row bases live on the scalar unit: one 64-bit image base per tile + 32-bit row offsets,
+    //  one vector byte offset per thread for all rows of a tensor, one lane-constant LDS base per tensor with the row step as an
+    //  immediate: 1426 -> 1019 vector issue slots per tile.  The launch time did not move (379 us alone, +0.2 % on the step): like the
+    //  operand-read and look-ahead experiments in tools/conv_ng3/, it says this kernel is bound by none of them.)
     Chunk<T> rz[6], ry[4];
-    const int pcol = (tid >> 3) & 31, pr = tid >> 8;
+    const int pcol = (tid >> 3) & 31;
+    const int pr = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int lbX = swzc(pr * WHC + pcol, pcol, cch), lbY = swzc(pr * WTC + pcol, pcol, cch);     // LDS element offsets of row pr; row pr + 2k: + k * 2 * W?C * 64
     auto coord = [&](int tile) { TileCoord c; c.t0 = (tile % tiles_t) * WTC; tile /= tiles_t; c.f0 = (tile % tiles_f) * TR; c.b = tile / tiles_f; return c; };
     auto issue_loads = [&](const TileCoord tc) {
+        constexpr unsigned PXB = C1IN ? 8u : 128u;                               // bytes per pixel of zin
+        const char* zimg = (const char*)zin + (long)tc.b * F * (long)Tn * PXB;   // (an image is < 4 GB: 32-bit offsets inside it)
+        const char* yimg = (const char*)dy + (long)tc.b * F * (long)Tn * 128;
+        const unsigned zrow = (unsigned)Tn * PXB, yrow = (unsigned)Tn * 128u;
+        const int tz = min(max(tc.t0 - 1 + pcol, 0), Tn - 1), ty = min(tc.t0 + pcol, Tn - 1);      // clamped: unconditional loads
+        const unsigned vz = C1IN ? (unsigned)tz * 8u : (unsigned)(tz * 64 + cch * 8) * 2u, vy = (unsigned)(ty * 64 + cch * 8) * 2u;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) rz[k] = load_z(tc.b, tc.f0 - 1 + pr + 2 * k, tc.t0 - 1 + pcol);
+        for (int k = 0; k < 5; ++k) {
+            const int f = min(max(tc.f0 - 1 + pr + 2 * k, 0), F - 1);
+            const char* prow = zimg + (unsigned)f * zrow;
+            if (C1IN) { const uint2 q = *(const uint2*)(prow + vz); rz[k].u.x = q.x; rz[k].u.y = q.y; }
+            else rz[k].u = *(const uint4*)(prow + vz);
+        }
         {
             const int q = tid >> 3, hr = q >> 1, te = tc.t0 + WTC - 1 + (q & 1);        // (threads >= 160: an unused, harmless extra chunk)
             rz[5] = load_z(tc.b, tc.f0 - 1 + hr, te);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ry[k] = load_chunk_clamped<T>(dy, tc.b, tc.f0 + pr + 2 * k, tc.t0 + pcol, F, Tn, cch * 8);
+        for (int k = 0; k < 4; ++k) {
+            const int f = min(tc.f0 + pr + 2 * k, F - 1);
+            ry[k].u = *(const uint4*)(yimg + (unsigned)f * yrow + vy);
+        }
     };
     // the tile is written in three pieces (halo rows 0-2 of this thread | halo rows 3-4 + edge columns | dy rows) so that the pieces can be
     // placed between the row iterations of the PREVIOUS tile's MFMA loop
@@ -1078,8 +1099,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 if ((piece == 0) != (k < 3)) continue;
-                const int i = pr + 2 * k, f = tc.f0 - 1 + i;
-                *(uint4*)&sX[swzc(i * WHC + pcol, pcol, cch)] = xform_z(rz[k], tv && f >= 0 && f < F);
+                const int f = tc.f0 - 1 + pr + 2 * k;
+                *(uint4*)&sX[lbX + k * (2 * WHC * 64)] = xform_z(rz[k], tv && f >= 0 && f < F);
             }
             if (piece == 1 && tid < 160) {
                 const int q = tid >> 3, hr = q >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + WTC - 1 + (q & 1);
@@ -1089,8 +1110,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
             const int ty = tc.t0 + pcol;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int i = pr + 2 * k;
-                *(uint4*)&sY[swzc(i * WTC + pcol, pcol, cch)] = xform_chunk<T>(ry[k], tc.f0 + i < F && ty < Tn, 0, sc, sh, 0);
+                *(uint4*)&sY[lbY + k * (2 * WTC * 64)] = xform_chunk<T>(ry[k], tc.f0 + pr + 2 * k < F && ty < Tn, 0, sc, sh, 0);
             }
         }
     };
