@@ -24,6 +24,9 @@ PASSES = {
     "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"],
     "lds": ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
             "SQ_WAVE_CYCLES"],
+    # instruction mix: dynamic instruction counts per class and the cycles the vector ALU / LDS / scalar issue was busy (per wave-cycle)
+    "valu": ["SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAVES",
+             "SQ_WAVE_CYCLES"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
 }
@@ -143,6 +146,13 @@ def main():
             e["wait_inst_any_frac"] = round(m["SQ_WAIT_INST_ANY"] / wc, 4)
             e["wait_inst_lds_frac"] = round(m["SQ_WAIT_INST_LDS"] / wc, 4)
             e["active_inst_frac"] = round(m["SQ_ACTIVE_INST_ANY"] / wc, 4)
+        if "SQ_INSTS_VALU" in m:
+            nw = max(m.get("SQ_WAVES", 0), 1)
+            e["insts_per_wave"] = {"valu": round(m["SQ_INSTS_VALU"] / nw, 1), "mfma": round(m.get("SQ_INSTS_MFMA", 0) / nw, 1),
+                                   "salu": round(m.get("SQ_INSTS_SALU", 0) / nw, 1), "lds": round(m.get("SQ_INSTS_LDS", 0) / nw, 1)}
+            wc = max(m.get("SQ_WAVE_CYCLES", 0), 1)
+            e["valu_active_frac"] = round(m.get("SQ_ACTIVE_INST_VALU", 0) / wc, 4)
+            e["lds_active_frac"] = round(m.get("SQ_ACTIVE_INST_LDS", 0) / wc, 4)
         if "FETCH_SIZE" in m:
             e["fetch_kb_raw"] = round(m["FETCH_SIZE"], 1)
             e["hbm_read_mb"] = round(2 * m["FETCH_SIZE"] * 1024 / 1e6, 2)
