@@ -225,7 +225,11 @@ class _PretrainFn(torch.autograd.Function):
         # (csrc/conv3x3.hip: conv_cus).  That pays for the spec stem, which starts while the spat stream is still in its three
         # Conformer blocks - and costs 1/8 of the chip for the spat stem, which runs last and alone (same-box A/B, three interleaved
         # rounds: 10.97 -> 10.84 ms with spec 7/8 + spat all, 11.08 ms the other way round).  One stream: every launch runs alone.
-        all_cus = 1 << 16 if engine._STEM_LAST_ALL_CUS else 0
+        # Data-parallel runs keep 7/8 for both stems: the bucket all-reduces overlap exactly this part of the backward pass, and a
+        # collective kernel holding a few CUs would make the persistent launch's last workgroups start late with their full share of
+        # tiles (a convolution workgroup owns its CU's whole register file and LDS - nothing co-resides).
+        from . import dist as _dist
+        all_cus = 1 << 16 if (engine._STEM_LAST_ALL_CUS and _dist.world_size() <= 1) else 0
         hip.conv_cus_override(all_cus if side is None else 0)
         engine.stem_bwd(dz_spec, spe.patch_embed, saved)
         hip.conv_cus_override(all_cus)
