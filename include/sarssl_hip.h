@@ -269,6 +269,10 @@ int sarssl_zero_arena(const void* base, long bytes);
  * (loss, diff); F <= 480. */
 int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
                           double* sums, float* out, int dtype, void* stream);
+/*      the same; the finalize launch also copies (loss, diff) to out_keep (f32[2]) and adds them to acc (f64[2]); either may be null
+ *      (the captured step's running sums, learner.py:104-110) */
+int sarssl_masked_mse_fwd_acc(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
+                              double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream);
 int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn,
                           int nm, float gscale, const float* gscale_dev, void* dpred, int dtype, void* stream);
 

@@ -682,12 +682,20 @@ __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict
         atomicAdd(&sums[q * MSE_SLOTS + (blockIdx.x & (MSE_SLOTS - 1))], (double)(red[q][0] + red[q][1] + red[q][2] + red[q][3]));
     }
 }
-__global__ void loss_finalize_kernel(const double* __restrict__ sums, double count, float* __restrict__ out) {
+// out_keep (optional f32[2]) receives a copy, acc (optional f64[2]) accumulates the two values (the captured step's running sums: three
+// copy / cast / add launches of ~4 us each sat between the loss and its backward, in a stretch of the step nothing overlaps)
+__global__ void loss_finalize_kernel(const double* __restrict__ sums, double count, float* __restrict__ out, float* __restrict__ out_keep,
+                                     double* __restrict__ acc) {
     const int lane = threadIdx.x;                        // 64 threads
     double a = sums[lane], c = sums[MSE_SLOTS + lane];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
-    if (lane == 0) { out[0] = (float)(a / count); out[1] = (float)(c / count); }
+    if (lane == 0) {
+        const float l = (float)(a / count), d = (float)(c / count);
+        out[0] = l; out[1] = d;
+        if (out_keep) { out_keep[0] = l; out_keep[1] = d; }
+        if (acc) { acc[0] += (double)l; acc[1] += (double)d; }
+    }
 }
 // dpred = gscale * 2 (pred - tar) / count on (masked frame, masked channel) entries, 0 elsewhere
 template <typename T>
@@ -967,16 +975,25 @@ extern "C" int sarssl_f64_accum(const double* src, float* dst, int n, float scal
     return 0;
 }
 // out: f32[2] = (loss, diff).  sums: f64[128] workspace (zeroed here).
-extern "C" int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
-                                     int nm, double* sums, float* out, int dtype, void* stream) {
+static int masked_mse_fwd_impl(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
+                               int nm, double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream) {
     const size_t lds = (size_t)MSE_TT * F * 4 * sizeof(float);
     SARSSL_REQUIRE(nb > 0 && nm > 0 && lds <= 60 * 1024, "sarssl_masked_mse_fwd (F <= 480)");
     const int groups = (Tn + MSE_TT - 1) / MSE_TT;
     if (SARSSL_ZERO(sums, 2 * MSE_SLOTS * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     DISPATCH_T(dtype, (masked_mse_fwd_kernel<T><<<nb * groups, 256, lds, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
-    loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out);
+    loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out, out_keep, acc);
     SARSSL_CHECK_LAUNCH("masked_mse_fwd_kernel");
     return 0;
+}
+extern "C" int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
+                                     int nm, double* sums, float* out, int dtype, void* stream) {
+    return masked_mse_fwd_impl(pred, x, idx, mch, nb, F, Tn, nm, sums, out, nullptr, nullptr, dtype, stream);
+}
+// The same; the finalize launch also copies (loss, diff) to out_keep (f32[2]) and adds them to acc (f64[2]) - either may be null.
+extern "C" int sarssl_masked_mse_fwd_acc(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
+                                         int nm, double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream) {
+    return masked_mse_fwd_impl(pred, x, idx, mch, nb, F, Tn, nm, sums, out, out_keep, acc, dtype, stream);
 }
 // dpred = gscale * dLoss/dpred, loss = mean over nb*nm*F*2 entries
 extern "C" int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F,

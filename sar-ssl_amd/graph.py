@@ -110,9 +110,11 @@ class PretrainStepGraph:
             hip.step_tick(self.state)
         x = hip.stft_frontend(src) if from_pcm else src
         ctx = _Ctx()
-        loss, out, pred = _PretrainFn.forward(ctx, net, x, idx, ch, mp)
-        self.out.copy_(out)
-        self.acc.add_(out.double())
+        net.__dict__["_loss_sink"] = (self.out, self.acc)     # (loss, diff) -> self.out, += self.acc inside the loss's finalize launch
+        try:
+            loss, out, pred = _PretrainFn.forward(ctx, net, x, idx, ch, mp)
+        finally:
+            net.__dict__.pop("_loss_sink", None)
         self.pred, self.xin, self.vis_masks = pred, x, (mp, ch)
         _PretrainFn.backward(ctx, self.one, None, None)
         if not with_adam:

@@ -174,11 +174,12 @@ class _PretrainFn(torch.autograd.Function):
             net.spat_encoder._fwd_cl(spat_in, B, T, saved_spat, out=ecat[:, ds:])
         saved.append(saved_spat)
         pred = engine.decoder_fwd(ecat, net.decoder, saved)
-        out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32)
+        sink = net.__dict__.get("_loss_sink")            # graph.py: (persistent f32[2], running f64[2] sums) filled by the finalize launch
+        out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink)
         ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds)
         ctx.nparams = len(params)
         ctx.mark_non_differentiable(out, pred)
-        return out[0].clone(), out, pred
+        return (out[0] if sink is not None else out[0].clone()), out, pred
 
     @staticmethod
     def backward(ctx, dloss, _dout, _dpred):
