@@ -1176,6 +1176,199 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     }
 }
 
+// Role-split variant of conv3x3_wgrad_db_kernel: 16 waves, waves 0-7 only run the MFMA loop (same decomposition: co half x ci half x tap
+// group), waves 8-15 only stage (global loads one tile ahead in registers, BatchNorm + ReLU / first-layer prologue, LDS writes).  Ablation
+// builds of the lockstep kernel ran 254 us without its staging and 268 us without its MFMAs, 378 us with both in the same waves.
+template <bool C1IN = false>
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
+    typedef bf16 T;
+    __shared__ __attribute__((aligned(16))) uint16_t sYb[2][WY_ELEMS];   // dy tiles  [8*32 px][64 co]
+    __shared__ __attribute__((aligned(16))) uint16_t sXb[2][WX_ELEMS];   // z halo tiles [340 px][64 ci]
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave_all >= 8;
+    const int tid = threadIdx.x & 511;                                  // thread id inside the role (8 waves each)
+    const int wave = wave_all & 7;
+    const int wi = wave & 1, wj = (wave >> 1) & 1, wt = wave >> 2;     // consumers: co half, ci half, tap group
+    const int tap0 = wt ? 5 : 0, ntap = wt ? 4 : 5;
+    const int F = a.F, Tn = a.T;
+    const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + WTC - 1) / WTC;
+    const int ntiles = a.nb * tiles_f * tiles_t;
+    const T* zin = (const T*)a.zin;
+    const T* dy = (const T*)a.dy;
+    const int cch = tid & 7;
+
+    const int nrounds = (ntiles + gridDim.x - 1) / gridDim.x;
+    int tile = xcd_tile(0, blockIdx.x, gridDim.x);
+    if (producer) {
+        // ---- staging waves: tile `it + 1` is written into the free buffer while the MFMA waves are on tile `it`; the loads of tile
+        // `it + 2` are issued right behind the writes and have the rest of the iteration (the wait at the barrier) to land
+        float sc[8], sh[8];
+    #pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f; }
+        C1Const kc1;
+        if (C1IN) c1_setup(kc1, a.c1_w, a.scale, a.shift, cch * 8);
+        auto load_z = [&](int b, int f, int t) __attribute__((always_inline)) {                    // clamped, unconditional (load_chunk_clamped); C1IN: the pixel's 4 input channels
+            Chunk<T> c;
+            if (C1IN) {
+                f = min(max(f, 0), F - 1); t = min(max(t, 0), Tn - 1);
+                const uint2 q = *(const uint2*)(zin + (((long)b * F + f) * Tn + t) * 4);
+                c.u = make_uint4(q.x, q.y, 0u, 0u);      // (whole object: a partially written chunk carried over the loop edge stays on the stack)
+            } else c = load_chunk_clamped<T>(zin, b, f, t, F, Tn, cch * 8);
+            return c;
+        };
+        auto xform_z = [&](const Chunk<T>& c, bool ok) __attribute__((always_inline)) { return C1IN ? c1_chunk(c.u.x, c.u.y, ok, kc1) : xform_chunk<T>(c, ok, a.prologue, sc, sh, 0); };
+
+        // staging: thread = (row parity pr, pixel column pcol of 32, 8-channel chunk): halo rows pr, pr+2, .. pr+8 and dy rows pr, pr+2, ..
+        // pr+6 of its column; threads < 160 also one chunk of halo columns 32 / 33
+        // (round 3: ~1100 vector instructions per wave and tile, a third of them addresses - 64-bit products per load, the LDS swizzle per
+        //  store.  The row parity is wave-uniform, so row bases live on the scalar unit: one 64-bit image base per tile + 32-bit row offsets,
+        //  one vector byte offset per thread for all rows of a tensor, one lane-constant LDS base per tensor with the row step as an
+        //  immediate: 1426 -> 1019 vector issue slots per tile.  The launch time did not move (379 us alone, +0.2 % on the step): like the
+        //  operand-read and look-ahead experiments in tools/conv_ng3/, it says this kernel is bound by none of them.)
+        Chunk<T> rz[6], ry[4];
+        const int pcol = (tid >> 3) & 31;
+        const int pr = __builtin_amdgcn_readfirstlane(tid >> 8);
+        const int lbX = swzc(pr * WHC + pcol, pcol, cch), lbY = swzc(pr * WTC + pcol, pcol, cch);     // LDS element offsets of row pr; row pr + 2k: + k * 2 * W?C * 64
+        auto coord = [&](int tile) __attribute__((always_inline)) { TileCoord c; c.t0 = (tile % tiles_t) * WTC; tile /= tiles_t; c.f0 = (tile % tiles_f) * TR; c.b = tile / tiles_f; return c; };
+        auto issue_loads = [&](const TileCoord tc) __attribute__((always_inline)) {
+            constexpr unsigned PXB = C1IN ? 8u : 128u;                               // bytes per pixel of zin
+            const char* zimg = (const char*)zin + (long)tc.b * F * (long)Tn * PXB;   // (an image is < 4 GB: 32-bit offsets inside it)
+            const char* yimg = (const char*)dy + (long)tc.b * F * (long)Tn * 128;
+            const unsigned zrow = (unsigned)Tn * PXB, yrow = (unsigned)Tn * 128u;
+            const int tz = min(max(tc.t0 - 1 + pcol, 0), Tn - 1), ty = min(tc.t0 + pcol, Tn - 1);      // clamped: unconditional loads
+            const unsigned vz = C1IN ? (unsigned)tz * 8u : (unsigned)(tz * 64 + cch * 8) * 2u, vy = (unsigned)(ty * 64 + cch * 8) * 2u;
+    #pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int f = min(max(tc.f0 - 1 + pr + 2 * k, 0), F - 1);
+                const char* prow = zimg + (unsigned)f * zrow;
+                if (C1IN) { const uint2 q = *(const uint2*)(prow + vz); rz[k].u = make_uint4(q.x, q.y, 0u, 0u); }
+                else rz[k].u = *(const uint4*)(prow + vz);
+            }
+            {
+                const int q = tid >> 3, hr = q >> 1, te = tc.t0 + WTC - 1 + (q & 1);        // (threads >= 160: an unused, harmless extra chunk)
+                rz[5] = load_z(tc.b, tc.f0 - 1 + hr, te);
+            }
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = min(tc.f0 + pr + 2 * k, F - 1);
+                ry[k].u = *(const uint4*)(yimg + (unsigned)f * yrow + vy);
+            }
+        };
+        // the tile is written in three pieces (halo rows 0-2 of this thread | halo rows 3-4 + edge columns | dy rows) so that the pieces can be
+        // placed between the row iterations of the PREVIOUS tile's MFMA loop
+        auto write_piece = [&](const int piece, const TileCoord tc, uint16_t* __restrict__ sX, uint16_t* __restrict__ sY) __attribute__((always_inline)) {
+            if (piece < 2) {
+                const int t = tc.t0 - 1 + pcol;
+                const bool tv = t >= 0 && t < Tn;
+    #pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    if ((piece == 0) != (k < 3)) continue;
+                    const int f = tc.f0 - 1 + pr + 2 * k;
+                    *(uint4*)&sX[lbX + k * (2 * WHC * 64)] = xform_z(rz[k], tv && f >= 0 && f < F);
+                    if (C1IN) __builtin_amdgcn_sched_barrier(0);       // one chunk's 16 packed FMAs at a time: the 128-register cap has no room for more
+                }
+                if (piece == 1 && tid < 160) {
+                    const int q = tid >> 3, hr = q >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + WTC - 1 + (q & 1);
+                    *(uint4*)&sX[swzc(hr * WHC + WTC + (q & 1), WTC + (q & 1), cch)] = xform_z(rz[5], f >= 0 && f < F && te < Tn);
+                }
+            } else {
+                const int ty = tc.t0 + pcol;
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    *(uint4*)&sY[lbY + k * (2 * WTC * 64)] = xform_chunk<T>(ry[k], tc.f0 + pr + 2 * k < F && ty < Tn, 0, sc, sh, 0);
+                }
+            }
+        };
+        auto write_tile = [&](const TileCoord tc, uint16_t* __restrict__ sX, uint16_t* __restrict__ sY) __attribute__((always_inline)) {
+            write_piece(0, tc, sX, sY); write_piece(1, tc, sX, sY); write_piece(2, tc, sX, sY);
+        };
+
+        TileCoord tc = coord(tile < ntiles ? tile : 0);
+        if (tile < ntiles) { issue_loads(tc); write_tile(tc, sXb[0], sYb[0]); }
+        int next = (1 < nrounds) ? xcd_tile(1, blockIdx.x, gridDim.x) : ntiles;
+        TileCoord tcn = coord(next < ntiles ? next : 0);
+        if (next < ntiles) issue_loads(tcn);
+        __syncthreads();
+        int cur = 0;
+        for (int it = 0; it < nrounds; ++it) {
+            if (tile >= ntiles) break;
+            if (next < ntiles) write_tile(tcn, sXb[cur ^ 1], sYb[cur ^ 1]);
+            const int nn = (it + 2 < nrounds) ? xcd_tile(it + 2, blockIdx.x, gridDim.x) : ntiles;
+            const TileCoord tcnn = coord(nn < ntiles ? nn : 0);
+            if (nn < ntiles) issue_loads(tcnn);
+            __syncthreads();
+            cur ^= 1; tile = next; next = nn; tcn = tcnn;
+        }
+        return;
+    }
+    // ---- MFMA waves
+    f32x16 acc[5];
+#pragma unroll
+    for (int t9 = 0; t9 < 5; ++t9)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t9][r] = 0.f;
+
+    int baseA[2], baseB[5][2];
+    {
+        const int chA = wi * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4, chB = wj * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int loff = (lane >> 5) * 8 + h * 4 + ((lane & 15) >> 2);
+            baseA[h] = swzc(loff, loff, chA >> 3) + (chA & 7);
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) {
+                const int tap = tap0 + (tt < ntap ? tt : 0);
+                const int kh = tap / 3, kw = tap - kh * 3;
+                baseB[tt][h] = swzc(kh * WHC + kw + loff, kw + loff, chB >> 3) + (chB & 7);
+            }
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int it = 0; it < nrounds; ++it) {
+        if (tile >= ntiles) break;
+        const int next = (it + 1 < nrounds) ? xcd_tile(it + 1, blockIdx.x, gridDim.x) : ntiles;
+        const uint16_t* sX = sXb[cur];
+        const uint16_t* sY = sYb[cur];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const uint16_t* ya[2] = {sY + baseA[0] + r * (WTC * 64), sY + baseA[1] + r * (WTC * 64)};
+            const uint16_t* xb[5][2];
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) { xb[tt][0] = sX + baseB[tt][0] + r * (WHC * 64); xb[tt][1] = sX + baseB[tt][1] + r * (WHC * 64); }
+#pragma unroll
+            for (int cb = 0; cb < WTC / 16; ++cb) {
+                const int co_ = cb * 16 * 64;                  // 16 pixels x 64 channels further on
+                const bf16x8 fa = tr_pair(ya[0] + co_, ya[1] + co_);
+                bf16x8 fb[2];
+                fb[0] = tr_pair(xb[0][0] + co_, xb[0][1] + co_);
+#pragma unroll
+                for (int tt = 0; tt < 5; ++tt) {
+                    if (tt + 1 < 5 && tt + 1 < ntap) fb[(tt + 1) & 1] = tr_pair(xb[tt + 1][0] + co_, xb[tt + 1][1] + co_);
+                    __builtin_amdgcn_sched_barrier(0);         // pin the next tap's transpose reads above this MFMA
+                    if (tt < ntap) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tt & 1], acc[tt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1; tile = next;
+    }
+    float* P = a.partial + (long)blockIdx.x * W_ELEMS;
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt) {
+        if (tt < ntap) {
+            const int tap = tap0 + tt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ci = wj * 32 + (lane & 31);
+                P[(tap * 64 + co) * 64 + ci] = acc[tt][r];
+            }
+        }
+    }
+}
+
 // dW[e] (+)= sum_p partial[p][e]; workgroup = 64 elements x 4 part-slots, 4-way unrolled loads
 // grad_oihw != null: the sum is ADDED to the parameter-gradient buffer in nn.Conv2d's own (co, ci, kh, kw) layout instead.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ dW,
@@ -1408,6 +1601,16 @@ extern "C" int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad,
     return 0;
 }
 
+// bf16 weight gradient: the role-split kernel (16 waves: 8 stage, 8 run the MFMA loop), or with SARSSL_WGRAD_WS=0 (A/B) the lockstep
+// double-buffered one.  Same box, three interleaved rounds, both weight-gradient launches of a stem: 10.87 -> 10.72 ms per step; alone
+// 361 -> 311 us (its MFMA loop alone: 254 us).
+template <bool C1IN>
+static void wgrad_bf16_launch(const WgradArgs& a, int g2, hipStream_t st) {
+    static const bool ws = []() { const char* e = getenv("SARSSL_WGRAD_WS"); return !(e && atoi(e) == 0); }();
+    if (ws) conv3x3_wgrad_ws_kernel<C1IN><<<g2, 1024, 0, st>>>(a);
+    else conv3x3_wgrad_db_kernel<C1IN><<<g2, 512, 0, st>>>(a);
+}
+
 extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T,
                                     const float* scale, const float* shift, float* dW, float* partial, int precise,
                                     void* stream) {
@@ -1420,7 +1623,7 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
     const int rblocks = W_ELEMS / 64;
     if (dtype == SARSSL_BF16) {
         const int g2 = wgrad_db_grid(nb, F, T);
-        conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a);
+        wgrad_bf16_launch<false>(a, g2, st);
         wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, g2, dW, 0);
     } else if (dtype == SARSSL_F32) {
         const int npass = precise ? 3 : 1;
@@ -1445,7 +1648,7 @@ extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb,
     a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
     hipStream_t st = (hipStream_t)stream;
     const int g2 = wgrad_db_grid(nb, F, T);
-    conv3x3_wgrad_db_kernel<false><<<g2, 512, 0, st>>>(a);
+    wgrad_bf16_launch<false>(a, g2, st);
     wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel(acc)");
     return 0;
@@ -1460,7 +1663,7 @@ extern "C" int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const
     a.partial = partial; a.nb = nb; a.F = F; a.T = T;
     hipStream_t st = (hipStream_t)stream;
     const int g2 = wgrad_db_grid(nb, F, T);
-    conv3x3_wgrad_db_kernel<true><<<g2, 512, 0, st>>>(a);
+    wgrad_bf16_launch<true>(a, g2, st);
     wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_db_kernel<c1in>");
     return 0;
