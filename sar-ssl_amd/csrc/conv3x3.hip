@@ -839,6 +839,434 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     }
 }
 
+// Role-split variant of conv3x3_fwd_pp_kernel (12 waves, three per SIMD, <= 168 registers): waves 0-7 are the two tile groups of the
+// ping-pong kernel WITHOUT their staging phases - wait for the tile, MFMA phase, accumulators -> LDS, drain / statistics / epilogues,
+// release the buffer; waves 8-11 only stage: for each group in turn wait until its buffer is released, write the prefetched tile
+// (BatchNorm + ReLU or the first-layer prologue), publish it, request the group's next tile.  Staging (2.6 k cycles), its barrier and
+// the prefetch issue (2.1 k) leave the MFMA waves' 16.7 k-cycle iteration.  LDS arrival counters: sReady[g] (4 staging waves per tile),
+// sFree[g] (4 MFMA waves per tile), sSync[g] (the group's own barrier between its MFMA phase and the accumulator hand-over).
+template <bool BNRED, bool C1IN = false, bool C1RED = false>
+__global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
+    typedef bf16 T;
+    __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
+    __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
+    __shared__ float sAff[BNRED ? 256 : 1];
+    // C1RED: MFMA "A" fragments of the scale-folded first-layer weights, [co][16 k]: k 0..3 = bf16 high parts of scale*W1[co][c], 4 = of
+    // shift, 8..12 = the low parts (the input fragment repeats [a0 | 1] in both k halves: one MFMA gives the f32-accurate pre-activation)
+    __shared__ __attribute__((aligned(16))) uint16_t sC1[C1RED ? 64 * 16 : 8];
+    __shared__ unsigned sSync[2], sReady[2], sFree[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave_all >= 8;
+    // wave-uniform ids as SCALARS (hipcc cannot prove tid >> 6 uniform): the tile coordinates (two integer divisions), row bases and
+    // validity tests derived from them then live on the scalar unit instead of costing ~250 vector instructions per tile
+    const int wave = wave_all & 7;                 // MFMA waves: group = wave >> 2; staging waves: wave_all - 8
+    const int half = wave >> 2, hw = wave & 3, htid = tid & 255;      // (staging waves: htid = their thread id, 0..255)
+    const int F = a.F, Tn = a.T;
+    const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + PTC - 1) / PTC;
+    const int ntiles = a.nb * tiles_f * tiles_t;
+    const int npairs = (ntiles + 1) >> 1;
+    const T* in = (const T*)a.in;
+    uint16_t* sX = sXh[half];                      // MFMA waves: their group's tile buffer
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[0] = __builtin_amdgcn_s_memtime(); a.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+    if (tid < 2) { sSync[tid] = 0u; sReady[tid] = 0u; sFree[tid] = 0u; }
+    if (BNRED && tid < 256) sAff[tid] = a.bn_aff[tid];
+    if (C1RED) {
+        for (int q = tid; q < 64 * 16; q += 768) {
+            const int co = q >> 4, k = q & 15, c = k & 7;
+            const float v = c < 4 ? a.scale[co] * a.c1_w[co * 4 + c] : (c == 4 ? a.shift[co] : 0.f);
+            const uint32_t hi = f32_to_bf16_bits(v);
+            sC1[q] = (uint16_t)(k < 8 ? hi : f32_to_bf16_bits(v - bf16_bits_to_f32(hi)));
+        }
+    }
+    const int cch = tid & 7;
+    {
+        const T* w = (const T*)a.w;
+        for (int q = tid; q < 9 * 64 * 8; q += 768) {
+            const int p = q >> 3, c = q & 7;
+            *(uint4*)&sW[swz(p, c)] = *(const uint4*)(w + (long)p * 64 + c * 8);
+        }
+    }
+    __syncthreads();                                // weights, counters (the only workgroup-wide barrier before the end)
+    // ------------------------------------------------------------------------------------------------ staging waves
+    if (producer) {
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = a.prologue ? a.scale[cch * 8 + e] : 1.f; sh[e] = a.prologue ? a.shift[cch * 8 + e] : 0.f;
+        }
+        C1Const kc1;
+        if (C1IN) c1_setup(kc1, a.c1_w, a.scale, a.shift, cch * 8);
+
+        // staging: thread of the half = (pixel column pc = htid >> 3 of 32, chunk): halo rows 0..9 + one chunk of halo columns 32 / 33
+        Chunk<T> regsg[2][X_ITERS];                    // one prefetched tile per group
+        const int pc = htid >> 3;
+        // addresses: row bases are scalar (tile coordinates are wave-uniform), each thread adds ONE byte offset (its clamped frame and chunk)
+        auto issue_loads = [&](Chunk<T> (&regs)[X_ITERS], const TileCoord tc) __attribute__((always_inline)) {
+            const int tcl = min(max(tc.t0 - 1 + pc, 0), Tn - 1);
+            const unsigned voff = C1IN ? (unsigned)tcl * 8u : (unsigned)(tcl * 64 + cch * 8) * 2u;
+            // one 64-bit base per tile (the image), 32-bit row offsets inside it (an image is < 4 GB): round-3 stamps showed this phase at
+            // 2.8 k cycles per half tile for 12 loads - ~14 scalar instructions of 64-bit multiply / add per row sat in front of every load
+            constexpr unsigned PXB = C1IN ? 8u : 128u;                               // bytes per pixel
+            const char* pimg = (const char*)in + (long)tc.b * F * (long)Tn * PXB;
+            const unsigned rowbytes = (unsigned)Tn * PXB;
+#pragma unroll
+            for (int i = 0; i < HR; ++i) {
+                const int f = min(max(tc.f0 - 1 + i, 0), F - 1);                      // (clamped: unconditional loads, see load_chunk_clamped)
+                const char* prow = pimg + (unsigned)f * rowbytes;
+                if (C1IN) { const uint2 q = *(const uint2*)(prow + voff); regs[i].u = make_uint4(q.x, q.y, 0u, 0u); }
+                else regs[i].u = *(const uint4*)(prow + voff);
+            }
+            {
+                const int hr = pc >> 1, te = tc.t0 + PTC - 1 + (pc & 1);        // (threads >= 160: an unused, harmless extra chunk)
+                if (C1IN) {
+                    const int f = min(max(tc.f0 - 1 + hr, 0), F - 1), t = min(max(te, 0), Tn - 1);
+                    const uint2 q = *(const uint2*)(in + (((long)tc.b * F + f) * Tn + t) * 4);
+                    regs[HR].u = make_uint4(q.x, q.y, 0u, 0u);
+                } else regs[HR] = load_chunk_clamped<T>(in, tc.b, tc.f0 - 1 + hr, te, F, Tn, cch * 8);
+            }
+        };
+        auto write_tile = [&](const Chunk<T> (&regs)[X_ITERS], const TileCoord tc, uint16_t* __restrict__ sX) __attribute__((always_inline)) {
+            const int t = tc.t0 - 1 + pc;
+            const bool tv = t >= 0 && t < Tn;
+#pragma unroll
+            for (int i = 0; i < HR; ++i) {
+                const int f = tc.f0 - 1 + i;
+                const bool ok = tv && f >= 0 && f < F;
+                *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = C1IN ? c1_chunk(regs[i].u.x, regs[i].u.y, ok, kc1)
+                                                                 : xform_chunk<T>(regs[i], ok, a.prologue, sc, sh, 0);
+            }
+            if (htid < 160) {
+                const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
+                const bool ok = f >= 0 && f < F && te < Tn;
+                *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = C1IN ? c1_chunk(regs[HR].u.x, regs[HR].u.y, ok, kc1)
+                                                                                           : xform_chunk<T>(regs[HR], ok, a.prologue, sc, sh, 0);
+            }
+        };
+
+
+        auto coord = [&](int tile) __attribute__((always_inline)) { TileCoord c; c.t0 = (tile % tiles_t) * PTC; tile /= tiles_t; c.f0 = (tile % tiles_f) * TR; c.b = tile / tiles_f; return c; };
+        auto tile_g = [&](int it, int g) __attribute__((always_inline)) { const int pr = xcd_tile(it, blockIdx.x, gridDim.x); return pr < npairs ? pr * 2 + g : ntiles; };
+        volatile __attribute__((address_space(3))) unsigned* free3 = (volatile __attribute__((address_space(3))) unsigned*)sFree;
+        const int nrounds = (npairs + gridDim.x - 1) / gridDim.x;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int t0_ = tile_g(0, g);
+            if (t0_ < ntiles) issue_loads(regsg[g], coord(t0_));
+        }
+        for (int it = 0; it < nrounds; ++it) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int tile = tile_g(it, g);
+                if (tile >= ntiles) continue;
+                while (free3[g] < (unsigned)it * 4u) __builtin_amdgcn_s_sleep(1);      // the group has drained its previous tile
+                asm volatile("" ::: "memory");
+                write_tile(regsg[g], coord(tile), sXh[g]);
+                __builtin_amdgcn_s_waitcnt(0xC07F);                                     // my LDS writes have landed (lgkmcnt(0))
+                if (lane == 0) atomicAdd(&sReady[g], 1u);
+                const int next = (it + 1 < nrounds) ? tile_g(it + 1, g) : ntiles;
+                if (next < ntiles) issue_loads(regsg[g], coord(next));
+            }
+        }
+        // the MFMA waves' final folds run behind workgroup barriers: take part in the same sequence
+        __syncthreads();
+        if (BNRED || a.stats) __syncthreads();
+        if (C1RED) __syncthreads();
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------ MFMA waves
+    // lane-constant fragment addresses; this wave computes rows 2*hw and 2*hw+1 (32 pixels x 64 channels each)
+    int laneW[4], laneX[3][4];
+    {
+        const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            laneW[kc] = swz(l31, kc * 2 + hi);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) laneX[kw][kc] = swzx(2 * hw * PHC + l31 + kw, l31 + kw, kc * 2 + hi);
+        }
+    }
+    auto tile_of = [&](int it) { const int pr = xcd_tile(it, blockIdx.x, gridDim.x); return pr < npairs ? pr * 2 + half : ntiles; };
+    auto coord = [&](int tile) { TileCoord c; c.t0 = (tile % tiles_t) * PTC; tile /= tiles_t; c.f0 = (tile % tiles_f) * TR; c.b = tile / tiles_f; return c; };
+
+    unsigned epoch = 0;
+    unsigned* cnt = &sSync[half];
+    float ssum[8], ssq[8];                         // this thread's 8 output channels ((lane & 7) * 8 + e), summed over all its tiles
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    float bthr[8];                                 // BNRED: relu'(y*sc + sh) as a threshold test on y (see cl_bn_bwd_reduce), lane-constant
+    unsigned bsgn = 0u;
+    if (BNRED) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (lane & 7) * 8 + e;
+            const float sc_ = sAff[c], sh_ = sAff[64 + c];
+            float thr = sc_ != 0.f ? -sh_ / sc_ : (sh_ > 0.f ? -INFINITY : INFINITY);
+            if (sc_ < 0.f) { thr = -thr; bsgn |= 1u << e; }
+            bthr[e] = thr;
+        }
+    }
+    float gacc[2][4];                              // C1RED: lanes < 32: G[c = r][co = nb*32 + lane]; lanes >= 32: r = 0: s1[co = nb*32 + lane - 32]
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gacc[nb][r] = 0.f;
+    const int nrounds = (npairs + gridDim.x - 1) / gridDim.x;
+    volatile __attribute__((address_space(3))) unsigned* ready3 = (volatile __attribute__((address_space(3))) unsigned*)&sReady[half];
+    for (int it = 0; it < nrounds; ++it) {
+        const int tile = tile_of(it);
+        if (tile >= ntiles) break;                 // (all four waves of the group take the same branch)
+        const TileCoord tc = coord(tile);
+        while (*ready3 < (unsigned)(it + 1) * 4u) __builtin_amdgcn_s_sleep(1);      // the staging waves have published this tile
+        asm volatile("" ::: "memory");
+
+        f32x16 acc[2][2];                          // [co half][row]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        {
+            bf16x8 wf[2][2], xf[2][2];
+            auto fetch = [&](int s, int buf) {
+                const int tap = s >> 2, kc = s & 3;
+                const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) wf[buf][i] = *(const bf16x8*)(sW + laneW[kc] + (tap * 64 + i * 32) * 64);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xf[buf][j] = *(const bf16x8*)(sX + laneX[kw][kc] + ((kh + j) * PHC) * 64);
+            };
+            // the wave that is on the matrix cores gets issue priority over the other half's wave on the same SIMD (which is staging
+            // its next tile / draining its outputs on the VALU): its MFMAs and fragment reads are never queued behind that work
+            if (a.prio) __builtin_amdgcn_s_setprio(3);
+            fetch(0, 0);
+#pragma unroll
+            for (int s = 0; s < 36; ++s) {
+                const int cur = s & 1;
+                if (s + 1 < 36) fetch(s + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
+            }
+            if (a.prio) __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // retire the prefetch before any output store is issued
+        // BatchNorm-backward mode: fetch the matching pre-BN activations now - their round trip runs under the half barrier and the
+        // accumulator hand-over below - and retire them BEFORE the first output store is issued (loads and stores share vmcnt and
+        // complete out of order on gfx9).  Unconditional loads from clamped addresses (out-of-image chunks are skipped in the drain).
+        uint4 yv[BNRED ? 8 : 1];
+        if (BNRED) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int px = (lane >> 3) + 8 * k;
+                const int f = min(tc.f0 + 2 * hw + (px >> 5), F - 1), t = min(tc.t0 + (px & 31), Tn - 1);
+                yv[k] = *(const uint4*)((const uint16_t*)a.bn_y + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8);
+            }
+        }
+        uint2 av[C1RED ? 2 : 1];                               // C1RED: the 4 input channels of this lane's pixel (lane & 31) in both rows
+        bool pv[C1RED ? 2 : 1];
+        if (C1RED) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int f = tc.f0 + 2 * hw + j, t = tc.t0 + (lane & 31);
+                pv[j] = f < F && t < Tn;
+                av[j] = *(const uint2*)((const uint16_t*)a.c1_a0 + (((long)tc.b * F + min(f, F - 1)) * Tn + min(t, Tn - 1)) * 4);
+            }
+        }
+        half_barrier(cnt, epoch, lane);                        // the half is done reading its input tile
+        uint16_t* stg = sX + hw * (64 * 64);                   // this wave's [64 px][64 co] slice (px = row * 32 + column)
+        if (C1RED) {
+            // (1) mask: pre-activation tile of the first layer in the accumulators' own layout (co x pixel), one MFMA per tile
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // av landed (the next tile's prefetch too: it had the whole MFMA loop)
+            uint16_t* a0t = sX + 4 * (64 * 64) + hw * 256;     // [4 c][64 px] of this wave, in the part of the input tile no slice uses
+            {
+                const int j = lane >> 5;                       // lanes < 32 file row 0, lanes >= 32 row 1 (both hold both rows' pixels)
+                const uint2 q = j ? av[1] : av[0];
+                uint16_t* d = a0t + j * 32 + (lane & 31);
+                d[0] = (uint16_t)(q.x & 0xffffu); d[64] = (uint16_t)(q.x >> 16); d[128] = (uint16_t)(q.y & 0xffffu); d[192] = (uint16_t)(q.y >> 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 wfr = *(const bf16x8*)&sC1[(i * 32 + (lane & 31)) * 16 + (lane >> 5) * 8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    union { uint4 u; bf16x8 b; } bx;
+                    bx.u = make_uint4(av[j].x, av[j].y, 0x00003f80u, 0u);          // [a0_0..a0_3, 1, 0, 0, 0]
+                    f32x16 y;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+                    y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr, bx.b, y, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = (y[r] > 0.f && pv[j]) ? acc[i][j][r] : 0.f;
+                }
+            }
+            // (2) masked gradient tile, bf16, [64 px][64 co] in the transpose-read layout (swz)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint2 w2;
+                        w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+                        w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                        *(uint2*)(stg + swz(j * 32 + (lane & 31), i * 4 + g) + 4 * (lane >> 5)) = w2;
+                    }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            // (3) G[c'][co] += sum_px [a0 | 1][px][c'] * g[px][co]: 4 k-steps of 16 pixels x 2 channel halves
+            f32x16 d2[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d2[nb][r] = 0.f;
+            const int m = lane & 31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                union { uint4 u; bf16x8 b; } ax;
+                ax.u = *(const uint4*)(a0t + min(m, 3) * 64 + ks * 16 + (lane >> 5) * 8);
+                if (m == 4) ax.u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                else if (m > 4) ax.u = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    d2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax.b, tr_frag(stg, ks * 16, nb * 32, lane), d2[nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[nb][r] += d2[nb][r];
+        } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // chunk (i*4+g) ^ (px & 7) only depends on the lane (px & 7 == lane & 7 for both rows): one address per (i, g)
+                uint16_t* q = stg + (lane & 31) * 64 + ((((i * 4 + g) ^ (lane & 7)) << 3) | (4 * (lane >> 5)));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint2 w2;
+                    w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+                    w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                    *(uint2*)(q + j * 32 * 64) = w2;
+                }
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (BNRED) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        // Interior tiles (every tile of a 256-multiple image): branch-free drain - all eight LDS reads in flight at once, one scalar base
+        // per wave, lane-constant byte offset, the row / column-block offsets immediate or scalar.  Round-3 stamps: the per-chunk validity
+        // branches (s_and_saveexec + branch around every store) made this phase a chain of eight LDS round trips, 2.4-4.5 k cycles per tile.
+        const bool interior = !BNRED && (tc.f0 + TR <= F) && (tc.t0 + PTC <= Tn);
+        if (interior) {
+            uint4 o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = *(const uint4*)&stg[((lane >> 3) + 8 * k) * 64 + (((lane & 7) ^ (lane >> 3)) << 3)];
+            char* obase = (char*)a.out + (((long)tc.b * F + tc.f0 + 2 * hw) * Tn + tc.t0) * 128;
+            const unsigned loff = (unsigned)((lane >> 3) * 128 + (lane & 7) * 16), rowb = (unsigned)Tn * 128u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *(uint4*)(obase + loff + (k & 3) * (8 * 128) + (k >> 2) * rowb) = o[k];
+            if (a.stats) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t w[4] = {o[k].x, o[k].y, o[k].z, o[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
+                    }
+                }
+            }
+        } else
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int px = (lane >> 3) + 8 * k;
+            const int f = tc.f0 + 2 * hw + (px >> 5), t = tc.t0 + (px & 31);
+            // (px & 7) == (lane >> 3) for every k: lane-constant chunk, k only moves the row offset
+            const uint4 o = *(const uint4*)&stg[px * 64 + (((lane & 7) ^ (lane >> 3)) << 3)];
+            if (f < F && t < Tn) {
+                *(uint4*)((uint16_t*)a.out + (((long)tc.b * F + f) * Tn + t) * 64 + (lane & 7) * 8) = o;
+                if (BNRED) {            // sums of g and g*y; turned into rstd*(sum g*y - mean*sum g) per tile below
+                    const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+                    const uint32_t yw[4] = {yv[k].x, yv[k].y, yv[k].z, yv[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float d0 = bf16_bits_to_f32(w[q] & 0xffffu), d1 = __uint_as_float(w[q] & 0xffff0000u);
+                        const float y0 = bf16_bits_to_f32(yw[q] & 0xffffu), y1 = __uint_as_float(yw[q] & 0xffff0000u);
+                        const float t0_ = __uint_as_float(__float_as_uint(y0) ^ (((bsgn >> (2 * q)) & 1u) << 31));
+                        const float t1_ = __uint_as_float(__float_as_uint(y1) ^ (((bsgn >> (2 * q + 1)) & 1u) << 31));
+                        const float g0 = t0_ > bthr[2 * q] ? d0 : 0.f, g1 = t1_ > bthr[2 * q + 1] ? d1 : 0.f;
+                        ssum[2 * q] += g0; ssq[2 * q] = fmaf(g0, y0, ssq[2 * q]);
+                        ssum[2 * q + 1] += g1; ssq[2 * q + 1] = fmaf(g1, y1, ssq[2 * q + 1]);
+                    }
+                } else if (a.stats) {
+                    const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
+                    }
+                }
+            }
+        }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    // my reads of the slice have landed (lgkmcnt(0)) ...
+        if (lane == 0) atomicAdd(&sFree[half], 1u);            // ... the staging waves may overwrite the buffer once all four say so
+    }
+    // per-channel sums: the thread's 8 channels were accumulated over ALL its tiles in registers (folding them per tile - 48 lane
+    // exchanges + 16 LDS atomics - showed as ~2.5 k of a half-tile's ~22 k cycles in the stamps); one fold per launch.
+    // The fold is ORDERED (round 3): every wave parks its 128 partial sums in a slot of its own (the weight table is free once all
+    // eight waves are past their last tile) and thread c adds the eight slots in wave order - the round-2 f32 LDS atomics summed them
+    // in arrival order, which flipped bf16 roundings downstream from run to run.  What leaves the workgroup is one f64 atomic per
+    // channel of f32-valued terms: exact (order-free) as long as the terms' exponents span < 2^20.
+    __syncthreads();                               // every wave is done with sW
+    if (a.clk && blockIdx.x == 0 && tid == 0) { a.clk[2] = __builtin_amdgcn_s_memtime(); a.clk[3] = __builtin_amdgcn_s_memrealtime(); }
+    float* part = (float*)sW;                      // [8 waves][128] statistics, then [8][320] first-layer sums (C1RED)
+    if (BNRED || a.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ssum[e] += __shfl_xor(ssum[e], 8, 64); ssum[e] += __shfl_xor(ssum[e], 16, 64); ssum[e] += __shfl_xor(ssum[e], 32, 64);
+            ssq[e] += __shfl_xor(ssq[e], 8, 64); ssq[e] += __shfl_xor(ssq[e], 16, 64); ssq[e] += __shfl_xor(ssq[e], 32, 64);
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s2 = ssq[e];
+                if (BNRED) s2 = sAff[192 + lane * 8 + e] * (s2 - sAff[128 + lane * 8 + e] * ssum[e]);     // rstd * (sum g*y - mean * sum g)
+                part[wave * 128 + lane * 8 + e] = ssum[e]; part[wave * 128 + 64 + lane * 8 + e] = s2;
+            }
+        }
+        __syncthreads();
+        if (a.stats && tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += part[w * 128 + tid];
+            atomicAdd(&a.stats[tid], (double)s);
+        }
+    }
+    if (C1RED) {                                   // fold the 8 waves through LDS in wave order, then f64 atomics
+        float* fold = part + 1024;                 // [8][320]: [0,256) G[co][c], [256,320) s1[co]
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int co = nb * 32 + (lane & 31);
+            if (lane < 32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fold[wave * 320 + co * 4 + r] = gacc[nb][r];
+            } else fold[wave * 320 + 256 + co] = gacc[nb][0];
+        }
+        __syncthreads();
+        for (int q = tid; q < 320; q += 512) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += fold[w * 320 + q];
+            atomicAdd(&a.c1_red[q < 256 ? q : 512 + (q - 256)], (double)s);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const void* dy;       // (B,F,T,64) gradient w.r.t. the conv output
@@ -1421,6 +1849,16 @@ extern "C" long sarssl_wall_clock_khz() {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) != hipSuccess) return 0;
     return (long)khz;
 }
+// forward / data-gradient kernel: the ping-pong kernel, or (SARSSL_CONV_WS=1) its role-split variant
+// Which launches take it (SARSSL_CONV_WS, bit mask: 1 plain forward / data gradient, 2 forward from the 4-channel input, 4 data gradient
+// consumed in its epilogue, 8 data gradient + BatchNorm sums; default 4).  In-step launch times, ping-pong -> role-split, same box:
+// BatchNorm-prologue forward 0.298 -> 0.314 ms and 4-channel-input forward 0.351 -> 0.350 (one 4-wave staging team serves both groups:
+// with a prologue to compute it becomes the bottleneck), data gradient + BatchNorm sums 0.361 -> 0.56 (80 B of scratch at the 168-register
+// cap), data gradient consumed in its epilogue (identity prologue, no output drain) 0.345 -> **0.314**: step 10.72 -> 10.68 ms.
+static bool conv_ws(int variant_bit) {
+    static const int mask = []() { const char* e = getenv("SARSSL_CONV_WS"); return e ? atoi(e) : 4; }();
+    return (mask & variant_bit) != 0;
+}
 static int conv_persistent_grid(int nunits, int kind) {
     const int cus = conv_cus(kind);
     if (nunits <= cus) return nunits;
@@ -1476,7 +1914,8 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
     a.in = a0; a.w = w; a.out = out; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    conv3x3_fwd_pp_kernel<false, true><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
+    if (conv_ws(2)) conv3x3_fwd_ws_kernel<false, true><<<conv_persistent_grid(npairs, 0), 768, 0, (hipStream_t)stream>>>(a);
+    else conv3x3_fwd_pp_kernel<false, true><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1in>");
     return 0;
 }
@@ -1498,7 +1937,8 @@ extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const v
     a.in = dy; a.w = w; a.out = nullptr; a.scale = scale; a.shift = shift; a.prologue = 0; a.c1_w = W1; a.c1_a0 = a0; a.c1_red = red;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    conv3x3_fwd_pp_kernel<false, false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
+    if (conv_ws(4)) conv3x3_fwd_ws_kernel<false, false, true><<<conv_persistent_grid(npairs, 1), 768, 0, (hipStream_t)stream>>>(a);
+    else conv3x3_fwd_pp_kernel<false, false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1red>");
     return 0;
 }
@@ -1525,7 +1965,9 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     if (dtype == SARSSL_BF16 && w_dtype == SARSSL_BF16) {
         const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
         const int g = conv_persistent_grid(npairs, scale != nullptr ? 0 : 1);      // (no prologue = a data-gradient launch)
-        if (bn_y) conv3x3_fwd_pp_kernel<true><<<g, 512, 0, st>>>(a);
+        if (bn_y && conv_ws(8)) conv3x3_fwd_ws_kernel<true><<<g, 768, 0, st>>>(a);
+        else if (!bn_y && conv_ws(1)) conv3x3_fwd_ws_kernel<false><<<g, 768, 0, st>>>(a);
+        else if (bn_y) conv3x3_fwd_pp_kernel<true><<<g, 512, 0, st>>>(a);
         else conv3x3_fwd_pp_kernel<false><<<g, 512, 0, st>>>(a);
     } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
         if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);

@@ -242,6 +242,7 @@ def knobs():
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
             "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
+            "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
             "SARSSL_CONV_CUS_BWD": os.environ.get("SARSSL_CONV_CUS_BWD", os.environ.get("SARSSL_CONV_CUS", "default(224)")),
             "SARSSL_GRAPH": os.environ.get("SARSSL_GRAPH", "default"),
