@@ -1694,8 +1694,7 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
                     if ((piece == 0) != (k < 3)) continue;
                     const int f = tc.f0 - 1 + pr + 2 * k;
                     *(uint4*)&sX[lbX + k * (2 * WHC * 64)] = xform_z(rz[k], tv && f >= 0 && f < F);
-                    if (C1IN) __builtin_amdgcn_sched_barrier(0);       // one chunk's 16 packed FMAs at a time: the 128-register cap has no room for more
-                }
+                    }
                 if (piece == 1 && tid < 160) {
                     const int q = tid >> 3, hr = q >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + WTC - 1 + (q & 1);
                     *(uint4*)&sX[swzc(hr * WHC + WTC + (q & 1), WTC + (q & 1), cch)] = xform_z(rz[5], f >= 0 && f < F && te < Tn);
