@@ -4,7 +4,11 @@
  * point below names the reference code whose device work it replaces (paths relative to the reference repository).
  * Conventions: plain pointers and sizes only (no torch types); every pointer is DEVICE memory owned by the caller,
  * including workspaces; kernels are enqueued on `stream` (a hipStream_t passed as void*) and never synchronise;
- * return 0 on success, negative on error with a message in sarssl_last_error().  dtype: 0 = f32, 1 = bf16, 2 = int16.
+ * return 0 on success, negative on error with a message in sarssl_last_error().
+ * dtype: 0 = f32, 1 = bf16, 2 = int16, 3 = fp16, 4 = "mixed 16": a backward kernel whose GRADIENT tensors (in / out) are bf16 while the
+ * tensors SAVED BY THE FORWARD PASS it reads are fp16 - the fp16-forward / bf16-backward numeric mode (abi version 2: fp16 has 3 more
+ * mantissa bits than bf16 at the same MFMA rate, which is what puts the forward pass inside the reference's 1e-3 per-bin tolerance;
+ * gradients keep bf16's exponent range, so no loss scaling - the reference's own AMP is fp16 with a GradScaler, code/learner.py:46-50).
  * "precise" != 0 (f32 storage only) runs every MFMA contraction as three split-bf16 passes (hi*hi + hi*lo + lo*hi).
  */
 #ifndef SARSSL_HIP_H
@@ -53,8 +57,11 @@ int sarssl_istft(const float* spec, int nb, int nch, int nt, int win_len, int ho
 int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC, int a_kc, int b_kc, int M, int N, int K,
                 long lda, long ldb, long ldc, int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0,
                 long sC1, float alpha, float out_scale, const float* bias, int act, const void* resid, long ldr, long sR0,
-                long sR1, float res_scale, void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
-                int precise, float* ws, int split_k, int c_row_shift, void* stream);
+                long sR1, float res_scale, void* preact, const void* aux, int aux_act, int aux_dtype, float p_drop,
+                unsigned long long seed, int precise, float* ws, int split_k, int c_row_shift, void* stream);
+/*      operand dtypes: (bf16,bf16) and (fp16,fp16) contract on the matrix cores as stored, (f32,f32) as split-bf16 parts; a bf16 / fp16
+ *      pair (gradient x saved activation) contracts in bf16, the fp16 operand re-encoded while staged.  aux_dtype: dtype of `aux`
+ *      (= dtC, or fp16 next to a bf16 C). */
 
 /* several split-K products reduced in one launch: C_q[m][n] += sum_s ws_q[s][m][n].  Pair with sarssl_gemm(split_k > 0, C = NULL,
  * bf16 operands), which then only writes the partials (split count = ceil(K / (ceil(ceil(K / split_k) / 64) * 64))). */
@@ -68,7 +75,7 @@ int sarssl_splitk_reduce_multi(const float* const* ws, const int* nsplit, const 
  * Returns 1 without launching when a shape is ragged (M, N % 128 or a K slice % 64). */
 int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* const* ws, const int* M, const int* N, const int* K,
                          const long* lda, const long* ldb, const int* split_k, int* split_out, float* const* csum_ws, int n_prob,
-                         void* stream);
+                         int dtB, void* stream);       /* dtB: dtype of every X_q (bf16 | fp16); dY_q is bf16 */
 
 /* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
  *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as
@@ -89,11 +96,11 @@ int sarssl_gemm_fp8(const void* A8, const void* B8, const float* sa, const float
 int sarssl_relpos_attn_supported(int T, int dh);
 int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, void* ctx, long ldc,
                            float* ctx32, float* lse, int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed,
-                           void* stream);
+                           int dtype, void* stream);      /* dtype of qu / k / v / bias / ctx: bf16 | fp16 */
 int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, const float* ctx32,
                            const float* lse, const void* dctx, long lddc, void* dqu, long lddq, void* dk, void* dv,
                            long lddk, void* dbias, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,
-                           unsigned long long seed, void* stream);
+                           unsigned long long seed, int dtype, void* stream);      /* bf16 | mixed 16 (qu / k / v / bias fp16) */
 
 /* ---- CNN stem, channels-last (B,F,T,C): code/model.py:50-64 (patch_embed), masking code/model.py:533-564 */
 int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn, int mode, void* spec,
@@ -113,7 +120,7 @@ int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int 
  *      red = f64[128] = [sum g | sum g*xhat], g = dz * relu'(bn(y)); aff = [scale|shift|mean|rstd] (4 x 64 f32); bf16 only.
  */
 int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, int F, int T, const void* y, const float* aff,
-                               double* red, void* stream);
+                               double* red, int y_dtype, void* stream);     /* y_dtype: bf16 | fp16 (dy, w, dz: bf16) */
 /*      measurement aid (no reference counterpart): buf = device memory, 5 slots x 4 u64; thread 0 of workgroup 0 of every bf16 3x3
  *      forward / data-gradient launch stores {s_memtime, s_memrealtime} at kernel entry and exit into the slot of its variant (0 forward
  *      with BN prologue, 1 data gradient, 2 data gradient + BN sums, 3 forward from the 4-channel input, 4 data gradient consumed in its
@@ -128,9 +135,9 @@ int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int
                          const float* shift, float* dW, float* partial, int precise, void* stream);
 /*      bf16: the weight gradient ADDED straight into the f32 (64,64,3,3) parameter-gradient buffer (nn.Conv2d layout) */
 int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb, int F, int T, const float* scale, const float* shift,
-                             float* grad_oihw, float* partial, void* stream);
+                             float* grad_oihw, float* partial, int z_dtype, void* stream);      /* z_dtype: bf16 | fp16 (dy: bf16) */
 /*      re-laid-out operands of the stem convolutions, one launch each (they follow the weights every step): conv_taps: (64,64,3,3)
- *      f32 -> fwd [9][co][ci] and dgr [9][ci][co] with flipped taps, f32 | bf16; patch_w: the frame-patch conv weight (d,4,F,1)
+ *      f32 -> fwd [9][co][ci] and dgr [9][ci][co] with flipped taps, f32 | bf16 | mixed 16 (fwd fp16, dgr bf16); patch_w: the frame-patch conv weight (d,4,F,1)
  *      (code/model.py:63) -> GEMM operand [d][f*4+c]; patch_wgrad_accum: grad (d,4,F,1) += sum over the nslice
  *      split-K partial products g [nslice][d][f*4+c]. */
 int sarssl_conv_taps(const float* W, void* fwd, void* dgr, int dtype, void* stream);
@@ -148,16 +155,16 @@ int sarssl_stem_c1_stats_affine(const void* a0, long npix, const float* W1, doub
                                 float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* aff,
                                 int dtype, void* stream);
 int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const float* scale, const float* shift, const void* w, void* out,
-                          int nb, int F, int T, double* stats, void* stream);
+                          int nb, int F, int T, double* stats, int dtype, void* stream);      /* dtype of a0 / w / out: bf16 | fp16 */
 int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const float* W1, int nb, int F, int T, const float* scale,
-                                const float* shift, float* grad_oihw, float* partial, void* stream);
+                                const float* shift, float* grad_oihw, float* partial, int a0_dtype, void* stream);
 int sarssl_stem_c1_bwd_a0(const void* dz1, const void* a0, const float* W1, long npix, const float* aff, int use_stats,
-                          double* red, float* dW1, float* dgamma, float* dbeta, void* stream);
+                          double* red, float* dW1, float* dgamma, float* dbeta, int dtype, void* stream);     /* bf16 | mixed 16 (a0 fp16) */
 /* conv3x3_dgrad_c1red: data gradient of patch_embed[3] consumed in its epilogue (masked with relu'(bn1(W1 a0)) and contracted over the
  * pixels against [a0 | 1] on the matrix cores): red f64[644] gets G at [co*4+c] and s1 at [512+co], nothing is stored;
  * stem_c1_bwd_finalize_mom completes dW1 / dgamma / dbeta from (red, the input's moments mom14 of sarssl_stem_c1_stats). */
 int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const void* a0, const float* W1, const float* scale, const float* shift,
-                               int nb, int F, int T, double* red, void* stream);
+                               int nb, int F, int T, double* red, int a0_dtype, void* stream);
 int sarssl_stem_c1_bwd_finalize_mom(const double* red, const double* mom14, const float* W1, long npix, const float* aff, int use_stats,
                                     float* dW1, float* dgamma, float* dbeta, void* stream);
 int sarssl_stem_c4_fwd(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
@@ -277,7 +284,8 @@ int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char*
                           int nm, float gscale, const float* gscale_dev, void* dpred, int dtype, void* stream);
 
 /* ---- optimiser: torch.optim.Adam(betas=(0.9,0.999), weight_decay=0) at code/learner.py:83, over one flat buffer */
-int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, long n, float gscale, float lr, float beta1,
+/*      p16 / ph16 (either may be null): bf16 / fp16 shadow copies of the updated parameters, the GEMM / convolution operands */
+int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr, float beta1,
                      float beta2, float eps, int step, void* stream);
 
 /* ---- device-resident step state: what varies from step to step when the whole step (code/learner.py:93-115: forward, backward,
@@ -291,8 +299,8 @@ int sarssl_step_state_init(void* state, unsigned long long salt, float lr, float
 int sarssl_step_state_reset(void* state, float lr, float beta1, float beta2, void* stream);
 int sarssl_step_state_attach(void* state);
 int sarssl_step_tick(void* state, void* stream);
-int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, long n, float gscale, const void* state, float eps,
-                         int zero_grad, void* stream);
+int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, const void* state,
+                         float eps, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,11 @@ def _to_rt(x):
     return x if x.dtype == RT.dtype else hip.cast(x.contiguous(), RT.dtype)
 
 
+def _to_g(dy):
+    """incoming gradient in the backward pass's storage dtype (bf16 next to fp16 activations)"""
+    return dy if dy.dtype == RT.gdtype else hip.cast(dy.contiguous(), RT.gdtype)
+
+
 class _TapeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fwd, bwd, x, *params):
@@ -22,12 +27,17 @@ class _TapeFn(torch.autograd.Function):
         saved = []
         y = fwd(_to_rt(x.detach().contiguous()), saved)
         ctx.bwd, ctx.saved, ctx.in_dtype, ctx.nparams = bwd, saved, x.dtype, len(params)
+        if y.dtype == torch.float16:
+            # node boundary of the fp16-forward mode: torch.autograd hands a node the gradient in its OUTPUT's dtype, and a gradient
+            # must never travel as fp16 (1e-7-sized values: below fp16's range, there is no loss scaling) - the output leaves as f32
+            # (exact), the next node's forward re-encodes it (exact round trip), gradients between nodes are f32
+            y = hip.cast(y.contiguous(), torch.float32)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         hip.sums_arena_reset(dy.device)
-        dx = ctx.bwd(_to_rt(dy.contiguous()), ctx.saved)
+        dx = ctx.bwd(_to_g(dy.contiguous()), ctx.saved)
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = hip.cast(dx.contiguous(), ctx.in_dtype)
         return (None, None, dx) + (None,) * ctx.nparams

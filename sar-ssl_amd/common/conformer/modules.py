@@ -6,7 +6,7 @@ import torch.nn.init as init
 
 from ... import engine
 from ...autograd import tape_apply
-from ...runtime import wt, gbuf
+from ...runtime import wt, wtg, gbuf
 from ... import hip
 
 
@@ -52,7 +52,7 @@ class Linear(nn.Module):
             engine.mm_tn_acc(d2, x2, gbuf(lin.weight))
             if lin.bias is not None:
                 hip.colsum(d2, gbuf(lin.bias))
-            return engine.mm_nn(d2, wt(lin.weight)).view(*lead, -1)
+            return engine.mm_nn(d2, wtg(lin.weight)).view(*lead, -1)
         return tape_apply(self, fwd, bwd, x)
 
 

@@ -10,7 +10,7 @@ void sarssl_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char* sarssl_last_error() { return g_err; }
-extern "C" int sarssl_abi_version() { return 1; }
+extern "C" int sarssl_abi_version() { return 2; }      // 2: fp16 / mixed-16 dtypes, dtype arguments of the 16-bit-only entry points
 
 // Device probe: returns 0 and fills name/arch info when a gfx950 device is usable.
 extern "C" int sarssl_device_info(int device, char* name_out, int name_len, int* cu_count, long* lds_bytes) {

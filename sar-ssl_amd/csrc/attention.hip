@@ -14,19 +14,24 @@
 // Dropout uses the library's counter hash on the element index ((b*H + h)*T + i)*T + j, recomputed identically in backward.
 #include "common.h"
 
+// 16-bit tensors are passed as element pointers; the kernels' template parameter TA says how the FORWARD tensors (qu, k, v, bias,
+// ctx) are encoded: bf16, or fp16 in the fp16-forward mode - there the forward kernel contracts fp16 operands
+// (v_mfma_f32_32x32x16_f16), the backward kernels recompute the scores on the same fp16 operands and re-encode k / v / q to bf16
+// while staging them for the products with the (always bf16) gradients.
+typedef uint16_t h16;
 struct AttnArgs {
-    const bf16* qu; long ldq;          // [B*T][ldq]: q + u_bias, head h at column h*DH
-    const bf16* k; const bf16* v; long ldk;
-    const bf16* bias;                  // (B,H,T,T) shifted positional score (unscaled)
-    bf16* ctx; long ldc;               // [B*T][ldc]
+    const h16* qu; long ldq;           // [B*T][ldq]: q + u_bias, head h at column h*DH
+    const h16* k; const h16* v; long ldk;
+    const h16* bias;                   // (B,H,T,T) shifted positional score (unscaled)
+    h16* ctx; long ldc;                // [B*T][ldc]
     float* ctx32;                      // [B*T][H*DH] f32 copy of ctx before rounding (forward out, backward in): D_i = dctx_i . ctx_i
                                        // enters dS as a small difference (flat softmax: 1/sqrt(d_model) scaling), so it must not
                                        // carry the bf16 rounding of ctx
     float* lse;                        // (B,H,T): log2-domain log-sum-exp of the scaled scores
-    const bf16* dctx; long lddc;       // backward: gradient of ctx
-    bf16* dqu; long lddq;              // backward outputs
-    bf16* dk; bf16* dv; long lddk;
-    bf16* dbias;                       // (B,H,T,T): gradient of the shifted positional score
+    const h16* dctx; long lddc;        // backward: gradient of ctx (bf16)
+    h16* dqu; long lddq;               // backward outputs (bf16)
+    h16* dk; h16* dv; long lddk;
+    h16* dbias;                        // (B,H,T,T): gradient of the shifted positional score (bf16)
     float* dsum;                       // (B,H,T): D_i = sum_c dctx * ctx, written by the dQ kernel, read by the dK / dV kernel
     int B, H, T;
     float scale, p_drop; unsigned long long seed;
@@ -34,6 +39,7 @@ struct AttnArgs {
 };
 
 #define LOG2E 1.4426950408889634f
+
 // v_exp_f32 as is: exp2f() wraps it in a denormal-range rescue (compare, two selects, add, ldexp: 7 instructions per probability);
 // a probability below 2^-126 is zero for every purpose here
 __device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -52,13 +58,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* s, int kbase, int r0, 
 }
 
 // Accumulator fragment (lane = row, 16 values = columns 8g + 4*half + e of a 32-column block) -> the two MFMA operand fragments
-// (8 consecutive columns at offset half*8 of each 16-column step) of the same 32 columns, in bf16.
+// (8 consecutive columns at offset half*8 of each 16-column step) of the same 32 columns, encoded as T.
+template <typename T>
 __device__ __forceinline__ void acc_to_operand(const f32x16& p, bf16x8 (&out)[2]) {
     uint32_t w[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        w[g][0] = pack2_bf16(p[4 * g + 0], p[4 * g + 1]);
-        w[g][1] = pack2_bf16(p[4 * g + 2], p[4 * g + 3]);
+        w[g][0] = H16<T>::pack(p[4 * g + 0], p[4 * g + 1]);
+        w[g][1] = H16<T>::pack(p[4 * g + 2], p[4 * g + 3]);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -110,7 +117,7 @@ struct AttnDrop {
 // ------------------------------------------------------------------------------------------------------------------- forward
 // (d_head <= 64: capped at 256 registers - 243 used, no spills - so that TWO workgroups share a CU: the kernel is a chain of
 //  latencies (K / V / bias tiles, softmax exchanges) and ran one wave per SIMD at 263 registers)
-template <int DH>
+template <int DH, typename TA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
     constexpr int PK = DH + 8, PV = DH + 32, PB = TK + 8;
@@ -124,12 +131,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const int i0 = blockIdx.x * TQ;
     const int i = i0 + wave * 32 + (lane & 31);               // this lane's query row
     const bool row_ok = i < T;
-    const bf16* K = a.k + (long)b * T * a.ldk + h * DH;
-    const bf16* V = a.v + (long)b * T * a.ldk + h * DH;
-    const bf16* Bi = a.bias + (long)bh * T * T;
+    const h16* K = a.k + (long)b * T * a.ldk + h * DH;
+    const h16* V = a.v + (long)b * T * a.ldk + h * DH;
+    const h16* Bi = a.bias + (long)bh * T * T;
     bf16x8 fq[DH / 16];
     {
-        const bf16* q = a.qu + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
+        const h16* q = a.qu + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
             uint4 u = row_ok ? *(const uint4*)(q + s * 16) : make_uint4(0, 0, 0, 0);
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 const bf16x8 kf = *(const bf16x8*)&sK[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
-                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, fq[st], s[f], 0, 0, 0);
+                s[f] = mfma16<TA>(kf, fq[st], s[f]);
             }
         // ---- scores in the log2 domain, masks, running max
         float mx = -INFINITY;
@@ -205,8 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
             for (int g = 0; g < 4; ++g) {
                 const int jl = f * 32 + 8 * g + 4 * half;
                 const uint2 bu = *(const uint2*)&sB[(wave * 32 + (lane & 31)) * PB + jl];
-                const float bv[4] = {bf16_bits_to_f32(bu.x & 0xffffu), __uint_as_float(bu.x & 0xffff0000u),
-                                     bf16_bits_to_f32(bu.y & 0xffffu), __uint_as_float(bu.y & 0xffff0000u)};
+                const float bv[4] = {H16<TA>::lo(bu.x), H16<TA>::hi(bu.x), H16<TA>::lo(bu.y), H16<TA>::hi(bu.y)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int j = j0 + jl + e;
@@ -249,13 +255,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             bf16x8 pf[2];
-            acc_to_operand(s[f], pf);
+            acc_to_operand<TA>(s[f], pf);
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
                 for (int c = 0; c < DH / 32; ++c) {
                     const bf16x8 vf = tr_frag<PV>(sV, f * 32 + st * 16, c * 32, lane);
-                    o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o[c], 0, 0, 0);
+                    o[c] = mfma16<TA>(vf, pf[st], o[c]);
                 }
         }
         __syncthreads();
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const float inv_l = 1.0f / l_tot;
     if (row_ok) {
         if (half == 0 && a.lse) a.lse[(long)bh * T + i] = m_run + log2f(l_tot);
-        bf16* out = a.ctx + ((long)b * T + i) * a.ldc + h * DH;
+        h16* out = a.ctx + ((long)b * T + i) * a.ldc + h * DH;
         float* out32 = a.ctx32 ? a.ctx32 + ((long)b * T + i) * ((long)a.H * DH) + h * DH : nullptr;
 #pragma unroll
         for (int c = 0; c < DH / 32; ++c)
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
             for (int g = 0; g < 4; ++g) {
                 const float4 v = make_float4(o[c][4 * g + 0] * inv_l, o[c][4 * g + 1] * inv_l, o[c][4 * g + 2] * inv_l, o[c][4 * g + 3] * inv_l);
                 uint2 u;
-                u.x = pack2_bf16(v.x, v.y);
-                u.y = pack2_bf16(v.z, v.w);
+                u.x = H16<TA>::pack(v.x, v.y);
+                u.y = H16<TA>::pack(v.z, v.w);
                 *(uint2*)(out + c * 32 + 8 * g + 4 * half) = u;
                 if (out32) *(float4*)(out32 + c * 32 + 8 * g + 4 * half) = v;
             }
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 }
 
 // ---------------------------------------------------------------------------- backward, part 1: D, dQ and d(bias), per query tile
-template <int DH>
+template <int DH, typename TA>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 2 : 1))) void relpos_attn_bwd_q_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
     constexpr int PK = DH + 8, PT = DH + 32, PB = TK + 8;
@@ -296,15 +302,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const int i0 = blockIdx.x * TQ;
     const int i = i0 + wave * 32 + (lane & 31);
     const bool row_ok = i < T;
-    const bf16* K = a.k + (long)b * T * a.ldk + h * DH;
-    const bf16* V = a.v + (long)b * T * a.ldk + h * DH;
-    const bf16* Bi = a.bias + (long)bh * T * T;
-    bf16* dBi = a.dbias + (long)bh * T * T;
+    const h16* K = a.k + (long)b * T * a.ldk + h * DH;
+    const h16* V = a.v + (long)b * T * a.ldk + h * DH;
+    const h16* Bi = a.bias + (long)bh * T * T;
+    h16* dBi = a.dbias + (long)bh * T * T;
     bf16x8 fq[DH / 16], fdo[DH / 16];
     float dpart = 0.f;
     {
-        const bf16* q = a.qu + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
-        const bf16* d = a.dctx + ((long)b * T + (row_ok ? i : 0)) * a.lddc + h * DH + half * 8;
+        const h16* q = a.qu + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
+        const h16* d = a.dctx + ((long)b * T + (row_ok ? i : 0)) * a.lddc + h * DH + half * 8;
         // D_i = dctx_i . ctx_i (the unrounded f32 context): this lane holds half of the row's dctx chunks anyway - the stand-alone
         // pass over dctx / ctx32 (17-19 us per layer) is gone; the row's value is stored for the dK / dV kernel that follows
         const float* c32 = a.ctx32 + ((long)b * T + (row_ok ? i : 0)) * ((long)a.H * DH) + h * DH + half * 8;
@@ -358,9 +364,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
         for (int c = 0; c < NKV; ++c) {
             const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-            *(uint4*)&sK[row * PK + c8 * 8] = rk[c];
-            *(uint4*)&sKt[row * PT + c8 * 8] = rk[c];
-            *(uint4*)&sV[row * PK + c8 * 8] = rv[c];
+            *(uint4*)&sK[row * PK + c8 * 8] = rk[c];                         // as saved: the scores are recomputed on the forward's operands
+            *(uint4*)&sKt[row * PT + c8 * 8] = recode8<TA, bf16>(rk[c]);     // bf16 copies meet the bf16 gradients (dQ += dS K, dP = dO V^T)
+            *(uint4*)&sV[row * PK + c8 * 8] = recode8<TA, bf16>(rv[c]);
         }
 #pragma unroll
         for (int c = 0; c < NBI; ++c) {
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
             for (int f = 0; f < 2; ++f) {
                 const bf16x8 kf = *(const bf16x8*)&sK[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
                 const bf16x8 vf = *(const bf16x8*)&sV[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
-                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, fq[st], s[f], 0, 0, 0);
+                s[f] = mfma16<TA>(kf, fq[st], s[f]);
                 dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, fdo[st], dp[f], 0, 0, 0);
             }
         // dScore = scale * p * (keep * dP - D)   (lane = query row, registers = keys); staged to LDS as the d(bias) tile
@@ -391,8 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                 const int jl = f * 32 + 8 * g + 4 * half;
                 uint16_t* bp = &sB[(wave * 32 + (lane & 31)) * PB + jl];
                 const uint2 bu = *(const uint2*)bp;
-                const float bv[4] = {bf16_bits_to_f32(bu.x & 0xffffu), __uint_as_float(bu.x & 0xffff0000u),
-                                     bf16_bits_to_f32(bu.y & 0xffffu), __uint_as_float(bu.y & 0xffff0000u)};
+                const float bv[4] = {H16<TA>::lo(bu.x), H16<TA>::hi(bu.x), H16<TA>::lo(bu.y), H16<TA>::hi(bu.y)};
                 float ds[4];
                 float kp[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (a.p_drop > 0.f) drop.keep4(rowbase + (unsigned long long)(j0 + jl), kp);
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             bf16x8 pf[2];
-            acc_to_operand(s[f], pf);
+            acc_to_operand<bf16>(s[f], pf);
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
         __syncthreads();
     }
     if (row_ok) {
-        bf16* out = a.dqu + ((long)b * T + i) * a.lddq + h * DH;
+        h16* out = a.dqu + ((long)b * T + i) * a.lddq + h * DH;
 #pragma unroll
         for (int c = 0; c < DH / 32; ++c)
 #pragma unroll
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 
 // ---------------------------------------------------------------------------- backward, part 2: dK and dV, per key tile
 // One workgroup per (batch, head, 128 keys), one wave per 32 keys; loops over 64-query tiles.  Lane = key row.
-template <int DH>
+template <int DH, typename TA>
 __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
     constexpr int TKB = 128, TQ = 64;
     constexpr int PK = DH + 8, PT = DH + 32, PB = TKB + 8;
@@ -466,17 +471,17 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
     const int j0 = blockIdx.x * TKB;
     const int j = j0 + wave * 32 + (lane & 31);                // this lane's key row
     const bool key_ok = j < T;
-    const bf16* Q = a.qu + (long)b * T * a.ldq + h * DH;
-    const bf16* DO = a.dctx + (long)b * T * a.lddc + h * DH;
-    const bf16* Bi = a.bias + (long)bh * T * T;
+    const h16* Q = a.qu + (long)b * T * a.ldq + h * DH;
+    const h16* DO = a.dctx + (long)b * T * a.lddc + h * DH;
+    const h16* Bi = a.bias + (long)bh * T * T;
     bf16x8 fk[DH / 16], fv[DH / 16];
     {
-        const bf16* kp = a.k + ((long)b * T + (key_ok ? j : 0)) * a.ldk + h * DH + half * 8;
-        const bf16* vp = a.v + ((long)b * T + (key_ok ? j : 0)) * a.ldk + h * DH + half * 8;
+        const h16* kp = a.k + ((long)b * T + (key_ok ? j : 0)) * a.ldk + h * DH + half * 8;
+        const h16* vp = a.v + ((long)b * T + (key_ok ? j : 0)) * a.ldk + h * DH + half * 8;
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
             fk[s] = __builtin_bit_cast(bf16x8, key_ok ? *(const uint4*)(kp + s * 16) : make_uint4(0, 0, 0, 0));
-            fv[s] = __builtin_bit_cast(bf16x8, key_ok ? *(const uint4*)(vp + s * 16) : make_uint4(0, 0, 0, 0));
+            fv[s] = __builtin_bit_cast(bf16x8, recode8<TA, bf16>(key_ok ? *(const uint4*)(vp + s * 16) : make_uint4(0, 0, 0, 0)));   // meets dO (bf16)
         }
     }
     f32x16 dk[DH / 32], dv[DH / 32];
@@ -519,8 +524,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < NQD; ++c) {
             const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-            *(uint4*)&sQ[row * PK + c8 * 8] = rq[c];
-            *(uint4*)&sQt[row * PT + c8 * 8] = rq[c];
+            *(uint4*)&sQ[row * PK + c8 * 8] = rq[c];                         // as saved (score recomputation)
+            *(uint4*)&sQt[row * PT + c8 * 8] = recode8<TA, bf16>(rq[c]);     // bf16 copy for dK += dS^T Q
             *(uint4*)&sDO[row * PK + c8 * 8] = rd[c];
             *(uint4*)&sDOt[row * PT + c8 * 8] = rd[c];
         }
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
             for (int f = 0; f < 2; ++f) {
                 const bf16x8 qf = *(const bf16x8*)&sQ[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
                 const bf16x8 df = *(const bf16x8*)&sDO[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
-                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, fk[st], s[f], 0, 0, 0);
+                s[f] = mfma16<TA>(qf, fk[st], s[f]);
                 dp[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, fv[st], dp[f], 0, 0, 0);
             }
         // P (dropped, for dV) -> dp registers are reused for it after dS has been formed in s
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int il = f * 32 + 8 * (r >> 2) + 4 * half + (r & 3);     // query row inside the tile
                 const int i = i0 + il;
-                const float bv = bf16_bits_to_f32(sB[il * PB + wave * 32 + (lane & 31)]);
+                const float bv = H16<TA>::lo(sB[il * PB + wave * 32 + (lane & 31)]);
                 const float x = (s[f][r] + (j == i + 1 ? 0.f : bv)) * sc2;
                 const float p = (i < T && key_ok) ? exp2_raw(x - sStat[il]) : 0.f;
                 float keep = 1.0f;
@@ -566,8 +571,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             bf16x8 sf[2], pf[2];
-            acc_to_operand(s[f], sf);
-            acc_to_operand(dp[f], pf);
+            acc_to_operand<bf16>(s[f], sf);
+            acc_to_operand<bf16>(dp[f], pf);
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -581,8 +586,8 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
         __syncthreads();
     }
     if (key_ok) {
-        bf16* ok_ = a.dk + ((long)b * T + j) * a.lddk + h * DH;
-        bf16* ov_ = a.dv + ((long)b * T + j) * a.lddk + h * DH;
+        h16* ok_ = a.dk + ((long)b * T + j) * a.lddk + h * DH;
+        h16* ov_ = a.dv + ((long)b * T + j) * a.lddk + h * DH;
 #pragma unroll
         for (int c = 0; c < DH / 32; ++c)
 #pragma unroll
@@ -613,17 +618,23 @@ extern "C" int sarssl_relpos_attn_supported(int T, int dh) { return (T > 0 && T 
 // ctx: bf16 [B*T][ldc]; ctx32 (optional, needed for backward): f32 [B*T][H*dh]; lse: f32 (B,H,T) (log2 domain, saved for backward).
 extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, void* ctx,
                                       long ldc, float* ctx32, float* lse, int B, int H, int T, int dh, float scale, float p_drop,
-                                      unsigned long long seed, void* stream) {
+                                      unsigned long long seed, int dtype, void* stream) {
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_fwd")) return -1;
-    SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr, "sarssl_relpos_attn_fwd");
+    SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr && (dtype == SARSSL_BF16 || dtype == SARSSL_F16), "sarssl_relpos_attn_fwd");
     AttnArgs a = {};
-    a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
-    a.ctx = (bf16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
+    a.qu = (const h16*)qu; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk; a.bias = (const h16*)bias;
+    a.ctx = (h16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     dim3 grid((T + 127) / 128, B * H);
     hipStream_t st = (hipStream_t)stream;
-    if (dh == 128) relpos_attn_fwd_kernel<128><<<grid, 256, 0, st>>>(a);
-    else if (dh == 64) relpos_attn_fwd_kernel<64><<<grid, 256, 0, st>>>(a);
-    else relpos_attn_fwd_kernel<32><<<grid, 256, 0, st>>>(a);
+    if (dtype == SARSSL_F16) {
+        if (dh == 128) relpos_attn_fwd_kernel<128, f16><<<grid, 256, 0, st>>>(a);
+        else if (dh == 64) relpos_attn_fwd_kernel<64, f16><<<grid, 256, 0, st>>>(a);
+        else relpos_attn_fwd_kernel<32, f16><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (dh == 128) relpos_attn_fwd_kernel<128, bf16><<<grid, 256, 0, st>>>(a);
+        else if (dh == 64) relpos_attn_fwd_kernel<64, bf16><<<grid, 256, 0, st>>>(a);
+        else relpos_attn_fwd_kernel<32, bf16><<<grid, 256, 0, st>>>(a);
+    }
     SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel");
     return 0;
 }
@@ -633,19 +644,24 @@ extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, c
 extern "C" int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias,
                                       const float* ctx32, const float* lse, const void* dctx, long lddc, void* dqu, long lddq,
                                       void* dk, void* dv, long lddk, void* dbias, float* dsum, int B, int H, int T, int dh,
-                                      float scale, float p_drop, unsigned long long seed, void* stream) {
+                                      float scale, float p_drop, unsigned long long seed, int dtype, void* stream) {
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_bwd")) return -1;
+    SARSSL_REQUIRE(dtype == SARSSL_BF16 || dtype == SARSSL_MIX16, "sarssl_relpos_attn_bwd(dtype: bf16, or MIX16 = fp16 forward tensors + bf16 gradients)");
     SARSSL_REQUIRE(lddc % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && dsum != nullptr && lse != nullptr && ctx32 != nullptr, "sarssl_relpos_attn_bwd");
     AttnArgs a = {};
-    a.qu = (const bf16*)qu; a.ldq = ldq; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ldk = ldk; a.bias = (const bf16*)bias;
-    a.ctx32 = (float*)ctx32; a.lse = (float*)lse; a.dctx = (const bf16*)dctx; a.lddc = lddc;
-    a.dqu = (bf16*)dqu; a.lddq = lddq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.lddk = lddk; a.dbias = (bf16*)dbias; a.dsum = dsum;
+    a.qu = (const h16*)qu; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk; a.bias = (const h16*)bias;
+    a.ctx32 = (float*)ctx32; a.lse = (float*)lse; a.dctx = (const h16*)dctx; a.lddc = lddc;
+    a.dqu = (h16*)dqu; a.lddq = lddq; a.dk = (h16*)dk; a.dv = (h16*)dv; a.lddk = lddk; a.dbias = (h16*)dbias; a.dsum = dsum;
     a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     hipStream_t st = (hipStream_t)stream;
     dim3 gq((T + 127) / 128, B * H), gk((T + 127) / 128, B * H);
-    if (dh == 128) { relpos_attn_bwd_q_kernel<128><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<128><<<gk, 256, 0, st>>>(a); }
-    else if (dh == 64) { relpos_attn_bwd_q_kernel<64><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<64><<<gk, 256, 0, st>>>(a); }
-    else { relpos_attn_bwd_q_kernel<32><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<32><<<gk, 256, 0, st>>>(a); }
+#define ATTN_BWD(DHv, TAv) do { relpos_attn_bwd_q_kernel<DHv, TAv><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<DHv, TAv><<<gk, 256, 0, st>>>(a); } while (0)
+    if (dtype == SARSSL_MIX16) {
+        if (dh == 128) ATTN_BWD(128, f16); else if (dh == 64) ATTN_BWD(64, f16); else ATTN_BWD(32, f16);
+    } else {
+        if (dh == 128) ATTN_BWD(128, bf16); else if (dh == 64) ATTN_BWD(64, bf16); else ATTN_BWD(32, bf16);
+    }
+#undef ATTN_BWD
     SARSSL_CHECK_LAUNCH("relpos_attn_bwd_kernel");
     return 0;
 }

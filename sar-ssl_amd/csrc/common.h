@@ -9,7 +9,14 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2 };
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// dtype codes of the C ABI (include/sarssl_hip.h).  SARSSL_F16: IEEE half.  SARSSL_MIX16 (kernels with both gradient-side and
+// saved-activation-side 16-bit tensors): gradients in / out are bf16, tensors SAVED BY THE FORWARD PASS are fp16 - the "fp16 forward /
+// bf16 backward" numeric mode (fp16 carries 3 more mantissa bits than bf16 at the same MFMA rate: per-bin deviation from the
+// reference's f32 path 8e-3 -> 1e-3 of range; gradients keep bf16's exponent range, so there is no loss scaling)
+enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2, SARSSL_F16 = 3, SARSSL_MIX16 = 4 };
 
 // error plumbing (api.cpp owns the storage)
 extern "C" const char* sarssl_last_error();
@@ -55,7 +62,29 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sarssl_bf16x2));
 }
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) { return pack2_bf16(f, 0.f) & 0xffffu; }
+// fp16 <-> f32: v_cvt_f32_f16 (the high half through SDWA: one VALU op per element, like the bf16 shift / mask), v_cvt_pk_f16_f32 (RNE)
+typedef _Float16 sarssl_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+    sarssl_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sarssl_f16x2));
+}
+__device__ __forceinline__ sarssl_f32x2 unpack2_f16(uint32_t w) { return __builtin_convertvector(__builtin_bit_cast(sarssl_f16x2, w), sarssl_f32x2); }
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t b) { return unpack2_f16(b).x; }
+// 16-bit storage traits: two elements per 32-bit word
+template <typename T> struct H16;
+template <> struct H16<bf16> {
+    static __device__ __forceinline__ float lo(uint32_t w) { return bf16_bits_to_f32(w & 0xffffu); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack2_bf16(a, b); }
+};
+template <> struct H16<f16> {
+    static __device__ __forceinline__ float lo(uint32_t w) { return unpack2_f16(w).x; }
+    static __device__ __forceinline__ float hi(uint32_t w) { return unpack2_f16(w).y; }
+    static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack2_f16(a, b); }
+};
 __device__ __forceinline__ float ld_f(const float* p) { return *p; }
+__device__ __forceinline__ float ld_f(const f16* p) { return (float)*p; }
+__device__ __forceinline__ void st_f(f16* p, float v) { *p = (f16)v; }
 __device__ __forceinline__ float ld_f(const bf16* p) { return bf16_bits_to_f32(*(const uint16_t*)p); }
 __device__ __forceinline__ void st_f(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st_f(bf16* p, float v) { *(uint16_t*)p = (uint16_t)f32_to_bf16_bits(v); }
@@ -66,6 +95,17 @@ __device__ __forceinline__ float4 ld4(const bf16* p) {
     uint2 u = *(const uint2*)p;
     return make_float4(bf16_bits_to_f32(u.x & 0xffffu), __uint_as_float(u.x & 0xffff0000u),
                        bf16_bits_to_f32(u.y & 0xffffu), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 ld4(const f16* p) {
+    uint2 u = *(const uint2*)p;
+    const sarssl_f32x2 a = unpack2_f16(u.x), b = unpack2_f16(u.y);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void st4(f16* p, float4 v) {
+    uint2 u;
+    u.x = pack2_f16(v.x, v.y);
+    u.y = pack2_f16(v.z, v.w);
+    *(uint2*)p = u;
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
 __device__ __forceinline__ void st4(bf16* p, float4 v) {
@@ -89,6 +129,35 @@ __device__ __forceinline__ f8 ld8(const bf16* p) {
     r.v[6] = bf16_bits_to_f32(u.w & 0xffffu); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
     return r;
 }
+// 8 packed 16-bit elements <-> 8 floats
+template <typename T>
+__device__ __forceinline__ f8 unpack8(const uint4& u) {
+    f8 r;
+    r.v[0] = H16<T>::lo(u.x); r.v[1] = H16<T>::hi(u.x); r.v[2] = H16<T>::lo(u.y); r.v[3] = H16<T>::hi(u.y);
+    r.v[4] = H16<T>::lo(u.z); r.v[5] = H16<T>::hi(u.z); r.v[6] = H16<T>::lo(u.w); r.v[7] = H16<T>::hi(u.w);
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const f8& r) {
+    uint4 u;
+    u.x = H16<T>::pack(r.v[0], r.v[1]); u.y = H16<T>::pack(r.v[2], r.v[3]);
+    u.z = H16<T>::pack(r.v[4], r.v[5]); u.w = H16<T>::pack(r.v[6], r.v[7]);
+    return u;
+}
+// x as it reads back after being stored as T (statistics of STORED tensors must see the rounded values)
+template <typename T> __device__ __forceinline__ float round_as(float x) {
+    if constexpr (sizeof(T) == 4) return x;
+    else if constexpr (__is_same(T, f16)) return (float)(f16)x;
+    else return bf16_bits_to_f32(f32_to_bf16_bits(x));
+}
+// 16-byte chunk of TS elements re-encoded as TD (identity when the types agree): saved fp16 activations entering a bf16 contraction
+template <typename TS, typename TD>
+__device__ __forceinline__ uint4 recode8(const uint4& u) {
+    if constexpr (sizeof(TS) == sizeof(TD) && __is_same(TS, TD)) return u;
+    else return pack8<TD>(unpack8<TS>(u));
+}
+__device__ __forceinline__ f8 ld8(const f16* p) { return unpack8<f16>(*(const uint4*)p); }
+__device__ __forceinline__ void st8(f16* p, const f8& r) { *(uint4*)p = pack8<f16>(r); }
 __device__ __forceinline__ void st8(float* p, const f8& r) {
     *(float4*)p = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
     *(float4*)(p + 4) = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);
@@ -100,6 +169,13 @@ __device__ __forceinline__ void st8(bf16* p, const f8& r) {
     u.z = pack2_bf16(r.v[4], r.v[5]);
     u.w = pack2_bf16(r.v[6], r.v[7]);
     *(uint4*)p = u;
+}
+
+// 32x32x16 MFMA on 16-bit operands of type TM (bf16x8 is the 128-bit fragment carrier for both encodings; same rate)
+template <typename TM>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (__is_same(TM, f16)) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // Split-bf16 ("precise") operand parts: x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi).

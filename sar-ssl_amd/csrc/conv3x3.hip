@@ -76,15 +76,16 @@ __device__ __forceinline__ void c1_setup(C1Const& k, const float* W1, const floa
         for (int c = 0; c < 4; ++c) k.wp[c][h] = sarssl_f32x2{scale[ch] * W1[ch * 4 + c], scale[ch + 1] * W1[(ch + 1) * 4 + c]};
     }
 }
+template <typename TI = bf16, typename TO = TI>      // TI: encoding of the 4-channel input, TO: of the operand written to LDS
 __device__ __forceinline__ uint4 c1_chunk(uint32_t lo, uint32_t hi, bool valid, const C1Const& k) {
     if (!valid) return make_uint4(0, 0, 0, 0);
-    const float a0 = bf16_bits_to_f32(lo & 0xffffu), a1 = __uint_as_float(lo & 0xffff0000u);
-    const float a2 = bf16_bits_to_f32(hi & 0xffffu), a3 = __uint_as_float(hi & 0xffff0000u);
+    const float a0 = H16<TI>::lo(lo), a1 = H16<TI>::hi(lo);
+    const float a2 = H16<TI>::lo(hi), a3 = H16<TI>::hi(hi);
     uint32_t o[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const sarssl_f32x2 y = k.wp[0][h] * a0 + k.wp[1][h] * a1 + k.wp[2][h] * a2 + k.wp[3][h] * a3 + k.shp[h];
-        o[h] = pack2_bf16(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f));
+        o[h] = H16<TO>::pack(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f));
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -97,6 +98,7 @@ __device__ __forceinline__ int swzx(int p, int col, int chunk) { return (p * 8 +
 // raw chunk in registers: 8 channels of one pixel
 template <typename T> struct Chunk;
 template <> struct Chunk<bf16> { uint4 u; };
+template <> struct Chunk<f16> { uint4 u; };
 template <> struct Chunk<float> { f8 v; };
 
 template <typename T>
@@ -124,20 +126,16 @@ __device__ __forceinline__ Chunk<T> load_chunk_clamped(const T* __restrict__ bas
     return load_chunk<T>(base + (((long)b * F + f) * Tn + t) * 64 + c8, true);
 }
 
-// prologue + (split) conversion to 8 bf16
-template <typename T>
+// prologue + conversion to the 8 MFMA-operand elements written to LDS (16-bit storage T -> TO; f32 storage: split bf16 parts)
+template <typename T, typename TO = T>
 __device__ __forceinline__ uint4 xform_chunk(const Chunk<T>& c, bool valid, int prologue, const float* sc, const float* sh, int part) {
     if (!valid) return make_uint4(0, 0, 0, 0);
     if constexpr (sizeof(T) == 2) {
-        if (!prologue) return c.u;
-        f8 v;
-        v.v[0] = bf16_bits_to_f32(c.u.x & 0xffffu); v.v[1] = __uint_as_float(c.u.x & 0xffff0000u);
-        v.v[2] = bf16_bits_to_f32(c.u.y & 0xffffu); v.v[3] = __uint_as_float(c.u.y & 0xffff0000u);
-        v.v[4] = bf16_bits_to_f32(c.u.z & 0xffffu); v.v[5] = __uint_as_float(c.u.z & 0xffff0000u);
-        v.v[6] = bf16_bits_to_f32(c.u.w & 0xffffu); v.v[7] = __uint_as_float(c.u.w & 0xffff0000u);
+        if (!prologue) return recode8<T, TO>(c.u);
+        f8 v = unpack8<T>(c.u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v.v[e] = fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
-        return pack8_part(v, 0);
+        return pack8<TO>(v);
     } else {
         f8 v = c.v;
         if (prologue) {
@@ -437,9 +435,12 @@ __device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& epoch, int
     asm volatile("" ::: "memory");
 }
 
-template <bool BNRED, bool C1IN = false, bool C1RED = false>
+// TM: encoding of the input / weights / LDS operands / output (bf16, or fp16 for the forward launches of the fp16-forward mode);
+// TY: encoding of the tensors SAVED BY THE FORWARD PASS that the gradient epilogues read (bn_y, c1_a0)
+template <bool BNRED, bool C1IN = false, bool C1RED = false, typename TM = bf16, typename TY = bf16>
 __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
-    typedef bf16 T;
+    typedef TM T;
+    static_assert(!C1RED || __is_same(TM, bf16), "gradient launches contract in bf16");
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
     __shared__ float sAff[BNRED ? 256 : 1];
@@ -535,13 +536,13 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         for (int i = 0; i < HR; ++i) {
             const int f = tc.f0 - 1 + i;
             const bool ok = tv && f >= 0 && f < F;
-            *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = C1IN ? c1_chunk(regs[i].u.x, regs[i].u.y, ok, kc1)
+            *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = C1IN ? c1_chunk<T>(regs[i].u.x, regs[i].u.y, ok, kc1)
                                                              : xform_chunk<T>(regs[i], ok, a.prologue, sc, sh, 0);
         }
         if (htid < 160) {
             const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
             const bool ok = f >= 0 && f < F && te < Tn;
-            *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = C1IN ? c1_chunk(regs[HR].u.x, regs[HR].u.y, ok, kc1)
+            *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = C1IN ? c1_chunk<T>(regs[HR].u.x, regs[HR].u.y, ok, kc1)
                                                                                        : xform_chunk<T>(regs[HR], ok, a.prologue, sc, sh, 0);
         }
     };
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<TM>(wf[cur][i], xf[cur][j], acc[i][j]);
             }
             if (a.prio) __builtin_amdgcn_s_setprio(0);
         }
@@ -650,6 +651,13 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
         if (C1RED) {
             // (1) mask: pre-activation tile of the first layer in the accumulators' own layout (co x pixel), one MFMA per tile
             __builtin_amdgcn_s_waitcnt(0x0F70);                // av landed (the next tile's prefetch too: it had the whole MFMA loop)
+            if constexpr (!__is_same(TY, bf16)) {              // saved fp16 input -> the bf16 operand of the two first-layer contractions below
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    av[j].x = pack2_bf16(H16<TY>::lo(av[j].x), H16<TY>::hi(av[j].x));
+                    av[j].y = pack2_bf16(H16<TY>::lo(av[j].y), H16<TY>::hi(av[j].y));
+                }
+            }
             uint16_t* a0t = sX + 4 * (64 * 64) + hw * 256;     // [4 c][64 px] of this wave, in the part of the input tile no slice uses
             {
                 const int j = lane >> 5;                       // lanes < 32 file row 0, lanes >= 32 row 1 (both hold both rows' pixels)
@@ -717,8 +725,8 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     uint2 w2;
-                    w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
-                    w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                    w2.x = H16<TM>::pack(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+                    w2.y = H16<TM>::pack(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
                     *(uint2*)(q + j * 32 * 64) = w2;
                 }
             }
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                     const uint32_t w[4] = {o[k].x, o[k].y, o[k].z, o[k].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        const float lo = H16<TM>::lo(w[q]), hi = H16<TM>::hi(w[q]);
                         ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
                     }
                 }
@@ -764,7 +772,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float d0 = bf16_bits_to_f32(w[q] & 0xffffu), d1 = __uint_as_float(w[q] & 0xffff0000u);
-                        const float y0 = bf16_bits_to_f32(yw[q] & 0xffffu), y1 = __uint_as_float(yw[q] & 0xffff0000u);
+                        const float y0 = H16<TY>::lo(yw[q]), y1 = H16<TY>::hi(yw[q]);
                         const float t0_ = __uint_as_float(__float_as_uint(y0) ^ (((bsgn >> (2 * q)) & 1u) << 31));
                         const float t1_ = __uint_as_float(__float_as_uint(y1) ^ (((bsgn >> (2 * q + 1)) & 1u) << 31));
                         const float g0 = t0_ > bthr[2 * q] ? d0 : 0.f, g1 = t1_ > bthr[2 * q + 1] ? d1 : 0.f;
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
                     const uint32_t w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        const float lo = H16<TM>::lo(w[q]), hi = H16<TM>::hi(w[q]);
                         ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
                     }
                 }
@@ -845,9 +853,10 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
 // (BatchNorm + ReLU or the first-layer prologue), publish it, request the group's next tile.  Staging (2.6 k cycles), its barrier and
 // the prefetch issue (2.1 k) leave the MFMA waves' 16.7 k-cycle iteration.  LDS arrival counters: sReady[g] (4 staging waves per tile),
 // sFree[g] (4 MFMA waves per tile), sSync[g] (the group's own barrier between its MFMA phase and the accumulator hand-over).
-template <bool BNRED, bool C1IN = false, bool C1RED = false>
+template <bool BNRED, bool C1IN = false, bool C1RED = false, typename TM = bf16, typename TY = bf16>
 __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
-    typedef bf16 T;
+    typedef TM T;
+    static_assert(!C1RED || __is_same(TM, bf16), "gradient launches contract in bf16");
     __shared__ __attribute__((aligned(16))) uint16_t sW[W_ELEMS];
     __shared__ __attribute__((aligned(16))) uint16_t sXh[2][PX_ELEMS];
     __shared__ float sAff[BNRED ? 256 : 1];
@@ -933,13 +942,13 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
             for (int i = 0; i < HR; ++i) {
                 const int f = tc.f0 - 1 + i;
                 const bool ok = tv && f >= 0 && f < F;
-                *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = C1IN ? c1_chunk(regs[i].u.x, regs[i].u.y, ok, kc1)
+                *(uint4*)&sX[swzx(i * PHC + pc, pc, cch)] = C1IN ? c1_chunk<T>(regs[i].u.x, regs[i].u.y, ok, kc1)
                                                                  : xform_chunk<T>(regs[i], ok, a.prologue, sc, sh, 0);
             }
             if (htid < 160) {
                 const int hr = pc >> 1, f = tc.f0 - 1 + hr, te = tc.t0 + PTC - 1 + (pc & 1);
                 const bool ok = f >= 0 && f < F && te < Tn;
-                *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = C1IN ? c1_chunk(regs[HR].u.x, regs[HR].u.y, ok, kc1)
+                *(uint4*)&sX[swzx(hr * PHC + PTC + (pc & 1), PTC + (pc & 1), cch)] = C1IN ? c1_chunk<T>(regs[HR].u.x, regs[HR].u.y, ok, kc1)
                                                                                            : xform_chunk<T>(regs[HR], ok, a.prologue, sc, sh, 0);
             }
         };
@@ -1050,7 +1059,7 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<TM>(wf[cur][i], xf[cur][j], acc[i][j]);
             }
             if (a.prio) __builtin_amdgcn_s_setprio(0);
         }
@@ -1082,6 +1091,13 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
         if (C1RED) {
             // (1) mask: pre-activation tile of the first layer in the accumulators' own layout (co x pixel), one MFMA per tile
             __builtin_amdgcn_s_waitcnt(0x0F70);                // av landed (the next tile's prefetch too: it had the whole MFMA loop)
+            if constexpr (!__is_same(TY, bf16)) {              // saved fp16 input -> the bf16 operand of the two first-layer contractions below
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    av[j].x = pack2_bf16(H16<TY>::lo(av[j].x), H16<TY>::hi(av[j].x));
+                    av[j].y = pack2_bf16(H16<TY>::lo(av[j].y), H16<TY>::hi(av[j].y));
+                }
+            }
             uint16_t* a0t = sX + 4 * (64 * 64) + hw * 256;     // [4 c][64 px] of this wave, in the part of the input tile no slice uses
             {
                 const int j = lane >> 5;                       // lanes < 32 file row 0, lanes >= 32 row 1 (both hold both rows' pixels)
@@ -1149,8 +1165,8 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     uint2 w2;
-                    w2.x = pack2_bf16(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
-                    w2.y = pack2_bf16(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                    w2.x = H16<TM>::pack(acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1]);
+                    w2.y = H16<TM>::pack(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
                     *(uint2*)(q + j * 32 * 64) = w2;
                 }
             }
@@ -1175,7 +1191,7 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
                     const uint32_t w[4] = {o[k].x, o[k].y, o[k].z, o[k].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        const float lo = H16<TM>::lo(w[q]), hi = H16<TM>::hi(w[q]);
                         ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
                     }
                 }
@@ -1195,7 +1211,7 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float d0 = bf16_bits_to_f32(w[q] & 0xffffu), d1 = __uint_as_float(w[q] & 0xffff0000u);
-                        const float y0 = bf16_bits_to_f32(yw[q] & 0xffffu), y1 = __uint_as_float(yw[q] & 0xffff0000u);
+                        const float y0 = H16<TY>::lo(yw[q]), y1 = H16<TY>::hi(yw[q]);
                         const float t0_ = __uint_as_float(__float_as_uint(y0) ^ (((bsgn >> (2 * q)) & 1u) << 31));
                         const float t1_ = __uint_as_float(__float_as_uint(y1) ^ (((bsgn >> (2 * q + 1)) & 1u) << 31));
                         const float g0 = t0_ > bthr[2 * q] ? d0 : 0.f, g1 = t1_ > bthr[2 * q + 1] ? d1 : 0.f;
@@ -1206,7 +1222,7 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
                     const uint32_t w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float lo = bf16_bits_to_f32(w[q] & 0xffffu), hi = __uint_as_float(w[q] & 0xffff0000u);
+                        const float lo = H16<TM>::lo(w[q]), hi = H16<TM>::hi(w[q]);
                         ssum[2 * q] += lo; ssq[2 * q] += lo * lo; ssum[2 * q + 1] += hi; ssq[2 * q + 1] += hi * hi;
                     }
                 }
@@ -1429,7 +1445,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(WgradArgs a) {
 #define WHC (WTC + 2)
 #define WX_ELEMS (HR * WHC * 64)
 #define WY_ELEMS (TR * WTC * 64)
-template <bool C1IN = false>
+template <bool C1IN = false, typename TA = bf16>      // TA: encoding of the saved forward operand (zin / a0); dy and the contraction are bf16
 __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     typedef bf16 T;
     __shared__ __attribute__((aligned(16))) uint16_t sYb[2][WY_ELEMS];   // dy tiles  [8*32 px][64 co]
@@ -1441,7 +1457,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     const int F = a.F, Tn = a.T;
     const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + WTC - 1) / WTC;
     const int ntiles = a.nb * tiles_f * tiles_t;
-    const T* zin = (const T*)a.zin;
+    const TA* zin = (const TA*)a.zin;
     const T* dy = (const T*)a.dy;
     const int cch = tid & 7;
 
@@ -1472,15 +1488,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     C1Const kc1;
     if (C1IN) c1_setup(kc1, a.c1_w, a.scale, a.shift, cch * 8);
     auto load_z = [&](int b, int f, int t) {                    // clamped, unconditional (load_chunk_clamped); C1IN: the pixel's 4 input channels
-        Chunk<T> c;
+        Chunk<TA> c;
         if (C1IN) {
             f = min(max(f, 0), F - 1); t = min(max(t, 0), Tn - 1);
             const uint2 q = *(const uint2*)(zin + (((long)b * F + f) * Tn + t) * 4);
             c.u.x = q.x; c.u.y = q.y;
-        } else c = load_chunk_clamped<T>(zin, b, f, t, F, Tn, cch * 8);
+        } else c = load_chunk_clamped<TA>(zin, b, f, t, F, Tn, cch * 8);
         return c;
     };
-    auto xform_z = [&](const Chunk<T>& c, bool ok) { return C1IN ? c1_chunk(c.u.x, c.u.y, ok, kc1) : xform_chunk<T>(c, ok, a.prologue, sc, sh, 0); };
+    auto xform_z = [&](const Chunk<TA>& c, bool ok) { return C1IN ? c1_chunk<TA, bf16>(c.u.x, c.u.y, ok, kc1) : xform_chunk<TA, bf16>(c, ok, a.prologue, sc, sh, 0); };
 
     // staging: thread = (row parity pr, pixel column pcol of 32, 8-channel chunk): halo rows pr, pr+2, .. pr+8 and dy rows pr, pr+2, ..
     // pr+6 of its column; threads < 160 also one chunk of halo columns 32 / 33
@@ -1489,7 +1505,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
     //  one vector byte offset per thread for all rows of a tensor, one lane-constant LDS base per tensor with the row step as an
     //  immediate: 1426 -> 1019 vector issue slots per tile.  The launch time did not move (379 us alone, +0.2 % on the step): like the
     //  operand-read and look-ahead experiments in tools/conv_ng3/, it says this kernel is bound by none of them.)
-    Chunk<T> rz[6], ry[4];
+    Chunk<TA> rz[6]; Chunk<T> ry[4];
     const int pcol = (tid >> 3) & 31;
     const int pr = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int lbX = swzc(pr * WHC + pcol, pcol, cch), lbY = swzc(pr * WTC + pcol, pcol, cch);     // LDS element offsets of row pr; row pr + 2k: + k * 2 * W?C * 64
@@ -1607,7 +1623,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_db_kernel(WgradArgs a) {
 // Role-split variant of conv3x3_wgrad_db_kernel: 16 waves, waves 0-7 only run the MFMA loop (same decomposition: co half x ci half x tap
 // group), waves 8-15 only stage (global loads one tile ahead in registers, BatchNorm + ReLU / first-layer prologue, LDS writes).  Ablation
 // builds of the lockstep kernel ran 254 us without its staging and 268 us without its MFMAs, 378 us with both in the same waves.
-template <bool C1IN = false>
+template <bool C1IN = false, typename TA = bf16>
 __global__ __launch_bounds__(1024) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
     typedef bf16 T;
     __shared__ __attribute__((aligned(16))) uint16_t sYb[2][WY_ELEMS];   // dy tiles  [8*32 px][64 co]
@@ -1622,7 +1638,7 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
     const int F = a.F, Tn = a.T;
     const int tiles_f = (F + TR - 1) / TR, tiles_t = (Tn + WTC - 1) / WTC;
     const int ntiles = a.nb * tiles_f * tiles_t;
-    const T* zin = (const T*)a.zin;
+    const TA* zin = (const TA*)a.zin;
     const T* dy = (const T*)a.dy;
     const int cch = tid & 7;
 
@@ -1637,15 +1653,15 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
         C1Const kc1;
         if (C1IN) c1_setup(kc1, a.c1_w, a.scale, a.shift, cch * 8);
         auto load_z = [&](int b, int f, int t) __attribute__((always_inline)) {                    // clamped, unconditional (load_chunk_clamped); C1IN: the pixel's 4 input channels
-            Chunk<T> c;
+            Chunk<TA> c;
             if (C1IN) {
                 f = min(max(f, 0), F - 1); t = min(max(t, 0), Tn - 1);
                 const uint2 q = *(const uint2*)(zin + (((long)b * F + f) * Tn + t) * 4);
                 c.u = make_uint4(q.x, q.y, 0u, 0u);      // (whole object: a partially written chunk carried over the loop edge stays on the stack)
-            } else c = load_chunk_clamped<T>(zin, b, f, t, F, Tn, cch * 8);
+            } else c = load_chunk_clamped<TA>(zin, b, f, t, F, Tn, cch * 8);
             return c;
         };
-        auto xform_z = [&](const Chunk<T>& c, bool ok) __attribute__((always_inline)) { return C1IN ? c1_chunk(c.u.x, c.u.y, ok, kc1) : xform_chunk<T>(c, ok, a.prologue, sc, sh, 0); };
+        auto xform_z = [&](const Chunk<TA>& c, bool ok) __attribute__((always_inline)) { return C1IN ? c1_chunk<TA, bf16>(c.u.x, c.u.y, ok, kc1) : xform_chunk<TA, bf16>(c, ok, a.prologue, sc, sh, 0); };
 
         // staging: thread = (row parity pr, pixel column pcol of 32, 8-channel chunk): halo rows pr, pr+2, .. pr+8 and dy rows pr, pr+2, ..
         // pr+6 of its column; threads < 160 also one chunk of halo columns 32 / 33
@@ -1654,7 +1670,7 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_ws_kernel(WgradArgs a) {
         //  one vector byte offset per thread for all rows of a tensor, one lane-constant LDS base per tensor with the row step as an
         //  immediate: 1426 -> 1019 vector issue slots per tile.  The launch time did not move (379 us alone, +0.2 % on the step): like the
         //  operand-read and look-ahead experiments in tools/conv_ng3/, it says this kernel is bound by none of them.)
-        Chunk<T> rz[6], ry[4];
+        Chunk<TA> rz[6]; Chunk<T> ry[4];
         const int pcol = (tid >> 3) & 31;
         const int pr = __builtin_amdgcn_readfirstlane(tid >> 8);
         const int lbX = swzc(pr * WHC + pcol, pcol, cch), lbY = swzc(pr * WTC + pcol, pcol, cch);     // LDS element offsets of row pr; row pr + 2k: + k * 2 * W?C * 64
@@ -1881,7 +1897,7 @@ static int conv_grid(int nb, int F, int T) {
 // precise (f32 only): 3-pass split with ws = f32 (B,F,T,64).
 static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                           const float* scale, const float* shift, int precise, float* ws, double* stats, const void* bn_y,
-                          const float* bn_aff, void* stream);
+                          const float* bn_aff, void* stream, int y_dtype = SARSSL_BF16);
 
 extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                                   const float* scale, const float* shift, int precise, float* ws, double* stats, void* stream) {
@@ -1891,17 +1907,19 @@ extern "C" int sarssl_conv3x3_fwd(const void* in, const void* w, void* out, int 
 // Data gradient of a 3x3 convolution (w = flipped / transposed taps, no prologue) that also returns, in red = f64[128], the
 // backward sums [sum g | sum g*xhat] of the BatchNorm + ReLU in front of that convolution (g = dz * relu'(bn(y)), y = its pre-BN
 // activations, aff = [scale | shift | mean | rstd], 4 x 64 f32).  bf16 (ping-pong kernel).
+// y_dtype: encoding of the saved activations y (SARSSL_BF16, or SARSSL_F16 in the fp16-forward mode); dy / w / dz are bf16.
 extern "C" int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, int F, int T, const void* y,
-                                          const float* aff, double* red, void* stream) {
-    SARSSL_REQUIRE(y != nullptr && aff != nullptr && red != nullptr, "sarssl_conv3x3_dgrad_bnred");
-    return conv3x3_launch(dy, w, dz, SARSSL_BF16, SARSSL_BF16, nb, F, T, nullptr, nullptr, 0, nullptr, red, y, aff, stream);
+                                          const float* aff, double* red, int y_dtype, void* stream) {
+    SARSSL_REQUIRE(y != nullptr && aff != nullptr && red != nullptr && (y_dtype == SARSSL_BF16 || y_dtype == SARSSL_F16), "sarssl_conv3x3_dgrad_bnred");
+    return conv3x3_launch(dy, w, dz, SARSSL_BF16, SARSSL_BF16, nb, F, T, nullptr, nullptr, 0, nullptr, red, y, aff, stream, y_dtype);
 }
 
 // 3x3 convolution of relu(bn1(W1 a0)) straight from the stem's 4-channel input a0 (B,F,T,4) bf16: W1 f32[64][4], scale / shift = bn1's
 // affine; out (B,F,T,64) bf16 and, optionally, stats = [sum | sum of squares] of the stored output.  bf16 (ping-pong kernel).
+// dtype: encoding of a0, w and out (SARSSL_BF16 or SARSSL_F16).
 extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const float* scale, const float* shift, const void* w, void* out,
-                                     int nb, int F, int T, double* stats, void* stream) {
-    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && a0 && W1 && scale && shift, "sarssl_conv3x3_fwd_c1");
+                                     int nb, int F, int T, double* stats, int dtype, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && a0 && W1 && scale && shift && (dtype == SARSSL_BF16 || dtype == SARSSL_F16), "sarssl_conv3x3_fwd_c1");
     if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
 #ifdef CONV_STAMPS
@@ -1913,7 +1931,10 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
     a.in = a0; a.w = w; a.out = out; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    if (conv_ws(2)) conv3x3_fwd_ws_kernel<false, true><<<conv_persistent_grid(npairs, 0), 768, 0, (hipStream_t)stream>>>(a);
+    if (dtype == SARSSL_F16) {
+        if (conv_ws(2)) conv3x3_fwd_ws_kernel<false, true, false, f16><<<conv_persistent_grid(npairs, 0), 768, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_fwd_pp_kernel<false, true, false, f16><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
+    } else if (conv_ws(2)) conv3x3_fwd_ws_kernel<false, true><<<conv_persistent_grid(npairs, 0), 768, 0, (hipStream_t)stream>>>(a);
     else conv3x3_fwd_pp_kernel<false, true><<<conv_persistent_grid(npairs, 0), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1in>");
     return 0;
@@ -1923,9 +1944,11 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
 // consumed in the epilogue instead of being stored: red (f64[644], the layout of sarssl_stem_c1_bwd, zeroed here) receives
 // G[co][c] = sum_p g[p][co] a0[p][c] at [co*4 + c] and s1[co] = sum_p g[p][co] at [512 + co], g = dz1 * relu'(scale * (W1 a0) + shift);
 // the remaining entries follow from the input's moments (sarssl_stem_c1_bwd_finalize_mom).  bf16 (ping-pong kernel).
+// a0_dtype: encoding of the saved input a0 (SARSSL_BF16 or SARSSL_F16); dy / w are bf16.
 extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const void* a0, const float* W1, const float* scale,
-                                          const float* shift, int nb, int F, int T, double* red, void* stream) {
-    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && dy && w && a0 && W1 && scale && shift && red, "sarssl_conv3x3_dgrad_c1red");
+                                          const float* shift, int nb, int F, int T, double* red, int a0_dtype, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && dy && w && a0 && W1 && scale && shift && red && (a0_dtype == SARSSL_BF16 || a0_dtype == SARSSL_F16),
+                   "sarssl_conv3x3_dgrad_c1red");
     if (SARSSL_ZERO(red, 644 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
 #ifdef CONV_STAMPS
@@ -1936,7 +1959,10 @@ extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const v
     a.in = dy; a.w = w; a.out = nullptr; a.scale = scale; a.shift = shift; a.prologue = 0; a.c1_w = W1; a.c1_a0 = a0; a.c1_red = red;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
-    if (conv_ws(4)) conv3x3_fwd_ws_kernel<false, false, true><<<conv_persistent_grid(npairs, 1), 768, 0, (hipStream_t)stream>>>(a);
+    if (a0_dtype == SARSSL_F16) {
+        if (conv_ws(4)) conv3x3_fwd_ws_kernel<false, false, true, bf16, f16><<<conv_persistent_grid(npairs, 1), 768, 0, (hipStream_t)stream>>>(a);
+        else conv3x3_fwd_pp_kernel<false, false, true, bf16, f16><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
+    } else if (conv_ws(4)) conv3x3_fwd_ws_kernel<false, false, true><<<conv_persistent_grid(npairs, 1), 768, 0, (hipStream_t)stream>>>(a);
     else conv3x3_fwd_pp_kernel<false, false, true><<<conv_persistent_grid(npairs, 1), 512, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("conv3x3_fwd_pp_kernel<c1red>");
     return 0;
@@ -1944,9 +1970,9 @@ extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const v
 
 static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, int w_dtype, int nb, int F, int T,
                           const float* scale, const float* shift, int precise, float* ws, double* stats, const void* bn_y,
-                          const float* bn_aff, void* stream) {
+                          const float* bn_aff, void* stream, int y_dtype) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0, "sarssl_conv3x3_fwd");
-    SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16, "sarssl_conv3x3_fwd(fused statistics: bf16 storage only)");
+    SARSSL_REQUIRE(stats == nullptr || dtype == SARSSL_BF16 || dtype == SARSSL_F16, "sarssl_conv3x3_fwd(fused statistics: 16-bit storage only)");
     if (stats && SARSSL_ZERO(stats, 128 * sizeof(double), (hipStream_t)stream) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     ConvArgs a = {};
 #ifdef CONV_STAMPS
@@ -1964,10 +1990,19 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     if (dtype == SARSSL_BF16 && w_dtype == SARSSL_BF16) {
         const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
         const int g = conv_persistent_grid(npairs, scale != nullptr ? 0 : 1);      // (no prologue = a data-gradient launch)
-        if (bn_y && conv_ws(8)) conv3x3_fwd_ws_kernel<true><<<g, 768, 0, st>>>(a);
+        if (bn_y && y_dtype == SARSSL_F16) {
+            if (conv_ws(8)) conv3x3_fwd_ws_kernel<true, false, false, bf16, f16><<<g, 768, 0, st>>>(a);
+            else conv3x3_fwd_pp_kernel<true, false, false, bf16, f16><<<g, 512, 0, st>>>(a);
+        } else if (bn_y && conv_ws(8)) conv3x3_fwd_ws_kernel<true><<<g, 768, 0, st>>>(a);
         else if (!bn_y && conv_ws(1)) conv3x3_fwd_ws_kernel<false><<<g, 768, 0, st>>>(a);
         else if (bn_y) conv3x3_fwd_pp_kernel<true><<<g, 512, 0, st>>>(a);
         else conv3x3_fwd_pp_kernel<false><<<g, 512, 0, st>>>(a);
+    } else if (dtype == SARSSL_F16 && w_dtype == SARSSL_F16) {              // forward launches of the fp16-forward mode
+        SARSSL_REQUIRE(bn_y == nullptr, "sarssl_conv3x3_fwd(fp16: forward launches only)");
+        const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
+        const int g = conv_persistent_grid(npairs, scale != nullptr ? 0 : 1);
+        if (conv_ws(1)) conv3x3_fwd_ws_kernel<false, false, false, f16><<<g, 768, 0, st>>>(a);
+        else conv3x3_fwd_pp_kernel<false, false, false, f16><<<g, 512, 0, st>>>(a);
     } else if (dtype == SARSSL_F32 && w_dtype == SARSSL_F32) {
         if (!precise) conv3x3_fwd_kernel<float, float><<<grid, 512, 0, st>>>(a);
         else {
@@ -1992,8 +2027,8 @@ extern "C" long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T) {
 // Re-laid-out taps of a (64, 64, 3, 3) f32 convolution weight in ONE launch (a permute + flip + 2 casts = 5 torch launches per
 // convolution otherwise, redone every step because the weights move): fwd [9][co][ci] and dgr [9][ci][co] with flipped taps
 // (= W.flip(2,3).permute(2,3,1,0)), as f32 (dtype 0) or bf16 (dtype 1).
-template <typename T>
-__global__ void conv_taps_kernel(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ dgr) {
+template <typename T, typename TD>
+__global__ void conv_taps_kernel(const float* __restrict__ W, T* __restrict__ fwd, TD* __restrict__ dgr) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 9 * 4096) return;
     const int tap = e >> 12, a = (e >> 6) & 63, b = e & 63;
@@ -2001,8 +2036,9 @@ __global__ void conv_taps_kernel(const float* __restrict__ W, T* __restrict__ fw
     st_f(dgr + e, W[(b * 64 + a) * 9 + (8 - tap)]);              // dgr[tap][ci = a][co = b] = W[co][ci][2 - kh][2 - kw]
 }
 extern "C" int sarssl_conv_taps(const float* W, void* fwd, void* dgr, int dtype, void* stream) {
-    if (dtype == SARSSL_BF16) conv_taps_kernel<bf16><<<144, 256, 0, (hipStream_t)stream>>>(W, (bf16*)fwd, (bf16*)dgr);
-    else if (dtype == SARSSL_F32) conv_taps_kernel<float><<<144, 256, 0, (hipStream_t)stream>>>(W, (float*)fwd, (float*)dgr);
+    if (dtype == SARSSL_BF16) conv_taps_kernel<bf16, bf16><<<144, 256, 0, (hipStream_t)stream>>>(W, (bf16*)fwd, (bf16*)dgr);
+    else if (dtype == SARSSL_MIX16) conv_taps_kernel<f16, bf16><<<144, 256, 0, (hipStream_t)stream>>>(W, (f16*)fwd, (bf16*)dgr);     // fp16 forward taps, bf16 gradient taps
+    else if (dtype == SARSSL_F32) conv_taps_kernel<float, float><<<144, 256, 0, (hipStream_t)stream>>>(W, (float*)fwd, (float*)dgr);
     else { sarssl_set_error("sarssl_conv_taps: unsupported dtype %d", dtype); return -1; }
     SARSSL_CHECK_LAUNCH("conv_taps_kernel");
     return 0;
@@ -2019,6 +2055,7 @@ extern "C" int sarssl_patch_w(const float* W, void* out, int d, int F, int dtype
     const long n = (long)d * F * 4;
     if (dtype == SARSSL_BF16) patch_w_kernel<bf16><<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, (bf16*)out, d, F);
     else if (dtype == SARSSL_F32) patch_w_kernel<float><<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, (float*)out, d, F);
+    else if (dtype == SARSSL_F16) patch_w_kernel<f16><<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, (f16*)out, d, F);
     else { sarssl_set_error("sarssl_patch_w: unsupported dtype %d", dtype); return -1; }
     SARSSL_CHECK_LAUNCH("patch_w_kernel");
     return 0;
@@ -2046,9 +2083,12 @@ extern "C" int sarssl_patch_wgrad_accum(const float* g, int nslice, float* grad,
 // double-buffered one.  Same box, three interleaved rounds, both weight-gradient launches of a stem: 10.87 -> 10.72 ms per step; alone
 // 361 -> 311 us (its MFMA loop alone: 254 us).
 template <bool C1IN>
-static void wgrad_bf16_launch(const WgradArgs& a, int g2, hipStream_t st) {
+static void wgrad_bf16_launch(const WgradArgs& a, int g2, hipStream_t st, bool z_f16) {
     static const bool ws = []() { const char* e = getenv("SARSSL_WGRAD_WS"); return !(e && atoi(e) == 0); }();
-    if (ws) conv3x3_wgrad_ws_kernel<C1IN><<<g2, 1024, 0, st>>>(a);
+    if (z_f16) {
+        if (ws) conv3x3_wgrad_ws_kernel<C1IN, f16><<<g2, 1024, 0, st>>>(a);
+        else conv3x3_wgrad_db_kernel<C1IN, f16><<<g2, 512, 0, st>>>(a);
+    } else if (ws) conv3x3_wgrad_ws_kernel<C1IN><<<g2, 1024, 0, st>>>(a);
     else conv3x3_wgrad_db_kernel<C1IN><<<g2, 512, 0, st>>>(a);
 }
 
@@ -2062,9 +2102,9 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
     hipStream_t st = (hipStream_t)stream;
     const int grid = conv_grid(nb, F, T);
     const int rblocks = W_ELEMS / 64;
-    if (dtype == SARSSL_BF16) {
+    if (dtype == SARSSL_BF16 || dtype == SARSSL_MIX16) {        // MIX16: dy bf16, zin fp16 (saved by the fp16 forward pass)
         const int g2 = wgrad_db_grid(nb, F, T);
-        wgrad_bf16_launch<false>(a, g2, st);
+        wgrad_bf16_launch<false>(a, g2, st, dtype == SARSSL_MIX16);
         wgrad_reduce_kernel<<<rblocks, 256, 0, st>>>(partial, g2, dW, 0);
     } else if (dtype == SARSSL_F32) {
         const int npass = precise ? 3 : 1;
@@ -2081,15 +2121,16 @@ extern "C" int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, 
 
 // bf16 weight gradient ADDED straight into the f32 (64, 64, 3, 3) parameter-gradient buffer (nn.Conv2d layout): no [9][64][64]
 // intermediate, no permute-add pass.
+// z_dtype: encoding of zin (SARSSL_BF16 or SARSSL_F16); dy is bf16.
 extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb, int F, int T, const float* scale, const float* shift,
-                                        float* grad_oihw, float* partial, void* stream) {
-    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && grad_oihw && partial, "sarssl_conv3x3_wgrad_acc");
+                                        float* grad_oihw, float* partial, int z_dtype, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && grad_oihw && partial && (z_dtype == SARSSL_BF16 || z_dtype == SARSSL_F16), "sarssl_conv3x3_wgrad_acc");
     WgradArgs a = {};
     a.dy = dy; a.zin = zin; a.scale = scale; a.shift = shift; a.prologue = (scale != nullptr);
     a.partial = partial; a.nb = nb; a.F = F; a.T = T; a.part_dy = 0; a.part_z = 0;
     hipStream_t st = (hipStream_t)stream;
     const int g2 = wgrad_db_grid(nb, F, T);
-    wgrad_bf16_launch<false>(a, g2, st);
+    wgrad_bf16_launch<false>(a, g2, st, z_dtype == SARSSL_F16);
     wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_kernel(acc)");
     return 0;
@@ -2097,14 +2138,15 @@ extern "C" int sarssl_conv3x3_wgrad_acc(const void* dy, const void* zin, int nb,
 // The same with the input operand relu(bn1(W1 a0)) formed from the stem's 4-channel input a0 (B,F,T,4) bf16 while staging (W1 f32[64][4],
 // scale / shift = bn1's affine): the first layer's 64-channel output is not read.  Double-buffered bf16 kernel.
 extern "C" int sarssl_conv3x3_wgrad_c1_acc(const void* dy, const void* a0, const float* W1, int nb, int F, int T, const float* scale,
-                                           const float* shift, float* grad_oihw, float* partial, void* stream) {
-    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && grad_oihw && partial && W1 && scale && shift, "sarssl_conv3x3_wgrad_c1_acc");
+                                           const float* shift, float* grad_oihw, float* partial, int a0_dtype, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && F > 0 && T > 0 && grad_oihw && partial && W1 && scale && shift && (a0_dtype == SARSSL_BF16 || a0_dtype == SARSSL_F16),
+                   "sarssl_conv3x3_wgrad_c1_acc");
     WgradArgs a = {};
     a.dy = dy; a.zin = a0; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
     a.partial = partial; a.nb = nb; a.F = F; a.T = T;
     hipStream_t st = (hipStream_t)stream;
     const int g2 = wgrad_db_grid(nb, F, T);
-    wgrad_bf16_launch<true>(a, g2, st);
+    wgrad_bf16_launch<true>(a, g2, st, a0_dtype == SARSSL_F16);
     wgrad_reduce_kernel<<<W_ELEMS / 64, 256, 0, st>>>(partial, g2, nullptr, 0, grad_oihw);
     SARSSL_CHECK_LAUNCH("conv3x3_wgrad_db_kernel<c1in>");
     return 0;

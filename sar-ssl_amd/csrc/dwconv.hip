@@ -18,9 +18,7 @@
 
 // value as the consumer will read it back from storage (bf16 rounding for bf16 tensors): keeps the fused and the unfused paths, and
 // the forward and the recomputing weight-gradient kernel, on identical numbers
-template <typename T> __device__ __forceinline__ float as_stored(float v);
-template <> __device__ __forceinline__ float as_stored<float>(float v) { return v; }
-template <> __device__ __forceinline__ float as_stored<bf16>(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+template <typename T> __device__ __forceinline__ float as_stored(float v) { return round_as<T>(v); }
 
 // GLU tile: sG[r][c] = a * sigmoid(b) for frames t0 - 15 + r (zero outside [0, T)), channels c0 .. c0 + 63 (zero beyond d)
 template <typename T>
@@ -118,8 +116,8 @@ __global__ __launch_bounds__(256) void dwglu_fwd_kernel(const T* __restrict__ h,
 }
 
 // dh[.., 0:d] = dg * sigmoid(b),  dh[.., d:2d] = dg * a * sigmoid(b) * (1 - sigmoid(b)),  dg = flipped-tap convolution of dc
-template <typename T>
-__global__ __launch_bounds__(256) void dwglu_bwd_kernel(const T* __restrict__ dc, const T* __restrict__ h, const float* __restrict__ w,
+template <typename T, typename TA>      // T: gradients, TA: the pointwise-conv output h saved by the forward pass
+__global__ __launch_bounds__(256) void dwglu_bwd_kernel(const T* __restrict__ dc, const TA* __restrict__ h, const float* __restrict__ w,
                                                         int Tn, int d, T* __restrict__ dh) {
     __shared__ __attribute__((aligned(16))) float sX[DHR][DTC];
     const int tid = threadIdx.x, ch = tid & 63, q = tid >> 6;
@@ -140,7 +138,7 @@ __global__ __launch_bounds__(256) void dwglu_bwd_kernel(const T* __restrict__ dc
     const int ch8 = (tid & 7) * 8;
     for (int r = tid >> 3; r < DTT; r += 32) {
         if (t0 + r < Tn && c0 + ch8 < d) {
-            const T* p = h + (row0 + t0 + r) * (2L * d) + c0 + ch8;
+            const TA* p = h + (row0 + t0 + r) * (2L * d) + c0 + ch8;
             const f8 a = ld8(p), b = ld8(p + d);
             const float4 g0 = *(const float4*)&sX[r][ch8], g1 = *(const float4*)&sX[r][ch8 + 4];
             const float dg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -159,8 +157,8 @@ __global__ __launch_bounds__(256) void dwglu_bwd_kernel(const T* __restrict__ dc
 }
 
 // partial[part][ch][k] = sum over this workgroup's share of (batch, frame tile)s; grid (channel tiles, parts)
-template <typename T>
-__global__ __launch_bounds__(256) void dwglu_wgrad_kernel(const T* __restrict__ dc, const T* __restrict__ h, int nb, int Tn, int d,
+template <typename T, typename TA>
+__global__ __launch_bounds__(256) void dwglu_wgrad_kernel(const T* __restrict__ dc, const TA* __restrict__ h, int nb, int Tn, int d,
                                                           float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float sG[DHR][DTC];
     __shared__ __attribute__((aligned(16))) float sD[DTT][DTC];
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(256) void dwglu_wgrad_kernel(const T* __restrict__ 
         const int b = tile / ttiles, t0 = (tile % ttiles) * DTT;
         const long row0 = (long)b * Tn;
         __syncthreads();
-        load_glu_tile<T>(h, row0, Tn, d, t0, c0, sG, tid);
+        load_glu_tile<TA>(h, row0, Tn, d, t0, c0, sG, tid);
         load_plain_tile<T>(dc, row0, Tn, d, t0, c0, DTT, 0, sD, tid);
         __syncthreads();
         float win[16 + DWK - 1];
@@ -220,6 +218,15 @@ __global__ __launch_bounds__(256) void dw_partial_reduce_kernel(const float* __r
     do {                                                                                                  \
         if ((dtype) == SARSSL_BF16) { typedef bf16 T; stmt; }                                             \
         else if ((dtype) == SARSSL_F32) { typedef float T; stmt; }                                        \
+        else if ((dtype) == SARSSL_F16) { typedef f16 T; stmt; }                                          \
+        else { sarssl_set_error("dwconv: unsupported dtype %d", (int)(dtype)); return -1; }              \
+    } while (0)
+// backward kernels: gradients T next to the saved forward tensor TA (SARSSL_MIX16 = bf16 gradients, fp16 saved activations)
+#define DW_DISPATCH_GA(dtype, stmt)                                                                       \
+    do {                                                                                                  \
+        if ((dtype) == SARSSL_BF16) { typedef bf16 T; typedef bf16 TA; stmt; }                            \
+        else if ((dtype) == SARSSL_F32) { typedef float T; typedef float TA; stmt; }                      \
+        else if ((dtype) == SARSSL_MIX16) { typedef bf16 T; typedef f16 TA; stmt; }                       \
         else { sarssl_set_error("dwconv: unsupported dtype %d", (int)(dtype)); return -1; }              \
     } while (0)
 
@@ -239,7 +246,7 @@ extern "C" int sarssl_dwglu_bwd(const void* dc, const void* h, const float* w, i
                                 void* stream) {
     SARSSL_REQUIRE(ksize == DWK && nb > 0 && Tn > 0 && d > 0 && d % 8 == 0, "sarssl_dwglu_bwd(kernel size 31, d % 8 == 0)");
     dim3 grid((d + DTC - 1) / DTC, (Tn + DTT - 1) / DTT, nb);
-    DW_DISPATCH(dtype, (dwglu_bwd_kernel<T><<<grid, 256, 0, ST>>>((const T*)dc, (const T*)h, w, Tn, d, (T*)dh)));
+    DW_DISPATCH_GA(dtype, (dwglu_bwd_kernel<T, TA><<<grid, 256, 0, ST>>>((const T*)dc, (const TA*)h, w, Tn, d, (T*)dh)));
     SARSSL_CHECK_LAUNCH("dwglu_bwd_kernel");
     return 0;
 }
@@ -254,7 +261,7 @@ extern "C" int sarssl_dwglu_wgrad(const void* dc, const void* h, int nb, int Tn,
     SARSSL_REQUIRE(ksize == DWK && partial && d % 8 == 0, "sarssl_dwglu_wgrad(kernel size 31, d % 8 == 0)");
     const int parts = dwglu_parts(nb, Tn);
     dim3 grid((d + DTC - 1) / DTC, parts);
-    DW_DISPATCH(dtype, (dwglu_wgrad_kernel<T><<<grid, 256, 0, ST>>>((const T*)dc, (const T*)h, nb, Tn, d, partial)));
+    DW_DISPATCH_GA(dtype, (dwglu_wgrad_kernel<T, TA><<<grid, 256, 0, ST>>>((const T*)dc, (const TA*)h, nb, Tn, d, partial)));
     const long n = (long)d * DWK;
     dw_partial_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, ST>>>(partial, parts, n, dw);
     SARSSL_CHECK_LAUNCH("dwglu_wgrad_kernel");

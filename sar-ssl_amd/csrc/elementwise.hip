@@ -12,6 +12,14 @@
 #define DISPATCH_T(dtype, CALL)                                                             \
     if (dtype == SARSSL_BF16) { typedef bf16 T; CALL; }                                     \
     else if (dtype == SARSSL_F32) { typedef float T; CALL; }                                \
+    else if (dtype == SARSSL_F16) { typedef f16 T; CALL; }                                  \
+    else { sarssl_set_error("unsupported dtype %d", dtype); return -1; }
+// kernels of the backward pass that read a tensor SAVED BY THE FORWARD PASS (type TA) next to gradients (type T):
+// SARSSL_MIX16 = bf16 gradients, fp16 saved activations (common.h)
+#define DISPATCH_GA(dtype, CALL)                                                            \
+    if (dtype == SARSSL_BF16) { typedef bf16 T; typedef bf16 TA; CALL; }                    \
+    else if (dtype == SARSSL_F32) { typedef float T; typedef float TA; CALL; }              \
+    else if (dtype == SARSSL_MIX16) { typedef bf16 T; typedef f16 TA; CALL; }               \
     else { sarssl_set_error("unsupported dtype %d", dtype); return -1; }
 static inline int nblocks_for(long work, int per_block, int cap = 4096) {
     long b = (work + per_block - 1) / per_block;
@@ -62,8 +70,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ resid);  dgamma += sum dy*xhat, dbeta += sum dy
 // Two rows per wave are in flight at a time (loads of both issued before either reduction) to hide HBM latency.
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
+template <typename T, typename TA, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, long lddy, const TA* __restrict__ x, long ldx,
                                                             long M, int d, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const T* __restrict__ resid, long ldr, T* __restrict__ dx, long lddx,
@@ -281,8 +289,8 @@ __global__ void glu_fwd_kernel(const T* __restrict__ h, long M, int d, T* __rest
         st4(g + row * d + c, make_float4(a.x * sigmoidf_(b.x), a.y * sigmoidf_(b.y), a.z * sigmoidf_(b.z), a.w * sigmoidf_(b.w)));
     }
 }
-template <typename T>
-__global__ void glu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ h, long M, int d, T* __restrict__ dh) {
+template <typename T, typename TA>
+__global__ void glu_bwd_kernel(const T* __restrict__ dg, const TA* __restrict__ h, long M, int d, T* __restrict__ dh) {
     const long total4 = M * (d >> 2);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const long row = i / (d >> 2); const int c = (int)(i % (d >> 2)) * 4;
@@ -329,8 +337,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 // partial[by][c][k] = sum over this workgroup's (b, t-tile) share of dy[b][t][c] * x[b][t + k - 15][c]
 // Workgroup = 64 channels x 4 waves; the waves take different (b, t-tile)s (4x the loads in flight of the former one-wave
 // workgroups - the kernel is latency-bound on its strided row loads) and are folded through LDS before the partial is written.
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, int nb, int Tn, int d,
+template <typename T, typename TA>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const TA* __restrict__ x, int nb, int Tn, int d,
                                                            float* __restrict__ partial) {
     __shared__ float sacc[3][64][DWK + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -421,8 +429,8 @@ __global__ __launch_bounds__(256) void softmax_relshift_fwd_kernel(const float* 
     }
 }
 // dscore = scale * p * (dp - sum_j dp*p),  dp = dpd * dropout mask
-template <typename T>
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dpd, const T* __restrict__ p, long nrows_total,
+template <typename T, typename TA>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dpd, const TA* __restrict__ p, long nrows_total,
                                                           int Tn, float scale, float p_drop, unsigned long long seed0,
                                                           T* __restrict__ dscore, const unsigned long long* __restrict__ salt) {
     const unsigned long long seed = salted_seed(seed0, salt);
@@ -589,8 +597,8 @@ __global__ void colsum_multi_kernel(ColsumMulti a) {
 }
 // dh = dz * act'(h) * dropout_mask(seed, idx) * gscale
 //   act 1: relu, h_is_post = 1 means h holds relu output;  act 2: swish with h = pre-activation;  act 0: none
-template <typename T>
-__global__ void act_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ h, long n, int act, float p_drop,
+template <typename T, typename TA>
+__global__ void act_bwd_kernel(const T* __restrict__ dz, const TA* __restrict__ h, long n, int act, float p_drop,
                                unsigned long long seed0, float gscale, T* __restrict__ dh, const unsigned long long* __restrict__ salt) {
     const unsigned long long seed = salted_seed(seed0, salt);
     const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -698,8 +706,8 @@ __global__ void loss_finalize_kernel(const double* __restrict__ sums, double cou
     }
 }
 // dpred = gscale * 2 (pred - tar) / count on (masked frame, masked channel) entries, 0 elsewhere
-template <typename T>
-__global__ void masked_mse_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ x, const uint8_t* __restrict__ mp,
+template <typename T, typename TA>
+__global__ void masked_mse_bwd_kernel(const TA* __restrict__ pred, const float* __restrict__ x, const uint8_t* __restrict__ mp,
                                       const int* __restrict__ mch, int nb, int F, int Tn, float coef0,
                                       const float* __restrict__ gs_dev, T* __restrict__ dpred) {
     const float coef = gs_dev ? coef0 * gs_dev[0] : coef0;        // upstream d(loss) kept on the device: no host sync
@@ -725,7 +733,7 @@ __global__ void masked_mse_bwd_kernel(const T* __restrict__ pred, const float* _
 // ------------------------------------------------------------------------------------ Adam
 // torch.optim.Adam (no amsgrad, no weight decay) on a flat f32 buffer; also refreshes the bf16 shadow copy.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            bf16* __restrict__ p16, long n, float gscale, float beta1, float beta2, float step_size,
+                            bf16* __restrict__ p16, f16* __restrict__ ph16, long n, float gscale, float beta1, float beta2, float step_size,
                             float inv_bc2_sqrt, float eps) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
@@ -736,13 +744,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         const float pi = p[i] - step_size * mi / denom;
         p[i] = pi;
         if (p16) st_f(p16 + i, pi);
+        if (ph16) st_f(ph16 + i, pi);
     }
 }
 
 // Same update with the step-dependent factors read from the device-resident step state (graph replay), optionally clearing the
 // gradient buffer in the same pass (the reference's optimizer.zero_grad() right after optimizer.step(), code/learner.py:113-115).
 __global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                bf16* __restrict__ p16, long n, float gscale, const SarsslStepState* __restrict__ st, float eps, int zero_g) {
+                                bf16* __restrict__ p16, f16* __restrict__ ph16, long n, float gscale, const SarsslStepState* __restrict__ st, float eps,
+                                int zero_g) {
     const float beta1 = st->beta1, beta2 = st->beta2, step_size = st->step_size, inv_bc2_sqrt = st->inv_bc2_sqrt;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
@@ -753,6 +763,7 @@ __global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, fl
         const float pi = p[i] - step_size * mi / denom;
         p[i] = pi;
         if (p16) st_f(p16 + i, pi);
+        if (ph16) st_f(ph16 + i, pi);
         if (zero_g) g[i] = 0.f;
     }
 }
@@ -778,9 +789,9 @@ extern "C" int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, lo
     SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (!dgamma || partial), "sarssl_layernorm_bwd");
     const int nblk = ln_bwd_blocks(M);
     float* part = partial;          // dgamma == null && partial != null: partials only, folded later (sarssl_ln_param_reduce_multi)
-#define LN_BWD_LAUNCH(NVv) layernorm_bwd_kernel<T, NVv><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd, \
+#define LN_BWD_LAUNCH(NVv) layernorm_bwd_kernel<T, TA, NVv><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const TA*)x, ldx, M, d, gamma, mean, rstd, \
                                                                            (const T*)resid, ldr, (T*)dx, lddx, part)
-    DISPATCH_T(dtype, (d <= 256 ? LN_BWD_LAUNCH(1) : (d <= 512 ? LN_BWD_LAUNCH(2) : LN_BWD_LAUNCH(4))));
+    DISPATCH_GA(dtype, (d <= 256 ? LN_BWD_LAUNCH(1) : (d <= 512 ? LN_BWD_LAUNCH(2) : LN_BWD_LAUNCH(4))));
 #undef LN_BWD_LAUNCH
     if (dgamma) {       // partial is [nblk][2][d]: viewed as nblk rows of 2d, column halves go to dgamma / dbeta
         ln_param_reduce_kernel<<<(2 * d + 63) / 64, 1024, 0, ST>>>(part, nblk, d, dgamma, dbeta);
@@ -798,9 +809,9 @@ extern "C" int sarssl_layernorm_bwd_drop(const void* dy, long lddy, const void* 
     const int nblk = ln_bwd_blocks(M);
     float* part = partial;
     const unsigned long long* salt = sarssl_dropout_salt();
-#define LN_BWD_LAUNCH(NVv) layernorm_bwd_kernel<T, NVv><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const T*)x, ldx, M, d, gamma, mean, rstd, \
+#define LN_BWD_LAUNCH(NVv) layernorm_bwd_kernel<T, TA, NVv><<<nblk, 256, 0, ST>>>((const T*)dy, lddy, (const TA*)x, ldx, M, d, gamma, mean, rstd, \
                                                                            (const T*)resid, ldr, (T*)dx, lddx, part, (T*)dx2, p_drop, seed, salt, gscale)
-    DISPATCH_T(dtype, (d <= 256 ? LN_BWD_LAUNCH(1) : (d <= 512 ? LN_BWD_LAUNCH(2) : LN_BWD_LAUNCH(4))));
+    DISPATCH_GA(dtype, (d <= 256 ? LN_BWD_LAUNCH(1) : (d <= 512 ? LN_BWD_LAUNCH(2) : LN_BWD_LAUNCH(4))));
 #undef LN_BWD_LAUNCH
     if (dgamma) ln_param_reduce_kernel<<<(2 * d + 63) / 64, 1024, 0, ST>>>(part, nblk, d, dgamma, dbeta);
     SARSSL_CHECK_LAUNCH("layernorm_bwd_kernel(drop)");
@@ -831,7 +842,7 @@ extern "C" int sarssl_glu_fwd(const void* h, long M, int d, void* g, int dtype, 
 }
 extern "C" int sarssl_glu_bwd(const void* dg, const void* h, long M, int d, void* dh, int dtype, void* stream) {
     SARSSL_REQUIRE((d & 3) == 0, "sarssl_glu_bwd");
-    DISPATCH_T(dtype, (glu_bwd_kernel<T><<<nblocks_for(M * (d >> 2), 256), 256, 0, ST>>>((const T*)dg, (const T*)h, M, d, (T*)dh)));
+    DISPATCH_GA(dtype, (glu_bwd_kernel<T, TA><<<nblocks_for(M * (d >> 2), 256), 256, 0, ST>>>((const T*)dg, (const TA*)h, M, d, (T*)dh)));
     SARSSL_CHECK_LAUNCH("glu_bwd_kernel");
     return 0;
 }
@@ -858,7 +869,7 @@ extern "C" int sarssl_dwconv_wgrad(const void* dy, const void* x, int nb, int Tn
     SARSSL_REQUIRE(ksize == DWK && partial, "sarssl_dwconv_wgrad(kernel size must be 31)");
     const int parts = dwconv_wgrad_parts(nb, Tn);
     dim3 grid((d + 63) / 64, parts);
-    DISPATCH_T(dtype, (dwconv_wgrad_kernel<T><<<grid, 256, 0, ST>>>((const T*)dy, (const T*)x, nb, Tn, d, partial)));
+    DISPATCH_GA(dtype, (dwconv_wgrad_kernel<T, TA><<<grid, 256, 0, ST>>>((const T*)dy, (const TA*)x, nb, Tn, d, partial)));
     const long n = (long)d * DWK;
     partial_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, ST>>>(partial, parts, n, dw);
     SARSSL_CHECK_LAUNCH("dwconv_wgrad_kernel");
@@ -877,12 +888,12 @@ extern "C" int sarssl_softmax_bwd(const float* dpd, const void* p, long nmat, in
                                   unsigned long long seed, void* dscore, int dtype, void* stream) {
     SARSSL_REQUIRE(Tn > 0 && Tn <= 64 * SM_MAXV, "sarssl_softmax_bwd(T <= 1024)");
     const int nblk = nblocks_for(nmat * Tn, 4, 8192);
-    DISPATCH_T(dtype, (softmax_bwd_kernel<T><<<nblk, 256, 0, ST>>>(dpd, (const T*)p, nmat * Tn, Tn, scale, p_drop, seed, (T*)dscore, sarssl_dropout_salt())));
+    DISPATCH_GA(dtype, (softmax_bwd_kernel<T, TA><<<nblk, 256, 0, ST>>>(dpd, (const TA*)p, nmat * Tn, Tn, scale, p_drop, seed, (T*)dscore, sarssl_dropout_salt())));
     SARSSL_CHECK_LAUNCH("softmax_bwd_kernel");
     return 0;
 }
 extern "C" int sarssl_relshift_bwd(const void* dscore, long nmat, int Tn, void* dpos, int dtype, void* stream) {
-    if (dtype == SARSSL_BF16 && (Tn & 7) == 0) {
+    if ((dtype == SARSSL_BF16 || dtype == SARSSL_F16) && (Tn & 7) == 0) {      // (16-bit elements are moved, not decoded)
         const long nrows = nmat * Tn;
         relshift_bwd8_kernel<<<nblocks_for(nrows * (Tn >> 3), 256, 8192), 256, 0, ST>>>((const uint16_t*)dscore, nrows, Tn, (uint16_t*)dpos);
         SARSSL_CHECK_LAUNCH("relshift_bwd8_kernel");
@@ -951,7 +962,7 @@ extern "C" int sarssl_colsum_multi_partials(const void* const* xs, const long* l
 extern "C" int sarssl_act_bwd(const void* dz, const void* h, long n, int act, float p_drop, unsigned long long seed, float gscale,
                               void* dh, int dtype, void* stream) {
     SARSSL_REQUIRE((n & 3) == 0, "sarssl_act_bwd(n % 4)");
-    DISPATCH_T(dtype, (act_bwd_kernel<T><<<nblocks_for(n >> 2, 256), 256, 0, ST>>>((const T*)dz, (const T*)h, n, act, p_drop, seed, gscale, (T*)dh, sarssl_dropout_salt())));
+    DISPATCH_GA(dtype, (act_bwd_kernel<T, TA><<<nblocks_for(n >> 2, 256), 256, 0, ST>>>((const T*)dz, (const TA*)h, n, act, p_drop, seed, gscale, (T*)dh, sarssl_dropout_salt())));
     SARSSL_CHECK_LAUNCH("act_bwd_kernel");
     return 0;
 }
@@ -960,6 +971,10 @@ extern "C" int sarssl_cast(const void* src, int src_dtype, void* dst, int dst_dt
     if (src_dtype == SARSSL_F32 && dst_dtype == SARSSL_BF16) cast_kernel<float, bf16><<<nblk, 256, 0, ST>>>((const float*)src, n, (bf16*)dst);
     else if (src_dtype == SARSSL_BF16 && dst_dtype == SARSSL_F32) cast_kernel<bf16, float><<<nblk, 256, 0, ST>>>((const bf16*)src, n, (float*)dst);
     else if (src_dtype == SARSSL_F32 && dst_dtype == SARSSL_F32) cast_kernel<float, float><<<nblk, 256, 0, ST>>>((const float*)src, n, (float*)dst);
+    else if (src_dtype == SARSSL_F32 && dst_dtype == SARSSL_F16) cast_kernel<float, f16><<<nblk, 256, 0, ST>>>((const float*)src, n, (f16*)dst);
+    else if (src_dtype == SARSSL_F16 && dst_dtype == SARSSL_F32) cast_kernel<f16, float><<<nblk, 256, 0, ST>>>((const f16*)src, n, (float*)dst);
+    else if (src_dtype == SARSSL_F16 && dst_dtype == SARSSL_BF16) cast_kernel<f16, bf16><<<nblk, 256, 0, ST>>>((const f16*)src, n, (bf16*)dst);
+    else if (src_dtype == SARSSL_BF16 && dst_dtype == SARSSL_F16) cast_kernel<bf16, f16><<<nblk, 256, 0, ST>>>((const bf16*)src, n, (f16*)dst);
     else { sarssl_set_error("sarssl_cast: unsupported (%d -> %d)", src_dtype, dst_dtype); return -1; }
     SARSSL_CHECK_LAUNCH("cast_kernel");
     return 0;
@@ -1000,23 +1015,24 @@ extern "C" int sarssl_masked_mse_bwd(const void* pred, const float* x, const uns
                                      int Tn, int nm, float gscale, const float* gscale_dev, void* dpred, int dtype,
                                      void* stream) {
     const float coef = gscale * 2.0f / (float)((double)nb * nm * F * 2);
-    DISPATCH_T(dtype, (masked_mse_bwd_kernel<T><<<nblocks_for((long)nb * Tn * F * 2, 256, 8192), 256, 0, ST>>>((const T*)pred, x, mp, mch, nb, F, Tn, coef, gscale_dev, (T*)dpred)));
+    DISPATCH_GA(dtype, (masked_mse_bwd_kernel<T, TA><<<nblocks_for((long)nb * Tn * F * 2, 256, 8192), 256, 0, ST>>>((const TA*)pred, x, mp, mch, nb, F, Tn, coef, gscale_dev, (T*)dpred)));
     SARSSL_CHECK_LAUNCH("masked_mse_bwd_kernel");
     return 0;
 }
-extern "C" int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, long n, float gscale, float lr,
+// p16 / ph16 (either may be null): bf16 and fp16 shadow copies of the updated parameters (the GEMM / convolution operands)
+extern "C" int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr,
                                 float beta1, float beta2, float eps, int step, void* stream) {
     SARSSL_REQUIRE(n > 0 && step >= 1, "sarssl_adam_step");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    adam_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, n, gscale, beta1, beta2, (float)(lr / bc1),
+    adam_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, beta1, beta2, (float)(lr / bc1),
                                                            (float)(1.0 / sqrt(bc2)), eps);
     SARSSL_CHECK_LAUNCH("adam_kernel");
     return 0;
 }
-extern "C" int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, long n, float gscale, const void* state,
+extern "C" int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, const void* state,
                                     float eps, int zero_grad, void* stream) {
     SARSSL_REQUIRE(n > 0 && state, "sarssl_adam_step_dev");
-    adam_dev_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, n, gscale, (const SarsslStepState*)state, eps,
+    adam_dev_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, (const SarsslStepState*)state, eps,
                                                                zero_grad);
     SARSSL_CHECK_LAUNCH("adam_dev_kernel");
     return 0;

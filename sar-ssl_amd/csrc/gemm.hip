@@ -7,8 +7,8 @@
 //   b_kc = 1: B is [N][K] (nn.Linear weight layout);          b_kc = 0: B is [K][N]
 // so Linear forward is (1,1), dX = dY*W is (1,0), dW = dY^T*X is (0,0) with A=dY, B=X.
 //
-// Storage types: f32 or bf16 per tensor.  MFMA inputs are always bf16 (v_mfma_f32_32x32x16_bf16,
-// f32 accumulate).  For f32 storage the "precise" mode splits every operand x = hi + lo
+// Storage types: f32, bf16 or fp16 per tensor.  MFMA inputs are bf16 (v_mfma_f32_32x32x16_bf16, f32 accumulate) - or fp16
+// (v_mfma_f32_32x32x16_f16, same rate) when BOTH operands are stored in fp16: the forward products of the fp16-forward mode.  For f32 storage the "precise" mode splits every operand x = hi + lo
 // (hi = bf16(x), lo = bf16(x - hi)) at LDS-staging time and the host runs three passes
 // (hi*hi, hi*lo, lo*hi) accumulating in an f32 workspace: ~2^-16 relative error per product,
 // on the same matrix cores and the same code path as the fast bf16 mode.
@@ -33,9 +33,14 @@
 #define BK 64
 #define PITCH (BK + 8)
 
-template <typename T>
+// MFMA operand type of a product: fp16 when both operands are stored in fp16 (the forward GEMMs of the fp16-forward mode), bf16 otherwise -
+// f32 operands are split into bf16 parts, and a saved fp16 activation that meets a bf16 gradient (weight-gradient / unfused attention
+// backward products of the mixed mode) is re-encoded to bf16 while it is staged (load_chunk)
+template <typename TA, typename TB> struct MfmaT { typedef bf16 type; };
+template <> struct MfmaT<f16, f16> { typedef f16 type; };
+template <typename T, typename TM>
 __device__ __forceinline__ uint4 load_chunk(const T* __restrict__ p, int part) {
-    if constexpr (sizeof(T) == 2) return *(const uint4*)p;
+    if constexpr (sizeof(T) == 2) return recode8<T, TM>(*(const uint4*)p);
     else { const f8 v = ld8(p); return pack8_part(v, part); }
 }
 
@@ -43,7 +48,7 @@ __device__ __forceinline__ uint4 load_chunk(const T* __restrict__ p, int part) {
 //   KC  ([row][k] in memory):  chunk i of thread t = row (t >> 3) + 32 i, k-chunk t & 7
 //   !KC ([k][row] in memory):  CPR = ROWS / 8 chunks per k-row; chunk i of thread t = k (t / CPR) + i * (256 / CPR), row-chunk t % CPR
 // `p` points at this thread's chunk 0 of the current K-tile; EDGE instantiations zero-fill rows >= R and k >= Kend.
-template <typename T, bool KC, int ROWS, bool EDGE>
+template <typename T, typename TM, bool KC, int ROWS, bool EDGE>
 __device__ __forceinline__ void tile_load(const T* __restrict__ p, long ld, int r0, int k0, int R, int Kend, int part, int tid,
                                           uint4 (&regs)[ROWS / 32]) {
     constexpr int CPR = ROWS / 8, KPP = 256 / CPR;
@@ -53,8 +58,8 @@ __device__ __forceinline__ void tile_load(const T* __restrict__ p, long ld, int 
         if constexpr (EDGE) {
             const int gr = KC ? r0 + (tid >> 3) + 32 * i : r0 + (tid % CPR) * 8;
             const int gk = KC ? k0 + (tid & 7) * 8 : k0 + tid / CPR + KPP * i;
-            regs[i] = (gr < R && gk < Kend) ? load_chunk(q, part) : make_uint4(0, 0, 0, 0);
-        } else regs[i] = load_chunk(q, part);
+            regs[i] = (gr < R && gk < Kend) ? load_chunk<T, TM>(q, part) : make_uint4(0, 0, 0, 0);
+        } else regs[i] = load_chunk<T, TM>(q, part);
     }
 }
 template <bool KC, int ROWS>
@@ -84,6 +89,8 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
 template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool CSUM = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, const int bid_y, const int bid_z, const int grid_x,
                                           const int grid_y, const int grid_z) {
+    typedef typename MfmaT<TA, TB>::type TM;
+    static_assert(sizeof(TA) == 2 || (sizeof(TA) == 4 && sizeof(TB) == 4), "f32 operands come in pairs (split-bf16 passes)");
     constexpr int BM = 64 * FM;
     constexpr int PTA = BM + 32, PTB = BN + 32;
     constexpr int A_ELEMS = AKC ? BM * PITCH : BK * PTA;
@@ -189,7 +196,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<TM>(fb[j], fa[i], acc[i][j]);
             if constexpr (CSUM) {
                 if (do_cs) {
                     union { uint32_t w[4]; bf16x8 b; } s0, s1;
@@ -219,8 +226,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
 
     {
         uint4 ra[BM / 32], rb[BN / 32];
-        tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
-        tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
+        tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
+        tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
 #ifdef GEMM_STAMPS
 #define GSTAMP(k) do { if (g.stamps && bid_x == 0 && bid_y == 0 && bid_z == 0 && lane == 0 && kt < 16) g.stamps[((tid >> 6) * 16 + kt) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
         int kt = 0;
@@ -236,8 +243,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             GSTAMP(2);
             if (k0 + BK < k_end) {                           // next K-tile in flight behind the MFMAs
                 pa += stepA; pb += stepB;
-                tile_load<TA, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
-                tile_load<TB, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
+                tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
+                tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
             }
             GSTAMP(3);
             mfma_phase(sA, sB);
@@ -277,6 +284,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     // (bf16 outputs only: with f32 outputs the two register sets did not survive hipcc's register allocation - they went to scratch)
     const TC* Ex = (!EDGE && sizeof(TC) == 2 && g.split_k <= 0 && !g.acc_out) ? (Rz && !Xa ? Rz : (Xa && !Rz ? Xa : nullptr)) : nullptr;
     const long ldex = (Ex == Rz) ? g.ldr : g.ldc;
+    const bool ex_f16 = g.aux_f16 && Ex == Xa && Ex != nullptr;      // the prefetched rows are the saved fp16 pre-activation
     // (two register sets addressed with compile-time indices only: an array that is copied / passed by pointer here ends up in
     //  scratch memory - 144 bytes per lane of private memory traffic per tile, which tripled the HBM writes of the residual /
     //  activation-backward GEMMs in the round-2 counters)
@@ -286,7 +294,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
         for (int k = 0; k < 4; ++k) {
             const int r = (tid >> 4) + 16 * k;
             const int m = m0 + (r >> 5) * (FM * 32) + i * 32 + (r & 31);
-            dst[k] = ld8(Ex + (long)m * ldex + n);
+            dst[k] = ld8_as(Ex + (long)m * ldex + n, ex_f16);
         }
     };
     const bool has_ex = !EDGE && sizeof(TC) == 2 && Ex != nullptr;
@@ -338,6 +346,7 @@ struct GemmGroup {
     int gx[GROUP_MAXP], gy[GROUP_MAXP], first[GROUP_MAXP + 1];
     int n;
 };
+template <typename TB>       // TB = f16: the saved activations of the fp16-forward mode, re-encoded to bf16 while staged
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void gemm_group_tn_kernel(GemmGroup a) {
     int q = 0;
     while (q + 1 < a.n && (int)blockIdx.x >= a.first[q + 1]) ++q;
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void g
     const int gx = a.gx[q], gy = a.gy[q], ns = a.p[q].split_k;
     if (local >= gx * gy * ns) return;               // (first[] is padded to multiples of 8: linear id % 8 stays the XCD inside a product)
     const int bz = local / (gx * gy), rem = local - bz * (gx * gy);
-    gemm_body<bf16, bf16, float, false, false, 2, false, true>(a.p[q], rem % gx, rem / gx, bz, gx, gy, ns);
+    gemm_body<bf16, TB, float, false, false, 2, false, true>(a.p[q], rem % gx, rem / gx, bz, gx, gy, ns);
 }
 
 // C[z][m][n] += sum_s ws[z][s][m][n]   (second stage of split-K weight-gradient GEMMs; C is f32)
@@ -476,7 +485,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
                            int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
                            float alpha, float out_scale, const float* bias, int act,
                            const void* resid, long ldr, long sR0, long sR1, float res_scale,
-                           void* preact, const void* aux, int aux_act, float p_drop, unsigned long long seed,
+                           void* preact, const void* aux, int aux_act, int aux_dtype, float p_drop, unsigned long long seed,
                            int precise, float* ws, int split_k, int c_row_shift, void* stream) {
     SARSSL_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0 && batch_inner > 0, "sarssl_gemm");
     SARSSL_REQUIRE(a_kc ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0), "sarssl_gemm(A alignment)");
@@ -487,6 +496,9 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.alpha = alpha; g.out_scale = out_scale; g.bias = bias; g.act = act;
     g.resid = resid; g.ldr = ldr; g.sR0 = sR0; g.sR1 = sR1; g.res_scale = res_scale;
     g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
+    // aux (the saved pre-activation of a fused activation backward) has C's dtype, or fp16 next to a bf16 C (fp16-forward mode)
+    SARSSL_REQUIRE(!aux || aux_dtype == dtC || (aux_dtype == SARSSL_F16 && dtC == SARSSL_BF16), "sarssl_gemm(aux dtype)");
+    g.aux_f16 = (aux && aux_dtype == SARSSL_F16 && dtC == SARSSL_BF16) ? 1 : 0;
     g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K;
     g.row_shift = 0; g.csum_ws = nullptr;
@@ -530,6 +542,24 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
         if (rc || g.split_k <= 0 || C == nullptr) return rc;          // C == null: partials only, reduced later (sarssl_splitk_reduce_multi)
         return reduce();
     }
+    // fp16-forward mode: forward products on fp16 operands ...
+    if (dtA == SARSSL_F16 && dtB == SARSSL_F16 && dtC == SARSSL_F16)
+        return launch_layout<f16, f16, f16, true>(g, a_kc, b_kc, nbatch, st);
+    if (dtA == SARSSL_F16 && dtB == SARSSL_F16 && dtC == SARSSL_F32) {
+        int rc = launch_layout<f16, f16, float, false>(g, a_kc, b_kc, nbatch, st);
+        if (rc || g.split_k <= 0 || C == nullptr) return rc;
+        return reduce();
+    }
+    // ... backward products of a bf16 gradient with a saved fp16 activation (either side), contracted in bf16
+    if (dtA == SARSSL_BF16 && dtB == SARSSL_F16 && dtC == SARSSL_BF16)
+        return launch_layout<bf16, f16, bf16, false>(g, a_kc, b_kc, nbatch, st);
+    if (dtA == SARSSL_BF16 && dtB == SARSSL_F16 && dtC == SARSSL_F32) {
+        int rc = launch_layout<bf16, f16, float, false>(g, a_kc, b_kc, nbatch, st);
+        if (rc || g.split_k <= 0 || C == nullptr) return rc;
+        return reduce();
+    }
+    if (dtA == SARSSL_F16 && dtB == SARSSL_BF16 && dtC == SARSSL_BF16)
+        return launch_layout<f16, bf16, bf16, false>(g, a_kc, b_kc, nbatch, st);
     if (dtA == SARSSL_F32 && dtB == SARSSL_F32 && dtC == SARSSL_F32) {
         if (g.split_k > 0) {          // the accumulate epilogue is linear: the split-precision passes just add up
             GemmArgs p = g;
@@ -563,8 +593,8 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
 // ragged (M % 128, N % 128 or the K slices % 64).
 extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* const* ws, const int* M, const int* N,
                                     const int* K, const long* lda, const long* ldb, const int* split_k, int* split_out,
-                                    float* const* csum_ws, int n_prob, void* stream) {
-    SARSSL_REQUIRE(n_prob > 0 && n_prob <= GROUP_MAXP, "sarssl_gemm_group_tn");
+                                    float* const* csum_ws, int n_prob, int dtB, void* stream) {
+    SARSSL_REQUIRE(n_prob > 0 && n_prob <= GROUP_MAXP && (dtB == SARSSL_BF16 || dtB == SARSSL_F16), "sarssl_gemm_group_tn");
     GemmGroup a;
     a.n = n_prob;
     int total = 0;
@@ -579,7 +609,7 @@ extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, 
         g.batch_inner = 1; g.sA0 = g.sA1 = g.sB0 = g.sB1 = g.sC0 = g.sC1 = 0;
         g.alpha = 1.f; g.out_scale = 1.f; g.bias = nullptr; g.act = 0;
         g.resid = nullptr; g.ldr = 0; g.sR0 = g.sR1 = 0; g.res_scale = 0.f;
-        g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
+        g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.aux_f16 = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
         g.p_drop = 0.f; g.seed = 0; g.salt = nullptr; g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
         g.split_k = ns; g.k_per_split = per; g.row_shift = 0;
         g.csum_ws = csum_ws ? csum_ws[q] : nullptr;
@@ -591,7 +621,8 @@ extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, 
     a.first[n_prob] = total;
     if (edge) return 1;            // ragged shapes: not taken (the caller launches the products one by one); the EDGE instantiation of
                                    // the grouped kernel crashes hipcc 7.2's simplifycfg
-    gemm_group_tn_kernel<<<total, 256, 0, (hipStream_t)stream>>>(a);
+    if (dtB == SARSSL_F16) gemm_group_tn_kernel<f16><<<total, 256, 0, (hipStream_t)stream>>>(a);
+    else gemm_group_tn_kernel<bf16><<<total, 256, 0, (hipStream_t)stream>>>(a);
     SARSSL_CHECK_LAUNCH("gemm_group_tn_kernel");
     return 0;
 }

@@ -14,6 +14,7 @@ struct GemmArgs {
     const void* resid; long ldr; long sR0, sR1; float res_scale;
     void* preact;               // optional (same dtype/ld as C): alpha*acc + bias before activation
     const void* aux; int aux_act;   // optional (same dtype/ld as C): multiply by act'(aux) (1 relu, 2 swish) - fused activation backward
+    int aux_f16;                    // aux is an fp16 tensor although C is bf16 (pre-activation saved by the fp16 forward pass)
     float* acc_ws; int acc_in, acc_out;   // f32 [nbatch][M][N] workspace for split passes
     int partA, partB;
     float p_drop; unsigned long long seed; const unsigned long long* salt;   // salt: device-resident seed addend (graph replay) or null
@@ -43,6 +44,14 @@ struct DropCtx {
     }
 };
 
+// 8 elements at p decoded as fp16 (as_f16, 16-bit TC only) or as TC
+template <typename TC>
+__device__ __forceinline__ f8 ld8_as(const TC* p, bool as_f16) {
+    if constexpr (sizeof(TC) == 2) {
+        const uint4 u = *(const uint4*)p;
+        return as_f16 ? unpack8<f16>(u) : unpack8<TC>(u);
+    } else return ld8(p);
+}
 // ---- fused epilogue on one 8-wide piece of one output row (v = alpha * accumulator) -------------------------------------------------
 template <typename TC, bool EDGE>
 __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m, int n, TC* __restrict__ C, const TC* __restrict__ Rz,
@@ -94,10 +103,10 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& g, f8 v, int z, int m,
     if (Xa) {                                            // dX epilogue: times act'(saved pre-activation)
         f8 h;
         if (has_pre) h = pre;
-        else if (vec) h = ld8(Xa + co);
+        else if (vec) h = ld8_as(Xa + co, g.aux_f16 != 0);
         else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) h.v[e] = (e < nvalid) ? ld_f(Xa + co + e) : 0.f;
+            for (int e = 0; e < 8; ++e) h.v[e] = (e < nvalid) ? (g.aux_f16 ? ld_f((const f16*)Xa + co + e) : ld_f(Xa + co + e)) : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

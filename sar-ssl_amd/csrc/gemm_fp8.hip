@@ -242,7 +242,7 @@ extern "C" int sarssl_gemm_fp8(const void* A8, const void* B8, const float* sa, 
     GemmArgs g = {};
     g.A = A8; g.B = B8; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.batch_inner = 1;
     g.alpha = alpha; g.out_scale = out_scale; g.bias = bias; g.act = act; g.resid = resid; g.ldr = ldr; g.res_scale = res_scale;
-    g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = 0; g.k_per_split = K;
+    g.preact = preact; g.aux = aux; g.aux_act = aux_act; g.aux_f16 = 0; g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = 0; g.k_per_split = K;
     const bool vec_ok = ((N & 7) == 0) && ((ldc & 7) == 0) && (!resid || (ldr & 7) == 0);
     const bool edge = (M % F8_BM) != 0 || (N % F8_BN) != 0 || (K % F8_BKB) != 0 || !vec_ok;
     dim3 grid((N + F8_BN - 1) / F8_BN, (M + F8_BM - 1) / F8_BM);

@@ -40,6 +40,9 @@ __global__ void mask_inputs_kernel(const float* __restrict__ x, const uint8_t* _
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16> { uint4 u; };
 template <> struct Raw8<float> { f8 v; };
+template <> struct Raw8<f16> { uint4 u; };
+__device__ __forceinline__ Raw8<f16> raw8_load(const f16* p) { Raw8<f16> r; r.u = *(const uint4*)p; return r; }
+__device__ __forceinline__ f8 raw8_unpack(const Raw8<f16>& r) { return unpack8<f16>(r.u); }
 __device__ __forceinline__ Raw8<bf16> raw8_load(const bf16* p) { Raw8<bf16> r; r.u = *(const uint4*)p; return r; }
 __device__ __forceinline__ Raw8<float> raw8_load(const float* p) { Raw8<float> r; r.v = ld8(p); return r; }
 __device__ __forceinline__ f8 raw8_unpack(const Raw8<float>& r) { return r.v; }
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ 
             if (stats) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float r = (sizeof(T) == 2) ? bf16_bits_to_f32(f32_to_bf16_bits(o.v[e])) : o.v[e];   // what was stored
+                    const float r = round_as<T>(o.v[e]);   // what was stored
                     acc[e] += r; acc[8 + e] += r * r;
                 }
             }
@@ -127,9 +130,9 @@ __global__ __launch_bounds__(256) void stem_c1_fwd_kernel(const T* __restrict__ 
 // BNF = 1: dy1 is not materialised - the kernel reads dz1 (gradient w.r.t. relu(bn1(y1))) and y1 and applies the BatchNorm-backward
 // normalisation dy1 = gamma*rstd*(g - s1/N - xhat*s2/N), g = dz1*relu'(bn1(y1)), on the fly (folded to A*g + B*y + C per channel).
 // The first conv's input is data, so dy1 has no other consumer: this removes one 64-channel write and one read per encoder.
-template <typename T, int BNF>
-__global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const T* __restrict__ a0, long npix, double* __restrict__ dW1d,
-                                     const T* __restrict__ y1, const float* __restrict__ aff, const double* __restrict__ bnred, int use_stats) {
+template <typename T, typename TA, int BNF>
+__global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const TA* __restrict__ a0, long npix, double* __restrict__ dW1d,
+                                     const TA* __restrict__ y1, const float* __restrict__ aff, const double* __restrict__ bnred, int use_stats) {
     __shared__ float red[256][33];
     const int cg = threadIdx.x & 7;
     float cA[8], cB[8], cC[8], thr[8];
@@ -191,8 +194,8 @@ __global__ void stem_c1_wgrad_kernel(const T* __restrict__ dy1, const T* __restr
 // so the gradient never has to be normalised per element: G, X, Sa, s1, s2 are accumulated together and a 256-thread finalize
 // kernel combines them.  Replaces cl_bn_bwd_reduce + cl_bn_bwd_apply + stem_c1_wgrad (6 passes over 64-channel tensors -> 2).
 // red: f64[644] = [G 64x4 | X 64x4 | s1 64 | s2 64 | Sa 4], zeroed by the caller.
-template <typename T>
-__global__ __launch_bounds__(256) void stem_c1_bwd_kernel(const T* __restrict__ dz1, const T* __restrict__ y1, const T* __restrict__ a0,
+template <typename T, typename TA>
+__global__ __launch_bounds__(256) void stem_c1_bwd_kernel(const T* __restrict__ dz1, const TA* __restrict__ y1, const TA* __restrict__ a0,
                                                           long npix, const float* __restrict__ aff, double* __restrict__ red) {
     __shared__ float sred[4][8][84];
     const int cg = threadIdx.x & 7;
@@ -254,9 +257,9 @@ __global__ __launch_bounds__(256) void stem_c1_bwd_kernel(const T* __restrict__ 
 // had one pixel (40 bytes) in flight per thread at 3 waves / SIMD: 253 us for 1.1 GB (4.4 TB/s) at B = 64.
 // FROM_A0: y1 = W1 a0 is recomputed from the 4-channel input (4 packed FMAs per channel pair) instead of being read - the first
 // stem layer's output is then never stored (engine.stem_fwd: the 3x3 convolution behind it forms it while staging, too).
-template <bool FROM_A0>
+template <bool FROM_A0, typename TA>     // TA: 16-bit type of the tensors saved by the forward pass (y1, a0); the gradient dz1 is bf16
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void stem_c1_bwd16_kernel(const bf16* __restrict__ dz1, const bf16* __restrict__ y1, const bf16* __restrict__ a0, long npix,
+void stem_c1_bwd16_kernel(const bf16* __restrict__ dz1, const TA* __restrict__ y1, const TA* __restrict__ a0, long npix,
                           const float* __restrict__ aff, double* __restrict__ red, const float* __restrict__ W1) {
     typedef sarssl_f32x2 f2;
     __shared__ float sred[4][16][44];
@@ -293,8 +296,8 @@ void stem_c1_bwd16_kernel(const bf16* __restrict__ dz1, const bf16* __restrict__
     const unsigned yoff = threadIdx.x * 8u, aoff = ps * 8u;
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const bf16* dzb = dz1 + blk * (16 * U * 64);
-        const bf16* yb = y1 + blk * (16 * U * 64);
-        const bf16* ab = a0 + blk * (16 * U * 4);
+        const TA* yb = y1 + blk * (16 * U * 64);
+        const TA* ab = a0 + blk * (16 * U * 4);
         uint2 d[U], v[U], a[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -304,13 +307,12 @@ void stem_c1_bwd16_kernel(const bf16* __restrict__ dz1, const bf16* __restrict__
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float av[4] = {bf16_bits_to_f32(a[u].x & 0xffffu), __uint_as_float(a[u].x & 0xffff0000u),
-                                 bf16_bits_to_f32(a[u].y & 0xffffu), __uint_as_float(a[u].y & 0xffff0000u)};
+            const float av[4] = {H16<TA>::lo(a[u].x), H16<TA>::hi(a[u].x), H16<TA>::lo(a[u].y), H16<TA>::hi(a[u].y)};
             const unsigned yr[2] = {FROM_A0 ? 0u : v[u].x, FROM_A0 ? 0u : v[u].y}, dr[2] = {d[u].x, d[u].y};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f2 y = FROM_A0 ? w1p[0][h] * av[0] + w1p[1][h] * av[1] + w1p[2][h] * av[2] + w1p[3][h] * av[3]
-                                     : f2{bf16_bits_to_f32(yr[h] & 0xffffu), __uint_as_float(yr[h] & 0xffff0000u)};
+                                     : f2{H16<TA>::lo(yr[h]), H16<TA>::hi(yr[h])};
                 const f2 dd = f2{bf16_bits_to_f32(dr[h] & 0xffffu), __uint_as_float(dr[h] & 0xffff0000u)};
                 const f2 g = f2{__uint_as_float(__float_as_uint(y.x) ^ sgn[2 * h]) > thr[2 * h] ? dd.x : 0.f,
                                 __uint_as_float(__float_as_uint(y.y) ^ sgn[2 * h + 1]) > thr[2 * h + 1] ? dd.y : 0.f};
@@ -409,7 +411,7 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
             if (stats) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float r = (sizeof(T) == 2) ? bf16_bits_to_f32(f32_to_bf16_bits(o[c])) : o[c];
+                    const float r = round_as<T>(o[c]);
                     ssum[c] += r; ssq[c] = fmaf(r, r, ssq[c]);
                 }
             }
@@ -464,8 +466,8 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
 // MODE 1: sums only (no store).  MODE 2: second phase - recomputes the masked gradient and writes the finished BatchNorm input
 // gradient dy3 = gamma*rstd*(g - s1/N - xhat*s2/N) directly (use_stats = 0: eval-mode BatchNorm, dy3 = gamma*rstd*g).
 // MODE 1 + MODE 2 move 1.7 GB per encoder instead of 2.7 GB (the 64->4 contraction is recomputed, 4 FMAs per element).
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ y3, const T* __restrict__ dy4, const float* __restrict__ W4,
+template <typename T, typename TA, int MODE>
+__global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const TA* __restrict__ y3, const T* __restrict__ dy4, const float* __restrict__ W4,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                    int nb, int F, int Tn, T* __restrict__ g3, double* __restrict__ red, int use_stats,
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ 
         // all 8 pixel chunks of the thread are requested before the first is used and stay packed (4 VGPRs each for bf16) until
         // then: the accumulators keep this kernel at 2 waves / SIMD, so bytes in flight per wave is what sets its bandwidth
         constexpr int U = 8;
-        Raw8<T> v[U]; bool ok[U]; long pix[U];
+        Raw8<TA> v[U]; bool ok[U]; long pix[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int pl = (threadIdx.x >> 3) + 32 * u;                 // 0..255: bin pl >> 4, frame pl & 15
@@ -589,8 +591,9 @@ __global__ __launch_bounds__(256) void stem_c4_bwd_kernel(const T* __restrict__ 
 // next dy4 tile) are requested before the current half is reduced.  Addresses are a scalar base (tile, bin) plus a per-thread
 // byte offset that never changes (8 * threadIdx.x: one bin row of 16 frames is 2 KB contiguous).
 // sum g*xhat is accumulated as the raw moment sum g*y and converted per thread at the end (frees the mean / rstd registers).
+template <typename TA>                   // TA: 16-bit type of the saved forward tensor y3; the gradient dy4 is bf16
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void stem_c4_bwd_sums16_kernel(const bf16* __restrict__ y3, const bf16* __restrict__ dy4, const float* __restrict__ W4,
+void stem_c4_bwd_sums16_kernel(const TA* __restrict__ y3, const bf16* __restrict__ dy4, const float* __restrict__ W4,
                                const float* __restrict__ scale, const float* __restrict__ shift,
                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                int nb, int F, int Tn, double* __restrict__ red, int nstream) {
@@ -647,8 +650,7 @@ void stem_c4_bwd_sums16_kernel(const bf16* __restrict__ y3, const bf16* __restri
 #pragma unroll
         for (int u = 0; u < H; ++u) {
             const float4 d = sD[buf][ps][half * H + u];
-            const f2 y[2] = {f2{bf16_bits_to_f32(v[u].x & 0xffffu), __uint_as_float(v[u].x & 0xffff0000u)},
-                             f2{bf16_bits_to_f32(v[u].y & 0xffffu), __uint_as_float(v[u].y & 0xffff0000u)}};
+            const f2 y[2] = {f2{H16<TA>::lo(v[u].x), H16<TA>::hi(v[u].x)}, f2{H16<TA>::lo(v[u].y), H16<TA>::hi(v[u].y)}};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f2 uu = y[h] * sc[h] + sh[h];
@@ -832,8 +834,8 @@ __global__ void cl_affine_act_kernel(const T* __restrict__ x, long rows, int L, 
 }
 
 // BatchNorm(+act) backward, pass 1: g = dz * act'(u), u = y*scale+shift; red[c] += sum g, red[C+c] += sum g*xhat
-template <typename T>
-__global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y, long rows, int L, int C,
+template <typename T, typename TA>
+__global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const TA* __restrict__ y, long rows, int L, int C,
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ mean, const float* __restrict__ rstd, int act,
                                         double* __restrict__ red) {
@@ -891,8 +893,8 @@ __global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __res
 // pass 2: dy = gamma*rstd * (g - s1/N - xhat*s2/N)      (train)   or   dy = gamma*rstd * g   (eval: use_stats = 0)
 // g_is_masked = 1 when dz already contains g (act' applied upstream).  Tensors viewed as [rows][L]; thread = fixed
 // 8-channel group so all per-channel constants live in registers.
-template <typename T>
-__global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, long rows, int L, int C, long N,
+template <typename T, typename TA>
+__global__ void cl_bn_bwd_apply_kernel(const T* __restrict__ dz, const TA* __restrict__ y, long rows, int L, int C, long N,
                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                        const float* __restrict__ mean, const float* __restrict__ rstd, int act,
                                        int g_is_masked, int use_stats, const double* __restrict__ red, T* __restrict__ dy,
@@ -987,6 +989,13 @@ static inline int nblocks_for(long work, int per_block, int cap = 2048) {
 #define DISPATCH_T(dtype, CALL)                                                             \
     if (dtype == SARSSL_BF16) { typedef bf16 T; CALL; }                                     \
     else if (dtype == SARSSL_F32) { typedef float T; CALL; }                                \
+    else if (dtype == SARSSL_F16) { typedef f16 T; CALL; }                                  \
+    else { sarssl_set_error("unsupported dtype %d", dtype); return -1; }
+// backward passes: gradients of type T next to tensors saved by the forward pass of type TA (SARSSL_MIX16: bf16 / fp16, common.h)
+#define DISPATCH_GA(dtype, CALL)                                                            \
+    if (dtype == SARSSL_BF16) { typedef bf16 T; typedef bf16 TA; CALL; }                    \
+    else if (dtype == SARSSL_F32) { typedef float T; typedef float TA; CALL; }              \
+    else if (dtype == SARSSL_MIX16) { typedef bf16 T; typedef f16 TA; CALL; }               \
     else { sarssl_set_error("unsupported dtype %d", dtype); return -1; }
 
 extern "C" int sarssl_mask_inputs(const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn, int mode,
@@ -1011,7 +1020,7 @@ extern "C" int sarssl_stem_c1_fwd(const void* a0, const float* W1, long npix, vo
 extern "C" int sarssl_stem_c1_wgrad(const void* dy1, const void* a0, long npix, double* dW1d, int dtype, void* stream) {
     if (hipMemsetAsync(dW1d, 0, 256 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for(npix * 8, 256, 1024);
-    DISPATCH_T(dtype, (stem_c1_wgrad_kernel<T, 0><<<nblk, 256, 0, ST>>>((const T*)dy1, (const T*)a0, npix, dW1d, (const T*)nullptr, nullptr, nullptr, 0)));
+    DISPATCH_GA(dtype, (stem_c1_wgrad_kernel<T, TA, 0><<<nblk, 256, 0, ST>>>((const T*)dy1, (const TA*)a0, npix, dW1d, (const TA*)nullptr, nullptr, nullptr, 0)));
     SARSSL_CHECK_LAUNCH("stem_c1_wgrad_kernel");
     return 0;
 }
@@ -1021,7 +1030,7 @@ extern "C" int sarssl_stem_c1_wgrad_bn(const void* dz1, const void* y1, const vo
                                        const double* bnred, int use_stats, double* dW1d, int dtype, void* stream) {
     if (hipMemsetAsync(dW1d, 0, 256 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for(npix * 8, 256, 1024);
-    DISPATCH_T(dtype, (stem_c1_wgrad_kernel<T, 1><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)a0, npix, dW1d, (const T*)y1, aff, bnred, use_stats)));
+    DISPATCH_GA(dtype, (stem_c1_wgrad_kernel<T, TA, 1><<<nblk, 256, 0, ST>>>((const T*)dz1, (const TA*)a0, npix, dW1d, (const TA*)y1, aff, bnred, use_stats)));
     SARSSL_CHECK_LAUNCH("stem_c1_wgrad_kernel<bn>");
     return 0;
 }
@@ -1033,13 +1042,15 @@ extern "C" int sarssl_stem_c1_bwd(const void* dz1, const void* y1, const void* a
     SARSSL_REQUIRE(npix > 0 && red && dW1 && dgamma && dbeta, "sarssl_stem_c1_bwd");
     if (SARSSL_ZERO(red, 644 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     constexpr int fast = 1;      // 4-channel-per-thread kernel wherever its shape constraints hold (the general kernel covers the rest)
-    if (fast && dtype == SARSSL_BF16 && (npix & 63) == 0) {
+    if (fast && (dtype == SARSSL_BF16 || dtype == SARSSL_MIX16) && (npix & 63) == 0) {
         const long nb64 = npix >> 6;
         static const int cap = grid_cap("SARSSL_GRID_C1B", 1024);
-        stem_c1_bwd16_kernel<false><<<(int)(nb64 < cap ? nb64 : cap), 256, 0, ST>>>((const bf16*)dz1, (const bf16*)y1, (const bf16*)a0, npix, aff, red, nullptr);
+        const int nblk = (int)(nb64 < cap ? nb64 : cap);
+        if (dtype == SARSSL_MIX16) stem_c1_bwd16_kernel<false, f16><<<nblk, 256, 0, ST>>>((const bf16*)dz1, (const f16*)y1, (const f16*)a0, npix, aff, red, nullptr);
+        else stem_c1_bwd16_kernel<false, bf16><<<nblk, 256, 0, ST>>>((const bf16*)dz1, (const bf16*)y1, (const bf16*)a0, npix, aff, red, nullptr);
     } else {
         const int nblk = nblocks_for(npix * 8, 256, 1024);
-        DISPATCH_T(dtype, (stem_c1_bwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)dz1, (const T*)y1, (const T*)a0, npix, aff, red)));
+        DISPATCH_GA(dtype, (stem_c1_bwd_kernel<T, TA><<<nblk, 256, 0, ST>>>((const T*)dz1, (const TA*)y1, (const TA*)a0, npix, aff, red)));
     }
     stem_c1_bwd_finalize_kernel<<<1, 256, 0, ST>>>(red, npix, aff, use_stats, dW1, dgamma, dbeta);
     SARSSL_CHECK_LAUNCH("stem_c1_bwd_kernel");
@@ -1082,12 +1093,15 @@ extern "C" int sarssl_stem_c1_bwd_finalize_mom(const double* red, const double* 
 
 // The same pass without y1: y1 = W1 a0 is recomputed (bf16 activations, npix % 64 == 0; W1 = the 64 x 4 first-layer weight).
 extern "C" int sarssl_stem_c1_bwd_a0(const void* dz1, const void* a0, const float* W1, long npix, const float* aff, int use_stats,
-                                     double* red, float* dW1, float* dgamma, float* dbeta, void* stream) {
+                                     double* red, float* dW1, float* dgamma, float* dbeta, int dtype, void* stream) {
+    SARSSL_REQUIRE(dtype == SARSSL_BF16 || dtype == SARSSL_MIX16, "sarssl_stem_c1_bwd_a0(dtype)");
     SARSSL_REQUIRE(npix > 0 && (npix & 63) == 0 && red && dW1 && dgamma && dbeta && W1, "sarssl_stem_c1_bwd_a0");
     if (SARSSL_ZERO(red, 644 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     static const int cap = grid_cap("SARSSL_GRID_C1B", 1024);
     const long nb64 = npix >> 6;
-    stem_c1_bwd16_kernel<true><<<(int)(nb64 < cap ? nb64 : cap), 256, 0, ST>>>((const bf16*)dz1, nullptr, (const bf16*)a0, npix, aff, red, W1);
+    const int nblk = (int)(nb64 < cap ? nb64 : cap);
+    if (dtype == SARSSL_MIX16) stem_c1_bwd16_kernel<true, f16><<<nblk, 256, 0, ST>>>((const bf16*)dz1, nullptr, (const f16*)a0, npix, aff, red, W1);
+    else stem_c1_bwd16_kernel<true, bf16><<<nblk, 256, 0, ST>>>((const bf16*)dz1, nullptr, (const bf16*)a0, npix, aff, red, W1);
     stem_c1_bwd_finalize_kernel<<<1, 256, 0, ST>>>(red, npix, aff, use_stats, dW1, dgamma, dbeta);
     SARSSL_CHECK_LAUNCH("stem_c1_bwd16_kernel<a0>");
     return 0;
@@ -1227,8 +1241,8 @@ extern "C" int sarssl_stem_c4_bwd(const void* y3, const void* dy4, const float* 
                                   int dtype, void* stream) {
     if (SARSSL_ZERO(red, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 1024);
-    DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 0><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
-                                                                     nb, F, Tn, (T*)g3, red, 1)));
+    DISPATCH_GA(dtype, (stem_c4_bwd_kernel<T, TA, 0><<<nblk, 256, 0, ST>>>((const TA*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
+                                                                          nb, F, Tn, (T*)g3, red, 1)));
     SARSSL_CHECK_LAUNCH("stem_c4_bwd_kernel");
     return 0;
 }
@@ -1239,18 +1253,19 @@ extern "C" int sarssl_stem_c4_bwd_sums(const void* y3, const void* dy4, const fl
                                        void* stream) {
     if (SARSSL_ZERO(red, 384 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     constexpr int fast = 1;      // 4-channel-per-thread kernel wherever its shape constraints hold (the general kernel covers the rest)
-    if (fast && dtype == SARSSL_BF16 && (F & 15) == 0 && (Tn & 15) == 0 && nb > 0) {
+    if (fast && (dtype == SARSSL_BF16 || dtype == SARSSL_MIX16) && (F & 15) == 0 && (Tn & 15) == 0 && nb > 0) {
         const long ntile = (long)nb * (F >> 4) * (Tn >> 4);
         static const int cap = grid_cap("SARSSL_GRID_C4S", 1024);         // 4 workgroups per CU
         const int nblk = (int)(ntile < cap ? ntile : cap);
         static const int nstream = grid_cap("SARSSL_C4S_STREAMS", 1);
-        stem_c4_bwd_sums16_kernel<<<nblk, 256, 0, ST>>>((const bf16*)y3, (const bf16*)dy4, W4, scale, shift, mean, rstd, nb, F, Tn, red, nstream);
+        if (dtype == SARSSL_MIX16) stem_c4_bwd_sums16_kernel<f16><<<nblk, 256, 0, ST>>>((const f16*)y3, (const bf16*)dy4, W4, scale, shift, mean, rstd, nb, F, Tn, red, nstream);
+        else stem_c4_bwd_sums16_kernel<bf16><<<nblk, 256, 0, ST>>>((const bf16*)y3, (const bf16*)dy4, W4, scale, shift, mean, rstd, nb, F, Tn, red, nstream);
         SARSSL_CHECK_LAUNCH("stem_c4_bwd_sums16_kernel");
         return 0;
     }
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 1024);
-    DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 1><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
-                                                                     nb, F, Tn, (T*)nullptr, red, 1)));
+    DISPATCH_GA(dtype, (stem_c4_bwd_kernel<T, TA, 1><<<nblk, 256, 0, ST>>>((const TA*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
+                                                                          nb, F, Tn, (T*)nullptr, red, 1)));
     SARSSL_CHECK_LAUNCH("stem_c4_bwd_kernel<sums>");
     return 0;
 }
@@ -1269,8 +1284,8 @@ extern "C" int sarssl_stem_c4_bwd_apply_pg(const void* y3, const void* dy4, cons
     SARSSL_REQUIRE((gW4 == nullptr) == (dgamma == nullptr) && (gW4 == nullptr) == (dbeta == nullptr), "sarssl_stem_c4_bwd_apply_pg");
     static const int cap = grid_cap("SARSSL_GRID_C4A", 4096);
     const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, cap);
-    DISPATCH_T(dtype, (stem_c4_bwd_kernel<T, 2><<<nblk, 256, 0, ST>>>((const T*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
-                                                                     nb, F, Tn, (T*)dy3, (double*)red, use_stats, gW4, dgamma, dbeta)));
+    DISPATCH_GA(dtype, (stem_c4_bwd_kernel<T, TA, 2><<<nblk, 256, 0, ST>>>((const TA*)y3, (const T*)dy4, W4, scale, shift, mean, rstd,
+                                                                          nb, F, Tn, (T*)dy3, (double*)red, use_stats, gW4, dgamma, dbeta)));
     SARSSL_CHECK_LAUNCH("stem_c4_bwd_kernel<apply>");
     return 0;
 }
@@ -1340,8 +1355,8 @@ extern "C" int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, in
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L), "sarssl_cl_bn_bwd_reduce");
     if (SARSSL_ZERO(red, 2 * C * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     const dim3 grid = cl_grid(rows, L, C);
-    DISPATCH_T(dtype, (cl_bn_bwd_reduce_kernel<T><<<grid, 256, 0, ST>>>((const T*)dz, (const T*)y, rows, L, C, scale, shift,
-                                                                       mean, rstd, act, red)));
+    DISPATCH_GA(dtype, (cl_bn_bwd_reduce_kernel<T, TA><<<grid, 256, 0, ST>>>((const T*)dz, (const TA*)y, rows, L, C, scale, shift,
+                                                                            mean, rstd, act, red)));
     SARSSL_CHECK_LAUNCH("cl_bn_bwd_reduce_kernel");
     return 0;
 }
@@ -1365,7 +1380,7 @@ extern "C" int sarssl_cl_bn_bwd_apply_pg(const void* dz, const void* y, long N, 
     const int rpb_ = 256 / (L >> 3);
     long nb_ = (rows + (long)rpb_ * 2 - 1) / ((long)rpb_ * 2); if (nb_ < 1) nb_ = 1;          // two rows per thread and round
     const int grid_ = (int)(nb_ > cap ? cap : nb_);
-    DISPATCH_T(dtype, (cl_bn_bwd_apply_kernel<T><<<grid_, 256, 0, ST>>>((const T*)dz, (const T*)y, rows, L, C, N, scale,
+    DISPATCH_GA(dtype, (cl_bn_bwd_apply_kernel<T, TA><<<grid_, 256, 0, ST>>>((const T*)dz, (const TA*)y, rows, L, C, N, scale,
                                                                                      shift, mean, rstd, act, g_is_masked,
                                                                                      use_stats, red, (T*)dy, dgamma, dbeta)));
     SARSSL_CHECK_LAUNCH("cl_bn_bwd_apply_kernel");

@@ -102,19 +102,29 @@ class FlatGradAllReduce:
     def finish(self):
         """Wait for all outstanding buckets (also reduces every span no stage hook fired for in this step, e.g. 'other' parameters
         not owned by a stage).  Returns the gradient scale (1/world) to fold into the optimizer step."""
+        bad = {}
         if self.strict and not self._closed:
             bad = {n: self._calls.get(n, 0) for n in self.spans if n in STAGES and self._calls.get(n, 0) != 1}
-            assert not bad, "gradient buckets must be reported exactly once per step, got %r" % (bad,)
-        if self.world > 1:
-            for name, (s, e) in sorted(self.spans.items(), key=lambda kv: kv[1]):
-                if name not in self._fired:
-                    self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-        for h in self.handles:
-            h.wait()
-        self.handles = []
-        self._fired = set()
-        self._closed = True
-        self.nsteps += 1
+        # drain first, complain afterwards: a failed check must not leave collectives in flight or stale per-step counters behind
+        try:
+            if self.world > 1:
+                for name, (s, e) in sorted(self.spans.items(), key=lambda kv: kv[1]):
+                    if name not in self._fired:
+                        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            for h in self.handles:
+                h.wait()
+        finally:
+            self.handles = []
+            self._fired = set()
+            self._calls = {}
+            self._closed = True
+            self.nsteps += 1
+        if bad:
+            msg = "gradient buckets must be reported exactly once per step, got %r" % (bad,)
+            if self.world > 1:                            # nothing is exchanged at world 1 (e.g. a manual extra backward): only say so
+                raise AssertionError(msg)
+            import warnings
+            warnings.warn(msg + " (world size 1: nothing was exchanged)")
         return 1.0 / self.world
 
     def describe(self):

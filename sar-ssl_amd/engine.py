@@ -13,7 +13,9 @@ import os
 import torch
 
 from . import hip
-from .runtime import RT, wt, gbuf, weights_version
+from .runtime import RT, wt, wtg, gbuf, weights_version
+
+_16 = (torch.bfloat16, torch.float16)          # 16-bit activation storage: the fused kernels' domain
 
 RELU, SWISH = 1, 2
 
@@ -127,7 +129,7 @@ def mm_tn_acc(dy, x, gW, group=True, bias=None):
     M, N = dy.shape
     K = x.shape[1]
     g2 = gW.view(N, K)
-    grouped = bool(group and _wg_blocks and RT.replay is None and _WGRAD_GROUP and RT.dtype == torch.bfloat16)
+    grouped = bool(group and _wg_blocks and RT.replay is None and _WGRAD_GROUP and RT.dtype in _16)
     split = _wgrad_split(M, N, K, grouped)
     if grouped:
         if bias is not None and not _WGRAD_CSUM:             # A/B: bias gradient by the stand-alone column-sum launch
@@ -142,6 +144,11 @@ def mm_tn_acc(dy, x, gW, group=True, bias=None):
 
 def to_rt(x):
     return x if x.dtype == RT.dtype else hip.cast(x.contiguous(), RT.dtype)
+
+
+def to_g(x):
+    """x in the storage dtype of gradients (RT.gdtype)."""
+    return x if x.dtype == RT.gdtype else hip.cast(x.contiguous(), RT.gdtype)
 
 
 def _cached(module, name, builder):
@@ -176,23 +183,25 @@ def bn_param_grads(bn, red, C):
 
 # ------------------------------------------------------------------------------------------------ CNN stem
 def _taps(conv):
-    """(co,ci,3,3) -> forward taps [9][co][ci] and data-gradient taps [9][ci][co] (flipped), runtime dtype."""
+    """(co,ci,3,3) -> forward taps [9][co][ci] (activation dtype) and data-gradient taps [9][ci][co] (flipped; gradient dtype)."""
     def build():                                              # one launch (rebuilt every step: the weights move)
-        return hip.conv_taps(conv.weight.data.contiguous(), RT.dtype)
+        return hip.conv_taps(conv.weight.data.contiguous(), RT.dtype, RT.gdtype)
     return _cached(conv, "taps", build)
 
 
-def _patch_w(conv, F):
-    """(d,4,F,1) -> [d][f*4+c] so the patch conv is a plain GEMM over the (B,T,F,4) tensor."""
+def _patch_w(conv, F, grad=False):
+    """(d,4,F,1) -> [d][f*4+c] so the patch conv is a plain GEMM over the (B,T,F,4) tensor (grad: the gradient-side copy)."""
+    dtype = RT.gdtype if grad else RT.dtype
+
     def build():
-        return hip.patch_w(conv.weight.data.contiguous(), RT.dtype)
-    return _cached(conv, "patchw", build)
+        return hip.patch_w(conv.weight.data.contiguous(), dtype)
+    return _cached(conv, "patchw_g" if (grad and dtype != RT.dtype) else "patchw", build)
 
 
 def stem_fwd(a0, pe, train, saved):
     """``patch_embed`` (code/model.py:50-64) on channels-last a0 (B,F,T,4) -> [B*T, d]."""
     B, F, T, _ = a0.shape
-    fuse = train and RT.dtype == torch.bfloat16          # BatchNorm sums come out of the producing kernel's epilogue
+    fuse = train and RT.dtype in _16                     # BatchNorm sums come out of the producing kernel's epilogue
     W1 = pe[0].weight.data.view(64, 4)
     y1 = y2 = mom1 = None
     if fuse and _C1IN and (B * F * T) % 64 == 0 and not RT.inference:
@@ -256,14 +265,14 @@ def patch_bwd(de, pe, saved):
     a0, z4 = saved[-1][0], saved[-1][9]
     B, F, T, _ = a0.shape
     d = de.shape[1]
-    if RT.dtype == torch.bfloat16 and RT.replay is None:   # split-K partials folded and re-laid-out in one pass (nothing zeroed)
+    if RT.dtype in _16 and RT.replay is None:   # split-K partials folded and re-laid-out in one pass (nothing zeroed)
         ws, nslice = hip.gemm_tn_partials(de, z4, _wgrad_split(de.shape[0], d, F * 4, False))
         hip.patch_wgrad_accum(ws, gbuf(pe[12].weight), nslice)
     else:
         gtmp = torch.zeros((d, F * 4), dtype=torch.float32, device=de.device)
         mm_tn_acc(de, z4, gtmp, group=False)
         hip.patch_wgrad_accum(gtmp, gbuf(pe[12].weight))
-    return mm_nn(de, _patch_w(pe[12], F), fp8=False)                                       # (B,T,F,4)
+    return mm_nn(de, _patch_w(pe[12], F, grad=True), fp8=False)                            # (B,T,F,4)
 
 
 def stem_bwd(dz4, pe, saved):
@@ -282,7 +291,7 @@ def stem_bwd(dz4, pe, saved):
     if dW is not None:
         gbuf(pe[6].weight).add_(dW.view(3, 3, 64, 64).permute(2, 3, 0, 1))
     red2 = None
-    if _DGRAD_BNRED and RT.dtype == torch.bfloat16:   # BatchNorm-backward sums accumulated in the data-gradient kernel's epilogue
+    if _DGRAD_BNRED and RT.dtype in _16:              # BatchNorm-backward sums accumulated in the data-gradient kernel's epilogue
         dz2, red2 = hip.conv3x3_dgrad_bnred(dy3, _taps(pe[6])[1], y2, aff2)
     else:
         dz2 = hip.conv3x3_fwd(dy3, _taps(pe[6])[1], precise=RT.precise)
@@ -369,11 +378,11 @@ def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
     x, ln, stats, hpre, a, p1, s1, p2, s2, factor = saved.pop()
     seq = ff.sequential
     if torch.is_tensor(s1) or torch.is_tensor(s2):        # replayed masks (see ffn_fwd)
-        dz2 = (dy * s2 if torch.is_tensor(s2) else dy) * factor
+        dz2 = (dy * s2.to(dy.dtype) if torch.is_tensor(s2) else dy) * factor
         mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight), bias=gbuf(seq[4].linear.bias))
-        dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH)
+        dh = mm_nn(dz2, wtg(seq[4].linear.weight), aux=hpre, aux_act=SWISH)
         if torch.is_tensor(s1):
-            dh = dh * s1
+            dh = dh * s1.to(dh.dtype)
     else:
         if dy_dropped is not None:
             dz2 = dy_dropped                                  # written by the previous LayerNorm backward (see _next_drop)
@@ -381,9 +390,9 @@ def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
             dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
         mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight), bias=gbuf(seq[4].linear.bias))
         # dh = (dz2 @ W2) * dropout_mask1 * swish'(hpre): activation backward fused into the GEMM epilogue
-        dh = mm_nn(dz2, wt(seq[4].linear.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
+        dh = mm_nn(dz2, wtg(seq[4].linear.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
     mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight), bias=gbuf(seq[1].linear.bias))
-    dln = mm_nn(dh, wt(seq[1].linear.weight))
+    dln = mm_nn(dh, wtg(seq[1].linear.weight))
     return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
                              drop=_next_drop(next_kind, saved))
 
@@ -404,11 +413,11 @@ def _adjacent(ts):
         all(ts[i + 1].data_ptr() == ts[i].data_ptr() + ts[i].numel() * ts[i].element_size() for i in range(len(ts) - 1))
 
 
-def _qkv_views(att):
+def _qkv_views(att, grad=False):
     """([3d,d] weight view, [3d] bias view, their gradient views) when q/k/v parameters are contiguous in memory
-    (runtime.FlatParams lays them out that way), else None."""
+    (runtime.FlatParams lays them out that way), else None.  grad: the weight view of the backward pass (gradient-side dtype)."""
     projs = (att.query_proj.linear, att.key_proj.linear, att.value_proj.linear)
-    ws = [wt(l.weight) for l in projs]
+    ws = [(wtg if grad else wt)(l.weight) for l in projs]
     bs = [l.bias.data for l in projs]
     gw = [gbuf(l.weight) for l in projs]
     gb = [gbuf(l.bias) for l in projs]
@@ -497,24 +506,24 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
     dev = x.device
     fused_attn = isinstance(pd, tuple)                                # fused forward saved (bias, (ctx32, lse)) in place of (p, pd)
     if torch.is_tensor(so):
-        dout = dy * so                                     # replayed mask
+        dout = dy * so.to(dy.dtype)                        # replayed mask
     elif dy_dropped is not None:
         dout = dy_dropped
     else:
         dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
     mm_tn_acc(dout, ctx, gbuf(att.out_proj.linear.weight), bias=gbuf(att.out_proj.linear.bias))
-    dctx = mm_nn(dout, wt(att.out_proj.linear.weight))
-    fused = _qkv_views(att)
+    dctx = mm_nn(dout, wtg(att.out_proj.linear.weight))
+    fused = _qkv_views(att, grad=True)
     ldk = k.stride(0)
     if fused is not None:                       # dq | dk | dv are written straight into one [M, 3d] buffer
-        dqkv = torch.empty((M, 3 * d), dtype=RT.dtype, device=dev)
+        dqkv = torch.empty((M, 3 * d), dtype=RT.gdtype, device=dev)
         dqu, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
         if fused_attn:      # the content-score part of dq in its own buffer: its column sum (u_bias gradient) can then wait for the
-            dqu = torch.empty((M, d), dtype=RT.dtype, device=dev)     # block's batched launch instead of running before dq overwrites it
+            dqu = torch.empty((M, d), dtype=RT.gdtype, device=dev)    # block's batched launch instead of running before dq overwrites it
     else:
-        dqu = torch.empty((M, d), dtype=RT.dtype, device=dev)
-        dk = torch.empty((M, d), dtype=RT.dtype, device=dev)
-        dv = torch.empty((M, d), dtype=RT.dtype, device=dev)
+        dqu = torch.empty((M, d), dtype=RT.gdtype, device=dev)
+        dk = torch.empty((M, d), dtype=RT.gdtype, device=dev)
+        dv = torch.empty((M, d), dtype=RT.gdtype, device=dev)
     ldg = dqu.stride(0)
     scale = 1.0 / math.sqrt(d)
     if fused_attn:
@@ -524,11 +533,11 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
     else:
         dps = _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ldg, scale, pa, sa)
     nbh = B * H
-    dqv = torch.empty((M, d), dtype=RT.dtype, device=dev)
+    dqv = torch.empty((M, d), dtype=RT.gdtype, device=dev)
     hip.gemm(dps, pos, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(0, dh), out=dqv, ldc=d, sC=(T * d, dh), precise=RT.precise)
     # d pos (per batch item, then summed over the batch): dpos[b][m][h,:] = sum_i dps[b,h,i,m] * qv[b,i,h,:]
-    dposb = torch.empty((B, T, d), dtype=RT.dtype, device=dev)
+    dposb = torch.empty((B, T, d), dtype=RT.gdtype, device=dev)
     hip.gemm(dps, qv, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=nbh, batch_inner=H,
              sA=(H * T * T, T * T), sB=(T * d, dh), out=dposb, ldc=d, sC=(T * d, dh), precise=RT.precise)
     del dps
@@ -560,12 +569,12 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
 
 def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None, dq_out=None):
     """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
-    if dposb.dtype == RT.dtype:                                      # batch sum straight into the GEMM operand's dtype: one launch
+    if dposb.dtype == RT.gdtype:                                     # batch sum straight into the GEMM operand's dtype: one launch
         dpos_rt = hip.colsum_store(dposb.view(B, T * d)).view(T, d)
     else:
         dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
         hip.colsum(dposb.view(B, T * d), dpos, now=True)             # consumed right below
-        dpos_rt = to_rt(dpos.view(T, d))
+        dpos_rt = to_g(dpos.view(T, d))
     mm_tn_acc(dpos_rt, pe, gbuf(att.pos_proj.linear.weight))
     if dq_out is None:
         dq_out = dqu
@@ -579,9 +588,9 @@ def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb
     else:
         for proj, g in ((att.query_proj, dq), (att.key_proj, dk), (att.value_proj, dv)):
             mm_tn_acc(g, ln, gbuf(proj.linear.weight), bias=gbuf(proj.linear.bias))
-        dln = mm_nn(dq, wt(att.query_proj.linear.weight))
-        dln = mm_nn(dk, wt(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
-        dln = mm_nn(dv, wt(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
+        dln = mm_nn(dq, wtg(att.query_proj.linear.weight))
+        dln = mm_nn(dk, wtg(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
+        dln = mm_nn(dv, wtg(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
     return hip.layernorm_bwd(dln, x, mod.layer_norm.weight.data, stats, resid=dy, dgamma=gbuf(mod.layer_norm.weight),
                              dbeta=gbuf(mod.layer_norm.bias), drop=drop)
 
@@ -621,13 +630,13 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
     d = x.shape[1]
     pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
     if torch.is_tensor(so):
-        dout = dy * so
+        dout = dy * so.to(dy.dtype)
     elif dy_dropped is not None:
         dout = dy_dropped
     else:
         dout = hip.act_bwd(dy, None, 0, p_drop=po, seed=so) if po > 0 else dy
     mm_tn_acc(dout, s, gbuf(pw2.weight), bias=gbuf(pw2.bias))
-    ds = mm_nn(dout, wt(pw2.weight).view(d, d))
+    ds = mm_nn(dout, wtg(pw2.weight).view(d, d))
     red = hip.cl_bn_bwd_reduce(ds, c, d, aff, SWISH)
     dc = hip.cl_bn_bwd_apply(ds, c, d, aff, SWISH, False, train, red, out=ds, pgrads=(gbuf(bn.weight), gbuf(bn.bias))).view(B, T, d)
     if g is None:                        # fused forward: the GLU output was never stored
@@ -638,7 +647,7 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
         hip.dwconv_wgrad(dc, g.view(B, T, d), gbuf(dw.weight).view(d, -1))
         dh = hip.glu_bwd(dg.view(B * T, d), h)
     mm_tn_acc(dh, ln, gbuf(pw1.weight), bias=gbuf(pw1.bias))
-    dln = mm_nn(dh, wt(pw1.weight).view(2 * d, d))
+    dln = mm_nn(dh, wtg(pw1.weight).view(2 * d, d))
     return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
                              drop=_next_drop(next_kind, saved))
 
@@ -702,6 +711,6 @@ def decoder_bwd(dpred, dec, saved):
     l1, l2 = dec.proj[0], dec.proj[2]
     with hip.colsum_batched(), hip.splitk_batched(), wgrad_block():
         mm_tn_acc(dpred, h, gbuf(l2.weight), bias=gbuf(l2.bias))
-        dh = mm_nn(dpred, wt(l2.weight), fp8=False, aux=h, aux_act=RELU)
+        dh = mm_nn(dpred, wtg(l2.weight), fp8=False, aux=h, aux_act=RELU)
         mm_tn_acc(dh, e, gbuf(l1.weight), bias=gbuf(l1.bias))
-        return mm_nn(dh, wt(l1.weight), fp8=False)
+        return mm_nn(dh, wtg(l1.weight), fp8=False)

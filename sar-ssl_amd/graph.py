@@ -126,7 +126,7 @@ class PretrainStepGraph:
         elif self.reducer is not None:
             self.reducer.finish()                          # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
-                          zero_grad=self.zero_grad_in_adam)
+                          zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16)
 
     def step_eager(self, x=None, pcm=None):
         """The same step enqueued launch by launch (inputs whose shape differs from the captured one, e.g. a ragged last batch):

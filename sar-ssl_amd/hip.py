@@ -11,12 +11,29 @@ import torch
 from . import _lib
 from ._lib import c_void_p, c_int, c_long, c_float, c_ulonglong
 
-F32, BF16, I16 = 0, 1, 2
-_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.int16: I16}
+F32, BF16, I16, F16, MIX16 = 0, 1, 2, 3, 4
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.int16: I16, torch.float16: F16}
+_16 = (torch.bfloat16, torch.float16)
 
 
 def dt(t):
     return _DT[t.dtype]
+
+
+def dt_ga(g, a):
+    """dtype code of a backward kernel that reads the gradient tensor ``g`` next to the tensor ``a`` SAVED BY THE FORWARD PASS: their
+    common dtype, or MIX16 for bf16 gradients + fp16 saved activations (the fp16-forward / bf16-backward mode, include/sarssl_hip.h).
+    Anything else is a plumbing error and raises here instead of being reinterpreted by a kernel."""
+    if a is None or g.dtype == a.dtype:
+        return _DT[g.dtype]
+    if g.dtype == torch.bfloat16 and a.dtype == torch.float16:
+        return MIX16
+    raise _lib.SarsslHipError("unsupported gradient / saved-activation dtype pair (%s, %s)" % (g.dtype, a.dtype))
+
+
+def gdtype_of(a_dtype):
+    """Gradient dtype that goes with activations of ``a_dtype``: bf16 for fp16 activations (no loss scaling needed), else the same."""
+    return torch.bfloat16 if a_dtype == torch.float16 else a_dtype
 
 
 def _p(t):
@@ -137,7 +154,7 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     ws = None
     deferred = None
     if split_k > 0:
-        if (_splitk_batch is not None and nbatch == 1 and A.dtype == torch.bfloat16 and out.dtype == torch.float32 and N % 4 == 0
+        if (_splitk_batch is not None and nbatch == 1 and A.dtype == torch.bfloat16 and B.dtype in _16 and out.dtype == torch.float32 and N % 4 == 0
                 and ldc % 4 == 0):
             # weight-gradient product inside splitk_batched(): write the partials only, fold them into `out` together with the
             # stage's other products when the batch closes
@@ -155,7 +172,8 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
               c_long(sA[0]), c_long(sA[1]), c_long(sB[0]), c_long(sB[1]), c_long(sC[0]), c_long(sC[1]),
               c_float(alpha), c_float(out_scale), _p(bias), c_int(act),
               _p(resid), c_long(ldr), c_long(sR[0]), c_long(sR[1]), c_float(res_scale),
-              _p(preact), _p(aux), c_int(aux_act), c_float(p_drop), c_ulonglong(seed), c_int(1 if (precise and A.dtype == torch.float32) else 0),
+              _p(preact), _p(aux), c_int(aux_act), c_int(dt(aux) if aux is not None else dt(out)), c_float(p_drop), c_ulonglong(seed),
+              c_int(1 if (precise and A.dtype == torch.float32) else 0),
               _p(ws), c_int(split_k), c_int(1 if c_row_shift else 0), _stream())
     if deferred is not None:
         _splitk_batch.append(deferred)
@@ -177,7 +195,7 @@ def gemm_group_tn(items):
     if _splitk_batch is None or n == 0 or n > 12:
         return False
     for dy, x, out, split, _ in items:
-        if not (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and out.dtype == torch.float32 and dy.stride(1) == 1
+        if not (dy.dtype == torch.bfloat16 and x.dtype == items[0][1].dtype and x.dtype in _16 and out.dtype == torch.float32 and dy.stride(1) == 1
                 and x.stride(1) == 1 and out.shape[1] % 4 == 0 and out.stride(0) % 4 == 0 and dy.shape[1] % 128 == 0
                 and x.shape[1] % 128 == 0):
             return False
@@ -192,7 +210,7 @@ def gemm_group_tn(items):
         arr(ctypes.c_int, [it[1].shape[1] for it in items]), arr(ctypes.c_int, [it[0].shape[0] for it in items]),
         arr(ctypes.c_long, [it[0].stride(0) for it in items]), arr(ctypes.c_long, [it[1].stride(0) for it in items]),
         arr(ctypes.c_int, [it[3] for it in items]), split_out, arr(ctypes.c_void_p, [c.data_ptr() if c is not None else None for c in cs]),
-        c_int(n), _stream())
+        c_int(n), c_int(dt(items[0][1])), _stream())
     _lib.ncalls += 1
     if rc == 1:
         return False
@@ -234,6 +252,17 @@ def splitk_flush():
 
 def _splitk_flush_items(items, n):
     import ctypes
+    # The reduce launch does a non-atomic read-modify-write of every destination from parallel workgroups: two problems with the same
+    # destination (a tied / shared parameter, one bias accumulated twice in a block) must not share a launch (advisor, round 3)
+    seen = set()
+    for i, it in enumerate(items):
+        dst = it[4].data_ptr()
+        assert dst % 16 == 0, "split-K fold destinations must be 16-byte aligned"
+        if dst in seen:
+            _splitk_flush_items(items[:i], i)
+            _splitk_flush_items(items[i:], n - i)
+            return
+        seen.add(dst)
     ws = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
     C = (ctypes.c_void_p * n)(*[it[4].data_ptr() for it in items])
     ns = (ctypes.c_int * n)(*[it[1] for it in items])
@@ -398,11 +427,11 @@ def conv3x3_dgrad_c1red(dy, w_tap_dgrad, a0, W1, aff, mom, train, dW1, dgamma, d
     layer's parameter gradients; the 64-channel gradient tensor is never stored (mom = the input's moments from stem_c1_stats)."""
     _need_cuda(dy, w_tap_dgrad, a0, W1, aff, mom)
     B, F, T, _ = a0.shape
-    assert dy.dtype == torch.bfloat16 and a0.dtype == torch.bfloat16 and dy.shape == (B, F, T, 64)
+    assert dy.dtype == torch.bfloat16 and a0.dtype in _16 and dy.shape == (B, F, T, 64)
     red = _sums(644, a0.device)
     with _Timed("conv3x3_dgrad_c1red"):
         _lib.call("sarssl_conv3x3_dgrad_c1red", _p(dy), _p(w_tap_dgrad), _p(a0), _p(W1), _p(aff[0]), _p(aff[1]), c_int(B), c_int(F), c_int(T),
-                  _p(red), _stream())
+                  _p(red), c_int(dt(a0)), _stream())
     _lib.call("sarssl_stem_c1_bwd_finalize_mom", _p(red), _p(mom), _p(W1), c_long(B * F * T), _p(aff), c_int(1 if train else 0),
               _p(dW1), _p(dgamma), _p(dbeta), _stream())
     return True
@@ -411,17 +440,17 @@ def conv3x3_dgrad_c1red(dy, w_tap_dgrad, a0, W1, aff, mom, train, dW1, dgamma, d
 def stem_c1_bwd_a0(dz1, a0, W1, aff, train, dW1, dgamma, dbeta):
     """stem_c1_bwd with y1 = W1 a0 recomputed from the input instead of read (bf16, pixel count a multiple of 64)."""
     npix = a0.numel() // 4
-    assert a0.dtype == torch.bfloat16 and npix % 64 == 0
+    assert a0.dtype in _16 and dz1.dtype == torch.bfloat16 and npix % 64 == 0
     ws = _sums(644, a0.device)
     _lib.call("sarssl_stem_c1_bwd_a0", _p(dz1), _p(a0), _p(W1), c_long(npix), _p(aff), c_int(1 if train else 0), _p(ws), _p(dW1),
-              _p(dgamma), _p(dbeta), _stream())
+              _p(dgamma), _p(dbeta), c_int(dt_ga(dz1, a0)), _stream())
 
 
 def stem_c1_wgrad(dy1, a0, grad_out):
     """grad_out (64,4,1,1) f32 += dW1."""
     npix = a0.numel() // 4
     ws = _f64ws(256, a0.device, "c1w")
-    _lib.call("sarssl_stem_c1_wgrad", _p(dy1), _p(a0), c_long(npix), _p(ws), c_int(dt(a0)), _stream())
+    _lib.call("sarssl_stem_c1_wgrad", _p(dy1), _p(a0), c_long(npix), _p(ws), c_int(dt_ga(dy1, a0)), _stream())
     _lib.call("sarssl_f64_accum", _p(ws), _p(grad_out), c_int(256), c_float(1.0), _stream())
 
 
@@ -430,7 +459,7 @@ def stem_c1_wgrad_bn(dz1, y1, a0, aff, red, train, grad_out):
     npix = a0.numel() // 4
     ws = _f64ws(256, a0.device, "c1w")
     _lib.call("sarssl_stem_c1_wgrad_bn", _p(dz1), _p(y1), _p(a0), c_long(npix), _p(aff), _p(red), c_int(1 if train else 0), _p(ws),
-              c_int(dt(a0)), _stream())
+              c_int(dt_ga(dz1, a0)), _stream())
     _lib.call("sarssl_f64_accum", _p(ws), _p(grad_out), c_int(256), c_float(1.0), _stream())
 
 
@@ -439,8 +468,9 @@ def stem_c1_bwd(dz1, y1, a0, aff, train, dW1, dgamma, dbeta):
     relu(bn1(y1))."""
     npix = a0.numel() // 4
     ws = _sums(644, a0.device)                 # (arena slice: already zero, no memset launch)
+    assert y1.dtype == a0.dtype
     _lib.call("sarssl_stem_c1_bwd", _p(dz1), _p(y1), _p(a0), c_long(npix), _p(aff), c_int(1 if train else 0), _p(ws), _p(dW1),
-              _p(dgamma), _p(dbeta), c_int(dt(a0)), _stream())
+              _p(dgamma), _p(dbeta), c_int(dt_ga(dz1, a0)), _stream())
 
 
 def stem_c4_fwd(y3, W4, scale, shift, want_stats=False):
@@ -459,10 +489,10 @@ def stem_c4_fwd(y3, W4, scale, shift, want_stats=False):
 def stem_c4_bwd(y3, dy4, W4, aff):
     """-> g3 (B,F,T,64), red f64[384] = [dW4 (4x64) | s1 (64) | s2 (64)]."""
     B, F, T, _ = y3.shape
-    g3 = torch.empty_like(y3)
+    g3 = torch.empty(y3.shape, dtype=dy4.dtype, device=y3.device)
     red = _sums(384, y3.device)
     _lib.call("sarssl_stem_c4_bwd", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
-              c_int(T), _p(g3), _p(red), c_int(dt(y3)), _stream())
+              c_int(T), _p(g3), _p(red), c_int(dt_ga(dy4, y3)), _stream())
     return g3, red
 
 
@@ -473,11 +503,11 @@ def stem_c4_bwd_two_phase(y3, dy4, W4, aff, train, pgrads=None):
     B, F, T, _ = y3.shape
     red = _sums(384, y3.device)
     _lib.call("sarssl_stem_c4_bwd_sums", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
-              c_int(T), _p(red), c_int(dt(y3)), _stream())
-    dy3 = torch.empty_like(y3)
+              c_int(T), _p(red), c_int(dt_ga(dy4, y3)), _stream())
+    dy3 = torch.empty(y3.shape, dtype=dy4.dtype, device=y3.device)
     gw, dg, db = pgrads if pgrads is not None else (None, None, None)
     _lib.call("sarssl_stem_c4_bwd_apply_pg", _p(y3), _p(dy4), _p(W4), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(B), c_int(F),
-              c_int(T), _p(red), c_int(1 if train else 0), _p(dy3), _p(gw), _p(dg), _p(db), c_int(dt(y3)), _stream())
+              c_int(T), _p(red), c_int(1 if train else 0), _p(dy3), _p(gw), _p(dg), _p(db), c_int(dt_ga(dy4, y3)), _stream())
     return dy3, red
 
 
@@ -486,13 +516,20 @@ def f64_accum2(src, dst1, dst2):
     _lib.call("sarssl_f64_accum2", _p(src), _p(dst1), _p(dst2), c_int(dst1.numel()), _stream())
 
 
-def conv_taps(W, dtype):
-    """(64,64,3,3) f32 weight -> (fwd [9][co][ci], dgrad [9][ci][co] with flipped taps) in `dtype`, one launch."""
+def conv_taps(W, dtype, gdtype=None):
+    """(64,64,3,3) f32 weight -> (fwd [9][co][ci] in `dtype`, dgrad [9][ci][co] with flipped taps in `gdtype` (default: `dtype`)), one
+    launch.  (fp16, bf16) is the pair of the fp16-forward mode: forward taps fp16, data-gradient taps bf16."""
     _need_cuda(W)
     assert W.shape == (64, 64, 3, 3) and W.dtype == torch.float32 and W.is_contiguous()
+    gdtype = gdtype or dtype
     fwd = torch.empty((9, 64, 64), dtype=dtype, device=W.device)
-    dgr = torch.empty((9, 64, 64), dtype=dtype, device=W.device)
-    _lib.call("sarssl_conv_taps", _p(W), _p(fwd), _p(dgr), c_int(_DT[dtype]), _stream())
+    dgr = torch.empty((9, 64, 64), dtype=gdtype, device=W.device)
+    if gdtype != dtype:
+        assert (dtype, gdtype) == (torch.float16, torch.bfloat16)
+        code = MIX16
+    else:
+        code = _DT[dtype]
+    _lib.call("sarssl_conv_taps", _p(W), _p(fwd), _p(dgr), c_int(code), _stream())
     return fwd, dgr
 
 
@@ -518,14 +555,14 @@ def gemm_tn_partials(dy, x, split):
     _need_cuda(dy, x)
     Mr, N = dy.shape
     K = x.shape[1]
-    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and split > 0
+    assert dy.dtype == torch.bfloat16 and x.dtype in _16 and split > 0
     per = ((Mr + split - 1) // split + 63) // 64 * 64
     nslice = (Mr + per - 1) // per
     ws = torch.empty((nslice, N, K), dtype=torch.float32, device=dy.device)
-    _lib.call("sarssl_gemm", _p(dy), _p(x), c_void_p(0), c_int(BF16), c_int(BF16), c_int(F32), c_int(0), c_int(0), c_int(N), c_int(K),
+    _lib.call("sarssl_gemm", _p(dy), _p(x), c_void_p(0), c_int(BF16), c_int(dt(x)), c_int(F32), c_int(0), c_int(0), c_int(N), c_int(K),
               c_int(Mr), c_long(dy.stride(0)), c_long(x.stride(0)), c_long(K), c_int(1), c_int(1),
               c_long(0), c_long(0), c_long(0), c_long(0), c_long(0), c_long(0), c_float(1.0), c_float(1.0), c_void_p(0), c_int(0),
-              c_void_p(0), c_long(0), c_long(0), c_long(0), c_float(1.0), c_void_p(0), c_void_p(0), c_int(0), c_float(0.0),
+              c_void_p(0), c_long(0), c_long(0), c_long(0), c_float(1.0), c_void_p(0), c_void_p(0), c_int(0), c_int(F32), c_float(0.0),
               c_ulonglong(0), c_int(0), _p(ws), c_int(split), c_int(0), _stream())
     return ws, nslice
 
@@ -556,12 +593,12 @@ def conv3x3_fwd_c1(a0, W1, scale, shift, w_tap, want_stats=False):
     64-channel output is formed while staging, never stored.  -> out (B,F,T,64) bf16 (or (out, stats f64[128]))."""
     _need_cuda(a0, W1, scale, shift, w_tap)
     B, F, T, C = a0.shape
-    assert C == 4 and a0.dtype == torch.bfloat16 and w_tap.dtype == torch.bfloat16 and a0.is_contiguous() and W1.is_contiguous()
-    out = torch.empty((B, F, T, 64), dtype=torch.bfloat16, device=a0.device)
+    assert C == 4 and a0.dtype in _16 and w_tap.dtype == a0.dtype and a0.is_contiguous() and W1.is_contiguous()
+    out = torch.empty((B, F, T, 64), dtype=a0.dtype, device=a0.device)
     stats = _sums(128, a0.device) if want_stats else None
     with _Timed("conv3x3_fwd_c1"):
         _lib.call("sarssl_conv3x3_fwd_c1", _p(a0), _p(W1), _p(scale), _p(shift), _p(w_tap), _p(out), c_int(B), c_int(F), c_int(T), _p(stats),
-                  _stream())
+                  c_int(dt(a0)), _stream())
     return (out, stats) if want_stats else out
 
 
@@ -575,13 +612,13 @@ def conv3x3_wgrad_c1(dy, a0, W1, scale, shift, acc_into):
     while staging."""
     _need_cuda(dy, a0, W1)
     B, F, T, _ = a0.shape
-    assert a0.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and acc_into.shape == (64, 64, 3, 3) and acc_into.is_contiguous()
+    assert a0.dtype in _16 and dy.dtype == torch.bfloat16 and acc_into.shape == (64, 64, 3, 3) and acc_into.is_contiguous()
     nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
     nbytes.restype = c_long
     part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), a0.device, "wgrad_part")
     with _Timed("conv3x3_wgrad_kernel"):
         _lib.call("sarssl_conv3x3_wgrad_c1_acc", _p(dy), _p(a0), _p(W1), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(acc_into),
-                  _p(part), _stream())
+                  _p(part), c_int(dt(a0)), _stream())
     return True
 
 
@@ -590,13 +627,13 @@ def conv3x3_dgrad_bnred(dy, w_tap_dgrad, y, aff):
     ``y``, ``aff`` = (4,64) scale|shift|mean|rstd), accumulated in the convolution's epilogue (bf16)."""
     _need_cuda(dy, w_tap_dgrad, y, aff)
     B, F, T, C = dy.shape
-    assert C == 64 and dy.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and y.shape == dy.shape
+    assert C == 64 and dy.dtype == torch.bfloat16 and w_tap_dgrad.dtype == torch.bfloat16 and y.dtype in _16 and y.shape == dy.shape
     assert aff.dtype == torch.float32 and aff.is_contiguous() and aff.numel() == 256 and dy.is_contiguous() and y.is_contiguous()
     dz = torch.empty_like(dy)
     red = _sums(128, dy.device)
     with _Timed("conv3x3_dgrad_bnred"):          # (its own label: this launch also reads y and reduces)
         _lib.call("sarssl_conv3x3_dgrad_bnred", _p(dy), _p(w_tap_dgrad), _p(dz), c_int(B), c_int(F), c_int(T), _p(y), _p(aff), _p(red),
-                  _stream())
+                  c_int(dt(y)), _stream())
     return dz, red
 
 
@@ -608,15 +645,15 @@ def conv3x3_wgrad(dy, zin, scale=None, shift=None, precise=False, acc_into=None)
     nbytes = _lib.lib().sarssl_conv3x3_wgrad_workspace_bytes
     nbytes.restype = c_long
     part = workspace(nbytes(c_int(B), c_int(F), c_int(T)), zin.device, "wgrad_part")
-    if acc_into is not None and zin.dtype == torch.bfloat16:
-        assert acc_into.shape == (64, 64, 3, 3) and acc_into.dtype == torch.float32 and acc_into.is_contiguous()
+    if acc_into is not None and zin.dtype in _16:
+        assert acc_into.shape == (64, 64, 3, 3) and acc_into.dtype == torch.float32 and acc_into.is_contiguous() and dy.dtype == torch.bfloat16
         with _Timed("conv3x3_wgrad_kernel"):
             _lib.call("sarssl_conv3x3_wgrad_acc", _p(dy), _p(zin), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(acc_into),
-                      _p(part), _stream())
+                      _p(part), c_int(dt(zin)), _stream())
         return None
     dW = torch.empty((9, 64, 64), dtype=torch.float32, device=zin.device)
     with _Timed("conv3x3_wgrad_kernel"):
-        _lib.call("sarssl_conv3x3_wgrad", _p(dy), _p(zin), c_int(dt(zin)), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW),
+        _lib.call("sarssl_conv3x3_wgrad", _p(dy), _p(zin), c_int(dt_ga(dy, zin)), c_int(B), c_int(F), c_int(T), _p(scale), _p(shift), _p(dW),
                   _p(part), c_int(1 if (precise and zin.dtype == torch.float32) else 0), _stream())
     return dW
 
@@ -659,18 +696,18 @@ def cl_affine_act(x, C, aff, act):
 def cl_bn_bwd_reduce(dz, y, C, aff, act):
     red = _sums(2 * C, y.device)
     _lib.call("sarssl_cl_bn_bwd_reduce", _p(dz), _p(y), c_long(y.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), _p(aff[2]),
-              _p(aff[3]), c_int(act), _p(red), c_int(dt(y)), _stream())
+              _p(aff[3]), c_int(act), _p(red), c_int(dt_ga(dz, y)), _stream())
     return red
 
 
 def cl_bn_bwd_apply(dz, y, C, aff, act, g_is_masked, use_stats, red, out=None, pgrads=None):
     """pgrads = (dgamma, dbeta) f32 [C] gradient buffers: dbeta += red[:C], dgamma += red[C:] in the same launch."""
     if out is None:
-        out = torch.empty_like(y)
+        out = torch.empty(y.shape, dtype=dz.dtype, device=y.device)
     dg, db = pgrads if pgrads is not None else (None, None)
     _lib.call("sarssl_cl_bn_bwd_apply_pg", _p(dz), _p(y), c_long(y.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), _p(aff[2]),
               _p(aff[3]), c_int(act), c_int(1 if g_is_masked else 0), c_int(1 if use_stats else 0), _p(red), _p(out), _p(dg), _p(db),
-              c_int(dt(y)), _stream())
+              c_int(dt_ga(dz, y)), _stream())
     return out
 
 
@@ -730,7 +767,7 @@ def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, 
     gscale)`` would compute in its own pass; then the result is (out, out2)."""
     M, d = x2d.shape
     if out is None:
-        out = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+        out = torch.empty((M, d), dtype=dy2d.dtype, device=x2d.device)
     part = None
     if dgamma is not None:
         fn = _lib.lib().sarssl_layernorm_bwd_workspace_bytes
@@ -743,15 +780,15 @@ def layernorm_bwd(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, 
             part = workspace(fn(c_long(M), c_int(d)), x2d.device, "ln_part")
     if drop is not None:
         p, seed, gscale = drop
-        out2 = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+        out2 = torch.empty((M, d), dtype=dy2d.dtype, device=x2d.device)
         _lib.call("sarssl_layernorm_bwd_drop", _p(dy2d), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
                   _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out),
                   c_long(out.stride(0)), _p(dgamma), _p(dbeta), _p(part), _p(out2), c_float(p), c_ulonglong(seed), c_float(gscale),
-                  c_int(dt(x2d)), _stream())
+                  c_int(dt_ga(dy2d, x2d)), _stream())
         return out, out2
     _lib.call("sarssl_layernorm_bwd", _p(dy2d), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
               _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out),
-              c_long(out.stride(0)), _p(dgamma), _p(dbeta), _p(part), c_int(dt(x2d)), _stream())
+              c_long(out.stride(0)), _p(dgamma), _p(dbeta), _p(part), c_int(dt_ga(dy2d, x2d)), _stream())
     return out
 
 
@@ -763,8 +800,8 @@ def glu_fwd(h):
 
 
 def glu_bwd(dg, h):
-    dh = torch.empty_like(h)
-    _lib.call("sarssl_glu_bwd", _p(dg), _p(h), c_long(h.shape[0]), c_int(h.shape[1] // 2), _p(dh), c_int(dt(h)), _stream())
+    dh = torch.empty(h.shape, dtype=dg.dtype, device=h.device)
+    _lib.call("sarssl_glu_bwd", _p(dg), _p(h), c_long(h.shape[0]), c_int(h.shape[1] // 2), _p(dh), c_int(dt_ga(dg, h)), _stream())
     return dh
 
 
@@ -791,8 +828,8 @@ def dwglu_fwd(h2d, w, B, T, want_stats=False):
 def dwglu_bwd(dc2d, h2d, w, B, T):
     """dc [B*T, d], h [B*T, 2d] -> dh [B*T, 2d] (depthwise-conv data gradient + GLU backward)."""
     d = dc2d.shape[1]
-    dh = torch.empty_like(h2d)
-    _lib.call("sarssl_dwglu_bwd", _p(dc2d), _p(h2d), _p(w), c_int(B), c_int(T), c_int(d), c_int(w.shape[-1]), _p(dh), c_int(dt(h2d)),
+    dh = torch.empty(h2d.shape, dtype=dc2d.dtype, device=h2d.device)
+    _lib.call("sarssl_dwglu_bwd", _p(dc2d), _p(h2d), _p(w), c_int(B), c_int(T), c_int(d), c_int(w.shape[-1]), _p(dh), c_int(dt_ga(dc2d, h2d)),
               _stream())
     return dh
 
@@ -804,7 +841,7 @@ def dwglu_wgrad(dc2d, h2d, dw_out, B, T):
     fn.restype = c_long
     part = workspace(fn(c_int(B), c_int(T), c_int(d)), dc2d.device, "dwglu_part")
     _lib.call("sarssl_dwglu_wgrad", _p(dc2d), _p(h2d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), _p(dw_out), _p(part),
-              c_int(dt(h2d)), _stream())
+              c_int(dt_ga(dc2d, h2d)), _stream())
 
 
 def dwconv_wgrad(dy3d, x3d, dw_out):
@@ -813,7 +850,7 @@ def dwconv_wgrad(dy3d, x3d, dw_out):
     fn.restype = c_long
     part = workspace(fn(c_int(B), c_int(T), c_int(d)), x3d.device, "dw_part")
     _lib.call("sarssl_dwconv_wgrad", _p(dy3d), _p(x3d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), _p(dw_out), _p(part),
-              c_int(dt(x3d)), _stream())
+              c_int(dt_ga(dy3d, x3d)), _stream())
 
 
 def softmax_relshift_fwd(content, pos, scale, dtype, p_drop=0.0, seed=0):
@@ -829,9 +866,9 @@ def softmax_relshift_fwd(content, pos, scale, dtype, p_drop=0.0, seed=0):
 def softmax_bwd(dpd, p, scale, p_drop=0.0, seed=0):
     T = p.shape[-1]
     nmat = p.numel() // (T * T)
-    ds = torch.empty_like(p)
+    ds = torch.empty(p.shape, dtype=gdtype_of(p.dtype), device=p.device)
     _lib.call("sarssl_softmax_bwd", _p(dpd), _p(p), c_long(nmat), c_int(T), c_float(scale), c_float(p_drop), c_ulonglong(seed),
-              _p(ds), c_int(dt(p)), _stream())
+              _p(ds), c_int(dt_ga(ds, p)), _stream())
     return ds
 
 
@@ -844,20 +881,21 @@ def relshift_bwd(dscore):
 
 def relpos_attn_supported(T, dh, dtype):
     """Shapes / dtypes the fused attention kernels take (csrc/attention.hip); otherwise the caller uses the GEMM + softmax path."""
-    return dtype == torch.bfloat16 and bool(_lib.lib().sarssl_relpos_attn_supported(c_int(T), c_int(dh)))
+    return dtype in _16 and bool(_lib.lib().sarssl_relpos_attn_supported(c_int(T), c_int(dh)))
 
 
 def relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True):
     """qu [B*T, d], k / v [B*T, d] (row-strided views), bias (B,H,T,T) shifted positional score -> ctx [B*T, d] bf16,
     (ctx32 [B*T, d] f32 unrounded, lse (B,H,T)) for backward."""
     _need_cuda(qu, k, v, bias)
-    assert k.stride(0) == v.stride(0) and bias.is_contiguous()
-    ctx = torch.empty((B * T, H * dh), dtype=torch.bfloat16, device=qu.device)
+    assert k.stride(0) == v.stride(0) and bias.is_contiguous() and qu.dtype in _16 and k.dtype == qu.dtype and v.dtype == qu.dtype and \
+        bias.dtype == qu.dtype
+    ctx = torch.empty((B * T, H * dh), dtype=qu.dtype, device=qu.device)
     ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if need_bwd else None
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
     _lib.call("sarssl_relpos_attn_fwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx),
               c_long(ctx.stride(0)), _p(ctx32), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
-              c_ulonglong(seed), _stream())
+              c_ulonglong(seed), c_int(dt(qu)), _stream())
     return ctx, (ctx32, lse)
 
 
@@ -866,13 +904,14 @@ def relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqu, dk, dv, B, H, T, dh, scale, 
     stride) and returns dbias (B,H,T,T)."""
     ctx32, lse = aux
     _need_cuda(qu, k, v, bias, ctx32, lse, dctx, dqu, dk, dv)
-    assert k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0)
-    dbias = torch.empty_like(bias)
+    assert k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0) and k.dtype == qu.dtype and v.dtype == qu.dtype and \
+        bias.dtype == qu.dtype and dqu.dtype == dctx.dtype and dk.dtype == dctx.dtype and dv.dtype == dctx.dtype
+    dbias = torch.empty(bias.shape, dtype=dctx.dtype, device=bias.device)
     dsum = _f32ws(B * H * T, qu.device, "attn_dsum")
     _lib.call("sarssl_relpos_attn_bwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx32),
               _p(lse), _p(dctx), c_long(dctx.stride(0)), _p(dqu), c_long(dqu.stride(0)), _p(dk), _p(dv),
               c_long(dk.stride(0)), _p(dbias), _p(dsum), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
-              c_ulonglong(seed), _stream())
+              c_ulonglong(seed), c_int(dt_ga(dctx, qu)), _stream())
     return dbias
 
 
@@ -999,7 +1038,7 @@ def act_bwd(dz, h, act, p_drop=0.0, seed=0, gscale=1.0, out=None):
     if out is None:
         out = torch.empty_like(dz)
     _lib.call("sarssl_act_bwd", _p(dz), _p(h), c_long(dz.numel()), c_int(act), c_float(p_drop), c_ulonglong(seed), c_float(gscale),
-              _p(out), c_int(dt(dz)), _stream())
+              _p(out), c_int(dt_ga(dz, h)), _stream())
     return out
 
 
@@ -1031,14 +1070,16 @@ def masked_mse_fwd(pred, x, idx_i32, mch_i32, sink=None):
 def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0, gscale_dev=None):
     """gscale_dev: optional f32 device scalar (the incoming d(loss)); multiplied in-kernel, no host sync."""
     B, _, F, T, _ = x.shape
-    dpred = torch.empty_like(pred)
+    dpred = torch.empty(pred.shape, dtype=gdtype_of(pred.dtype), device=pred.device)
     _lib.call("sarssl_masked_mse_bwd", _p(pred), _p(x), _p(mp_u8), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm),
-              c_float(gscale), _p(gscale_dev), _p(dpred), c_int(dt(pred)), _stream())
+              c_float(gscale), _p(gscale_dev), _p(dpred), c_int(dt_ga(dpred, pred)), _stream())
     return dpred
 
 
-def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8):
-    _lib.call("sarssl_adam_step", _p(p), _p(g), _p(m), _p(v), _p(p16), c_long(p.numel()), c_float(gscale), c_float(lr),
+def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8, ph16=None):
+    """p16 / ph16: bf16 / fp16 shadow copies of the parameters rewritten by the same pass (either may be None)."""
+    assert (p16 is None or p16.dtype == torch.bfloat16) and (ph16 is None or ph16.dtype == torch.float16)
+    _lib.call("sarssl_adam_step", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), c_float(lr),
               c_float(betas[0]), c_float(betas[1]), c_float(eps), c_int(step), _stream())
 
 
@@ -1067,6 +1108,7 @@ def step_tick(st):
     _lib.call("sarssl_step_tick", _p(st), _stream())
 
 
-def adam_step_dev(p, g, m, v, p16, st, gscale=1.0, eps=1e-8, zero_grad=False):
-    _lib.call("sarssl_adam_step_dev", _p(p), _p(g), _p(m), _p(v), _p(p16), c_long(p.numel()), c_float(gscale), _p(st), c_float(eps),
+def adam_step_dev(p, g, m, v, p16, st, gscale=1.0, eps=1e-8, zero_grad=False, ph16=None):
+    assert (p16 is None or p16.dtype == torch.bfloat16) and (ph16 is None or ph16.dtype == torch.float16)
+    _lib.call("sarssl_adam_step_dev", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), _p(st), c_float(eps),
               c_int(1 if zero_grad else 0), _stream())

@@ -50,10 +50,12 @@ class Learner(ABC):
         raise hip._lib.SarsslHipError("the sar_ssl_amd learner runs on the GPU only: there is no CPU fallback "
                                       "(use the oracle in oracle/ for CPU reference numbers)")
 
-    def amp(self):
-        """Mixed precision = bf16 storage / MFMA inputs with f32 accumulation; no loss scaling is needed for bf16."""
+    def amp(self, dtype=None):
+        """Mixed precision (code/learner.py:46-50: the reference autocasts to fp16 with a GradScaler).  Here: 'fp16' (default; or
+        SARSSL_AMP_DTYPE) = fp16 forward - storage and MFMA operands, the reference's autocast dtype - with a bf16 backward pass, so
+        gradients keep their range and no loss scaling is needed; 'bf16' = bf16 throughout.  f32 accumulation either way."""
         self.use_amp = True
-        runtime.set_precision("bf16")
+        runtime.set_precision(dtype or os.environ.get("SARSSL_AMP_DTYPE", "fp16"))
 
     @abstractmethod
     def data_preprocess(self, mic_sig_batch=None, gt_batch=None):
@@ -105,6 +107,10 @@ class Learner(ABC):
         """The captured step can run the STFT front-end itself (as bench.py's does) when the batch is the plain 2-microphone case
         of the default front-end: no per-step STFT launch + 67 MB copy into the graph's input buffer, only the 17 MB int16 /
         34 MB f32 batch."""
+        # a subclass that overrides data_preprocess (augmentation, another eps / normalisation) must get ITS front-end in the captured
+        # step too: the raw-batch path is only the default front-end's (advisor, round 3)
+        if getattr(type(self), "data_preprocess", None) is not STFTLearner.data_preprocess:
+            return False
         return (torch.is_tensor(sig) and sig.dim() == 3 and sig.shape[2] == 2 and sig.dtype in (torch.float32, torch.int16)
                 and getattr(self, "ch_mode", None) == "M" and getattr(self, "win_len", None) == 512 and getattr(self, "nfft", None) == 512
                 and getattr(self, "win_shift_ratio", None) == 0.5)

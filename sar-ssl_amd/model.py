@@ -231,12 +231,14 @@ class _PretrainFn(torch.autograd.Function):
         # tiles (a convolution workgroup owns its CU's whole register file and LDS - nothing co-resides).
         from . import dist as _dist
         all_cus = 1 << 16 if (engine._STEM_LAST_ALL_CUS and _dist.world_size() <= 1) else 0
-        hip.conv_cus_override(all_cus if side is None else 0)
-        engine.stem_bwd(dz_spec, spe.patch_embed, saved)
-        hip.conv_cus_override(all_cus)
-        with on_side():
-            engine.stem_bwd(dz_spat, spa.patch_embed, saved_spat)
-        hip.conv_cus_override(0)
+        try:        # the override is per host thread (here: autograd's worker) and must not outlive this pass if a launch raises
+            hip.conv_cus_override(all_cus if side is None else 0)
+            engine.stem_bwd(dz_spec, spe.patch_embed, saved)
+            hip.conv_cus_override(all_cus)
+            with on_side():
+                engine.stem_bwd(dz_spat, spa.patch_embed, saved_spat)
+        finally:
+            hip.conv_cus_override(0)
         if side is not None:
             main.wait_stream(side)
         net._after_backward_stage("stems")

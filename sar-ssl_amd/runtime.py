@@ -1,8 +1,12 @@
 """Runtime configuration and parameter storage for the HIP path.
 
-Two numeric modes, same kernels:
-  * ``bf16``  - activations / GEMM weights stored in bf16, f32 accumulation and statistics (the fast path,
-                what bench.py times);
+Numeric modes, same kernels:
+  * ``fp16``  - fp16 FORWARD / bf16 BACKWARD: activations, forward weights and the tensors saved for backward are fp16 and the
+                forward contractions run on v_mfma_f32_32x32x16_f16; gradients, gradient-side weights and the backward contractions
+                are bf16 (bf16's exponent range: no loss scaling; saved fp16 operands are re-encoded to bf16 while staged).  Same MFMA
+                rate as bf16, 3 more mantissa bits where the reference's per-bin tolerance is decided (oracle/operand_rounding_study.py:
+                per-bin deviation 7.4e-3 -> 0.9e-3 of range); what bench.py times;
+  * ``bf16``  - activations / GEMM weights / gradients stored in bf16, f32 accumulation and statistics;
   * ``fp32``  - f32 storage, every MFMA contraction done as three split-bf16 passes (hi*hi + hi*lo + lo*hi):
                 ~1e-5 relative error, used for the 1e-3 parity gates against the oracle.
 
@@ -16,8 +20,14 @@ from . import hip
 
 
 class _RT:
-    dtype = torch.bfloat16
+    dtype = torch.bfloat16     # storage dtype of forward activations / forward weights / tensors saved for backward
     precise = False
+
+    @property
+    def gdtype(self):
+        """storage dtype of gradients and gradient-side weights: bf16 next to fp16 activations, else ``dtype``"""
+        return hip.gdtype_of(self.dtype)
+
     fp8 = False
     inference = False      # set while a forward runs that no backward will follow (no_grad / frozen): skips backward-only outputs
     replay = None          # DropoutReplay: masks drawn on the host in the reference's order (parity tests only)
@@ -62,7 +72,9 @@ def set_precision(mode):
     """'bf16' (fast path), 'fp32' (split-bf16 precise path) or 'fp8' (bf16 storage; the Linear / pointwise-conv forward and
     input-gradient GEMMs of the Conformer blocks - FFN, q/k/v and output projections, conv-module pointwise convs - on the OCP-e4m3
     block-scaled MFMA with per-tensor scales chosen on the device: BASELINE.json config 5; everything else as 'bf16')."""
-    if mode in ("bf16", torch.bfloat16):
+    if mode in ("fp16", torch.float16):
+        RT.dtype, RT.precise, RT.fp8 = torch.float16, False, False
+    elif mode in ("bf16", torch.bfloat16):
         RT.dtype, RT.precise, RT.fp8 = torch.bfloat16, False, False
     elif mode in ("fp32", "f32", torch.float32):
         RT.dtype, RT.precise, RT.fp8 = torch.float32, True, False
@@ -74,10 +86,12 @@ def set_precision(mode):
         # of the three split passes of 'fp32'
         RT.dtype, RT.precise, RT.fp8 = torch.float32, False, False
     else:
-        raise ValueError("precision must be 'bf16', 'fp32', 'fp32_1pass' or 'fp8'")
+        raise ValueError("precision must be 'fp16', 'bf16', 'fp32', 'fp32_1pass' or 'fp8'")
 
 
 def get_precision():
+    if RT.dtype == torch.float16:
+        return "fp16"
     return "fp8" if RT.fp8 else ("bf16" if RT.dtype == torch.bfloat16 else ("fp32" if RT.precise else "fp32_1pass"))
 
 
@@ -92,20 +106,32 @@ def weights_version():
     return _GLOBAL_VERSION[0]
 
 
-def wt(p):
-    """Tensor to feed a GEMM/conv kernel for parameter ``p`` in the current precision."""
-    if RT.dtype == torch.float32:
-        return p.data
+def _wt16(p, dtype):
     flat = getattr(p, "_flat", None)
     if flat is not None:
         if not flat._fresh:                    # one full version scan per top-level forward (begin_forward), not per weight use
             flat.ensure_shadow()
-        return p._w16
-    cache = getattr(p, "_w16_cache", None)
+        return p._w16 if dtype == torch.bfloat16 else p._wh16
+    name = "_w16_cache" if dtype == torch.bfloat16 else "_wh16_cache"
+    cache = getattr(p, name, None)
     if cache is None or cache[0] != p._version:
-        p._w16_cache = (p._version, hip.cast(p.data.contiguous(), torch.bfloat16))
+        setattr(p, name, (p._version, hip.cast(p.data.contiguous(), dtype)))
         bump_version()                         # derived copies (fp8 weights, re-laid-out taps) follow
-    return p._w16_cache[1]
+    return getattr(p, name)[1]
+
+
+def wt(p):
+    """Tensor to feed a FORWARD GEMM / conv kernel for parameter ``p`` in the current precision."""
+    if RT.dtype == torch.float32:
+        return p.data
+    return _wt16(p, RT.dtype)
+
+
+def wtg(p):
+    """The same for the data-gradient products of the backward pass (dX = dY W): bf16 in the fp16-forward mode."""
+    if RT.dtype == torch.float32:
+        return p.data
+    return _wt16(p, RT.gdtype)
 
 
 def begin_forward(params):
@@ -187,12 +213,14 @@ class FlatParams:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.w16 = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+        self.wh16 = torch.zeros(total, dtype=torch.float16, device=dev)      # fp16 shadow: forward operands of the fp16-forward mode
         for p, o in zip(params, offs):
             n = p.numel()
             self.flat[o:o + n].view_as(p.data).copy_(p.data)
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
             p._w16 = self.w16[o:o + n].view(p.shape)
+            p._wh16 = self.wh16[o:o + n].view(p.shape)
             p._flat = self
         self.group_spans = {}
         for p, o in zip(params, offs):
@@ -209,11 +237,12 @@ class FlatParams:
         return tuple(p._version for p in self.params)
 
     def ensure_shadow(self):
-        """Refresh the bf16 shadow if any parameter was modified through torch (load_state_dict, init, ...)."""
+        """Refresh the 16-bit shadows if any parameter was modified through torch (load_state_dict, init, ...)."""
         sig = self._sig()
         if sig != self._synced:
             if self.on_gpu:
                 hip.cast(self.flat, torch.bfloat16, out=self.w16)
+                hip.cast(self.flat, torch.float16, out=self.wh16)
             self._synced = sig
             bump_version()
         self._fresh = True
@@ -270,5 +299,5 @@ class FusedAdam:
     def step(self, grad_scale=1.0):
         self.step_count += 1
         hip.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.lr, self.step_count,
-                      gscale=grad_scale, betas=self.betas, eps=self.eps)
+                      gscale=grad_scale, betas=self.betas, eps=self.eps, ph16=self.flat.wh16)
         bump_version()

@@ -125,9 +125,8 @@ def _worker4(rank, world, port, q):
             red.finish()
         except AssertionError:
             caught += 1
-            red.strict = False                             # drain the collectives every rank has issued, then re-arm
-            red.finish()
-            red.strict = True
+            # finish() drains and re-arms BEFORE it raises: nothing in flight, no stale per-step record (advisor, round 3)
+            ok = ok and red.handles == [] and red._fired == set() and red._calls == {} and red._closed
     desc = red.describe()
     ms = red.time_buckets(iters=1)
     ok = ok and caught == 2 and desc["world"] == 4 and desc["backend"] == "gloo" and [b["name"] for b in desc["buckets"]] == \

@@ -39,7 +39,7 @@ def _batches(T, n, B):
     return [hip.stft_frontend(sig[i * B:(i + 1) * B]) for i in range(n)]
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("prec", ["fp16", "bf16", "fp32"])
 def test_graph_step_equals_eager_step(prec):
     """6 Adam steps, dropout off, same masks: per-step loss / diff, final parameters, BatchNorm running statistics."""
     from sar_ssl_amd import runtime
@@ -97,8 +97,9 @@ def test_graph_step_equals_eager_step(prec):
         runtime.set_precision("bf16")
 
 
-def test_full_batch_captured_bf16_step_against_the_fp32_mode():
-    """The configuration bench.py times (BASELINE config 2: B = 64, 65 792 samples, T = 256, bf16, captured step, two encoder
+@pytest.mark.parametrize("fast", ["fp16", "bf16"])
+def test_full_batch_captured_16bit_step_against_the_fp32_mode(fast):
+    """The configuration bench.py times (BASELINE config 2: B = 64, 65 792 samples, T = 256, fp16 forward / bf16 backward - or bf16 -, captured step, two encoder
     streams, C1IN / C1RED kernels, 224-CU gradient grids) against the fp32 mode (split-bf16 MFMA, the mode that is pinned to the
     reference at 1e-3 everywhere) on the same weights, masks and input, dropout off (the two modes' fused / unfused attention cores
     index their dropout draws differently): loss, diff, and the gradient per data-parallel bucket (cosine and norm ratio)."""
@@ -111,7 +112,7 @@ def test_full_batch_captured_bf16_step_against_the_fp32_mode():
     pcm = torch.from_numpy(synth.to_pcm16(segs)).to(dev)
     res = {}
     try:
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", fast):
             runtime.set_precision(prec)
             net, flat = _make(T, 21, 0.0)
             random.seed(31)
@@ -133,20 +134,21 @@ def test_full_batch_captured_bf16_step_against_the_fp32_mode():
     finally:
         runtime.set_precision("bf16")
     (l32, d32), g32, spans = res["fp32"]
-    (l16, d16), g16, _ = res["bf16"]
-    check("fullbatch_bf16_vs_fp32.loss", abs(l16 - l32) / abs(l32), 1e-3)
-    check("fullbatch_bf16_vs_fp32.diff", abs(d16 - d32) / abs(d32), 1e-3)
+    (l16, d16), g16, _ = res[fast]
+    check("fullbatch_%s_vs_fp32.loss" % fast, abs(l16 - l32) / abs(l32), 1e-3)
+    check("fullbatch_%s_vs_fp32.diff" % fast, abs(d16 - d32) / abs(d32), 1e-3)
     assert set(spans) == {"stems", "spec_encoder", "spat_encoder", "decoder"}
     for name, (s, e) in sorted(spans.items()):
         a, b = g16[s:e].double(), g32[s:e].double()
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         # measured on MI355X: 1 - cos = 3e-5 (decoder), 1.1e-4 / 1.2e-4 (spat / spec encoder), 2.1e-3 (stems: 3x3 convolution and
         # BatchNorm parameters, whose gradients are contractions of bf16-rounded 64-channel tensors over 4.2 M pixels)
-        check("fullbatch_bf16_vs_fp32.grad_1_minus_cos[%s]" % name, 1.0 - cos, 5e-3 if name == "stems" else 5e-4)
-        check("fullbatch_bf16_vs_fp32.grad_norm_ratio[%s]" % name, abs(float(a.norm() / b.norm()) - 1.0), 1e-2)
+        check("fullbatch_%s_vs_fp32.grad_1_minus_cos[%s]" % (fast, name), 1.0 - cos, 5e-3 if name == "stems" else 5e-4)
+        check("fullbatch_%s_vs_fp32.grad_norm_ratio[%s]" % (fast, name), abs(float(a.norm() / b.norm()) - 1.0), 1e-2)
 
 
-def test_bf16_training_is_run_to_run_reproducible_with_dropout_on():
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_16bit_training_is_run_to_run_reproducible_with_dropout_on(prec):
     """Round 3: no floating-point atomics whose order can change a result are left on the training path (statistics epilogues and bias
     gradients fold partial sums in a fixed order), so two runs of the same bf16 training - same seeds, same masks, dropout ON, two
     encoder streams, captured step - end with bit-identical parameters and BatchNorm buffers.  (Round 2: 18 % of the update norm apart
@@ -156,14 +158,18 @@ def test_bf16_training_is_run_to_run_reproducible_with_dropout_on():
     T, B, n = 16, 4, 5
     xs = _batches(T, n, B)
     outs = []
-    for run in range(2):
-        runtime.RT.manual_seed(4711)
-        net, flat = _make(T, 13, 0.1)
-        g = PretrainStepGraph(net, flat, lr=1e-3)
-        random.seed(123)
-        losses = [float(g.step(x=x)[0]) for x in xs]
-        torch.cuda.synchronize()
-        outs.append((losses, flat.flat.clone(), [b.clone() for b in net.buffers()]))
+    runtime.set_precision(prec)
+    try:
+        for run in range(2):
+            runtime.RT.manual_seed(4711)
+            net, flat = _make(T, 13, 0.1)
+            g = PretrainStepGraph(net, flat, lr=1e-3)
+            random.seed(123)
+            losses = [float(g.step(x=x)[0]) for x in xs]
+            torch.cuda.synchronize()
+            outs.append((losses, flat.flat.clone(), [b.clone() for b in net.buffers()]))
+    finally:
+        runtime.set_precision("bf16")
     assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
     for a, b in zip(outs[0][2], outs[1][2]):

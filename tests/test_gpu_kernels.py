@@ -32,25 +32,35 @@ def _mk(shape, dtype, dev, seed):
 
 
 @pytest.mark.parametrize("a_kc,b_kc", LAYOUTS)
-@pytest.mark.parametrize("mode", ["bf16", "bf16_f32out", "f32_precise", "f32_fast"])
+@pytest.mark.parametrize("mode", ["bf16", "bf16_f32out", "f32_precise", "f32_fast", "fp16", "fp16_f32out", "mix_g_a", "mix_g_a_f32out", "mix_a_g"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 40), (48, 136, 32), (1000, 264, 520)])
 def test_gemm_layouts(a_kc, b_kc, mode, M, N, K):
+    """fp16*: both operands fp16 (v_mfma_f32_32x32x16_f16: the forward products of the fp16-forward mode); mix_g_a / mix_a_g: a bf16
+    gradient times a saved fp16 activation (either side), contracted in bf16 with the fp16 operand re-encoded while staged."""
     from sar_ssl_amd import hip
     dev = _dev()
     if not a_kc and M % 8:
         pytest.skip("transposed A needs M % 8 == 0")
-    in_dt = torch.bfloat16 if mode.startswith("bf16") else torch.float32
-    out_dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    in_dt = torch.bfloat16 if mode.startswith("bf16") else (torch.float16 if mode.startswith("fp16") else torch.float32)
+    out_dt = torch.bfloat16 if mode == "bf16" else (torch.float16 if mode == "fp16" else torch.float32)
     A = _mk((M, K) if a_kc else (K, M), in_dt, dev, 1)
     B = _mk((N, K) if b_kc else (K, N), in_dt, dev, 2)      # asymmetric random operands
+    if mode.startswith("mix"):
+        a_dt, b_dt = (torch.bfloat16, torch.float16) if mode.startswith("mix_g_a") else (torch.float16, torch.bfloat16)
+        A, B = A.to(a_dt), B.to(b_dt)
+        out_dt = torch.float32 if mode.endswith("f32out") else torch.bfloat16
     bias = _mk((N,), torch.float32, dev, 3)
     C = hip.gemm(A, B, a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], out_dtype=out_dt,
                  bias=bias, alpha=0.5, precise=(mode == "f32_precise"))
+    assert C.dtype == out_dt
     Af = A.float() if a_kc else A.float().t()
     Bf = B.float() if b_kc else B.float().t()
+    if mode.startswith("mix"):          # the fp16 operand enters the contraction rounded to bf16
+        Af, Bf = Af.bfloat16().float(), Bf.bfloat16().float()
     ref = 0.5 * (Af.double() @ Bf.double().t()) + bias.double()
     err = _relerr(C, ref)
-    tol = {"bf16": 1e-2, "bf16_f32out": 1e-5, "f32_precise": 5e-5, "f32_fast": 1e-2}[mode]
+    tol = {"bf16": 1e-2, "bf16_f32out": 1e-5, "f32_precise": 5e-5, "f32_fast": 1e-2, "fp16": 1.5e-3, "fp16_f32out": 1e-5, "mix_g_a": 1e-2,
+           "mix_g_a_f32out": 1e-5, "mix_a_g": 1e-2}[mode]
     if mode == "bf16_f32out":
         tol = 1e-5       # bf16 inputs are exact in the reference too; only f32 accumulation order differs
     assert err < tol, (mode, err)
@@ -168,13 +178,13 @@ def _cl(x_nchw):          # (B,C,F,T) -> channels-last (B,F,T,C)
     return x_nchw.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("mode", ["bf16", "f32_precise"])
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "f32_precise"])
 @pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64)])
 @pytest.mark.parametrize("prologue", [False, True])
 def test_conv3x3_fwd(mode, B, F, T, prologue):
     from sar_ssl_amd import hip
     dev = _dev()
-    dtp = torch.bfloat16 if mode == "bf16" else torch.float32
+    dtp = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(mode, torch.float32)
     g = torch.Generator().manual_seed(B * 100 + F + T)
     x = torch.randn((B, 64, F, T), generator=g)
     W = torch.randn((64, 64, 3, 3), generator=g) * 0.05
@@ -182,15 +192,16 @@ def test_conv3x3_fwd(mode, B, F, T, prologue):
     sh = torch.randn(64, generator=g) * 0.3
     xq = x.to(dtp).float(); Wq = W.to(dtp).float()
     z = torch.relu(xq * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if prologue else xq
-    if mode == "bf16" and prologue:
-        z = z.to(dtp).float()            # the kernel rounds the prologue output to bf16 before the MFMA
+    if mode in ("bf16", "fp16") and prologue:
+        z = z.to(dtp).float()            # the kernel rounds the prologue output to its 16-bit operand type before the MFMA
     ref = torch.nn.functional.conv2d(z.double(), Wq.double(), padding=1)
     w_tap = Wq.permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous().to(dtp).to(dev)
     out = hip.conv3x3_fwd(_cl(xq).to(dtp).to(dev), w_tap, sc.to(dev) if prologue else None, sh.to(dev) if prologue else None,
                           precise=(mode == "f32_precise"))
     err = _relerr(out.float().cpu(), _cl(ref))
-    assert err < (1e-2 if mode == "bf16" else 5e-5), err
-    if mode == "bf16":            # fused BatchNorm statistics of the stored output
+    assert out.dtype == dtp
+    assert err < {"bf16": 1e-2, "fp16": 1.5e-3}.get(mode, 5e-5), err
+    if mode in ("bf16", "fp16"):            # fused BatchNorm statistics of the stored output
         out2, sums = hip.conv3x3_fwd(_cl(xq).to(dtp).to(dev), w_tap, sc.to(dev) if prologue else None, sh.to(dev) if prologue else None,
                                      want_stats=True)
         assert torch.equal(out2, out)
@@ -198,32 +209,38 @@ def test_conv3x3_fwd(mode, B, F, T, prologue):
         assert _relerr(sums[:64], o64.sum(0)) < 1e-5 and _relerr(sums[64:], (o64 ** 2).sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["bf16", "f32_precise"])
+@pytest.mark.parametrize("mode", ["bf16", "mix16", "f32_precise"])
 @pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136)])
 def test_conv3x3_wgrad_and_dgrad(mode, B, F, T):
+    """mix16: the saved forward activation is fp16, the gradient bf16 (the backward pass of the fp16-forward mode)."""
     from sar_ssl_amd import hip
     dev = _dev()
-    dtp = torch.bfloat16 if mode == "bf16" else torch.float32
+    dtp = torch.bfloat16 if mode in ("bf16", "mix16") else torch.float32
+    adt = torch.float16 if mode == "mix16" else dtp                # dtype of the saved forward tensor
     g = torch.Generator().manual_seed(7 + F)
-    yprev = torch.randn((B, 64, F, T), generator=g).to(dtp).float()
+    yprev = torch.randn((B, 64, F, T), generator=g).to(adt).float()
     dy = torch.randn((B, 64, F, T), generator=g).to(dtp).float()
     W = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).to(dtp).float()
     sc = torch.rand(64, generator=g) + 0.5
     sh = torch.randn(64, generator=g) * 0.3
     z = torch.relu(yprev * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    if mode == "bf16":
+    if mode in ("bf16", "mix16"):
         z = z.to(dtp).float()
     z64 = z.double().requires_grad_(True)
     W64 = W.double().requires_grad_(True)
     out = torch.nn.functional.conv2d(z64, W64, padding=1)
     out.backward(dy.double())
-    dW = hip.conv3x3_wgrad(_cl(dy).to(dtp).to(dev), _cl(yprev).to(dtp).to(dev), sc.to(dev), sh.to(dev), precise=(mode == "f32_precise"))
+    dW = hip.conv3x3_wgrad(_cl(dy).to(dtp).to(dev), _cl(yprev).to(adt).to(dev), sc.to(dev), sh.to(dev), precise=(mode == "f32_precise"))
     ref_dW = W64.grad.permute(2, 3, 0, 1).reshape(9, 64, 64)
-    assert _relerr(dW, ref_dW) < (1e-2 if mode == "bf16" else 5e-5)
+    assert _relerr(dW, ref_dW) < (5e-5 if mode == "f32_precise" else 1e-2)
+    if mode != "f32_precise":        # the variant that adds straight into the (64,64,3,3) parameter-gradient buffer
+        acc = torch.zeros((64, 64, 3, 3), device=dev)
+        assert hip.conv3x3_wgrad(_cl(dy).to(dtp).to(dev), _cl(yprev).to(adt).to(dev), sc.to(dev), sh.to(dev), acc_into=acc) is None
+        assert _relerr(acc, W64.grad) < 1e-2
     # data gradient = forward kernel with flipped / transposed weights
     w_dgrad = W.flip(2, 3).permute(2, 3, 1, 0).reshape(9, 64, 64).contiguous().to(dtp).to(dev)
     dz = hip.conv3x3_fwd(_cl(dy).to(dtp).to(dev), w_dgrad, precise=(mode == "f32_precise"))
-    assert _relerr(dz.float().cpu(), _cl(z64.grad)) < (1e-2 if mode == "bf16" else 5e-5)
+    assert _relerr(dz.float().cpu(), _cl(z64.grad)) < (5e-5 if mode == "f32_precise" else 1e-2)
 
 
 def test_conv3x3_full_batch_shape_against_the_precise_f32_kernels():
@@ -754,24 +771,27 @@ def _attn_mask(B, H, T, dh, p_drop, seed, dev):
     return mask
 
 
+@pytest.mark.parametrize("adt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 @pytest.mark.parametrize("B,H,T,dh", [(2, 4, 256, 128), (3, 4, 40, 64), (1, 2, 624, 64), (2, 4, 64, 32), (1, 4, 136, 128)])
-def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop):
+def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
     """Positional-score GEMM written in the relative-shift layout + fused attention forward / backward against an f64 torch
-    restatement of attention.py:87-113 on the same bf16 operands (dropout mask read back from the kernel's own hash)."""
+    restatement of attention.py:87-113 on the same 16-bit operands (dropout mask read back from the kernel's own hash).  adt = dtype
+    of the forward tensors: bf16, or fp16 with bf16 gradients (the fp16-forward mode)."""
     from sar_ssl_amd import hip
     from conftest import check
     dev = _dev()
     d = H * dh
     scale = 1.0 / (d ** 0.5)
     g = torch.Generator().manual_seed(B * 1000 + T + dh)
-    mk = lambda *shape, s=1.0: (torch.randn(shape, generator=g) * s).to(torch.bfloat16).to(dev)
+    mk = lambda *shape, s=1.0, dt_=adt: (torch.randn(shape, generator=g) * s).to(dt_).to(dev)
     qkv = mk(B * T, 3 * d)
     qu, k, v = mk(B * T, d), qkv[:, d:2 * d], qkv[:, 2 * d:]                 # k / v as column slices (row stride 3d), as in the engine
     qv, pos = mk(B * T, d), mk(T, d, s=2.0)
-    dctx = mk(B * T, d)
+    dctx = mk(B * T, d, dt_=torch.bfloat16)
+    ftol = 1e-2 if adt == torch.bfloat16 else 2e-3                           # forward quantities: fp16 operands / outputs are 8x finer
     # positional score in the shifted layout straight from the GEMM epilogue
-    bias = torch.full((B, H, T, T), float("nan"), dtype=torch.bfloat16, device=dev)
+    bias = torch.full((B, H, T, T), float("nan"), dtype=adt, device=dev)
     hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=B * H, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
              sC=(H * T * T, T * T), c_row_shift=True)
     raw = torch.einsum("bihc,mhc->bhim", qv.view(B, T, H, dh).double(), pos.view(T, H, dh).double())
@@ -780,7 +800,7 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop):
     got_bias = bias.double().clone()
     assert torch.isnan(got_bias[:, :, ii, ii + 1]).all()                     # the padding zeros are never written ...
     got_bias[:, :, ii, ii + 1] = 0.0                                         # ... and ignored by the attention kernels
-    check("attn.bias_shift_gemm", _relerr(got_bias, want_bias), 1e-2)
+    check("attn.bias_shift_gemm", _relerr(got_bias, want_bias), ftol)
     seed = 991
     ctx, aux = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, seed)
     lse = aux[1]
@@ -799,7 +819,8 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop):
     b64 = got_bias.clone().requires_grad_(True)
     A = torch.softmax((q64 @ k64.transpose(-1, -2) + b64) * scale, dim=-1)
     O = (A * keep) @ v64
-    check("attn.fwd.ctx[p=%g]" % p_drop, _relerr(ctx.view(B, T, H, dh).permute(0, 2, 1, 3), O.detach()), 1e-2)
+    assert ctx.dtype == adt
+    check("attn.fwd.ctx[p=%g]" % p_drop, _relerr(ctx.view(B, T, H, dh).permute(0, 2, 1, 3), O.detach()), ftol)
     lse_ref = torch.logsumexp((q64 @ k64.transpose(-1, -2) + b64) * scale, dim=-1) / np.log(2.0)
     check("attn.fwd.lse[p=%g]" % p_drop, (lse.double() - lse_ref.detach()).abs().max().item(), 1e-3)
     O.backward(dctx.view(B, T, H, dh).double().permute(0, 2, 1, 3))

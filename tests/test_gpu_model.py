@@ -41,7 +41,9 @@ def _set_dropout(m, p):
 
 # bf16 gradient tolerance is wide at these toy sizes (B*T = 48 rows, 384 stem pixels): BatchNorm/LayerNorm backward subtracts
 # batch means of bf16-rounded tensors; the full-size bf16 test below is the meaningful fast-path gate.
-TOL = {"fp32": dict(y=2e-4, dx=5e-4, g=1e-3), "bf16": dict(y=3e-2, dx=1.2e-1, g=6e-1, gall=1e-1)}
+TOL = {"fp32": dict(y=2e-4, dx=5e-4, g=1e-3), "bf16": dict(y=3e-2, dx=1.2e-1, g=6e-1, gall=1e-1),
+       # fp16 forward / bf16 backward: outputs 8x closer than bf16's, gradients bf16-class
+       "fp16": dict(y=4e-3, dx=1.2e-1, g=6e-1, gall=1e-1)}
 
 
 def _run_block(name, build, seed, prec, call=None, check_dx=True, residual=False):
@@ -85,7 +87,7 @@ def _run_block(name, build, seed, prec, call=None, check_dx=True, residual=False
         runtime.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_ffn_module(prec):
     from sar_ssl_amd.common.conformer.feed_forward import FeedForwardModule
     _run_block("ffn", lambda: FeedForwardModule(encoder_dim=32, expansion_factor=4, dropout_p=0.1), 21, prec,
@@ -94,7 +96,7 @@ def test_ffn_module(prec):
         _run_block("ffn", lambda: FeedForwardModule(encoder_dim=32, expansion_factor=4, dropout_p=0.1), 21, prec)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_mhsa_module(prec):
     from sar_ssl_amd.common.conformer.attention import MultiHeadedSelfAttentionModule
     _run_block("mhsa", lambda: MultiHeadedSelfAttentionModule(d_model=32, num_heads=4, dropout_p=0.1), 22, prec,
@@ -103,7 +105,7 @@ def test_mhsa_module(prec):
         _run_block("mhsa", lambda: MultiHeadedSelfAttentionModule(d_model=32, num_heads=4, dropout_p=0.1), 22, prec)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_conv_module(prec):
     from sar_ssl_amd.common.conformer.convolution import ConformerConvModule
     mk = lambda: ConformerConvModule(in_channels=32, kernel_size=31, expansion_factor=2, dropout_p=0.1)
@@ -112,7 +114,7 @@ def test_conv_module(prec):
         _run_block("convmod", mk, 23, prec)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_conformer_block_and_encoder(prec):
     from sar_ssl_amd.common.Conformer import ConformerBlock, ConformerEncoder
     _run_block("block", lambda: ConformerBlock(encoder_dim=32, num_attention_heads=4), 24, prec)
@@ -121,7 +123,7 @@ def test_conformer_block_and_encoder(prec):
                call=lambda m, x: m(x, False))
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_embed_encoder_decoder(prec):
     from sar_ssl_amd import model
     _run_block("embed_encoder", lambda: model.EmbedEncoder(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed=32,
@@ -172,10 +174,13 @@ def _fullsize(prec, mode):
 # stats 9.6e-4; recorded by conftest.check in gpurun_out/parity_measured.jsonl).
 FULL_TOL = {"fp32": dict(loss=1e-3, pred=1e-3, grad=5e-3, bn=1e-4), "bf16": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3),
             # f32 storage + single-pass bf16 MFMA (runtime.set_precision("fp32_1pass")): first measured in round 3
-            "fp32_1pass": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3)}
+            "fp32_1pass": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3),
+            # fp16 forward / bf16 backward (the timed mode since round 4): first measured in round 4; the CPU study
+            # (oracle/operand_rounding_study.py) predicts 0.9e-3 / 1.1e-3 per bin (eval / train)
+            "fp16": dict(loss=1e-3, pred=5e-3, grad=6e-2, bn=5e-3)}
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_1pass"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_1pass", "fp16"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_fullsize_forward_backward(mode, prec):
     """north_star gate: loss and per-bin outputs within 1e-3 relative of the reference CPU path (fp32 mode); the bf16 fast path is
@@ -231,7 +236,7 @@ def test_downstream_forward():
         runtime.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_reloaded_weights_are_picked_up_without_flat_params(prec):
     """Re-laid-out weight caches (3x3 taps, patch-GEMM weight, bf16 shadows) must follow ``load_state_dict`` / in-place updates on a
     model that is NOT flattened: forward -> load_state_dict -> forward equals a fresh model carrying the second weights."""

@@ -63,21 +63,22 @@ def test_loss_curve_100_steps_vs_reference_fp32():
     check("curve100.fp32.max", rel.max(), 1e-3)
 
 
-def test_loss_curve_100_steps_bf16_tracks_reference():
-    """Fast path (bf16 storage, what bench.py times): all 100 steps of the same curve at the north_star's 1e-3 (measured on
-    MI355X: max relative deviation 2.1e-4, i.e. ~5x margin)."""
-    got, _, z = _curve("bf16", 100)
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_loss_curve_100_steps_16bit_modes_track_reference(prec):
+    """Fast paths (fp16 forward / bf16 backward = what bench.py times; bf16 throughout): all 100 steps of the same curve at the
+    north_star's 1e-3 (bf16 measured on MI355X: max relative deviation 1.6e-4)."""
+    got, _, z = _curve(prec, 100)
     ref = z["loss"][:100]
     rel = np.abs(got - ref) / ref
-    check("curve100.bf16.first10", rel[:10].max(), 1e-3)
-    check("curve100.bf16.max", rel.max(), 1e-3)
+    check("curve100.%s.first10" % prec, rel[:10].max(), 1e-3)
+    check("curve100.%s.max" % prec, rel.max(), 1e-3)
 
 
 def _update_norms(net, init):
     return {k: float((p.detach().float().cpu().double() - init[k].double()).norm()) for k, p in net.named_parameters()}
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_pretrain_epoch_vs_reference_pretrain_epoch(prec):
     """``STFTLearner.pretrain_epoch`` against fixture F12, produced by the reference's OWN ``pretrain_epoch``
     (code/learner.py:76-131): two epochs x four batches, returned (loss, diff, vis) per epoch, a new learning rate and a fresh Adam
@@ -86,7 +87,8 @@ def test_pretrain_epoch_vs_reference_pretrain_epoch(prec):
     from sar_ssl_amd import learner as L, model, runtime, synth
     dev = torch.device("cuda:0")
     z = np.load(os.path.join(GOLD, "f12_pretrain_epoch.npz"))
-    tol = {"fp32": dict(loss=1e-3, rms=5e-2, upd=1e-2, upd1=2e-1), "bf16": dict(loss=2e-3, rms=1e-1, upd=2e-2, upd1=3e-1)}[prec]
+    tol = {"fp32": dict(loss=1e-3, rms=5e-2, upd=1e-2, upd1=2e-1), "bf16": dict(loss=2e-3, rms=1e-1, upd=2e-2, upd1=3e-1),
+           "fp16": dict(loss=1e-3, rms=1e-1, upd=2e-2, upd1=3e-1)}[prec]
     try:
         man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
         net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev)
@@ -95,8 +97,8 @@ def test_pretrain_epoch_vs_reference_pretrain_epoch(prec):
         _set_dropout(net, 0.0)
         lrn = L.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
         lrn.cuda()
-        if prec == "bf16":
-            lrn.amp()
+        if prec != "fp32":
+            lrn.amp(prec)
         B, nb = int(z["B"]), int(z["nbatch"])
         pool = torch.from_numpy(synth.make_batch(int(z["sig_seed"]), B * nb))
         dataset = [[pool[i * B:(i + 1) * B]] for i in range(nb)]
@@ -159,7 +161,7 @@ def test_checkpoint_written_by_reference_resumes(tmp_path):
         runtime.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_dropout_on_curve_with_replayed_masks_vs_reference(prec):
     """SURVEY fixture F5(ii) / Q17: the reference's dropout-ON training run (p = 0.1, 40 Adam steps, batch 8).  The build draws the
     step's 28 dropout masks on the host with torch's CPU generator in the reference's order and layouts (runtime.DropoutReplay,

@@ -24,7 +24,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert len(names) >= 35
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
-    assert lib.sarssl_abi_version() == 1
+    assert lib.sarssl_abi_version() == 2
 
 
 def test_state_dict_layout_matches_reference_manifest():

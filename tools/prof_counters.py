@@ -47,7 +47,7 @@ def short(name):
     return name.split("(")[0][:90]
 
 
-def build_marker():
+def build_marker(hipcc=None):
     """tools/libprofmarker.so (marker kernel whose grid size tags the next group of launches), compiled HERE, in the un-profiled
     driver process and with the profiler's preload variables stripped - never from tools/prof_targets.py, which runs under rocprofv3
     with the GPU already initialised."""
@@ -55,7 +55,7 @@ def build_marker():
     if os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(src):
         return lib
     env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",) and not k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "HSA_TOOLS"))}
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", lib, src], env=env)
+    subprocess.check_call([hipcc or os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", lib, src], env=env)
     return lib
 
 
