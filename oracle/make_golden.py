@@ -469,6 +469,41 @@ def f5_curve_dropout(ref_model, ref_learner, nstep=40, B=8):
                             mask_seed_base=9000, dropout_seed_base=7000, pool=64, weight_seed=0, p_drop=0.1)
 
 
+def f13_full_batch(ref_model, ref_learner, B=64):
+    """Round-3 verdict, "B = 64 has no reference pin": the reference's own forward (code/model.py:519-601, no_grad) on the batch
+    bench.py times - 64 two-channel 65 792-sample segments (synth.make_batch(5000, 16) rolled to 64, as PCM-16: what the loader ships),
+    recipe weights, masks drawn by the reference from Python's RNG - in train mode with dropout p = 0 (BatchNorm batch statistics: the
+    forward of the captured training step) and in eval mode: loss, diff, 4 096 sampled `pred` bins each."""
+    from sar_ssl_amd import synth
+    uniq = synth.make_batch(5000, 16)
+    segs = np.stack([np.roll(uniq[i % 16], 997 * (i // 16), axis=0) for i in range(B)], axis=0)
+    pcm = synth.to_pcm16(segs)
+    sig = torch.from_numpy(pcm.astype(np.float32) / 32768.0)                      # what a PCM-16 WAV reader hands the reference
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    man = load_recipe(net, 0)
+    set_dropout(net, 0.0)
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    x, = lrn.data_preprocess(sig, None)
+    store = {"B": B, "weight_seed": 0, "sig_seed": 5000, "mask_seed": 31}
+    for mode in ("train", "eval"):
+        net.train(mode == "train")
+        net.load_state_dict(recipes.recipe_state_dict(man, 0))
+        random.seed(31)
+        idx, ch = orc.gen_masks(B, 256, 128, 2, random)
+        random.seed(31)
+        with torch.no_grad():
+            loss, diff, vis = net(x)
+        pred_patch = vis["pred"].permute(0, 2, 1, 3, 4).contiguous()                # (B,T,F,reim,mic)
+        sidx = sample_idx(pred_patch.numel(), 4096, 19)
+        store.update({mode + ".loss": np.float64(loss.item()), mode + ".diff": np.float64(diff.item()), mode + ".pred_idx": sidx,
+                      mode + ".pred_vals": pred_patch.reshape(-1)[sidx].numpy(), mode + ".pred_absmax": np.float64(pred_patch.abs().max())})
+        print("f13", mode, "loss", loss.item(), "diff", diff.item(), flush=True)
+        del vis, pred_patch
+    store["mask_idx"], store["mask_ch"] = idx.numpy(), ch.numpy()
+    np.savez_compressed(os.path.join(GOLD, "f13_full_batch.npz"), **store)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--curve", action="store_true")
@@ -479,7 +514,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_learner, ref_um = ref_shim.load()
-    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
+    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     if "manifest" in todo: f_manifest(ref_model)
     if "f1" in todo: f1_frontend(ref_learner, ref_model)
     if "f2" in todo: f2_blocks(ref_model)
@@ -492,6 +527,7 @@ if __name__ == "__main__":
     if "f11" in todo: f11_eval_export(ref_model, ref_learner, ref_um)
     if "f12" in todo: f12_pretrain_epoch(ref_model, ref_learner)
     if "f6" in todo: f6_checkpoint(ref_model, ref_learner)
+    if "f13" in todo: f13_full_batch(ref_model, ref_learner)
     if a.curve: f5_curve(ref_model, ref_learner)
     if a.curve_dropout: f5_curve_dropout(ref_model, ref_learner)
     print("golden vectors written to", GOLD)

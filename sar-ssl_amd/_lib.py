@@ -37,11 +37,19 @@ def check(rc, what=""):
 ncalls = 0          # C-ABI calls made so far (launch accounting: tools/host_time.py, graph.py's empty-segment check)
 
 
+call_timer = None   # hip.profile_start(all_calls=True): context-manager factory(name) bracketing every C call with events
+
+
 def call(name, *args):
     global ncalls
     ncalls += 1
     fn = getattr(lib(), name)
-    check(fn(*args), name)
+    if call_timer is not None:
+        with call_timer(name):
+            rc = fn(*args)
+    else:
+        rc = fn(*args)
+    check(rc, name)
 
 
 c_void_p, c_int, c_long, c_float, c_ulonglong, c_double = (

@@ -64,15 +64,19 @@ def _need_cuda(*ts):
 _prof = None
 
 
-def profile_start():
+def profile_start(all_calls=False):
+    """Event-time the labelled launches (_Timed) until profile_stop(); all_calls: additionally EVERY C-ABI call under its entry point's
+    name ("call:<symbol>": a step's whole kernel-time budget by family - run single-stream, where a launch has the GPU to itself)."""
     global _prof
     _prof = {}
+    _lib.call_timer = (lambda name: _Timed("call:" + name)) if all_calls else None
 
 
 def profile_stop():
     """-> {name: (launches, total_ms)}; synchronises."""
     global _prof
     p, _prof = _prof, None
+    _lib.call_timer = None
     torch.cuda.synchronize()
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (p or {}).items()}
 
@@ -204,13 +208,14 @@ def gemm_group_tn(items):
     cs = [torch.empty((it[3] * it[0].shape[1],), dtype=torch.float32, device=it[0].device) if it[4] is not None else None for it in items]
     arr = lambda ty, vals: (ty * n)(*vals)
     split_out = (ctypes.c_int * n)()
-    rc = _lib.lib().sarssl_gemm_group_tn(
-        arr(ctypes.c_void_p, [it[0].data_ptr() for it in items]), arr(ctypes.c_void_p, [it[1].data_ptr() for it in items]),
-        arr(ctypes.c_void_p, [w.data_ptr() for w in ws]), arr(ctypes.c_int, [it[0].shape[1] for it in items]),
-        arr(ctypes.c_int, [it[1].shape[1] for it in items]), arr(ctypes.c_int, [it[0].shape[0] for it in items]),
-        arr(ctypes.c_long, [it[0].stride(0) for it in items]), arr(ctypes.c_long, [it[1].stride(0) for it in items]),
-        arr(ctypes.c_int, [it[3] for it in items]), split_out, arr(ctypes.c_void_p, [c.data_ptr() if c is not None else None for c in cs]),
-        c_int(n), c_int(dt(items[0][1])), _stream())
+    with _Timed("call:sarssl_gemm_group_tn"):
+        rc = _lib.lib().sarssl_gemm_group_tn(
+            arr(ctypes.c_void_p, [it[0].data_ptr() for it in items]), arr(ctypes.c_void_p, [it[1].data_ptr() for it in items]),
+            arr(ctypes.c_void_p, [w.data_ptr() for w in ws]), arr(ctypes.c_int, [it[0].shape[1] for it in items]),
+            arr(ctypes.c_int, [it[1].shape[1] for it in items]), arr(ctypes.c_int, [it[0].shape[0] for it in items]),
+            arr(ctypes.c_long, [it[0].stride(0) for it in items]), arr(ctypes.c_long, [it[1].stride(0) for it in items]),
+            arr(ctypes.c_int, [it[3] for it in items]), split_out, arr(ctypes.c_void_p, [c.data_ptr() if c is not None else None for c in cs]),
+            c_int(n), c_int(dt(items[0][1])), _stream())
     _lib.ncalls += 1
     if rc == 1:
         return False

@@ -1,0 +1,42 @@
+"""Parity class of every numeric mode: the gates that tests/ ASSERT against the reference's golden vectors on MI355X, in one place so
+that bench.py's `parity_class` prints exactly what is asserted (round-3 verdict: the line claimed 1e-2 per bin while the test gate
+was 3e-2).  north_star: "within 1e-3 relative on the reconstruction loss and per-bin magnitudes ... 100-step recon-loss curve within
+1e-3 of reference".
+
+Quantities (fixture F3, tests/test_gpu_model.py::test_fullsize_forward_backward; F5 / F12, tests/test_gpu_train.py):
+  loss          |loss / loss_ref - 1|, full-size forward, eval and train mode
+  per_bin_max   max over F3's 2 048 sampled `pred` bins of |pred - pred_ref| / max|pred_ref|
+  per_bin_rms   rms of the same deviations / max|pred_ref|
+  grad_norm     worst per-parameter gradient L2 norm, relative
+  bn_running    BatchNorm running statistics after one train-mode forward
+  curve100      max relative deviation of the 100-step loss curve (dropout off, replayed masks)
+`measured` = what the MI355X run of round 4 measured (eval / train), for the reader; gates sit at <= 5x measured and never above the
+class the mode claims.
+"""
+
+GATES = {
+    # fp16 forward / bf16 backward - the mode bench.py times since round 4
+    "fp16": dict(loss=1e-3, per_bin_max=1.5e-3, per_bin_rms=5e-4, grad_norm=4e-2, bn_running=5e-4, curve100=1e-3,
+                 measured=dict(loss=(6.1e-6, 9.6e-7), per_bin_max=(9.1e-4, 1.21e-3), grad_norm=(1.5e-2, 7.9e-3), curve100=1.9e-4)),
+    # bf16 throughout - the timed mode of rounds 1-3
+    "bf16": dict(loss=2e-3, per_bin_max=3e-2, per_bin_rms=1e-2, grad_norm=6e-2, bn_running=5e-3, curve100=1e-3,
+                 measured=dict(loss=(3.8e-4, 1.2e-4), per_bin_max=(5.8e-3, 1.1e-2), grad_norm=(2.3e-2, 3.5e-2), curve100=1.6e-4)),
+    # f32 storage, every contraction as three split-bf16 MFMA passes
+    "fp32": dict(loss=1e-3, per_bin_max=1e-3, per_bin_rms=1e-3, grad_norm=5e-3, bn_running=1e-4, curve100=1e-3,
+                 measured=dict(loss=(2.3e-7, 2.4e-7), per_bin_max=(9.7e-6, 1.5e-5), grad_norm=(3.5e-4, 3.9e-4), curve100=1.9e-4)),
+    # f32 storage, one bf16 MFMA pass (round-3 experiment)
+    "fp32_1pass": dict(loss=2e-3, per_bin_max=3e-2, per_bin_rms=1e-2, grad_norm=6e-2, bn_running=5e-3, curve100=None, measured=dict()),
+}
+
+
+def parity_class(precision):
+    """What bench.py prints for the timed mode."""
+    if precision == "fp8":
+        return {"loss_vs_bf16_path": 2e-3, "per_bin_pred_of_range": 0.15, "status": "parity only (slower than bf16 on this model, DESIGN.md 4.5)",
+                "pinned_by": "tests/test_gpu_fp8.py (against the bf16 path)"}
+    g = GATES[precision]
+    return {"loss_vs_reference": g["loss"], "loss_curve_100_steps": g["curve100"], "per_bin_pred_of_range_max": g["per_bin_max"],
+            "per_bin_pred_of_range_rms": g["per_bin_rms"], "per_parameter_grad_norm": g["grad_norm"], "measured_eval_train": g["measured"],
+            "north_star": "1e-3 on the loss, the per-bin magnitudes and the 100-step curve",
+            "pinned_by": "tests/test_gpu_model.py::test_fullsize_forward_backward (F3), tests/test_gpu_train.py (F5, F12), "
+                         "tests/test_gpu_graph.py (B = 64 captured step vs the fp32 mode, F13 reference forward at B = 64)"}

@@ -172,12 +172,13 @@ def _fullsize(prec, mode):
 # Full-size tolerances.  fp32 (split-bf16 MFMA) path: the north_star's 1e-3.  bf16 path (what bench.py times): 2.5-5x the deviation
 # measured on MI355X (round 2: loss 3.6e-4, sampled pred 9.6e-3 of range, worst per-parameter gradient norm 2.6e-2, BN running
 # stats 9.6e-4; recorded by conftest.check in gpurun_out/parity_measured.jsonl).
-FULL_TOL = {"fp32": dict(loss=1e-3, pred=1e-3, grad=5e-3, bn=1e-4), "bf16": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3),
-            # f32 storage + single-pass bf16 MFMA (runtime.set_precision("fp32_1pass")): first measured in round 3
-            "fp32_1pass": dict(loss=2e-3, pred=3e-2, grad=6e-2, bn=5e-3),
-            # fp16 forward / bf16 backward (the timed mode since round 4): first measured in round 4; the CPU study
-            # (oracle/operand_rounding_study.py) predicts 0.9e-3 / 1.1e-3 per bin (eval / train)
-            "fp16": dict(loss=1e-3, pred=5e-3, grad=6e-2, bn=5e-3)}
+# (round 4: the gates live in sar_ssl_amd/parity.py, which bench.py's `parity_class` prints - the line claims what is asserted here.
+#  fp16 forward / bf16 backward, the timed mode: per-bin max 9.1e-4 / 1.21e-3 of range (eval / train) as oracle/operand_rounding_study.py
+#  predicted on the CPU (8.9e-4 / 1.10e-3); gated at the north_star's 1e-3 x 1.5, the rms of the same deviations at 5e-4.)
+def _full_tol(prec):
+    from sar_ssl_amd.parity import GATES
+    g = GATES[prec]
+    return dict(loss=g["loss"], pred=g["per_bin_max"], pred_rms=g["per_bin_rms"], grad=g["grad_norm"], bn=g["bn_running"])
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_1pass", "fp16"])
@@ -185,7 +186,7 @@ FULL_TOL = {"fp32": dict(loss=1e-3, pred=1e-3, grad=5e-3, bn=1e-4), "bf16": dict
 def test_fullsize_forward_backward(mode, prec):
     """north_star gate: loss and per-bin outputs within 1e-3 relative of the reference CPU path (fp32 mode); the bf16 fast path is
     gated at a small multiple of its measured deviation."""
-    tol = FULL_TOL[prec]
+    tol = _full_tol(prec)
     net, loss, diff, vis, z = _fullsize(prec, mode)
     tag = "fullsize.%s.%s." % (prec, mode)
     check(tag + "loss", abs(loss.item() / float(z[mode + ".loss"]) - 1), tol["loss"])
@@ -194,6 +195,7 @@ def test_fullsize_forward_backward(mode, prec):
     got = pred[torch.from_numpy(z[mode + ".pred_idx"])]
     want = torch.from_numpy(z[mode + ".pred_vals"])
     check(tag + "pred", ((got - want).abs().max() / float(z[mode + ".pred_absmax"])).item(), tol["pred"])
+    check(tag + "pred_rms", ((got - want).pow(2).mean().sqrt() / float(z[mode + ".pred_absmax"])).item(), tol["pred_rms"])
     gn = json.loads(str(z[mode + ".gradnorm_json"]))
     _check_gradnorms(net, gn, tol["grad"], tag + "gradnorm")
     if mode == "train":

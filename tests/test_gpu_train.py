@@ -88,7 +88,7 @@ def test_pretrain_epoch_vs_reference_pretrain_epoch(prec):
     dev = torch.device("cuda:0")
     z = np.load(os.path.join(GOLD, "f12_pretrain_epoch.npz"))
     tol = {"fp32": dict(loss=1e-3, rms=5e-2, upd=1e-2, upd1=2e-1), "bf16": dict(loss=2e-3, rms=1e-1, upd=2e-2, upd1=3e-1),
-           "fp16": dict(loss=1e-3, rms=1e-1, upd=2e-2, upd1=3e-1)}[prec]
+           "fp16": dict(loss=1e-3, rms=2e-2, upd=5e-3, upd1=2e-1)}[prec]      # measured: 9.8e-5, 3.2e-3, 6.1e-4, 4.9e-2
     try:
         man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
         net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev)
@@ -196,8 +196,8 @@ def test_dropout_on_curve_with_replayed_masks_vs_reference(prec):
         assert runtime.RT.replay.draws == 28 * n                       # 7 draws x (1 spec + 3 spat) blocks per step
         got = torch.stack(losses).cpu().numpy().astype(np.float64)
         rel = np.abs(got - z["loss"]) / z["loss"]
-        check("curve_dropout_on.%s.first10" % prec, rel[:10].max(), 1e-3 if prec == "fp32" else 2e-3)
-        check("curve_dropout_on.%s.max" % prec, rel.max(), 1e-3 if prec == "fp32" else 3e-3)
+        check("curve_dropout_on.%s.first10" % prec, rel[:10].max(), 2e-3 if prec == "bf16" else 1e-3)      # (fp16 measured: 1.5e-4)
+        check("curve_dropout_on.%s.max" % prec, rel.max(), 3e-3 if prec == "bf16" else 1e-3)
     finally:
         runtime.RT.replay = None
         runtime.set_precision("bf16")

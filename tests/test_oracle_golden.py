@@ -299,3 +299,25 @@ def test_oracle_dropout_on_steps_vs_reference_curve():
         loss, diff = orc.train_step(pool[s * B:(s + 1) * B], sd, state, float(z["lr"]), p_drop=float(z["p_drop"]))
         assert abs(loss / float(z["loss"][s]) - 1) < 2e-5, (s, loss)
         assert abs(diff / float(z["diff"][s]) - 1) < 1e-6
+
+
+def test_f13_oracle_forward_at_the_timed_batch_size():
+    """Fixture F13: the reference's own forward at B = 64 (the batch bench.py times), train mode with dropout 0.  The oracle on the same
+    PCM-16 segments / recipe weights / masks reproduces loss, diff and the 4 096 sampled `pred` bins (train-mode BatchNorm couples the
+    segments, so the whole batch is run: ~15 s on 8 threads)."""
+    from sar_ssl_amd import synth
+    z = _npz("f13_full_batch.npz")
+    B = int(z["B"])
+    uniq = synth.make_batch(int(z["sig_seed"]), 16)
+    segs = np.stack([np.roll(uniq[i % 16], 997 * (i // 16), axis=0) for i in range(B)], axis=0)
+    sig = torch.from_numpy(synth.to_pcm16(segs).astype(np.float32) / 32768.0)
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    sd = recipes.recipe_state_dict(man, int(z["weight_seed"]))
+    random.seed(int(z["mask_seed"]))
+    idx, ch = orc.gen_masks(B, 256, 128, 2, random)
+    assert np.array_equal(idx.numpy(), z["mask_idx"]) and np.array_equal(ch.numpy(), z["mask_ch"])
+    with torch.no_grad():
+        loss, diff, aux = orc.sarssl_pretrain_forward(orc.data_preprocess(sig), sd, idx, ch, train=True, p_drop=0.0)
+    assert abs(float(loss) / float(z["train.loss"]) - 1) < 1e-5 and abs(float(diff) / float(z["train.diff"]) - 1) < 1e-5
+    got = aux["pred"].reshape(-1)[torch.from_numpy(z["train.pred_idx"])]
+    assert float((got - torch.from_numpy(z["train.pred_vals"])).abs().max()) < 2e-4 * float(z["train.pred_absmax"])
