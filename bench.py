@@ -319,10 +319,16 @@ def main():
         os.environ["SARSSL_TWO_STREAMS"] = "0"             # one stream: each launch has the GPU to itself, as in rocprof's
         step_eager()                                       # per-kernel statistics of a single-stream run
         torch.cuda.synchronize()
+        import gc
+        gc.collect()
+        gc.disable()                                       # (a collection pause inside an event interval reads as a slow launch)
         hip.profile_start(all_calls=True)                  # + every C-ABI call under its entry point's name: the step's time by family
         for _ in range(6):
+            hip.gpu_runway(40.0)                           # the profiled step is host-bound: keep the GPU queue fed (hip.gpu_runway)
             step_eager()
+            torch.cuda.synchronize()
         prof = hip.profile_stop()
+        gc.enable()
         os.environ["SARSSL_TWO_STREAMS"] = "1"
     wall_khz = _lib.lib().sarssl_wall_clock_khz()
     clk_step = clk.cpu().numpy().reshape(5, 4).copy()
@@ -386,6 +392,10 @@ def main():
         flop_per_launch = 2.0 * npix_b * 256 * T * 64 * 576              # one 3x3 64->64 conv over B' x 256 x T pixels
         achieved = (flop_per_launch / (ms / n * 1e-3)) / 1e12 if n else 0.0
         nw, msw = prof.get("conv3x3_wgrad_kernel", (0, 0.0))
+        if os.environ.get("SARSSL_BENCH_DEBUG"):
+            for k in sorted(prof):
+                if "conv" in k:
+                    print("prof", k, prof[k][0], round(prof[k][1] / max(prof[k][0], 1), 4), file=sys.stderr)
         traffic, mfma_busy, pmc_file = None, None, None  # per launch, from the committed PMC passes (same kernel, same shape; tools/prof_counters.py)
         for name in ("r03_kernel_counters.json", "r02_kernel_counters.json"):
             pmc = os.path.join(ROOT, "profiles", name)

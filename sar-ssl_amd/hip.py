@@ -62,6 +62,7 @@ def _need_cuda(*ts):
 
 # ---- optional per-kernel timing with events on the launch stream (bench.py roofline) ---------------------------------
 _prof = None
+_prof_shapes = os.environ.get("SARSSL_PROF_SHAPES", "0") == "1"      # tools: label every GEMM launch with its shape
 
 
 def profile_start(all_calls=False):
@@ -81,19 +82,40 @@ def profile_stop():
     return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (p or {}).items()}
 
 
+_runway_cycles_per_ms = None
+
+
+def gpu_runway(ms):
+    """Enqueue ~``ms`` milliseconds of spinning on the current stream (torch.cuda._sleep, calibrated once with events).  Event-bracketed
+    launches only measure kernel durations while the GPU queue never runs dry: an eager step that is being profiled call by call is
+    host-bound (two event records per launch), and every interval would include the host's gaps - so the profiled step is enqueued
+    BEHIND a runway long enough for the host to finish enqueueing it."""
+    global _runway_cycles_per_ms
+    if _runway_cycles_per_ms is None:
+        torch.cuda._sleep(1000)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        torch.cuda._sleep(2000000)
+        b.record()
+        torch.cuda.synchronize()
+        _runway_cycles_per_ms = 2000000.0 / max(a.elapsed_time(b), 1e-3)
+    torch.cuda._sleep(int(ms * _runway_cycles_per_ms))
+
+
 class _Timed:
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
-        if _prof is not None:
+        if _prof is not None and self.name is not None:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
             self.a.record()                      # current stream == the stream the kernel is launched on
         return self
 
     def __exit__(self, *exc):
-        if _prof is not None:
+        if _prof is not None and self.name is not None:
             self.b.record()
             _prof.setdefault(self.name, []).append((self.a, self.b))
         return False
@@ -170,7 +192,10 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
             ws = workspace(4 * nbatch * split_k * M * N, A.device, "gemm_split")
     elif precise and A.dtype == torch.float32:
         ws = workspace(4 * nbatch * M * N, A.device, "gemm_acc")
-    _lib.call("sarssl_gemm", _p(A), _p(B), _p(out) if deferred is None else c_void_p(0), c_int(dt(A)), c_int(dt(B)), c_int(dt(out)),
+    with _Timed("gemm[%d,%d,%d x%d %s%s %s%s%s%s]" % (M, N, K, nbatch, "k" if a_kc else "m", "k" if b_kc else "n", str(out.dtype)[6:],
+                                                 " sk%d" % split_k if split_k else "", " act%d" % act if act else "",
+                                                 " aux" if aux is not None else "") if _prof_shapes and _prof is not None else None):
+      _lib.call("sarssl_gemm", _p(A), _p(B), _p(out) if deferred is None else c_void_p(0), c_int(dt(A)), c_int(dt(B)), c_int(dt(out)),
               c_int(1 if a_kc else 0), c_int(1 if b_kc else 0), c_int(M), c_int(N), c_int(K),
               c_long(lda), c_long(ldb), c_long(ldc), c_int(nbatch), c_int(batch_inner),
               c_long(sA[0]), c_long(sA[1]), c_long(sB[0]), c_long(sB[1]), c_long(sC[0]), c_long(sC[1]),

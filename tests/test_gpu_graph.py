@@ -182,6 +182,7 @@ def test_full_batch_captured_step_and_eval_forward_vs_the_reference_at_batch_64(
         o = g.step(pcm=pcm, static=True)                              # capture + first replay, exactly bench.py's call
         assert sum(1 for k, _ in g._plan if k == "graph") == 1
         got = {"train": (float(o[0]), float(o[1]), g.pred.detach().float().reshape(-1).cpu())}
+        net.load_state_dict(recipes.recipe_state_dict(man, int(z["weight_seed"])))      # (the train-mode step moved the BatchNorm running statistics)
         net.eval()
         net.set_masks(z["mask_idx"], z["mask_ch"])
         with torch.no_grad():
