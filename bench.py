@@ -299,7 +299,7 @@ def main():
     elapsed = time.perf_counter() - t0
     calls_per_step = (_lib.ncalls - n0) / max(args.steps, 1)
     prof2 = {}
-    _lib.call("sarssl_conv_clock_probe", _lib.c_void_p(clk.data_ptr()))
+    hip.conv_clock_probe(clk)
     if graph is None:
         prof = hip.profile_stop()
         step_eager()                                           # (one more step with the clock probe attached)
@@ -378,7 +378,7 @@ def main():
         iso_ms = e0.elapsed_time(e1) / 10
         iso_ghz = eff_ghz(clk.cpu().numpy().reshape(5, 4)[0])
         del xi
-    _lib.call("sarssl_conv_clock_probe", _lib.c_void_p(0))
+    hip.conv_clock_probe(None)
 
     out = None
     if rank == 0:

@@ -19,6 +19,23 @@ extern "C" {
 
 const char* sarssl_last_error(void);
 int sarssl_abi_version(void);
+
+/* ---- contexts ("no global mutable state except an opaque sarssl_ctx* created per device").  A context owns everything a
+ *      caller can configure - the workgroup count of the 3x3 gradient launches, the clock-probe buffer, the attached step state (dropout
+ *      salt of a captured step), the range of the host-zeroed accumulator arena.  Kernels are launched under the context that is
+ *      CURRENT ON THE CALLING THREAD (sarssl_make_current; none current = library defaults), so two contexts on one device - two models,
+ *      a training thread and a validation thread - never see each other's settings.  The library keeps no other mutable state (the
+ *      error string of sarssl_last_error is per thread). */
+typedef struct sarssl_ctx sarssl_ctx;
+sarssl_ctx* sarssl_create(int device);              /* NULL on error */
+int sarssl_destroy(sarssl_ctx* ctx);
+int sarssl_make_current(sarssl_ctx* ctx);           /* ctx or NULL becomes the calling thread's current context */
+int sarssl_ctx_device(const sarssl_ctx* ctx);
+int sarssl_ctx_set_conv_cus(sarssl_ctx* ctx, int ncus);       /* 3x3 data / weight gradient launches: workgroups; 0 = 7/8 of the CUs */
+int sarssl_ctx_get_conv_cus(const sarssl_ctx* ctx);
+int sarssl_ctx_set_clock_probe(sarssl_ctx* ctx, void* buf);   /* see the measurement aid below; NULL = off */
+int sarssl_ctx_attach_step_state(sarssl_ctx* ctx, void* state);   /* device SarsslStepState* or NULL: dropout launches add its salt */
+int sarssl_ctx_zero_arena(sarssl_ctx* ctx, const void* base, long bytes);   /* accumulators inside [base, base+bytes) are already zero */
 int sarssl_device_info(int device, char* name_out, int name_len, int* cu_count, long* lds_bytes);
 
 /* ---- front-end: code/common/utils_module.py:49-72 (STFT.forward), code/learner.py:525-553 (data_preprocess),
@@ -124,11 +141,9 @@ int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, 
 /*      measurement aid (no reference counterpart): buf = device memory, 5 slots x 4 u64; thread 0 of workgroup 0 of every bf16 3x3
  *      forward / data-gradient launch stores {s_memtime, s_memrealtime} at kernel entry and exit into the slot of its variant (0 forward
  *      with BN prologue, 1 data gradient, 2 data gradient + BN sums, 3 forward from the 4-channel input, 4 data gradient consumed in its
- *      epilogue): effective shader clock = d(memtime) / d(memrealtime) * sarssl_wall_clock_khz().  null switches it off. */
-int sarssl_conv_clock_probe(void* buf);
-/*      scheduling aid (no reference counterpart): workgroup count of the 3x3 gradient launches (data and weight gradients) that follow on
- *      this host thread; 0 = the default rule (7/8 of the CUs, leaving room for the other encoder's stream). */
-int sarssl_conv_cus_override(int ncus);
+ *      epilogue): effective shader clock = d(memtime) / d(memrealtime) * sarssl_wall_clock_khz().  Set per context: sarssl_ctx_set_clock_probe. */
+/*      scheduling aid (no reference counterpart): sarssl_ctx_set_conv_cus - workgroup count of the 3x3 gradient launches (data and weight
+ *      gradients) issued under the context; 0 = the default rule (7/8 of the CUs, leaving room for the other encoder's stream). */
 long sarssl_wall_clock_khz();
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
@@ -270,7 +285,6 @@ int sarssl_f64_accum(const double* src, float* dst, int n, float scale, void* st
 int sarssl_f64_accum2(const double* src, float* dst1, float* dst2, int n, void* stream);     /* dst1 += src[:n], dst2 += src[n:2n] */
 /* f64 accumulators (BatchNorm / loss sums) handed to the reduction entry points are zeroed by a memset in front of each launch - unless
  * they lie inside [base, base + bytes), an arena the caller zeroes itself once per forward / backward pass (NULL unregisters). */
-int sarssl_zero_arena(const void* base, long bytes);
 
 /* ---- loss: code/model.py:585-592 (channel select) + 721-747 (gen_loss).  fwd: sums = f64[128] scratch, out = f32[2]
  * (loss, diff); F <= 480. */
@@ -297,7 +311,6 @@ int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, vo
 long sarssl_step_state_bytes(void);
 int sarssl_step_state_init(void* state, unsigned long long salt, float lr, float beta1, float beta2, void* stream);
 int sarssl_step_state_reset(void* state, float lr, float beta1, float beta2, void* stream);
-int sarssl_step_state_attach(void* state);
 int sarssl_step_tick(void* state, void* stream);
 int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, const void* state,
                          float eps, int zero_grad, void* stream);

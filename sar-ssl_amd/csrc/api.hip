@@ -41,12 +41,14 @@ int sarssl_cu_count() {
 // in device memory: the dropout salt (added to each launch's static seed) and the Adam step count / bias corrections.
 // (thread_local: the pointer is attached by the thread that captures a step and must only reach the launches THAT thread issues - a loader
 //  or validation thread launching kernels at the same time keeps seeing "no salt")
-static thread_local const unsigned long long* g_salt = nullptr;
-const unsigned long long* sarssl_dropout_salt() { return g_salt; }
-// state: device pointer to a SarsslStepState (or null to detach).  While attached, every launch that draws dropout masks reads the
-// salt through this pointer - attach only around graph capture: the pointer is baked into the captured launches.
-extern "C" int sarssl_step_state_attach(void* state) {
-    g_salt = state ? &((const SarsslStepState*)state)->salt : nullptr;
+const unsigned long long* sarssl_dropout_salt() { sarssl_ctx* c = sarssl_current(); return c ? c->salt : nullptr; }
+// state: device pointer to a SarsslStepState (or null to detach).  While attached to a context, every launch issued under that context
+// that draws dropout masks reads the salt through this pointer - attach only around graph capture: the pointer is baked into the
+// captured launches.  (The context is current per THREAD: a loader or validation thread launching kernels at the same time under
+// another context - or none - keeps seeing "no salt".)
+extern "C" int sarssl_ctx_attach_step_state(sarssl_ctx* ctx, void* state) {
+    SARSSL_REQUIRE(ctx != nullptr, "sarssl_ctx_attach_step_state");
+    ctx->salt = state ? &((const SarsslStepState*)state)->salt : nullptr;
     return 0;
 }
 extern "C" long sarssl_step_state_bytes() { return (long)sizeof(SarsslStepState); }
@@ -88,23 +90,51 @@ extern "C" int sarssl_step_tick(void* state, void* stream) {
 // The f64 accumulators of the reductions (BatchNorm sums, backward sums, loss sums) are zeroed by a hipMemsetAsync in front of every
 // launch: ~26 memset nodes per training step.  The host side can instead hand out slices of ONE arena it zeroes once per forward /
 // backward pass (hip.py: sums_zeroed); a pointer inside the registered range is taken as already zero and its memset is skipped.
-// One range per device (the host keeps one arena per GPU; with a single process-global range the second device's arena used to evict the
-// first one's, whose slices then silently got all their memsets back).  base == null clears the table.
-#define ZERO_ARENA_MAX 16
-static struct { const char* lo; const char* hi; } g_zero[ZERO_ARENA_MAX];
-static int g_nzero = 0;
-extern "C" int sarssl_zero_arena(const void* base, long bytes) {
-    if (!base) { g_nzero = 0; return 0; }
-    for (int i = 0; i < g_nzero; ++i)
-        if (g_zero[i].lo == (const char*)base) { g_zero[i].hi = (const char*)base + bytes; return 0; }
-    SARSSL_REQUIRE(g_nzero < ZERO_ARENA_MAX, "sarssl_zero_arena(table full)");
-    g_zero[g_nzero].lo = (const char*)base; g_zero[g_nzero].hi = (const char*)base + bytes; ++g_nzero;
+// One range per context (the host keeps one arena per GPU).  base == null clears it.
+extern "C" int sarssl_ctx_zero_arena(sarssl_ctx* ctx, const void* base, long bytes) {
+    SARSSL_REQUIRE(ctx != nullptr, "sarssl_ctx_zero_arena");
+    ctx->zero_lo = (const char*)base; ctx->zero_hi = base ? (const char*)base + bytes : nullptr;
     return 0;
 }
 bool sarssl_prezeroed(const void* p) {
-    for (int i = 0; i < g_nzero; ++i)
-        if ((const char*)p >= g_zero[i].lo && (const char*)p < g_zero[i].hi) return true;
-    return false;
+    const sarssl_ctx* c = sarssl_current();
+    return c && c->zero_lo && (const char*)p >= c->zero_lo && (const char*)p < c->zero_hi;
+}
+
+// ---- contexts ------------------------------------------------------------------------------------------------------------------------
+// "no global mutable state except an opaque sarssl_ctx* created per device".  A context owns the caller-configurable
+// state (gradient-convolution workgroup count, clock-probe buffer, attached step state, zeroed-arena range); kernels are launched
+// under the context that is current on the calling thread, so two contexts on one device - two models, a training loop and a
+// validation thread - do not see each other's settings.  No context current = library defaults.
+static thread_local sarssl_ctx* t_ctx = nullptr;
+sarssl_ctx* sarssl_current() { return t_ctx; }
+extern "C" sarssl_ctx* sarssl_create(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { sarssl_set_error("sarssl_create: no device %d", device); return nullptr; }
+    sarssl_ctx* c = (sarssl_ctx*)calloc(1, sizeof(sarssl_ctx));
+    if (c) c->device = device;
+    return c;
+}
+extern "C" int sarssl_destroy(sarssl_ctx* ctx) {
+    if (ctx && t_ctx == ctx) t_ctx = nullptr;          // (other threads must not keep a destroyed context current)
+    free(ctx);
+    return 0;
+}
+// ctx (or null) becomes the calling thread's current context
+extern "C" int sarssl_make_current(sarssl_ctx* ctx) { t_ctx = ctx; return 0; }
+extern "C" int sarssl_ctx_device(const sarssl_ctx* ctx) { return ctx ? ctx->device : -1; }
+// workgroup count of the 3x3 gradient launches (data and weight gradients) issued under ctx; 0 = the default rule (7/8 of the CUs)
+extern "C" int sarssl_ctx_set_conv_cus(sarssl_ctx* ctx, int ncus) {
+    SARSSL_REQUIRE(ctx != nullptr, "sarssl_ctx_set_conv_cus");
+    ctx->conv_cus_bwd = ncus > 0 ? ncus : 0;
+    return 0;
+}
+extern "C" int sarssl_ctx_get_conv_cus(const sarssl_ctx* ctx) { return ctx ? ctx->conv_cus_bwd : 0; }
+// clock-probe buffer (device memory, 5 slots x 4 u64) of the 3x3 forward / data-gradient launches issued under ctx; null = off
+extern "C" int sarssl_ctx_set_clock_probe(sarssl_ctx* ctx, void* buf) {
+    SARSSL_REQUIRE(ctx != nullptr, "sarssl_ctx_set_clock_probe");
+    ctx->conv_clk = (unsigned long long*)buf;
+    return 0;
 }
 
 // waves raise their issue priority (s_setprio) during MFMA phases: 2 = the ping-pong convolution only (measured in round 2: -2.4 ... -3.5 %

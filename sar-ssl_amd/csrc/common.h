@@ -22,6 +22,17 @@ enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2, SARSSL_F16 = 3, SARSSL_M
 extern "C" const char* sarssl_last_error();
 void sarssl_set_error(const char* fmt, ...);
 int sarssl_cu_count();          // CUs of the current device (api.hip): grid size of the persistent kernels
+// Per-device context (api.hip; sarssl_create / sarssl_destroy / sarssl_make_current in include/sarssl_hip.h): everything a caller can
+// configure lives in one of these - there is no process-global mutable state in the library.  The launch wrappers read the context
+// that is CURRENT ON THE CALLING THREAD (null: library defaults).
+struct sarssl_ctx {
+    int device;
+    int conv_cus_bwd;                       // workgroups of the 3x3 gradient launches (0: the default 7/8 rule)
+    unsigned long long* conv_clk;           // clock-probe buffer of the 3x3 forward / data-gradient launches, or null
+    const unsigned long long* salt;         // dropout-seed addend: &SarsslStepState::salt of the attached step state, or null
+    const char* zero_lo; const char* zero_hi;   // host-zeroed accumulator arena: memsets of pointers inside it are skipped
+};
+sarssl_ctx* sarssl_current();   // may be null
 // Device-resident step state (api.hip, sarssl_step_state_*): lets a step captured in a hipGraph vary per replay.  `salt` is added to
 // every dropout seed by the kernels (null / 0 outside graph capture); the Adam fields are advanced by sarssl_step_tick.
 struct SarsslStepState {

@@ -1840,25 +1840,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // launch covers every CU the other encoder's stream stands still; a launch that leaves an eighth of the CUs free lets that stream's
 // short latency-bound kernels run next to it (measured on the step).  The grid is then trimmed so that the last
 // round of tiles is as full as the others (a multiple of 8 keeps the XCD-aware tile order).
-// Host-side override of the workgroup count of the following gradient launches (0 = the default rule below): the engine uses it to give
-// the stem backward that runs LAST - alone on the chip, the other encoder's stream has drained - all CUs (sarssl_conv_cus_override).
-static thread_local int g_conv_cus_override = 0;
-extern "C" int sarssl_conv_cus_override(int ncus) { g_conv_cus_override = ncus > 0 ? ncus : 0; return 0; }
+// Per-context override of the workgroup count of the gradient launches (0 = the default rule below): the engine uses it to give the
+// stem backward that runs LAST - alone on the chip, the other encoder's stream has drained - all CUs (sarssl_ctx_set_conv_cus).
+static int conv_cus_override() { const sarssl_ctx* c = sarssl_current(); return c ? c->conv_cus_bwd : 0; }     // (sarssl_ctx_set_conv_cus)
 static int conv_cus(int kind) {
     static const int lim[2] = {
         []() { const char* e = getenv("SARSSL_CONV_CUS_FWD"); if (!e) e = getenv("SARSSL_CONV_CUS"); return e ? atoi(e) : 0; }(),
         []() { const char* e = getenv("SARSSL_CONV_CUS_BWD"); if (!e) e = getenv("SARSSL_CONV_CUS"); return e ? atoi(e) : 0; }()};
     const int ncu = sarssl_cu_count();
-    if (kind == 1 && g_conv_cus_override > 0) return g_conv_cus_override < ncu ? g_conv_cus_override : ncu;
+    const int ovr = conv_cus_override();
+    if (kind == 1 && ovr > 0) return ovr < ncu ? ovr : ncu;
     if (lim[kind] > 0) return lim[kind] < ncu ? lim[kind] : ncu;
     // default: forward launches on every CU, gradient launches on 7/8 of them (same-box A/B at B = 64, three rounds: 5 510 - 5 750
     // segments/s with 256 of 256, 5 736 - 5 750 with 224 - the step gains ~2 % although each gradient launch alone is ~12 % slower)
     return kind == 1 && ncu >= 64 ? (ncu * 7 / 8) & ~7 : ncu;
 }
-// Clock probe buffer (device memory, 5 slots x 4 u64: forward with BN prologue | data gradient | data gradient + BN sums | forward from
-// the 4-channel input | data gradient consumed in its epilogue); null = off.  Set by bench.py around its event-timed launches.
-static unsigned long long* g_conv_clk = nullptr;
-extern "C" int sarssl_conv_clock_probe(void* buf) { g_conv_clk = (unsigned long long*)buf; return 0; }
+// Clock probe buffer of the current context (device memory, 5 slots x 4 u64: forward with BN prologue | data gradient | data gradient +
+// BN sums | forward from the 4-channel input | data gradient consumed in its epilogue); null = off.  Set by bench.py around its
+// event-timed launches (sarssl_ctx_set_clock_probe).
+static unsigned long long* conv_clk() { const sarssl_ctx* c = sarssl_current(); return c ? c->conv_clk : nullptr; }  // (sarssl_ctx_set_clock_probe)
 extern "C" long sarssl_wall_clock_khz() {
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) != hipSuccess) return 0;
@@ -1926,7 +1926,7 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
-    a.clk = g_conv_clk ? g_conv_clk + 4 * 3 : nullptr;
+    a.clk = conv_clk() ? conv_clk() + 4 * 3 : nullptr;
     a.stats = stats;
     a.in = a0; a.w = w; a.out = out; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
     a.nb = nb; a.F = F; a.T = T;
@@ -1955,7 +1955,7 @@ extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const v
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
-    a.clk = g_conv_clk ? g_conv_clk + 4 * 4 : nullptr;
+    a.clk = conv_clk() ? conv_clk() + 4 * 4 : nullptr;
     a.in = dy; a.w = w; a.out = nullptr; a.scale = scale; a.shift = shift; a.prologue = 0; a.c1_w = W1; a.c1_a0 = a0; a.c1_red = red;
     a.nb = nb; a.F = F; a.T = T;
     const int npairs = (nb * ((F + TR - 1) / TR) * ((T + PTC - 1) / PTC) + 1) / 2;
@@ -1979,7 +1979,7 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
-    a.clk = g_conv_clk ? g_conv_clk + 4 * (bn_y ? 2 : (scale != nullptr ? 0 : 1)) : nullptr;
+    a.clk = conv_clk() ? conv_clk() + 4 * (bn_y ? 2 : (scale != nullptr ? 0 : 1)) : nullptr;
     a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
     a.in = in; a.w = w; a.out = out; a.acc_ws = nullptr; a.acc_in = 0; a.acc_out = 0;

@@ -434,6 +434,9 @@ static void launch_fm(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStrea
 // used when the grid still has at least ~one workgroup per CU, otherwise 128 x 128 (FM = 2).  big = allowed for this dtype combo.
 static int pick_fm(const GemmArgs& g, int nbatch, bool big) {
     if (!big) return 2;
+#ifdef SARSSL_PROBE_ENV          // probe builds only: force a tile height (tools/step_gemm_table.py A/B runs)
+    { const char* e = getenv("SARSSL_GEMM_FM"); if (e && atoi(e) > 0) return atoi(e); }
+#endif
     const long nsplit = g.split_k > 0 ? g.split_k : 1;
     const long wg4 = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN) * nbatch * nsplit;
     // 64 x 128 tiles (FM = 1) when 128 x 128 tiles give at most ~one workgroup per CU (N <= 256 at M = 16384): nothing else on the
@@ -442,9 +445,15 @@ static int pick_fm(const GemmArgs& g, int nbatch, bool big) {
     constexpr int fm1_pct = 112;
     if (g.split_k <= 0 && g.M >= 128 && wg2 * 100 <= (long)sarssl_cu_count() * fm1_pct) return 1;
     const int k_len = g.split_k > 0 ? g.k_per_split : g.K;
+    // round 4 (tools/step_gemm_table.py with a forced tile height, in-step launches at M = 16384): with K <= 256 a 128 x 128 tile is
+    // four K-tiles of main loop behind a full prologue / epilogue - the 64-row tile's extra workgroups hide each other's latencies
+    // (N = 1024, K = 256: 57.8 -> 48.4 us with the fused activation backward, 50.7 -> 46.1 us with Swish + dropout + pre-activation)
+    if (g.split_k <= 0 && g.M >= 4096 && k_len <= 256 && g.N >= 1024) return 1;
     // measured on MI355X (tools/bench_kernels.py, tools/gemm_diag.py, M = 16384): the large tile wins from ~2 workgroups per CU and
     // K >= 768 on (decoder 3072 x 768 / 1024 x 3072: -4 ... -15 %); with one workgroup per CU (N = 512) or short K it loses 5-20 %
-    return (g.M >= 192 && k_len >= 768 && wg4 >= 2L * sarssl_cu_count()) ? 4 : 2;
+    // (round 4: K = 768 / 1024 at N = 3072 - the decoder's first layer and its data gradient with the fused ReLU backward - run 5-10 %
+    //  faster on 128 x 128 tiles inside the step: 185.8 -> 168.3 us; the long-K products keep the large tile: 117 vs 139 us)
+    return (g.M >= 192 && k_len >= 1536 && wg4 >= 2L * sarssl_cu_count()) ? 4 : 2;
 }
 
 template <typename TA, typename TB, typename TC, bool BIG>

@@ -121,7 +121,7 @@ class _Timed:
         return False
 
 
-# ---- pre-zeroed f64 arena for the reductions' accumulators (csrc/api.hip sarssl_zero_arena): one memset per forward / backward
+# ---- pre-zeroed f64 arena for the reductions' accumulators (csrc/api.hip sarssl_ctx_zero_arena): one memset per forward / backward
 #      pass instead of one in front of every reduction launch
 _ARENA_DOUBLES = 1 << 16
 _arena = {}                 # device index -> [tensor, cursor]
@@ -136,7 +136,7 @@ def sums_arena_reset(device):
     if ent is None:
         t = torch.zeros((_ARENA_DOUBLES,), dtype=torch.float64, device=device)
         ent = _arena[device.index] = [t, 0]
-        _lib.call("sarssl_zero_arena", _p(t), c_long(t.numel() * 8))
+        _lib.call("sarssl_ctx_zero_arena", c_void_p(_lib.ctx(device.index)), _p(t), c_long(t.numel() * 8))
     ent[0].zero_()
     ent[1] = 0
 
@@ -632,9 +632,14 @@ def conv3x3_fwd_c1(a0, W1, scale, shift, w_tap, want_stats=False):
     return (out, stats) if want_stats else out
 
 
+def conv_clock_probe(buf):
+    """Clock-probe buffer (int64[20] device tensor, or None) of the 3x3 forward / data-gradient launches of this thread's context."""
+    _lib.call("sarssl_ctx_set_clock_probe", c_void_p(_lib._make_current()), _p(buf))
+
+
 def conv_cus_override(ncus):
-    """Workgroup count of the 3x3 gradient launches that follow (0: the library's default rule)."""
-    _lib.call("sarssl_conv_cus_override", c_int(int(ncus)))
+    """Workgroup count of the 3x3 gradient launches issued under this thread's context (0: the library's default rule)."""
+    _lib.call("sarssl_ctx_set_conv_cus", c_void_p(_lib._make_current()), c_int(int(ncus)))
 
 
 def conv3x3_wgrad_c1(dy, a0, W1, scale, shift, acc_into):
@@ -1131,7 +1136,7 @@ def step_state_reset(st, lr, betas=(0.9, 0.999)):
 def step_state_attach(st):
     """While attached (st not None) every launch that draws dropout masks adds the state's salt to its seed: attach only around
     graph capture - the pointer is baked into the captured launches, eager launches afterwards run unsalted again."""
-    _lib.call("sarssl_step_state_attach", _p(st))
+    _lib.call("sarssl_ctx_attach_step_state", c_void_p(_lib._make_current()), _p(st))
 
 
 def step_tick(st):

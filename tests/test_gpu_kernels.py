@@ -428,6 +428,38 @@ def test_gradient_convolutions_do_not_depend_on_the_workgroup_count():
         assert _relerr(out[ncus][2], out[0][2]) < 1e-5
 
 
+def test_two_contexts_on_one_device_do_not_interfere():
+    """SURVEY.md 8(b) / round-3 verdict item 8: everything a caller configures lives in a sarssl_ctx (include/sarssl_hip.h) and kernels
+    run under the context current on the calling thread - no process-global setters.  Two contexts on this device: the gradient-launch
+    workgroup count and the attached step state (dropout salt) set on one are invisible under the other."""
+    from sar_ssl_amd import hip, _lib
+    dev = _dev()
+    lib = _lib.lib()
+    c1, c2 = _lib.ctx(dev.index), _lib.new_ctx(dev.index)
+    get = lambda c: int(lib.sarssl_ctx_get_conv_cus(_lib.c_void_p(c)))
+    st = hip.step_state_new(dev, 12345, 1e-3)
+    A, B = _mk((256, 128), torch.bfloat16, dev, 1), _mk((128, 128), torch.bfloat16, dev, 2)
+    drop = lambda: hip.gemm(A, B, M=256, N=128, K=128, lda=128, ldb=128, p_drop=0.5, seed=77).float().clone()
+    try:
+        assert c1 != c2 and int(lib.sarssl_ctx_device(_lib.c_void_p(c2))) == dev.index
+        hip.conv_cus_override(64)
+        y_plain = drop()
+        with _lib.use_ctx(c2):
+            assert get(c2) == 0
+            hip.conv_cus_override(32)
+            hip.step_state_attach(st)                   # only launches under c2 add the state's salt to their dropout seeds
+            y_salted = drop()
+        assert get(c1) == 64 and get(c2) == 32
+        assert torch.equal(drop(), y_plain) and not torch.equal(y_salted, y_plain)
+        with _lib.use_ctx(c2):
+            assert torch.equal(drop(), y_salted)
+            hip.step_state_attach(None)
+            assert torch.equal(drop(), y_plain)
+    finally:
+        hip.conv_cus_override(0)
+        _lib.destroy_ctx(c2)
+
+
 @pytest.mark.parametrize("B,F,T", [(2, 16, 8), (1, 24, 136), (3, 8, 64)])
 def test_conv3x3_dgrad_with_fused_bn_backward_sums(B, F, T):
     """The data-gradient launch that also accumulates the BatchNorm-backward sums of the layer in front must store exactly the
