@@ -194,7 +194,7 @@ def test_full_batch_captured_step_and_eval_forward_vs_the_reference_at_batch_64(
             check(tag + "diff", abs(d / float(z[mode + ".diff"]) - 1), 1e-4)
             err = (pred[torch.from_numpy(z[mode + ".pred_idx"])] - torch.from_numpy(z[mode + ".pred_vals"])).abs() / float(z[mode + ".pred_absmax"])
             # (max over 4 096 bins of 64 segments instead of F3's 2 048 of 2: the same per-bin class with a slightly longer tail)
-            check(tag + "pred_max", err.max().item(), 1.35 * gate["per_bin_max"])
+            check(tag + "pred_max", err.max().item(), gate["per_bin_max"] if prec == "fp16" else 1.35 * gate["per_bin_max"])
             check(tag + "pred_rms", err.pow(2).mean().sqrt().item(), gate["per_bin_rms"])
     finally:
         runtime.set_precision("bf16")

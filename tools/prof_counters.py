@@ -105,11 +105,11 @@ def aggregate(rows):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_kernel_counters.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_kernel_counters.json"))
     ap.add_argument("--build-marker", action="store_true", help="only compile tools/libprofmarker.so (no GPU needed) and exit")
     ap.add_argument("--only", default="")
     ap.add_argument("--passes", default="mfma,lds,fetch,write")
-    ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "pmc_r03"))
+    ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "pmc_r04"))
     args = ap.parse_args()
     build_marker()                                           # before any rocprofv3 pass starts the target
     if args.build_marker:
@@ -137,8 +137,19 @@ def main():
         e = {"tag": tag, "group": label, "kernel": kern, "launches": m["n"], "avg_us": round(dur / 1e3, 2)}
         if "GRBM_GUI_ACTIVE" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
             clk_cycles = m["GRBM_GUI_ACTIVE"] / 8.0
-            e["eff_clock_ghz"] = round(clk_cycles / max(m.get("mfma.dur_ns", dur * m["n"]) / m["n"], 1), 3)
-            e["mfma_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (NSIMD * clk_cycles), 4)
+            dur_mfma = max(m.get("mfma.dur_ns", dur * m["n"]) / m["n"], 1)              # ns per launch in the pass that read the counters
+            ghz = clk_cycles / dur_mfma
+            # GRBM_GUI_ACTIVE keeps counting around a launch (command processor, cache flushes): for launches shorter than ~100 us the
+            # clock derived from it came out at 3-15 GHz in round 3, and an MFMA-busy figure normalised by it is meaningless (verdict
+            # r03, weak #10).  Those launches - and any whose derived clock is implausible - are normalised by the kernel-trace duration
+            # at the NOMINAL 2.4 GHz instead: a lower bound of the pipe's busy fraction (the chip never clocks above nominal), flagged.
+            if dur_mfma < 100e3 or ghz > 2.5:
+                e["mfma_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (NSIMD * dur_mfma * 2.4), 4)
+                e["mfma_busy_basis"] = "kernel-trace duration x nominal 2.4 GHz (lower bound; GRBM-derived clock %.1f GHz rejected)" % ghz
+            else:
+                e["eff_clock_ghz"] = round(ghz, 3)
+                e["mfma_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (NSIMD * clk_cycles), 4)
+                e["mfma_busy_basis"] = "GRBM_GUI_ACTIVE / 8 (active cycles of the launch)"
         if "SQ_LDS_IDX_ACTIVE" in m:
             e["lds_conflict_rate"] = round(m["SQ_LDS_BANK_CONFLICT"] / max(m["SQ_LDS_IDX_ACTIVE"], 1), 4)
             wc = max(m.get("SQ_WAVE_CYCLES", 0), 1)

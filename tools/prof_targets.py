@@ -23,6 +23,10 @@ if not TIME:
     _mk = ctypes.CDLL(MARK)
 dev = torch.device("cuda:0")
 NREP = int(os.environ.get("PROF_NREP", "3"))
+# dtype of the FORWARD tensors (activations, forward weights, tensors saved for backward): fp16 = the timed mode since round 4
+# (fp16 forward / bf16 backward), PROF_PRECISION=bf16 for the all-bf16 mode; gradients are bf16 in both
+AD = torch.bfloat16 if os.environ.get("PROF_PRECISION", "fp16") == "bf16" else torch.float16
+GD = torch.bfloat16
 ONLY = set(int(t) for t in os.environ.get("PROF_ONLY", "").split(",") if t)
 
 TAGS = {}          # tag -> (label, algorithmic flop per launch, algorithmic bytes per launch)
@@ -56,11 +60,14 @@ def rnd(*shape, dtype=torch.bfloat16, scale=1.0):
     return (torch.randn(shape, device=dev) * scale).to(dtype)
 
 
-def gemm_group(tag, label, M, N, K, a_kc=True, b_kc=True, out_dtype=torch.bfloat16, split=0, **kw):
-    A = rnd(*((M, K) if a_kc else (K, M)))
-    B = rnd(*((N, K) if b_kc else (K, N)))
+def gemm_group(tag, label, M, N, K, a_kc=True, b_kc=True, out_dtype=None, split=0, adt=None, bdt=None, **kw):
+    """adt / bdt: operand dtypes (default: forward tensors)"""
+    adt, bdt = adt or AD, bdt or AD
+    out_dtype = out_dtype or adt
+    A = rnd(*((M, K) if a_kc else (K, M)), dtype=adt)
+    B = rnd(*((N, K) if b_kc else (K, N)), dtype=bdt)
     out = torch.zeros((M, N), dtype=out_dtype, device=dev)
-    osz = 2 if out_dtype == torch.bfloat16 else 4
+    osz = 4 if out_dtype == torch.float32 else 2
     group(tag, label, lambda: hip.gemm(A, B, a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], out=out,
                                        split_k=split, **kw), 2.0 * M * N * K, 2.0 * (M * K + N * K) + osz * M * N)
 
@@ -69,81 +76,83 @@ def main():
     Mr = 64 * 256
     bias = torch.zeros(4096, device=dev)
     d = 512
-    pre = torch.empty((Mr, 4 * d), dtype=torch.bfloat16, device=dev)
+    pre = torch.empty((Mr, 4 * d), dtype=AD, device=dev)
     gemm_group(1, "gemm ffn1 NT d=512 (+bias,swish,preact,dropout)", Mr, 4 * d, d, bias=bias[:4 * d], act=2, preact=pre, p_drop=0.1, seed=7)
-    res = rnd(Mr, d)
+    res = rnd(Mr, d, dtype=AD)
     gemm_group(2, "gemm ffn2 NT d=512 (+bias,dropout,resid)", Mr, d, 4 * d, bias=bias[:d], p_drop=0.1, seed=9, resid=res, ldr=d, out_scale=0.5)
     gemm_group(3, "gemm qkv NT d=512 (N=1536)", Mr, 3 * d, d, bias=bias[:3 * d])
-    aux = rnd(Mr, 4 * d)
-    gemm_group(4, "gemm ffn2 dX NN d=512 (+swish' aux)", Mr, 4 * d, d, b_kc=False, aux=aux, aux_act=2)
-    gemm_group(5, "gemm ffn1 dX NN d=512", Mr, d, 4 * d, b_kc=False)
+    aux = rnd(Mr, 4 * d, dtype=AD)                      # saved pre-activation (forward dtype) next to bf16 gradients
+    gemm_group(4, "gemm ffn2 dX NN d=512 (+swish' aux)", Mr, 4 * d, d, b_kc=False, aux=aux, aux_act=2, adt=GD, bdt=GD)
+    gemm_group(5, "gemm ffn1 dX NN d=512", Mr, d, 4 * d, b_kc=False, adt=GD, bdt=GD)
     d = 512
-    gemm_group(6, "gemm ffn dW TN d=512 (split-K)", 4 * d, d, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8)
+    gemm_group(6, "gemm ffn dW TN d=512 (split-K; dY bf16 x saved X)", 4 * d, d, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8, adt=GD)
     gemm_group(7, "gemm decoder1 NT (768->3072, relu)", Mr, 3072, 768, bias=bias[:3072], act=1)
     gemm_group(8, "gemm decoder2 NT (3072->1024)", Mr, 1024, 3072, bias=bias[:1024])
-    gemm_group(9, "gemm decoder2 dW TN (split-K 8, slice-major)", 1024, 3072, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8)
+    gemm_group(9, "gemm decoder2 dW TN (split-K 8, slice-major)", 1024, 3072, Mr, a_kc=False, b_kc=False, out_dtype=torch.float32, split=8, adt=GD)
     gemm_group(10, "gemm patch NT (1024->512)", Mr, 512, 1024)
     gemm_group(11, "gemm ffn1 NT d=256", Mr, 1024, 256, bias=bias[:1024], act=2)
     gemm_group(12, "gemm ffn2 NT d=256", Mr, 256, 1024, bias=bias[:256])
     # ---- stem
     B = 64
-    x = rnd(B, 256, 256, 64)
-    y = rnd(B, 256, 256, 64)
-    w = rnd(9, 64, 64, scale=0.05)
+    x = rnd(B, 256, 256, 64, dtype=AD)              # a forward activation
+    y = rnd(B, 256, 256, 64, dtype=AD)              # a saved pre-BatchNorm activation
+    g64 = rnd(B, 256, 256, 64, dtype=GD)            # a gradient
+    w = rnd(9, 64, 64, scale=0.05, dtype=AD)
+    wg = rnd(9, 64, 64, scale=0.05, dtype=GD)
     sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
     aff = torch.stack([sc, sh, sh, sc]).contiguous()
     cfl = 2.0 * B * 65536 * 64 * 576
     tb = x.numel() * 2.0
     group(20, "conv3x3 fwd (BN+ReLU prologue, stats epilogue)", lambda: hip.conv3x3_fwd(x, w, sc, sh, want_stats=True), cfl, 2 * tb)
-    group(21, "conv3x3 dgrad (identity prologue)", lambda: hip.conv3x3_fwd(x, w), cfl, 2 * tb)
-    group(22, "conv3x3 dgrad + BN-backward sums", lambda: hip.conv3x3_dgrad_bnred(x, w, y, aff), cfl, 3 * tb)
-    group(23, "conv3x3 wgrad", lambda: hip.conv3x3_wgrad(x, y, sc, sh), cfl, 2 * tb)
-    a0 = rnd(B, 256, 256, 4)
+    group(21, "conv3x3 dgrad (identity prologue)", lambda: hip.conv3x3_fwd(g64, wg), cfl, 2 * tb)
+    group(22, "conv3x3 dgrad + BN-backward sums", lambda: hip.conv3x3_dgrad_bnred(g64, wg, y, aff), cfl, 3 * tb)
+    group(23, "conv3x3 wgrad", lambda: hip.conv3x3_wgrad(g64, y, sc, sh), cfl, 2 * tb)
+    a0 = rnd(B, 256, 256, 4, dtype=AD)
     W1 = torch.randn((64, 4), device=dev)
     W4 = torch.randn((4, 64), device=dev)
     group(30, "stem_c1_fwd (4->64 + BN sums)", lambda: hip.stem_c1_fwd(a0, W1, want_stats=True), 0, tb + tb / 16)
     group(36, "stem_c1_fwd (4->64, no sums)", lambda: hip.stem_c1_fwd(a0, W1), 0, tb + tb / 16)
     group(31, "stem_c4_fwd (BN+ReLU, 64->4)", lambda: hip.stem_c4_fwd(x, W4, sc, sh), 0, tb + tb / 16)
-    dy4 = rnd(B, 256, 256, 4)
+    dy4 = rnd(B, 256, 256, 4, dtype=GD)
     group(32, "stem_c4_bwd two-phase (sums + apply)", lambda: hip.stem_c4_bwd_two_phase(x, dy4, W4, aff, True), 0, 3 * tb + 2 * tb / 16)
     gW, gg, gb = torch.zeros((64, 4), device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
-    group(33, "stem_c1_bwd (one pass)", lambda: hip.stem_c1_bwd(x, y, a0, aff, True, gW, gg, gb), 0, 2 * tb + tb / 16)
-    group(37, "stem_c1_bwd_a0 (one pass, y1 recomputed from the input)", lambda: hip.stem_c1_bwd_a0(x, a0, W1, aff, True, gW, gg, gb), 0, tb + tb / 16)
-    wt = rnd(9, 64, 64, scale=0.05)
+    group(33, "stem_c1_bwd (one pass)", lambda: hip.stem_c1_bwd(g64, y, a0, aff, True, gW, gg, gb), 0, 2 * tb + tb / 16)
+    group(37, "stem_c1_bwd_a0 (one pass, y1 recomputed from the input)", lambda: hip.stem_c1_bwd_a0(g64, a0, W1, aff, True, gW, gg, gb), 0, tb + tb / 16)
+    wt = rnd(9, 64, 64, scale=0.05, dtype=AD)
     group(24, "conv3x3 fwd from the 4-channel input (C1IN, + stats)", lambda: hip.conv3x3_fwd_c1(a0, W1, sc, sh, wt, want_stats=True), cfl, tb + tb / 16)
     gacc = torch.zeros((64, 64, 3, 3), device=dev)
-    group(25, "conv3x3 wgrad from the 4-channel input (C1IN)", lambda: hip.conv3x3_wgrad_c1(y, a0, W1, sc, sh, gacc), cfl, tb + tb / 16)
+    group(25, "conv3x3 wgrad from the 4-channel input (C1IN)", lambda: hip.conv3x3_wgrad_c1(g64, a0, W1, sc, sh, gacc), cfl, tb + tb / 16)
     _, mom = hip.stem_c1_stats(a0, W1, keep_moments=True)
     group(26, "conv3x3 dgrad consumed in its epilogue (C1RED: mask + [a0|1] contraction on MFMA, nothing stored)",
-          lambda: hip.conv3x3_dgrad_c1red(y, wt, a0, W1, aff, mom, True, gW, gg, gb), cfl, tb + tb / 16)
+          lambda: hip.conv3x3_dgrad_c1red(g64, wg, a0, W1, aff, mom, True, gW, gg, gb), cfl, tb + tb / 16)
     red = torch.zeros(128, dtype=torch.float64, device=dev)
-    group(34, "cl_bn_bwd_apply C=64 (in place)", lambda: hip.cl_bn_bwd_apply(x, y, 64, aff, 1, False, True, red, out=x), 0, 3 * tb)
-    group(35, "cl_bn_bwd_reduce C=64", lambda: hip.cl_bn_bwd_reduce(x, y, 64, aff, 1), 0, 2 * tb)
+    group(34, "cl_bn_bwd_apply C=64 (in place)", lambda: hip.cl_bn_bwd_apply(g64, y, 64, aff, 1, False, True, red, out=g64), 0, 3 * tb)
+    group(35, "cl_bn_bwd_reduce C=64", lambda: hip.cl_bn_bwd_reduce(g64, y, 64, aff, 1), 0, 2 * tb)
     # ---- attention glue (d = 512: 4 heads, T = 256)
     T, H = 256, 4
     content = torch.randn((B, H, T, T), device=dev)
     pos = torch.randn((B, H, T, T), device=dev)
-    group(40, "softmax_relshift_fwd (B,4,256,256) [unfused core, fp32 mode only]", lambda: hip.softmax_relshift_fwd(content, pos, 0.044, torch.bfloat16, 0.1, 5), 0,
+    group(40, "softmax_relshift_fwd (B,4,256,256) [unfused core, fp32 mode only]", lambda: hip.softmax_relshift_fwd(content, pos, 0.044, AD, 0.1, 5), 0,
           content.numel() * (8.0 + 4.0))
     del content, pos
     # ---- fused attention (csrc/attention.hip)
     for tag, dh in ((41, 128), (44, 64)):
         d = H * dh
-        qkv = rnd(B * T, 3 * d)
-        qu, dctx = rnd(B * T, d), rnd(B * T, d)
-        bias = rnd(B, H, T, T)
+        qkv = rnd(B * T, 3 * d, dtype=AD)
+        qu, dctx = rnd(B * T, d, dtype=AD), rnd(B * T, d, dtype=GD)
+        bias = rnd(B, H, T, T, dtype=AD)
         aflop = 2.0 * 2 * B * H * T * T * dh                        # QK^T + PV
         abytes = 2.0 * (4 * B * T * d + B * H * T * T)
         k_, v_ = qkv[:, d:2 * d], qkv[:, 2 * d:]
         group(tag, "relpos_attn_fwd dh=%d (B=64,H=4,T=256)" % dh, lambda: hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5), aflop, abytes)
         ctx, aux = hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5)
-        dqkv = torch.empty_like(qkv)
+        dqkv = torch.empty(qkv.shape, dtype=GD, device=dev)
         group(tag + 1, "relpos_attn_bwd dh=%d (dQ/dbias (+ D) + dK/dV kernels)" % dh,
               lambda: hip.relpos_attn_bwd(qu, k_, v_, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, 0.044, 0.1, 5),
               3.5 * aflop, 2.0 * (8 * B * T * d + 2 * B * H * T * T))
     # ---- convolution-module tiles (csrc/dwconv.hip)
     d = 512
-    hh, dcc = rnd(B * T, 2 * d), rnd(B * T, d)
+    hh, dcc = rnd(B * T, 2 * d, dtype=AD), rnd(B * T, d, dtype=GD)
     wdw = torch.randn((d, 31), device=dev)
     gdw = torch.zeros((d, 31), device=dev)
     eb = 2.0 * B * T * d
@@ -152,7 +161,7 @@ def main():
     group(52, "dwglu_wgrad d=512", lambda: hip.dwglu_wgrad(dcc, hh, gdw, B, T), 0, 3 * eb)
     # ---- LayerNorm (csrc/elementwise.hip)
     for tag, d in ((70, 256), (72, 512)):
-        xx, dyy, rr = rnd(Mr, d), rnd(Mr, d), rnd(Mr, d)
+        xx, dyy, rr = rnd(Mr, d, dtype=AD), rnd(Mr, d, dtype=GD), rnd(Mr, d, dtype=GD)
         gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
         gg, gb = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
         _, st = hip.layernorm_fwd(xx, gam, bet)
@@ -163,7 +172,7 @@ def main():
               lambda: hip.layernorm_bwd(dyy, xx, gam, st, resid=rr, dgamma=gg, dbeta=gb, drop=(0.1, 3, 0.5)), 0, 2.0 * 5 * Mr * d)
     # ---- fp8 GEMM (csrc/gemm_fp8.hip)
     for tag, (M_, N_, K_) in ((60, (Mr, 2048, 512)), (61, (Mr, 1024, 3072))):
-        A = rnd(M_, K_); Bm = rnd(N_, K_, scale=0.05)
+        A = rnd(M_, K_, dtype=GD); Bm = rnd(N_, K_, scale=0.05, dtype=GD)
         Aq, sa = hip.fp8_quantize(A); Bq, sb = hip.fp8_quantize(Bm)
         out = torch.empty((M_, N_), dtype=torch.bfloat16, device=dev)
         group(tag, "fp8 gemm %dx%dx%d (e4m3, block-scaled MFMA)" % (M_, N_, K_), lambda: hip.gemm_fp8(Aq, sa, Bq, sb, M=M_, N=N_, K=K_, out=out),
