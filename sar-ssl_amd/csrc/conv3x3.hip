@@ -56,7 +56,7 @@ struct ConvArgs {
     const void* c1_a0; double* c1_red;
     // optional clock probe (sarssl_conv_clock_probe): thread 0 of workgroup 0 stores {s_memtime, s_memrealtime} at kernel entry and
     // exit - shader-clock ticks over constant-rate ticks = the effective shader clock this launch ran at (bench.py reports it next to
-    // the launch durations: the chip clocks down under matrix load)
+    // the launch durations: the chip clocks down under matrix load, NOTES.md 6)
     unsigned long long* clk;
 #ifdef CONV_STAMPS
     unsigned long long* stamps;
@@ -1838,7 +1838,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Workgroups of the persistent convolution launches.  kind 0 = forward launches, 1 = data / weight gradients.  One per CU, or
 // SARSSL_CONV_CUS[_FWD | _BWD] of them: a convolution workgroup takes a CU's whole LDS and nearly all of its registers, so while a
 // launch covers every CU the other encoder's stream stands still; a launch that leaves an eighth of the CUs free lets that stream's
-// short latency-bound kernels run next to it (measured on the step).  The grid is then trimmed so that the last
+// short latency-bound kernels run next to it (measured on the step, see NOTES.md 4.7).  The grid is then trimmed so that the last
 // round of tiles is as full as the others (a multiple of 8 keeps the XCD-aware tile order).
 // Per-context override of the workgroup count of the gradient launches (0 = the default rule below): the engine uses it to give the
 // stem backward that runs LAST - alone on the chip, the other encoder's stream has drained - all CUs (sarssl_ctx_set_conv_cus).

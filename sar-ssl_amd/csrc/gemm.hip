@@ -99,7 +99,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     constexpr int PC = BN + 4;                                  // f32 staging pitch of the epilogue (conflict-free 16-byte LDS writes)
     constexpr int EPI_ELEMS = 64 * PC * 2;                      // 64 x 132 f32, in 16-bit units
     constexpr int LDS_ELEMS = STAGE > EPI_ELEMS ? STAGE : EPI_ELEMS;      // (a double-buffered variant - two LDS stages, two register
-                                                                           //  stages - measured neutral inside the step: DESIGN.md 4.2)
+                                                                           //  stages - measured neutral inside the step: NOTES.md 4.2)
     __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];    // FM = 2: 2 x 32-37 KiB (2 workgroups / CU), FM = 4: 56 KiB (2 / CU)
     uint16_t* sA = smem;
     uint16_t* sB = smem + A_ELEMS;

@@ -233,7 +233,7 @@ def stem_fwd(a0, pe, train, saved):
     return e
 
 
-# A/B switches of the round-2 work-removal passes; bench.py prints their resolved state.  The paths measured
+# A/B switches of the round-2 work-removal passes (NOTES.md 4.1a / 4.6); bench.py prints their resolved state.  The paths measured
 # slower in round 2 (BatchNorm-backward transform inside the convolution staging, consumer-side BatchNorm finalize, one-pass 64->4
 # backward, the separate / half-fused first-layer backward) were removed from the engine in round 3.
 _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"

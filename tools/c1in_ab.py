@@ -1,4 +1,4 @@
-"""Model-level A/B of engine._C1IN / _C1RED: same weights / masks, dropout off; loss, gradients and BatchNorm running
+"""Model-level A/B of engine._C1IN / _C1RED (NOTES.md 4.1a): same weights / masks, dropout off; loss, gradients and BatchNorm running
 statistics with and without the stored first-layer tensors, next to the run-to-run noise of the stored path itself."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

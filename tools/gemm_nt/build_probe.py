@@ -1,6 +1,6 @@
 """Probe copy of the library with the direct-to-LDS pipelined NT GEMM (tools/gemm_nt/gemm_nt.hip) linked in and dispatched from sarssl_gemm
 (-DSARSSL_WITH_GEMM_NT; SARSSL_GEMM_NT=0 switches it off again, SARSSL_GEMM_NT_CFG=<n> forces one tile configuration) - round-3 experiment,
-not part of the product library.  hipcc 7.2 note: simplifycfg segfaults when it sinks "common" instructions out of branches
+not part of the product library (NOTES.md 4.2).  hipcc 7.2 note: simplifycfg segfaults when it sinks "common" instructions out of branches
 that hold the LDS-DMA intrinsic (llvm.amdgcn.raw.ptr.buffer.load.lds has immediate operands): -mllvm -simplifycfg-sink-common=false."""
 import os
 import subprocess

@@ -1,6 +1,6 @@
 """Library yardstick (torch.matmul -> hipBLASLt) for the hot GEMM shapes of the step at M = 16384: forward NT, dX NN and dW TN products.
 Not part of the product path (the step runs csrc/gemm.hip); used to judge how far the hand-written kernel is from the library on the plain
-large shapes (library 1.3-1.45x faster on forward / dX, 1.5-3x slower on the weight gradients)."""
+large shapes (NOTES.md 7: library 1.3-1.45x faster on forward / dX, 1.5-3x slower on the weight gradients)."""
 import torch
 dev = "cuda"
 def t(fn, n=30):

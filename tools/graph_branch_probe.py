@@ -1,7 +1,7 @@
 """Does a replayed HIP graph run forked branches concurrently?  Two chains of sleep kernels (100-300 nodes each) forked off one
 root node, captured in different host orders; replay time in units of one sleep.  ROCm 7.2 on MI355X: yes, in every capture order
 (206 node times for two 200-node branches) - the little overlap between the two encoder branches of the captured training step
- is a matter of resources (LDS / registers of the persistent convolution kernels), not of the graph runtime."""
+(NOTES.md 4.7) is a matter of resources (LDS / registers of the persistent convolution kernels), not of the graph runtime."""
 import sys, time, torch
 dev = torch.device("cuda:0")
 def run(mode, NA, NB, CY, root=1):

@@ -1,5 +1,5 @@
 """Yardstick for the HBM-bound passes: what torch's own streaming kernels reach on 537 MB tensors on this part (pure read, pure
-write, read + write mixes).  MI355X: pure write 6.5 TB/s, mixes 5.8-6.1 TB/s, a single sequential read stream 3.4-3.9 TB/s."""
+write, read + write mixes).  MI355X: pure write 6.5 TB/s, mixes 5.8-6.1 TB/s, a single sequential read stream 3.4-3.9 TB/s (NOTES.md 4.6)."""
 import torch
 a = torch.randn(268435456 // 2, device="cuda").bfloat16().repeat(2)
 b = torch.empty_like(a)

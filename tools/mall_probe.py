@@ -1,5 +1,5 @@
 """Does the 256 MB Infinity Cache speed up producer -> consumer chains of HBM-bound passes?  A 3-pass elementwise chain over 537 MB
-tensors, whole or cut into chunks that fit the cache.  MI355X: +10 % at 134 MB chunks, lost again to launch overhead below."""
+tensors, whole or cut into chunks that fit the cache.  MI355X: +10 % at 134 MB chunks, lost again to launch overhead below (NOTES.md 4.6)."""
 import torch, time
 dev = torch.device("cuda:0")
 N = 64 * 256 * 256 * 64          # bf16 elements: 537 MB
