@@ -397,7 +397,7 @@ def main():
                 if "conv" in k:
                     print("prof", k, prof[k][0], round(prof[k][1] / max(prof[k][0], 1), 4), file=sys.stderr)
         traffic, mfma_busy, pmc_file = None, None, None  # per launch, from the committed PMC passes (same kernel, same shape; tools/prof_counters.py)
-        for name in ("r03_kernel_counters.json", "r02_kernel_counters.json"):
+        for name in ("r04_kernel_counters.json", "r03_kernel_counters.json", "r02_kernel_counters.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if traffic is None and args.workload == "config2" and batch == 64 and os.path.exists(pmc):
                 for e in json.load(open(pmc)).get("kernels", []):
