@@ -114,6 +114,14 @@ int sarssl_relpos_attn_supported(int T, int dh);
 int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, void* ctx, long ldc,
                            float* ctx32, float* lse, int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed,
                            int dtype, void* stream);      /* dtype of qu / k / v / bias / ctx: bf16 | fp16 */
+/* The same forward with the shifted positional score formed INSIDE the kernel (attention.py:87-89 and the pad-and-reshape shift of
+ * :105-113 fused into the score): qv = q + v_bias [B*T][ldq], pos = positional projection [T][ldp], head h at column h*dh.  bias_out
+ * (optional, (B,H,T,T)): the shifted score as the kernel used it, for sarssl_relpos_attn_bwd.  sarssl_relpos_attn_pos_supported:
+ * T <= 256 (the score tile of 128 query rows lives in LDS), T % 8 == 0. */
+int sarssl_relpos_attn_pos_supported(int T, int dh);
+int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos, long ldp,
+                               void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh, float scale,
+                               float p_drop, unsigned long long seed, int dtype, void* stream);
 int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, const float* ctx32,
                            const float* lse, const void* dctx, long lddc, void* dqu, long lddq, void* dk, void* dv,
                            long lddk, void* dbias, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,

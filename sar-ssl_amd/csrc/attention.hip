@@ -33,6 +33,10 @@ struct AttnArgs {
     h16* dk; h16* dv; long lddk;
     h16* dbias;                        // (B,H,T,T): gradient of the shifted positional score (bf16)
     float* dsum;                       // (B,H,T): D_i = sum_c dctx * ctx, written by the dQ kernel, read by the dK / dV kernel
+    // positional score computed in the kernel (relpos_attn_fwd_kernel<.., POS>): qv = q + v_bias [B*T][ldq], pos = the positional
+    // projection [T][ldp] (head h at column h*DH, shared by the batch); bias_out (optional): the (B,H,T,T) shifted score the kernel
+    // formed, for backward kernels that still read it
+    const h16* qv; const h16* pos; long ldp; h16* bias_out;
     int B, H, T;
     float scale, p_drop; unsigned long long seed;
     const unsigned long long* salt;    // device-resident addend of the seed (graph replay), or null
@@ -117,10 +121,19 @@ struct AttnDrop {
 // ------------------------------------------------------------------------------------------------------------------- forward
 // (d_head <= 64: capped at 256 registers - 243 used, no spills - so that TWO workgroups share a CU: the kernel is a chain of
 //  latencies (K / V / bias tiles, softmax exchanges) and ran one wave per SIMD at 263 registers)
-template <int DH, typename TA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
+// POS (round 4; T <= 256): the shifted positional score is not read from memory but formed here, on the matrix cores, before the key
+// loop.  The reference's pad-and-reshape shift (attention.py:105-113) is a bijection of the unshifted product R[r][m] = (q_r + v) . p_m:
+//     bias[i][j] = R[i][T-1-i+j]   for j <= i,      0 for j = i+1,      R[i+1][j-i-2]   for j >= i+2
+// so a query tile needs R of its rows (the "low" part) and of its rows + 1 (the "up" part) against all T positions: the position
+// tiles stream through the K buffer like key tiles, S'^T = P Q^T puts the query row on the lane as for the content score, and every
+// value is scattered to its shifted column of a [128][T] LDS tile (2-byte stores) that the key loop then reads in place of the staged
+// bias tile.  Per wave and position tile only the part that can be valid for its 32 rows is computed.  What this removes per layer: the
+// batched positional-score GEMM launch (K = d_head: 53 us for a 33 MB output written element by element in the shifted layout) and
+// the kernel's own 33 MB bias read.
+template <int DH, typename TA, bool POS = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 && !POS) ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
-    constexpr int PK = DH + 8, PV = DH + 32, PB = TK + 8;
+    constexpr int PK = DH + 8, PV = DH + 32, PB = POS ? (256 + 8) : (TK + 8);
     constexpr int CPR = DH / 8;                               // 16-byte chunks per K / V row
     __shared__ __attribute__((aligned(16))) uint16_t smem[TK * PK + TK * PV + TQ * PB];
     uint16_t* sK = smem;
@@ -169,14 +182,80 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                 rv[c] = *(const uint4*)(V + (long)(j0 + row) * a.ldk + c8 * 8);
             }
         }
+        if constexpr (!POS) {
 #pragma unroll
-        for (int c = 0; c < NBI; ++c) {
-            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
-            rbi[c] = make_uint4(0, 0, 0, 0);
-            if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
+            for (int c = 0; c < NBI; ++c) {
+                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+                rbi[c] = make_uint4(0, 0, 0, 0);
+                if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
+            }
         }
     };
     load_tile(0);
+    if constexpr (POS) {
+        const h16* Pm = a.pos + h * DH;
+        const int il = wave * 32 + (lane & 31), r0 = i0 + wave * 32;
+        bf16x8 fqv[DH / 16], fqvn[DH / 16];
+        {
+            const bool nx = row_ok && (i + 1 < T);
+            const h16* q0 = a.qv + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
+#pragma unroll
+            for (int s = 0; s < DH / 16; ++s) {
+                fqv[s] = __builtin_bit_cast(bf16x8, row_ok ? *(const uint4*)(q0 + s * 16) : make_uint4(0, 0, 0, 0));
+                fqvn[s] = __builtin_bit_cast(bf16x8, nx ? *(const uint4*)(q0 + a.ldq + s * 16) : make_uint4(0, 0, 0, 0));
+            }
+        }
+        if (half == 0 && row_ok && i + 1 < T) sB[il * PB + i + 1] = 0;          // the zero of the padding column (masked in the key loop anyway)
+        for (int mb = 0; mb < T; mb += TK) {
+#pragma unroll
+            for (int c = 0; c < NKV; ++c) {
+                const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+                *(uint4*)&sK[row * PK + c8 * 8] = (mb + row < T) ? *(const uint4*)(Pm + (long)(mb + row) * a.ldp + c8 * 8) : make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();
+            // wave-uniform: can any of this wave's rows r0 .. r0+31 have a valid entry in positions mb .. mb+63 ?
+            const bool need_low = (mb + TK - 1) >= (T - 1 - (r0 + 31));         // low: m >= T-1-i
+            const bool need_up = mb <= (T - 3 - r0);                            // up:  m <= T-3-i
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                if (part == 0 ? !need_low : !need_up) continue;
+                f32x16 s[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
+#pragma unroll
+                for (int st = 0; st < DH / 16; ++st)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const bf16x8 pf = *(const bf16x8*)&sK[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                        s[f] = mfma16<TA>(pf, part == 0 ? fqv[st] : fqvn[st], s[f]);
+                    }
+                if (row_ok) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int m = mb + f * 32 + 8 * g + 4 * half + e;
+                                const uint16_t bits = (uint16_t)(H16<TA>::pack(s[f][4 * g + e], 0.f) & 0xffffu);
+                                if (part == 0) { if (m < T && m >= T - 1 - i) sB[il * PB + (m - (T - 1) + i)] = bits; }
+                                else { if (m <= T - 3 - i) sB[il * PB + (m + i + 2)] = bits; }
+                            }
+                }
+            }
+            __syncthreads();
+        }
+        if (a.bias_out) {                                                       // (T % 8 == 0, T <= 256)
+            h16* Bo = a.bias_out + (long)bh * T * T;
+            const int cpr = T >> 3;
+            for (int cid = tid; cid < TQ * cpr; cid += 256) {
+                const int row = cid / cpr, c8 = cid - row * cpr;
+                if (i0 + row < T) *(uint4*)(Bo + (long)(i0 + row) * T + c8 * 8) = *(const uint4*)&sB[row * PB + c8 * 8];
+            }
+        }
+    }
     for (int j0 = 0; j0 < T; j0 += TK) {
 #pragma unroll
         for (int c = 0; c < NKV; ++c) {
@@ -184,10 +263,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
             *(uint4*)&sK[row * PK + c8 * 8] = rk[c];
             *(uint4*)&sV[row * PV + c8 * 8] = rv[c];
         }
+        if constexpr (!POS) {
 #pragma unroll
-        for (int c = 0; c < NBI; ++c) {
-            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
-            *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
+            for (int c = 0; c < NBI; ++c) {
+                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+                *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
+            }
         }
         __syncthreads();
         if (j0 + TK < T) load_tile(j0 + TK);
@@ -211,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int jl = f * 32 + 8 * g + 4 * half;
-                const uint2 bu = *(const uint2*)&sB[(wave * 32 + (lane & 31)) * PB + jl];
+                const uint2 bu = *(const uint2*)&sB[(wave * 32 + (lane & 31)) * PB + (POS ? j0 : 0) + jl];
                 const float bv[4] = {H16<TA>::lo(bu.x), H16<TA>::hi(bu.x), H16<TA>::lo(bu.y), H16<TA>::hi(bu.y)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -636,6 +717,35 @@ extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, c
         else relpos_attn_fwd_kernel<32, bf16><<<grid, 256, 0, st>>>(a);
     }
     SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel");
+    return 0;
+}
+
+// The same forward with the shifted positional score formed inside the kernel (attention.py:87-89 + 105-113 fused): qv = q + v_bias
+// [B*T][ldq], pos = positional projection [T][ldp] (head h at column h*dh).  bias_out (optional, (B,H,T,T)) receives the shifted score
+// for backward kernels that read it.  T <= 256, T % 8 == 0 (sarssl_relpos_attn_pos_supported).
+extern "C" int sarssl_relpos_attn_pos_supported(int T, int dh) { return (T > 0 && T <= 256 && T % 8 == 0 && (dh == 32 || dh == 64 || dh == 128)) ? 1 : 0; }
+extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
+                                          long ldp, void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh,
+                                          float scale, float p_drop, unsigned long long seed, int dtype, void* stream) {
+    if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_fwd_pos")) return -1;
+    SARSSL_REQUIRE(sarssl_relpos_attn_pos_supported(T, dh) && ldp % 8 == 0 && qv && pos, "sarssl_relpos_attn_fwd_pos(T <= 256)");
+    SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr && (dtype == SARSSL_BF16 || dtype == SARSSL_F16), "sarssl_relpos_attn_fwd_pos");
+    AttnArgs a = {};
+    a.qu = (const h16*)qu; a.qv = (const h16*)qv; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk;
+    a.pos = (const h16*)pos; a.ldp = ldp; a.bias_out = (h16*)bias_out;
+    a.ctx = (h16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
+    dim3 grid((T + 127) / 128, B * H);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SARSSL_F16) {
+        if (dh == 128) relpos_attn_fwd_kernel<128, f16, true><<<grid, 256, 0, st>>>(a);
+        else if (dh == 64) relpos_attn_fwd_kernel<64, f16, true><<<grid, 256, 0, st>>>(a);
+        else relpos_attn_fwd_kernel<32, f16, true><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (dh == 128) relpos_attn_fwd_kernel<128, bf16, true><<<grid, 256, 0, st>>>(a);
+        else if (dh == 64) relpos_attn_fwd_kernel<64, bf16, true><<<grid, 256, 0, st>>>(a);
+        else relpos_attn_fwd_kernel<32, bf16, true><<<grid, 256, 0, st>>>(a);
+    }
+    SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel<pos>");
     return 0;
 }
 

@@ -239,6 +239,7 @@ def stem_fwd(a0, pe, train, saved):
 _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
 _DWGLU = os.environ.get("SARSSL_DWGLU", "1") != "0"             # 0: separate glu / dwconv / cl_stats kernels (A/B runs)
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
+_ATTN_POS = os.environ.get("SARSSL_ATTN_POS", "1") != "0"       # 0: positional score by its own GEMM launch instead of inside the attention kernel (A/B runs)
 _C1IN = os.environ.get("SARSSL_C1IN", "1") != "0"             # 0: store the first layer's 64-channel output (A/B runs)
 _C1RED = os.environ.get("SARSSL_C1RED", "1") != "0"           # 0: store the gradient w.r.t. that output and reduce it in a pass of its own
 
@@ -460,10 +461,14 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     if _FUSED_ATTN and not replay and hip.relpos_attn_supported(T, dh, RT.dtype):
         # fused path (csrc/attention.hip): the positional-score GEMM writes its product directly in the relative-shift layout and
         # one flash-style kernel does content score + shifted bias + softmax + dropout + PV; no (B,H,T,T) score / probability tensor
-        bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
-        hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
-                 sC=(H * T * T, T * T), c_row_shift=True)
-        ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)   # lse = (ctx32, lse)
+        if _ATTN_POS and hip.relpos_attn_pos_supported(T, dh, RT.dtype):
+            # T <= 256: the kernel forms the shifted positional score itself (position tiles stream through its K buffer)
+            ctx, lse, bias = hip.relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)
+        else:
+            bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
+            hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
+                     sC=(H * T * T, T * T), c_row_shift=True)
+            ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)   # lse = (ctx32, lse)
         po = _p(mod.dropout, train)
         so = RT.next_seed() if po > 0 else 0
         y = mm_nt(ctx, wt(att.out_proj.linear.weight), bias=att.out_proj.linear.bias.data, p_drop=po, seed=so,

@@ -178,6 +178,7 @@ def test_backward_stage_hooks_fire_before_the_stem_backward(monkeypatch):
     monkeypatch.setattr(engine, "stem_bwd", lambda d, pe, saved: log.append("stem"))
     monkeypatch.setattr(engine, "decoder_bwd", lambda d, dec, saved, after_dx=None: (log.append("decoder"), torch.zeros(16, 768))[1])
     monkeypatch.setattr(hip, "masked_mse_bwd", lambda *a, **k: torch.zeros(1))
+    monkeypatch.setattr(hip, "conv_cus_override", lambda n: log.append("cus") if n else None)     # (a per-context knob: needs a device)
     monkeypatch.setattr(net, "_side_stream", lambda dev: None)
     red = sdist.FlatGradAllReduce(net, flat)
     inner = net._stage_hook
@@ -185,5 +186,5 @@ def test_backward_stage_hooks_fire_before_the_stem_backward(monkeypatch):
     ctx = types.SimpleNamespace(net=net, saved=[[]], aux=(None, torch.zeros(2, 2, 16, 8, 2), None, None, 4, 512), nparams=0)
     model._PretrainFn.backward(ctx, torch.ones(()), None, None)
     assert log == ["decoder", "hook:decoder", "block", "block", "block", "block", "patch", "hook:spat_encoder", "patch",
-                   "hook:spec_encoder", "hook:stem_bwd_begin", "stem", "stem", "hook:stems"]
+                   "hook:spec_encoder", "hook:stem_bwd_begin", "cus", "stem", "cus", "stem", "hook:stems"]
     assert red.order == ["decoder", "spat_encoder", "spec_encoder", "stems"]

@@ -838,6 +838,19 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
     lse = aux[1]
     ctx2, _ = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, seed)
     assert torch.equal(ctx, ctx2)
+    if hip.relpos_attn_pos_supported(T, dh, adt):
+        # the forward that forms the shifted positional score inside the kernel (T <= 256): the same MFMA products in the same
+        # order as the GEMM, so the score tile, the output and the log-sum-exp are the two-launch path's bit for bit
+        ctx_p, aux_p, bias_p = hip.relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop, seed)
+        bp = bias_p.double()
+        bp[:, :, ii, ii + 1] = 0.0
+        check("attn.pos_in_kernel.bias", _relerr(bp, want_bias), ftol)
+        assert torch.equal(bp, got_bias), (bp - got_bias).abs().max().item()
+        assert torch.equal(ctx_p, ctx) and torch.equal(aux_p[0], aux[0]) and torch.equal(aux_p[1], aux[1])
+        ctx_i, _, none_bias = hip.relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop, seed, need_bwd=False)
+        assert none_bias is None and torch.equal(ctx_i, ctx)
+    else:
+        assert T > 256
     keep = torch.ones((B, H, T, T), dtype=torch.float64, device=dev)
     if p_drop > 0:
         mask = _attn_mask(B, H, T, dh, p_drop, seed, dev)
