@@ -37,6 +37,11 @@ struct AttnArgs {
     // projection [T][ldp] (head h at column h*DH, shared by the batch); bias_out (optional): the (B,H,T,T) shifted score the kernel
     // formed, for backward kernels that still read it
     const h16* qv; const h16* pos; long ldp; h16* bias_out;
+    // backward with the positional-score gradients formed in the dQ kernel (relpos_attn_bwd_q_kernel<.., POS>): dqv [B*T][lddqv] =
+    // gradient of q + v_bias through the positional score; dpos_part (B, ntile, T, H*DH) bf16: per (batch item, query tile) partial
+    // gradient of the positional projection; dqv_fix f32 (B*H, ntile, 2, DH): the two halves of the one row per tile boundary whose
+    // gradient comes from two workgroups (summed and rounded once by the dK / dV kernel that follows)
+    h16* dqv; long lddqv; h16* dpos_part; float* dqv_fix;
     int B, H, T;
     float scale, p_drop; unsigned long long seed;
     const unsigned long long* salt;    // device-resident addend of the seed (graph replay), or null
@@ -133,7 +138,11 @@ struct AttnDrop {
 template <int DH, typename TA, bool POS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 && !POS) ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
+#ifdef ATTN_EXP_1WG
+    constexpr int PK = DH + 8, PV = DH + 32, PB = 256 + 8;
+#else
     constexpr int PK = DH + 8, PV = DH + 32, PB = POS ? (256 + 8) : (TK + 8);
+#endif
     constexpr int CPR = DH / 8;                               // 16-byte chunks per K / V row
     __shared__ __attribute__((aligned(16))) uint16_t smem[TK * PK + TK * PV + TQ * PB];
     uint16_t* sK = smem;
@@ -191,9 +200,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
             }
         }
     };
-    load_tile(0);
+    uint4 rp[POS ? CPR : 1];                                  // POS: the head's whole positional projection (T <= 256 rows), one request burst
     if constexpr (POS) {
         const h16* Pm = a.pos + h * DH;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            const int row = tid / CPR + c * (256 / CPR);
+            rp[c] = row < T ? *(const uint4*)(Pm + (long)row * a.ldp + (tid % CPR) * 8) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    load_tile(0);
+    if constexpr (POS) {
         const int il = wave * 32 + (lane & 31), r0 = i0 + wave * 32;
         bf16x8 fqv[DH / 16], fqvn[DH / 16];
         {
@@ -206,46 +223,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
             }
         }
         if (half == 0 && row_ok && i + 1 < T) sB[il * PB + i + 1] = 0;          // the zero of the padding column (masked in the key loop anyway)
-        for (int mb = 0; mb < T; mb += TK) {
+        // lane-constant parts of the shifted columns: low  R[i][m]   -> column m - (T-1) + i   (valid when >= 0)
+        //                                             up   R[i+1][m] -> column m + i + 2       (valid when <= T-1)
+        uint16_t* rowp = sB + il * PB;
+        const int cl = i - (T - 1), cu = i + 2;
+        uint16_t* sP = sK;                                                      // [128 positions][PK]: the K and V buffers together
+        static_assert(TK * PK + TK * PV >= 128 * PK, "position stage must fit the K + V buffers");
 #pragma unroll
-            for (int c = 0; c < NKV; ++c) {
-                const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-                *(uint4*)&sK[row * PK + c8 * 8] = (mb + row < T) ? *(const uint4*)(Pm + (long)(mb + row) * a.ldp + c8 * 8) : make_uint4(0, 0, 0, 0);
-            }
-            __syncthreads();
-            // wave-uniform: can any of this wave's rows r0 .. r0+31 have a valid entry in positions mb .. mb+63 ?
-            const bool need_low = (mb + TK - 1) >= (T - 1 - (r0 + 31));         // low: m >= T-1-i
-            const bool need_up = mb <= (T - 3 - r0);                            // up:  m <= T-3-i
+        for (int stage = 0; stage < 2; ++stage) {
+            if (stage * 128 < T) {
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                if (part == 0 ? !need_low : !need_up) continue;
-                f32x16 s[2];
-#pragma unroll
-                for (int f = 0; f < 2; ++f)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
-#pragma unroll
-                for (int st = 0; st < DH / 16; ++st)
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        const bf16x8 pf = *(const bf16x8*)&sK[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
-                        s[f] = mfma16<TA>(pf, part == 0 ? fqv[st] : fqvn[st], s[f]);
-                    }
-                if (row_ok) {
-#pragma unroll
-                    for (int f = 0; f < 2; ++f)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int m = mb + f * 32 + 8 * g + 4 * half + e;
-                                const uint16_t bits = (uint16_t)(H16<TA>::pack(s[f][4 * g + e], 0.f) & 0xffffu);
-                                if (part == 0) { if (m < T && m >= T - 1 - i) sB[il * PB + (m - (T - 1) + i)] = bits; }
-                                else { if (m <= T - 3 - i) sB[il * PB + (m + i + 2)] = bits; }
-                            }
+                for (int c = 0; c < CPR / 2; ++c) {
+                    const int row = tid / CPR + c * (256 / CPR);
+                    *(uint4*)&sP[row * PK + (tid % CPR) * 8] = rp[stage * (CPR / 2) + c];
                 }
+                __syncthreads();
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int m0 = stage * 128 + f * 32;
+                    // wave-uniform: can any of this wave's rows r0 .. r0+31 have a valid entry among positions m0 .. m0+31 ?
+                    const bool need[2] = {m0 < T && (m0 + 31) >= (T - 1 - (r0 + 31)), m0 <= (T - 3 - r0)};
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        if (!need[part]) continue;
+                        f32x16 s;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                        for (int st = 0; st < DH / 16; ++st) {
+                            const bf16x8 pf = *(const bf16x8*)&sP[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                            s = mfma16<TA>(pf, part == 0 ? fqv[st] : fqvn[st], s);
+                        }
+                        if (row_ok) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; e += 2) {
+                                    const int m = m0 + 8 * g + 4 * half + e;
+                                    const uint32_t w = H16<TA>::pack(s[4 * g + e], s[4 * g + e + 1]);
+                                    if (part == 0) {
+                                        if (m + cl >= 0 && m < T) rowp[m + cl] = (uint16_t)w;
+                                        if (m + 1 + cl >= 0 && m + 1 < T) rowp[m + 1 + cl] = (uint16_t)(w >> 16);
+                                    } else {
+                                        if (m + cu < T) rowp[m + cu] = (uint16_t)w;
+                                        if (m + 1 + cu < T) rowp[m + 1 + cu] = (uint16_t)(w >> 16);
+                                    }
+                                }
+                        }
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (a.bias_out) {                                                       // (T % 8 == 0, T <= 256)
             h16* Bo = a.bias_out + (long)bh * T * T;
@@ -368,10 +396,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
 }
 
 // ---------------------------------------------------------------------------- backward, part 1: D, dQ and d(bias), per query tile
-template <int DH, typename TA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 2 : 1))) void relpos_attn_bwd_q_kernel(AttnArgs a) {
+// POS (round 4, T <= 256): the tile's whole [128][T] slab of the shifted positional score is loaded into LDS once, every key tile's dS
+// overwrites the 64 columns it has just read, and after the key loop the slab IS the tile's gradient of the shifted score - so the two
+// products that used to follow as batched GEMM launches over a (B,H,T,T) d(bias) tensor (after an un-shift pass over it) run here, on
+// operands gathered from the slab through the inverse of the shift:
+//     dR[r][m] = dS[r][m-(T-1)+r]  (m >= T-1-r),   dS[r-1][m+r+1]  (m <= T-2-r)          (R[r][m] = (q_r + v) . p_m, unshifted)
+//     dqv[r]  = sum_m dR[r][m] p_m      (lane = query row, 8 consecutive m per operand register quad: 2-byte LDS gathers)
+//     dpos[m] = sum_r dR[r][m] qv_r     (lane = position, 8 consecutive rows: gathers at the constant stride pitch + 1)
+// A tile's last row feeds row i0+128 of the next tile (its "upper" part): that one row's two halves go to dqv_fix in f32.
+template <int DH, typename TA, bool POS = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 && !POS) ? 2 : 1))) void relpos_attn_bwd_q_kernel(AttnArgs a) {
     constexpr int TQ = 128, TK = 64;
-    constexpr int PK = DH + 8, PT = DH + 32, PB = TK + 8;
+    constexpr int PK = DH + 8, PT = DH + 32, PB = POS ? (256 + 8) : (TK + 8);
     constexpr int CPR = DH / 8;
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TK * PK + TK * PT + TQ * PB];
     uint16_t* sK = smem;                 // [key][c]  (b128 fragment reads: S)
@@ -386,7 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const h16* K = a.k + (long)b * T * a.ldk + h * DH;
     const h16* V = a.v + (long)b * T * a.ldk + h * DH;
     const h16* Bi = a.bias + (long)bh * T * T;
-    h16* dBi = a.dbias + (long)bh * T * T;
+    h16* dBi = POS ? nullptr : a.dbias + (long)bh * T * T;
     bf16x8 fq[DH / 16], fdo[DH / 16];
     float dpart = 0.f;
     {
@@ -433,14 +469,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                 rv[c] = *(const uint4*)(V + (long)(j0 + row) * a.ldk + c8 * 8);
             }
         }
+        if constexpr (!POS) {
 #pragma unroll
-        for (int c = 0; c < NBI; ++c) {
-            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
-            rbi[c] = make_uint4(0, 0, 0, 0);
-            if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
+            for (int c = 0; c < NBI; ++c) {
+                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+                rbi[c] = make_uint4(0, 0, 0, 0);
+                if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
+            }
         }
     };
     load_tile(0);
+    if constexpr (POS) {                                          // the tile's slab of the shifted score, rows beyond T zero
+        const int cpr = T >> 3, total = TQ * cpr;
+        for (int c0 = tid; c0 < total; c0 += 256 * 4) {
+            uint4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cid = c0 + 256 * u, row = cid / cpr, c8 = cid - row * cpr;
+                t[u] = (cid < total && i0 + row < T) ? *(const uint4*)(Bi + (long)(i0 + row) * T + c8 * 8) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cid = c0 + 256 * u, row = cid / cpr, c8 = cid - row * cpr;
+                if (cid < total) *(uint4*)&sB[row * PB + c8 * 8] = t[u];
+            }
+        }
+    }
     for (int j0 = 0; j0 < T; j0 += TK) {
 #pragma unroll
         for (int c = 0; c < NKV; ++c) {
@@ -449,10 +503,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
             *(uint4*)&sKt[row * PT + c8 * 8] = recode8<TA, bf16>(rk[c]);     // bf16 copies meet the bf16 gradients (dQ += dS K, dP = dO V^T)
             *(uint4*)&sV[row * PK + c8 * 8] = recode8<TA, bf16>(rv[c]);
         }
+        if constexpr (!POS) {
 #pragma unroll
-        for (int c = 0; c < NBI; ++c) {
-            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
-            *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
+            for (int c = 0; c < NBI; ++c) {
+                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+                *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
+            }
         }
         __syncthreads();
         if (j0 + TK < T) load_tile(j0 + TK);
@@ -476,7 +532,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int jl = f * 32 + 8 * g + 4 * half;
-                uint16_t* bp = &sB[(wave * 32 + (lane & 31)) * PB + jl];
+                uint16_t* bp = &sB[(wave * 32 + (lane & 31)) * PB + (POS ? j0 : 0) + jl];
                 const uint2 bu = *(const uint2*)bp;
                 const float bv[4] = {H16<TA>::lo(bu.x), H16<TA>::hi(bu.x), H16<TA>::lo(bu.y), H16<TA>::hi(bu.y)};
                 float ds[4];
@@ -510,14 +566,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                 }
         }
         __syncthreads();
-        // d(bias) tile -> global, 16-byte row pieces (the element (i, i+1) is the padding zero of the shift: its gradient is dropped
-        // by the consumer, which never reads it back through the shifted addressing)
+        if constexpr (!POS) {
+            // d(bias) tile -> global, 16-byte row pieces (the element (i, i+1) is the padding zero of the shift: its gradient is dropped
+            // by the consumer, which never reads it back through the shifted addressing)
 #pragma unroll
-        for (int c = 0; c < TQ * (TK / 8) / 256; ++c) {
-            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
-            if (i0 + row < T && j0 + c8 * 8 < T) *(uint4*)(dBi + (long)(i0 + row) * T + j0 + c8 * 8) = *(const uint4*)&sB[row * PB + c8 * 8];
+            for (int c = 0; c < TQ * (TK / 8) / 256; ++c) {
+                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+                if (i0 + row < T && j0 + c8 * 8 < T) *(uint4*)(dBi + (long)(i0 + row) * T + j0 + c8 * 8) = *(const uint4*)&sB[row * PB + c8 * 8];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (row_ok) {
         h16* out = a.dqu + ((long)b * T + i) * a.lddq + h * DH;
@@ -530,6 +588,145 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                 u.y = pack2_bf16(dq[c][4 * g + 2], dq[c][4 * g + 3]);
                 *(uint2*)(out + c * 32 + 8 * g + 4 * half) = u;
             }
+    }
+    if constexpr (POS) {
+        // sB now holds dS[il][j] (bf16) for the tile's 128 rows and all T keys; element (i, i+1) is not in the image of the shift
+        const int il = wave * 32 + (lane & 31);
+        const int ntile = gridDim.x, q = blockIdx.x;
+        const int r1 = i0 + TQ;                                   // first row of the next tile: its "upper" part lives in this tile's last row
+        const bool has_extra = r1 < T;
+        constexpr int NPART = 256 / DH;
+        const int xc = tid % DH, xp = tid / DH;
+        float xacc = 0.f;
+        // ---- dqv^T[c][r] = sum_m P^T[c][m] dR[r][m]: position tiles stream through the transpose-read buffer
+        const h16* Pm = a.pos + h * DH;
+        f32x16 dqv[DH / 32];
+#pragma unroll
+        for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqv[c][r] = 0.f;
+        for (int mb = 0; mb < T; mb += TK) {
+#pragma unroll
+            for (int c = 0; c < NKV; ++c) {
+                const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+                const uint4 u = (mb + row < T) ? *(const uint4*)(Pm + (long)(mb + row) * a.ldp + c8 * 8) : make_uint4(0, 0, 0, 0);
+                *(uint4*)&sKt[row * PT + c8 * 8] = recode8<TA, bf16>(u);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < TK / 16; ++ks) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = mb + ks * 16 + half * 8 + e;
+                    const int cl = m - (T - 1) + i;               // own row, "lower" part; otherwise the previous row's "upper" part
+                    const bool low = cl >= 0;
+                    const bool ok = row_ok && m < T && (low || il >= 1);
+                    const int idx = low ? il * PB + cl : (il - 1) * PB + m + i + 1;
+                    const uint32_t v = ok ? (uint32_t)sB[idx] : 0u;
+                    if (e & 1) w[e >> 1] |= v << 16; else w[e >> 1] = v;
+                }
+                union { uint32_t u[4]; bf16x8 b; } fr;
+                fr.u[0] = w[0]; fr.u[1] = w[1]; fr.u[2] = w[2]; fr.u[3] = w[3];
+#pragma unroll
+                for (int c = 0; c < DH / 32; ++c) {
+                    const bf16x8 pf = tr_frag<PT>(sKt, ks * 16, c * 32, lane);
+                    dqv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, fr.b, dqv[c], 0, 0, 0);
+                }
+            }
+            if (has_extra) {                                      // the next tile's first row: plain dot products, DH x 64 per position tile
+                for (int ml = xp; ml < TK; ml += NPART) {
+                    const int m = mb + ml;
+                    if (m <= T - 2 - r1) xacc += bf16_bits_to_f32(sB[(TQ - 1) * PB + m + r1 + 1]) * bf16_bits_to_f32(sKt[ml * PT + xc]);
+                }
+            }
+            __syncthreads();
+        }
+        if (row_ok) {
+            h16* out = a.dqv + ((long)b * T + i) * a.lddqv + h * DH;
+#pragma unroll
+            for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 u;
+                    u.x = pack2_bf16(dqv[c][4 * g + 0], dqv[c][4 * g + 1]);
+                    u.y = pack2_bf16(dqv[c][4 * g + 2], dqv[c][4 * g + 3]);
+                    *(uint2*)(out + c * 32 + 8 * g + 4 * half) = u;
+                }
+        }
+        if (q >= 1 && il == 0) {                                  // this tile's share of its first row, unrounded
+            float* fx = a.dqv_fix + ((long)(bh * ntile + q) * 2 + 0) * DH;
+#pragma unroll
+            for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(fx + c * 32 + 8 * g + 4 * half) = make_float4(dqv[c][4 * g], dqv[c][4 * g + 1], dqv[c][4 * g + 2], dqv[c][4 * g + 3]);
+        }
+        float* red = (float*)sK;
+        red[tid] = xacc;
+        __syncthreads();
+        if (has_extra && tid < DH) {
+            float t = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < NPART; ++pp) t += red[pp * DH + tid];
+            a.dqv_fix[((long)(bh * ntile + q + 1) * 2 + 1) * DH + tid] = t;
+        }
+        __syncthreads();
+        // ---- dpos^T[c][m] = sum_r qv^T[c][r] dR[r][m], this tile's rows only: "lower" parts against qv rows i, "upper" parts against rows i+1
+        uint16_t* sQ = sK;                                        // [129][PT] bf16
+        static_assert(2 * TK * PK + TK * PT >= (TQ + 1) * PT, "qv rows must fit the K / V buffers");
+        const h16* QV = a.qv + (long)b * T * a.ldq + h * DH;
+        for (int cid = tid; cid < (TQ + 1) * CPR; cid += 256) {
+            const int row = cid / CPR, c8 = cid % CPR;
+            const uint4 u = (i0 + row < T) ? *(const uint4*)(QV + (long)(i0 + row) * a.ldq + c8 * 8) : make_uint4(0, 0, 0, 0);
+            *(uint4*)&sQ[row * PT + c8 * 8] = recode8<TA, bf16>(u);
+        }
+        __syncthreads();
+        h16* DP = a.dpos_part + ((long)(b * ntile + q) * T) * ((long)a.H * DH) + h * DH;
+        for (int mblk = wave; mblk * 32 < T; mblk += 4) {
+            const int m = mblk * 32 + (lane & 31);
+            f32x16 acc[DH / 32];
+#pragma unroll
+            for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                for (int ks = 0; ks < TQ / 16; ++ks) {
+                    const int k0 = ks * 16;
+                    // wave-uniform: any valid (row, position) pair in this 16 x 32 block ?
+                    const bool any = part == 0 ? (mblk * 32 + 31 + i0 + k0 + 15 >= T - 1) : (mblk * 32 + i0 + k0 <= T - 3);
+                    if (!any) continue;
+                    uint32_t w[4];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ilk = k0 + half * 8 + e, ii = i0 + ilk;
+                        const int col = part == 0 ? m - (T - 1) + ii : m + ii + 2;
+                        const bool ok = part == 0 ? (col >= 0 && m < T && ii < T) : (col <= T - 1);
+                        const uint32_t v = ok ? (uint32_t)sB[ilk * PB + col] : 0u;
+                        if (e & 1) w[e >> 1] |= v << 16; else w[e >> 1] = v;
+                    }
+                    union { uint32_t u[4]; bf16x8 b; } fr;
+                    fr.u[0] = w[0]; fr.u[1] = w[1]; fr.u[2] = w[2]; fr.u[3] = w[3];
+#pragma unroll
+                    for (int c = 0; c < DH / 32; ++c) {
+                        const bf16x8 qf = tr_frag<PT>(sQ, k0 + part, c * 32, lane);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, fr.b, acc[c], 0, 0, 0);
+                    }
+                }
+            }
+            if (m < T) {
+#pragma unroll
+                for (int c = 0; c < DH / 32; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 u;
+                        u.x = pack2_bf16(acc[c][4 * g + 0], acc[c][4 * g + 1]);
+                        u.y = pack2_bf16(acc[c][4 * g + 2], acc[c][4 * g + 3]);
+                        *(uint2*)(DP + (long)m * ((long)a.H * DH) + c * 32 + 8 * g + 4 * half) = u;
+                    }
+            }
+        }
     }
 }
 
@@ -680,6 +877,10 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
                 *(uint2*)(ov_ + c * 32 + 8 * g + 4 * half) = w;
             }
     }
+    if (a.dqv_fix && blockIdx.x >= 1 && tid < DH) {               // the dQ kernel's boundary row (see there): both halves, rounded once
+        const float* fx = a.dqv_fix + ((long)(bh * gridDim.x + blockIdx.x) * 2) * DH;
+        a.dqv[((long)b * T + j0) * a.lddqv + h * DH + tid] = (h16)(pack2_bf16(fx[tid] + fx[DH + tid], 0.f) & 0xffffu);
+    }
 }
 
 // C ABI ----------------------------------------------------------------------------------------------------------------------
@@ -751,6 +952,40 @@ extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long l
 
 // Backward of sarssl_relpos_attn_fwd.  dsum: f32 workspace (B,H,T).  Outputs: dqu [B*T][lddq], dk / dv [B*T][lddk] (head h at
 // column h*dh), dbias bf16 (B,H,T,T) = gradient of the shifted positional score (the element (i, i+1) carries no meaning).
+// Backward with the positional-score gradients formed in the dQ kernel (no d(bias) tensor, no un-shift pass, no batched products
+// after it): qv / pos as in sarssl_relpos_attn_fwd_pos, bias = the (B,H,T,T) shifted score that forward wrote.  Outputs besides dqu /
+// dk / dv: dqv [B*T][lddqv] (gradient of q + v_bias through the positional score), dpos_part bf16 (B, ntile, T, H*dh) with
+// ntile = ceil(T / 128): partial gradients of the positional projection, to be summed over the first two axes.  dqv_fix: f32
+// workspace (B*H, ntile, 2, dh).  T <= 256 (sarssl_relpos_attn_pos_supported).
+extern "C" int sarssl_relpos_attn_bwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
+                                          long ldp, const void* bias, const float* ctx32, const float* lse, const void* dctx, long lddc,
+                                          void* dqu, long lddq, void* dqv, long lddqv, void* dk, void* dv, long lddk, void* dpos_part,
+                                          float* dqv_fix, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,
+                                          unsigned long long seed, int dtype, void* stream) {
+    if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_bwd_pos")) return -1;
+    SARSSL_REQUIRE(sarssl_relpos_attn_pos_supported(T, dh) && ldp % 8 == 0 && qv && pos && bias && dqv && dpos_part && dqv_fix, "sarssl_relpos_attn_bwd_pos(T <= 256)");
+    SARSSL_REQUIRE(dtype == SARSSL_BF16 || dtype == SARSSL_MIX16, "sarssl_relpos_attn_bwd_pos(dtype: bf16, or MIX16 = fp16 forward tensors + bf16 gradients)");
+    SARSSL_REQUIRE(lddc % 8 == 0 && lddq % 4 == 0 && lddqv % 4 == 0 && lddk % 4 == 0 && dsum != nullptr && lse != nullptr && ctx32 != nullptr, "sarssl_relpos_attn_bwd_pos");
+    AttnArgs a = {};
+    a.qu = (const h16*)qu; a.qv = (const h16*)qv; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk; a.bias = (const h16*)bias;
+    a.pos = (const h16*)pos; a.ldp = ldp;
+    a.ctx32 = (float*)ctx32; a.lse = (float*)lse; a.dctx = (const h16*)dctx; a.lddc = lddc;
+    a.dqu = (h16*)dqu; a.lddq = lddq; a.dk = (h16*)dk; a.dv = (h16*)dv; a.lddk = lddk; a.dsum = dsum;
+    a.dqv = (h16*)dqv; a.lddqv = lddqv; a.dpos_part = (h16*)dpos_part; a.dqv_fix = dqv_fix;
+    a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gq((T + 127) / 128, B * H), gk((T + 127) / 128, B * H);
+#define ATTN_BWD(DHv, TAv) do { relpos_attn_bwd_q_kernel<DHv, TAv, true><<<gq, 256, 0, st>>>(a); relpos_attn_bwd_kv_kernel<DHv, TAv><<<gk, 256, 0, st>>>(a); } while (0)
+    if (dtype == SARSSL_MIX16) {
+        if (dh == 128) ATTN_BWD(128, f16); else if (dh == 64) ATTN_BWD(64, f16); else ATTN_BWD(32, f16);
+    } else {
+        if (dh == 128) ATTN_BWD(128, bf16); else if (dh == 64) ATTN_BWD(64, bf16); else ATTN_BWD(32, bf16);
+    }
+#undef ATTN_BWD
+    SARSSL_CHECK_LAUNCH("relpos_attn_bwd_kernel<pos>");
+    return 0;
+}
+
 extern "C" int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias,
                                       const float* ctx32, const float* lse, const void* dctx, long lddc, void* dqu, long lddq,
                                       void* dk, void* dv, long lddk, void* dbias, float* dsum, int B, int H, int T, int dh,

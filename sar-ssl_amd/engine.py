@@ -531,6 +531,12 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
         dv = torch.empty((M, d), dtype=RT.gdtype, device=dev)
     ldg = dqu.stride(0)
     scale = 1.0 / math.sqrt(d)
+    if fused_attn and _ATTN_POS and hip.relpos_attn_pos_supported(T, dh, RT.dtype):
+        # T <= 256: the dQ kernel also forms the positional-score gradients (no d(bias) tensor, un-shift pass or batched products)
+        dqv = torch.empty((M, d), dtype=RT.gdtype, device=dev)
+        dposb = hip.relpos_attn_bwd_pos(qu, qv, k, v, pos, p, pd, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, pa, sa)
+        return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d,
+                              dev, drop=_next_drop(next_kind, saved), dq_out=dqkv[:, :d] if fused is not None else dqu)
     if fused_attn:
         dbias = hip.relpos_attn_bwd(qu, k, v, p, pd, dctx, dqu, dk, dv, B, H, T, dh, scale, pa, sa)      # p = bias, pd = (ctx32, lse) here
         dps = hip.relshift_bwd(dbias)                                                        # d (unshifted) pos score
@@ -575,7 +581,7 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
 def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None, dq_out=None):
     """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
     if dposb.dtype == RT.gdtype:                                     # batch sum straight into the GEMM operand's dtype: one launch
-        dpos_rt = hip.colsum_store(dposb.view(B, T * d)).view(T, d)
+        dpos_rt = hip.colsum_store(dposb.view(dposb.shape[0], T * d)).view(T, d)      # (B rows, or B * ntile partials of the fused backward)
     else:
         dpos = torch.zeros((T * d,), dtype=torch.float32, device=dev)
         hip.colsum(dposb.view(B, T * d), dpos, now=True)             # consumed right below

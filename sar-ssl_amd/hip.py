@@ -971,6 +971,25 @@ def relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqu, dk, dv, B, H, T, dh, scale, 
     return dbias
 
 
+def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0):
+    """Backward of relpos_attn_fwd_pos with the positional-score gradients formed in the dQ kernel.  Writes dqu / dqv / dk / dv and
+    returns dpos_part (B * ntile, T, d): partial gradients of the positional projection (sum over axis 0)."""
+    ctx32, lse = aux
+    _need_cuda(qu, qv, k, v, pos, bias, ctx32, lse, dctx, dqu, dqv, dk, dv)
+    assert k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0) and qu.stride(0) == qv.stride(0) and pos.stride(1) == 1 and \
+        all(t.dtype == qu.dtype for t in (qv, k, v, pos, bias)) and all(t.dtype == dctx.dtype for t in (dqu, dqv, dk, dv)) and \
+        bias.is_contiguous()
+    ntile = (T + 127) // 128
+    dpos_part = torch.empty((B * ntile, T, H * dh), dtype=dctx.dtype, device=qu.device)
+    dsum = _f32ws(B * H * T, qu.device, "attn_dsum")
+    fix = _f32ws(B * H * ntile * 2 * dh, qu.device, "attn_dqv_fix")
+    _lib.call("sarssl_relpos_attn_bwd_pos", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),
+              c_long(pos.stride(0)), _p(bias), _p(ctx32), _p(lse), _p(dctx), c_long(dctx.stride(0)), _p(dqu), c_long(dqu.stride(0)),
+              _p(dqv), c_long(dqv.stride(0)), _p(dk), _p(dv), c_long(dk.stride(0)), _p(dpos_part), _p(fix), _p(dsum), c_int(B), c_int(H),
+              c_int(T), c_int(dh), c_float(scale), c_float(p_drop), c_ulonglong(seed), c_int(dt_ga(dctx, qu)), _stream())
+    return dpos_part
+
+
 def bias2(q2d, u, v):
     M, d = q2d.shape
     qu = torch.empty((M, d), dtype=q2d.dtype, device=q2d.device)

@@ -885,6 +885,25 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
     raw_leaf = raw.clone().requires_grad_(True)
     (_ref_shift(raw_leaf) * wb).sum().backward()
     check("attn.bwd.unshift[p=%g]" % p_drop, _relerr(dps, raw_leaf.grad), 2e-2)
+    if hip.relpos_attn_pos_supported(T, dh, adt):
+        # backward with the positional-score gradients formed in the dQ kernel (no d(bias) tensor): dqu / dk / dv are the two-kernel
+        # path's bit for bit; dqv and the positional-projection gradient against f64 products with the reference's un-shifted gradient
+        quc = qu.contiguous()
+        dqkv2 = torch.full((B * T, 3 * d), float("nan"), dtype=torch.bfloat16, device=dev)
+        dqv = torch.full((B * T, d), float("nan"), dtype=torch.bfloat16, device=dev)
+        dpart = hip.relpos_attn_bwd_pos(quc, qv, k, v, pos, bias_p, aux_p, dctx, dqkv2[:, :d], dqv, dqkv2[:, d:2 * d], dqkv2[:, 2 * d:],
+                                        B, H, T, dh, scale, p_drop, seed)
+        assert torch.equal(dqkv2, dqkv)
+        g64 = raw_leaf.grad                                                      # (B,H,T,T): d loss / d R[b,h,r,m]
+        want_dqv = torch.einsum("bhrm,mhc->brhc", g64, pos.view(T, H, dh).double()).reshape(B * T, d)
+        want_dpos = torch.einsum("bhrm,brhc->mhc", g64, qv.view(B, T, H, dh).double()).reshape(T, d)
+        assert not torch.isnan(dqv.float()).any() and not torch.isnan(dpart.float()).any()
+        check("attn.bwd_pos.dqv[p=%g]" % p_drop, _relerr(dqv, want_dqv), 2e-2)
+        assert dpart.shape == (B * ((T + 127) // 128), T, d)
+        check("attn.bwd_pos.dpos[p=%g]" % p_drop, _relerr(dpart.double().sum(0), want_dpos), 2e-2)
+        # per row: the tile-boundary row (128) is assembled from two workgroups' halves
+        rows = (dqv.double() - want_dqv).view(B, T, d).norm(dim=-1) / want_dqv.view(B, T, d).norm(dim=-1).clamp_min(1e-30)
+        check("attn.bwd_pos.dqv_worst_row[p=%g]" % p_drop, rows.max().item(), 5e-2)
 
 
 # ---------------------------------------------------------------- depthwise-conv tiles of the convolution module (csrc/dwconv.hip)

@@ -31,11 +31,45 @@ def run(B, H, T, dh, p_drop, iters):
     def fwd():
         hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, 11)
 
+    qv = (torch.randn((B * T, d), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    pos = (torch.randn((T, d), device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    quc = qu.contiguous()                       # (q + u and q + v share a row stride, as the engine's bias2 produces them)
+
+    def gemm_fwd():                             # what a layer issues with SARSSL_ATTN_POS=0: shifted positional-score GEMM, then the kernel
+        hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=B * H, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
+                 sC=(H * T * T, T * T), c_row_shift=True)
+        hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop, 11)
+
+    def fwd_pos():                              # the default: positional score formed in the kernel, score tile written for the backward
+        hip.relpos_attn_fwd_pos(quc, qv, k, v, pos, B, H, T, dh, scale, p_drop, 11)
+
+    def fwd_pos_inf():                          # inference: no score tile written
+        hip.relpos_attn_fwd_pos(quc, qv, k, v, pos, B, H, T, dh, scale, p_drop, 11, need_bwd=False)
+
+    ctx_p, aux_p, bias_p = hip.relpos_attn_fwd_pos(quc, qv, k, v, pos, B, H, T, dh, scale, p_drop, 11)
+    dqv = torch.empty((B * T, d), dtype=torch.bfloat16, device=dev)
+
+    def bwd_unfused_all():                      # SARSSL_ATTN_POS=0: kernels + un-shift pass + the two batched products of the positional gradients
+        dbias = hip.relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, scale, p_drop, 11)
+        dps = hip.relshift_bwd(dbias)
+        hip.gemm(dps, pos, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=B * H, batch_inner=H,
+                 sA=(H * T * T, T * T), sB=(0, dh), out=dqv, ldc=d, sC=(T * d, dh))
+        dposb = torch.empty((B, T, d), dtype=torch.bfloat16, device=dev)
+        hip.gemm(dps, qv, a_kc=False, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=d, nbatch=B * H, batch_inner=H,
+                 sA=(H * T * T, T * T), sB=(T * d, dh), out=dposb, ldc=d, sC=(T * d, dh))
+        hip.colsum_store(dposb.view(B, T * d))
+
+    def bwd_pos():                              # the default: positional gradients formed in the dQ kernel
+        dpart = hip.relpos_attn_bwd_pos(quc, qv, k, v, pos, bias_p, aux_p, dctx, dqkv[:, :d], dqv, dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                                        B, H, T, dh, scale, p_drop, 11)
+        hip.colsum_store(dpart.view(dpart.shape[0], T * d))
+
     def bwd():
         hip.relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, scale, p_drop, 11)
 
     out = {}
-    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    for name, fn in (("fwd", fwd), ("bwd", bwd), ("gemm_fwd", gemm_fwd), ("fwd_pos", fwd_pos), ("fwd_pos_inf", fwd_pos_inf),
+                     ("bwd_unfused_all", bwd_unfused_all), ("bwd_pos", bwd_pos)):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
@@ -49,7 +83,10 @@ def run(B, H, T, dh, p_drop, iters):
     fl_f = 2 * 2 * T * T * dh * B * H          # S and PV
     fl_b = 5 * 2 * T * T * dh * B * H * 1.0 + 2 * 2 * T * T * dh * B * H   # dQ, dK, dV, + recomputed S and dP twice
     print(f"B={B} H={H} T={T} dh={dh} drop={p_drop}:  fwd {out['fwd']:8.1f} us ({fl_f / out['fwd'] / 1e6:6.1f} TFLOP/s)   "
-          f"bwd {out['bwd']:8.1f} us ({fl_b / out['bwd'] / 1e6:6.1f} TFLOP/s)", flush=True)
+          f"bwd {out['bwd']:8.1f} us ({fl_b / out['bwd'] / 1e6:6.1f} TFLOP/s)   pos-score GEMM + fwd {out['gemm_fwd']:7.1f} us   "
+          f"fwd with in-kernel pos score {out['fwd_pos']:7.1f} us  (no score tile written: {out['fwd_pos_inf']:7.1f} us)\n"
+          f"        backward incl. positional gradients: kernels + un-shift + 2 products + batch sum {out['bwd_unfused_all']:7.1f} us   "
+          f"in the dQ kernel {out['bwd_pos']:7.1f} us", flush=True)
 
 
 if __name__ == "__main__":
