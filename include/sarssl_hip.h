@@ -331,6 +331,20 @@ int sarssl_step_tick(void* state, void* stream);
 int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, const void* state,
                          float eps, int zero_grad, void* stream);
 
+/* ---- collectives: the gradient exchange of data-parallel training (replaces torch.nn.DataParallel's per-step replicate / gather /
+ *      reduce, code/learner.py:25-31, :102).  One communicator per (process, device); the 128-byte id is generated by rank 0 and moved
+ *      to the other ranks by the caller (any side channel: a file, a socket, torch.distributed's store).  RCCL is resolved with dlopen
+ *      at first use - the library has no link-time dependency on it.  sarssl_allreduce_bucket: in-place f32 sum of one contiguous
+ *      bucket of the flat gradient buffer over all ranks, enqueued on `stream` (asynchronous, capturable into a hipGraph); the
+ *      1/world scaling is the `gscale` argument of sarssl_adam_step*. */
+int sarssl_comm_available(void);                /* 1 when librccl.so.1 could be resolved in this process */
+int sarssl_comm_rccl_version(void);             /* RCCL's version code, or -1 */
+int sarssl_comm_unique_id(void* id128);
+void* sarssl_comm_create(int nranks, int rank, const void* id128);     /* on the current HIP device; collective; NULL on failure */
+int sarssl_comm_destroy(void* comm);
+int sarssl_comm_size(void* comm);
+int sarssl_allreduce_bucket(void* comm, float* bucket, long count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

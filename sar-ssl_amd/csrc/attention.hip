@@ -409,11 +409,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
     constexpr int TQ = 128, TK = 64;
     constexpr int PK = DH + 8, PT = DH + 32, PB = POS ? (256 + 8) : (TK + 8);
     constexpr int CPR = DH / 8;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TK * PK + TK * PT + TQ * PB];
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * TK * PK + TK * PT + (TQ + (POS ? 1 : 0)) * PB];
     uint16_t* sK = smem;                 // [key][c]  (b128 fragment reads: S)
     uint16_t* sV = sK + TK * PK;         // [key][c]  (dP)
     uint16_t* sKt = sV + TK * PK;        // [key][c] with the transpose-read pitch (dQ += dS K)
-    uint16_t* sB = sKt + TK * PT;        // bias tile in, d(bias) tile out
+    uint16_t* sB = sKt + TK * PT + (POS ? PB : 0);   // bias tile in, d(bias) tile out (POS: the whole slab, behind one row of zeros = "row -1")
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H, T = a.T;
     const int i0 = blockIdx.x * TQ;
@@ -469,31 +469,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
                 rv[c] = *(const uint4*)(V + (long)(j0 + row) * a.ldk + c8 * 8);
             }
         }
-        if constexpr (!POS) {
 #pragma unroll
-            for (int c = 0; c < NBI; ++c) {
-                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
-                rbi[c] = make_uint4(0, 0, 0, 0);
-                if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
-            }
+        for (int c = 0; c < NBI; ++c) {
+            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+            rbi[c] = make_uint4(0, 0, 0, 0);
+            if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
         }
     };
     load_tile(0);
-    if constexpr (POS) {                                          // the tile's slab of the shifted score, rows beyond T zero
-        const int cpr = T >> 3, total = TQ * cpr;
-        for (int c0 = tid; c0 < total; c0 += 256 * 4) {
-            uint4 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cid = c0 + 256 * u, row = cid / cpr, c8 = cid - row * cpr;
-                t[u] = (cid < total && i0 + row < T) ? *(const uint4*)(Bi + (long)(i0 + row) * T + c8 * 8) : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cid = c0 + 256 * u, row = cid / cpr, c8 = cid - row * cpr;
-                if (cid < total) *(uint4*)&sB[row * PB + c8 * 8] = t[u];
-            }
-        }
+    if constexpr (POS) {                                          // "row -1" of the slab
+        if (tid < PB / 8) *(uint4*)&sB[-PB + tid * 8] = make_uint4(0, 0, 0, 0);
     }
     for (int j0 = 0; j0 < T; j0 += TK) {
 #pragma unroll
@@ -503,12 +488,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
             *(uint4*)&sKt[row * PT + c8 * 8] = recode8<TA, bf16>(rk[c]);     // bf16 copies meet the bf16 gradients (dQ += dS K, dP = dO V^T)
             *(uint4*)&sV[row * PK + c8 * 8] = recode8<TA, bf16>(rv[c]);
         }
-        if constexpr (!POS) {
 #pragma unroll
-            for (int c = 0; c < NBI; ++c) {
-                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
-                *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
-            }
+        for (int c = 0; c < NBI; ++c) {                           // (POS: into columns j0 .. j0+63 of the slab, which keeps every tile's dS)
+            const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+            *(uint4*)&sB[row * PB + (POS ? j0 : 0) + c8 * 8] = rbi[c];
         }
         __syncthreads();
         if (j0 + TK < T) load_tile(j0 + TK);
@@ -598,49 +581,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
         constexpr int NPART = 256 / DH;
         const int xc = tid % DH, xp = tid / DH;
         float xacc = 0.f;
-        // ---- dqv^T[c][r] = sum_m P^T[c][m] dR[r][m]: position tiles stream through the transpose-read buffer
+        // ---- dqv^T[c][r] = sum_m P^T[c][m] dR[r][m].  The head's positional projection and the tile's 129 qv rows are requested in one
+        //      burst; the projection goes through the K / V / transpose buffers 128 positions at a time
         const h16* Pm = a.pos + h * DH;
+        const h16* QV = a.qv + (long)b * T * a.ldq + h * DH;
+        constexpr int NQV = ((TQ + 1) * CPR + 255) / 256;
+        uint4 rp[CPR], rqv[NQV];
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) {
+            const int row = tid / CPR + c * (256 / CPR);
+            rp[c] = row < T ? *(const uint4*)(Pm + (long)row * a.ldp + (tid % CPR) * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < NQV; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            rqv[c] = (cid < (TQ + 1) * CPR && i0 + row < T) ? *(const uint4*)(QV + (long)(i0 + row) * a.ldq + c8 * 8) : make_uint4(0, 0, 0, 0);
+        }
         f32x16 dqv[DH / 32];
 #pragma unroll
         for (int c = 0; c < DH / 32; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dqv[c][r] = 0.f;
-        for (int mb = 0; mb < T; mb += TK) {
+        uint16_t* sP = sK;                                        // [128 positions][PT] bf16
+        static_assert(2 * TK * PK + TK * PT >= 128 * PT, "position stage must fit the K / V buffers");
+        // dR[r][m] sits at slab index il * PB + (m - (T-1) + i) when that column is >= 0 (own row), else T - PB further on: the previous
+        // row's column m + i + 1 (row -1 = zeros)
+        const int gbase = il * PB + i - (T - 1);
 #pragma unroll
-            for (int c = 0; c < NKV; ++c) {
-                const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-                const uint4 u = (mb + row < T) ? *(const uint4*)(Pm + (long)(mb + row) * a.ldp + c8 * 8) : make_uint4(0, 0, 0, 0);
-                *(uint4*)&sKt[row * PT + c8 * 8] = recode8<TA, bf16>(u);
-            }
-            __syncthreads();
+        for (int stage = 0; stage < 2; ++stage) {
+            if (stage * 128 < T) {
 #pragma unroll
-            for (int ks = 0; ks < TK / 16; ++ks) {
-                uint32_t w[4];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int m = mb + ks * 16 + half * 8 + e;
-                    const int cl = m - (T - 1) + i;               // own row, "lower" part; otherwise the previous row's "upper" part
-                    const bool low = cl >= 0;
-                    const bool ok = row_ok && m < T && (low || il >= 1);
-                    const int idx = low ? il * PB + cl : (il - 1) * PB + m + i + 1;
-                    const uint32_t v = ok ? (uint32_t)sB[idx] : 0u;
-                    if (e & 1) w[e >> 1] |= v << 16; else w[e >> 1] = v;
+                for (int c = 0; c < CPR / 2; ++c) {
+                    const int row = tid / CPR + c * (256 / CPR);
+                    *(uint4*)&sP[row * PT + (tid % CPR) * 8] = recode8<TA, bf16>(rp[stage * (CPR / 2) + c]);
                 }
-                union { uint32_t u[4]; bf16x8 b; } fr;
-                fr.u[0] = w[0]; fr.u[1] = w[1]; fr.u[2] = w[2]; fr.u[3] = w[3];
+                __syncthreads();
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int m0 = stage * 128 + ks * 16 + half * 8;
+                    if (stage * 128 + ks * 16 >= T) break;
+#ifdef ATTN_EXP_NO_A
+                    if (a.T > 0) break;
+#endif
+                    uint32_t w[4];
 #pragma unroll
-                for (int c = 0; c < DH / 32; ++c) {
-                    const bf16x8 pf = tr_frag<PT>(sKt, ks * 16, c * 32, lane);
-                    dqv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, fr.b, dqv[c], 0, 0, 0);
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = m0 + e;
+                        const int cl = m - (T - 1) + i;
+                        // (unconditional load - a load under a lane condition costs an exec-mask round trip and a wait each - then a select)
+                        const uint32_t ld = (uint32_t)sB[gbase + min(m, T - 1) + (cl < 0 ? T - PB : 0)];
+                        const uint32_t v = m < T ? ld : 0u;
+                        if (e & 1) w[e >> 1] |= v << 16; else w[e >> 1] = v;
+                    }
+                    union { uint32_t u[4]; bf16x8 b; } fr;
+                    fr.u[0] = w[0]; fr.u[1] = w[1]; fr.u[2] = w[2]; fr.u[3] = w[3];
+#pragma unroll
+                    for (int c = 0; c < DH / 32; ++c) {
+                        const bf16x8 pf = tr_frag<PT>(sP, ks * 16, c * 32, lane);
+                        dqv[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, fr.b, dqv[c], 0, 0, 0);
+                    }
                 }
-            }
-            if (has_extra) {                                      // the next tile's first row: plain dot products, DH x 64 per position tile
-                for (int ml = xp; ml < TK; ml += NPART) {
-                    const int m = mb + ml;
-                    if (m <= T - 2 - r1) xacc += bf16_bits_to_f32(sB[(TQ - 1) * PB + m + r1 + 1]) * bf16_bits_to_f32(sKt[ml * PT + xc]);
+                if (has_extra) {                                  // the next tile's first row: plain dot products
+                    for (int ml = xp; ml < 128; ml += NPART) {
+                        const int m = stage * 128 + ml;
+                        if (m <= T - 2 - r1) xacc += bf16_bits_to_f32(sB[(TQ - 1) * PB + m + r1 + 1]) * bf16_bits_to_f32(sP[ml * PT + xc]);
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (row_ok) {
             h16* out = a.dqv + ((long)b * T + i) * a.lddqv + h * DH;
@@ -675,14 +682,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
         // ---- dpos^T[c][m] = sum_r qv^T[c][r] dR[r][m], this tile's rows only: "lower" parts against qv rows i, "upper" parts against rows i+1
         uint16_t* sQ = sK;                                        // [129][PT] bf16
         static_assert(2 * TK * PK + TK * PT >= (TQ + 1) * PT, "qv rows must fit the K / V buffers");
-        const h16* QV = a.qv + (long)b * T * a.ldq + h * DH;
-        for (int cid = tid; cid < (TQ + 1) * CPR; cid += 256) {
-            const int row = cid / CPR, c8 = cid % CPR;
-            const uint4 u = (i0 + row < T) ? *(const uint4*)(QV + (long)(i0 + row) * a.ldq + c8 * 8) : make_uint4(0, 0, 0, 0);
-            *(uint4*)&sQ[row * PT + c8 * 8] = recode8<TA, bf16>(u);
+#pragma unroll
+        for (int c = 0; c < NQV; ++c) {
+            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            if (cid < (TQ + 1) * CPR) *(uint4*)&sQ[row * PT + c8 * 8] = recode8<TA, bf16>(rqv[c]);
         }
         __syncthreads();
         h16* DP = a.dpos_part + ((long)(b * ntile + q) * T) * ((long)a.H * DH) + h * DH;
+#ifdef ATTN_EXP_NO_B
+        if (a.T > 0) return;
+#endif
         for (int mblk = wave; mblk * 32 < T; mblk += 4) {
             const int m = mblk * 32 + (lane & 31);
             f32x16 acc[DH / 32];
@@ -703,7 +712,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
                         const int ilk = k0 + half * 8 + e, ii = i0 + ilk;
                         const int col = part == 0 ? m - (T - 1) + ii : m + ii + 2;
                         const bool ok = part == 0 ? (col >= 0 && m < T && ii < T) : (col <= T - 1);
-                        const uint32_t v = ok ? (uint32_t)sB[ilk * PB + col] : 0u;
+                        const uint32_t ld = (uint32_t)sB[ilk * PB + min(max(col, 0), T - 1)];       // unconditional load, then a select
+                        const uint32_t v = ok ? ld : 0u;
                         if (e & 1) w[e >> 1] |= v << 16; else w[e >> 1] = v;
                     }
                     union { uint32_t u[4]; bf16x8 b; } fr;

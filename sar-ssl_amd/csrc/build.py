@@ -6,7 +6,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip", "comm.hip"]
 LIB = os.path.join(HERE, "libsarssl_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wno-unused-result"]
 EXTRA_FLAGS = {}             # per-file extras (none in the product build; tools/gemm_nt/ documents one hipcc 7.2 workaround)
@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
             if verbose and w.strip():
                 print(w[-3000:])
     if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-ldl"])
     return LIB
 
 
