@@ -60,10 +60,45 @@ def stage_slices(net, flat):
     return spans
 
 
+class _NativeExchange:
+    """The bucket all-reduces through the library's own RCCL entry points (sarssl_allreduce_bucket, csrc/comm.hip) instead of
+    torch.distributed's NCCL process group: one communicator per rank, created from an id that rank 0 generates and the existing
+    process group (any backend - gloo is enough) carries to the others; every bucket is enqueued on ONE dedicated communication stream
+    behind an event of the stream that produced its gradients, and finish() makes the compute stream wait for that stream - the same
+    overlap torch's async_op gives, with plain HIP events, capturable into the step graph.  Opt-in (SARSSL_NATIVE_RCCL=1)."""
+
+    def __init__(self, device, world, rank, group=None):
+        from . import hip
+        self.hip = hip
+        ids = [hip.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0, group=group)
+        self.comm = hip.comm_create(world, rank, ids[0])
+        self.stream = torch.cuda.Stream(device=device)
+        self.pending = False
+
+    def all_reduce(self, t):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        self.hip.allreduce_bucket(self.comm, t, stream=self.stream)
+        self.pending = True
+
+    def wait(self):
+        if self.pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.pending = False
+
+    def close(self):
+        if self.comm:
+            self.hip.comm_destroy(self.comm)
+            self.comm = None
+
+
 class FlatGradAllReduce:
     """Bucketed, overlapped gradient all-reduce driven by the model's backward-stage hooks."""
 
-    def __init__(self, net, flat, process_group=None, strict=None):
+    def __init__(self, net, flat, process_group=None, strict=None, native=None):
         self.net, self.flat, self.pg = net, flat, process_group
         self.spans = stage_slices(net, flat)
         covered = sorted(self.spans.values())
@@ -80,6 +115,14 @@ class FlatGradAllReduce:
         # was exchanged before its gradients were final (or twice) - fail loudly instead of training on a wrong average
         self.strict = bool(getattr(net, "pretrain", False)) if strict is None else bool(strict)
         self.nsteps = 0
+        # native: the exchange through sarssl_allreduce_bucket (None: SARSSL_NATIVE_RCCL=1 and a GPU buffer; world 1 included, where RCCL's
+        # all-reduce is a copy - that is how the path is exercised on a one-GPU box)
+        if native is None:
+            native = os.environ.get("SARSSL_NATIVE_RCCL", "0") == "1"
+        self.native = None
+        if native and flat.grad.is_cuda:
+            rank = dist.get_rank(process_group) if self.world > 1 else 0
+            self.native = _NativeExchange(flat.grad.device, self.world, rank, process_group)
         net.set_backward_stage_hook(self._on_stage)
 
     def _on_stage(self, name):
@@ -93,11 +136,17 @@ class FlatGradAllReduce:
         if name in self._fired:
             return
         self.order.append(name)
-        if self.world <= 1:
+        if self.world <= 1 and self.native is None:
             return
         self._fired.add(name)
         s, e = self.spans[name]
-        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._reduce(self.flat.grad[s:e])
+
+    def _reduce(self, t):
+        if self.native is not None:
+            self.native.all_reduce(t)
+        else:
+            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
         """Wait for all outstanding buckets (also reduces every span no stage hook fired for in this step, e.g. 'other' parameters
@@ -107,12 +156,14 @@ class FlatGradAllReduce:
             bad = {n: self._calls.get(n, 0) for n in self.spans if n in STAGES and self._calls.get(n, 0) != 1}
         # drain first, complain afterwards: a failed check must not leave collectives in flight or stale per-step counters behind
         try:
-            if self.world > 1:
+            if self.world > 1 or self.native is not None:
                 for name, (s, e) in sorted(self.spans.items(), key=lambda kv: kv[1]):
                     if name not in self._fired:
-                        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                        self._reduce(self.flat.grad[s:e])
             for h in self.handles:
                 h.wait()
+            if self.native is not None:
+                self.native.wait()
         finally:
             self.handles = []
             self._fired = set()
@@ -129,7 +180,8 @@ class FlatGradAllReduce:
 
     def describe(self):
         """What a benchmark line needs to prove which exchange ran: backend, library version, ranks, bucket sizes in issue order."""
-        info = {"world": self.world, "backend": (dist.get_backend(self.pg) if self.world > 1 else None),
+        info = {"world": self.world, "backend": ("sarssl_allreduce_bucket (RCCL %d)" % self.native.hip.comm_rccl_version() if self.native is not None
+                                                 else dist.get_backend(self.pg) if self.world > 1 else None),
                 "buckets": [{"name": n, "bytes": 4 * (self.spans[n][1] - self.spans[n][0])} for n in STAGES if n in self.spans]}
         if self.world > 1 and info["backend"] == "nccl":
             try:

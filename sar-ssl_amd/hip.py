@@ -1179,6 +1179,51 @@ def step_state_attach(st):
     _lib.call("sarssl_ctx_attach_step_state", c_void_p(_lib._make_current()), _p(st))
 
 
+# ---- collectives behind the C ABI (csrc/comm.hip): RCCL resolved with dlopen, one communicator per (process, device)
+def comm_available():
+    return bool(_lib.lib().sarssl_comm_available())
+
+
+def comm_rccl_version():
+    return int(_lib.lib().sarssl_comm_rccl_version())
+
+
+def comm_unique_id():
+    """128-byte id for comm_create (rank 0 generates it and hands it to the other ranks)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    _lib.call("sarssl_comm_unique_id", buf)
+    return buf.raw
+
+
+def comm_create(nranks, rank, id128):
+    """Communicator of `rank` among `nranks` on torch's current device (collective: every rank calls it with the same id)."""
+    import ctypes
+    assert len(id128) == 128
+    L = _lib.lib()
+    L.sarssl_comm_create.restype = c_void_p
+    c = L.sarssl_comm_create(c_int(nranks), c_int(rank), ctypes.create_string_buffer(bytes(id128), 128))
+    if not c:
+        raise _lib.SarsslHipError("sarssl_comm_create: %s" % L.sarssl_last_error().decode())
+    return c
+
+
+def comm_destroy(comm):
+    _lib.call("sarssl_comm_destroy", c_void_p(comm))
+
+
+def comm_size(comm):
+    return int(_lib.lib().sarssl_comm_size(c_void_p(comm)))
+
+
+def allreduce_bucket(comm, bucket, stream=None):
+    """In-place sum over the communicator's ranks of a contiguous f32 tensor, enqueued on `stream` (default: torch's current)."""
+    _need_cuda(bucket)
+    assert bucket.dtype == torch.float32 and bucket.is_contiguous()
+    st = c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    _lib.call("sarssl_allreduce_bucket", c_void_p(comm), _p(bucket), c_long(bucket.numel()), st)
+
+
 def step_tick(st):
     _lib.call("sarssl_step_tick", _p(st), _stream())
 

@@ -324,3 +324,56 @@ def test_two_rank_training_mode_batchnorm_step_vs_per_replica_oracle(prec):
     # (fp32 measured: relative L2 2.1e-4 over all parameters; single entries of the 3x3 convolution gradients - sums over 16 k pixels of
     #  BatchNorm-centred terms at this toy size - up to 2.6e-3 of the largest gradient entry)
     check("dp2_bn_train.%s.grad_max_err_over_max_grad" % prec, out["max_err_over_max_grad"], 1e-2 if prec == "fp32" else 5e-2)
+
+
+def test_native_rccl_bucket_exchange_at_world_size_one():
+    """§8(b) `sarssl_allreduce_bucket`: the library's own RCCL entry points (csrc/comm.hip, RCCL resolved with dlopen).  One GPU is
+    all there is, so the communicator has ONE rank - where RCCL's all-reduce is a copy: (1) a bucket comes back unchanged, on a side
+    stream, ordered by events; (2) a pretraining forward / backward whose bucket hooks go through the native exchange (dedicated
+    communication stream) yields the gradient of the plain run bit for bit, with every bucket issued before the stem backward ends."""
+    from sar_ssl_amd import dist as sdist, hip, model, runtime
+    dev = torch.device("cuda:0")
+    assert hip.comm_available() and hip.comm_rccl_version() > 0
+    comm = hip.comm_create(1, 0, hip.comm_unique_id())
+    try:
+        assert hip.comm_size(comm) == 1
+        x = torch.randn(1 << 20, device=dev)
+        want = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        hip.allreduce_bucket(comm, x, stream=side)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(x, want)
+    finally:
+        hip.comm_destroy(comm)
+    runtime.set_precision("fp16")
+    try:
+        T, B = 16, 2
+        torch.manual_seed(7)
+        net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev).to(dev)
+        _set_dropout(net, 0.0)
+        flat = runtime.FlatParams(net)
+        g = np.random.default_rng(11)
+        sig = torch.from_numpy(g.standard_normal((B, 512 + 256 * (T - 1), 2)).astype(np.float32)).to(dev)
+        idx = np.stack([np.sort(g.choice(T, T // 2, replace=False)) for _ in range(B)])
+        ch = g.integers(0, 2, size=B)
+
+        def grad():
+            flat.zero_grad()
+            net.set_masks(idx, ch)
+            loss, _, _ = net(hip.stft_frontend(sig))
+            loss.backward()
+
+        red = sdist.FlatGradAllReduce(net, flat, native=True)
+        assert red.native is not None and "sarssl_allreduce_bucket" in red.describe()["backend"]
+        grad()
+        assert red.finish() == 1.0 and red.order == ["decoder", "spat_encoder", "spec_encoder", "stems"]
+        torch.cuda.synchronize()
+        got = flat.grad.clone()
+        red.native.close()
+        net.set_backward_stage_hook(None)
+        grad()
+        torch.cuda.synchronize()
+        assert torch.equal(got, flat.grad) and float(got.abs().max()) > 0
+    finally:
+        runtime.set_precision("fp32")

@@ -25,6 +25,10 @@ def test_cabi_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
     assert lib.sarssl_abi_version() == 2
+    # collectives: RCCL is resolved with dlopen at first use - the answer needs no GPU, and the library loaded without librccl linked in
+    assert lib.sarssl_comm_available() in (0, 1)
+    if lib.sarssl_comm_available():
+        assert lib.sarssl_comm_rccl_version() > 20000
 
 
 def test_state_dict_layout_matches_reference_manifest():
