@@ -573,7 +573,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
             }
     }
     if constexpr (POS) {
-        // sB now holds dS[il][j] (bf16) for the tile's 128 rows and all T keys; element (i, i+1) is not in the image of the shift
+        // sB now holds dS[il][j] (bf16) for the tile's 128 rows and all T keys, rows PB apart.  Re-pitched to T (through registers, in
+        // place) the slab is the un-shifted gradient laid out flat:  dR[i0 + rl][m]  sits at halfword  F = rl * (T+1) + m + i0 - (T-1)
+        // - the reference's pad-and-reshape read backwards - with row -1 (zeros) in front for the entries the previous tile owns.
         const int il = wave * 32 + (lane & 31);
         const int ntile = gridDim.x, q = blockIdx.x;
         const int r1 = i0 + TQ;                                   // first row of the next tile: its "upper" part lives in this tile's last row
@@ -581,11 +583,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
         constexpr int NPART = 256 / DH;
         const int xc = tid % DH, xp = tid / DH;
         float xacc = 0.f;
-        // ---- dqv^T[c][r] = sum_m P^T[c][m] dR[r][m].  The head's positional projection and the tile's 129 qv rows are requested in one
-        //      burst; the projection goes through the K / V / transpose buffers 128 positions at a time
+        // the head's positional projection and the tile's 129 qv rows: one request burst, consumed after the re-pitch
         const h16* Pm = a.pos + h * DH;
         const h16* QV = a.qv + (long)b * T * a.ldq + h * DH;
-        constexpr int NQV = ((TQ + 1) * CPR + 255) / 256;
+        constexpr int NQV = ((TQ + 16) * CPR + 255) / 256;
         uint4 rp[CPR], rqv[NQV];
 #pragma unroll
         for (int c = 0; c < CPR; ++c) {
@@ -595,8 +596,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
 #pragma unroll
         for (int c = 0; c < NQV; ++c) {
             const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-            rqv[c] = (cid < (TQ + 1) * CPR && i0 + row < T) ? *(const uint4*)(QV + (long)(i0 + row) * a.ldq + c8 * 8) : make_uint4(0, 0, 0, 0);
+            rqv[c] = (row <= TQ && i0 + row < T) ? *(const uint4*)(QV + (long)(i0 + row) * a.ldq + c8 * 8) : make_uint4(0, 0, 0, 0);
         }
+        {
+            const int cpr = T >> 3, total = TQ * cpr;
+            uint4 t[16];                                          // (128 rows x T <= 256 columns: at most 16 pieces per thread)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int cid = tid + 256 * u, row = cid / cpr, c8 = cid - row * cpr;
+                t[u] = cid < total ? *(const uint4*)&sB[row * PB + c8 * 8] : make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int cid = tid + 256 * u, row = cid / cpr, c8 = cid - row * cpr;
+                if (cid < total) *(uint4*)&sB[row * T + c8 * 8] = t[u];
+            }
+        }
+        // ---- dqv^T[c][r] = sum_m P^T[c][m] dR[r][m]: a lane's 8 consecutive m are 8 consecutive halfwords of the flat slab at an
+        //      arbitrary 2-byte phase - five aligned dwords and a funnel shift
         f32x16 dqv[DH / 32];
 #pragma unroll
         for (int c = 0; c < DH / 32; ++c)
@@ -604,9 +622,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
             for (int r = 0; r < 16; ++r) dqv[c][r] = 0.f;
         uint16_t* sP = sK;                                        // [128 positions][PT] bf16
         static_assert(2 * TK * PK + TK * PT >= 128 * PT, "position stage must fit the K / V buffers");
-        // dR[r][m] sits at slab index il * PB + (m - (T-1) + i) when that column is >= 0 (own row), else T - PB further on: the previous
-        // row's column m + i + 1 (row -1 = zeros)
-        const int gbase = il * PB + i - (T - 1);
+        const uint32_t* sBw = (const uint32_t*)sB;
+        const int fa0 = il * T + i - (T - 1);                     // + m
+        const uint32_t sh = (uint32_t)(fa0 & 1) * 16u;            // (m advances in steps of 8: the phase is the lane's for the whole pass)
 #pragma unroll
         for (int stage = 0; stage < 2; ++stage) {
             if (stage * 128 < T) {
@@ -619,21 +637,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
                 for (int ks = 0; ks < 8; ++ks) {
                     const int m0 = stage * 128 + ks * 16 + half * 8;
                     if (stage * 128 + ks * 16 >= T) break;
-#ifdef ATTN_EXP_NO_A
-                    if (a.T > 0) break;
-#endif
-                    uint32_t w[4];
+                    const int dw = (fa0 + m0) >> 1;
+                    uint32_t dd[5];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int m = m0 + e;
-                        const int cl = m - (T - 1) + i;
-                        // (unconditional load - a load under a lane condition costs an exec-mask round trip and a wait each - then a select)
-                        const uint32_t ld = (uint32_t)sB[gbase + min(m, T - 1) + (cl < 0 ? T - PB : 0)];
-                        const uint32_t v = m < T ? ld : 0u;
-                        if (e & 1) w[e >> 1] |= v << 16; else w[e >> 1] = v;
-                    }
+                    for (int x = 0; x < 5; ++x) dd[x] = sBw[dw + x];
                     union { uint32_t u[4]; bf16x8 b; } fr;
-                    fr.u[0] = w[0]; fr.u[1] = w[1]; fr.u[2] = w[2]; fr.u[3] = w[3];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) fr.u[x] = m0 < T ? __builtin_amdgcn_alignbit(dd[x + 1], dd[x], sh) : 0u;   // (T % 8 == 0: all in or all out)
 #pragma unroll
                     for (int c = 0; c < DH / 32; ++c) {
                         const bf16x8 pf = tr_frag<PT>(sP, ks * 16, c * 32, lane);
@@ -643,7 +653,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
                 if (has_extra) {                                  // the next tile's first row: plain dot products
                     for (int ml = xp; ml < 128; ml += NPART) {
                         const int m = stage * 128 + ml;
-                        if (m <= T - 2 - r1) xacc += bf16_bits_to_f32(sB[(TQ - 1) * PB + m + r1 + 1]) * bf16_bits_to_f32(sP[ml * PT + xc]);
+                        if (m <= T - 2 - r1) xacc += bf16_bits_to_f32(sB[(TQ - 1) * T + m + r1 + 1]) * bf16_bits_to_f32(sP[ml * PT + xc]);
                     }
                 }
                 __syncthreads();
@@ -679,50 +689,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
             a.dqv_fix[((long)(bh * ntile + q + 1) * 2 + 1) * DH + tid] = t;
         }
         __syncthreads();
-        // ---- dpos^T[c][m] = sum_r qv^T[c][r] dR[r][m], this tile's rows only: "lower" parts against qv rows i, "upper" parts against rows i+1
-        uint16_t* sQ = sK;                                        // [129][PT] bf16
-        static_assert(2 * TK * PK + TK * PT >= (TQ + 1) * PT, "qv rows must fit the K / V buffers");
+        // ---- dpos^T[c][m] = sum_rl qv^T[c][i0 + rl] dR[i0 + rl][m], rl = 0 .. 128: lane = position, 8 consecutive rows are T+1 halfwords apart
+        uint16_t* sQ = sK;                                        // [144][PT] bf16: 129 qv rows, zeros behind them
+        static_assert(2 * TK * PK + TK * PT >= (TQ + 16) * PT, "qv rows must fit the K / V buffers");
 #pragma unroll
         for (int c = 0; c < NQV; ++c) {
             const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-            if (cid < (TQ + 1) * CPR) *(uint4*)&sQ[row * PT + c8 * 8] = recode8<TA, bf16>(rqv[c]);
+            if (cid < (TQ + 16) * CPR) *(uint4*)&sQ[row * PT + c8 * 8] = recode8<TA, bf16>(rqv[c]);
         }
         __syncthreads();
         h16* DP = a.dpos_part + ((long)(b * ntile + q) * T) * ((long)a.H * DH) + h * DH;
-#ifdef ATTN_EXP_NO_B
-        if (a.T > 0) return;
-#endif
+        const int nks = (min(TQ, T - i0) + 15) >> 4;
         for (int mblk = wave; mblk * 32 < T; mblk += 4) {
             const int m = mblk * 32 + (lane & 31);
+            const int fb0 = m + i0 - (T - 1);
             f32x16 acc[DH / 32];
 #pragma unroll
             for (int c = 0; c < DH / 32; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#ifdef ATTN_EXP_NO_B
+            if (a.T > 0) return;
+#endif
+            for (int ks = 0; ks < nks; ++ks) {
+                const int base = fb0 + (ks * 16 + half * 8) * (T + 1);
+                union { uint32_t u[4]; bf16x8 b; } fr;
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                for (int ks = 0; ks < TQ / 16; ++ks) {
-                    const int k0 = ks * 16;
-                    // wave-uniform: any valid (row, position) pair in this 16 x 32 block ?
-                    const bool any = part == 0 ? (mblk * 32 + 31 + i0 + k0 + 15 >= T - 1) : (mblk * 32 + i0 + k0 <= T - 3);
-                    if (!any) continue;
-                    uint32_t w[4];
+                for (int e = 0; e < 8; e += 2)
+                    fr.u[e >> 1] = (uint32_t)sB[base + e * (T + 1)] | ((uint32_t)sB[base + (e + 1) * (T + 1)] << 16);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int ilk = k0 + half * 8 + e, ii = i0 + ilk;
-                        const int col = part == 0 ? m - (T - 1) + ii : m + ii + 2;
-                        const bool ok = part == 0 ? (col >= 0 && m < T && ii < T) : (col <= T - 1);
-                        const uint32_t ld = (uint32_t)sB[ilk * PB + min(max(col, 0), T - 1)];       // unconditional load, then a select
-                        const uint32_t v = ok ? ld : 0u;
-                        if (e & 1) w[e >> 1] |= v << 16; else w[e >> 1] = v;
-                    }
-                    union { uint32_t u[4]; bf16x8 b; } fr;
-                    fr.u[0] = w[0]; fr.u[1] = w[1]; fr.u[2] = w[2]; fr.u[3] = w[3];
+                for (int c = 0; c < DH / 32; ++c) {
+                    const bf16x8 qf = tr_frag<PT>(sQ, ks * 16, c * 32, lane);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, fr.b, acc[c], 0, 0, 0);
+                }
+            }
+            if (has_extra) {                                      // row i0 + 128: only its "upper" part (m <= T-2-r1) lives in this slab
+                const int f = fb0 + TQ * (T + 1);
+                const uint32_t ld = (uint32_t)sB[min(f, TQ * T - 1)];
+                union { uint32_t u[4]; bf16x8 b; } fr;
+                fr.u[0] = (half == 0 && m <= T - 2 - r1) ? ld : 0u;
+                fr.u[1] = 0u; fr.u[2] = 0u; fr.u[3] = 0u;
 #pragma unroll
-                    for (int c = 0; c < DH / 32; ++c) {
-                        const bf16x8 qf = tr_frag<PT>(sQ, k0 + part, c * 32, lane);
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, fr.b, acc[c], 0, 0, 0);
-                    }
+                for (int c = 0; c < DH / 32; ++c) {
+                    const bf16x8 qf = tr_frag<PT>(sQ, TQ, c * 32, lane);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, fr.b, acc[c], 0, 0, 0);
                 }
             }
             if (m < T) {
