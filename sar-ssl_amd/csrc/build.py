@@ -8,6 +8,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip", "comm.hip"]
 LIB = os.path.join(HERE, "libsarssl_hip.so")
+# -munsafe-fp-atomics: the only floating-point atomics left are the f64 `atomicAdd`s of the statistics reductions (BatchNorm sums, loss
+# sums, STFT magnitude sums, first-layer moments: one per (workgroup, channel) after an LDS fold - csrc/stem.hip, conv3x3.hip, dwconv.hip,
+# elementwise.hip, stft.hip); the flag makes them the hardware `global_atomic_add_f64` instead of a compare-and-swap loop.  Their arrival
+# order is not fixed, but every addend is an f32-derived partial accumulated in f64 and the result is rounded back to f32 once, so the
+# step stays bit-reproducible (tests/test_gpu_graph.py); gradient / split-K folds use no atomics at all (slice-ordered reduce launches).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics", "-Wno-unused-result"]
 EXTRA_FLAGS = {}             # per-file extras (none in the product build; tools/gemm_nt/ documents one hipcc 7.2 workaround)
 
