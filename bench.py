@@ -198,6 +198,11 @@ def main():
     ap.add_argument("--eager", action="store_true", help="enqueue the step launch by launch instead of replaying the captured HIP graph")
     ap.add_argument("--graph", action="store_true", help="replay the captured step also when data-parallel (default there: eager launches)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: everything else that writes to file descriptor 1 - RCCL prints a version banner there
+    # from C, buffered until exit - is sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     bad = sorted(k for k in os.environ if k.startswith("SARSSL_ABLATE"))
     if bad:
@@ -211,6 +216,7 @@ def main():
     torch.cuda.set_device(local)
     rank, world, _ = sdist.init_from_env()
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    dp = sdist.exchanging()             # more than one rank - or SARSSL_DIST_FORCE=1: the data-parallel step with a process group of ONE rank
     dev = torch.device("cuda", local)
     runtime.set_precision(args.precision)
     torch.manual_seed(1234)
@@ -254,7 +260,7 @@ def main():
     # captured into HIP graph(s) and replayed - same kernels, same order, one graph launch per step instead of ~450 launches from Python.
     # Data parallel: the segmented replay (four graphs with the RCCL collectives in between) has never run on a multi-GPU node, so the
     # default there is the launch-by-launch step with the overlapped bucket all-reduce (--graph opts in).
-    use_graph = (not args.eager) and (world == 1 or args.graph)
+    use_graph = (not args.eager) and (not dp or args.graph)
     graph = None
     if use_graph:
         from sar_ssl_amd.graph import PretrainStepGraph
@@ -280,7 +286,7 @@ def main():
             return step_eager()
 
     def barrier():
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -333,7 +339,7 @@ def main():
     wall_khz = _lib.lib().sarssl_wall_clock_khz()
     clk_step = clk.cpu().numpy().reshape(5, 4).copy()
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dp:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el[0])
     loss_val = float(last.detach())
@@ -347,8 +353,10 @@ def main():
         return round((s1 - s0) / (r1 - r0) * wall_khz * 1e-6, 3)
 
     dist_info = None
-    if world > 1:
+    if dp:
         dist_info = reducer.describe()
+        if world == 1:
+            dist_info["note"] = "SARSSL_DIST_FORCE=1: one rank - every all-reduce is a copy; this run exercises the RCCL code path, it is not a scaling point"
         ms = reducer.time_buckets(iters=5)
         t = torch.tensor([ms.get(b["name"], 0.0) for b in dist_info["buckets"]], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -450,14 +458,14 @@ def main():
             "host_calls_per_step": round(calls_per_step, 1),
             # (SARSSL_STEM_LAST_ALL_CUS only takes effect on one GPU: under data parallelism both stems keep the 7/8 rule, model.py - the N = 1
             #  point of a scaling curve is therefore this build with the knob on, the N > 1 points are with it off: +1.2 % at N = 1)
-            "knobs": dict(engine.knobs(), STEM_LAST_ALL_CUS_effective=int(engine._STEM_LAST_ALL_CUS and world <= 1)),
+            "knobs": dict(engine.knobs(), STEM_LAST_ALL_CUS_effective=int(engine._STEM_LAST_ALL_CUS and not dp)),
             "parity_class": parity.parity_class(args.precision),
         }
         if dist_info is not None:
             out["dist"] = dist_info
     del graph, state
     if world == 1:
-        want_loop = (not args.no_product_loop or args.via_learner) and args.workload == "config2"
+        want_loop = (not args.no_product_loop or args.via_learner) and args.workload == "config2" and not dp
         if want_loop:
             opt = None
             net._stage_hook = None
@@ -474,8 +482,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dp:
         torch.distributed.barrier()                 # rank 0 may still be printing / timing the isolated kernel
         torch.distributed.destroy_process_group()
 

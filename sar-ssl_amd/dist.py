@@ -23,7 +23,10 @@ def init_from_env(backend=None):
     if torch.cuda.is_available() and torch.cuda.device_count() > 0:
         # select this rank's GPU before the process group exists: RCCL binds a communicator to the current device at its first collective
         torch.cuda.set_device(local % torch.cuda.device_count())
-    if world > 1 and not dist.is_initialized():
+    # SARSSL_DIST_FORCE=1: a process group (and every exchange of the data-parallel step) also at world size 1 - how the RCCL code path
+    # is exercised on a one-GPU box: communicator set-up, the bucket all-reduce kernels on RCCL's stream under the stem backward, the
+    # segmented graph replay with collectives between the graphs; each all-reduce is then a copy
+    if (world > 1 or os.environ.get("SARSSL_DIST_FORCE", "0") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -34,6 +37,13 @@ def init_from_env(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def exchanging():
+    """True when gradients are exchanged between ranks: more than one rank, or SARSSL_DIST_FORCE=1 with a process group of one."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("SARSSL_DIST_FORCE", "0") == "1"
 
 
 STAGES = ("decoder", "spat_encoder", "spec_encoder", "stems")          # order in which backward completes them
@@ -71,7 +81,7 @@ class _NativeExchange:
         from . import hip
         self.hip = hip
         ids = [hip.comm_unique_id() if rank == 0 else None]
-        if world > 1:
+        if world > 1 and dist.is_initialized():
             dist.broadcast_object_list(ids, src=0, group=group)
         self.comm = hip.comm_create(world, rank, ids[0])
         self.stream = torch.cuda.Stream(device=device)
@@ -111,6 +121,7 @@ class FlatGradAllReduce:
         self._closed = True                               # finish() ran: the next hook call starts a new step's record
         self.order = []                                   # stage names in the order their all-reduce was issued in the LAST step (tests)
         self.world = world_size()
+        self.exchange = exchanging()                      # (world > 1, or the forced single-rank process group of the readiness runs)
         # strict: the pretraining backward (model._PretrainFn) reports every stage exactly once per step; anything else means a bucket
         # was exchanged before its gradients were final (or twice) - fail loudly instead of training on a wrong average
         self.strict = bool(getattr(net, "pretrain", False)) if strict is None else bool(strict)
@@ -121,7 +132,7 @@ class FlatGradAllReduce:
             native = os.environ.get("SARSSL_NATIVE_RCCL", "0") == "1"
         self.native = None
         if native and flat.grad.is_cuda:
-            rank = dist.get_rank(process_group) if self.world > 1 else 0
+            rank = dist.get_rank(process_group) if self.exchange else 0
             self.native = _NativeExchange(flat.grad.device, self.world, rank, process_group)
         net.set_backward_stage_hook(self._on_stage)
 
@@ -136,7 +147,7 @@ class FlatGradAllReduce:
         if name in self._fired:
             return
         self.order.append(name)
-        if self.world <= 1 and self.native is None:
+        if not self.exchange and self.native is None:
             return
         self._fired.add(name)
         s, e = self.spans[name]
@@ -156,7 +167,7 @@ class FlatGradAllReduce:
             bad = {n: self._calls.get(n, 0) for n in self.spans if n in STAGES and self._calls.get(n, 0) != 1}
         # drain first, complain afterwards: a failed check must not leave collectives in flight or stale per-step counters behind
         try:
-            if self.world > 1 or self.native is not None:
+            if self.exchange or self.native is not None:
                 for name, (s, e) in sorted(self.spans.items(), key=lambda kv: kv[1]):
                     if name not in self._fired:
                         self._reduce(self.flat.grad[s:e])
@@ -181,9 +192,9 @@ class FlatGradAllReduce:
     def describe(self):
         """What a benchmark line needs to prove which exchange ran: backend, library version, ranks, bucket sizes in issue order."""
         info = {"world": self.world, "backend": ("sarssl_allreduce_bucket (RCCL %d)" % self.native.hip.comm_rccl_version() if self.native is not None
-                                                 else dist.get_backend(self.pg) if self.world > 1 else None),
+                                                 else dist.get_backend(self.pg) if self.exchange else None),
                 "buckets": [{"name": n, "bytes": 4 * (self.spans[n][1] - self.spans[n][0])} for n in STAGES if n in self.spans]}
-        if self.world > 1 and info["backend"] == "nccl":
+        if self.exchange and info["backend"] == "nccl":
             try:
                 info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception as e:                        # (version query is informational only)
@@ -194,7 +205,7 @@ class FlatGradAllReduce:
         """Event-timed all-reduce of every bucket's slice on its own (ms per bucket, max over ranks is the caller's business):
         the exchange a step issues, without the backward it normally hides under.  Scratch copies: gradients are not touched."""
         out = {}
-        if self.world <= 1:
+        if not self.exchange:
             return out
         for n in STAGES:
             if n not in self.spans:

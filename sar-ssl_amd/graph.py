@@ -121,7 +121,7 @@ class PretrainStepGraph:
             return
         world = self.reducer.world if self.reducer is not None else 1
         if seg is not None:
-            if world > 1:
+            if self.reducer is not None and self.reducer.exchange:
                 seg.cut(("finish", None))
         elif self.reducer is not None:
             self.reducer.finish()                          # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
@@ -190,7 +190,7 @@ class PretrainStepGraph:
                 runtime.bump_version()            # every re-laid-out weight cache misses during capture: its rebuild becomes graph nodes
                 seg = _Segments(self, cap)
                 net._stage_hook = seg.on_stage
-                net._cut_mode = self.reducer is not None and self.reducer.world > 1
+                net._cut_mode = self.reducer is not None and self.reducer.exchange
                 hip.step_state_attach(self.state)
                 try:
                     self._seed_ctr0 = RT._ctr               # (tests: the static dropout seeds of the captured launches)
@@ -276,5 +276,5 @@ class _Segments:
 
     def on_stage(self, name):
         red = self.owner.reducer
-        if red is not None and red.world > 1 and name in red.spans:
+        if red is not None and red.exchange and name in red.spans:
             self.cut(("reduce", name))

@@ -230,7 +230,7 @@ class _PretrainFn(torch.autograd.Function):
         # collective kernel holding a few CUs would make the persistent launch's last workgroups start late with their full share of
         # tiles (a convolution workgroup owns its CU's whole register file and LDS - nothing co-resides).
         from . import dist as _dist
-        all_cus = 1 << 16 if (engine._STEM_LAST_ALL_CUS and _dist.world_size() <= 1) else 0
+        all_cus = 1 << 16 if (engine._STEM_LAST_ALL_CUS and not _dist.exchanging()) else 0
         try:        # the override is per host thread (here: autograd's worker) and must not outlive this pass if a launch raises
             hip.conv_cus_override(all_cus if side is None else 0)
             engine.stem_bwd(dz_spec, spe.patch_embed, saved)

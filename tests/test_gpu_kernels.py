@@ -805,7 +805,8 @@ def _attn_mask(B, H, T, dh, p_drop, seed, dev):
 
 @pytest.mark.parametrize("adt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
-@pytest.mark.parametrize("B,H,T,dh", [(2, 4, 256, 128), (3, 4, 40, 64), (1, 2, 624, 64), (2, 4, 64, 32), (1, 4, 136, 128)])
+@pytest.mark.parametrize("B,H,T,dh", [(2, 4, 256, 128), (3, 4, 40, 64), (1, 2, 624, 64), (2, 4, 64, 32), (1, 4, 136, 128),
+                                      (2, 2, 8, 32), (1, 2, 128, 64), (2, 1, 248, 64), (1, 3, 200, 32), (2, 4, 256, 64)])
 def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
     """Positional-score GEMM written in the relative-shift layout + fused attention forward / backward against an f64 torch
     restatement of attention.py:87-113 on the same 16-bit operands (dropout mask read back from the kernel's own hash).  adt = dtype

@@ -288,6 +288,33 @@ def test_two_rank_bench_path_over_gloo():
     assert d["steps_seen_by_reducer"] >= 3 and out["knobs"]["SARSSL_C1IN"] == 1
 
 
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_data_parallel_step_over_rccl_with_a_one_rank_process_group(mode):
+    """RCCL needs one GPU per rank and this box has one: SARSSL_DIST_FORCE=1 runs the DATA-PARALLEL step - NCCL process group,
+    communicator set-up, the four bucket all-reduces issued from the backward-stage hooks on RCCL's stream, max-over-ranks timing,
+    launch by launch and as the segmented graph replay with the collectives between the graphs - with a process group of ONE rank,
+    where every all-reduce is a copy.  What it pins: the RCCL code path executes on the hardware, the loss stays finite, and stdout
+    carries exactly one line (RCCL prints a banner to file descriptor 1 from C)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SARSSL_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("SARSSL_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"]
+    if mode == "graph":
+        cmd.append("--graph")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    d = out["dist"]
+    assert d["world"] == 1 and d["backend"] == "nccl" and d["rccl_version"][0].isdigit() and "one rank" in d["note"]
+    assert [b["name"] for b in d["buckets"]] == ["decoder", "spat_encoder", "spec_encoder", "stems"] and d["steps_seen_by_reducer"] >= 6
+    assert np.isfinite(out["final_loss"]) and out["value"] > 0 and "product_loop" not in out
+    assert out["step_mode"] == ("eager launches" if mode == "eager" else "hipGraph replay (4 graph(s) per step)")
+    assert out["knobs"]["STEM_LAST_ALL_CUS_effective"] == 0             # the data-parallel knob set
+
+
 @pytest.mark.parametrize("two_streams", ["0", "1"])
 def test_two_rank_overlapped_allreduce_equals_full_batch_gradient(two_streams):
     """The overlapped data-parallel path on the real SARSSL (stage hooks issued from the hand-written backward, side stream on/off,

@@ -140,16 +140,22 @@ def main():
         d = H * dh
         qkv = rnd(B * T, 3 * d, dtype=AD)
         qu, dctx = rnd(B * T, d, dtype=AD), rnd(B * T, d, dtype=GD)
-        bias = rnd(B, H, T, T, dtype=AD)
         aflop = 2.0 * 2 * B * H * T * T * dh                        # QK^T + PV
         abytes = 2.0 * (4 * B * T * d + B * H * T * T)
         k_, v_ = qkv[:, d:2 * d], qkv[:, 2 * d:]
-        group(tag, "relpos_attn_fwd dh=%d (B=64,H=4,T=256)" % dh, lambda: hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5), aflop, abytes)
-        ctx, aux = hip.relpos_attn_fwd(qu, k_, v_, bias, B, H, T, dh, 0.044, 0.1, 5)
+        # the product path for T <= 256: positional score formed in the forward kernel, its gradients' products in the dQ kernel
+        qv, posp = rnd(B * T, d, dtype=AD), rnd(T, d, dtype=AD)
+        pflop = 2.0 * B * H * T * T * dh                            # (q + v) P^T
+        group(tag, "relpos_attn_fwd_pos dh=%d (B=64,H=4,T=256; score in-kernel, slab saved)" % dh,
+              lambda: hip.relpos_attn_fwd_pos(qu, qv, k_, v_, posp, B, H, T, dh, 0.044, 0.1, 5), aflop + pflop,
+              2.0 * (5 * B * T * d + B * H * T * T) + 4.0 * B * T * d)
+        ctx, aux, bias = hip.relpos_attn_fwd_pos(qu, qv, k_, v_, posp, B, H, T, dh, 0.044, 0.1, 5)
         dqkv = torch.empty(qkv.shape, dtype=GD, device=dev)
-        group(tag + 1, "relpos_attn_bwd dh=%d (dQ/dbias (+ D) + dK/dV kernels)" % dh,
-              lambda: hip.relpos_attn_bwd(qu, k_, v_, bias, aux, dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, T, dh, 0.044, 0.1, 5),
-              3.5 * aflop, 2.0 * (8 * B * T * d + 2 * B * H * T * T))
+        dqv = torch.empty((B * T, d), dtype=GD, device=dev)
+        group(tag + 1, "relpos_attn_bwd_pos dh=%d (dQ + positional gradients (+ D) + dK/dV kernels)" % dh,
+              lambda: hip.relpos_attn_bwd_pos(qu, qv, k_, v_, posp, bias, aux, dctx, dqkv[:, :d], dqv, dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                                              B, H, T, dh, 0.044, 0.1, 5),
+              3.5 * aflop + 2 * pflop, 2.0 * (10 * B * T * d + 2 * B * H * T * T + 2 * T * d * B))
     # ---- convolution-module tiles (csrc/dwconv.hip)
     d = 512
     hh, dcc = rnd(B * T, 2 * d, dtype=AD), rnd(B * T, d, dtype=GD)
