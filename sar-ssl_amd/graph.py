@@ -17,7 +17,9 @@ What makes a step replayable although launch arguments are frozen at capture:
 Data parallel (world > 1): the collectives stay OUTSIDE the graphs.  The step is cut into segments at the points where a gradient
 bucket becomes final (model._PretrainFn.backward: decoder | Conformer blocks + patch GEMMs | stems); between two segments the
 bucket's all-reduce is issued eagerly (RCCL, its own stream) and runs underneath the next segment - four graph launches and four
-collectives per step instead of ~450 launches.
+collectives per step instead of ~450 launches.  With the library's own exchange (SARSSL_NATIVE_RCCL=1: sarssl_allreduce_bucket on a
+dedicated communication stream forked and joined by events) the collectives are ordinary stream operations and are captured with
+everything else: one graph per step also when data-parallel.  (Both exercised on hardware with a one-rank communicator only.)
 """
 import numpy as np
 import torch
@@ -120,10 +122,11 @@ class PretrainStepGraph:
         if not with_adam:
             return
         world = self.reducer.world if self.reducer is not None else 1
-        if seg is not None:
+        in_graph = self.reducer is not None and getattr(self.reducer, "native", None) is not None
+        if seg is not None and not in_graph:
             if self.reducer is not None and self.reducer.exchange:
                 seg.cut(("finish", None))
-        elif self.reducer is not None:
+        elif self.reducer is not None:                     # (native exchange under capture: the join with the communication stream becomes a graph edge)
             self.reducer.finish()                          # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
                           zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16)
@@ -190,7 +193,7 @@ class PretrainStepGraph:
                 runtime.bump_version()            # every re-laid-out weight cache misses during capture: its rebuild becomes graph nodes
                 seg = _Segments(self, cap)
                 net._stage_hook = seg.on_stage
-                net._cut_mode = self.reducer is not None and self.reducer.exchange
+                net._cut_mode = self.reducer is not None and self.reducer.exchange and getattr(self.reducer, "native", None) is None
                 hip.step_state_attach(self.state)
                 try:
                     self._seed_ctr0 = RT._ctr               # (tests: the static dropout seeds of the captured launches)
@@ -276,5 +279,9 @@ class _Segments:
 
     def on_stage(self, name):
         red = self.owner.reducer
-        if red is not None and red.exchange and name in red.spans:
+        if red is not None and getattr(red, "native", None) is not None:
+            # the library's own RCCL entry point is an ordinary stream operation: the bucket's all-reduce is captured where the hook
+            # fires, on the communication stream forked off by an event - ONE graph per step also when data-parallel
+            red._on_stage(name)
+        elif red is not None and red.exchange and name in red.spans:
             self.cut(("reduce", name))
