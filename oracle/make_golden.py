@@ -504,6 +504,44 @@ def f13_full_batch(ref_model, ref_learner, B=64):
     np.savez_compressed(os.path.join(GOLD, "f13_full_batch.npz"), **store)
 
 
+def f14_full_batch_gradient(ref_model, ref_learner, B=64):
+    """The backward pass at the timed batch size, pinned on the reference itself: `loss.backward()` of the reference (train mode,
+    dropout p = 0, masks from Python's RNG) on F13's batch - per-parameter gradient norms, 48 sampled entries of every parameter's
+    gradient and two BatchNorm running statistics after the step's forward.  (~25 GB of autograd state, a few minutes of CPU.)"""
+    from sar_ssl_amd import synth
+    uniq = synth.make_batch(5000, 16)
+    segs = np.stack([np.roll(uniq[i % 16], 997 * (i // 16), axis=0) for i in range(B)], axis=0)
+    sig = torch.from_numpy(synth.to_pcm16(segs).astype(np.float32) / 32768.0)
+    net = ref_model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device="cpu")
+    man = load_recipe(net, 0)
+    set_dropout(net, 0.0)
+    lrn = ref_learner.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
+    lrn.cpu()
+    x, = lrn.data_preprocess(sig, None)
+    net.train()
+    net.load_state_dict(recipes.recipe_state_dict(man, 0))
+    net.zero_grad()
+    random.seed(31)
+    idx, ch = orc.gen_masks(B, 256, 128, 2, random)
+    random.seed(31)
+    loss, diff, vis = net(x)
+    del vis
+    loss.backward()
+    names, offs, sidx, svals, gn = [], [0], [], [], {}
+    for k, p in net.named_parameters():
+        g = p.grad.reshape(-1)
+        gn[k] = float(g.double().norm())
+        si = sample_idx(g.numel(), min(48, g.numel()), 23)
+        names.append(k); sidx.append(si); svals.append(g[si].numpy().copy()); offs.append(offs[-1] + len(si))
+    store = {"B": B, "weight_seed": 0, "sig_seed": 5000, "mask_seed": 31, "loss": np.float64(loss.item()), "diff": np.float64(diff.item()),
+             "gradnorm_json": np.array(json.dumps(gn)), "names_json": np.array(json.dumps(names)), "sample_offsets": np.array(offs),
+             "sample_idx": np.concatenate(sidx), "sample_vals": np.concatenate(svals), "mask_idx": idx.numpy(), "mask_ch": ch.numpy()}
+    for k in ("spec_encoder.patch_embed.4.running_mean", "spat_encoder.embed.layers.1.sequential.2.module.sequential.5.running_var"):
+        store["after." + k] = net.state_dict()[k].numpy().copy()
+    print("f14 loss", loss.item(), "total grad norm", sum(v * v for v in gn.values()) ** 0.5, flush=True)
+    np.savez_compressed(os.path.join(GOLD, "f14_full_batch_gradient.npz"), **store)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--curve", action="store_true")
@@ -514,7 +552,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_learner, ref_um = ref_shim.load()
-    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
+    todo = a.only.split(",") if a.only else ["manifest", "f1", "f2", "f3", "f4", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14"]
     if "manifest" in todo: f_manifest(ref_model)
     if "f1" in todo: f1_frontend(ref_learner, ref_model)
     if "f2" in todo: f2_blocks(ref_model)
@@ -528,6 +566,7 @@ if __name__ == "__main__":
     if "f12" in todo: f12_pretrain_epoch(ref_model, ref_learner)
     if "f6" in todo: f6_checkpoint(ref_model, ref_learner)
     if "f13" in todo: f13_full_batch(ref_model, ref_learner)
+    if "f14" in todo: f14_full_batch_gradient(ref_model, ref_learner)
     if a.curve: f5_curve(ref_model, ref_learner)
     if a.curve_dropout: f5_curve_dropout(ref_model, ref_learner)
     print("golden vectors written to", GOLD)

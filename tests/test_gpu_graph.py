@@ -200,6 +200,68 @@ def test_full_batch_captured_step_and_eval_forward_vs_the_reference_at_batch_64(
         runtime.set_precision("bf16")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_full_batch_gradient_vs_the_reference_at_batch_64(prec):
+    """Fixture F14 (round 4): the REFERENCE's own `loss.backward()` on the batch bench.py times (B = 64, train mode, dropout 0, the
+    reference's masks) - the backward pass at the timed shape pinned on the reference itself instead of on this repo's fp32 mode:
+    per-parameter gradient norms, 48 sampled entries of every parameter's gradient (relative L2 and cosine over all 13 k samples),
+    total norm, BatchNorm running statistics after the forward.  Only at this shape run the C1IN / C1RED convolution variants, the
+    224-CU gradient grids, the grouped weight-gradient launches at full size and the in-kernel positional gradients at T = 256."""
+    import json, os
+    import recipes
+    from conftest import GOLD
+    from sar_ssl_amd import hip, model, runtime, synth
+    from sar_ssl_amd.parity import GATES
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLD, "f14_full_batch_gradient.npz"))
+    B, T = int(z["B"]), 256
+    uniq = synth.make_batch(int(z["sig_seed"]), 16)
+    segs = np.stack([np.roll(uniq[i % 16], 997 * (i // 16), axis=0) for i in range(B)], axis=0)
+    pcm = torch.from_numpy(synth.to_pcm16(segs)).to(dev)
+    gate = GATES[prec]
+    runtime.set_precision(prec)
+    try:
+        man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+        net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev)
+        net.load_state_dict(recipes.recipe_state_dict(man, int(z["weight_seed"])))
+        _set_dropout(net, 0.0)
+        net.to(dev).train()
+        flat = runtime.FlatParams(net)
+        flat.zero_grad()
+        net.set_masks(z["mask_idx"], z["mask_ch"])
+        loss, diff, _ = net(hip.stft_frontend(pcm))
+        loss.backward()
+        torch.cuda.synchronize()
+        tag = "f14_b64.%s." % prec
+        check(tag + "loss", abs(float(loss) / float(z["loss"]) - 1), gate["loss"])
+        gn = json.loads(str(z["gradnorm_json"]))
+        names, offs = json.loads(str(z["names_json"])), z["sample_offsets"]
+        params = dict(net.named_parameters())
+        top = max(gn.values())
+        worst, got_all, want_all = (0.0, ""), [], []
+        for i, k in enumerate(names):
+            g = params[k].grad.detach().double().reshape(-1).cpu()
+            si = torch.from_numpy(z["sample_idx"][offs[i]:offs[i + 1]])
+            got_all.append(g[si]); want_all.append(torch.from_numpy(z["sample_vals"][offs[i]:offs[i + 1]]).double())
+            if gn[k] < 1e-6 * top:                     # analytically zero in the reference too (e.g. the key-projection bias)
+                assert float(g.norm()) < 1e-4 * top, (k, float(g.norm()), gn[k])
+            else:
+                worst = max(worst, (abs(float(g.norm()) - gn[k]) / gn[k], k))
+        check(tag + "gradnorm[worst=%s]" % worst[1], worst[0], gate["grad_norm"])
+        tot_ref = sum(v * v for v in gn.values()) ** 0.5
+        tot = sum(float(p.grad.double().norm()) ** 2 for p in params.values()) ** 0.5
+        check(tag + "gradnorm_total", abs(tot / tot_ref - 1), 0.25 * gate["grad_norm"])
+        ga, wa = torch.cat(got_all), torch.cat(want_all)
+        check(tag + "sampled_entries_rel_l2", float((ga - wa).norm() / wa.norm()), gate["grad_norm"])
+        check(tag + "sampled_entries_1_minus_cos", 1.0 - float((ga * wa).sum() / (ga.norm() * wa.norm())), 0.5 * gate["grad_norm"] ** 2 + 1e-7)
+        sd = net.state_dict()
+        for k in ("spec_encoder.patch_embed.4.running_mean", "spat_encoder.embed.layers.1.sequential.2.module.sequential.5.running_var"):
+            ref = torch.from_numpy(z["after." + k]).double()
+            check(tag + "bn." + k, float((sd[k].double().cpu() - ref).norm() / ref.norm()), gate["bn_running"])
+    finally:
+        runtime.set_precision("bf16")
+
+
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_16bit_training_is_run_to_run_reproducible_with_dropout_on(prec):
     """Round 3: no floating-point atomics whose order can change a result are left on the training path (statistics epilogues and bias

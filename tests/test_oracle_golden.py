@@ -321,3 +321,19 @@ def test_f13_oracle_forward_at_the_timed_batch_size():
     assert abs(float(loss) / float(z["train.loss"]) - 1) < 1e-5 and abs(float(diff) / float(z["train.diff"]) - 1) < 1e-5
     got = aux["pred"].reshape(-1)[torch.from_numpy(z["train.pred_idx"])]
     assert float((got - torch.from_numpy(z["train.pred_vals"])).abs().max()) < 2e-4 * float(z["train.pred_absmax"])
+
+
+def test_f14_fixture_is_the_backward_of_the_f13_batch():
+    """Fixture F14 (the reference's `loss.backward()` at B = 64; consumed by the `-m gpu` tests): same batch, weights and masks as F13's
+    train-mode forward - the losses agree to the bit - and one entry per parameter of the state-dict manifest.  (The oracle itself is
+    pinned on gradients by F2 / F3; running its backward at B = 64 needs ~25 GB of autograd state and is left to the generator.)"""
+    z13, z14 = _npz("f13_full_batch.npz"), _npz("f14_full_batch_gradient.npz")
+    assert float(z14["loss"]) == float(z13["train.loss"]) and float(z14["diff"]) == float(z13["train.diff"])
+    assert np.array_equal(z14["mask_idx"], z13["mask_idx"]) and np.array_equal(z14["mask_ch"], z13["mask_ch"])
+    names = json.loads(str(z14["names_json"]))
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    params = [k for k in man if not k.endswith(("running_mean", "running_var", "num_batches_tracked", ".pe"))]
+    assert names == params and len(z14["sample_offsets"]) == len(names) + 1 and int(z14["sample_offsets"][-1]) == len(z14["sample_vals"])
+    gn = json.loads(str(z14["gradnorm_json"]))
+    assert set(gn) == set(names) and all(np.isfinite(v) for v in gn.values())
+    assert abs(sum(v * v for v in gn.values()) ** 0.5 - 2.8583218) < 1e-5
