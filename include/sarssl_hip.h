@@ -47,6 +47,11 @@ int sarssl_stft_frontend(const void* sig, int sig_dtype, int nb, long nsample, i
  *      out: (B*npair, 2, 256, nt, 2). */
 int sarssl_stft_frontend_pairs(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft,
                                int nt, float eps, int pair_mode, float* U, double* magsum, float* out, void* stream);
+/* the same followed by sarssl_mask_inputs(mode 0) in ONE pass over the spectrum (code/learner.py:533-551 + code/model.py:541, :563):
+ * mp (B*npair, nt) u8 frame mask, mch (B*npair) i32 masked channel; spec / spat (B*npair, 256, nt, 4) of `dtype` */
+int sarssl_stft_frontend_pairs_masked(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft,
+                                      int nt, float eps, int pair_mode, float* U, double* magsum, float* out, const unsigned char* mp,
+                                      const int* mch, void* spec, void* spat, int dtype, void* stream);
 /*      out: complex64 (B, 257, nt, nch) interleaved, the STFT.forward return value. */
 int sarssl_stft_raw(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop, int nfft, int nt,
                     float* U, double* magsum, float* out, void* stream);

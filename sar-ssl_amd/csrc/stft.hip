@@ -170,6 +170,44 @@ __global__ void frontend_pack_kernel(const float* __restrict__ U, const double* 
     }
 }
 
+// The same with the pretraining masks applied in the same pass (model.py:541, :563 - what sarssl_mask_inputs does to `out`): one thread
+// per (pair, bin, frame) handles both microphones, writes their two `out` entries and the (B, F, T, 4) 16-bit inputs of the two encoders:
+//   spec = x * mask_patch_ch (frame mask on the masked channel, its complement on the other), spat = x * frame mask
+// - bit-identical to the two-launch sequence (the masks multiply the very f32 values that are stored to `out`), one 67 MB read less.
+template <typename T>
+__global__ void frontend_pack_masked_kernel(const float* __restrict__ U, const double* __restrict__ magsum, int nb, int nch, int nt,
+                                            float eps, int pair_mode, int npair, float* __restrict__ out,
+                                            const uint8_t* __restrict__ mp, const int* __restrict__ mch, T* __restrict__ spec,
+                                            T* __restrict__ spat) {
+    const long per = (long)256 * nt;
+    const long total = (long)nb * npair * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long e = i % per;
+        const long bp = i / per;
+        const int p = (int)(bp % npair);
+        const int b = (int)(bp / npair);
+        int c0 = 0, c1 = p + 1;
+        if (pair_mode != 0) {
+            int i0 = 0, rem = p;
+            while (rem >= nch - 1 - i0) { rem -= nch - 1 - i0; ++i0; }
+            c0 = i0; c1 = i0 + 1 + rem;
+        }
+        const float scale = 1.0f / ((float)(magsum[b] / ((double)NBIN * nt)) + eps);
+        const float2 u0 = *(const float2*)(U + ((((long)b * nch + c0) * NBIN) * nt + nt + e) * 2);   // skip DC row
+        const float2 u1 = *(const float2*)(U + ((((long)b * nch + c1) * NBIN) * nt + nt + e) * 2);
+        const float2 m0 = make_float2(u0.x * scale, u0.y * scale), m1 = make_float2(u1.x * scale, u1.y * scale);
+        *(float2*)(out + ((bp * 2 + 0) * per + e) * 2) = m0;
+        *(float2*)(out + ((bp * 2 + 1) * per + e) * 2) = m1;
+        const int t = (int)(e % nt);
+        const float pm = mp[bp * nt + t] ? 1.f : 0.f;
+        const int mc = mch[bp];
+        const float v0 = (mc == 0) ? 0.f : 1.f, v1 = (mc == 1) ? 0.f : 1.f;       // mask_ch_dense per mic
+        const float s0 = (1.f - pm) * v0 + pm * (1.f - v0), s1 = (1.f - pm) * v1 + pm * (1.f - v1);
+        st4(spec + i * 4, make_float4(m0.x * s0, m1.x * s1, m0.y * s0, m1.y * s1));
+        st4(spat + i * 4, make_float4(m0.x * pm, m1.x * pm, m0.y * pm, m1.y * pm));
+    }
+}
+
 // complex64 (B, 257, nt, nch) view of U for the STFT.forward drop-in
 __global__ void stft_permute_kernel(const float* __restrict__ U, int nb, int nch, int nt, float* __restrict__ out) {
     const long total = (long)nb * NBIN * nt * nch;
@@ -212,6 +250,28 @@ extern "C" int sarssl_stft_frontend_pairs(const void* sig, int sig_dtype, int nb
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
     frontend_pack_kernel<<<blocks, 256, 0, st>>>(U, magsum, nb, nch, nt, eps, pair_mode, npair, out);
     SARSSL_CHECK_LAUNCH("frontend_pack_kernel");
+    return 0;
+}
+// data_preprocess + the pretraining input masks in one pass over the spectrum (sarssl_stft_frontend_pairs followed by sarssl_mask_inputs
+// mode 0 on its result): mp (B*npair, nt) u8 frame mask (0 = masked), mch (B*npair) i32 masked channel; spec / spat (B*npair, 256, nt, 4)
+// of `dtype`.
+extern "C" int sarssl_stft_frontend_pairs_masked(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop,
+                                                 int nfft, int nt, float eps, int pair_mode, float* U, double* magsum, float* out,
+                                                 const unsigned char* mp, const int* mch, void* spec, void* spat, int dtype, void* stream) {
+    SARSSL_REQUIRE(win_len == NFFT && nfft == NFFT && hop == HOP, "sarssl_stft_frontend(only win=nfft=512, hop=256)");
+    SARSSL_REQUIRE(nch >= 2 && nb > 0 && nt > 0 && (long)(nt - 1) * HOP + NFFT <= nsample, "sarssl_stft_frontend_pairs_masked");
+    SARSSL_REQUIRE((pair_mode == 0 || pair_mode == 1) && mp && mch && spec && spat, "sarssl_stft_frontend_pairs_masked");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_stft(sig, sig_dtype, nb, nsample, nch, nt, U, magsum, st);
+    if (rc) return rc;
+    const int npair = pair_mode == 0 ? nch - 1 : nch * (nch - 1) / 2;
+    const long total = (long)nb * npair * 256 * nt;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (dtype == SARSSL_F16) frontend_pack_masked_kernel<f16><<<blocks, 256, 0, st>>>(U, magsum, nb, nch, nt, eps, pair_mode, npair, out, mp, mch, (f16*)spec, (f16*)spat);
+    else if (dtype == SARSSL_BF16) frontend_pack_masked_kernel<bf16><<<blocks, 256, 0, st>>>(U, magsum, nb, nch, nt, eps, pair_mode, npair, out, mp, mch, (bf16*)spec, (bf16*)spat);
+    else if (dtype == SARSSL_F32) frontend_pack_masked_kernel<float><<<blocks, 256, 0, st>>>(U, magsum, nb, nch, nt, eps, pair_mode, npair, out, mp, mch, (float*)spec, (float*)spat);
+    else { sarssl_set_error("sarssl_stft_frontend_pairs_masked: dtype"); return -1; }
+    SARSSL_CHECK_LAUNCH("frontend_pack_masked_kernel");
     return 0;
 }
 extern "C" int sarssl_stft_frontend(const void* sig, int sig_dtype, int nb, long nsample, int nch, int win_len, int hop,

@@ -110,13 +110,18 @@ class PretrainStepGraph:
         net = self.net
         if with_adam:
             hip.step_tick(self.state)
-        x = hip.stft_frontend(src) if from_pcm else src
+        if from_pcm:        # front-end and input masks in one pass over the spectrum; the forward below picks the masked inputs up
+            x, spec_in, spat_in = hip.stft_frontend(src, masks=(mp, ch), dtype=RT.dtype)
+            net.__dict__["_premasked"] = (x, spec_in, spat_in)
+        else:
+            x = src
         ctx = _Ctx()
         net.__dict__["_loss_sink"] = (self.out, self.acc)     # (loss, diff) -> self.out, += self.acc inside the loss's finalize launch
         try:
             loss, out, pred = _PretrainFn.forward(ctx, net, x, idx, ch, mp)
         finally:
             net.__dict__.pop("_loss_sink", None)
+            net.__dict__.pop("_premasked", None)
         self.pred, self.xin, self.vis_masks = pred, x, (mp, ch)
         _PretrainFn.backward(ctx, self.one, None, None)
         if not with_adam:

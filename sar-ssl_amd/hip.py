@@ -356,9 +356,11 @@ def gemm_fp8(A8, sa, B8, sb, *, M, N, K, out=None, out_dtype=torch.bfloat16, ldc
     return out
 
 
-def stft_frontend(sig, eps=1e-6, win_len=512, hop=256, nfft=512, ch_mode="M"):
+def stft_frontend(sig, eps=1e-6, win_len=512, hop=256, nfft=512, ch_mode="M", masks=None, dtype=None):
     """(B, nsample, nch) f32|int16 -> (B*npair, 2, nfft/2, nt, 2) f32 (data_preprocess output); ch_mode 'M' pairs mic 0 with
-    every other mic (npair = nch-1), 'MM' takes every mic pair (npair = nch(nch-1)/2)."""
+    every other mic (npair = nch-1), 'MM' takes every mic pair (npair = nch(nch-1)/2).
+    masks = (mp_u8 (B*npair, nt), mch_i32 (B*npair)): also the two encoders' masked inputs of `dtype` in the same pass (what mask_inputs
+    would make of the result) -> (out, spec_in, spat_in)."""
     _need_cuda(sig)
     sig = sig.contiguous()
     nb, nsample, nch = sig.shape
@@ -368,6 +370,16 @@ def stft_frontend(sig, eps=1e-6, win_len=512, hop=256, nfft=512, ch_mode="M"):
     U = torch.empty((nb, nch, nfft // 2 + 1, nt, 2), dtype=torch.float32, device=sig.device)
     magsum = torch.empty((nb,), dtype=torch.float64, device=sig.device)
     out = torch.empty((nb * npair, 2, nfft // 2, nt, 2), dtype=torch.float32, device=sig.device)
+    if masks is not None:
+        mp, mch = masks
+        _need_cuda(mp, mch)
+        assert mp.dtype == torch.uint8 and mch.dtype == torch.int32 and mp.numel() == nb * npair * nt and mch.numel() == nb * npair
+        spec = torch.empty((nb * npair, nfft // 2, nt, 4), dtype=dtype, device=sig.device)
+        spat = torch.empty_like(spec)
+        _lib.call("sarssl_stft_frontend_pairs_masked", _p(sig), c_int(dt(sig)), c_int(nb), c_long(nsample), c_int(nch), c_int(win_len),
+                  c_int(hop), c_int(nfft), c_int(nt), c_float(eps), c_int(mode), _p(U), _p(magsum), _p(out), _p(mp), _p(mch), _p(spec),
+                  _p(spat), c_int(dt(spec)), _stream())
+        return out, spec, spat
     _lib.call("sarssl_stft_frontend_pairs", _p(sig), c_int(dt(sig)), c_int(nb), c_long(nsample), c_int(nch), c_int(win_len),
               c_int(hop), c_int(nfft), c_int(nt), c_float(eps), c_int(mode), _p(U), _p(magsum), _p(out), _stream())
     return out
@@ -436,7 +448,7 @@ def stem_c1_stats(a0, W1, keep_moments=False):
     keep_moments: also return the moments f64[14] in memory of their own (the backward pass reads them, see conv3x3_dgrad_c1red)."""
     npix = a0.numel() // 4
     sums = _sums(128, a0.device)
-    mom = torch.zeros(16, dtype=torch.float64, device=a0.device) if keep_moments else _sums(16, a0.device)
+    mom = torch.empty(16, dtype=torch.float64, device=a0.device) if keep_moments else _sums(16, a0.device)      # (zeroed by the launch wrapper)
     _lib.call("sarssl_stem_c1_stats", _p(a0), c_long(npix), _p(W1), _p(mom), _p(sums), c_int(dt(a0)), _stream())
     return (sums, mom) if keep_moments else sums
 
@@ -445,7 +457,7 @@ def stem_c1_bn_affine(a0, W1, gamma, beta, running_mean, running_var, nbt, eps=1
     """Training-mode BatchNorm(1) affine of y1 = W1 a0 from the input's moments: -> (aff (4,64) f32 = scale | shift | mean | rstd, moments
     f64[14]); running statistics and the batch counter are updated like sarssl_bn_finalize does."""
     npix = a0.numel() // 4
-    mom = torch.zeros(16, dtype=torch.float64, device=a0.device)
+    mom = torch.empty(16, dtype=torch.float64, device=a0.device)               # memory of its own (the backward pass reads it); zeroed by the launch wrapper
     aff = torch.empty((4, 64), dtype=torch.float32, device=a0.device)
     _lib.call("sarssl_stem_c1_stats_affine", _p(a0), c_long(npix), _p(W1), _p(mom), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
               _p(running_mean), _p(running_var), _p(nbt), _p(aff), c_int(dt(a0)), _stream())

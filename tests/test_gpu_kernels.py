@@ -174,6 +174,29 @@ def test_stft_frontend_vs_golden_and_oracle():
 
 
 # ---------------------------------------------------------------- conv stem kernels
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("nch,ch_mode,pcm", [(2, "M", True), (3, "M", False), (4, "MM", True)])
+def test_frontend_with_masks_in_the_same_pass_equals_the_two_launch_sequence(nch, ch_mode, pcm, dtp):
+    """`sarssl_stft_frontend_pairs_masked` (what the captured step calls): data_preprocess output and the two encoders' masked inputs
+    from ONE pass over the spectrum - bit for bit what `stft_frontend` followed by `mask_inputs` (pinned on F1 / the oracle above and
+    below) produce; 2 / 3 / 4 microphones, both pairing modes, int16 PCM and f32 signals, ragged frame count."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(nch * 7 + len(ch_mode))
+    B, nt = 3, 21
+    sig = torch.randn((B, 512 + 256 * (nt - 1) + 37, nch), generator=g) * 0.1
+    sig = (sig * 32767).clamp(-32768, 32767).to(torch.int16) if pcm else sig
+    npair = nch - 1 if ch_mode == "M" else nch * (nch - 1) // 2
+    mp = (torch.rand((B * npair, nt), generator=g) < 0.5).to(torch.uint8).to(dev)
+    ch = torch.randint(0, 2, (B * npair,), generator=g).to(torch.int32).to(dev)
+    x = hip.stft_frontend(sig.to(dev), ch_mode=ch_mode)
+    spec, spat = hip.mask_inputs(x, mp, ch, 0, dtp)
+    x2, spec2, spat2 = hip.stft_frontend(sig.to(dev), ch_mode=ch_mode, masks=(mp, ch), dtype=dtp)
+    assert x2.shape == x.shape and spec2.shape == spec.shape == (B * npair, 256, nt, 4)
+    assert torch.equal(x2, x) and torch.equal(spec2, spec) and torch.equal(spat2, spat)
+    assert float(spec2.float().abs().max()) > 0 and not torch.equal(spec2, spat2)
+
+
 def _cl(x_nchw):          # (B,C,F,T) -> channels-last (B,F,T,C)
     return x_nchw.permute(0, 2, 3, 1).contiguous()
 
