@@ -263,7 +263,7 @@ extern "C" int sarssl_dwglu_wgrad(const void* dc, const void* h, int nb, int Tn,
     dim3 grid((d + DTC - 1) / DTC, parts);
     DW_DISPATCH_GA(dtype, (dwglu_wgrad_kernel<T, TA><<<grid, 256, 0, ST>>>((const T*)dc, (const TA*)h, nb, Tn, d, partial)));
     const long n = (long)d * DWK;
-    dw_partial_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, ST>>>(partial, parts, n, dw);
+    if (dw) dw_partial_reduce_kernel<<<(int)((n + 63) / 64), 256, 0, ST>>>(partial, parts, n, dw);    // (dw == null: the caller folds the partials)
     SARSSL_CHECK_LAUNCH("dwglu_wgrad_kernel");
     return 0;
 }

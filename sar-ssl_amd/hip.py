@@ -886,7 +886,16 @@ def dwglu_wgrad(dc2d, h2d, dw_out, B, T):
     d = dc2d.shape[1]
     fn = _lib.lib().sarssl_dwglu_wgrad_workspace_bytes
     fn.restype = c_long
-    part = workspace(fn(c_int(B), c_int(T), c_int(d)), dc2d.device, "dwglu_part")
+    nbytes = fn(c_int(B), c_int(T), c_int(d))
+    n = dw_out.numel()
+    if _splitk_batch is not None and dw_out.is_contiguous() and n % 4 == 0 and dw_out.data_ptr() % 16 == 0:
+        # inside a block's backward: the per-tile-group partials join the block's ONE fold launch (split-K partials, bias column sums)
+        part = torch.empty((nbytes // 4,), dtype=torch.float32, device=dc2d.device)
+        _lib.call("sarssl_dwglu_wgrad", _p(dc2d), _p(h2d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), c_void_p(0), _p(part),
+                  c_int(dt_ga(dc2d, h2d)), _stream())
+        _splitk_batch.append((part, nbytes // 4 // n, 1, n, dw_out.view(1, n), n))
+        return
+    part = workspace(nbytes, dc2d.device, "dwglu_part")
     _lib.call("sarssl_dwglu_wgrad", _p(dc2d), _p(h2d), c_int(B), c_int(T), c_int(d), c_int(dw_out.shape[-1]), _p(dw_out), _p(part),
               c_int(dt_ga(dc2d, h2d)), _stream())
 
