@@ -90,6 +90,14 @@ class wgrad_block:
         items = _wg_blocks.pop()
         if exc[0] is not None:
             return False
+        # products whose contraction length is no multiple of a K-tile (the positional projection's T rows when T % 64 != 0: config 5)
+        # cannot join the grouped launch (it has no ragged instantiation) - they must not keep the block's other products out of it
+        ragged = [it for it in items if it[0].shape[0] % 64 != 0]
+        items = [it for it in items if it[0].shape[0] % 64 == 0]
+        for dy, x, g2, split, bias in ragged:
+            _wgrad_gemm(dy, x, g2, split)
+            if bias is not None:
+                hip.colsum(dy, bias)
         for i in range(0, len(items), 12):                 # one grouped launch per <= 12 products (csrc/gemm.hip)
             chunk = items[i:i + 12]
             if not (_WGRAD_GROUP and len(chunk) > 1 and hip.gemm_group_tn(chunk)):

@@ -16,19 +16,21 @@ from sar_ssl_amd import hip, model, runtime, synth  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="fp16")
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--workload", default="config2", choices=["config2", "config5"], help="config5: 4 microphones x 10 s, T = 624, batch 16 x 6 pairs")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 runtime.set_precision(a.precision)
 torch.manual_seed(1)
-net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev).to(dev).train()
+T_, nsample_, nmic_, batch_ = (256, 65792, 2, 64) if a.workload == "config2" else (624, 160000, 4, 16)
+net = model.SARSSL(sig_shape=(256, T_, 2, 2), pretrain=True, device=dev).to(dev).train()
 flat = runtime.FlatParams(net)
 opt = runtime.FusedAdam(flat, lr=1e-3)
 opt.zero_grad()
-pcm = torch.from_numpy(synth.to_pcm16(synth.make_batch(0, 64))).to(dev)
+pcm = torch.from_numpy(synth.to_pcm16(synth.make_batch(0, batch_, nsample=nsample_, nch=nmic_))).to(dev)
 
 
 def step():
-    loss, _, _ = net(hip.stft_frontend(pcm))
+    loss, _, _ = net(hip.stft_frontend(pcm, ch_mode="M" if nmic_ == 2 else "MM"))
     loss.backward()
     opt.step()
     opt.zero_grad()
