@@ -315,6 +315,10 @@ int sarssl_masked_mse_fwd(const void* pred, const float* x, const int* idx, cons
  *      (the captured step's running sums, learner.py:104-110) */
 int sarssl_masked_mse_fwd_acc(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
                               double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream);
+/* loss and, in the same pass, its gradient w.r.t. pred for an incoming gradient of 1 (= sarssl_masked_mse_bwd with gscale 1):
+ * dpred (nb, Tn, F*4) of the gradient dtype; dtype: bf16 | f32 | mixed 16 (pred fp16, dpred bf16) */
+int sarssl_masked_mse_fwd_bwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
+                              double* sums, float* out, float* out_keep, double* acc, void* dpred, int dtype, void* stream);
 int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn,
                           int nm, float gscale, const float* gscale_dev, void* dpred, int dtype, void* stream);
 

@@ -641,10 +641,14 @@ __global__ void f64_accum2_kernel(const double* __restrict__ s, float* __restric
 // its own order (64 contiguous bytes per f) - both sides coalesced.  Partial sums go to 64 slots x 2 quantities.
 #define MSE_TT 8
 #define MSE_SLOTS 64
-template <typename T>
+// dpred (optional; TG = gradient dtype): the loss gradient 2 (pred - tar) / count of the same entries, zero elsewhere, written for all
+// eight frames of the workgroup's group - what masked_mse_bwd_kernel computes with an incoming gradient of 1 (the captured step's
+// backward starts right behind this launch; a separate pass re-read pred and x from a stretch of the step nothing overlaps)
+template <typename T, typename TG>
 __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ x,
                                                              const int* __restrict__ idx, const int* __restrict__ mch, int nb,
-                                                             int F, int Tn, int nm, double* __restrict__ sums) {
+                                                             int F, int Tn, int nm, double* __restrict__ sums,
+                                                             TG* __restrict__ dpred = nullptr, float coef = 0.f) {
     extern __shared__ float sp[];                       // [MSE_TT][F * 4]
     __shared__ unsigned smask;
     __shared__ float red[2][4];
@@ -659,8 +663,15 @@ __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict
     }
     __syncthreads();
     const unsigned mask = smask;
-    if (mask == 0u) return;
     const int row = F * 4;
+    if (dpred) {                                        // frames of the group that are not masked: zero gradient rows
+        for (int tl = 0; tl < MSE_TT; ++tl) {
+            if (((mask >> tl) & 1u) || t0 + tl >= Tn) continue;
+            TG* dst = dpred + ((long)b * Tn + t0 + tl) * row;
+            for (int e = threadIdx.x; e < F; e += 256) st4(dst + e * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    if (mask == 0u) return;
     for (int tl = 0; tl < MSE_TT; ++tl) {
         if (!((mask >> tl) & 1u)) continue;
         const T* src = pred + ((long)b * Tn + t0 + tl) * row;
@@ -680,6 +691,19 @@ __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict
         const float p0 = sp[tl * row + f * 4 + mc], p1 = sp[tl * row + f * 4 + 2 + mc];
         l += (p0 - tar.x) * (p0 - tar.x) + (p1 - tar.y) * (p1 - tar.y);
         dsum += (tar.x - oth.x) * (tar.x - oth.x) + (tar.y - oth.y) * (tar.y - oth.y);
+        if (dpred) {                                    // the staged row becomes the gradient row (each thread owns its four entries)
+            float* q = &sp[tl * row + f * 4];
+            q[mc] = coef * (p0 - tar.x); q[2 + mc] = coef * (p1 - tar.y);
+            q[1 - mc] = 0.f; q[3 - mc] = 0.f;
+        }
+    }
+    if (dpred) {
+        __syncthreads();
+        for (int tl = 0; tl < MSE_TT; ++tl) {
+            if (!((mask >> tl) & 1u)) continue;
+            TG* dst = dpred + ((long)b * Tn + t0 + tl) * row;
+            for (int e = threadIdx.x; e < F; e += 256) st4(dst + e * 4, *(const float4*)&sp[tl * row + e * 4]);
+        }
     }
     l = wave_sum(l); dsum = wave_sum(dsum);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -991,12 +1015,18 @@ extern "C" int sarssl_f64_accum(const double* src, float* dst, int n, float scal
 }
 // out: f32[2] = (loss, diff).  sums: f64[128] workspace (zeroed here).
 static int masked_mse_fwd_impl(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
-                               int nm, double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream) {
+                               int nm, double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream,
+                               void* dpred = nullptr) {
     const size_t lds = (size_t)MSE_TT * F * 4 * sizeof(float);
     SARSSL_REQUIRE(nb > 0 && nm > 0 && lds <= 60 * 1024, "sarssl_masked_mse_fwd (F <= 480)");
     const int groups = (Tn + MSE_TT - 1) / MSE_TT;
     if (SARSSL_ZERO(sums, 2 * MSE_SLOTS * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    DISPATCH_T(dtype, (masked_mse_fwd_kernel<T><<<nb * groups, 256, lds, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
+    if (dpred) {
+        const float coef = 2.0f / (float)((double)nb * nm * F * 2);
+        DISPATCH_GA(dtype, (masked_mse_fwd_kernel<TA, T><<<nb * groups, 256, lds, ST>>>((const TA*)pred, x, idx, mch, nb, F, Tn, nm, sums, (T*)dpred, coef)));
+    } else {
+        DISPATCH_T(dtype, (masked_mse_fwd_kernel<T, T><<<nb * groups, 256, lds, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
+    }
     loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out, out_keep, acc);
     SARSSL_CHECK_LAUNCH("masked_mse_fwd_kernel");
     return 0;
@@ -1009,6 +1039,14 @@ extern "C" int sarssl_masked_mse_fwd(const void* pred, const float* x, const int
 extern "C" int sarssl_masked_mse_fwd_acc(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
                                          int nm, double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream) {
     return masked_mse_fwd_impl(pred, x, idx, mch, nb, F, Tn, nm, sums, out, out_keep, acc, dtype, stream);
+}
+// Loss forward AND its gradient w.r.t. pred for an incoming gradient of 1 in one pass over pred / x (gen_loss, code/model.py:585-592, and
+// its backward): dpred (nb, Tn, F*4) of the gradient dtype = what sarssl_masked_mse_bwd(gscale = 1) writes.  dtype: bf16 | f32 | mixed 16.
+extern "C" int sarssl_masked_mse_fwd_bwd(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
+                                         int nm, double* sums, float* out, float* out_keep, double* acc, void* dpred, int dtype,
+                                         void* stream) {
+    SARSSL_REQUIRE(dpred != nullptr, "sarssl_masked_mse_fwd_bwd");
+    return masked_mse_fwd_impl(pred, x, idx, mch, nb, F, Tn, nm, sums, out, out_keep, acc, dtype, stream, dpred);
 }
 // dpred = gscale * dLoss/dpred, loss = mean over nb*nm*F*2 entries
 extern "C" int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F,

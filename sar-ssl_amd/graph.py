@@ -117,10 +117,14 @@ class PretrainStepGraph:
             x = src
         ctx = _Ctx()
         net.__dict__["_loss_sink"] = (self.out, self.acc)     # (loss, diff) -> self.out, += self.acc inside the loss's finalize launch
+        import os
+        if os.environ.get("SARSSL_LOSS_GRAD_FUSED", "1") != "0":     # backward below starts from d(loss) = 1: the loss launch writes dpred too
+            net.__dict__["_loss_grad_with_forward"] = True
         try:
             loss, out, pred = _PretrainFn.forward(ctx, net, x, idx, ch, mp)
         finally:
             net.__dict__.pop("_loss_sink", None)
+            net.__dict__.pop("_loss_grad_with_forward", None)
             net.__dict__.pop("_premasked", None)
         self.pred, self.xin, self.vis_masks = pred, x, (mp, ch)
         _PretrainFn.backward(ctx, self.one, None, None)

@@ -1145,13 +1145,20 @@ def cast(src, dtype, out=None):
     return out
 
 
-def masked_mse_fwd(pred, x, idx_i32, mch_i32, sink=None):
+def masked_mse_fwd(pred, x, idx_i32, mch_i32, sink=None, with_grad=False):
     """pred (B,T,F*4) -> f32[2] device tensor (loss, diff).  sink = (out_keep f32[2], acc f64[2]): the finalize launch also copies the
-    two values into out_keep and adds them to acc (graph.py's running sums)."""
+    two values into out_keep and adds them to acc (graph.py's running sums).  with_grad: -> (out, dpred), the loss gradient for an
+    incoming gradient of 1 from the same pass (what masked_mse_bwd would compute in a pass of its own)."""
     B, _, F, T, _ = x.shape
     nm = idx_i32.shape[1]
     sums = _sums(128, x.device)
     out = torch.empty((2,), dtype=torch.float32, device=x.device)
+    if with_grad:
+        dpred = torch.empty(pred.shape, dtype=gdtype_of(pred.dtype), device=pred.device)
+        keep, acc = sink if sink is not None else (None, None)
+        _lib.call("sarssl_masked_mse_fwd_bwd", _p(pred), _p(x), _p(idx_i32), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm),
+                  _p(sums), _p(out), _p(keep), _p(acc), _p(dpred), c_int(dt_ga(dpred, pred)), _stream())
+        return out, dpred
     if sink is not None:
         keep, acc = sink
         assert keep.dtype == torch.float32 and acc.dtype == torch.float64 and keep.numel() == 2 and acc.numel() == 2

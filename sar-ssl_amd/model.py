@@ -179,7 +179,11 @@ class _PretrainFn(torch.autograd.Function):
         saved.append(saved_spat)
         pred = engine.decoder_fwd(ecat, net.decoder, saved)
         sink = net.__dict__.get("_loss_sink")            # graph.py: (persistent f32[2], running f64[2] sums) filled by the finalize launch
-        out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink)
+        ctx.dpred = None
+        if net.__dict__.get("_loss_grad_with_forward"):  # graph.py: backward follows at once with an incoming gradient of exactly 1
+            out, ctx.dpred = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink, with_grad=True)
+        else:
+            out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink)
         ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds)
         ctx.nparams = len(params)
         ctx.mark_non_differentiable(out, pred)
@@ -190,7 +194,9 @@ class _PretrainFn(torch.autograd.Function):
         net, saved = ctx.net, ctx.saved
         pred, x, mp_u8, ch_i32, nm, ds = ctx.aux
         hip.sums_arena_reset(x.device)
-        dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
+        dpred = getattr(ctx, "dpred", None)
+        if dpred is None:
+            dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
         decat = engine.decoder_bwd(dpred, net.decoder, saved)
         net._after_backward_stage("decoder")
         saved_spat = saved.pop()

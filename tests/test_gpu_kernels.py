@@ -772,6 +772,19 @@ def test_masked_mse_and_adam(dtp):
     assert abs(out[0].item() / loss.item() - 1) < 1e-5 and abs(out[1].item() / diff.item() - 1) < 1e-5
     dpred = hip.masked_mse_bwd(pred.to(dev), x.to(dev), mp.to(torch.uint8).to(dev), ch.to(torch.int32).to(dev), T // 2)
     assert _relerr(dpred.float().reshape(B, T, F, 2, 2), p64.grad) < (1e-5 if dtp == torch.float32 else 1e-2)
+    # loss and its gradient from ONE pass (the captured step): the two launches' results bit for bit, incl. the all-zero rows of
+    # unmasked frames, ragged frame groups (T = 12: groups of 8) and fp16 predictions next to a bf16 gradient
+    for dt2, T2 in ((dtp, T), (dtp, 12), (torch.float16, 12)):
+        x2 = torch.randn((B, 2, F, T2, 2), generator=g).to(dev)
+        pr2 = torch.randn((B, T2, F * 4), generator=g).to(dt2).to(dev)
+        idx2, ch2 = orc.gen_masks(B, T2, T2 // 2, 2)
+        mp2, _ = orc.dense_masks(idx2, ch2, T2, 2)
+        i2, c2 = idx2.to(torch.int32).to(dev), ch2.to(torch.int32).to(dev)
+        o_sep = hip.masked_mse_fwd(pr2, x2, i2, c2)
+        d_sep = hip.masked_mse_bwd(pr2, x2, mp2.to(torch.uint8).to(dev), c2, T2 // 2)
+        o_one, d_one = hip.masked_mse_fwd(pr2, x2, i2, c2, with_grad=True)
+        assert torch.equal(o_one, o_sep) and d_one.dtype == d_sep.dtype and torch.equal(d_one, d_sep)
+        assert float(d_one.float().abs().sum()) > 0
     if dtp == torch.float32:
         n = 1000
         p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g)
