@@ -234,6 +234,12 @@ int sarssl_bn_eval_affine(int C, const float* gamma, const float* beta, float ep
                           const float* running_var, float* scale, float* shift, float* mean, float* rstd, void* stream);
 int sarssl_cl_affine_act(const void* x, long N, int C, const float* scale, const float* shift, int act, void* z, int dtype,
                          void* stream);
+/* sarssl_bn_finalize + sarssl_cl_affine_act in one launch (training-mode BatchNorm + activation of the convolution module,
+ * conformer/convolution.py:141-142): every thread forms its channels' affine from the sums, workgroup 0 writes the rows and moves the
+ * running statistics; bit-identical to the two launches.  C % 8 == 0, C >= 64. */
+int sarssl_cl_bn_train_act(const void* x, long N, int C, const double* sums, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, long* nbt, float* scale, float* shift, float* mean,
+                           float* rstd, int act, void* z, int dtype, void* stream);
 int sarssl_cl_bn_bwd_reduce(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,
                             const float* mean, const float* rstd, int act, double* red, int dtype, void* stream);
 int sarssl_cl_bn_bwd_apply(const void* dz, const void* y, long N, int C, const float* scale, const float* shift,

@@ -833,6 +833,46 @@ __global__ void cl_affine_act_kernel(const T* __restrict__ x, long rows, int L, 
     }
 }
 
+// The same with training-mode BatchNorm's affine formed from the finished sums by every thread for its own 8 channels (bn_finalize_kernel's
+// arithmetic: f64 mean / variance, one rounding to f32 - bit-identical) instead of by a 5-us launch of its own in front of this one;
+// workgroup 0 also writes the affine / statistics rows (the backward pass reads them) and moves the running statistics.  C >= 64 (L == C).
+template <typename T>
+__global__ void cl_bn_train_act_kernel(const T* __restrict__ x, long rows, int C, const double* __restrict__ sums,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var, long* __restrict__ nbt,
+                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                                       float* __restrict__ rstd, int act, T* __restrict__ z) {
+    const int gpr = C >> 3, cg = threadIdx.x % gpr, rslot = threadIdx.x / gpr, rpb = 256 / gpr;
+    const int col = cg * 8;
+    const bool writer = blockIdx.x == 0 && rslot == 0;
+    if (writer && cg == 0 && nbt) *nbt += 1;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = col + e;
+        const double m = sums[ch] / (double)rows;
+        double var = sums[C + ch] / (double)rows - m * m;
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)eps));
+        sc[e] = gamma[ch] * r;
+        sh[e] = beta[ch] - (float)m * gamma[ch] * r;
+        if (writer) {
+            mean[ch] = (float)m; rstd[ch] = r; scale[ch] = sc[e]; shift[ch] = sh[e];
+            if (running_mean) {
+                const double unb = (rows > 1) ? var * (double)rows / (double)(rows - 1) : var;
+                running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+            }
+        }
+    }
+    for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
+        f8 v = ld8(x + n * C + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.v[e] = act_fwd(fmaf(v.v[e], sc[e], sh[e]), act);
+        st8(z + n * C + col, v);
+    }
+}
+
 // BatchNorm(+act) backward, pass 1: g = dz * act'(u), u = y*scale+shift; red[c] += sum g, red[C+c] += sum g*xhat
 template <typename T, typename TA>
 __global__ void cl_bn_bwd_reduce_kernel(const T* __restrict__ dz, const TA* __restrict__ y, long rows, int L, int C,
@@ -1345,6 +1385,19 @@ extern "C" int sarssl_cl_affine_act(const void* x, long N, int C, const float* s
     SARSSL_REQUIRE(cl_view(N, C, &rows, &L) && cl_rowthreads_ok(L), "sarssl_cl_affine_act");
     DISPATCH_T(dtype, (cl_affine_act_kernel<T><<<cl_rowgrid(rows, L), 256, 0, ST>>>((const T*)x, rows, L, C, scale, shift, act, (T*)z)));
     SARSSL_CHECK_LAUNCH("cl_affine_act_kernel");
+    return 0;
+}
+
+// z = act(BatchNorm_train(x)) from the finished sums (sum | sum of squares, f64[2C]) in ONE launch: sarssl_bn_finalize followed by
+// sarssl_cl_affine_act, bit-identical (scale / shift / mean / rstd rows and the running statistics are written by workgroup 0).
+// C % 8 == 0, 64 <= C <= 2048, 256 % (C / 8) == 0.
+extern "C" int sarssl_cl_bn_train_act(const void* x, long N, int C, const double* sums, const float* gamma, const float* beta, float eps,
+                                      float momentum, float* running_mean, float* running_var, long* nbt, float* scale, float* shift,
+                                      float* mean, float* rstd, int act, void* z, int dtype, void* stream) {
+    SARSSL_REQUIRE(N > 0 && C >= 64 && cl_rowthreads_ok(C) && sums && gamma && beta && scale && shift && mean && rstd, "sarssl_cl_bn_train_act");
+    DISPATCH_T(dtype, (cl_bn_train_act_kernel<T><<<cl_rowgrid(N, C), 256, 0, ST>>>((const T*)x, N, C, sums, gamma, beta, eps, momentum, running_mean,
+                                                                                  running_var, nbt, scale, shift, mean, rstd, act, (T*)z)));
+    SARSSL_CHECK_LAUNCH("cl_bn_train_act_kernel");
     return 0;
 }
 

@@ -625,12 +625,16 @@ def convmod_fwd(x, cm, B, T, train, saved):
     if _DWGLU and d % 8 == 0:            # GLU + depthwise conv + BatchNorm batch sums in one LDS-tiled pass (csrc/dwconv.hip)
         c, sums = hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T, want_stats=True) if train else \
             (hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T), None)
-        aff = bn_affine(c, d, bn, train, sums=sums)
+        if train and d >= 64 and 256 % (d // 8) == 0:       # BatchNorm finalize + affine + Swish in one launch (bit-identical to the two)
+            aff, s_act = hip.cl_bn_train_act(c, d, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                             sums, SWISH, eps=bn.eps, momentum=bn.momentum)
+        else:
+            aff, s_act = bn_affine(c, d, bn, train, sums=sums), None
     else:
         g = hip.glu_fwd(h)
         c = hip.dwconv(g.view(B, T, d), dw.weight.data.view(d, -1))
-        aff = bn_affine(c, d, bn, train)
-    s = hip.cl_affine_act(c, d, aff, SWISH).view(B * T, d)
+        aff, s_act = bn_affine(c, d, bn, train), None
+    s = (s_act if s_act is not None else hip.cl_affine_act(c, d, aff, SWISH)).view(B * T, d)
     po = _p(seq[8], train)
     if _replaying(train) and po > 0:                       # the reference draws this mask on the (B, d, T) conv output
         y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data)

@@ -733,6 +733,16 @@ def bn_eval_affine(C, gamma, beta, running_mean, running_var, eps=1e-5):
     return aff
 
 
+def cl_bn_train_act(x, C, gamma, beta, running_mean, running_var, nbt, sums, act, eps=1e-5, momentum=0.1):
+    """bn_train_affine(sums=...) + cl_affine_act in one launch -> (aff (4, C), z)."""
+    aff = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    z = torch.empty_like(x)
+    _lib.call("sarssl_cl_bn_train_act", _p(x), c_long(x.numel() // C), c_int(C), _p(sums), _p(gamma), _p(beta), c_float(eps),
+              c_float(momentum), _p(running_mean), _p(running_var), _p(nbt), _p(aff[0]), _p(aff[1]), _p(aff[2]), _p(aff[3]), c_int(act),
+              _p(z), c_int(dt(x)), _stream())
+    return aff, z
+
+
 def cl_affine_act(x, C, aff, act):
     z = torch.empty_like(x)
     _lib.call("sarssl_cl_affine_act", _p(x), c_long(x.numel() // C), c_int(C), _p(aff[0]), _p(aff[1]), c_int(act), _p(z),

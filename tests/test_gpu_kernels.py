@@ -749,6 +749,27 @@ def test_softmax_relshift(dtp, T):
     assert _relerr(ds2, 0.17 * pr * (dp - (dp * pr).sum(-1, keepdim=True))) < 1e-4
 
 
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,C", [(1000, 256), (4096, 512), (77, 64)])
+def test_batchnorm_finalize_affine_activation_in_one_launch(rows, C, dtp):
+    """`sarssl_cl_bn_train_act` (the convolution module's BatchNorm + Swish, conformer/convolution.py:141-142): affine rows, running
+    statistics, batch counter and the activated output - bit for bit what `sarssl_bn_finalize` + `sarssl_cl_affine_act` produce."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn((rows, C), generator=g) * 1.5 + 0.3).to(dtp).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    sums, N = hip.cl_stats(x, C)
+    st = lambda: (torch.linspace(-1, 1, C).to(dev), torch.linspace(0.5, 2, C).to(dev), torch.tensor(7, device=dev))
+    rm1, rv1, n1 = st()
+    aff1 = hip.bn_train_affine(None, C, gamma, beta, rm1, rv1, n1, sums=sums, N=N)
+    z1 = hip.cl_affine_act(x, C, aff1, 2)
+    rm2, rv2, n2 = st()
+    aff2, z2 = hip.cl_bn_train_act(x, C, gamma, beta, rm2, rv2, n2, sums, 2)
+    assert torch.equal(aff2, aff1) and torch.equal(z2, z1) and torch.equal(rm2, rm1) and torch.equal(rv2, rv1) and int(n2) == int(n1) == 8
+    assert float(z2.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
 def test_masked_mse_and_adam(dtp):
     from sar_ssl_amd import hip
