@@ -126,7 +126,9 @@ int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, const void* 
 int sarssl_relpos_attn_pos_supported(int T, int dh);
 int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos, long ldp,
                                void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh, float scale,
-                               float p_drop, unsigned long long seed, int dtype, void* stream);
+                               float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias, int dtype, void* stream);
+/* u_bias / v_bias (both or neither, f32 [H*dh]; attention.py:54-55): qu == qv == the plain query projection q and the kernels form
+ * q + u / q + v while loading their rows (the values sarssl_bias2 would have stored); same for sarssl_relpos_attn_bwd_pos */
 /* Backward with the positional-score gradients formed in the dQ kernel - no d(bias) tensor, no sarssl_relshift_bwd pass, no batched
  * products after it (attention.py:87-89, 105-113 backward).  bias: the (B,H,T,T) shifted score sarssl_relpos_attn_fwd_pos wrote.
  * dqv [B*T][lddqv]: gradient of q + v_bias through the positional score; dpos_part bf16 (B, ntile, T, H*dh), ntile = ceil(T/128):
@@ -134,7 +136,8 @@ int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const v
 int sarssl_relpos_attn_bwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos, long ldp,
                                const void* bias, const float* ctx32, const float* lse, const void* dctx, long lddc, void* dqu, long lddq,
                                void* dqv, long lddqv, void* dk, void* dv, long lddk, void* dpos_part, float* dqv_fix, float* dsum,
-                               int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed, int dtype, void* stream);
+                               int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed, const float* u_bias,
+                               const float* v_bias, int dtype, void* stream);
 int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, const float* ctx32,
                            const float* lse, const void* dctx, long lddc, void* dqu, long lddq, void* dk, void* dv,
                            long lddk, void* dbias, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,

@@ -42,12 +42,26 @@ struct AttnArgs {
     // gradient of the positional projection; dqv_fix f32 (B*H, ntile, 2, DH): the two halves of the one row per tile boundary whose
     // gradient comes from two workgroups (summed and rounded once by the dK / dV kernel that follows)
     h16* dqv; long lddqv; h16* dpos_part; float* dqv_fix;
+    // ub / vb (optional, f32 [H*DH]): the u / v biases of attention.py:54-55.  When given, `qu` and `qv` both point at the plain query
+    // projection q and every kernel forms q + u / q + v while it loads its rows - in f32, rounded to the forward encoding, i.e. the values
+    // a separate bias pass (sarssl_bias2) would have stored
+    const float* ub; const float* vb;
     int B, H, T;
     float scale, p_drop; unsigned long long seed;
     const unsigned long long* salt;    // device-resident addend of the seed (graph replay), or null
 };
 
 #define LOG2E 1.4426950408889634f
+
+// 8 consecutive 16-bit elements + 8 f32 biases -> the 16-bit encoding of the sums
+template <typename T>
+__device__ __forceinline__ uint4 addb8(const uint4& q, const float* __restrict__ b) {
+    f8 v = unpack8<T>(q);
+    const float4 b0 = *(const float4*)b, b1 = *(const float4*)(b + 4);
+    v.v[0] += b0.x; v.v[1] += b0.y; v.v[2] += b0.z; v.v[3] += b0.w;
+    v.v[4] += b1.x; v.v[5] += b1.y; v.v[6] += b1.z; v.v[7] += b1.w;
+    return pack8<T>(v);
+}
 
 // v_exp_f32 as is: exp2f() wraps it in a denormal-range rescue (compare, two selects, add, ldexp: 7 instructions per probability);
 // a probability below 2^-126 is zero for every purpose here
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
             uint4 u = row_ok ? *(const uint4*)(q + s * 16) : make_uint4(0, 0, 0, 0);
+            if (a.ub && row_ok) u = addb8<TA>(u, a.ub + h * DH + s * 16 + half * 8);
             fq[s] = __builtin_bit_cast(bf16x8, u);
         }
     }
@@ -218,8 +233,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
             const h16* q0 = a.qv + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
 #pragma unroll
             for (int s = 0; s < DH / 16; ++s) {
-                fqv[s] = __builtin_bit_cast(bf16x8, row_ok ? *(const uint4*)(q0 + s * 16) : make_uint4(0, 0, 0, 0));
-                fqvn[s] = __builtin_bit_cast(bf16x8, nx ? *(const uint4*)(q0 + a.ldq + s * 16) : make_uint4(0, 0, 0, 0));
+                uint4 w0 = row_ok ? *(const uint4*)(q0 + s * 16) : make_uint4(0, 0, 0, 0);
+                uint4 w1 = nx ? *(const uint4*)(q0 + a.ldq + s * 16) : make_uint4(0, 0, 0, 0);
+                if (a.vb) {
+                    if (row_ok) w0 = addb8<TA>(w0, a.vb + h * DH + s * 16 + half * 8);
+                    if (nx) w1 = addb8<TA>(w1, a.vb + h * DH + s * 16 + half * 8);
+                }
+                fqv[s] = __builtin_bit_cast(bf16x8, w0);
+                fqvn[s] = __builtin_bit_cast(bf16x8, w1);
             }
         }
         if (half == 0 && row_ok && i + 1 < T) sB[il * PB + i + 1] = 0;          // the zero of the padding column (masked in the key loop anyway)
@@ -433,7 +454,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
         const float* c32 = a.ctx32 + ((long)b * T + (row_ok ? i : 0)) * ((long)a.H * DH) + h * DH + half * 8;
 #pragma unroll
         for (int s = 0; s < DH / 16; ++s) {
-            fq[s] = __builtin_bit_cast(bf16x8, row_ok ? *(const uint4*)(q + s * 16) : make_uint4(0, 0, 0, 0));
+            uint4 qw = row_ok ? *(const uint4*)(q + s * 16) : make_uint4(0, 0, 0, 0);
+            if (a.ub && row_ok) qw = addb8<TA>(qw, a.ub + h * DH + s * 16 + half * 8);
+            fq[s] = __builtin_bit_cast(bf16x8, qw);
             const uint4 du = row_ok ? *(const uint4*)(d + s * 16) : make_uint4(0, 0, 0, 0);
             fdo[s] = __builtin_bit_cast(bf16x8, du);
             const float4 c0 = *(const float4*)(c32 + s * 16), c1 = *(const float4*)(c32 + s * 16 + 4);
@@ -695,7 +718,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
 #pragma unroll
         for (int c = 0; c < NQV; ++c) {
             const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-            if (cid < (TQ + 16) * CPR) *(uint4*)&sQ[row * PT + c8 * 8] = recode8<TA, bf16>(rqv[c]);
+            if (cid < (TQ + 16) * CPR) {
+                uint4 w = rqv[c];
+                if (a.vb && row <= TQ && i0 + row < T) w = addb8<TA>(w, a.vb + h * DH + c8 * 8);
+                *(uint4*)&sQ[row * PT + c8 * 8] = recode8<TA, bf16>(w);
+            }
         }
         __syncthreads();
         h16* DP = a.dpos_part + ((long)(b * ntile + q) * T) * ((long)a.H * DH) + h * DH;
@@ -822,8 +849,10 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < NQD; ++c) {
             const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
-            *(uint4*)&sQ[row * PK + c8 * 8] = rq[c];                         // as saved (score recomputation)
-            *(uint4*)&sQt[row * PT + c8 * 8] = recode8<TA, bf16>(rq[c]);     // bf16 copy for dK += dS^T Q
+            uint4 qw = rq[c];
+            if (a.ub && i0 + row < T) qw = addb8<TA>(qw, a.ub + h * DH + c8 * 8);   // (q + u formed here when the caller passed plain q)
+            *(uint4*)&sQ[row * PK + c8 * 8] = qw;                            // as saved (score recomputation)
+            *(uint4*)&sQt[row * PT + c8 * 8] = recode8<TA, bf16>(qw);        // bf16 copy for dK += dS^T Q
             *(uint4*)&sDO[row * PK + c8 * 8] = rd[c];
             *(uint4*)&sDOt[row * PT + c8 * 8] = rd[c];
         }
@@ -945,15 +974,19 @@ extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, c
 // [B*T][ldq], pos = positional projection [T][ldp] (head h at column h*dh).  bias_out (optional, (B,H,T,T)) receives the shifted score
 // for backward kernels that read it.  T <= 256, T % 8 == 0 (sarssl_relpos_attn_pos_supported).
 extern "C" int sarssl_relpos_attn_pos_supported(int T, int dh) { return (T > 0 && T <= 256 && T % 8 == 0 && (dh == 32 || dh == 64 || dh == 128)) ? 1 : 0; }
+// u_bias / v_bias (both or neither; f32 [H*dh]): qu and qv are then the SAME plain query projection q and the kernels form q + u / q + v
+// while loading (the values sarssl_bias2 would have stored).
 extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
                                           long ldp, void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh,
-                                          float scale, float p_drop, unsigned long long seed, int dtype, void* stream) {
+                                          float scale, float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias,
+                                          int dtype, void* stream) {
+    SARSSL_REQUIRE((u_bias == nullptr) == (v_bias == nullptr) && (!u_bias || qu == qv), "sarssl_relpos_attn_fwd_pos(u_bias / v_bias)");
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_fwd_pos")) return -1;
     SARSSL_REQUIRE(sarssl_relpos_attn_pos_supported(T, dh) && ldp % 8 == 0 && qv && pos, "sarssl_relpos_attn_fwd_pos(T <= 256)");
     SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr && (dtype == SARSSL_BF16 || dtype == SARSSL_F16), "sarssl_relpos_attn_fwd_pos");
     AttnArgs a = {};
     a.qu = (const h16*)qu; a.qv = (const h16*)qv; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk;
-    a.pos = (const h16*)pos; a.ldp = ldp; a.bias_out = (h16*)bias_out;
+    a.pos = (const h16*)pos; a.ldp = ldp; a.bias_out = (h16*)bias_out; a.ub = u_bias; a.vb = v_bias;
     a.ctx = (h16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     dim3 grid((T + 127) / 128, B * H);
     hipStream_t st = (hipStream_t)stream;
@@ -981,14 +1014,15 @@ extern "C" int sarssl_relpos_attn_bwd_pos(const void* qu, const void* qv, long l
                                           long ldp, const void* bias, const float* ctx32, const float* lse, const void* dctx, long lddc,
                                           void* dqu, long lddq, void* dqv, long lddqv, void* dk, void* dv, long lddk, void* dpos_part,
                                           float* dqv_fix, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,
-                                          unsigned long long seed, int dtype, void* stream) {
+                                          unsigned long long seed, const float* u_bias, const float* v_bias, int dtype, void* stream) {
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_bwd_pos")) return -1;
+    SARSSL_REQUIRE((u_bias == nullptr) == (v_bias == nullptr) && (!u_bias || qu == qv), "sarssl_relpos_attn_bwd_pos(u_bias / v_bias)");
     SARSSL_REQUIRE(sarssl_relpos_attn_pos_supported(T, dh) && ldp % 8 == 0 && qv && pos && bias && dqv && dpos_part && dqv_fix, "sarssl_relpos_attn_bwd_pos(T <= 256)");
     SARSSL_REQUIRE(dtype == SARSSL_BF16 || dtype == SARSSL_MIX16, "sarssl_relpos_attn_bwd_pos(dtype: bf16, or MIX16 = fp16 forward tensors + bf16 gradients)");
     SARSSL_REQUIRE(lddc % 8 == 0 && lddq % 4 == 0 && lddqv % 4 == 0 && lddk % 4 == 0 && dsum != nullptr && lse != nullptr && ctx32 != nullptr, "sarssl_relpos_attn_bwd_pos");
     AttnArgs a = {};
     a.qu = (const h16*)qu; a.qv = (const h16*)qv; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk; a.bias = (const h16*)bias;
-    a.pos = (const h16*)pos; a.ldp = ldp;
+    a.pos = (const h16*)pos; a.ldp = ldp; a.ub = u_bias; a.vb = v_bias;
     a.ctx32 = (float*)ctx32; a.lse = (float*)lse; a.dctx = (const h16*)dctx; a.lddc = lddc;
     a.dqu = (h16*)dqu; a.lddq = lddq; a.dk = (h16*)dk; a.dv = (h16*)dv; a.lddk = lddk; a.dsum = dsum;
     a.dqv = (h16*)dqv; a.lddqv = lddqv; a.dpos_part = (h16*)dpos_part; a.dqv_fix = dqv_fix;

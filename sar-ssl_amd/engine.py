@@ -460,18 +460,23 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     ldk = k.stride(0)
     pe = _pe(mod, T)
     pos = mm_nt(pe, wt(att.pos_proj.linear.weight), fp8=False)                               # [T, d]
-    qu, qv = hip.bias2(q, att.u_bias.data.view(-1), att.v_bias.data.view(-1))
     nbh = B * H
     pa = _p(att.dropout, train)
     sa = RT.next_seed() if pa > 0 else 0
     scale = 1.0 / math.sqrt(d)                                                               # 1/sqrt(d_model), attention.py:57
     replay = _replaying(train) and (pa > 0 or _p(mod.dropout, train) > 0)
-    if _FUSED_ATTN and not replay and hip.relpos_attn_supported(T, dh, RT.dtype):
+    fused_attn = _FUSED_ATTN and not replay and hip.relpos_attn_supported(T, dh, RT.dtype)
+    in_kernel = fused_attn and _ATTN_POS and hip.relpos_attn_pos_supported(T, dh, RT.dtype)
+    ub, vb = att.u_bias.data.view(-1), att.v_bias.data.view(-1)
+    # (positional score in the kernels: they also form q + u / q + v while loading the query rows - no biased copies of q)
+    qu, qv = (q, None) if in_kernel else hip.bias2(q, ub, vb)
+    if fused_attn:
         # fused path (csrc/attention.hip): the positional-score GEMM writes its product directly in the relative-shift layout and
         # one flash-style kernel does content score + shifted bias + softmax + dropout + PV; no (B,H,T,T) score / probability tensor
-        if _ATTN_POS and hip.relpos_attn_pos_supported(T, dh, RT.dtype):
+        if in_kernel:
             # T <= 256: the kernel forms the shifted positional score itself (position tiles stream through its K buffer)
-            ctx, lse, bias = hip.relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)
+            ctx, lse, bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference,
+                                                     biases=(ub, vb))
         else:
             bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
             hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
@@ -542,7 +547,9 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
     if fused_attn and _ATTN_POS and hip.relpos_attn_pos_supported(T, dh, RT.dtype):
         # T <= 256: the dQ kernel also forms the positional-score gradients (no d(bias) tensor, un-shift pass or batched products)
         dqv = torch.empty((M, d), dtype=RT.gdtype, device=dev)
-        dposb = hip.relpos_attn_bwd_pos(qu, qv, k, v, pos, p, pd, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, pa, sa)
+        plain_q = qv is None                       # forward saved the plain query projection: the kernels add u / v while loading
+        dposb = hip.relpos_attn_bwd_pos(qu, qu if plain_q else qv, k, v, pos, p, pd, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, pa, sa,
+                                        biases=(att.u_bias.data.view(-1), att.v_bias.data.view(-1)) if plain_q else None)
         return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d,
                               dev, drop=_next_drop(next_kind, saved), dq_out=dqkv[:, :d] if fused is not None else dqu)
     if fused_attn:

@@ -970,10 +970,14 @@ def relpos_attn_pos_supported(T, dh, dtype):
     return dtype in _16 and bool(_lib.lib().sarssl_relpos_attn_pos_supported(c_int(T), c_int(dh)))
 
 
-def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True):
+def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True, biases=None):
     """relpos_attn_fwd with the shifted positional score (qv pos^T, relative shift) formed inside the kernel.  Returns
-    ctx, (ctx32, lse), bias ((B,H,T,T) as the kernel used it; None when need_bwd is False)."""
+    ctx, (ctx32, lse), bias ((B,H,T,T) as the kernel used it; None when need_bwd is False).
+    biases = (u, v) f32 [H*dh]: qu and qv are then the same plain query projection q, the kernel adds the biases while loading."""
     _need_cuda(qu, qv, k, v, pos)
+    ub, vb = biases if biases is not None else (None, None)
+    assert biases is None or (qu.data_ptr() == qv.data_ptr() and ub.dtype == torch.float32 and vb.dtype == torch.float32 and
+                              ub.numel() == H * dh and vb.numel() == H * dh)
     assert k.stride(0) == v.stride(0) and qu.stride(0) == qv.stride(0) and qu.dtype in _16 and \
         all(t.dtype == qu.dtype for t in (qv, k, v, pos)) and pos.stride(1) == 1
     ctx = torch.empty((B * T, H * dh), dtype=qu.dtype, device=qu.device)
@@ -982,7 +986,7 @@ def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
     _lib.call("sarssl_relpos_attn_fwd_pos", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),
               c_long(pos.stride(0)), _p(bias), _p(ctx), c_long(ctx.stride(0)), _p(ctx32), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh),
-              c_float(scale), c_float(p_drop), c_ulonglong(seed), c_int(dt(qu)), _stream())
+              c_float(scale), c_float(p_drop), c_ulonglong(seed), _p(ub), _p(vb), c_int(dt(qu)), _stream())
     return ctx, (ctx32, lse), bias
 
 
@@ -1002,7 +1006,7 @@ def relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqu, dk, dv, B, H, T, dh, scale, 
     return dbias
 
 
-def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0):
+def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0, biases=None):
     """Backward of relpos_attn_fwd_pos with the positional-score gradients formed in the dQ kernel.  Writes dqu / dqv / dk / dv and
     returns dpos_part (B * ntile, T, d): partial gradients of the positional projection (sum over axis 0)."""
     ctx32, lse = aux
@@ -1010,6 +1014,8 @@ def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B,
     assert k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0) and qu.stride(0) == qv.stride(0) and pos.stride(1) == 1 and \
         all(t.dtype == qu.dtype for t in (qv, k, v, pos, bias)) and all(t.dtype == dctx.dtype for t in (dqu, dqv, dk, dv)) and \
         bias.is_contiguous()
+    ub, vb = biases if biases is not None else (None, None)
+    assert biases is None or qu.data_ptr() == qv.data_ptr()
     ntile = (T + 127) // 128
     dpos_part = torch.empty((B * ntile, T, H * dh), dtype=dctx.dtype, device=qu.device)
     dsum = _f32ws(B * H * T, qu.device, "attn_dsum")
@@ -1017,7 +1023,7 @@ def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B,
     _lib.call("sarssl_relpos_attn_bwd_pos", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),
               c_long(pos.stride(0)), _p(bias), _p(ctx32), _p(lse), _p(dctx), c_long(dctx.stride(0)), _p(dqu), c_long(dqu.stride(0)),
               _p(dqv), c_long(dqv.stride(0)), _p(dk), _p(dv), c_long(dk.stride(0)), _p(dpos_part), _p(fix), _p(dsum), c_int(B), c_int(H),
-              c_int(T), c_int(dh), c_float(scale), c_float(p_drop), c_ulonglong(seed), c_int(dt_ga(dctx, qu)), _stream())
+              c_int(T), c_int(dh), c_float(scale), c_float(p_drop), c_ulonglong(seed), _p(ub), _p(vb), c_int(dt_ga(dctx, qu)), _stream())
     return dpos_part
 
 

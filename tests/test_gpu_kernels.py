@@ -959,6 +959,21 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
         check("attn.bwd_pos.dqv[p=%g]" % p_drop, _relerr(dqv, want_dqv), 2e-2)
         assert dpart.shape == (B * ((T + 127) // 128), T, d)
         check("attn.bwd_pos.dpos[p=%g]" % p_drop, _relerr(dpart.double().sum(0), want_dpos), 2e-2)
+        # the same kernels fed the PLAIN query projection and the u / v biases (they add them while loading their rows): bit for bit
+        # what they produce from the biased copies a separate pass (bias2) stores
+        q0 = mk(B * T, 3 * d)[:, :d]                                             # (a column slice: row stride 3d, as in the engine)
+        ub, vb = torch.randn(d, generator=g).to(dev), torch.randn(d, generator=g).to(dev)
+        qu2, qv2 = hip.bias2(q0, ub, vb)
+        ca, auxa, biasa = hip.relpos_attn_fwd_pos(qu2, qv2, k, v, pos, B, H, T, dh, scale, p_drop, seed)
+        cb, auxb, biasb = hip.relpos_attn_fwd_pos(q0, q0, k, v, pos, B, H, T, dh, scale, p_drop, seed, biases=(ub, vb))
+        assert torch.equal(ca, cb) and torch.equal(auxa[0], auxb[0]) and torch.equal(auxa[1], auxb[1]) and torch.equal(biasa, biasb)
+        outs = []
+        for qa, qb, bi in ((qu2, qv2, None), (q0, q0, (ub, vb))):
+            o = [torch.full((B * T, d), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(4)]
+            part = hip.relpos_attn_bwd_pos(qa, qb, k, v, pos, biasa, auxa, dctx, o[0], o[1], o[2], o[3], B, H, T, dh, scale, p_drop, seed,
+                                           biases=bi)
+            outs.append(o + [part])
+        assert all(torch.equal(x1, x2) for x1, x2 in zip(*outs)) and not torch.isnan(outs[1][1].float()).any()
         # per row: the tile-boundary row (128) is assembled from two workgroups' halves
         rows = (dqv.double() - want_dqv).view(B, T, d).norm(dim=-1) / want_dqv.view(B, T, d).norm(dim=-1).clamp_min(1e-30)
         check("attn.bwd_pos.dqv_worst_row[p=%g]" % p_drop, rows.max().item(), 5e-2)
