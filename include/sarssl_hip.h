@@ -137,7 +137,9 @@ int sarssl_relpos_attn_bwd_pos(const void* qu, const void* qv, long ldq, const v
                                const void* bias, const float* ctx32, const float* lse, const void* dctx, long lddc, void* dqu, long lddq,
                                void* dqv, long lddqv, void* dk, void* dv, long lddk, void* dpos_part, float* dqv_fix, float* dsum,
                                int B, int H, int T, int dh, float scale, float p_drop, unsigned long long seed, const float* u_bias,
-                               const float* v_bias, int dtype, void* stream);
+                               const float* v_bias, void* dq_sum, long lddq_sum, int dtype, void* stream);
+/* dq_sum (optional, [B*T][lddq_sum], not aliasing dqu / dqv): dqu + dqv - the gradient of the query projection - written by the dK / dV
+ * kernel (what sarssl_axpby2d would make of the two tensors in a launch of its own) */
 int sarssl_relpos_attn_bwd(const void* qu, long ldq, const void* k, const void* v, long ldk, const void* bias, const float* ctx32,
                            const float* lse, const void* dctx, long lddc, void* dqu, long lddq, void* dk, void* dv,
                            long lddk, void* dbias, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,

@@ -46,6 +46,9 @@ struct AttnArgs {
     // projection q and every kernel forms q + u / q + v while it loads its rows - in f32, rounded to the forward encoding, i.e. the values
     // a separate bias pass (sarssl_bias2) would have stored
     const float* ub; const float* vb;
+    // dq_sum (optional, [B*T][lddq_sum]): dqu + dqv, the gradient of the query projection, written by the dK / dV kernel for its 128 rows
+    // after the boundary row is final (bf16 + bf16 in f32, rounded: what sarssl_axpby2d makes of the two tensors)
+    h16* dq_sum; long lddq_sum;
     int B, H, T;
     float scale, p_drop; unsigned long long seed;
     const unsigned long long* salt;    // device-resident addend of the seed (graph replay), or null
@@ -930,6 +933,20 @@ __global__ __launch_bounds__(256) void relpos_attn_bwd_kv_kernel(AttnArgs a) {
         const float* fx = a.dqv_fix + ((long)(bh * gridDim.x + blockIdx.x) * 2) * DH;
         a.dqv[((long)b * T + j0) * a.lddqv + h * DH + tid] = (h16)(pack2_bf16(fx[tid] + fx[DH + tid], 0.f) & 0xffffu);
     }
+    if (a.dq_sum) {
+        __syncthreads();                                          // (the boundary row above is one of the addends)
+        for (int cid = tid; cid < TKB * CPR; cid += 256) {
+            const int row = cid / CPR, c8 = cid % CPR;
+            if (j0 + row < T) {
+                const long r = (long)b * T + j0 + row;
+                f8 x = unpack8<bf16>(*(const uint4*)(a.dqu + r * a.lddq + h * DH + c8 * 8));
+                const f8 y = unpack8<bf16>(*(const uint4*)(a.dqv + r * a.lddqv + h * DH + c8 * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x.v[e] += y.v[e];
+                *(uint4*)(a.dq_sum + r * a.lddq_sum + h * DH + c8 * 8) = pack8<bf16>(x);
+            }
+        }
+    }
 }
 
 // C ABI ----------------------------------------------------------------------------------------------------------------------
@@ -1014,7 +1031,8 @@ extern "C" int sarssl_relpos_attn_bwd_pos(const void* qu, const void* qv, long l
                                           long ldp, const void* bias, const float* ctx32, const float* lse, const void* dctx, long lddc,
                                           void* dqu, long lddq, void* dqv, long lddqv, void* dk, void* dv, long lddk, void* dpos_part,
                                           float* dqv_fix, float* dsum, int B, int H, int T, int dh, float scale, float p_drop,
-                                          unsigned long long seed, const float* u_bias, const float* v_bias, int dtype, void* stream) {
+                                          unsigned long long seed, const float* u_bias, const float* v_bias, void* dq_sum, long lddq_sum,
+                                          int dtype, void* stream) {
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_bwd_pos")) return -1;
     SARSSL_REQUIRE((u_bias == nullptr) == (v_bias == nullptr) && (!u_bias || qu == qv), "sarssl_relpos_attn_bwd_pos(u_bias / v_bias)");
     SARSSL_REQUIRE(sarssl_relpos_attn_pos_supported(T, dh) && ldp % 8 == 0 && qv && pos && bias && dqv && dpos_part && dqv_fix, "sarssl_relpos_attn_bwd_pos(T <= 256)");
@@ -1026,6 +1044,8 @@ extern "C" int sarssl_relpos_attn_bwd_pos(const void* qu, const void* qv, long l
     a.ctx32 = (float*)ctx32; a.lse = (float*)lse; a.dctx = (const h16*)dctx; a.lddc = lddc;
     a.dqu = (h16*)dqu; a.lddq = lddq; a.dk = (h16*)dk; a.dv = (h16*)dv; a.lddk = lddk; a.dsum = dsum;
     a.dqv = (h16*)dqv; a.lddqv = lddqv; a.dpos_part = (h16*)dpos_part; a.dqv_fix = dqv_fix;
+    SARSSL_REQUIRE(!dq_sum || (lddq % 8 == 0 && lddqv % 8 == 0 && lddq_sum % 8 == 0 && dq_sum != dqu && dq_sum != dqv), "sarssl_relpos_attn_bwd_pos(dq_sum)");
+    a.dq_sum = (h16*)dq_sum; a.lddq_sum = lddq_sum;
     a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     hipStream_t st = (hipStream_t)stream;
     dim3 gq((T + 127) / 128, B * H), gk((T + 127) / 128, B * H);

@@ -548,10 +548,12 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
         # T <= 256: the dQ kernel also forms the positional-score gradients (no d(bias) tensor, un-shift pass or batched products)
         dqv = torch.empty((M, d), dtype=RT.gdtype, device=dev)
         plain_q = qv is None                       # forward saved the plain query projection: the kernels add u / v while loading
+        dq_out = dqkv[:, :d] if fused is not None else None      # dq = dqu + dqv written by the dK / dV kernel (needs a buffer of its own)
         dposb = hip.relpos_attn_bwd_pos(qu, qu if plain_q else qv, k, v, pos, p, pd, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, pa, sa,
-                                        biases=(att.u_bias.data.view(-1), att.v_bias.data.view(-1)) if plain_q else None)
+                                        biases=(att.u_bias.data.view(-1), att.v_bias.data.view(-1)) if plain_q else None, dq_sum=dq_out)
         return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d,
-                              dev, drop=_next_drop(next_kind, saved), dq_out=dqkv[:, :d] if fused is not None else dqu)
+                              dev, drop=_next_drop(next_kind, saved), dq_out=dq_out if dq_out is not None else dqu,
+                              dq_done=dq_out is not None)
     if fused_attn:
         dbias = hip.relpos_attn_bwd(qu, k, v, p, pd, dctx, dqu, dk, dv, B, H, T, dh, scale, pa, sa)      # p = bias, pd = (ctx32, lse) here
         dps = hip.relshift_bwd(dbias)                                                        # d (unshifted) pos score
@@ -593,7 +595,8 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
     return dps
 
 
-def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None, dq_out=None):
+def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None, dq_out=None,
+                   dq_done=False):
     """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
     if dposb.dtype == RT.gdtype:                                     # batch sum straight into the GEMM operand's dtype: one launch
         dpos_rt = hip.colsum_store(dposb.view(dposb.shape[0], T * d)).view(T, d)      # (B rows, or B * ntile partials of the fused backward)
@@ -607,7 +610,7 @@ def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb
     inplace = dq_out.data_ptr() == dqu.data_ptr()                    # dq = dqu + dqv overwrites dqu: its column sum has to run first
     hip.colsum(dqu, gbuf(att.u_bias).view(-1), now=inplace)
     hip.colsum(dqv, gbuf(att.v_bias).view(-1))
-    dq = hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dq_out)
+    dq = dq_out if dq_done else hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dq_out)      # (dq_done: the attention backward wrote dqu + dqv itself)
     if fused is not None:
         mm_tn_acc(dqkv, ln, fused[2], bias=fused[3])
         dln = mm_nn(dqkv, fused[0])

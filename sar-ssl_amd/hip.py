@@ -1006,7 +1006,8 @@ def relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqu, dk, dv, B, H, T, dh, scale, 
     return dbias
 
 
-def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0, biases=None):
+def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0, biases=None,
+                        dq_sum=None):
     """Backward of relpos_attn_fwd_pos with the positional-score gradients formed in the dQ kernel.  Writes dqu / dqv / dk / dv and
     returns dpos_part (B * ntile, T, d): partial gradients of the positional projection (sum over axis 0)."""
     ctx32, lse = aux
@@ -1023,7 +1024,8 @@ def relpos_attn_bwd_pos(qu, qv, k, v, pos, bias, aux, dctx, dqu, dqv, dk, dv, B,
     _lib.call("sarssl_relpos_attn_bwd_pos", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),
               c_long(pos.stride(0)), _p(bias), _p(ctx32), _p(lse), _p(dctx), c_long(dctx.stride(0)), _p(dqu), c_long(dqu.stride(0)),
               _p(dqv), c_long(dqv.stride(0)), _p(dk), _p(dv), c_long(dk.stride(0)), _p(dpos_part), _p(fix), _p(dsum), c_int(B), c_int(H),
-              c_int(T), c_int(dh), c_float(scale), c_float(p_drop), c_ulonglong(seed), _p(ub), _p(vb), c_int(dt_ga(dctx, qu)), _stream())
+              c_int(T), c_int(dh), c_float(scale), c_float(p_drop), c_ulonglong(seed), _p(ub), _p(vb), _p(dq_sum),
+              c_long(dq_sum.stride(0) if dq_sum is not None else 0), c_int(dt_ga(dctx, qu)), _stream())
     return dpos_part
 
 

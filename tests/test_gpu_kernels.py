@@ -969,11 +969,13 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
         assert torch.equal(ca, cb) and torch.equal(auxa[0], auxb[0]) and torch.equal(auxa[1], auxb[1]) and torch.equal(biasa, biasb)
         outs = []
         for qa, qb, bi in ((qu2, qv2, None), (q0, q0, (ub, vb))):
-            o = [torch.full((B * T, d), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(4)]
+            o = [torch.full((B * T, d), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(5)]
             part = hip.relpos_attn_bwd_pos(qa, qb, k, v, pos, biasa, auxa, dctx, o[0], o[1], o[2], o[3], B, H, T, dh, scale, p_drop, seed,
-                                           biases=bi)
+                                           biases=bi, dq_sum=o[4])
             outs.append(o + [part])
         assert all(torch.equal(x1, x2) for x1, x2 in zip(*outs)) and not torch.isnan(outs[1][1].float()).any()
+        # dq = dqu + dqv from the dK / dV kernel (after the boundary row is final): the separate add launch's result bit for bit
+        assert torch.equal(outs[0][4], hip.axpby2d(outs[0][0], outs[0][1], 1.0, 1.0))
         # per row: the tile-boundary row (128) is assembled from two workgroups' halves
         rows = (dqv.double() - want_dqv).view(B, T, d).norm(dim=-1) / want_dqv.view(B, T, d).norm(dim=-1).clamp_min(1e-30)
         check("attn.bwd_pos.dqv_worst_row[p=%g]" % p_drop, rows.max().item(), 5e-2)
