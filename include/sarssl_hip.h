@@ -269,6 +269,11 @@ int sarssl_dwglu_wgrad(const void* dc, const void* h, int nb, int Tn, int d, int
  *      (attention.py:87-113), u/v bias add (attention.py:87-88) */
 int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps, void* y,
                          long ldy, float* mean, float* rstd, int dtype, void* stream);
+/* a Conformer block's closing LayerNorm followed by the first LayerNorm of the next block's feed-forward module (Conformer.py:88-90,
+ * feed_forward.py:48) in one launch: y = LN_a(x), z = LN_b(y as stored); bit-identical to two sarssl_layernorm_fwd launches */
+int sarssl_layernorm_fwd2(const void* x, long ldx, long M, int d, const float* gamma_a, const float* beta_a, float eps_a, void* y, long ldy,
+                          float* mean_a, float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b, void* z, long ldz,
+                          float* mean_b, float* rstd_b, int dtype, void* stream);
 long sarssl_layernorm_bwd_workspace_bytes(long M, int d);
 int sarssl_layernorm_bwd(const void* dy, long lddy, const void* x, long ldx, long M, int d, const float* gamma,
                          const float* mean, const float* rstd, const void* resid, long ldr, void* dx, long lddx,

@@ -68,6 +68,61 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
+// Two LayerNorms in a row on the same data - a Conformer block's closing LayerNorm and the first one of the next block's feed-forward
+// module (Conformer.py:88-90, feed_forward.py:48): y = LN_a(x) is stored (rounded to T), z = LN_b(y as stored) - the arithmetic of two
+// launches of the kernel above, bit for bit, in one pass over the row.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const T* __restrict__ x, long ldx, long M, int d,
+                                                             const float* __restrict__ ga, const float* __restrict__ ba, float epsa,
+                                                             T* __restrict__ y, long ldy, float* __restrict__ meana, float* __restrict__ rstda,
+                                                             const float* __restrict__ gb, const float* __restrict__ bb, float epsb,
+                                                             T* __restrict__ z, long ldz, float* __restrict__ meanb, float* __restrict__ rstdb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;
+    for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+        float4 v[LN_MAXV];
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c4 = lane + i * 64;
+            if (c4 < nv) v[i] = ld4(x + row * ldx + c4 * 4);
+        }
+#pragma unroll
+        for (int stage = 0; stage < 2; ++stage) {
+            const float* gamma = stage ? gb : ga; const float* beta = stage ? bb : ba;
+            const float eps = stage ? epsb : epsa;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) { const int c4 = lane + i * 64; if (c4 < nv) s += v[i].x + v[i].y + v[i].z + v[i].w; }
+            const float mu = wave_sum(s) / (float)d;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c4 = lane + i * 64;
+                if (c4 < nv) {
+                    const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, e = v[i].w - mu;
+                    q += a * a + b * b + c * c + e * e;
+                }
+            }
+            const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+            T* out = stage ? z : y; const long ldo = stage ? ldz : ldy;
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c4 = lane + i * 64;
+                if (c4 < nv) {
+                    const float4 g = *(const float4*)(gamma + c4 * 4), be = *(const float4*)(beta + c4 * 4);
+                    const float4 o = make_float4((v[i].x - mu) * rs * g.x + be.x, (v[i].y - mu) * rs * g.y + be.y,
+                                                 (v[i].z - mu) * rs * g.z + be.z, (v[i].w - mu) * rs * g.w + be.w);
+                    st4(out + row * ldo + c4 * 4, o);
+                    // the next stage reads the row as it was stored
+                    v[i] = make_float4(round_as<T>(o.x), round_as<T>(o.y), round_as<T>(o.z), round_as<T>(o.w));
+                }
+            }
+            float* mean = stage ? meanb : meana; float* rstd = stage ? rstdb : rstda;
+            if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+        }
+    }
+}
+
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ resid);  dgamma += sum dy*xhat, dbeta += sum dy
 // Two rows per wave are in flight at a time (loads of both issued before either reduction) to hide HBM latency.
 template <typename T, typename TA, int NV>
@@ -799,6 +854,17 @@ extern "C" int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, cons
     const int nblk = nblocks_for(M, 4, 4096);
     DISPATCH_T(dtype, (layernorm_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)x, ldx, M, d, gamma, beta, eps, (T*)y, ldy, mean, rstd)));
     SARSSL_CHECK_LAUNCH("layernorm_fwd_kernel");
+    return 0;
+}
+// y = LN_a(x), z = LN_b(y) in one launch (bit-identical to two sarssl_layernorm_fwd launches); statistics of both are saved
+extern "C" int sarssl_layernorm_fwd2(const void* x, long ldx, long M, int d, const float* gamma_a, const float* beta_a, float eps_a,
+                                     void* y, long ldy, float* mean_a, float* rstd_a, const float* gamma_b, const float* beta_b,
+                                     float eps_b, void* z, long ldz, float* mean_b, float* rstd_b, int dtype, void* stream) {
+    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldz & 3) == 0, "sarssl_layernorm_fwd2");
+    const int nblk = nblocks_for(M, 4, 4096);
+    DISPATCH_T(dtype, (layernorm_fwd2_kernel<T><<<nblk, 256, 0, ST>>>((const T*)x, ldx, M, d, gamma_a, beta_a, eps_a, (T*)y, ldy, mean_a, rstd_a,
+                                                                     gamma_b, beta_b, eps_b, (T*)z, ldz, mean_b, rstd_b)));
+    SARSSL_CHECK_LAUNCH("layernorm_fwd2_kernel");
     return 0;
 }
 static inline int ln_bwd_blocks(long M) { return nblocks_for(M, 4 * 8, 512); }

@@ -337,7 +337,11 @@ def _replaying(train):
 def ffn_fwd(x, ff, factor, train, saved, out=None):
     """x + factor * FeedForwardModule(x)  (conformer/feed_forward.py:47-57, Conformer.py:60-67)."""
     seq = ff.sequential
-    ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+    pre = _PRE_LN.pop(x.data_ptr(), None)           # (block_fwd of the previous block already normalised this very tensor for us)
+    if pre is not None and pre[0] is seq[0]:
+        ln, stats = pre[1], pre[2]
+    else:
+        ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
     hpre = torch.empty((x.shape[0], seq[1].linear.weight.shape[0]), dtype=x.dtype, device=x.device)
     if _replaying(train) and (p1 > 0 or p2 > 0):          # host-drawn masks in the reference's order: hidden, then output
@@ -685,14 +689,25 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
                              drop=_next_drop(next_kind, saved))
 
 
-def block_fwd(x, blk, B, T, train, saved, out=None):
-    """ConformerBlock (code/common/Conformer.py:59-91)."""
+_LN_PAIR = os.environ.get("SARSSL_LN_PAIR", "1") != "0"       # 0: the two LayerNorms of a block boundary as two launches (A/B runs)
+_PRE_LN = {}          # data_ptr of a block's output -> (LayerNorm module, its output, its statistics) computed by the previous block's closing launch
+
+
+def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None):
+    """ConformerBlock (code/common/Conformer.py:59-91).  next_blk: the block that consumes the result - its first LayerNorm (the
+    feed-forward module's) is applied by this block's closing LayerNorm launch (two row passes in one kernel, bit-identical)."""
     seq = blk.sequential
     x = ffn_fwd(x, seq[0].module, seq[0].module_factor, train, saved)
     x = mhsa_fwd(x, seq[1].module, B, T, train, saved)
     x = convmod_fwd(x, seq[2].module, B, T, train, saved)
     x = ffn_fwd(x, seq[3].module, seq[3].module_factor, train, saved)
-    y, stats = hip.layernorm_fwd(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
+    if next_blk is not None and out is None and _LN_PAIR:
+        nln = next_blk.sequential[0].module.sequential[0]
+        y, stats, z, zstats = hip.layernorm_fwd2(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps)
+        _PRE_LN.clear()
+        _PRE_LN[y.data_ptr()] = (nln, z, zstats)
+    else:
+        y, stats = hip.layernorm_fwd(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
     saved.append((x, stats))
     return y
 
@@ -718,7 +733,7 @@ def encoder_fwd(x, enc, B, T, train, saved, out=None):
     """ConformerEncoder.forward, add_same_one=False (code/common/Conformer.py:165-195)."""
     n = len(enc.layers)
     for i, blk in enumerate(enc.layers):
-        x = block_fwd(x, blk, B, T, train, saved, out=out if i == n - 1 else None)
+        x = block_fwd(x, blk, B, T, train, saved, out=out if i == n - 1 else None, next_blk=enc.layers[i + 1] if i + 1 < n else None)
     return x
 
 

@@ -781,6 +781,20 @@ def layernorm_fwd(x2d, gamma, beta, eps=1e-5, out=None, save=True):
     return out, stats
 
 
+def layernorm_fwd2(x2d, ga, ba, epsa, gb, bb, epsb, out=None):
+    """y = LN_a(x), z = LN_b(y) in one launch -> (y, stats_a, z, stats_b); the results of two layernorm_fwd calls bit for bit."""
+    M, d = x2d.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+    z = torch.empty((M, d), dtype=x2d.dtype, device=x2d.device)
+    sa = torch.empty((2, M), dtype=torch.float32, device=x2d.device)
+    sb = torch.empty((2, M), dtype=torch.float32, device=x2d.device)
+    _lib.call("sarssl_layernorm_fwd2", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d), _p(ga), _p(ba), c_float(epsa), _p(out),
+              c_long(out.stride(0)), _p(sa[0]), _p(sa[1]), _p(gb), _p(bb), c_float(epsb), _p(z), c_long(z.stride(0)), _p(sb[0]), _p(sb[1]),
+              c_int(dt(x2d)), _stream())
+    return out, sa, z, sb
+
+
 _ln_batch = None              # list of (partials, nparts, d, dgamma, dbeta) while an ln_reduce_batched() context is open
 
 

@@ -165,13 +165,15 @@ class _PretrainFn(torch.autograd.Function):
             e_spec = engine.stem_fwd(spec_in, spe.patch_embed, train, saved)
             nl = len(spa.embed.layers)
             with torch.cuda.stream(side):
-                e_spat = engine.block_fwd(e_spat, spa.embed.layers[0], B, T, train, saved_spat, out=ecat[:, ds:] if nl == 1 else None)
+                e_spat = engine.block_fwd(e_spat, spa.embed.layers[0], B, T, train, saved_spat, out=ecat[:, ds:] if nl == 1 else None,
+                                          next_blk=spa.embed.layers[1] if nl > 1 else None)
             assert len(spe.embed.layers) == 1
             engine.block_fwd(e_spec, spe.embed.layers[0], B, T, train, saved, out=ecat[:, :ds])
             with torch.cuda.stream(side):
                 for li in range(1, nl):
                     e_spat = engine.block_fwd(e_spat, spa.embed.layers[li], B, T, train, saved_spat,
-                                              out=ecat[:, ds:] if li == nl - 1 else None)
+                                              out=ecat[:, ds:] if li == nl - 1 else None,
+                                              next_blk=spa.embed.layers[li + 1] if li + 1 < nl else None)
             main.wait_stream(side)
         else:
             net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])

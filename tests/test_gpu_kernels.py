@@ -750,6 +750,22 @@ def test_softmax_relshift(dtp, T):
 
 
 @pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,d", [(1000, 256), (333, 512), (64, 32), (50, 1024)])
+def test_two_layernorms_in_one_launch(M, d, dtp):
+    """`sarssl_layernorm_fwd2` (a block's closing LayerNorm + the next block's first): both outputs and both statistics bit for bit
+    what two `sarssl_layernorm_fwd` launches produce."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + d)
+    x = (torch.randn((M, d), generator=g) * 1.7 - 0.4).to(dtp).to(dev)
+    ga, ba, gb, bb = [(torch.randn(d, generator=g) * 0.3 + (1.0 if i % 2 == 0 else 0.0)).to(dev) for i in range(4)]
+    y1, s1 = hip.layernorm_fwd(x, ga, ba, 1e-5)
+    z1, t1 = hip.layernorm_fwd(y1, gb, bb, 1e-5)
+    y2, s2, z2, t2 = hip.layernorm_fwd2(x, ga, ba, 1e-5, gb, bb, 1e-5)
+    assert torch.equal(y2, y1) and torch.equal(s2, s1) and torch.equal(z2, z1) and torch.equal(t2, t1)
+
+
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("rows,C", [(1000, 256), (4096, 512), (77, 64)])
 def test_batchnorm_finalize_affine_activation_in_one_launch(rows, C, dtp):
     """`sarssl_cl_bn_train_act` (the convolution module's BatchNorm + Swish, conformer/convolution.py:141-142): affine rows, running
