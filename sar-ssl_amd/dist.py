@@ -189,6 +189,22 @@ class FlatGradAllReduce:
             warnings.warn(msg + " (world size 1: nothing was exchanged)")
         return 1.0 / self.world
 
+    def close(self):
+        """Teardown: detach from the model and destroy the library communicator of the native exchange (ncclCommDestroy)."""
+        if self.native is not None:
+            self.native.wait()
+            self.native.close()
+            self.native = None
+        if getattr(self.net, "_stage_hook", None) == self._on_stage:
+            self.net.set_backward_stage_hook(None)
+
+    def __del__(self):
+        try:
+            if self.native is not None:
+                self.native.close()
+        except Exception:
+            pass
+
     def describe(self):
         """What a benchmark line needs to prove which exchange ran: backend, library version, ranks, bucket sizes in issue order."""
         info = {"world": self.world, "backend": ("sarssl_allreduce_bucket (RCCL %d)" % self.native.hip.comm_rccl_version() if self.native is not None

@@ -19,7 +19,9 @@ bucket becomes final (model._PretrainFn.backward: decoder | Conformer blocks + p
 bucket's all-reduce is issued eagerly (RCCL, its own stream) and runs underneath the next segment - four graph launches and four
 collectives per step instead of ~450 launches.  With the library's own exchange (SARSSL_NATIVE_RCCL=1: sarssl_allreduce_bucket on a
 dedicated communication stream forked and joined by events) the collectives are ordinary stream operations and are captured with
-everything else: one graph per step also when data-parallel.  (Both exercised on hardware with a one-rank communicator only.)
+everything else: one graph per step - at world size 1 (the form that has run on hardware) or with SARSSL_NATIVE_RCCL_CAPTURE=1; with
+more ranks the native exchange is issued between the segment graphs like torch.distributed's until a captured RCCL kernel has run on a
+multi-GPU node.  The segmented replay is the data-parallel default since round 5 (bit-equal to the eager step at world 2 and 4).
 """
 import numpy as np
 import torch
@@ -131,14 +133,25 @@ class PretrainStepGraph:
         if not with_adam:
             return
         world = self.reducer.world if self.reducer is not None else 1
-        in_graph = self.reducer is not None and getattr(self.reducer, "native", None) is not None
+        in_graph = self._exchange_in_graph()
         if seg is not None and not in_graph:
-            if self.reducer is not None and self.reducer.exchange:
+            if self.reducer is not None and (self.reducer.exchange or getattr(self.reducer, "native", None) is not None):
                 seg.cut(("finish", None))
         elif self.reducer is not None:                     # (native exchange under capture: the join with the communication stream becomes a graph edge)
             self.reducer.finish()                          # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
                           zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16)
+
+    def _exchange_in_graph(self):
+        """True when the bucket all-reduces are captured INSIDE the step graph: the library's own exchange (sarssl_allreduce_bucket,
+        SARSSL_NATIVE_RCCL=1) - and only at world size 1 unless SARSSL_NATIVE_RCCL_CAPTURE=1 says otherwise.  With more than one rank
+        a captured RCCL kernel has never run (no multi-GPU node in five rounds): there the native exchange is issued BETWEEN the
+        segment graphs like torch.distributed's, which is the form the 2- and 4-rank tests pin (advisor, round 4)."""
+        import os
+        red = self.reducer
+        if red is None or getattr(red, "native", None) is None:
+            return False
+        return red.world == 1 or os.environ.get("SARSSL_NATIVE_RCCL_CAPTURE", "0") == "1"
 
     def step_eager(self, x=None, pcm=None):
         """The same step enqueued launch by launch (inputs whose shape differs from the captured one, e.g. a ragged last batch):
@@ -202,7 +215,13 @@ class PretrainStepGraph:
                 runtime.bump_version()            # every re-laid-out weight cache misses during capture: its rebuild becomes graph nodes
                 seg = _Segments(self, cap)
                 net._stage_hook = seg.on_stage
-                net._cut_mode = self.reducer is not None and self.reducer.exchange and getattr(self.reducer, "native", None) is None
+                # cut mode: the spat / spec hooks fire on the ORIGIN stream after the side stream has joined it.  Needed where the graph is
+                # cut at a bucket boundary, and also when the exchange is captured: its communication stream must fork off the origin
+                # stream, not off the already-forked side stream (a fork of a fork crashes hipStreamEndCapture on ROCm 7.2,
+                # tools/capture_nested_fork_repro.py)
+                in_graph = self._exchange_in_graph()
+                net._cut_mode = in_graph or (self.reducer is not None and (self.reducer.exchange or getattr(self.reducer, "native", None) is not None))
+                seg.in_graph = in_graph
                 hip.step_state_attach(self.state)
                 try:
                     self._seed_ctr0 = RT._ctr               # (tests: the static dropout seeds of the captured launches)
@@ -286,11 +305,13 @@ class _Segments:
         self.plan.append(action)
         self.begin()
 
+    in_graph = False
+
     def on_stage(self, name):
         red = self.owner.reducer
-        if red is not None and getattr(red, "native", None) is not None:
+        if red is not None and self.in_graph:
             # the library's own RCCL entry point is an ordinary stream operation: the bucket's all-reduce is captured where the hook
             # fires, on the communication stream forked off by an event - ONE graph per step also when data-parallel
             red._on_stage(name)
-        elif red is not None and red.exchange and name in red.spans:
+        elif red is not None and (red.exchange or getattr(red, "native", None) is not None) and name in red.spans:
             self.cut(("reduce", name))

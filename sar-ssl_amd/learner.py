@@ -96,11 +96,10 @@ class Learner(ABC):
         """The captured step (graph.py) is the default training step on one GPU; SARSSL_GRAPH=0, replayed dropout masks (parity
         fixtures that need the reference's draw order), models without the pretraining node and models with frozen parameters (the
         captured Adam pass updates the whole flat buffer) fall back to the launch-by-launch step.  Data parallel (world > 1): the
-        segmented replay with RCCL collectives between the graph launches has only ever run over gloo with two ranks on one GPU
-        (tests/test_gpu_graph.py) - until it has run on a multi-GPU node it is opt-in (SARSSL_GRAPH=1), the default there is the
-        launch-by-launch step with the overlapped bucket all-reduce."""
-        default = "1" if sdist.world_size() == 1 else "0"
-        return (os.environ.get("SARSSL_GRAPH", default) != "0" and runtime.RT.replay is None and getattr(self.model, "pretrain", False)
+        segmented replay - four graph launches with the bucket all-reduces between them - is the default too since round 5 (bit-equal
+        to the launch-by-launch step at world 2 and 4, tests/test_gpu_graph.py; the eager step leaves the host only 25 % of margin per
+        rank with eight ranks on one host); SARSSL_GRAPH=0 opts out."""
+        return (os.environ.get("SARSSL_GRAPH", "1") != "0" and runtime.RT.replay is None and getattr(self.model, "pretrain", False)
                 and self._flat is not None and self._flat.on_gpu and all(p.requires_grad for p in self._flat.params))
 
     def _graph_takes_raw_batch(self, sig):

@@ -1,11 +1,14 @@
 """Pretraining entry point with the reference's command line (code/run_pretrain.py):
 
     python run_pretrain.py --pretrain --simu-exp --gpu-id 0,                      # one GPU
-    torchrun --nproc-per-node 8 run_pretrain.py --pretrain --simu-exp --gpu-id 0,1,2,3,4,5,6,7 [--use-amp]
+    python run_pretrain.py --pretrain --simu-exp --gpu-id 0,1,2,3,4,5,6,7 [--use-amp]       # eight GPUs, the reference's own form
+    torchrun --nproc-per-node 8 run_pretrain.py --pretrain --simu-exp --gpu-id 0,1,2,3,4,5,6,7 [--use-amp]     # same thing
 
 Only the ``--pretrain --simu-exp`` branch (fixed pre-generated simulated segments) is implemented - the path BASELINE.json
-names.  Multi-GPU = one process per GPU under torchrun (RCCL), not DataParallel; per-epoch scalars go to a JSONL log
-(tensorboardX is optional and absent here).
+names.  Multi-GPU = one process per GPU over RCCL, not DataParallel (code/learner.py:25-31): with more than one id in ``--gpu-id``
+and no launcher in the environment this entry point starts its own ranks (launch.py) before anything touches the GPU, like the
+reference's single command (code/run_pretrain.py:204-205); per-epoch scalars go to a JSONL log (tensorboardX is optional and absent
+here).
 """
 import json
 import os
@@ -21,8 +24,14 @@ def main(argv=None):
     opts = opt_pretrain()
     args = opts.parse(argv)
     dirs = opts.dir()
-    if "LOCAL_RANK" not in os.environ:
-        os.environ["HIP_VISIBLE_DEVICES"] = ",".join(g for g in args.gpu_id.split(",") if g != "")
+    from sar_ssl_amd import launch
+    gpu_ids = launch.parse_gpu_ids(args.gpu_id)
+    if not launch.launched():
+        if len(gpu_ids) > 1 and not args.no_cuda and not args.test:
+            # one rank per listed GPU; this process only waits for them (it has not initialised HIP and never will)
+            raise SystemExit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), len(gpu_ids),
+                                                gpu_ids=gpu_ids))
+        os.environ["HIP_VISIBLE_DEVICES"] = ",".join(gpu_ids[:1]) if gpu_ids else ""
 
     import torch
     from sar_ssl_amd import dataset as at_dataset, learner as at_learner, model as at_model, dist as sdist

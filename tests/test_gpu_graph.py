@@ -97,6 +97,51 @@ def test_graph_step_equals_eager_step(prec):
         runtime.set_precision("bf16")
 
 
+@pytest.mark.parametrize("form", ["captured", "between_graphs"])
+def test_step_with_the_native_rccl_exchange_equals_the_eager_step(form, monkeypatch):
+    """Advisor (round 4): the library's own exchange (sarssl_allreduce_bucket, SARSSL_NATIVE_RCCL) inside the captured step had no test.
+    One GPU = a one-rank communicator, where RCCL's all-reduce is a copy - so the step with the exchange must equal the plain eager
+    step bit for bit (fp32 mode), in both forms: 'captured' = the four bucket all-reduces are nodes of ONE graph, their communication
+    stream forked off the ORIGIN stream after the encoder streams have joined (never off the forked side stream); 'between_graphs' =
+    what every world > 1 gets until a captured RCCL kernel has run on a multi-GPU node: four graphs, the exchange issued eagerly in
+    between.  Also: close() destroys the communicator and detaches the hook."""
+    from sar_ssl_amd import dist as sdist, runtime
+    from sar_ssl_amd.graph import PretrainStepGraph
+    runtime.set_precision("fp32")
+    try:
+        T, B, n = 16, 4, 4
+        xs = _batches(T, n, B)
+        net_a, flat_a = _make(T, 21, 0.0)
+        opt = runtime.FusedAdam(flat_a, lr=1e-3)
+        opt.zero_grad()
+        random.seed(5)
+        ref = []
+        for x in xs:
+            loss, diff, _ = net_a(x)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            ref.append(float(loss))
+        net_b, flat_b = _make(T, 21, 0.0)
+        red = sdist.FlatGradAllReduce(net_b, flat_b, native=True)
+        assert red.native is not None and red.world == 1
+        g = PretrainStepGraph(net_b, flat_b, red, lr=1e-3)
+        if form == "between_graphs":
+            monkeypatch.setattr(g, "_exchange_in_graph", lambda: False)
+        random.seed(5)
+        got = [float(g.step(x=x)[0]) for x in xs]
+        torch.cuda.synchronize()
+        ngraphs = sum(1 for k, _ in g._plan if k == "graph")
+        assert ngraphs == (1 if form == "captured" else 4), g._plan
+        assert red.order == ["decoder", "spat_encoder", "spec_encoder", "stems"] and red.nsteps >= 1
+        assert got == ref, (got, ref)
+        assert torch.equal(flat_a.flat, flat_b.flat)
+        red.close()
+        assert red.native is None and net_b._stage_hook is None
+    finally:
+        runtime.set_precision("bf16")
+
+
 @pytest.mark.parametrize("fast", ["fp16", "bf16"])
 def test_full_batch_captured_16bit_step_against_the_fp32_mode(fast):
     """The configuration bench.py times (BASELINE config 2: B = 64, 65 792 samples, T = 256, fp16 forward / bf16 backward - or bf16 -, captured step, two encoder

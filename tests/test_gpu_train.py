@@ -281,7 +281,7 @@ def test_two_rank_bench_path_over_gloo():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak" and out["value"] > 0
     assert np.isfinite(out["final_loss"]) and "cpu_baseline" not in out and "product_loop" not in out
-    assert out["step_mode"] == "eager launches"                      # data parallel: the captured step is opt-in (--graph)
+    assert out["step_mode"] == "hipGraph replay (4 graph(s) per step)"   # data parallel default since round 5: the segmented replay
     d = out["dist"]
     assert d["world"] == 2 and d["backend"] == "gloo" and [b["name"] for b in d["buckets"]] == ["decoder", "spat_encoder", "spec_encoder", "stems"]
     assert sum(b["bytes"] for b in d["buckets"]) > 70e6 and all(b["allreduce_ms_alone"] > 0 for b in d["buckets"])
@@ -300,8 +300,8 @@ def test_data_parallel_step_over_rccl_with_a_one_rank_process_group(mode):
     env = dict(os.environ, SARSSL_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.pop("SARSSL_DIST_BACKEND", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"]
-    if mode == "graph":
-        cmd.append("--graph")
+    if mode == "eager":
+        cmd.append("--eager")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
