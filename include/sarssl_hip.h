@@ -99,6 +99,27 @@ int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* cons
                          const long* lda, const long* ldb, const int* split_k, int* split_out, float* const* csum_ws, int n_prob,
                          int dtB, void* stream);       /* dtB: dtype of every X_q (bf16 | fp16); dY_q is bf16 */
 
+/* ---- fused feed-forward module (round 5): FeedForwardModule.forward, code/common/conformer/feed_forward.py:47-54, under the half-step
+ *      residual of ConformerBlock (code/common/Conformer.py:60-67) - Linear(d, 4d) + Swish + Dropout + Linear(4d, d) + Dropout as ONE
+ *      launch per 64-row tile (csrc/ffn2.hip): the [64, 4d] hidden tile never travels through HBM as an operand.  Replaces the pair of
+ *      sarssl_gemm launches (bias + Swish + dropout + saved pre-activation | bias + dropout + scaled residual); dropout masks are the same
+ *      function of (seed, row * N + column).  M % 64 == 0, d in {256, 512} (sarssl_ffn2_supported), else use sarssl_gemm.
+ *      Weights are read from PACKS in MFMA fragment order (sarssl_ffn_pack: block (n / 32, k / 16) = 64 lanes x 8 elements, lane l =
+ *      row 32 nb + (l & 31), k = 16 ks + 8 (l >> 5) ..): src(n, k) = src[n * rs + k * cs], so rs / cs select a matrix or its transpose;
+ *      up to 32 matrices per launch; 16-bit elements.
+ *      forward:  y = resid + out_scale * drop(p2, s2)(W2 drop(p1, s1)(swish(W1 ln + b1)) + b2); preact, hidden: [M][4d] saved for backward.
+ *                w1p = pack(W1 [4d x d]), w2p = pack(W2 [d x 4d]); dtype SARSSL_F16 | SARSSL_BF16 (every 16-bit tensor).
+ *      backward: dh = (dz2 W2) * dropmask(p1, s1) * swish'(preact) [M][4d] (operand of both weight-gradient products), dln = dh W1 [M][d];
+ *                w2tp = pack(W2^T [4d x d]), w1tp = pack(W1^T [d x 4d]); dtype SARSSL_BF16 | SARSSL_MIX16 (bf16 gradients, fp16 preact). */
+int sarssl_ffn2_supported(long M, int d);
+int sarssl_ffn_pack(const void* const* src, void* const* dst, const int* N, const int* K, const long* rs, const long* cs, int n_mat,
+                    void* stream);
+int sarssl_ffn2_fwd(const void* ln, long ldln, const void* w1p, const void* w2p, const float* b1, const float* b2, void* preact,
+                    void* hidden, void* y, long ldy, const void* resid, long ldr, long M, int d, float p1, unsigned long long s1,
+                    float p2, unsigned long long s2, float out_scale, int dtype, void* stream);
+int sarssl_ffn2_bwd(const void* dz2, long lddz, const void* w2tp, const void* w1tp, const void* preact, void* dh, void* dln, long lddln,
+                    long M, int d, float p1, unsigned long long s1, int dtype, void* stream);
+
 /* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
  *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as
  *      sarssl_gemm.  sarssl_fp8_quantize: x [rows][cols] (f32 | bf16, row stride ld) -> q fp8 [rows][cols] or (transpose) [cols][rows],

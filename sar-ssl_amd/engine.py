@@ -258,7 +258,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
@@ -334,6 +334,56 @@ def _replaying(train):
     return train and RT.replay is not None
 
 
+_FFN2 = os.environ.get("SARSSL_FFN2", "1") != "0"             # 0: the feed-forward module as two GEMM launches (A/B runs)
+# Model widths that take the fused forward / backward launch.  Default: d = 256 only (the spat encoder - the step's critical chain).  The
+# fused launch owns whole CUs (512 threads, 101-134 KB of LDS); at d = 512 (spec encoder) it runs 100-160 us during which the other
+# encoder's stream gets no CU, and the step is SLOWER with it (same box, two rounds: off 10.69 / 10.70 ms, d = 256 only 10.64 / 10.59,
+# d = 512 only 10.86 / 10.83, both 10.78 / 10.71) although the launch itself beats its two GEMMs alone (101 vs 121 us forward).
+_FFN2_FWD = set(int(v) for v in os.environ.get("SARSSL_FFN2_FWD", "256").split(",") if v)
+_FFN2_BWD = set(int(v) for v in os.environ.get("SARSSL_FFN2_BWD", "256").split(",") if v)
+
+
+def prepare_ffn_packs(ffs, need_bwd=True):
+    """Fragment-order packs of the feed-forward modules' weights for the fused kernel (csrc/ffn2.hip): W1, W2 in the forward dtype and,
+    for the backward launch, W2^T, W1^T in the gradient dtype - all modules of ``ffs`` whose packs are stale in ONE launch.  Buffers are
+    persistent per module (a captured step rewrites them in place from the shadow weights the Adam kernel wrote)."""
+    jobs, fresh = [], []
+    for ff in ffs:
+        l1, l2 = ff.sequential[1].linear, ff.sequential[4].linear
+        if l1.weight.shape[1] not in _FFN2_FWD and l1.weight.shape[1] not in _FFN2_BWD:
+            continue
+        w1, w2 = wt(l1.weight), wt(l2.weight)
+        if w1.dtype not in _16 or not w1.is_cuda:
+            continue
+        key = (weights_version(), w1.dtype, l1.weight._version, l2.weight._version, w1.data_ptr(), bool(need_bwd))
+        c = ff.__dict__.get("_ffn2_packs")
+        if c is not None and (c[0] == key or (c[0][:5] == key[:5] and c[0][5])):
+            continue
+        bufs = ff.__dict__.get("_ffn2_bufs")
+        if bufs is None or bufs[0].dtype != w1.dtype or bufs[0].device != w1.device:
+            gd = RT.gdtype
+            bufs = ff.__dict__["_ffn2_bufs"] = (torch.empty(w1.numel(), dtype=w1.dtype, device=w1.device), torch.empty(w2.numel(), dtype=w1.dtype, device=w1.device),
+                                                torch.empty(w2.numel(), dtype=gd, device=w1.device), torch.empty(w1.numel(), dtype=gd, device=w1.device))
+        jobs += [(w1, bufs[0]), (w2, bufs[1])]
+        if need_bwd:
+            jobs += [(wtg(l2.weight).t(), bufs[2]), (wtg(l1.weight).t(), bufs[3])]
+        fresh.append((ff, key, bufs))
+    if jobs:
+        hip.ffn_pack(jobs)
+    for ff, key, bufs in fresh:
+        ff.__dict__["_ffn2_packs"] = (key, bufs)
+
+
+def _ffn_packs(ff, need_bwd=True):
+    prepare_ffn_packs([ff], need_bwd)
+    return ff.__dict__["_ffn2_packs"][1]
+
+
+def block_ffns(enc):
+    """The feed-forward modules of a ConformerEncoder (two per block) - for one pack launch per step (model._PretrainFn)."""
+    return [blk.sequential[i].module for blk in enc.layers for i in (0, 3)]
+
+
 def ffn_fwd(x, ff, factor, train, saved, out=None):
     """x + factor * FeedForwardModule(x)  (conformer/feed_forward.py:47-57, Conformer.py:60-67)."""
     seq = ff.sequential
@@ -343,6 +393,16 @@ def ffn_fwd(x, ff, factor, train, saved, out=None):
     else:
         ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
+    d = x.shape[1]
+    if (_FFN2 and d in _FFN2_FWD and not _replaying(train) and not RT.fp8 and hip.ffn2_supported(x.shape[0], d, x.dtype)
+            and seq[1].linear.weight.shape[0] == 4 * d):
+        # one launch for Linear + Swish + Dropout + Linear + Dropout + scaled residual: the hidden tile stays on the CU (csrc/ffn2.hip)
+        packs = _ffn_packs(ff, need_bwd=not RT.inference)
+        s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
+        y, hpre, a = hip.ffn2_fwd(ln, packs[0], packs[1], seq[1].linear.bias.data, seq[4].linear.bias.data, x, d, p1=p1, s1=s1, p2=p2, s2=s2,
+                                  out_scale=factor, out=out)
+        saved.append((x, ln, stats, hpre, a, p1, s1, p2, s2, factor))
+        return y
     hpre = torch.empty((x.shape[0], seq[1].linear.weight.shape[0]), dtype=x.dtype, device=x.device)
     if _replaying(train) and (p1 > 0 or p2 > 0):          # host-drawn masks in the reference's order: hidden, then output
         a = mm_nt(ln, wt(seq[1].linear.weight), bias=seq[1].linear.bias.data, act=SWISH, preact=hpre)
@@ -402,6 +462,16 @@ def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
         else:
             dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
         mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight), bias=gbuf(seq[4].linear.bias))
+        d = x.shape[1]
+        if (_FFN2 and d in _FFN2_BWD and not RT.fp8 and dz2.dtype in _16 and dz2.stride(1) == 1 and hip.ffn2_supported(x.shape[0], d, dz2.dtype)
+                and hpre.shape[1] == 4 * d and ff.__dict__.get("_ffn2_packs") is not None and ff.__dict__["_ffn2_packs"][0][5]):
+            # both data-gradient products in one launch: dh = (dz2 W2) * mask * swish'(hpre) leaves the chip once (the two weight-gradient
+            # products read it), dln = dh W1 is formed from the LDS-resident tile (csrc/ffn2.hip, packs of the transposed weights)
+            packs = _ffn_packs(ff)
+            dln, dh = hip.ffn2_bwd(dz2, packs[2], packs[3], hpre, d, p1=p1, s1=s1)
+            mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight), bias=gbuf(seq[1].linear.bias))
+            return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
+                                     drop=_next_drop(next_kind, saved))
         # dh = (dz2 @ W2) * dropout_mask1 * swish'(hpre): activation backward fused into the GEMM epilogue
         dh = mm_nn(dz2, wtg(seq[4].linear.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
     mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight), bias=gbuf(seq[1].linear.bias))

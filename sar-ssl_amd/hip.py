@@ -211,6 +211,53 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     return out
 
 
+# ---- fused feed-forward module (csrc/ffn2.hip) ------------------------------------------------------------------------------------
+def ffn2_supported(M, d, dtype):
+    return dtype in _16 and bool(_lib.lib().sarssl_ffn2_supported(c_long(M), c_int(d)))
+
+
+def ffn_pack(jobs):
+    """jobs: [(src 2-D view (N, K) - any strides, e.g. ``W`` or ``W.t()`` -, dst flat 16-bit tensor of N * K elements)]: every matrix
+    into MFMA fragment order (include/sarssl_hip.h) in ONE launch (<= 32 per launch)."""
+    for i in range(0, len(jobs), 32):
+        part = jobs[i:i + 32]
+        n = len(part)
+        _need_cuda(*[t for j in part for t in j])
+        for src, dst in part:
+            assert src.dim() == 2 and src.element_size() == 2 and dst.element_size() == 2 and dst.numel() == src.numel() and dst.is_contiguous()
+        VP, I, L = c_void_p * n, c_int * n, c_long * n
+        _lib.call("sarssl_ffn_pack", VP(*[s.data_ptr() for s, _ in part]), VP(*[d.data_ptr() for _, d in part]),
+                  I(*[s.shape[0] for s, _ in part]), I(*[s.shape[1] for s, _ in part]), L(*[s.stride(0) for s, _ in part]),
+                  L(*[s.stride(1) for s, _ in part]), c_int(n), _stream())
+
+
+def ffn2_fwd(ln, w1p, w2p, b1, b2, resid, d, p1=0.0, s1=0, p2=0.0, s2=0, out_scale=1.0, out=None):
+    """-> (y [M, d], preact [M, 4d], hidden [M, 4d]); y = resid + out_scale * drop2(W2 drop1(swish(W1 ln + b1)) + b2)."""
+    _need_cuda(ln, w1p, w2p, b1, b2, resid, out)
+    M = ln.shape[0]
+    pre = torch.empty((M, 4 * d), dtype=ln.dtype, device=ln.device)
+    hid = torch.empty((M, 4 * d), dtype=ln.dtype, device=ln.device)
+    if out is None:
+        out = torch.empty((M, d), dtype=ln.dtype, device=ln.device)
+    with _Timed("ffn2_fwd[d%d]" % d if _prof_shapes and _prof is not None else None):
+        _lib.call("sarssl_ffn2_fwd", _p(ln), c_long(ln.stride(0)), _p(w1p), _p(w2p), _p(b1), _p(b2), _p(pre), _p(hid), _p(out), c_long(out.stride(0)),
+                  _p(resid), c_long(resid.stride(0) if resid is not None else 0), c_long(M), c_int(d), c_float(p1), c_ulonglong(s1), c_float(p2),
+                  c_ulonglong(s2), c_float(out_scale), c_int(dt(ln)), _stream())
+    return out, pre, hid
+
+
+def ffn2_bwd(dz2, w2tp, w1tp, preact, d, p1=0.0, s1=0):
+    """-> (dln [M, d], dh [M, 4d]) in the gradient dtype of dz2."""
+    _need_cuda(dz2, w2tp, w1tp, preact)
+    M = dz2.shape[0]
+    dh = torch.empty((M, 4 * d), dtype=dz2.dtype, device=dz2.device)
+    dln = torch.empty((M, d), dtype=dz2.dtype, device=dz2.device)
+    with _Timed("ffn2_bwd[d%d]" % d if _prof_shapes and _prof is not None else None):
+        _lib.call("sarssl_ffn2_bwd", _p(dz2), c_long(dz2.stride(0)), _p(w2tp), _p(w1tp), _p(preact), _p(dh), _p(dln), c_long(dln.stride(0)),
+                  c_long(M), c_int(d), c_float(p1), c_ulonglong(s1), c_int(dt_ga(dz2, preact)), _stream())
+    return dln, dh
+
+
 _splitk_batch = None
 
 

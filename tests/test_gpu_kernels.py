@@ -1259,3 +1259,72 @@ def test_stem_c4_forward_statistics_epilogue(dtp, shape):
     y4, sums = hip.stem_c4_fwd(y3, W4, sc, sh, want_stats=True)
     assert torch.equal(y4, ref)
     assert _relerr(sums[:4], sums_ref[:4]) < 1e-5 and _relerr(sums[4:], sums_ref[4:]) < 1e-5
+
+
+# ---------------------------------------------------------------- fused feed-forward module (csrc/ffn2.hip)
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("M,d", [(128, 256), (320, 512), (1024, 256)])
+def test_fused_feed_forward_module_fwd_bwd(M, d, p_drop, dtp):
+    """FeedForwardModule under the half-step residual (feed_forward.py:47-54, Conformer.py:60-67) as ONE launch per direction against
+    (1) the pair of GEMM launches it replaces - same MFMA products in the same order, same dropout decisions: the saved tensors and
+    the result must agree to the last rounding - and (2) an f64 restatement fed the kernel's own dropout mask."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    gdt = torch.bfloat16
+    H = 4 * d
+    ln = (_mk((M, d), torch.float32, dev, 1)).to(dtp)
+    x = (_mk((M, d), torch.float32, dev, 2)).to(dtp)
+    W1 = (_mk((H, d), torch.float32, dev, 3) * d ** -0.5).to(dtp)
+    W2 = (_mk((d, H), torch.float32, dev, 4) * H ** -0.5).to(dtp)
+    b1 = _mk((H,), torch.float32, dev, 5) * 0.1
+    b2 = _mk((d,), torch.float32, dev, 6) * 0.1
+    s1, s2, factor = 0x1234567, 0x7654321, 0.5
+    w1p, w2p = torch.empty(H * d, dtype=dtp, device=dev), torch.empty(H * d, dtype=dtp, device=dev)
+    w2tp, w1tp = torch.empty(H * d, dtype=gdt, device=dev), torch.empty(H * d, dtype=gdt, device=dev)
+    hip.ffn_pack([(W1, w1p), (W2, w2p), (W2.to(gdt).t(), w2tp), (W1.to(gdt).t(), w1tp)])
+    # the pack itself: block (n / 32, k / 16), lane l = row 32 nb + (l & 31), k = 16 ks + 8 (l >> 5) + 0..7
+    pk = w1p.view(H // 32, d // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(H, d)
+    assert torch.equal(pk, W1)
+    pk = w2tp.view(H // 32, d // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(H, d)
+    assert torch.equal(pk, W2.to(gdt).t())
+    y, hpre, a = hip.ffn2_fwd(ln, w1p, w2p, b1, b2, x, d, p1=p_drop, s1=s1, p2=p_drop, s2=s2, out_scale=factor)
+    # (1) the two-launch sequence of engine.ffn_fwd
+    hpre_r = torch.empty((M, H), dtype=dtp, device=dev)
+    a_r = hip.gemm(ln, W1, M=M, N=H, K=d, lda=d, ldb=d, bias=b1, act=2, preact=hpre_r, p_drop=p_drop, seed=s1)
+    y_r = hip.gemm(a_r, W2, M=M, N=d, K=H, lda=H, ldb=H, bias=b2, p_drop=p_drop, seed=s2, out_scale=factor, resid=x, ldr=d, res_scale=1.0)
+    assert torch.equal(hpre, hpre_r)
+    assert torch.equal(a, a_r)
+    assert _relerr(y, y_r) < 1e-6
+    # (2) f64, with the kernel's own masks (read back from its outputs: hidden == 0 where dropped; second mask from the unfused twin at p = 1 - 1)
+    h64 = ln.double() @ W1.double().t() + b1.double()
+    act = h64 * torch.sigmoid(h64)
+    if p_drop > 0:
+        # the library's own masks: keep / (1 - p) as a function of (seed, m * N + n), read back through sarssl_act_bwd on ones
+        keep1 = hip.act_bwd(torch.ones((M, H), dtype=torch.float32, device=dev), None, 0, p_drop=p_drop, seed=s1).double()
+        keep2 = hip.act_bwd(torch.ones((M, d), dtype=torch.float32, device=dev), None, 0, p_drop=p_drop, seed=s2).double()
+        assert abs(1.0 - (keep1 != 0).double().mean().item() - p_drop) < 0.02
+        act = act * keep1
+    else:
+        keep2 = torch.ones((M, d), dtype=torch.float64, device=dev)
+    tol = 4e-3 if dtp == torch.float16 else 2e-2
+    assert _relerr(hpre, h64) < tol
+    assert _relerr(a, act) < tol
+    y64 = x.double() + factor * ((a.double() @ W2.double().t() + b2.double()) * keep2)
+    assert _relerr(y, y64) < tol
+    # ---- backward: dh, dln against the two launches of engine.ffn_bwd and f64
+    dz2 = (_mk((M, d), torch.float32, dev, 7) * 1e-3).to(gdt)
+    dln, dh = hip.ffn2_bwd(dz2, w2tp, w1tp, hpre, d, p1=p_drop, s1=s1)
+    W2g, W1g = W2.to(gdt), W1.to(gdt)
+    dh_r = hip.gemm(dz2, W2g, a_kc=True, b_kc=False, M=M, N=H, K=d, lda=d, ldb=H, aux=hpre, aux_act=2, p_drop=p_drop, seed=s1)
+    dln_r = hip.gemm(dh_r, W1g, a_kc=True, b_kc=False, M=M, N=d, K=H, lda=H, ldb=d)
+    assert dh.dtype == gdt and dln.dtype == gdt
+    assert torch.equal(dh, dh_r)
+    assert _relerr(dln, dln_r) < 1e-6
+    hp = hpre.double()
+    sg = torch.sigmoid(hp)
+    dh64 = (dz2.double() @ W2g.double()) * (sg * (1 + hp * (1 - sg)))
+    if p_drop > 0:
+        dh64 = dh64 * keep1
+    assert _relerr(dh, dh64) < 2e-2
+    assert _relerr(dln, dh.double() @ W1g.double()) < 2e-2
