@@ -32,6 +32,12 @@ int sarssl_destroy(sarssl_ctx* ctx);
 int sarssl_make_current(sarssl_ctx* ctx);           /* ctx or NULL becomes the calling thread's current context */
 int sarssl_ctx_device(const sarssl_ctx* ctx);
 int sarssl_ctx_set_conv_cus(sarssl_ctx* ctx, int ncus);       /* 3x3 data / weight gradient launches: workgroups; 0 = 7/8 of the CUs */
+/* fp16 range guard: kernels that encode externally scaled data as fp16 (sarssl_mask_inputs, sarssl_stft_frontend_pairs_masked with
+ * dtype fp16: the spectrum divided by mean|X_0| + eps, code/learner.py:539-542) set a device word of the context when a value does not fit
+ * (|v| > 65 504).  The next sarssl_masked_mse_* launch under the context then reports the loss as NaN and clears the word - an overflowed
+ * forward does not reach the loss by itself (BatchNorm makes NaN of inf, ReLU makes 0 of NaN) - and the guarded Adam launches skip the
+ * step.  sarssl_ctx_fp16_overflow reads (and optionally clears) the word from the host; synchronises `stream`. */
+int sarssl_ctx_fp16_overflow(sarssl_ctx* ctx, int clear, void* stream);
 int sarssl_ctx_get_conv_cus(const sarssl_ctx* ctx);
 int sarssl_ctx_set_clock_probe(sarssl_ctx* ctx, void* buf);   /* see the measurement aid below; NULL = off */
 int sarssl_ctx_attach_step_state(sarssl_ctx* ctx, void* state);   /* device SarsslStepState* or NULL: dropout launches add its salt */
@@ -363,6 +369,11 @@ int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char*
 /*      p16 / ph16 (either may be null): bf16 / fp16 shadow copies of the updated parameters, the GEMM / convolution operands */
 int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr, float beta1,
                      float beta2, float eps, int step, void* stream);
+/*      the same behind a device-side guard: `guard` -> the step's loss (f32 on the device).  Not finite -> the update is skipped as a
+ *      whole (parameters, moments, shadow copies untouched; *nskipped += 1 when given): torch.cuda.amp.GradScaler.step of the reference's
+ *      fp16 autocast path (code/learner.py:105-108: a step whose forward overflowed is not an optimizer step) without a host sync. */
+int sarssl_adam_step_guard(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr, float beta1,
+                           float beta2, float eps, int step, const float* guard, int* nskipped, void* stream);
 
 /* ---- device-resident step state: what varies from step to step when the whole step (code/learner.py:93-115: forward, backward,
  *      optimizer.step(), optimizer.zero_grad()) is replayed from a hipGraph with frozen launch arguments.  `state` is
@@ -376,6 +387,11 @@ int sarssl_step_state_reset(void* state, float lr, float beta1, float beta2, voi
 int sarssl_step_tick(void* state, void* stream);
 int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, const void* state,
                          float eps, int zero_grad, void* stream);
+/*      guarded form (see sarssl_adam_step_guard): a skipped step still clears the gradient buffer (zero_grad), takes the state's step
+ *      count back by one and counts itself in the state (sarssl_step_state_skipped) */
+int sarssl_adam_step_dev_guard(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, void* state, float eps,
+                               int zero_grad, const float* guard, void* stream);
+int sarssl_step_state_skipped(const void* state, void* stream);      /* synchronises `stream`; -> steps skipped since init, < 0 on error */
 
 /* ---- collectives: the gradient exchange of data-parallel training (replaces torch.nn.DataParallel's per-step replicate / gather /
  *      reduce, code/learner.py:25-31, :102).  One communicator per (process, device); the 128-byte id is generated by rank 0 and moved

@@ -65,3 +65,20 @@ def recipe_signal(nbatch, nsample, nch=2, seed=0):
         out[:, :, c] = 0.6 * src[:, d:d + nsample] + 0.3 * src[:, d + 2:d + 2 + nsample] \
             + 0.1 * g.standard_normal((nbatch, nsample)).astype(np.float32)
     return torch.from_numpy(out * 0.2)
+
+
+def edge_case_signals():
+    """Inputs of fixture F15 (shared with tests/): recipe signal seed 3 (as F3), B = 2 full-size segments, modified per case.
+    Reference microphone = channel 0: data_preprocess divides by mean|X0| + 1e-6 (code/learner.py:539-542)."""
+    base = recipe_signal(2, 65792, 2, seed=3)
+    cases = {}
+    for name, att in (("ref_mic_minus40dB", 1e-2), ("ref_mic_minus60dB", 1e-3)):
+        s = base.clone()
+        s[:, :, 0] *= att                                   # a quiet reference microphone next to a loud second one
+        cases[name] = s
+    s = base.clone()
+    s[:, :, 0] = 0.0                                        # an all-zero reference channel: the normaliser is its 1e-6 epsilon
+    cases["ref_mic_all_zero"] = s
+    s = (base * (8.0 / base.abs().max())).clamp(-1.0, 32767.0 / 32768.0)      # full-scale clipped recording, as PCM-16 hands it over
+    cases["clipped_full_scale_pcm"] = torch.round(s * 32768.0).clamp(-32768, 32767) / 32768.0
+    return cases

@@ -54,7 +54,7 @@ extern "C" int sarssl_ctx_attach_step_state(sarssl_ctx* ctx, void* state) {
 extern "C" long sarssl_step_state_bytes() { return (long)sizeof(SarsslStepState); }
 
 __global__ void step_state_init_kernel(SarsslStepState* s, unsigned long long salt, float lr, float beta1, float beta2) {
-    s->salt = salt; s->step = 0; s->lr = lr; s->beta1 = beta1; s->beta2 = beta2; s->step_size = 0.f; s->inv_bc2_sqrt = 1.f;
+    s->salt = salt; s->step = 0; s->lr = lr; s->beta1 = beta1; s->beta2 = beta2; s->step_size = 0.f; s->inv_bc2_sqrt = 1.f; s->nskipped = 0;
 }
 // (re)start: step count 0 (a fresh torch.optim.Adam, code/learner.py:83), learning rate, betas; salt_seed != 0 also reseeds the salt
 __global__ void step_state_reset_kernel(SarsslStepState* s, float lr, float beta1, float beta2) {
@@ -79,6 +79,12 @@ __global__ void step_tick_kernel(SarsslStepState* s) {
     const double bc1 = 1.0 - pow((double)s->beta1, (double)t), bc2 = 1.0 - pow((double)s->beta2, (double)t);
     s->step_size = (float)((double)s->lr / bc1);
     s->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+}
+extern "C" int sarssl_step_state_skipped(const void* state, void* stream) {
+    SarsslStepState h;
+    if (hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    return h.nskipped;
 }
 extern "C" int sarssl_step_tick(void* state, void* stream) {
     step_tick_kernel<<<1, 1, 0, (hipStream_t)stream>>>((SarsslStepState*)state);
@@ -112,13 +118,35 @@ extern "C" sarssl_ctx* sarssl_create(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { sarssl_set_error("sarssl_create: no device %d", device); return nullptr; }
     sarssl_ctx* c = (sarssl_ctx*)calloc(1, sizeof(sarssl_ctx));
-    if (c) c->device = device;
+    if (c) {
+        c->device = device;
+        // fp16-overflow word (see common.h): 4 bytes of device memory per context, allocated on the context's device
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess && (cur == device || hipSetDevice(device) == hipSuccess)) {
+            if (hipMalloc((void**)&c->ovf_flag, sizeof(int)) != hipSuccess || hipMemset(c->ovf_flag, 0, sizeof(int)) != hipSuccess) c->ovf_flag = nullptr;
+            if (cur != device) (void)hipSetDevice(cur);
+        }
+    }
     return c;
 }
+// Requires that NO other thread has this context current (the pointer it holds would dangle): destroy after the threads that used it
+// have made another context (or null) current.  The library keeps no list of threads.
 extern "C" int sarssl_destroy(sarssl_ctx* ctx) {
-    if (ctx && t_ctx == ctx) t_ctx = nullptr;          // (other threads must not keep a destroyed context current)
+    if (ctx && t_ctx == ctx) t_ctx = nullptr;
+    if (ctx && ctx->ovf_flag) (void)hipFree(ctx->ovf_flag);
     free(ctx);
     return 0;
+}
+int* sarssl_overflow_flag() { sarssl_ctx* c = sarssl_current(); return c ? c->ovf_flag : nullptr; }
+// 1 when a kernel issued under ctx has met a value outside fp16's range since the flag was last cleared (by a loss launch or by this
+// call); synchronises `stream`.  -1 on error.
+extern "C" int sarssl_ctx_fp16_overflow(sarssl_ctx* ctx, int clear, void* stream) {
+    if (!ctx || !ctx->ovf_flag) return 0;
+    int h = 0;
+    if (hipMemcpyAsync(&h, ctx->ovf_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+    if (clear && hipMemsetAsync(ctx->ovf_flag, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    return h != 0;
 }
 // ctx (or null) becomes the calling thread's current context
 extern "C" int sarssl_make_current(sarssl_ctx* ctx) { t_ctx = ctx; return 0; }

@@ -31,7 +31,10 @@ struct sarssl_ctx {
     unsigned long long* conv_clk;           // clock-probe buffer of the 3x3 forward / data-gradient launches, or null
     const unsigned long long* salt;         // dropout-seed addend: &SarsslStepState::salt of the attached step state, or null
     const char* zero_lo; const char* zero_hi;   // host-zeroed accumulator arena: memsets of pointers inside it are skipped
+    int* ovf_flag;                          // device word: set by the kernels that encode external-scale data as fp16 when a value does not
+                                            // fit (|v| > 65 504); the loss launch reads it, poisons the loss with NaN and clears it
 };
+int* sarssl_overflow_flag();                // the current context's flag (null without a context)
 sarssl_ctx* sarssl_current();   // may be null
 // Device-resident step state (api.hip, sarssl_step_state_*): lets a step captured in a hipGraph vary per replay.  `salt` is added to
 // every dropout seed by the kernels (null / 0 outside graph capture); the Adam fields are advanced by sarssl_step_tick.
@@ -41,6 +44,7 @@ struct SarsslStepState {
     float lr, beta1, beta2;
     float step_size;             // lr / (1 - beta1^step)
     float inv_bc2_sqrt;          // 1 / sqrt(1 - beta2^step)
+    int nskipped;                // optimizer steps skipped because the step's loss was not finite (sarssl_adam_step_dev_guard)
 };
 int sarssl_mfma_prio();         // where waves raise their issue priority (s_setprio) during MFMA phases: 2 = the ping-pong convolution only
 bool sarssl_prezeroed(const void* p);               // pointer inside the host-zeroed arena (api.hip): its memset can be skipped

@@ -771,17 +771,21 @@ __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict
 }
 // out_keep (optional f32[2]) receives a copy, acc (optional f64[2]) accumulates the two values (the captured step's running sums: three
 // copy / cast / add launches of ~4 us each sat between the loss and its backward, in a stretch of the step nothing overlaps)
+// ovf (optional): the context's fp16-overflow word (common.h) - set means the forward pass encoded a value outside fp16's range: the loss
+// is reported as NaN (what the step's optimizer guard and the caller see) and the word is cleared for the next step.
 __global__ void loss_finalize_kernel(const double* __restrict__ sums, double count, float* __restrict__ out, float* __restrict__ out_keep,
-                                     double* __restrict__ acc) {
+                                     double* __restrict__ acc, int* __restrict__ ovf) {
     const int lane = threadIdx.x;                        // 64 threads
     double a = sums[lane], c = sums[MSE_SLOTS + lane];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
     if (lane == 0) {
-        const float l = (float)(a / count), d = (float)(c / count);
+        float l = (float)(a / count);
+        const float d = (float)(c / count);
+        if (ovf && ovf[0]) { l = __builtin_nanf(""); ovf[0] = 0; }
         out[0] = l; out[1] = d;
         if (out_keep) { out_keep[0] = l; out_keep[1] = d; }
-        if (acc) { acc[0] += (double)l; acc[1] += (double)d; }
+        if (acc && isfinite(l)) { acc[0] += (double)l; acc[1] += (double)d; }      // (a skipped step - non-finite loss - is not part of the epoch mean)
     }
 }
 // dpred = gscale * 2 (pred - tar) / count on (masked frame, masked channel) entries, 0 elsewhere
@@ -811,9 +815,16 @@ __global__ void masked_mse_bwd_kernel(const TA* __restrict__ pred, const float* 
 
 // ------------------------------------------------------------------------------------ Adam
 // torch.optim.Adam (no amsgrad, no weight decay) on a flat f32 buffer; also refreshes the bf16 shadow copy.
+// guard (optional): the step's loss on the device.  Not finite -> the whole update is skipped (parameters, moments and shadow copies keep
+// their values, *nskipped counts it): what torch.cuda.amp.GradScaler.step does for the reference's fp16 autocast path when the
+// forward overflowed (code/learner.py:105-108) - decided on the device, no host synchronisation.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             bf16* __restrict__ p16, f16* __restrict__ ph16, long n, float gscale, float beta1, float beta2, float step_size,
-                            float inv_bc2_sqrt, float eps) {
+                            float inv_bc2_sqrt, float eps, const float* __restrict__ guard, int* __restrict__ nskipped) {
+    if (guard && !isfinite(guard[0])) {
+        if (nskipped && blockIdx.x == 0 && threadIdx.x == 0) nskipped[0] += 1;
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
@@ -830,9 +841,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // Same update with the step-dependent factors read from the device-resident step state (graph replay), optionally clearing the
 // gradient buffer in the same pass (the reference's optimizer.zero_grad() right after optimizer.step(), code/learner.py:113-115).
 __global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                bf16* __restrict__ p16, f16* __restrict__ ph16, long n, float gscale, const SarsslStepState* __restrict__ st, float eps,
-                                int zero_g) {
+                                bf16* __restrict__ p16, f16* __restrict__ ph16, long n, float gscale, SarsslStepState* __restrict__ st, float eps,
+                                int zero_g, const float* __restrict__ guard) {
     const float beta1 = st->beta1, beta2 = st->beta2, step_size = st->step_size, inv_bc2_sqrt = st->inv_bc2_sqrt;
+    if (guard && !isfinite(guard[0])) {
+        // skipped step: nothing moves, the gradient buffer is still cleared (zero_grad follows the step), the Adam step count is taken
+        // back so that the next tick recomputes this step's bias corrections (GradScaler: a skipped step is not an optimizer step)
+        if (zero_g)
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] = 0.f;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->step -= 1; st->nskipped += 1; }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
@@ -1093,7 +1112,7 @@ static int masked_mse_fwd_impl(const void* pred, const float* x, const int* idx,
     } else {
         DISPATCH_T(dtype, (masked_mse_fwd_kernel<T, T><<<nb * groups, 256, lds, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums)));
     }
-    loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out, out_keep, acc);
+    loss_finalize_kernel<<<1, 64, 0, ST>>>(sums, (double)nb * nm * F * 2, out, out_keep, acc, sarssl_overflow_flag());
     SARSSL_CHECK_LAUNCH("masked_mse_fwd_kernel");
     return 0;
 }
@@ -1124,20 +1143,28 @@ extern "C" int sarssl_masked_mse_bwd(const void* pred, const float* x, const uns
     return 0;
 }
 // p16 / ph16 (either may be null): bf16 and fp16 shadow copies of the updated parameters (the GEMM / convolution operands)
-extern "C" int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr,
-                                float beta1, float beta2, float eps, int step, void* stream) {
+extern "C" int sarssl_adam_step_guard(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr,
+                                      float beta1, float beta2, float eps, int step, const float* guard, int* nskipped, void* stream) {
     SARSSL_REQUIRE(n > 0 && step >= 1, "sarssl_adam_step");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     adam_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, beta1, beta2, (float)(lr / bc1),
-                                                           (float)(1.0 / sqrt(bc2)), eps);
+                                                           (float)(1.0 / sqrt(bc2)), eps, guard, nskipped);
     SARSSL_CHECK_LAUNCH("adam_kernel");
+    return 0;
+}
+extern "C" int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr,
+                                float beta1, float beta2, float eps, int step, void* stream) {
+    return sarssl_adam_step_guard(p, g, m, v, p16, ph16, n, gscale, lr, beta1, beta2, eps, step, nullptr, nullptr, stream);
+}
+extern "C" int sarssl_adam_step_dev_guard(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, void* state,
+                                          float eps, int zero_grad, const float* guard, void* stream) {
+    SARSSL_REQUIRE(n > 0 && state, "sarssl_adam_step_dev");
+    adam_dev_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, (SarsslStepState*)state, eps,
+                                                               zero_grad, guard);
+    SARSSL_CHECK_LAUNCH("adam_dev_kernel");
     return 0;
 }
 extern "C" int sarssl_adam_step_dev(float* p, float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, const void* state,
                                     float eps, int zero_grad, void* stream) {
-    SARSSL_REQUIRE(n > 0 && state, "sarssl_adam_step_dev");
-    adam_dev_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, (const SarsslStepState*)state, eps,
-                                                               zero_grad);
-    SARSSL_CHECK_LAUNCH("adam_dev_kernel");
-    return 0;
+    return sarssl_adam_step_dev_guard(p, g, m, v, p16, ph16, n, gscale, const_cast<void*>(state), eps, zero_grad, nullptr, stream);
 }

@@ -14,8 +14,9 @@
 // mode 0: pretrain masks (model.py:541, :563);  mode 1: no masking, both outputs = x (model.py:676).
 template <typename T>
 __global__ void mask_inputs_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mp, const int* __restrict__ mch,
-                                   int nb, int F, int Tn, int mode, T* __restrict__ spec, T* __restrict__ spat) {
+                                   int nb, int F, int Tn, int mode, T* __restrict__ spec, T* __restrict__ spat, int* __restrict__ ovf) {
     const long total = (long)nb * F * Tn;
+    bool over = false;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int t = (int)(i % Tn);
         const long bf = i / Tn;
@@ -30,9 +31,14 @@ __global__ void mask_inputs_kernel(const float* __restrict__ x, const uint8_t* _
             s0 = (1.f - p) * v0 + p * (1.f - v0);
             s1 = (1.f - p) * v1 + p * (1.f - v1);
         }
+        // this is where externally scaled data (the spectrum divided by mean|X_0| + eps, code/learner.py:539-542) is first encoded in the
+        // forward dtype: a value outside fp16's range would become inf, and inf does NOT reach the loss (BatchNorm turns it into NaN,
+        // the next ReLU's max(NaN, 0) into 0): flag it for the loss launch instead of training on silently clipped input
+        if constexpr (__is_same(T, f16)) over = over || !(fmaxf(fmaxf(fabsf(m0.x), fabsf(m0.y)), fmaxf(fabsf(m1.x), fabsf(m1.y))) <= 65504.f);
         st4(spec + i * 4, make_float4(m0.x * s0, m1.x * s1, m0.y * s0, m1.y * s1));
         st4(spat + i * 4, make_float4(m0.x * p, m1.x * p, m0.y * p, m1.y * p));
     }
+    if (over && ovf) atomicOr(ovf, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -788,7 +794,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long N, int 
     mean[c] = (float)m; rstd[c] = r;
     scale[c] = gamma[c] * r;
     shift[c] = beta[c] - (float)m * gamma[c] * r;
-    if (running_mean) {
+    if (running_mean && isfinite(m) && isfinite(var)) {      // (an overflowed fp16 forward must not poison the running statistics)
         const double unb = (N > 1) ? var * (double)N / (double)(N - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
@@ -858,7 +864,7 @@ __global__ void cl_bn_train_act_kernel(const T* __restrict__ x, long rows, int C
         sh[e] = beta[ch] - (float)m * gamma[ch] * r;
         if (writer) {
             mean[ch] = (float)m; rstd[ch] = r; scale[ch] = sc[e]; shift[ch] = sh[e];
-            if (running_mean) {
+            if (running_mean && isfinite(m) && isfinite(var)) {
                 const double unb = (rows > 1) ? var * (double)rows / (double)(rows - 1) : var;
                 running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
                 running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
@@ -1042,7 +1048,7 @@ extern "C" int sarssl_mask_inputs(const float* x, const unsigned char* mp, const
                                   void* spec, void* spat, int dtype, void* stream) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && Tn > 0, "sarssl_mask_inputs");
     const int nblk = nblocks_for((long)nb * F * Tn, 256, 8192);
-    DISPATCH_T(dtype, (mask_inputs_kernel<T><<<nblk, 256, 0, ST>>>(x, mp, mch, nb, F, Tn, mode, (T*)spec, (T*)spat)));
+    DISPATCH_T(dtype, (mask_inputs_kernel<T><<<nblk, 256, 0, ST>>>(x, mp, mch, nb, F, Tn, mode, (T*)spec, (T*)spat, sarssl_overflow_flag())));
     SARSSL_CHECK_LAUNCH("mask_inputs_kernel");
     return 0;
 }
@@ -1226,7 +1232,7 @@ __global__ void stem_c1_affine_from_moments_kernel(const double* __restrict__ mo
     if (var < 0.0) var = 0.0;
     const float r = (float)(1.0 / sqrt(var + (double)eps));
     aff[co] = gamma[co] * r; aff[64 + co] = beta[co] - (float)m * gamma[co] * r; aff[128 + co] = (float)m; aff[192 + co] = r;
-    if (running_mean) {
+    if (running_mean && isfinite(m) && isfinite(var)) {      // (an overflowed fp16 forward must not poison the running statistics)
         const double unb = (N > 1) ? var * (double)N / (double)(N - 1) : var;
         running_mean[co] = (1.f - momentum) * running_mean[co] + momentum * (float)m;
         running_var[co] = (1.f - momentum) * running_var[co] + momentum * (float)unb;

@@ -139,8 +139,10 @@ class PretrainStepGraph:
                 seg.cut(("finish", None))
         elif self.reducer is not None:                     # (native exchange under capture: the join with the communication stream becomes a graph edge)
             self.reducer.finish()                          # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
+        # guard = the step's loss: a forward that overflowed fp16 (non-finite loss) leaves parameters and moments alone - the reference's
+        # GradScaler skips such a step too (code/learner.py:105-108); decided on the device, counted in the step state
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
-                          zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16)
+                          zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16, guard=self.out)
 
     def _exchange_in_graph(self):
         """True when the bucket all-reduces are captured INSIDE the step graph: the library's own exchange (sarssl_allreduce_bucket,
@@ -268,6 +270,10 @@ class PretrainStepGraph:
         runtime.bump_version()                             # weights moved: eager users of the re-laid-out caches must rebuild
         self.nsteps += 1
         return self.out
+
+    def skipped_steps(self):
+        """Steps whose update was skipped because the loss was not finite (synchronises)."""
+        return hip.step_state_skipped(self.state)
 
     def vis(self):
         """vis dict of the last step (same keys as SARSSL.forward's third result).  Copies: the graph's pool tensors are overwritten

@@ -1258,11 +1258,13 @@ def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0, gscale_dev=None):
     return dpred
 
 
-def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8, ph16=None):
-    """p16 / ph16: bf16 / fp16 shadow copies of the parameters rewritten by the same pass (either may be None)."""
+def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8, ph16=None, guard=None, nskipped=None):
+    """p16 / ph16: bf16 / fp16 shadow copies of the parameters rewritten by the same pass (either may be None).  guard: f32 device
+    tensor holding the step's loss - not finite -> the update is skipped on the device (nskipped: int32 device counter, += 1)."""
     assert (p16 is None or p16.dtype == torch.bfloat16) and (ph16 is None or ph16.dtype == torch.float16)
-    _lib.call("sarssl_adam_step", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), c_float(lr),
-              c_float(betas[0]), c_float(betas[1]), c_float(eps), c_int(step), _stream())
+    assert guard is None or (guard.dtype == torch.float32 and guard.is_cuda)
+    _lib.call("sarssl_adam_step_guard", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), c_float(lr),
+              c_float(betas[0]), c_float(betas[1]), c_float(eps), c_int(step), _p(guard), _p(nskipped), _stream())
 
 
 # ---- device-resident step state (graph replay: dropout salt, Adam step count / bias corrections; csrc/api.hip) --------------
@@ -1335,7 +1337,25 @@ def step_tick(st):
     _lib.call("sarssl_step_tick", _p(st), _stream())
 
 
-def adam_step_dev(p, g, m, v, p16, st, gscale=1.0, eps=1e-8, zero_grad=False, ph16=None):
+def adam_step_dev(p, g, m, v, p16, st, gscale=1.0, eps=1e-8, zero_grad=False, ph16=None, guard=None):
     assert (p16 is None or p16.dtype == torch.bfloat16) and (ph16 is None or ph16.dtype == torch.float16)
-    _lib.call("sarssl_adam_step_dev", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), _p(st), c_float(eps),
-              c_int(1 if zero_grad else 0), _stream())
+    assert guard is None or (guard.dtype == torch.float32 and guard.is_cuda)
+    _lib.call("sarssl_adam_step_dev_guard", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), _p(st), c_float(eps),
+              c_int(1 if zero_grad else 0), _p(guard), _stream())
+
+
+def fp16_overflow(clear=True, device=None):
+    """True when a kernel of this process's context has met a value outside fp16's range while encoding the network input since the last
+    loss launch / the last call (include/sarssl_hip.h: sarssl_ctx_fp16_overflow).  Synchronises the current stream."""
+    r = _lib.lib().sarssl_ctx_fp16_overflow(c_void_p(_lib.ctx(device)), c_int(1 if clear else 0), _stream())
+    if r < 0:
+        raise _lib.SarsslHipError("sarssl_ctx_fp16_overflow failed")
+    return bool(r)
+
+
+def step_state_skipped(st):
+    """Optimizer steps the guarded Adam launch skipped since the state was created (non-finite loss).  Synchronises the current stream."""
+    n = _lib.lib().sarssl_step_state_skipped(_p(st), _stream())
+    if n < 0:
+        raise _lib.SarsslHipError("sarssl_step_state_skipped failed")
+    return int(n)

@@ -77,12 +77,28 @@ class Learner(ABC):
             loss_batch, diff_batch, vis_batch = self.model(in_batch)
             loss_batch.backward()
             gscale = self._reducer.finish() if self._reducer is not None else 1.0
-            optimizer.step(grad_scale=gscale)
+            # (16-bit modes: a non-finite loss - an fp16 forward that overflowed - skips the update on the device, like GradScaler.step)
+            optimizer.step(grad_scale=gscale, guard=loss_batch.detach() if (self.use_amp and loss_batch.dtype == torch.float32) else None)
             optimizer.zero_grad()
-            acc[0] += loss_batch.detach().double()                                           # no per-step .item() sync
-            acc[1] += diff_batch.detach().double()
+            if self.use_amp:                                                                # a skipped step is not part of the epoch mean
+                ok = torch.isfinite(loss_batch.detach())
+                acc[0] += torch.where(ok, loss_batch.detach().double(), acc.new_zeros(()))
+                acc[1] += torch.where(ok, diff_batch.detach().double(), acc.new_zeros(()))
+            else:
+                acc[0] += loss_batch.detach().double()                                       # no per-step .item() sync
+                acc[1] += diff_batch.detach().double()
             n += 1
-        return self._epoch_means(acc, n, vis_batch, return_diff)
+        nskip = int(optimizer.nskipped.item()) if optimizer.nskipped is not None else 0
+        self._report_skipped(nskip, n)
+        return self._epoch_means(acc, n - nskip, vis_batch, return_diff)
+
+    def _report_skipped(self, nskip, n):
+        self.skipped_steps_last_epoch = nskip
+        if nskip:
+            import warnings
+            warnings.warn("%d of %d training steps had a non-finite loss (fp16 forward overflow) and were skipped - parameters and Adam "
+                          "moments untouched, as torch.cuda.amp.GradScaler does for the reference (code/learner.py:105-108); "
+                          "`--use-amp` with SARSSL_AMP_DTYPE=bf16, or no `--use-amp`, has the range for such input" % (nskip, n))
 
     def _epoch_means(self, acc, n, vis_batch, return_diff):
         acc = acc / max(n, 1)
@@ -124,6 +140,7 @@ class Learner(ABC):
         if g is None:
             g = self.__dict__["_step_graph"] = PretrainStepGraph(self.model, self._flat, self._reducer, lr=float(lr), betas=(0.9, 0.999))
         g.reset_epoch(float(lr))                                                            # "Adam re-created every epoch" (learner.py:83)
+        skipped0 = g.skipped_steps()
         self._flat.grad.zero_()
         for batch in dataset:
             mic_sig_batch = batch[0] if isinstance(batch, (list, tuple)) else batch
@@ -143,7 +160,9 @@ class Learner(ABC):
             else:
                 g.step_eager(x=in_batch)
         vis_batch = g.vis() if g.nsteps else None
-        return self._epoch_means(g.acc.clone(), g.nsteps, vis_batch, return_diff)
+        nskip = g.skipped_steps() - skipped0
+        self._report_skipped(nskip, g.nsteps)
+        return self._epoch_means(g.acc.clone(), g.nsteps - nskip, vis_batch, return_diff)
 
     def pretest_epoch(self, dataset, return_diff=True, return_eval=False):
         self.model.eval()
@@ -194,6 +213,11 @@ class Learner(ABC):
             torch.distributed.all_reduce(acc)
             acc /= world
         loss, metric = float(acc[0]), acc[1].float().cpu()
+        if self.use_amp and runtime.RT.dtype == torch.float16 and hip.fp16_overflow(clear=True):
+            # (the downstream path has no loss launch that reads the context's fp16-overflow word: report it once per epoch)
+            import warnings
+            warnings.warn("network input outside fp16's range in this epoch (spectrum / (mean|X_0| + eps) > 65 504: a near-silent reference "
+                          "microphone?) - the fp16 forward clipped it; SARSSL_AMP_DTYPE=bf16 or no --use-amp has the range")
         return (loss, metric) if return_metric else loss
 
     def test_epoch(self, dataset, return_metric=False, return_vis=False):

@@ -12,11 +12,19 @@ Quantities (fixture F3, tests/test_gpu_model.py::test_fullsize_forward_backward;
   curve100      max relative deviation of the 100-step loss curve (dropout off, replayed masks)
 `measured` = what the MI355X run of round 4 measured (eval / train), for the reader; gates sit at <= 5x measured and never above the
 class the mode claims.
+
+Round 5, per_bin_max of the timed mode: it sits AT north_star's 1e-3, not inside it - 9.1e-4 in eval mode, 1.21e-3 in train mode (maximum
+of 2 048 bins whose rms deviation is 2-3e-4 of range), gated at 1.5e-3 and stated so in `parity_class`.  A two-pass fp16 split of a SUBSET of
+the contractions does not change that (profiles/r05_operand_rounding_study.txt: decoder in f32 - eval 6.5e-4 but train 1.12e-3; every
+Conformer Linear in f32 operands AND f32 storage - 6.3e-4 / 7.7e-4; with 16-bit activation storage no family subset moves the train-mode
+rms of 3.1e-4): the deviation is the fp16 rounding of the STORED activations between layers, amplified by the train-mode BatchNorm
+statistics, not the operand rounding of a few products.  Inside 1e-3 with margin costs f32 storage (`fp32`, 61 ms).  What the timed mode
+claims: loss / curve / rms inside 1e-3, per-bin maximum 1.5e-3.
 """
 
 GATES = {
     # fp16 forward / bf16 backward - the mode bench.py times since round 4
-    "fp16": dict(loss=1e-3, per_bin_max=1.5e-3, per_bin_rms=5e-4, grad_norm=4e-2, bn_running=5e-4, curve100=1e-3,
+    "fp16": dict(loss=1e-3, per_bin_max=1.5e-3, per_bin_rms=5e-4, grad_norm=2.5e-2, bn_running=5e-4, curve100=1e-3,
                  measured=dict(loss=(6.1e-6, 9.6e-7), per_bin_max=(9.1e-4, 1.21e-3), grad_norm=(1.5e-2, 7.9e-3), curve100=1.9e-4)),
     # bf16 throughout - the timed mode of rounds 1-3
     "bf16": dict(loss=2e-3, per_bin_max=3e-2, per_bin_rms=1e-2, grad_norm=6e-2, bn_running=5e-3, curve100=1e-3,
@@ -38,5 +46,9 @@ def parity_class(precision):
     return {"loss_vs_reference": g["loss"], "loss_curve_100_steps": g["curve100"], "per_bin_pred_of_range_max": g["per_bin_max"],
             "per_bin_pred_of_range_rms": g["per_bin_rms"], "per_parameter_grad_norm": g["grad_norm"], "measured_eval_train": g["measured"],
             "north_star": "1e-3 on the loss, the per-bin magnitudes and the 100-step curve",
+            "meets_north_star": ({"loss": True, "curve100": True, "per_bin_rms": True,
+                                  "per_bin_max": "NO in train mode: measured 9.1e-4 (eval) / 1.21e-3 (train) of range, gated at 1.5e-3 - the maximum over "
+                                                 "2 048 bins of rounding noise with rms 2-3e-4; the fp32 mode measures 1.5e-5"}
+                                 if g["per_bin_max"] > 1e-3 else {"loss": True, "curve100": g["curve100"] is not None, "per_bin_rms": True, "per_bin_max": True}),
             "pinned_by": "tests/test_gpu_model.py::test_fullsize_forward_backward (F3), tests/test_gpu_train.py (F5, F12), "
                          "tests/test_gpu_graph.py (B = 64 captured step vs the fp32 mode, F13 reference forward at B = 64)"}

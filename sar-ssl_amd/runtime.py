@@ -292,12 +292,20 @@ class FusedAdam:
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
         self.step_count = 0
+        self.nskipped = None
 
     def zero_grad(self):
         self.flat.zero_grad()
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, guard=None):
+        """guard: the step's loss as an f32 device tensor - a non-finite loss skips the update on the device (what GradScaler.step does
+        for the reference's fp16 autocast path, code/learner.py:105-108) and counts it in ``self.nskipped`` (device int32; no host sync.
+        The host-side step count still advances: after a skipped step the bias corrections are one step ahead, the captured step -
+        whose count lives on the device - takes it back)."""
         self.step_count += 1
+        if guard is not None and self.nskipped is None:
+            self.nskipped = torch.zeros(1, dtype=torch.int32, device=self.flat.flat.device)
         hip.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.lr, self.step_count,
-                      gscale=grad_scale, betas=self.betas, eps=self.eps, ph16=self.flat.wh16)
+                      gscale=grad_scale, betas=self.betas, eps=self.eps, ph16=self.flat.wh16,
+                      guard=guard.detach().reshape(-1) if guard is not None else None, nskipped=self.nskipped if guard is not None else None)
         bump_version()

@@ -337,3 +337,27 @@ def test_f14_fixture_is_the_backward_of_the_f13_batch():
     gn = json.loads(str(z14["gradnorm_json"]))
     assert set(gn) == set(names) and all(np.isfinite(v) for v in gn.values())
     assert abs(sum(v * v for v in gn.values()) ** 0.5 - 2.8583218) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["ref_mic_minus40dB", "ref_mic_minus60dB", "ref_mic_all_zero", "clipped_full_scale_pcm"])
+def test_f15_oracle_on_inputs_at_the_edge_of_the_normalisation(case):
+    """Fixture F15 (round 5): the reference's own forward + backward on a reference microphone 40 / 60 dB below the other one, an
+    all-zero reference channel (normaliser = its 1e-6 epsilon, inputs ~1e7) and a full-scale clipped PCM recording - the oracle must
+    restate all of them (the reference stays finite in fp32 on every case)."""
+    z = _npz("f15_edge_cases.npz")
+    assert case in json.loads(str(z["cases_json"])) and bool(z[case + ".finite"])
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
+    sd = recipes.recipe_state_dict(man, 0)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if orc.is_param(k)}
+    x = orc.data_preprocess(recipes.edge_case_signals()[case])
+    assert abs(float(x.abs().max()) / float(z[case + ".input_absmax"]) - 1) < 1e-5
+    loss, diff, aux = orc.sarssl_pretrain_forward(x, sd, torch.from_numpy(z["mask_idx"]), torch.from_numpy(z["mask_ch"]), train=True, p_drop=0.0)
+    loss.backward()
+    assert abs(loss.item() / float(z[case + ".loss"]) - 1) < 1e-4
+    assert abs(diff.item() / float(z[case + ".diff"]) - 1) < 1e-5
+    pv = aux["pred"].detach().reshape(-1)[torch.from_numpy(z[case + ".pred_idx"])]
+    assert float((pv - torch.from_numpy(z[case + ".pred_vals"])).abs().max()) < 3e-4 * float(z[case + ".pred_absmax"])
+    gn = json.loads(str(z[case + ".gradnorm_json"]))
+    top = max(gn.values())
+    for k, p in params.items():
+        assert abs(p.grad.double().norm().item() - gn[k]) <= 3e-3 * gn[k] + 1e-6 * top, k
