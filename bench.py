@@ -118,7 +118,7 @@ def _smi_sample():
         return None
 
 
-def telemetry(run_steps, seconds=2.0):
+def telemetry(run_steps, nsteps=150, sample=True):
     """Socket power and shader clock WHILE the step runs (round-4 verdict: the in-kernel probe read 1.6 GHz of 2.4 inside the step, with
     no power / clock telemetry next to it): a thread polls rocm-smi (a child process: it never touches this process's HIP state) while
     the main thread keeps replaying the step for `seconds` - in a loop of its own AFTER the timed region, so the timing is not disturbed."""
@@ -131,23 +131,27 @@ def telemetry(run_steps, seconds=2.0):
             if v is not None:
                 samples.append(v)
 
-    idle = _smi_sample()
+    # (a FIXED number of steps: under data parallelism every rank runs this loop - the steps contain collectives - and only rank 0 samples)
+    idle = _smi_sample() if sample else None
     th = threading.Thread(target=poll, daemon=True)
-    th.start()
-    t0 = time.perf_counter()
+    if sample:
+        th.start()
     n = 0
-    while time.perf_counter() - t0 < seconds:
+    while n < nsteps:
         run_steps(10)
         torch.cuda.synchronize()
         n += 10
     stop.set()
-    th.join(timeout=15)
+    if sample:
+        th.join(timeout=15)
+    else:
+        return None
     if not samples:
         return {"available": False, "note": "rocm-smi gave no reading on this box"}
     pw = [p for p, _, _ in samples if p == p]
     ck = [c for _, _, c in samples if c == c]
     cap = next((c for _, c, _ in samples if c == c), None)
-    out = {"available": True, "source": "rocm-smi --showpower --showclocks --showmaxpower, polled while %d further steps replay (after the timed region)" % n,
+    out = {"available": True, "source": "rocm-smi --showpower --showclocks --showmaxpower, polled while %d further steps run (after the timed region)" % n,
            "samples": len(samples), "power_cap_w": cap,
            "socket_power_w_avg": round(sum(pw) / len(pw), 1) if pw else None, "socket_power_w_max": max(pw) if pw else None,
            "sclk_mhz_avg": round(sum(ck) / len(ck), 1) if ck else None, "sclk_mhz_min": min(ck) if ck else None, "sclk_mhz_max": max(ck) if ck else None,
@@ -410,8 +414,8 @@ def main():
     torch.cuda.synchronize()
     host_enqueue_ms = 1e3 * sorted(enq)[len(enq) // 2]
     tele = None
-    if rank == 0 and not os.environ.get("SARSSL_BENCH_NO_TELEMETRY"):
-        tele = telemetry(lambda k: [step() for _ in range(k)])
+    if not os.environ.get("SARSSL_BENCH_NO_TELEMETRY"):
+        tele = telemetry(lambda k: [step() for _ in range(k)], sample=(rank == 0))
     prof2 = {}
     hip.conv_clock_probe(clk)
     if graph is None:

@@ -120,11 +120,20 @@ int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* cons
 int sarssl_ffn2_supported(long M, int d);
 int sarssl_ffn_pack(const void* const* src, void* const* dst, const int* N, const int* K, const long* rs, const long* cs, int n_mat,
                     void* stream);
+/*      LayerNorm in the same launch (feed_forward.py:48 and its backward; arithmetic of sarssl_layernorm_fwd / _bwd):
+ *      forward,  x_ln != NULL: ln = LayerNorm(x_ln; gamma, beta, eps) is formed in the launch's prologue (bit-identical to
+ *                sarssl_layernorm_fwd), written to ln_out [M][d] with ln_mean / ln_rstd [M]; the `ln` argument is ignored.
+ *      backward, x_ln != NULL (the module's saved input, dtype of preact): the epilogue runs sarssl_layernorm_bwd(_drop) on the second
+ *                product - `dln` receives dx = LayerNorm'(dh W1) + resid, dx2 (optional, [M][d]) = dx * dropmask(p2, s2) * gscale2,
+ *                ln_partial [M / 64][2][d] the per-tile dgamma | dbeta sums (fold: sarssl_ln_param_reduce_multi, nparts = M / 64). */
 int sarssl_ffn2_fwd(const void* ln, long ldln, const void* w1p, const void* w2p, const float* b1, const float* b2, void* preact,
                     void* hidden, void* y, long ldy, const void* resid, long ldr, long M, int d, float p1, unsigned long long s1,
-                    float p2, unsigned long long s2, float out_scale, int dtype, void* stream);
+                    float p2, unsigned long long s2, float out_scale, const void* x_ln, long ldx, const float* ln_gamma,
+                    const float* ln_beta, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd, int dtype, void* stream);
 int sarssl_ffn2_bwd(const void* dz2, long lddz, const void* w2tp, const void* w1tp, const void* preact, void* dh, void* dln, long lddln,
-                    long M, int d, float p1, unsigned long long s1, int dtype, void* stream);
+                    long M, int d, float p1, unsigned long long s1, const void* x_ln, long ldx, const float* ln_gamma,
+                    const float* ln_mean, const float* ln_rstd, const void* resid, long ldr, void* dx2, float p2, unsigned long long s2,
+                    float gscale2, float* ln_partial, int dtype, void* stream);
 
 /* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
  *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as

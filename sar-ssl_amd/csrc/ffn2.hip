@@ -43,6 +43,16 @@ struct Ffn2Args {
     float p1, p2; unsigned long long s1, s2; const unsigned long long* salt;
     float out_scale;
     int M;
+    // LayerNorm fused into the launch (either may be unused):
+    //   forward  (X != null): A is ignored - the input tile is LayerNorm(X rows) (feed_forward.py:48), written to LNout [M][D] with its
+    //            statistics (saved for the backward pass) and kept in LDS as the first product's operand; R is normally X itself
+    //   backward (X != null): the second product's result is not stored - it is the gradient w.r.t. the LayerNorm output, and the
+    //            epilogue runs the LayerNorm backward on it: Y = dx (+ R), Y2 (optional) = dx * dropmask(p2, s2) * out_scale (the dropout
+    //            backward of the next module of the chain), ln_partial [grid][2][D] = per-workgroup sums for dgamma | dbeta
+    const void* X; long ldx;
+    const float* ln_g; const float* ln_b; float ln_eps;
+    void* LNout; float* ln_mean; float* ln_rstd;
+    void* Y2; float* ln_partial;
 };
 
 struct FfnDrop {
@@ -100,7 +110,47 @@ __global__ __launch_bounds__(FFN_NT) void ffn2_kernel(Ffn2Args g) {
     for (int j = 0; j < 16; ++j) q[j] = *w1_piece(0, j);
 
     // ---- input tile -> LDS (padded pitch: conflict-free ds_read_b128 fragment reads)
-    {
+    if (!BWD && g.X) {
+        // LayerNorm of the tile's rows, the arithmetic of layernorm_fwd_kernel (csrc/elementwise.hip) operation for operation - one wave per
+        // row, lane = 4 consecutive columns (+ 256 i), two-pass mean / variance through the same xor-shuffle tree - so that the fused launch
+        // reproduces the stand-alone kernel bit for bit: rows w * 8 .. w * 8 + 7 of the tile belong to wave w
+        constexpr int NVL = D / 256;
+        const T* X = (const T*)g.X;
+        T* LN = (T*)g.LNout;
+        float4 v[8][NVL];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) v[j][i] = ld4(X + (m0 + w * 8 + j) * g.ldx + (lane + i * 64) * 4);
+        float4 gam[NVL], bet[NVL];
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) { gam[i] = *(const float4*)(g.ln_g + (lane + i * 64) * 4); bet[i] = *(const float4*)(g.ln_b + (lane + i * 64) * 4); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = w * 8 + j;
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) sm += v[j][i].x + v[j][i].y + v[j][i].z + v[j][i].w;
+            const float mu = wave_sum(sm) / (float)D;
+            float qv = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const float a = v[j][i].x - mu, b = v[j][i].y - mu, c = v[j][i].z - mu, e = v[j][i].w - mu;
+                qv += a * a + b * b + c * c + e * e;
+            }
+            const float rs = rsqrtf(wave_sum(qv) / (float)D + g.ln_eps);
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const int c4 = lane + i * 64;
+                const float4 o = make_float4((v[j][i].x - mu) * rs * gam[i].x + bet[i].x, (v[j][i].y - mu) * rs * gam[i].y + bet[i].y,
+                                             (v[j][i].z - mu) * rs * gam[i].z + bet[i].z, (v[j][i].w - mu) * rs * gam[i].w + bet[i].w);
+                st4(LN + (m0 + row) * (long)D + c4 * 4, o);
+                const float ov[4] = {o.x, o.y, o.z, o.w};
+                *(uint2*)&sA[row * PA + c4 * 4] = pack4<T>(ov);
+            }
+            if (lane == 0) { g.ln_mean[m0 + row] = mu; g.ln_rstd[m0 + row] = rs; }
+        }
+    } else {
         constexpr int CPRW = D / 8, RPI = FFN_NT / CPRW;            // 16-byte chunks per row, rows per pass
         const int r = tid / CPRW, ch = tid % CPRW;
 #pragma unroll
@@ -278,6 +328,75 @@ __global__ __launch_bounds__(FFN_NT) void ffn2_kernel(Ffn2Args g) {
             const float4 b0 = *(const float4*)(g.b2 + n), b1v = *(const float4*)(g.b2 + n + 4);
             bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1v.x; bias8[5] = b1v.y; bias8[6] = b1v.z; bias8[7] = b1v.w;
         }
+        if (BWD && g.X) {
+            // LayerNorm backward on the rows of the tile (layernorm_bwd_kernel, csrc/elementwise.hip): dx = rstd (g - mean(g) - xhat mean(g xhat))
+            // + resid with g = dln * gamma, dln rounded to the gradient dtype as the stand-alone sequence stores it; a row's CPRW threads fold
+            // their sums by xor shuffles; dgamma / dbeta partial sums over the tile's 64 rows go to ln_partial (folded by the block's reduce)
+            const TP* Xs = (const TP*)g.X;
+            float gam8[8], ag[8], ab[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gam8[e] = g.ln_g[n + e]; ag[e] = 0.f; ab[e] = 0.f; }
+            FfnDrop dq;
+            dq.init(g.Y2 ? g.p2 : 0.f, g.s2, g.salt);
+#pragma unroll
+            for (int j = 0; j < 64 / RPI; ++j) {
+                const int row = r + RPI * j;
+                const long m = m0 + row;
+                const float4 a0 = *(const float4*)&sY[row * PY + n], a1 = *(const float4*)&sY[row * PY + n + 4];
+                const float av[8] = {round_as<T>(a0.x), round_as<T>(a0.y), round_as<T>(a0.z), round_as<T>(a0.w),
+                                     round_as<T>(a1.x), round_as<T>(a1.y), round_as<T>(a1.z), round_as<T>(a1.w)};
+                const f8 xx = ld8(Xs + m * g.ldx + n);
+                const float mu = g.ln_mean[m], rs = g.ln_rstd[m];
+                float xh[8], gq[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[e] = (xx.v[e] - mu) * rs;
+                    gq[e] = av[e] * gam8[e];
+                    s1 += gq[e]; s2 += gq[e] * xh[e];
+                    ag[e] += av[e] * xh[e]; ab[e] += av[e];
+                }
+#pragma unroll
+                for (int o = CPRW / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                s1 /= (float)D; s2 /= (float)D;
+                f8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = rs * (gq[e] - s1 - xh[e] * s2);
+                if (g.R) {
+                    const f8 rr = ld8((const T*)g.R + m * g.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] += rr.v[e];
+                }
+                st8(Yo + m * g.ldy + n, v);
+                if (g.Y2) {
+                    if (dq.p > 0.f) {
+                        float k0[4], k1[4];
+                        const unsigned long long base = (unsigned long long)m * D + n;
+                        dq.scale4(base, k0);
+                        dq.scale4(base + 4, k1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v.v[e] *= k0[e]; v.v[4 + e] *= k1[e]; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] *= g.out_scale;
+                    st8((T*)g.Y2 + m * (long)D + n, v);
+                }
+            }
+            if (g.ln_partial) {
+                __syncthreads();                                   // every thread is done with the staged accumulators
+                float* sR = (float*)smem;                          // [RPI][2][D]
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sR[(r * 2 + 0) * D + n + e] = ag[e]; sR[(r * 2 + 1) * D + n + e] = ab[e]; }
+                __syncthreads();
+                float* P = g.ln_partial + (long)blockIdx.x * 2 * D;
+                for (int c = tid; c < 2 * D; c += FFN_NT) {
+                    float acc_ = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < RPI; ++rr) acc_ += sR[rr * 2 * D + c];
+                    P[c] = acc_;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 64 / RPI; ++j) {
             const int row = r + RPI * j;
@@ -373,13 +492,18 @@ static int ffn2_launch(const Ffn2Args& g, int d, hipStream_t st) {
 extern "C" int sarssl_ffn2_supported(long M, int d) { return (M > 0 && M % 64 == 0 && (d == 256 || d == 512)) ? 1 : 0; }
 
 // forward: y[M][d] = resid + out_scale * drop(p2, s2)( W2 drop(p1, s1)( swish(W1 ln + b1) ) + b2 );  preact / hidden [M][4d] are written
-// for the backward pass.  dtype: SARSSL_F16 | SARSSL_BF16 (ln, packs, preact, hidden, y, resid).
+// for the backward pass.  dtype: SARSSL_F16 | SARSSL_BF16 (ln, packs, preact, hidden, y, resid).  x_ln != null: ln = LayerNorm(x_ln) is
+// formed in the launch (gamma, beta, eps), stored to ln_out [M][d] with ln_mean / ln_rstd [M]; the `ln` argument is ignored.
 extern "C" int sarssl_ffn2_fwd(const void* ln, long ldln, const void* w1p, const void* w2p, const float* b1, const float* b2, void* preact,
                                void* hidden, void* y, long ldy, const void* resid, long ldr, long M, int d, float p1,
-                               unsigned long long s1, float p2, unsigned long long s2, float out_scale, int dtype, void* stream) {
-    SARSSL_REQUIRE(sarssl_ffn2_supported(M, d) && ldln % 8 == 0 && ldy % 8 == 0 && (!resid || ldr % 8 == 0) && b1 && b2 && preact && hidden,
-                   "sarssl_ffn2_fwd");
+                               unsigned long long s1, float p2, unsigned long long s2, float out_scale, const void* x_ln, long ldx,
+                               const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd,
+                               int dtype, void* stream) {
+    SARSSL_REQUIRE(sarssl_ffn2_supported(M, d) && ldy % 8 == 0 && (!resid || ldr % 8 == 0) && b1 && b2 && preact && hidden, "sarssl_ffn2_fwd");
+    SARSSL_REQUIRE(x_ln ? (ldx % 8 == 0 && ln_gamma && ln_beta && ln_out && ln_mean && ln_rstd) : (ln != nullptr && ldln % 8 == 0), "sarssl_ffn2_fwd(layernorm)");
     Ffn2Args g;
+    g.X = x_ln; g.ldx = ldx; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps; g.LNout = ln_out; g.ln_mean = ln_mean; g.ln_rstd = ln_rstd;
+    g.Y2 = nullptr; g.ln_partial = nullptr;
     g.A = ln; g.lda = ldln; g.W1p = w1p; g.W2p = w2p; g.b1 = b1; g.b2 = b2; g.P = preact; g.Hs = hidden; g.Y = y; g.ldy = ldy;
     g.R = resid; g.ldr = ldr; g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt(); g.out_scale = out_scale; g.M = (int)M;
     if (dtype == SARSSL_F16) return ffn2_launch<f16, f16, false>(g, d, (hipStream_t)stream);
@@ -390,14 +514,21 @@ extern "C" int sarssl_ffn2_fwd(const void* ln, long ldln, const void* w1p, const
 
 // backward: dh[M][4d] = (dz2 W2) * dropmask(p1, s1) * swish'(preact) (written: operand of both weight-gradient products),
 // dln[M][d] = dh W1.  w2tp / w1tp: packs of W2^T ([4d x d]) and W1^T ([d x 4d]).  dtype: SARSSL_BF16 (all 16-bit tensors bf16) or
-// SARSSL_MIX16 (bf16 gradients, fp16 saved pre-activation).
+// SARSSL_MIX16 (bf16 gradients, fp16 saved pre-activation / x_ln).  x_ln != null: the LayerNorm backward runs in the epilogue -
+// dln receives dx = LN'(dh W1) + resid, dx2 (optional) = dx * dropmask(p2, s2) * gscale2, ln_partial [M / 64][2][d] the dgamma | dbeta partials.
 extern "C" int sarssl_ffn2_bwd(const void* dz2, long lddz, const void* w2tp, const void* w1tp, const void* preact, void* dh, void* dln,
-                               long lddln, long M, int d, float p1, unsigned long long s1, int dtype, void* stream) {
+                               long lddln, long M, int d, float p1, unsigned long long s1, const void* x_ln, long ldx, const float* ln_gamma,
+                               const float* ln_mean, const float* ln_rstd, const void* resid, long ldr, void* dx2, float p2,
+                               unsigned long long s2, float gscale2, float* ln_partial, int dtype, void* stream) {
     SARSSL_REQUIRE(sarssl_ffn2_supported(M, d) && lddz % 8 == 0 && lddln % 8 == 0 && preact && dh, "sarssl_ffn2_bwd");
+    SARSSL_REQUIRE(!x_ln || (ldx % 8 == 0 && ln_gamma && ln_mean && ln_rstd && (!resid || ldr % 8 == 0)), "sarssl_ffn2_bwd(layernorm)");
     Ffn2Args g;
     g.A = dz2; g.lda = lddz; g.W1p = w2tp; g.W2p = w1tp; g.b1 = nullptr; g.b2 = nullptr; g.P = const_cast<void*>(preact); g.Hs = dh; g.Y = dln;
-    g.ldy = lddln; g.R = nullptr; g.ldr = 0; g.p1 = p1; g.p2 = 0.f; g.s1 = s1; g.s2 = 0; g.salt = sarssl_dropout_salt(); g.out_scale = 1.f;
+    g.ldy = lddln; g.R = x_ln ? resid : nullptr; g.ldr = ldr; g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt();
+    g.out_scale = x_ln ? gscale2 : 1.f;
     g.M = (int)M;
+    g.X = x_ln; g.ldx = ldx; g.ln_g = ln_gamma; g.ln_b = nullptr; g.ln_eps = 0.f; g.LNout = nullptr; g.ln_mean = const_cast<float*>(ln_mean);
+    g.ln_rstd = const_cast<float*>(ln_rstd); g.Y2 = x_ln ? dx2 : nullptr; g.ln_partial = x_ln ? ln_partial : nullptr;
     if (dtype == SARSSL_BF16) return ffn2_launch<bf16, bf16, true>(g, d, (hipStream_t)stream);
     if (dtype == SARSSL_MIX16) return ffn2_launch<bf16, f16, true>(g, d, (hipStream_t)stream);
     sarssl_set_error("sarssl_ffn2_bwd: dtype %d", dtype);

@@ -258,7 +258,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
@@ -339,6 +339,7 @@ _FFN2 = os.environ.get("SARSSL_FFN2", "1") != "0"             # 0: the feed-forw
 # fused launch owns whole CUs (512 threads, 101-134 KB of LDS); at d = 512 (spec encoder) it runs 100-160 us during which the other
 # encoder's stream gets no CU, and the step is SLOWER with it (same box, two rounds: off 10.69 / 10.70 ms, d = 256 only 10.64 / 10.59,
 # d = 512 only 10.86 / 10.83, both 10.78 / 10.71) although the launch itself beats its two GEMMs alone (101 vs 121 us forward).
+_FFN2_LN = os.environ.get("SARSSL_FFN2_LN", "1") != "0"       # the module's LayerNorm (forward / backward) inside the fused launches (0: own launches)
 _FFN2_FWD = set(int(v) for v in os.environ.get("SARSSL_FFN2_FWD", "256").split(",") if v)
 _FFN2_BWD = set(int(v) for v in os.environ.get("SARSSL_FFN2_BWD", "256").split(",") if v)
 
@@ -388,19 +389,25 @@ def ffn_fwd(x, ff, factor, train, saved, out=None):
     """x + factor * FeedForwardModule(x)  (conformer/feed_forward.py:47-57, Conformer.py:60-67)."""
     seq = ff.sequential
     pre = _PRE_LN.pop(x.data_ptr(), None)           # (block_fwd of the previous block already normalised this very tensor for us)
-    if pre is not None and pre[0] is seq[0]:
-        ln, stats = pre[1], pre[2]
-    else:
-        ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
     d = x.shape[1]
-    if (_FFN2 and d in _FFN2_FWD and not _replaying(train) and not RT.fp8 and hip.ffn2_supported(x.shape[0], d, x.dtype)
-            and seq[1].linear.weight.shape[0] == 4 * d):
-        # one launch for Linear + Swish + Dropout + Linear + Dropout + scaled residual: the hidden tile stays on the CU (csrc/ffn2.hip)
+    fused = (_FFN2 and d in _FFN2_FWD and not _replaying(train) and not RT.fp8 and hip.ffn2_supported(x.shape[0], d, x.dtype)
+             and seq[1].linear.weight.shape[0] == 4 * d)
+    if pre is not None and pre[0] is seq[0]:
+        ln, stats = pre[1], pre[2]
+    elif fused and _FFN2_LN and x.stride(1) == 1:
+        ln = stats = None                           # the fused launch normalises its rows itself (bit-identical to the stand-alone kernel)
+    else:
+        ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+    if fused:
+        # one launch for (LayerNorm +) Linear + Swish + Dropout + Linear + Dropout + scaled residual: the hidden tile stays on the CU (csrc/ffn2.hip)
         packs = _ffn_packs(ff, need_bwd=not RT.inference)
         s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
-        y, hpre, a = hip.ffn2_fwd(ln, packs[0], packs[1], seq[1].linear.bias.data, seq[4].linear.bias.data, x, d, p1=p1, s1=s1, p2=p2, s2=s2,
-                                  out_scale=factor, out=out)
+        r = hip.ffn2_fwd(ln, packs[0], packs[1], seq[1].linear.bias.data, seq[4].linear.bias.data, x, d, p1=p1, s1=s1, p2=p2, s2=s2,
+                         out_scale=factor, out=out, ln_in=None if ln is not None else (x, seq[0].weight.data, seq[0].bias.data, seq[0].eps))
+        y, hpre, a = r[0], r[1], r[2]
+        if ln is None:
+            ln, stats = r[3], r[4]
         saved.append((x, ln, stats, hpre, a, p1, s1, p2, s2, factor))
         return y
     hpre = torch.empty((x.shape[0], seq[1].linear.weight.shape[0]), dtype=x.dtype, device=x.device)
@@ -468,6 +475,12 @@ def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
             # both data-gradient products in one launch: dh = (dz2 W2) * mask * swish'(hpre) leaves the chip once (the two weight-gradient
             # products read it), dln = dh W1 is formed from the LDS-resident tile (csrc/ffn2.hip, packs of the transposed weights)
             packs = _ffn_packs(ff)
+            if _FFN2_LN and x.dtype == hpre.dtype and x.stride(1) == 1 and dy.stride(1) == 1:
+                # ... and the LayerNorm backward of the module's first layer in the same launch's epilogue (dln never leaves the chip)
+                dx, dh = hip.ffn2_bwd(dz2, packs[2], packs[3], hpre, d, p1=p1, s1=s1,
+                                      ln_bwd=(x, seq[0].weight.data, stats, dy, gbuf(seq[0].weight), gbuf(seq[0].bias), _next_drop(next_kind, saved)))
+                mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight), bias=gbuf(seq[1].linear.bias))
+                return dx
             dln, dh = hip.ffn2_bwd(dz2, packs[2], packs[3], hpre, d, p1=p1, s1=s1)
             mm_tn_acc(dh, ln, gbuf(seq[1].linear.weight), bias=gbuf(seq[1].linear.bias))
             return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),

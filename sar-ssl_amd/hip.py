@@ -231,30 +231,70 @@ def ffn_pack(jobs):
                   L(*[s.stride(1) for s, _ in part]), c_int(n), _stream())
 
 
-def ffn2_fwd(ln, w1p, w2p, b1, b2, resid, d, p1=0.0, s1=0, p2=0.0, s2=0, out_scale=1.0, out=None):
-    """-> (y [M, d], preact [M, 4d], hidden [M, 4d]); y = resid + out_scale * drop2(W2 drop1(swish(W1 ln + b1)) + b2)."""
-    _need_cuda(ln, w1p, w2p, b1, b2, resid, out)
-    M = ln.shape[0]
-    pre = torch.empty((M, 4 * d), dtype=ln.dtype, device=ln.device)
-    hid = torch.empty((M, 4 * d), dtype=ln.dtype, device=ln.device)
+def ffn2_fwd(ln, w1p, w2p, b1, b2, resid, d, p1=0.0, s1=0, p2=0.0, s2=0, out_scale=1.0, out=None, ln_in=None):
+    """-> (y [M, d], preact [M, 4d], hidden [M, 4d]); y = resid + out_scale * drop2(W2 drop1(swish(W1 ln + b1)) + b2).
+    ln_in = (x, gamma, beta, eps): the LayerNorm runs in the launch (``ln`` is ignored) -> (y, preact, hidden, ln, stats)."""
+    src = ln if ln_in is None else ln_in[0]
+    _need_cuda(src, w1p, w2p, b1, b2, resid, out)
+    M = src.shape[0]
+    pre = torch.empty((M, 4 * d), dtype=src.dtype, device=src.device)
+    hid = torch.empty((M, 4 * d), dtype=src.dtype, device=src.device)
     if out is None:
-        out = torch.empty((M, d), dtype=ln.dtype, device=ln.device)
-    with _Timed("ffn2_fwd[d%d]" % d if _prof_shapes and _prof is not None else None):
-        _lib.call("sarssl_ffn2_fwd", _p(ln), c_long(ln.stride(0)), _p(w1p), _p(w2p), _p(b1), _p(b2), _p(pre), _p(hid), _p(out), c_long(out.stride(0)),
-                  _p(resid), c_long(resid.stride(0) if resid is not None else 0), c_long(M), c_int(d), c_float(p1), c_ulonglong(s1), c_float(p2),
-                  c_ulonglong(s2), c_float(out_scale), c_int(dt(ln)), _stream())
+        out = torch.empty((M, d), dtype=src.dtype, device=src.device)
+    lno = stats = None
+    if ln_in is not None:
+        x, gamma, beta, eps = ln_in
+        lno = torch.empty((M, d), dtype=x.dtype, device=x.device)
+        stats = torch.empty((2, M), dtype=torch.float32, device=x.device)
+    with _Timed("ffn2_fwd[d%d%s]" % (d, " +ln" if ln_in is not None else "") if _prof_shapes and _prof is not None else None):
+        _lib.call("sarssl_ffn2_fwd", _p(ln), c_long(ln.stride(0) if ln is not None else 0), _p(w1p), _p(w2p), _p(b1), _p(b2), _p(pre), _p(hid), _p(out),
+                  c_long(out.stride(0)), _p(resid), c_long(resid.stride(0) if resid is not None else 0), c_long(M), c_int(d), c_float(p1), c_ulonglong(s1),
+                  c_float(p2), c_ulonglong(s2), c_float(out_scale),
+                  _p(ln_in[0]) if ln_in is not None else c_void_p(0), c_long(ln_in[0].stride(0) if ln_in is not None else 0),
+                  _p(ln_in[1]) if ln_in is not None else c_void_p(0), _p(ln_in[2]) if ln_in is not None else c_void_p(0),
+                  c_float(ln_in[3] if ln_in is not None else 0.0), _p(lno), _p(stats[0]) if stats is not None else c_void_p(0),
+                  _p(stats[1]) if stats is not None else c_void_p(0), c_int(dt(src)), _stream())
+    if ln_in is not None:
+        return out, pre, hid, lno, stats
     return out, pre, hid
 
 
-def ffn2_bwd(dz2, w2tp, w1tp, preact, d, p1=0.0, s1=0):
-    """-> (dln [M, d], dh [M, 4d]) in the gradient dtype of dz2."""
+def ffn2_bwd(dz2, w2tp, w1tp, preact, d, p1=0.0, s1=0, ln_bwd=None):
+    """-> (dln [M, d], dh [M, 4d]) in the gradient dtype of dz2.
+    ln_bwd = (x, gamma, stats, resid, dgamma, dbeta, drop): the LayerNorm backward of the module's first layer runs in the launch's
+    epilogue (hip.layernorm_bwd on dln) -> (dx, dh) or ((dx, dx2), dh) with drop = (p, seed, gscale); dgamma / dbeta are folded from
+    per-tile partials - with the block's other LayerNorms inside ``ln_reduce_batched()``, else right away."""
     _need_cuda(dz2, w2tp, w1tp, preact)
     M = dz2.shape[0]
     dh = torch.empty((M, 4 * d), dtype=dz2.dtype, device=dz2.device)
     dln = torch.empty((M, d), dtype=dz2.dtype, device=dz2.device)
-    with _Timed("ffn2_bwd[d%d]" % d if _prof_shapes and _prof is not None else None):
+    x = gamma = stats = resid = dgamma = dbeta = drop = dx2 = part = None
+    flush_now = None
+    if ln_bwd is not None:
+        x, gamma, stats, resid, dgamma, dbeta, drop = ln_bwd
+        assert x.dtype == preact.dtype
+        if dgamma is not None:
+            part = torch.empty(((M // 64) * 2 * d,), dtype=torch.float32, device=dz2.device)
+            if _ln_batch is not None:
+                _ln_batch.append((part, M // 64, d, dgamma, dbeta))
+            else:
+                flush_now = (part, M // 64, d, dgamma, dbeta)
+        if drop is not None:
+            dx2 = torch.empty((M, d), dtype=dz2.dtype, device=dz2.device)
+    p2, s2, g2 = drop if drop is not None else (0.0, 0, 1.0)
+    with _Timed("ffn2_bwd[d%d%s]" % (d, " +ln" if ln_bwd is not None else "") if _prof_shapes and _prof is not None else None):
         _lib.call("sarssl_ffn2_bwd", _p(dz2), c_long(dz2.stride(0)), _p(w2tp), _p(w1tp), _p(preact), _p(dh), _p(dln), c_long(dln.stride(0)),
-                  c_long(M), c_int(d), c_float(p1), c_ulonglong(s1), c_int(dt_ga(dz2, preact)), _stream())
+                  c_long(M), c_int(d), c_float(p1), c_ulonglong(s1), _p(x), c_long(x.stride(0) if x is not None else 0), _p(gamma),
+                  _p(stats[0]) if stats is not None else c_void_p(0), _p(stats[1]) if stats is not None else c_void_p(0), _p(resid),
+                  c_long(resid.stride(0) if resid is not None else 0), _p(dx2), c_float(p2), c_ulonglong(s2), c_float(g2), _p(part),
+                  c_int(dt_ga(dz2, preact)), _stream())
+    if flush_now is not None:
+        import ctypes
+        _lib.call("sarssl_ln_param_reduce_multi", (ctypes.c_void_p * 1)(flush_now[0].data_ptr()), (ctypes.c_int * 1)(flush_now[1]),
+                  (ctypes.c_int * 1)(flush_now[2]), (ctypes.c_void_p * 1)(flush_now[3].data_ptr()), (ctypes.c_void_p * 1)(flush_now[4].data_ptr()),
+                  c_int(1), _stream())
+    if dx2 is not None:
+        return (dln, dx2), dh
     return dln, dh
 
 

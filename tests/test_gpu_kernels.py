@@ -1328,3 +1328,54 @@ def test_fused_feed_forward_module_fwd_bwd(M, d, p_drop, dtp):
         dh64 = dh64 * keep1
     assert _relerr(dh, dh64) < 2e-2
     assert _relerr(dln, dh.double() @ W1g.double()) < 2e-2
+
+
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,d", [(128, 256), (192, 512), (1024, 256)])
+def test_fused_feed_forward_module_with_its_layernorm(M, d, dtp):
+    """The module's LayerNorm inside the fused launches (feed_forward.py:48): forward - the prologue normalises the tile's rows with the
+    arithmetic of sarssl_layernorm_fwd, so ln / statistics and everything downstream are BIT-identical to LayerNorm launch + fused launch;
+    backward - the epilogue runs sarssl_layernorm_bwd(_drop) on the second product: dx / dx2 / dgamma / dbeta against the stand-alone
+    kernel on the stored dln (same formula; the row sums are folded in another order: f32 round-off apart)."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    gdt = torch.bfloat16
+    H = 4 * d
+    x = (_mk((M, d), torch.float32, dev, 11) * 1.5 + 0.3).to(dtp)
+    gamma = 1.0 + 0.1 * _mk((d,), torch.float32, dev, 12)
+    beta = 0.1 * _mk((d,), torch.float32, dev, 13)
+    W1 = (_mk((H, d), torch.float32, dev, 3) * d ** -0.5).to(dtp)
+    W2 = (_mk((d, H), torch.float32, dev, 4) * H ** -0.5).to(dtp)
+    b1 = _mk((H,), torch.float32, dev, 5) * 0.1
+    b2 = _mk((d,), torch.float32, dev, 6) * 0.1
+    w1p, w2p = torch.empty(H * d, dtype=dtp, device=dev), torch.empty(H * d, dtype=dtp, device=dev)
+    w2tp, w1tp = torch.empty(H * d, dtype=gdt, device=dev), torch.empty(H * d, dtype=gdt, device=dev)
+    hip.ffn_pack([(W1, w1p), (W2, w2p), (W2.to(gdt).t(), w2tp), (W1.to(gdt).t(), w1tp)])
+    p, s1, s2 = 0.1, 77, 78
+    # forward
+    ln_r, st_r = hip.layernorm_fwd(x, gamma, beta, 1e-5)
+    y_r, hpre_r, a_r = hip.ffn2_fwd(ln_r, w1p, w2p, b1, b2, x, d, p1=p, s1=s1, p2=p, s2=s2, out_scale=0.5)
+    y, hpre, a, ln, st = hip.ffn2_fwd(None, w1p, w2p, b1, b2, x, d, p1=p, s1=s1, p2=p, s2=s2, out_scale=0.5, ln_in=(x, gamma, beta, 1e-5))
+    assert torch.equal(ln, ln_r)
+    if d == 256:
+        assert torch.equal(st, st_r)
+    else:       # d = 512 (two float4 per lane): the compiler contracts the variance sum differently in the two kernels - an ulp in mean / rstd
+        assert _relerr(st, st_r) < 1e-6
+    assert torch.equal(hpre, hpre_r) and torch.equal(a, a_r) and torch.equal(y, y_r)
+    # backward
+    dz2 = (_mk((M, d), torch.float32, dev, 7) * 1e-3).to(gdt)
+    dy = (_mk((M, d), torch.float32, dev, 8) * 1e-3).to(gdt)
+    for drop in (None, (0.1, 99, 0.5)):
+        dln_r, dh_r = hip.ffn2_bwd(dz2, w2tp, w1tp, hpre, d, p1=p, s1=s1)
+        dg_r, db_r = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        ref = hip.layernorm_bwd(dln_r, x, gamma, st, resid=dy, dgamma=dg_r, dbeta=db_r, drop=drop)
+        dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        got, dh = hip.ffn2_bwd(dz2, w2tp, w1tp, hpre, d, p1=p, s1=s1, ln_bwd=(x, gamma, st, dy, dg, db, drop))
+        assert torch.equal(dh, dh_r)
+        dx_r, dx2_r = ref if drop is not None else (ref, None)
+        dx, dx2 = got if drop is not None else (got, None)
+        assert _relerr(dx, dx_r) < 1e-2                                         # (bf16 outputs: one rounding step of the largest entry)
+        assert float((dx.float() - dx_r.float()).abs().mean() / dx_r.float().abs().mean()) < 2e-4
+        if drop is not None:
+            assert torch.equal(dx2 == 0, dx2_r == 0) and _relerr(dx2, dx2_r) < 1e-2
+        assert _relerr(dg, dg_r) < 1e-4 and _relerr(db, db_r) < 1e-4

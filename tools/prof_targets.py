@@ -92,6 +92,22 @@ def main():
     gemm_group(10, "gemm patch NT (1024->512)", Mr, 512, 1024)
     gemm_group(11, "gemm ffn1 NT d=256", Mr, 1024, 256, bias=bias[:1024], act=2)
     gemm_group(12, "gemm ffn2 NT d=256", Mr, 256, 1024, bias=bias[:256])
+    # ---- fused feed-forward launches (csrc/ffn2.hip): forward and backward, d = 256 (the default) and d = 512
+    for tag, dd in ((13, 256), (15, 512)):
+        Hh = 4 * dd
+        W1 = rnd(Hh, dd, dtype=AD, scale=dd ** -0.5); W2 = rnd(dd, Hh, dtype=AD, scale=Hh ** -0.5)
+        packs = [torch.empty(Hh * dd, dtype=AD, device=dev), torch.empty(Hh * dd, dtype=AD, device=dev),
+                 torch.empty(Hh * dd, dtype=GD, device=dev), torch.empty(Hh * dd, dtype=GD, device=dev)]
+        hip.ffn_pack([(W1, packs[0]), (W2, packs[1]), (W2.to(GD).t(), packs[2]), (W1.to(GD).t(), packs[3])])
+        lnx, resx = rnd(Mr, dd, dtype=AD), rnd(Mr, dd, dtype=AD)
+        hp = rnd(Mr, Hh, dtype=AD)
+        dz = rnd(Mr, dd, dtype=GD, scale=1e-3)
+        flop = 4.0 * Mr * dd * Hh
+        group(tag, "ffn2 fused forward d=%d (LN out -> y; pre-activation + hidden saved; dropout 0.1)" % dd,
+              lambda: hip.ffn2_fwd(lnx, packs[0], packs[1], bias[:Hh], bias[:dd], resx, dd, p1=0.1, s1=7, p2=0.1, s2=9, out_scale=0.5),
+              flop, 2.0 * (3 * Mr * dd + 2 * Mr * Hh))
+        group(tag + 1, "ffn2 fused backward d=%d (dz2 -> dh saved, dln)" % dd,
+              lambda: hip.ffn2_bwd(dz, packs[2], packs[3], hp, dd, p1=0.1, s1=7), flop, 2.0 * (2 * Mr * dd + 2 * Mr * Hh))
     # ---- stem
     B = 64
     x = rnd(B, 256, 256, 64, dtype=AD)              # a forward activation
