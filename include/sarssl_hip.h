@@ -112,7 +112,7 @@ int sarssl_gemm_group_tn(const void* const* A, const void* const* B, float* cons
  *      function of (seed, row * N + column).  M % 64 == 0, d in {256, 512} (sarssl_ffn2_supported), else use sarssl_gemm.
  *      Weights are read from PACKS in MFMA fragment order (sarssl_ffn_pack: block (n / 32, k / 16) = 64 lanes x 8 elements, lane l =
  *      row 32 nb + (l & 31), k = 16 ks + 8 (l >> 5) ..): src(n, k) = src[n * rs + k * cs], so rs / cs select a matrix or its transpose;
- *      up to 32 matrices per launch; 16-bit elements.
+ *      up to 64 matrices per launch; 16-bit elements.
  *      forward:  y = resid + out_scale * drop(p2, s2)(W2 drop(p1, s1)(swish(W1 ln + b1)) + b2); preact, hidden: [M][4d] saved for backward.
  *                w1p = pack(W1 [4d x d]), w2p = pack(W2 [d x 4d]); dtype SARSSL_F16 | SARSSL_BF16 (every 16-bit tensor).
  *      backward: dh = (dz2 W2) * dropmask(p1, s1) * swish'(preact) [M][4d] (operand of both weight-gradient products), dln = dh W1 [M][d];
@@ -134,6 +134,22 @@ int sarssl_ffn2_bwd(const void* dz2, long lddz, const void* w2tp, const void* w1
                     long M, int d, float p1, unsigned long long s1, const void* x_ln, long ldx, const float* ln_gamma,
                     const float* ln_mean, const float* ln_rstd, const void* resid, long ldr, void* dx2, float p2, unsigned long long s2,
                     float gscale2, float* ln_partial, int dtype, void* stream);
+
+/* ---- row-tile-resident Linear layers of the d = 256 Conformer blocks (round 5, csrc/lin256.hip): nn.Linear / Conv1d(k = 1) forward and
+ *      data gradient (code/common/conformer/attention.py:82-85, :113 q/k/v and output projections; convolution.py:138, :143 pointwise
+ *      convolutions) as ONE launch per layer with the 64 x K input tile resident in LDS and the weights read from fragment-order packs
+ *      (sarssl_ffn_pack) - optionally together with the LayerNorm in front of the layer (attention.py:146, convolution.py:137; forward:
+ *      prologue, bit-identical to sarssl_layernorm_fwd; backward: sarssl_layernorm_bwd(_drop) in the epilogue).  Replaces sarssl_gemm (+ the
+ *      LayerNorm launches) for these shapes: M % 64 == 0, N and K multiples of 256, K <= 768, K == 256 or N == 256.
+ *      fwd: y = resid + out_scale * drop(p, seed)(a W^T + bias), wp = pack(W [N x K]); dtype SARSSL_F16 | SARSSL_BF16.
+ *      bwd: dx = dy Wt^T, wtp = pack(W^T [N x K]) with N = the layer's input width; dtype SARSSL_BF16 | SARSSL_MIX16 (fp16 x_ln). */
+int sarssl_lin256_supported(long M, int N, int K);
+int sarssl_lin256_fwd(const void* a, long lda, const void* wp, const float* bias, void* y, long ldy, const void* resid, long ldr, long M,
+                      int N, int K, float p, unsigned long long seed, float out_scale, const void* x_ln, long ldx, const float* ln_gamma,
+                      const float* ln_beta, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd, int dtype, void* stream);
+int sarssl_lin256_bwd(const void* dy, long lddy, const void* wtp, void* dx, long lddx, long M, int N, int K, const void* x_ln, long ldx,
+                      const float* ln_gamma, const float* ln_mean, const float* ln_rstd, const void* resid, long ldr, void* dx2, float p2,
+                      unsigned long long s2, float gscale2, float* ln_partial, int dtype, void* stream);
 
 /* ---- OCP fp8 (e4m3fn) GEMM path (BASELINE.json config 5; no reference counterpart - the reference is fp32 / fp16-AMP,
  *      code/learner.py:46-50): per-tensor scales chosen on the device, block-scaled MFMA with unit block scales, same fused epilogue as

@@ -55,31 +55,7 @@ struct Ffn2Args {
     void* Y2; float* ln_partial;
 };
 
-struct FfnDrop {
-    unsigned long long seed; uint32_t key0, thr; float inv_keep; float p;
-    __device__ __forceinline__ void init(float p_drop, unsigned long long s, const unsigned long long* salt) {
-        p = p_drop;
-        inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-        seed = 0; key0 = 0; thr = 0;
-        if (p_drop > 0.f) { seed = salted_seed(s, salt); key0 = dropout_key(seed, 0u); thr = dropout_thr16(p_drop); }
-    }
-    // keep-scales of 4 consecutive elements from idx (a multiple of 4)
-    __device__ __forceinline__ void scale4(unsigned long long idx, float (&k)[4]) const {
-        const uint32_t key = (idx >> 33) == 0 ? key0 : dropout_key(seed, (uint32_t)(idx >> 33));
-        const uint32_t pair = (uint32_t)(idx >> 1);
-        const uint32_t h0 = hash_u32(pair ^ key), h1 = hash_u32((pair + 1u) ^ key);
-        k[0] = (h0 & 0xffffu) >= thr ? inv_keep : 0.0f; k[1] = (h0 >> 16) >= thr ? inv_keep : 0.0f;
-        k[2] = (h1 & 0xffffu) >= thr ? inv_keep : 0.0f; k[3] = (h1 >> 16) >= thr ? inv_keep : 0.0f;
-    }
-};
-
-template <typename T>
-__device__ __forceinline__ uint2 pack4(const float (&v)[4]) {
-    uint2 u;
-    u.x = H16<T>::pack(v[0], v[1]);
-    u.y = H16<T>::pack(v[2], v[3]);
-    return u;
-}
+#include "ffn_common.h"
 
 template <typename T, typename TP, int D, bool BWD>
 __global__ __launch_bounds__(FFN_NT) void ffn2_kernel(Ffn2Args g) {
@@ -431,7 +407,7 @@ __global__ __launch_bounds__(FFN_NT) void ffn2_kernel(Ffn2Args g) {
 // ---- weight packs ---------------------------------------------------------------------------------------------------------------------
 // dst block (n / 32, k / 16) = 64 lanes x 8 elements: lane l <- src(n = 32 nb + (l & 31), k = 16 ks + 8 (l >> 5) + 0..7),
 // src(n, k) = src[n * rs + k * cs] (rs / cs select the matrix or its transpose).  One launch for up to FFN_PACK_MAX matrices.
-#define FFN_PACK_MAX 32
+#define FFN_PACK_MAX 64
 struct FfnPackJobs {
     const void* src[FFN_PACK_MAX]; void* dst[FFN_PACK_MAX];
     int N[FFN_PACK_MAX], K[FFN_PACK_MAX]; long rs[FFN_PACK_MAX], cs[FFN_PACK_MAX];

@@ -258,7 +258,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
@@ -373,6 +373,70 @@ def prepare_ffn_packs(ffs, need_bwd=True):
         hip.ffn_pack(jobs)
     for ff, key, bufs in fresh:
         ff.__dict__["_ffn2_packs"] = (key, bufs)
+
+
+# LayerNorm + q/k/v / first pointwise convolution (and their data gradient + LayerNorm backward) of the d = 256 blocks as one tile-resident
+# launch each (csrc/lin256.hip).  OFF by default: alone the launches beat the pairs they replace (LayerNorm + q/k/v 21.2 vs 27.4 us, data
+# gradient + LayerNorm backward 33.0 vs 37.7 us; tools/bench_lin256.py), inside the two-stream step they do not - same box, three interleaved
+# rounds: 10.67 / 10.67 / 10.66 ms with, 10.64 / 10.62 / 10.65 ms without.  Like the d = 512 feed-forward launch, a 512-thread / 100 KB
+# workgroup owns its CU, and what it displaces from the other encoder's stream costs what it saves (NOTES.md section 10).
+_LIN256 = os.environ.get("SARSSL_LIN256", "0") != "0"
+
+
+def _lin_pack_jobs(owner, name, w_fwd, w_bwd, need_bwd):
+    """Pack jobs (and the cache entry to commit) of one Linear weight [N, K]: forward pack of W in the forward dtype, pack of W^T in the
+    gradient dtype; persistent buffers on ``owner`` (an nn.Module), stale when the weights' version moved."""
+    key = (weights_version(), w_fwd.dtype, w_fwd.data_ptr(), bool(need_bwd))
+    c = owner.__dict__.get("_lin256_" + name)
+    if c is not None and (c[0] == key or (c[0][:3] == key[:3] and c[0][3])):
+        return [], None
+    bufs = owner.__dict__.get("_lin256_bufs_" + name)
+    if bufs is None or bufs[0].dtype != w_fwd.dtype or bufs[0].device != w_fwd.device or bufs[0].numel() != w_fwd.numel():
+        bufs = owner.__dict__["_lin256_bufs_" + name] = (torch.empty(w_fwd.numel(), dtype=w_fwd.dtype, device=w_fwd.device),
+                                                         torch.empty(w_fwd.numel(), dtype=RT.gdtype, device=w_fwd.device))
+    jobs = [(w_fwd, bufs[0])]
+    if need_bwd:
+        jobs.append((w_bwd.t(), bufs[1]))
+    return jobs, ("_lin256_" + name, key, bufs)
+
+
+def _lin256_weights(blk_mod, kind):
+    """(forward view [N, K], gradient-side view) of the layer a tile-resident launch replaces: 'qkv' of an attention module (the three
+    projections back to back in the flat buffers) or 'pw1' of a convolution module; None when the layout does not allow it."""
+    if kind == "qkv":
+        att = blk_mod.attention
+        f, gsd = _qkv_views(att), _qkv_views(att, grad=True)
+        return None if f is None or gsd is None else (f[0], gsd[0])
+    pw1 = blk_mod.sequential[2].conv
+    d = pw1.weight.shape[1]
+    return wt(pw1.weight).view(2 * d, d), wtg(pw1.weight).view(2 * d, d)
+
+
+def prepare_lin256_packs(mods, need_bwd=True):
+    """mods: [(module, kind)] - packs of every stale weight in one launch (model._PretrainFn: once per step for the whole spat encoder)."""
+    jobs, commits = [], []
+    for m, kind in mods:
+        ws = _lin256_weights(m, kind)
+        if ws is None or ws[0].dtype not in _16 or not ws[0].is_cuda or ws[0].shape[1] != 256:
+            continue
+        j, c = _lin_pack_jobs(m, kind, ws[0], ws[1], need_bwd)
+        jobs += j
+        if c is not None:
+            commits.append((m, c))
+    if jobs:
+        hip.ffn_pack(jobs)
+    for m, (name, key, bufs) in commits:
+        m.__dict__[name] = (key, bufs)
+
+
+def _lin256_pack(m, kind, need_bwd=True):
+    prepare_lin256_packs([(m, kind)], need_bwd)
+    c = m.__dict__.get("_lin256_" + kind)
+    return None if c is None else c[1]
+
+
+def block_lin256_mods(enc):
+    return [(blk.sequential[1].module, "qkv") for blk in enc.layers] + [(blk.sequential[2].module, "pw1") for blk in enc.layers]
 
 
 def _ffn_packs(ff, need_bwd=True):
@@ -535,9 +599,18 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     att = mod.attention
     H, dh, d = att.num_heads, att.d_head, att.d_model
     M = B * T
-    ln, stats = hip.layernorm_fwd(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps)
     fused = _qkv_views(att)
-    if fused is not None:                       # one [M, 3d] GEMM; q / k / v are column slices (row stride 3d)
+    lin = (_LIN256 and fused is not None and d == 256 and not RT.fp8 and not _replaying(train) and x.stride(1) == 1
+           and hip.lin256_supported(M, 3 * d, d, x.dtype))
+    pk = _lin256_pack(mod, "qkv", need_bwd=not RT.inference) if lin else None
+    if pk is not None:      # LayerNorm + the [M, 3d] projection in one tile-resident launch (csrc/lin256.hip)
+        qkv, ln, stats = hip.lin256_fwd(None, pk[0], fused[1], 3 * d, d, ln_in=(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps))
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    else:
+        ln, stats = hip.layernorm_fwd(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps)
+    if pk is not None:
+        pass
+    elif fused is not None:                     # one [M, 3d] GEMM; q / k / v are column slices (row stride 3d)
         qkv = mm_nt(ln, fused[0], bias=fused[1])
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
     else:
@@ -700,6 +773,12 @@ def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb
     dq = dq_out if dq_done else hip.axpby2d(dqu, dqv, 1.0, 1.0, out=dq_out)      # (dq_done: the attention backward wrote dqu + dqv itself)
     if fused is not None:
         mm_tn_acc(dqkv, ln, fused[2], bias=fused[3])
+        pk = mod.__dict__.get("_lin256_qkv")
+        if (_LIN256 and pk is not None and pk[0][3] and pk[0][0] == weights_version() and d == 256 and dqkv.dtype in _16 and x.dtype == ln.dtype
+                and x.stride(1) == 1 and dy.stride(1) == 1 and hip.lin256_supported(dqkv.shape[0], d, 3 * d, dqkv.dtype)):
+            # data gradient of the projection + the LayerNorm backward in one tile-resident launch
+            return hip.lin256_bwd(dqkv, pk[1][1], d, 3 * d, ln_bwd=(x, mod.layer_norm.weight.data, stats, dy, gbuf(mod.layer_norm.weight),
+                                                                     gbuf(mod.layer_norm.bias), drop))
         dln = mm_nn(dqkv, fused[0])
     else:
         for proj, g in ((att.query_proj, dq), (att.key_proj, dk), (att.value_proj, dv)):
@@ -715,9 +794,14 @@ def convmod_fwd(x, cm, B, T, train, saved):
     """x + ConformerConvModule(x)  (conformer/convolution.py:136-149)."""
     seq = cm.sequential
     d = x.shape[1]
-    ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
     pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
-    h = mm_nt(ln, wt(pw1.weight).view(2 * d, d), bias=pw1.bias.data)                         # [M, 2d]
+    lin = (_LIN256 and d == 256 and not RT.fp8 and not _replaying(train) and x.stride(1) == 1 and hip.lin256_supported(x.shape[0], 2 * d, d, x.dtype))
+    pk = _lin256_pack(cm, "pw1", need_bwd=not RT.inference) if lin else None
+    if pk is not None:      # LayerNorm + first pointwise convolution in one tile-resident launch (csrc/lin256.hip)
+        h, ln, stats = hip.lin256_fwd(None, pk[0], pw1.bias.data, 2 * d, d, ln_in=(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps))
+    else:
+        ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+        h = mm_nt(ln, wt(pw1.weight).view(2 * d, d), bias=pw1.bias.data)                     # [M, 2d]
     g = None
     if _DWGLU and d % 8 == 0:            # GLU + depthwise conv + BatchNorm batch sums in one LDS-tiled pass (csrc/dwconv.hip)
         c, sums = hip.dwglu_fwd(h, dw.weight.data.view(d, -1), B, T, want_stats=True) if train else \
@@ -767,6 +851,11 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
         hip.dwconv_wgrad(dc, g.view(B, T, d), gbuf(dw.weight).view(d, -1))
         dh = hip.glu_bwd(dg.view(B * T, d), h)
     mm_tn_acc(dh, ln, gbuf(pw1.weight), bias=gbuf(pw1.bias))
+    pk = cm.__dict__.get("_lin256_pw1")
+    if (_LIN256 and pk is not None and pk[0][3] and pk[0][0] == weights_version() and d == 256 and dh.dtype in _16 and x.dtype == ln.dtype
+            and x.stride(1) == 1 and dy.stride(1) == 1 and dh.stride(1) == 1 and hip.lin256_supported(dh.shape[0], d, 2 * d, dh.dtype)):
+        return hip.lin256_bwd(dh, pk[1][1], d, 2 * d, ln_bwd=(x, seq[0].weight.data, stats, dy, gbuf(seq[0].weight), gbuf(seq[0].bias),
+                                                               _next_drop(next_kind, saved)))
     dln = mm_nn(dh, wtg(pw1.weight).view(2 * d, d))
     return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
                              drop=_next_drop(next_kind, saved))

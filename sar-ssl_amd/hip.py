@@ -218,9 +218,9 @@ def ffn2_supported(M, d, dtype):
 
 def ffn_pack(jobs):
     """jobs: [(src 2-D view (N, K) - any strides, e.g. ``W`` or ``W.t()`` -, dst flat 16-bit tensor of N * K elements)]: every matrix
-    into MFMA fragment order (include/sarssl_hip.h) in ONE launch (<= 32 per launch)."""
-    for i in range(0, len(jobs), 32):
-        part = jobs[i:i + 32]
+    into MFMA fragment order (include/sarssl_hip.h) in ONE launch (<= 64 per launch)."""
+    for i in range(0, len(jobs), 64):
+        part = jobs[i:i + 64]
         n = len(part)
         _need_cuda(*[t for j in part for t in j])
         for src, dst in part:
@@ -296,6 +296,74 @@ def ffn2_bwd(dz2, w2tp, w1tp, preact, d, p1=0.0, s1=0, ln_bwd=None):
     if dx2 is not None:
         return (dln, dx2), dh
     return dln, dh
+
+
+# ---- row-tile-resident Linear layers of the d = 256 blocks (csrc/lin256.hip) ------------------------------------------------------------
+def lin256_supported(M, N, K, dtype):
+    return dtype in _16 and bool(_lib.lib().sarssl_lin256_supported(c_long(M), c_int(N), c_int(K)))
+
+
+def _ln_partial_register(M, d, dgamma, dbeta, device):
+    """partials [M / 64][2][d] of a fused LayerNorm backward: folded with the block's other LayerNorms inside ln_reduce_batched(), else
+    by the returned callable right behind the launch."""
+    part = torch.empty(((M // 64) * 2 * d,), dtype=torch.float32, device=device)
+    item = (part, M // 64, d, dgamma, dbeta)
+    if _ln_batch is not None:
+        _ln_batch.append(item)
+        return part, None
+
+    def flush():
+        import ctypes
+        _lib.call("sarssl_ln_param_reduce_multi", (ctypes.c_void_p * 1)(item[0].data_ptr()), (ctypes.c_int * 1)(item[1]), (ctypes.c_int * 1)(item[2]),
+                  (ctypes.c_void_p * 1)(item[3].data_ptr()), (ctypes.c_void_p * 1)(item[4].data_ptr()), c_int(1), _stream())
+    return part, flush
+
+
+def lin256_fwd(a, wp, bias, N, K, resid=None, p_drop=0.0, seed=0, out_scale=1.0, out=None, ln_in=None):
+    """y [M, N] = resid + out_scale * drop(a W^T + bias), wp = pack(W [N, K]).  ln_in = (x, gamma, beta, eps): a = LayerNorm(x) formed in the
+    launch -> (y, ln, stats)."""
+    src = a if ln_in is None else ln_in[0]
+    _need_cuda(src, wp, bias, resid, out)
+    M = src.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=src.dtype, device=src.device)
+    lno = stats = None
+    if ln_in is not None:
+        lno = torch.empty((M, K), dtype=src.dtype, device=src.device)
+        stats = torch.empty((2, M), dtype=torch.float32, device=src.device)
+    with _Timed("lin256_fwd[%d,%d%s]" % (N, K, " +ln" if ln_in is not None else "") if _prof_shapes and _prof is not None else None):
+        _lib.call("sarssl_lin256_fwd", _p(a), c_long(a.stride(0) if a is not None else 0), _p(wp), _p(bias), _p(out), c_long(out.stride(0)), _p(resid),
+                  c_long(resid.stride(0) if resid is not None else 0), c_long(M), c_int(N), c_int(K), c_float(p_drop), c_ulonglong(seed),
+                  c_float(out_scale), _p(ln_in[0]) if ln_in is not None else c_void_p(0), c_long(ln_in[0].stride(0) if ln_in is not None else 0),
+                  _p(ln_in[1]) if ln_in is not None else c_void_p(0), _p(ln_in[2]) if ln_in is not None else c_void_p(0),
+                  c_float(ln_in[3] if ln_in is not None else 0.0), _p(lno), _p(stats[0]) if stats is not None else c_void_p(0),
+                  _p(stats[1]) if stats is not None else c_void_p(0), c_int(dt(src)), _stream())
+    return (out, lno, stats) if ln_in is not None else out
+
+
+def lin256_bwd(dy, wtp, N, K, ln_bwd=None):
+    """dx [M, N] = dy [M, K] W (wtp = pack(W^T [N, K])).  ln_bwd = (x, gamma, stats, resid, dgamma, dbeta, drop): the LayerNorm backward of
+    the layer's input runs in the epilogue -> dx or (dx, dx2)."""
+    _need_cuda(dy, wtp)
+    M = dy.shape[0]
+    dx = torch.empty((M, N), dtype=dy.dtype, device=dy.device)
+    x = gamma = stats = resid = dx2 = part = flush = None
+    drop = None
+    if ln_bwd is not None:
+        x, gamma, stats, resid, dgamma, dbeta, drop = ln_bwd
+        if dgamma is not None:
+            part, flush = _ln_partial_register(M, N, dgamma, dbeta, dy.device)
+        if drop is not None:
+            dx2 = torch.empty((M, N), dtype=dy.dtype, device=dy.device)
+    p2, s2, g2 = drop if drop is not None else (0.0, 0, 1.0)
+    with _Timed("lin256_bwd[%d,%d%s]" % (N, K, " +ln" if ln_bwd is not None else "") if _prof_shapes and _prof is not None else None):
+        _lib.call("sarssl_lin256_bwd", _p(dy), c_long(dy.stride(0)), _p(wtp), _p(dx), c_long(dx.stride(0)), c_long(M), c_int(N), c_int(K), _p(x),
+                  c_long(x.stride(0) if x is not None else 0), _p(gamma), _p(stats[0]) if stats is not None else c_void_p(0),
+                  _p(stats[1]) if stats is not None else c_void_p(0), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(dx2),
+                  c_float(p2), c_ulonglong(s2), c_float(g2), _p(part), c_int(dt_ga(dy, x) if x is not None else dt(dy)), _stream())
+    if flush is not None:
+        flush()
+    return (dx, dx2) if dx2 is not None else dx
 
 
 _splitk_batch = None

@@ -140,6 +140,9 @@ class _PretrainFn(torch.autograd.Function):
         if engine._FFN2 and RT.dtype in engine._16 and not RT.fp8 and RT.replay is None:
             # fragment-order packs of every feed-forward module's weights for the fused kernel: one launch per step, on the main stream
             engine.prepare_ffn_packs(engine.block_ffns(net.spec_encoder.embed) + engine.block_ffns(net.spat_encoder.embed), need_bwd=not RT.inference)
+            if engine._LIN256:
+                engine.prepare_lin256_packs(engine.block_lin256_mods(net.spec_encoder.embed) + engine.block_lin256_mods(net.spat_encoder.embed),
+                                            need_bwd=not RT.inference)
         pre = net.__dict__.pop("_premasked", None)          # (graph.py: the front-end launch already applied the masks to this very x)
         if pre is not None and pre[0] is x and pre[1].dtype == RT.dtype:
             spec_in, spat_in = pre[1], pre[2]

@@ -1379,3 +1379,60 @@ def test_fused_feed_forward_module_with_its_layernorm(M, d, dtp):
         if drop is not None:
             assert torch.equal(dx2 == 0, dx2_r == 0) and _relerr(dx2, dx2_r) < 1e-2
         assert _relerr(dg, dg_r) < 1e-4 and _relerr(db, db_r) < 1e-4
+
+
+# ---------------------------------------------------------------- row-tile-resident Linear layers of the d = 256 blocks (csrc/lin256.hip)
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 768, 256), (192, 512, 256), (256, 256, 256), (128, 256, 768), (192, 256, 512), (1024, 768, 256)])
+def test_tile_resident_linear_layers(M, N, K, dtp):
+    """nn.Linear / pointwise Conv1d of the d = 256 blocks as one launch per layer (attention.py:82-85, convolution.py:138,143) against the
+    sarssl_gemm launches it replaces: forward with bias / dropout / residual (same MFMA products in the same order, same dropout
+    decisions: equal to the last rounding), with the LayerNorm in front formed in the prologue (bit-identical to sarssl_layernorm_fwd +
+    the plain launch); data gradient plain and with the LayerNorm backward in the epilogue (against sarssl_layernorm_bwd_drop)."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    gdt = torch.bfloat16
+    a = _mk((M, K), torch.float32, dev, 1).to(dtp)
+    W = (_mk((N, K), torch.float32, dev, 2) * K ** -0.5).to(dtp)
+    bias = _mk((N,), torch.float32, dev, 3) * 0.1
+    wp = torch.empty(N * K, dtype=dtp, device=dev)
+    hip.ffn_pack([(W, wp)])
+    res = _mk((M, N), torch.float32, dev, 4).to(dtp)
+    # forward: bias + dropout + residual
+    y = hip.lin256_fwd(a, wp, bias, N, K, resid=res, p_drop=0.1, seed=5)
+    y_r = hip.gemm(a, W, M=M, N=N, K=K, lda=K, ldb=K, bias=bias, p_drop=0.1, seed=5, resid=res, ldr=N, res_scale=1.0)
+    assert _relerr(y, y_r) < 1e-6
+    y = hip.lin256_fwd(a, wp, bias, N, K)
+    assert torch.equal(y, hip.gemm(a, W, M=M, N=N, K=K, lda=K, ldb=K, bias=bias))
+    ref64 = a.double() @ W.double().t() + bias.double()
+    assert _relerr(y, ref64) < (4e-3 if dtp == torch.float16 else 2e-2)
+    if K == 256:    # LayerNorm prologue
+        x = (_mk((M, K), torch.float32, dev, 6) * 1.3 + 0.2).to(dtp)
+        gamma, beta = 1.0 + 0.1 * _mk((K,), torch.float32, dev, 7), 0.1 * _mk((K,), torch.float32, dev, 8)
+        ln_r, st_r = hip.layernorm_fwd(x, gamma, beta, 1e-5)
+        y2, ln, st = hip.lin256_fwd(None, wp, bias, N, K, ln_in=(x, gamma, beta, 1e-5))
+        assert torch.equal(ln, ln_r) and torch.equal(st, st_r) and torch.equal(y2, hip.lin256_fwd(ln_r, wp, bias, N, K))
+    # data gradient: dx [M, K] = dy [M, N] W   (pack of W^T: [K x N])
+    if N <= 768 and (N == 256 or K == 256):
+        dy = (_mk((M, N), torch.float32, dev, 9) * 1e-3).to(gdt)
+        Wg = W.to(gdt)
+        wtp = torch.empty(N * K, dtype=gdt, device=dev)
+        hip.ffn_pack([(Wg.t(), wtp)])
+        dx = hip.lin256_bwd(dy, wtp, K, N)
+        dx_r = hip.gemm(dy, Wg, a_kc=True, b_kc=False, M=M, N=K, K=N, lda=N, ldb=K)
+        assert torch.equal(dx, dx_r)
+        if K == 256:
+            x = (_mk((M, K), torch.float32, dev, 6) * 1.3 + 0.2).to(dtp)
+            gamma = 1.0 + 0.1 * _mk((K,), torch.float32, dev, 7)
+            _, st = hip.layernorm_fwd(x, gamma, torch.zeros(K, device=dev), 1e-5)
+            rs = (_mk((M, K), torch.float32, dev, 10) * 1e-3).to(gdt)
+            for drop in (None, (0.1, 31, 0.5)):
+                dg_r, db_r = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+                ref = hip.layernorm_bwd(dx_r, x, gamma, st, resid=rs, dgamma=dg_r, dbeta=db_r, drop=drop)
+                dg, db = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+                got = hip.lin256_bwd(dy, wtp, K, N, ln_bwd=(x, gamma, st, rs, dg, db, drop))
+                g1, r1 = (got[0], ref[0]) if drop is not None else (got, ref)
+                assert _relerr(g1, r1) < 1e-2 and float((g1.float() - r1.float()).abs().mean() / r1.float().abs().mean()) < 2e-4
+                if drop is not None:
+                    assert torch.equal(got[1] == 0, ref[1] == 0) and _relerr(got[1], ref[1]) < 1e-2
+                assert _relerr(dg, dg_r) < 1e-4 and _relerr(db, db_r) < 1e-4
