@@ -274,7 +274,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a > 2 s timed region at ~11 ms per step)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="segments per GPU (default 64; config5: 16 four-microphone segments = 48 pairs)")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "fp32_1pass", "fp8"])
+    # (round 5: "fp8" is no longer a bench choice - the e4m3 Linear GEMMs are 1.2-1.65x faster than the bf16 kernels, the just-in-time
+    #  quantisation makes the step 7-12 % SLOWER and the ceiling with fused quantisation is +4-6 % (NOTES.md 4.5): the mode stays in
+    #  runtime.set_precision as a parity-tested experiment, tests/test_gpu_fp8.py, and is not advertised as a configuration to time)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "fp32_1pass"])
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-product-loop", action="store_true")

@@ -223,6 +223,9 @@ int sarssl_conv3x3_dgrad_bnred(const void* dy, const void* w, void* dz, int nb, 
 /*      scheduling aid (no reference counterpart): sarssl_ctx_set_conv_cus - workgroup count of the 3x3 gradient launches (data and weight
  *      gradients) issued under the context; 0 = the default rule (7/8 of the CUs, leaving room for the other encoder's stream). */
 long sarssl_wall_clock_khz();
+/*      sarssl_stamp: a one-thread launch that stores the constant-rate device clock (sarssl_wall_clock_khz ticks per ms) to *dst -
+ *      capturable into the step graph: timeline markers of an unprofiled replay (tools/step_stamps.py) */
+int sarssl_stamp(unsigned long long* dst, void* stream);
 long sarssl_conv3x3_wgrad_workspace_bytes(int nb, int F, int T);
 int sarssl_conv3x3_wgrad(const void* dy, const void* zin, int dtype, int nb, int F, int T, const float* scale,
                          const float* shift, float* dW, float* partial, int precise, void* stream);

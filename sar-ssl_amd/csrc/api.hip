@@ -80,6 +80,15 @@ __global__ void step_tick_kernel(SarsslStepState* s) {
     s->step_size = (float)((double)s->lr / bc1);
     s->inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
 }
+// Measurement aid: one 64-bit store of the constant-rate device clock (s_memrealtime: sarssl_wall_clock_khz ticks per ms) - a marker that
+// can be captured into the step graph between two launches of a stream, so that the timeline of an UNPROFILED replay can be read back
+// (tools/step_stamps.py: rocprofv3 delays the second hardware queue's packets, its traces under-state the two-stream overlap).
+__global__ void stamp_kernel(unsigned long long* dst) { *dst = __builtin_amdgcn_s_memrealtime(); }
+extern "C" int sarssl_stamp(unsigned long long* dst, void* stream) {
+    stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(dst);
+    SARSSL_CHECK_LAUNCH("stamp_kernel");
+    return 0;
+}
 extern "C" int sarssl_step_state_skipped(const void* state, void* stream) {
     SarsslStepState h;
     if (hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;

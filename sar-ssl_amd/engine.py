@@ -452,7 +452,7 @@ def block_ffns(enc):
 def ffn_fwd(x, ff, factor, train, saved, out=None):
     """x + factor * FeedForwardModule(x)  (conformer/feed_forward.py:47-57, Conformer.py:60-67)."""
     seq = ff.sequential
-    pre = _PRE_LN.pop(x.data_ptr(), None)           # (block_fwd of the previous block already normalised this very tensor for us)
+    pre = x.__dict__.pop("_pre_ln", None)            # (block_fwd of the previous block already normalised this very tensor for us)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
     d = x.shape[1]
     fused = (_FFN2 and d in _FFN2_FWD and not _replaying(train) and not RT.fp8 and hip.ffn2_supported(x.shape[0], d, x.dtype)
@@ -862,7 +862,6 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
 
 
 _LN_PAIR = os.environ.get("SARSSL_LN_PAIR", "1") != "0"       # 0: the two LayerNorms of a block boundary as two launches (A/B runs)
-_PRE_LN = {}          # data_ptr of a block's output -> (LayerNorm module, its output, its statistics) computed by the previous block's closing launch
 
 
 def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None):
@@ -876,8 +875,10 @@ def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None):
     if next_blk is not None and out is None and _LN_PAIR:
         nln = next_blk.sequential[0].module.sequential[0]
         y, stats, z, zstats = hip.layernorm_fwd2(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps)
-        _PRE_LN.clear()
-        _PRE_LN[y.data_ptr()] = (nln, z, zstats)
+        # the paired LayerNorm's result travels ON the tensor object it belongs to (round 4 kept it in a process-global dict keyed by the
+        # tensor's address: a stale entry could outlive its tensor and match a recycled address - advisor): whoever consumes y as the next
+        # block's input finds it, anything else never sees it, and it dies with y
+        y._pre_ln = (nln, z, zstats)
     else:
         y, stats = hip.layernorm_fwd(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
     saved.append((x, stats))

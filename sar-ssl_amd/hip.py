@@ -799,6 +799,20 @@ def conv3x3_fwd_c1(a0, W1, scale, shift, w_tap, want_stats=False):
     return (out, stats) if want_stats else out
 
 
+_stamps = None              # (int64 device tensor, [labels]) while tools/step_stamps.py records timeline markers
+
+
+def stamp(label):
+    """Timeline marker (tools only): records the device clock on the current stream when markers are being collected, else nothing."""
+    if _stamps is None:
+        return
+    buf, labels = _stamps
+    i = len(labels)
+    if i < buf.numel():
+        labels.append(label)
+        _lib.call("sarssl_stamp", c_void_p(buf.data_ptr() + 8 * i), _stream())
+
+
 def conv_clock_probe(buf):
     """Clock-probe buffer (int64[20] device tensor, or None) of the 3x3 forward / data-gradient launches of this thread's context."""
     _lib.call("sarssl_ctx_set_clock_probe", c_void_p(_lib._make_current()), _p(buf))

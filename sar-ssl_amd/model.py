@@ -167,20 +167,27 @@ class _PretrainFn(torch.autograd.Function):
             train = net.training
             spe, spa = net.spec_encoder, net.spat_encoder
             with torch.cuda.stream(side):
+                hip.stamp("fwd.spat.stem.begin")
                 e_spat = engine.stem_fwd(spat_in, spa.patch_embed, train, saved_spat)
+                hip.stamp("fwd.spat.stem.end")
+            hip.stamp("fwd.spec.stem.begin")
             e_spec = engine.stem_fwd(spec_in, spe.patch_embed, train, saved)
+            hip.stamp("fwd.spec.stem.end")
             nl = len(spa.embed.layers)
             with torch.cuda.stream(side):
                 e_spat = engine.block_fwd(e_spat, spa.embed.layers[0], B, T, train, saved_spat, out=ecat[:, ds:] if nl == 1 else None,
                                           next_blk=spa.embed.layers[1] if nl > 1 else None)
             assert len(spe.embed.layers) == 1
             engine.block_fwd(e_spec, spe.embed.layers[0], B, T, train, saved, out=ecat[:, :ds])
+            hip.stamp("fwd.spec.block.end")
             with torch.cuda.stream(side):
                 for li in range(1, nl):
                     e_spat = engine.block_fwd(e_spat, spa.embed.layers[li], B, T, train, saved_spat,
                                               out=ecat[:, ds:] if li == nl - 1 else None,
                                               next_blk=spa.embed.layers[li + 1] if li + 1 < nl else None)
+                hip.stamp("fwd.spat.blocks.end")
             main.wait_stream(side)
+            hip.stamp("fwd.join")
         else:
             net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
             net.spat_encoder._fwd_cl(spat_in, B, T, saved_spat, out=ecat[:, ds:])
@@ -205,7 +212,9 @@ class _PretrainFn(torch.autograd.Function):
         dpred = getattr(ctx, "dpred", None)
         if dpred is None:
             dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
+        hip.stamp("bwd.decoder.begin")
         decat = engine.decoder_bwd(dpred, net.decoder, saved)
+        hip.stamp("bwd.decoder.end")
         net._after_backward_stage("decoder")
         saved_spat = saved.pop()
         # encoder backward takes column slices of the concatenated decoder-input gradient (row stride 768).  Schedule: all
@@ -220,16 +229,20 @@ class _PretrainFn(torch.autograd.Function):
         spe, spa = net.spec_encoder, net.spat_encoder
         nl = len(spa.embed.layers)
         with on_side():                                         # the host enqueues the two streams in alternating chunks, see forward
+            hip.stamp("bwd.spat.blocks.begin")
             d_spat = decat[:, ds:]
             for li in range(nl - 1, 0, -1):
                 d_spat = engine.block_bwd(d_spat, spa.embed.layers[li], saved_spat)
         d_spec = decat[:, :ds]
+        hip.stamp("bwd.spec.block.begin")
         for blk in reversed(spe.embed.layers):
             d_spec = engine.block_bwd(d_spec, blk, saved)
+        hip.stamp("bwd.spec.block.end")
         cut = side is not None and getattr(net, "_cut_mode", False)   # graph capture cut at the bucket boundaries (graph.py): a cut
         with on_side():                                               # needs both streams joined, so the two hooks fire after the join
             d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat)
             dz_spat = engine.patch_bwd(d_spat, spa.patch_embed, saved_spat)
+            hip.stamp("bwd.spat.blocks.end")
             if not cut:
                 net._after_backward_stage("spat_encoder")      # its bucket is reduced behind the side stream
         dz_spec = engine.patch_bwd(d_spec, spe.patch_embed, saved)
@@ -251,10 +264,14 @@ class _PretrainFn(torch.autograd.Function):
         all_cus = 1 << 16 if (engine._STEM_LAST_ALL_CUS and not _dist.exchanging()) else 0
         try:        # the override is per host thread (here: autograd's worker) and must not outlive this pass if a launch raises
             hip.conv_cus_override(all_cus if side is None else 0)
+            hip.stamp("bwd.spec.stem.begin")
             engine.stem_bwd(dz_spec, spe.patch_embed, saved)
+            hip.stamp("bwd.spec.stem.end")
             hip.conv_cus_override(all_cus)
             with on_side():
+                hip.stamp("bwd.spat.stem.begin")
                 engine.stem_bwd(dz_spat, spa.patch_embed, saved_spat)
+                hip.stamp("bwd.spat.stem.end")
         finally:
             hip.conv_cus_override(0)
         if side is not None:
