@@ -392,6 +392,20 @@ int sarssl_masked_mse_fwd_bwd(const void* pred, const float* x, const int* idx, 
                               double* sums, float* out, float* out_keep, double* acc, void* dpred, int dtype, void* stream);
 int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F, int Tn,
                           int nm, float gscale, const float* gscale_dev, void* dpred, int dtype, void* stream);
+/* ---- the decoder on the masked frames only (round 5).  gen_loss (code/model.py:721-747) reads the prediction at the masked frames of
+ *      the masked channel; EmbedDecoder ['', 'fc'] (code/model.py:296-301, :321-334) is Linear - ReLU - Linear on every frame separately.
+ *      Rows of unmasked frames therefore get a zero gradient and add nothing to a parameter gradient: the training step runs the decoder
+ *      on the nb * nm gathered rows (exact; half the decoder's forward, data-gradient and weight-gradient work) and forms the full
+ *      prediction only on request (vis).  idx [nb][nm] int32 ASCENDING per item; rows are 16-bit or f32 (dtype), d % 8 == 0.
+ *      sarssl_gather_rows: dst [nb * nm][d] <- src rows (b, idx[b][j]); sarssl_scatter_rows: dst [nb * Tn][d] (zeroed first) <- src rows.
+ *      sarssl_masked_mse_compact: loss / diff (and dpred_c for an incoming gradient of 1 when dpred_c != NULL) on pred_c [nb][nm][F * 4];
+ *      sarssl_masked_mse_bwd_compact: the stand-alone gradient, scaled by gscale * (*gscale_dev). */
+int sarssl_gather_rows(const void* src, long ld_src, const int* idx, int nb, int Tn, int nm, int d, void* dst, int dtype, void* stream);
+int sarssl_scatter_rows(const void* src, const int* idx, int nb, int Tn, int nm, int d, void* dst, long ld_dst, int dtype, void* stream);
+int sarssl_masked_mse_compact(const void* pred_c, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm, double* sums,
+                              float* out, float* out_keep, double* acc, void* dpred_c, int dtype, void* stream);
+int sarssl_masked_mse_bwd_compact(const void* pred_c, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
+                                  float gscale, const float* gscale_dev, void* dpred_c, int dtype, void* stream);
 
 /* ---- optimiser: torch.optim.Adam(betas=(0.9,0.999), weight_decay=0) at code/learner.py:83, over one flat buffer */
 /*      p16 / ph16 (either may be null): bf16 / fp16 shadow copies of the updated parameters, the GEMM / convolution operands */

@@ -699,27 +699,35 @@ __global__ void f64_accum2_kernel(const double* __restrict__ s, float* __restric
 // dpred (optional; TG = gradient dtype): the loss gradient 2 (pred - tar) / count of the same entries, zero elsewhere, written for all
 // eight frames of the workgroup's group - what masked_mse_bwd_kernel computes with an incoming gradient of 1 (the captured step's
 // backward starts right behind this launch; a separate pass re-read pred and x from a stretch of the step nothing overlaps)
-template <typename T, typename TG>
+// COMPACT: pred / dpred hold the MASKED frames only, [nb][nm][F * 4] with an item's rows in ascending frame order (the decoder ran on
+// the gathered rows, sarssl_gather_rows): frame t of item b lives in row (number of masked frames of b below t).
+template <typename T, typename TG, bool COMPACT = false>
 __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ x,
                                                              const int* __restrict__ idx, const int* __restrict__ mch, int nb,
                                                              int F, int Tn, int nm, double* __restrict__ sums,
                                                              TG* __restrict__ dpred = nullptr, float coef = 0.f) {
     extern __shared__ float sp[];                       // [MSE_TT][F * 4]
     __shared__ unsigned smask;
+    __shared__ int sbelow;
     __shared__ float red[2][4];
     const int groups = (Tn + MSE_TT - 1) / MSE_TT;
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int t0 = g * MSE_TT, mc = mch[b];
-    if (threadIdx.x == 0) smask = 0u;
+    if (threadIdx.x == 0) { smask = 0u; sbelow = 0; }
     __syncthreads();
     for (int k = threadIdx.x; k < nm; k += 256) {
         const int t = idx[(long)b * nm + k];
         if (t >= t0 && t < t0 + MSE_TT) atomicOr(&smask, 1u << (t - t0));
+        if (COMPACT && t < t0) atomicAdd(&sbelow, 1);
     }
     __syncthreads();
     const unsigned mask = smask;
     const int row = F * 4;
-    if (dpred) {                                        // frames of the group that are not masked: zero gradient rows
+    // row of frame t0 + tl in pred / dpred
+    auto prow = [&](int tl) -> long {
+        return COMPACT ? (long)b * nm + sbelow + __builtin_popcount(mask & ((1u << tl) - 1u)) : (long)b * Tn + t0 + tl;
+    };
+    if (dpred && !COMPACT) {                            // frames of the group that are not masked: zero gradient rows
         for (int tl = 0; tl < MSE_TT; ++tl) {
             if (((mask >> tl) & 1u) || t0 + tl >= Tn) continue;
             TG* dst = dpred + ((long)b * Tn + t0 + tl) * row;
@@ -729,7 +737,7 @@ __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict
     if (mask == 0u) return;
     for (int tl = 0; tl < MSE_TT; ++tl) {
         if (!((mask >> tl) & 1u)) continue;
-        const T* src = pred + ((long)b * Tn + t0 + tl) * row;
+        const T* src = pred + prow(tl) * row;
         for (int e = threadIdx.x; e < F; e += 256) {
             *(float4*)&sp[tl * row + e * 4] = ld4(src + e * 4);
         }
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const T* __restrict
         __syncthreads();
         for (int tl = 0; tl < MSE_TT; ++tl) {
             if (!((mask >> tl) & 1u)) continue;
-            TG* dst = dpred + ((long)b * Tn + t0 + tl) * row;
+            TG* dst = dpred + prow(tl) * row;
             for (int e = threadIdx.x; e < F; e += 256) st4(dst + e * 4, *(const float4*)&sp[tl * row + e * 4]);
         }
     }
@@ -1101,12 +1109,16 @@ extern "C" int sarssl_f64_accum(const double* src, float* dst, int n, float scal
 // out: f32[2] = (loss, diff).  sums: f64[128] workspace (zeroed here).
 static int masked_mse_fwd_impl(const void* pred, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
                                int nm, double* sums, float* out, float* out_keep, double* acc, int dtype, void* stream,
-                               void* dpred = nullptr) {
+                               void* dpred = nullptr, bool compact = false) {
     const size_t lds = (size_t)MSE_TT * F * 4 * sizeof(float);
     SARSSL_REQUIRE(nb > 0 && nm > 0 && lds <= 60 * 1024, "sarssl_masked_mse_fwd (F <= 480)");
     const int groups = (Tn + MSE_TT - 1) / MSE_TT;
     if (SARSSL_ZERO(sums, 2 * MSE_SLOTS * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
-    if (dpred) {
+    if (compact) {
+        const float coef = 2.0f / (float)((double)nb * nm * F * 2);
+        if (dpred) { DISPATCH_GA(dtype, (masked_mse_fwd_kernel<TA, T, true><<<nb * groups, 256, lds, ST>>>((const TA*)pred, x, idx, mch, nb, F, Tn, nm, sums, (T*)dpred, coef))); }
+        else { DISPATCH_T(dtype, (masked_mse_fwd_kernel<T, T, true><<<nb * groups, 256, lds, ST>>>((const T*)pred, x, idx, mch, nb, F, Tn, nm, sums))); }
+    } else if (dpred) {
         const float coef = 2.0f / (float)((double)nb * nm * F * 2);
         DISPATCH_GA(dtype, (masked_mse_fwd_kernel<TA, T><<<nb * groups, 256, lds, ST>>>((const TA*)pred, x, idx, mch, nb, F, Tn, nm, sums, (T*)dpred, coef)));
     } else {
@@ -1132,6 +1144,90 @@ extern "C" int sarssl_masked_mse_fwd_bwd(const void* pred, const float* x, const
                                          void* stream) {
     SARSSL_REQUIRE(dpred != nullptr, "sarssl_masked_mse_fwd_bwd");
     return masked_mse_fwd_impl(pred, x, idx, mch, nb, F, Tn, nm, sums, out, out_keep, acc, dtype, stream, dpred);
+}
+// ---- the decoder on the masked frames only.  gen_loss (code/model.py:721-747) reads the prediction at the masked frames of the masked
+// channel and nowhere else, and the decoder (Linear - ReLU - Linear, code/model.py:296-301) acts on every frame independently: rows of
+// unmasked frames receive a zero gradient and contribute nothing to any parameter gradient.  So the training step gathers the nm masked
+// frames of every item (ascending frame order = ascending idx), runs the decoder forward / backward on [nb * nm] rows - half of them -
+// and scatters the input gradient back (zeros elsewhere).  Exact, not an approximation; the full prediction (vis) is formed on request.
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, long lds_, const int* __restrict__ idx, int nb, int Tn, int nm, int d,
+                                   T* __restrict__ dst) {
+    const int cpr = d >> 3;                                   // 16-byte chunks per row
+    const long total = (long)nb * nm * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr);
+        const long r = i / cpr;                               // b * nm + j
+        const int b = (int)(r / nm);
+        const int t = idx[r];
+        *(uint4*)(dst + r * d + c * 8) = *(const uint4*)(src + ((long)b * Tn + t) * lds_ + c * 8);
+    }
+}
+template <typename T>
+__global__ void scatter_rows_kernel(const T* __restrict__ src, const int* __restrict__ idx, int nb, int Tn, int nm, int d,
+                                    T* __restrict__ dst, long ldd) {
+    const int cpr = d >> 3;
+    const long total = (long)nb * nm * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr);
+        const long r = i / cpr;
+        const int b = (int)(r / nm);
+        const int t = idx[r];
+        *(uint4*)(dst + ((long)b * Tn + t) * ldd + c * 8) = *(const uint4*)(src + r * d + c * 8);
+    }
+}
+// dst [nb * nm][d] (contiguous) <- rows (b, idx[b][j]) of src [nb * Tn][d] (row stride lds); 16-bit or f32 elements, d % 8 == 0
+extern "C" int sarssl_gather_rows(const void* src, long ld_src, const int* idx, int nb, int Tn, int nm, int d, void* dst, int dtype,
+                                  void* stream) {
+    SARSSL_REQUIRE(nb > 0 && nm > 0 && d > 0 && d % 8 == 0 && ld_src % 8 == 0, "sarssl_gather_rows");
+    const int es = dtype == SARSSL_F32 ? 2 : 1;              // f32 rows move as twice as many 16-bit elements
+    const int nblk = nblocks_for((long)nb * nm * (d * es / 8), 256, 8192);
+    gather_rows_kernel<uint16_t><<<nblk, 256, 0, ST>>>((const uint16_t*)src, ld_src * es, idx, nb, Tn, nm, d * es, (uint16_t*)dst);
+    SARSSL_CHECK_LAUNCH("gather_rows_kernel");
+    return 0;
+}
+// dst [nb * Tn][d] (row stride ld_dst; the whole [nb * Tn][d] block is zeroed first) <- src rows (b, j) at rows (b, idx[b][j])
+extern "C" int sarssl_scatter_rows(const void* src, const int* idx, int nb, int Tn, int nm, int d, void* dst, long ld_dst, int dtype,
+                                   void* stream) {
+    SARSSL_REQUIRE(nb > 0 && nm > 0 && d > 0 && d % 8 == 0 && ld_dst == d, "sarssl_scatter_rows (contiguous destination)");
+    const int es = dtype == SARSSL_F32 ? 2 : 1;
+    if (hipMemsetAsync(dst, 0, (size_t)nb * Tn * d * es * 2, ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    const int nblk = nblocks_for((long)nb * nm * (d * es / 8), 256, 8192);
+    scatter_rows_kernel<uint16_t><<<nblk, 256, 0, ST>>>((const uint16_t*)src, idx, nb, Tn, nm, d * es, (uint16_t*)dst, ld_dst * es);
+    SARSSL_CHECK_LAUNCH("scatter_rows_kernel");
+    return 0;
+}
+// loss (and, dpred != null, its gradient for an incoming gradient of 1) on the compact prediction pred_c [nb][nm][F * 4]; idx must be
+// ascending per item.  dtype as sarssl_masked_mse_fwd (dpred == null) / sarssl_masked_mse_fwd_bwd (dpred != null).
+extern "C" int sarssl_masked_mse_compact(const void* pred_c, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,
+                                         double* sums, float* out, float* out_keep, double* acc, void* dpred_c, int dtype, void* stream) {
+    return masked_mse_fwd_impl(pred_c, x, idx, mch, nb, F, Tn, nm, sums, out, out_keep, acc, dtype, stream, dpred_c, true);
+}
+// dpred_c = gscale * (*gscale_dev) * dLoss/dpred_c for a compact prediction (the stand-alone backward of the launch above)
+template <typename T, typename TA>
+__global__ void masked_mse_bwd_compact_kernel(const TA* __restrict__ pred, const float* __restrict__ x, const int* __restrict__ idx,
+                                              const int* __restrict__ mch, int nb, int F, int Tn, int nm, float coef0,
+                                              const float* __restrict__ gs_dev, T* __restrict__ dpred) {
+    const float coef = gs_dev ? coef0 * gs_dev[0] : coef0;
+    const long total = (long)nb * nm * F * 2;                 // one thread per (b, j, f, reim): 2 mics = 2 consecutive outputs
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i & 1);
+        long q = i >> 1;
+        const int f = (int)(q % F); q /= F;                   // q = b * nm + j
+        const int b = (int)(q / nm);
+        const int t = idx[q], mc = mch[b];
+        const float pv = ld_f(pred + i * 2 + mc);
+        const float tar = x[((((long)b * 2 + mc) * F + f) * Tn + t) * 2 + r];
+        const float gv = coef * (pv - tar);
+        st_f(dpred + i * 2, mc == 0 ? gv : 0.f); st_f(dpred + i * 2 + 1, mc == 0 ? 0.f : gv);
+    }
+}
+extern "C" int sarssl_masked_mse_bwd_compact(const void* pred_c, const float* x, const int* idx, const int* mch, int nb, int F, int Tn,
+                                             int nm, float gscale, const float* gscale_dev, void* dpred_c, int dtype, void* stream) {
+    const float coef = gscale * 2.0f / (float)((double)nb * nm * F * 2);
+    DISPATCH_GA(dtype, (masked_mse_bwd_compact_kernel<T, TA><<<nblocks_for((long)nb * nm * F * 2, 256, 8192), 256, 0, ST>>>((const TA*)pred_c, x, idx, mch, nb, F, Tn, nm, coef, gscale_dev, (T*)dpred_c)));
+    SARSSL_CHECK_LAUNCH("masked_mse_bwd_compact_kernel");
+    return 0;
 }
 // dpred = gscale * dLoss/dpred, loss = mean over nb*nm*F*2 entries
 extern "C" int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char* mp, const int* mch, int nb, int F,

@@ -258,7 +258,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
@@ -334,6 +334,7 @@ def _replaying(train):
     return train and RT.replay is not None
 
 
+_DEC_MASKED = os.environ.get("SARSSL_DEC_MASKED", "1") != "0"   # training steps run the decoder on the masked frames only (model._PretrainFn; 0: every frame)
 _FFN2 = os.environ.get("SARSSL_FFN2", "1") != "0"             # 0: the feed-forward module as two GEMM launches (A/B runs)
 # Model widths that take the fused forward / backward launch.  Default: d = 256 only (the spat encoder - the step's critical chain).  The
 # fused launch owns whole CUs (512 threads, 101-134 KB of LDS); at d = 512 (spec encoder) it runs 100-160 us during which the other

@@ -86,7 +86,7 @@ class PretrainStepGraph:
             nm = net.patch_mask.nmasked_patch
             idx = np.tile(np.arange(nm, dtype=np.int64)[None, :] * 2 % T, (B, 1))
             ch = np.zeros((B,), dtype=np.int64)
-        return np.asarray(idx), np.asarray(ch).reshape(-1)
+        return np.sort(np.asarray(idx), axis=1), np.asarray(ch).reshape(-1)      # ascending per item (row order of the compact decoder path)
 
     def _upload_masks(self, idx, ch, B, T):
         nm = idx.shape[1]
@@ -129,6 +129,7 @@ class PretrainStepGraph:
             net.__dict__.pop("_loss_grad_with_forward", None)
             net.__dict__.pop("_premasked", None)
         self.pred, self.xin, self.vis_masks = pred, x, (mp, ch)
+        self.ecat = net.__dict__.pop("_last_ecat", None)      # compact decoder path: the decoder's input of every frame (for vis)
         _PretrainFn.backward(ctx, self.one, None, None)
         if not with_adam:
             return
@@ -279,7 +280,13 @@ class PretrainStepGraph:
         """vis dict of the last step (same keys as SARSSL.forward's third result).  Copies: the graph's pool tensors are overwritten
         by the next replay, a vis dict of the eager path keeps its contents."""
         from .model import LazyVis
-        return LazyVis(self.pred.clone(), self.xin.clone(), self.vis_masks[0].clone(), self.vis_masks[1].clone())
+        pred = self.pred.clone()
+        if getattr(self, "ecat", None) is not None:
+            # the step ran its decoder on the masked frames only: the full prediction is formed on request from the step's decoder input
+            # (with the decoder as it is NOW - after the step's update; the learner runs the batch whose vis it returns with the full decoder)
+            from .model import _full_pred_fn
+            pred = _full_pred_fn(self.ecat.clone(), self.net.decoder)
+        return LazyVis(pred, self.xin.clone(), self.vis_masks[0].clone(), self.vis_masks[1].clone())
 
 
 class _Segments:

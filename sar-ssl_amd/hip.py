@@ -1371,6 +1371,46 @@ def masked_mse_fwd(pred, x, idx_i32, mch_i32, sink=None, with_grad=False):
     return out
 
 
+# ---- decoder on the masked frames only (include/sarssl_hip.h): gather / scatter of the masked rows, loss on the compact prediction
+def gather_rows(src2d, idx_i32, B, T):
+    """src [B*T, d] (row stride any) -> [B*nm, d]: rows (b, idx[b][j]); idx ascending per item."""
+    nm, d = idx_i32.shape[1], src2d.shape[1]
+    dst = torch.empty((B * nm, d), dtype=src2d.dtype, device=src2d.device)
+    _lib.call("sarssl_gather_rows", _p(src2d), c_long(src2d.stride(0)), _p(idx_i32), c_int(B), c_int(T), c_int(nm), c_int(d), _p(dst),
+              c_int(dt(src2d)), _stream())
+    return dst
+
+
+def scatter_rows(src2d, idx_i32, B, T):
+    """[B*nm, d] -> [B*T, d] with the rows at (b, idx[b][j]) and zeros elsewhere."""
+    nm, d = idx_i32.shape[1], src2d.shape[1]
+    dst = torch.empty((B * T, d), dtype=src2d.dtype, device=src2d.device)
+    _lib.call("sarssl_scatter_rows", _p(src2d), _p(idx_i32), c_int(B), c_int(T), c_int(nm), c_int(d), _p(dst), c_long(d), c_int(dt(src2d)), _stream())
+    return dst
+
+
+def masked_mse_compact(pred_c, x, idx_i32, mch_i32, sink=None, with_grad=False):
+    """masked_mse_fwd on the compact prediction pred_c (B*nm, F*4) (rows in ascending frame order) -> out f32[2] or (out, dpred_c)."""
+    B, _, F, T, _ = x.shape
+    nm = idx_i32.shape[1]
+    sums = _sums(128, x.device)
+    out = torch.empty((2,), dtype=torch.float32, device=x.device)
+    keep, acc = sink if sink is not None else (None, None)
+    dpred = torch.empty(pred_c.shape, dtype=gdtype_of(pred_c.dtype), device=pred_c.device) if with_grad else None
+    _lib.call("sarssl_masked_mse_compact", _p(pred_c), _p(x), _p(idx_i32), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm), _p(sums), _p(out),
+              _p(keep), _p(acc), _p(dpred), c_int(dt_ga(dpred, pred_c) if with_grad else dt(pred_c)), _stream())
+    return (out, dpred) if with_grad else out
+
+
+def masked_mse_bwd_compact(pred_c, x, idx_i32, mch_i32, gscale=1.0, gscale_dev=None):
+    B, _, F, T, _ = x.shape
+    nm = idx_i32.shape[1]
+    dpred = torch.empty(pred_c.shape, dtype=gdtype_of(pred_c.dtype), device=pred_c.device)
+    _lib.call("sarssl_masked_mse_bwd_compact", _p(pred_c), _p(x), _p(idx_i32), _p(mch_i32), c_int(B), c_int(F), c_int(T), c_int(nm), c_float(gscale),
+              _p(gscale_dev), _p(dpred), c_int(dt_ga(dpred, pred_c)), _stream())
+    return dpred
+
+
 def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0, gscale_dev=None):
     """gscale_dev: optional f32 device scalar (the incoming d(loss)); multiplied in-kernel, no host sync."""
     B, _, F, T, _ = x.shape

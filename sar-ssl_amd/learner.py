@@ -14,6 +14,19 @@ from . import hip, runtime, dist as sdist
 from .common import utils_module as at_module
 
 
+def _flag_last(iterable):
+    """(item, is_last) for every item of ``iterable`` (one item of look-ahead)."""
+    it = iter(iterable)
+    try:
+        prev = next(it)
+    except StopIteration:
+        return
+    for cur in it:
+        yield prev, False
+        prev = cur
+    yield prev, True
+
+
 class Learner(ABC):
     def __init__(self, model):
         self.model = model
@@ -71,9 +84,11 @@ class Learner(ABC):
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         n = 0
         vis_batch = None
-        for batch in dataset:
+        for batch, last in _flag_last(dataset):
             mic_sig_batch = batch[0] if isinstance(batch, (list, tuple)) else batch
             in_batch, = self.data_preprocess(mic_sig_batch, None)
+            if last:        # the batch whose vis is returned (code/learner.py:131): full decoder, so vis["pred"] is this very step's prediction
+                self.model.__dict__["_full_pred_once"] = True
             loss_batch, diff_batch, vis_batch = self.model(in_batch)
             loss_batch.backward()
             gscale = self._reducer.finish() if self._reducer is not None else 1.0
@@ -142,20 +157,22 @@ class Learner(ABC):
         g.reset_epoch(float(lr))                                                            # "Adam re-created every epoch" (learner.py:83)
         skipped0 = g.skipped_steps()
         self._flat.grad.zero_()
-        for batch in dataset:
+        for batch, last in _flag_last(dataset):
             mic_sig_batch = batch[0] if isinstance(batch, (list, tuple)) else batch
             if not torch.is_tensor(mic_sig_batch):
                 mic_sig_batch = torch.as_tensor(mic_sig_batch)
+            if last:        # the batch whose vis is returned (code/learner.py:131) takes the step launch by launch with the FULL decoder (the
+                self.model.__dict__["_full_pred_once"] = True      # captured step runs it on the masked frames only): vis["pred"] = this step's prediction
             if self._graph_takes_raw_batch(mic_sig_batch):                                  # STFT front-end inside the replay
                 sig = mic_sig_batch.to(self.device, non_blocking=True).contiguous()
-                if g.matches(pcm=sig):
+                if g.matches(pcm=sig) and not last:
                     g.step(pcm=sig)
                 else:
                     g.step_eager(pcm=sig)
                 continue
             in_batch, = self.data_preprocess(mic_sig_batch, None)
             in_batch = in_batch.contiguous().float()
-            if g.matches(x=in_batch):
+            if g.matches(x=in_batch) and not last:
                 g.step(x=in_batch)
             else:
                 g.step_eager(x=in_batch)

@@ -118,6 +118,8 @@ class LazyVis(dict):
             pred, x, mp, mch = self._src
             B, _, F, T, _ = x.shape
             if key == "pred":                                  # (B,T,F,2,2) -> (B,F,T,2,2)
+                if callable(pred):                             # training step: the decoder ran on the masked frames only (_PretrainFn) -
+                    pred = pred()                              # the full prediction is formed now, from the step's decoder input
                 v = pred.detach().float().view(B, T, F, 2, 2).permute(0, 2, 1, 3, 4)
             elif key == "tar":                                 # x is (B,mic,F,T,reim) -> (B,F,T,reim,mic)
                 v = x.detach().permute(0, 2, 3, 4, 1)
@@ -192,14 +194,30 @@ class _PretrainFn(torch.autograd.Function):
             net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
             net.spat_encoder._fwd_cl(spat_in, B, T, saved_spat, out=ecat[:, ds:])
         saved.append(saved_spat)
-        pred = engine.decoder_fwd(ecat, net.decoder, saved)
         sink = net.__dict__.get("_loss_sink")            # graph.py: (persistent f32[2], running f64[2] sums) filled by the finalize launch
         ctx.dpred = None
-        if net.__dict__.get("_loss_grad_with_forward"):  # graph.py: backward follows at once with an incoming gradient of exactly 1
-            out, ctx.dpred = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink, with_grad=True)
+        # Decoder on the masked frames only: the loss reads the prediction at the masked frames (code/model.py:585-592, 721-747) and the
+        # decoder treats every frame separately, so a TRAINING step (a backward pass follows) gathers those rows, runs the decoder on half
+        # the rows and scatters the input gradient back - exact.  Forward-only calls (eval, no_grad) and `_full_pred_once` (the learner sets
+        # it for the batch whose vis it returns) keep the full decoder; otherwise vis["pred"] is formed on request from the decoder input.
+        full_once = net.__dict__.pop("_full_pred_once", False)
+        compact = engine._DEC_MASKED and not full_once and not RT.inference and RT.dtype in engine._16 and RT.replay is None
+        net.__dict__["_last_ecat"] = None
+        if compact:
+            ecat_c = hip.gather_rows(ecat, idx_i32, B, T)
+            pred = engine.decoder_fwd(ecat_c, net.decoder, saved)                                   # [B * nm, F * 4]
+            if net.__dict__.get("_loss_grad_with_forward"):
+                out, ctx.dpred = hip.masked_mse_compact(pred, x, idx_i32, ch_i32, sink=sink, with_grad=True)
+            else:
+                out = hip.masked_mse_compact(pred, x, idx_i32, ch_i32, sink=sink)
+            net.__dict__["_last_ecat"] = ecat
         else:
-            out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink)
-        ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds)
+            pred = engine.decoder_fwd(ecat, net.decoder, saved)
+            if net.__dict__.get("_loss_grad_with_forward"):  # graph.py: backward follows at once with an incoming gradient of exactly 1
+                out, ctx.dpred = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink, with_grad=True)
+            else:
+                out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink)
+        ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds, idx_i32 if compact else None)
         ctx.nparams = len(params)
         ctx.mark_non_differentiable(out, pred)
         return (out[0] if sink is not None else out[0].clone()), out, pred
@@ -207,13 +225,18 @@ class _PretrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dout, _dpred):
         net, saved = ctx.net, ctx.saved
-        pred, x, mp_u8, ch_i32, nm, ds = ctx.aux
+        pred, x, mp_u8, ch_i32, nm, ds, idx_c = ctx.aux
         hip.sums_arena_reset(x.device)
         dpred = getattr(ctx, "dpred", None)
-        if dpred is None:
-            dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
         hip.stamp("bwd.decoder.begin")
-        decat = engine.decoder_bwd(dpred, net.decoder, saved)
+        if idx_c is not None:           # compact decoder (forward): gradient rows of the masked frames, scattered back behind the decoder
+            if dpred is None:
+                dpred = hip.masked_mse_bwd_compact(pred, x, idx_c, ch_i32, 1.0, dloss.contiguous().float())
+            decat = hip.scatter_rows(engine.decoder_bwd(dpred, net.decoder, saved), idx_c, x.shape[0], x.shape[3])
+        else:
+            if dpred is None:
+                dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
+            decat = engine.decoder_bwd(dpred, net.decoder, saved)
         hip.stamp("bwd.decoder.end")
         net._after_backward_stage("decoder")
         saved_spat = saved.pop()
@@ -366,6 +389,7 @@ class SARSSL(nn.Module):
             self._forced_masks = None
         else:
             idx, ch = self.patch_mask.sample(B, 2)
+        idx = np.sort(np.asarray(idx), axis=1)            # ascending per item: the row order of the compact decoder path (the mask is a set)
         mp = np.ones((B, T), dtype=np.uint8)
         np.put_along_axis(mp, idx, 0, axis=1)
         # pinned staging: an H2D copy from pageable memory first drains the stream (the host could never run ahead of the GPU
@@ -395,6 +419,9 @@ class SARSSL(nn.Module):
                     loss, out, pred = _PretrainFn.forward(_NoCtx(), self, x, idx, ch, mp)
                 finally:
                     RT.inference = False
+            ecat = self.__dict__.pop("_last_ecat", None)
+            if ecat is not None:        # compact training step: vis["pred"] = the decoder on every frame of this step's decoder input, on request
+                pred = _full_pred_fn(ecat, self.decoder)
             return loss, out[1], LazyVis(pred, x, mp, ch)
         # ---- downstream branch (code/model.py:667-719): both encoders on the unmasked input, mean over frames, MLP head
         B, T, F = nbatch, nt, nf
@@ -413,6 +440,24 @@ class SARSSL(nn.Module):
         pooled = embed.float().mean(dim=1)
         head = self.mlp_head if self.downstream_dlabel == 1 else self.joint_head
         return head(pooled), pooled
+
+
+def _full_pred_fn(ecat, dec):
+    """The decoder on every frame of a step's decoder input, in the numeric mode of that step (the caller may have switched modes since)."""
+    from . import runtime
+    prec = runtime.get_precision()
+
+    def full_pred():
+        now, keep = runtime.get_precision(), RT.inference
+        runtime.set_precision(prec)
+        RT.inference = True
+        try:
+            with torch.no_grad():
+                return engine.decoder_fwd(ecat, dec, [])
+        finally:
+            RT.inference = keep
+            runtime.set_precision(now)
+    return full_pred
 
 
 class _NoCtx:

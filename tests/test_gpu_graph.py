@@ -226,7 +226,9 @@ def test_full_batch_captured_step_and_eval_forward_vs_the_reference_at_batch_64(
         net.set_masks(z["mask_idx"], z["mask_ch"])
         o = g.step(pcm=pcm, static=True)                              # capture + first replay, exactly bench.py's call
         assert sum(1 for k, _ in g._plan if k == "graph") == 1
-        got = {"train": (float(o[0]), float(o[1]), g.pred.detach().float().reshape(-1).cpu())}
+        # (the captured step runs its decoder on the masked frames only; the full prediction comes from g.vis(), formed on request from the
+        #  step's decoder input - lr = 0: the decoder's weights are the step's)
+        got = {"train": (float(o[0]), float(o[1]), g.vis()["pred"].permute(0, 2, 1, 3, 4).reshape(-1).float().cpu())}
         net.load_state_dict(recipes.recipe_state_dict(man, int(z["weight_seed"])))      # (the train-mode step moved the BatchNorm running statistics)
         net.eval()
         net.set_masks(z["mask_idx"], z["mask_ch"])

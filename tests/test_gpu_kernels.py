@@ -1436,3 +1436,43 @@ def test_tile_resident_linear_layers(M, N, K, dtp):
                 if drop is not None:
                     assert torch.equal(got[1] == 0, ref[1] == 0) and _relerr(got[1], ref[1]) < 1e-2
                 assert _relerr(dg, dg_r) < 1e-4 and _relerr(db, db_r) < 1e-4
+
+
+# ---------------------------------------------------------------- decoder on the masked frames only: gather / scatter / compact loss
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,F", [(3, 16, 16), (2, 40, 256), (2, 624, 256)])
+def test_masked_rows_gather_scatter_and_compact_loss(B, T, F, dtp):
+    """sarssl_gather_rows / sarssl_scatter_rows and the loss on the compact prediction against the full-frame launches: same loss / diff,
+    the same gradient rows at the masked frames (bit for bit: same arithmetic per element), zeros elsewhere."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = np.random.default_rng(5)
+    nm = T // 2
+    idx = np.stack([np.sort(g.choice(T, nm, replace=False)) for _ in range(B)]).astype(np.int32)
+    ch = g.integers(0, 2, size=B).astype(np.int32)
+    idx_t, ch_t = torch.from_numpy(idx).to(dev), torch.from_numpy(ch).to(dev)
+    mp = np.ones((B, T), dtype=np.uint8)
+    np.put_along_axis(mp, idx.astype(np.int64), 0, axis=1)
+    mp_t = torch.from_numpy(mp).to(dev)
+    d = 768
+    e = _mk((B * T, d), torch.float32, dev, 1).to(dtp)
+    ec = hip.gather_rows(e, idx_t, B, T)
+    want = torch.stack([e.view(B, T, d)[b, torch.from_numpy(idx[b]).long().to(dev)] for b in range(B)]).reshape(B * nm, d)
+    assert torch.equal(ec, want)
+    back = hip.scatter_rows(ec, idx_t, B, T)
+    assert torch.equal(back.view(B, T, d) * (1 - mp_t.view(B, T, 1).to(dtp)), back.view(B, T, d))
+    assert torch.equal(back.view(B, T, d)[mp_t == 0], e.view(B, T, d)[mp_t == 0]) and float(back.view(B, T, d)[mp_t == 1].abs().max()) == 0.0
+    # loss
+    x = _mk((B, 2, F, T, 2), torch.float32, dev, 2)
+    pred = _mk((B, T, F * 4), torch.float32, dev, 3).to(dtp)
+    pred_c = hip.gather_rows(pred.view(B * T, F * 4), idx_t, B, T)
+    gdt = torch.bfloat16 if dtp == torch.float16 else dtp
+    out, dpred = hip.masked_mse_fwd(pred, x, idx_t, ch_t, with_grad=True)
+    out_c, dpred_c = hip.masked_mse_compact(pred_c, x, idx_t, ch_t, with_grad=True)
+    assert _relerr(out_c, out) < 1e-6 and dpred_c.dtype == gdt
+    assert torch.equal(dpred_c, hip.gather_rows(dpred.view(B * T, F * 4), idx_t, B, T))
+    assert _relerr(hip.masked_mse_compact(pred_c, x, idx_t, ch_t), out) < 1e-6
+    gs = torch.tensor([0.37], dtype=torch.float32, device=dev)
+    d2 = hip.masked_mse_bwd(pred, x, mp_t, ch_t, nm, 1.0, gs)
+    d2c = hip.masked_mse_bwd_compact(pred_c, x, idx_t, ch_t, 1.0, gs)
+    assert torch.equal(d2c, hip.gather_rows(d2.view(B * T, F * 4), idx_t, B, T))
