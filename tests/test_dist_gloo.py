@@ -183,7 +183,7 @@ def test_backward_stage_hooks_fire_before_the_stem_backward(monkeypatch):
     red = sdist.FlatGradAllReduce(net, flat)
     inner = net._stage_hook
     net.set_backward_stage_hook(lambda name: (log.append("hook:" + name), inner(name)))
-    ctx = types.SimpleNamespace(net=net, saved=[[]], aux=(None, torch.zeros(2, 2, 16, 8, 2), None, None, 4, 512), nparams=0)
+    ctx = types.SimpleNamespace(net=net, saved=[[]], aux=(None, torch.zeros(2, 2, 16, 8, 2), None, None, 4, 512, None), nparams=0)
     model._PretrainFn.backward(ctx, torch.ones(()), None, None)
     assert log == ["decoder", "hook:decoder", "block", "block", "block", "block", "patch", "hook:spat_encoder", "patch",
                    "hook:spec_encoder", "hook:stem_bwd_begin", "cus", "stem", "cus", "stem", "hook:stems"]
