@@ -258,7 +258,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
@@ -335,6 +335,7 @@ def _replaying(train):
 
 
 _DEC_MASKED = os.environ.get("SARSSL_DEC_MASKED", "1") != "0"   # training steps run the decoder on the masked frames only (model._PretrainFn; 0: every frame)
+_TAIL_MASKED = os.environ.get("SARSSL_TAIL_MASKED", "1") != "0"  # ... and the row-wise tail of each encoder's last block (second feed-forward module + closing LayerNorm)
 _FFN2 = os.environ.get("SARSSL_FFN2", "1") != "0"             # 0: the feed-forward module as two GEMM launches (A/B runs)
 # Model widths that take the fused forward / backward launch.  Default: d = 256 only (the spat encoder - the step's critical chain).  The
 # fused launch owns whole CUs (512 threads, 101-134 KB of LDS); at d = 512 (spec encoder) it runs 100-160 us during which the other
@@ -865,13 +866,23 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
 _LN_PAIR = os.environ.get("SARSSL_LN_PAIR", "1") != "0"       # 0: the two LayerNorms of a block boundary as two launches (A/B runs)
 
 
-def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None):
+def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None, rows=None):
     """ConformerBlock (code/common/Conformer.py:59-91).  next_blk: the block that consumes the result - its first LayerNorm (the
-    feed-forward module's) is applied by this block's closing LayerNorm launch (two row passes in one kernel, bit-identical)."""
+    feed-forward module's) is applied by this block's closing LayerNorm launch (two row passes in one kernel, bit-identical).
+    rows = idx (int32 [B, nm], ascending): the caller only consumes the rows of these frames (the LAST block of an encoder in a training
+    step: the decoder runs on the masked frames) - the second feed-forward module and the closing LayerNorm act on every row separately,
+    so they run on the gathered rows only and the result is [B * nm, d]; everything in front of them mixes frames (attention, depthwise
+    convolution, BatchNorm statistics) and sees every row."""
     seq = blk.sequential
     x = ffn_fwd(x, seq[0].module, seq[0].module_factor, train, saved)
     x = mhsa_fwd(x, seq[1].module, B, T, train, saved)
     x = convmod_fwd(x, seq[2].module, B, T, train, saved)
+    if rows is not None:
+        xc = hip.gather_rows(x, rows, B, T)
+        xc = ffn_fwd(xc, seq[3].module, seq[3].module_factor, train, saved)
+        y, stats = hip.layernorm_fwd(xc, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
+        saved.append((xc, stats, (rows, B, T), x))          # (x: the full-row input of the tail, for a full prediction on request - vis)
+        return y
     x = ffn_fwd(x, seq[3].module, seq[3].module_factor, train, saved)
     if next_blk is not None and out is None and _LN_PAIR:
         nln = next_blk.sequential[0].module.sequential[0]
@@ -888,7 +899,9 @@ def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None):
 
 def block_bwd(dy, blk, saved):
     seq = blk.sequential
-    x, stats = saved.pop()
+    top = saved.pop()
+    x, stats = top[0], top[1]
+    rows = top[2] if len(top) > 2 else None        # compact tail (block_fwd(rows=...)): dy, x are [B * nm, d]
     # the block's ~9 bias-gradient column sums and the reductions of its 9 split-K weight-gradient products: one launch each, at the end
     with hip.colsum_batched(), hip.splitk_batched(), hip.ln_reduce_batched(), wgrad_block():
         # each module's backward starts with the dropout backward of its incoming gradient: the LayerNorm backward that produces
@@ -896,11 +909,23 @@ def block_bwd(dy, blk, saved):
         pair = lambda r: r if isinstance(r, tuple) else (r, None)
         d, dd = pair(hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias),
                                        drop=_next_drop("ffn", saved)))
-        d, dd = pair(ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind="conv"))
+        if rows is not None:    # the tail ran on the gathered rows: its input gradient goes back to its frames, zeros elsewhere
+            d = ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind=None)
+            d, dd = hip.scatter_rows(d, rows[0], rows[1], rows[2]), None
+        else:
+            d, dd = pair(ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind="conv"))
         d, dd = pair(convmod_bwd(d, seq[2].module, saved, dy_dropped=dd, next_kind="mhsa"))
         d, dd = pair(mhsa_bwd(d, seq[1].module, saved, dy_dropped=dd, next_kind="ffn"))
         d = ffn_bwd(d, seq[0].module, saved, dy_dropped=dd)
     return d
+
+
+def block_tail_full(x_full, blk, train, out=None):
+    """Second feed-forward module + closing LayerNorm of ``blk`` on EVERY row of its input (no tensors saved): what block_fwd(rows=...)
+    skipped for the frames nobody consumed - for a full prediction on request (vis).  Dropout (train mode) draws fresh masks."""
+    seq = blk.sequential
+    y = ffn_fwd(x_full, seq[3].module, seq[3].module_factor, train, [])
+    return hip.layernorm_fwd(y, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out, save=False)[0]
 
 
 def encoder_fwd(x, enc, B, T, train, saved, out=None):

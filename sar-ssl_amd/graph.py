@@ -285,7 +285,9 @@ class PretrainStepGraph:
             # the step ran its decoder on the masked frames only: the full prediction is formed on request from the step's decoder input
             # (with the decoder as it is NOW - after the step's update; the learner runs the batch whose vis it returns with the full decoder)
             from .model import _full_pred_fn
-            pred = _full_pred_fn(self.ecat.clone(), self.net.decoder)
+            e = self.ecat
+            e = tuple(t.clone() if torch.is_tensor(t) else t for t in e) if isinstance(e, tuple) else e.clone()
+            pred = _full_pred_fn(e, self.net.decoder, self.net)
         return LazyVis(pred, self.xin.clone(), self.vis_masks[0].clone(), self.vis_masks[1].clone())
 
 

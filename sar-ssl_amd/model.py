@@ -151,7 +151,16 @@ class _PretrainFn(torch.autograd.Function):
         else:
             spec_in, spat_in = hip.mask_inputs(x, mp_u8, ch_i32, 0, RT.dtype)
         ds, dt_ = net.spec_encoder.dembed, net.spat_encoder.dembed
-        ecat = torch.empty((B * T, ds + dt_), dtype=RT.dtype, device=x.device)
+        # Decoder - and the row-wise tail of each encoder's last block - on the masked frames only: the loss reads the prediction at the
+        # masked frames (code/model.py:585-592, 721-747) and these layers treat every frame separately, so a TRAINING step (a backward pass
+        # follows) runs them on the gathered rows - half of them - and scatters the input gradient back: exact.  Forward-only calls (eval,
+        # no_grad) and `_full_pred_once` (the learner sets it for the batch whose vis it returns) keep every row; otherwise vis["pred"] is
+        # formed on request from the tensors the skipped part starts from.
+        full_once = net.__dict__.pop("_full_pred_once", False)
+        compact = engine._DEC_MASKED and not full_once and not RT.inference and RT.dtype in engine._16 and RT.replay is None
+        tail = compact and engine._TAIL_MASKED and net._side_stream(x.device) is not None
+        nrow = B * idx_i32.shape[1] if tail else B * T
+        ecat = torch.empty((nrow, ds + dt_), dtype=RT.dtype, device=x.device)
         # The two encoders are independent until the decoder: run them on two HIP streams so one encoder's HBM-bound passes
         # (BatchNorm statistics / backward, LayerNorm, ...) overlap the other's MFMA-bound convolutions and GEMMs.
         saved_spat = []
@@ -178,46 +187,43 @@ class _PretrainFn(torch.autograd.Function):
             nl = len(spa.embed.layers)
             with torch.cuda.stream(side):
                 e_spat = engine.block_fwd(e_spat, spa.embed.layers[0], B, T, train, saved_spat, out=ecat[:, ds:] if nl == 1 else None,
-                                          next_blk=spa.embed.layers[1] if nl > 1 else None)
+                                          next_blk=spa.embed.layers[1] if nl > 1 else None, rows=idx_i32 if (tail and nl == 1) else None)
             assert len(spe.embed.layers) == 1
-            engine.block_fwd(e_spec, spe.embed.layers[0], B, T, train, saved, out=ecat[:, :ds])
+            engine.block_fwd(e_spec, spe.embed.layers[0], B, T, train, saved, out=ecat[:, :ds], rows=idx_i32 if tail else None)
             hip.stamp("fwd.spec.block.end")
             with torch.cuda.stream(side):
                 for li in range(1, nl):
                     e_spat = engine.block_fwd(e_spat, spa.embed.layers[li], B, T, train, saved_spat,
                                               out=ecat[:, ds:] if li == nl - 1 else None,
-                                              next_blk=spa.embed.layers[li + 1] if li + 1 < nl else None)
+                                              next_blk=spa.embed.layers[li + 1] if li + 1 < nl else None,
+                                              rows=idx_i32 if (tail and li == nl - 1) else None)
                 hip.stamp("fwd.spat.blocks.end")
             main.wait_stream(side)
             hip.stamp("fwd.join")
         else:
             net.spec_encoder._fwd_cl(spec_in, B, T, saved, out=ecat[:, :ds])
             net.spat_encoder._fwd_cl(spat_in, B, T, saved_spat, out=ecat[:, ds:])
+        tails_x = (saved[-1][3], saved_spat[-1][3]) if tail else None      # full-row inputs of the two compact tails (vis on request)
         saved.append(saved_spat)
         sink = net.__dict__.get("_loss_sink")            # graph.py: (persistent f32[2], running f64[2] sums) filled by the finalize launch
         ctx.dpred = None
-        # Decoder on the masked frames only: the loss reads the prediction at the masked frames (code/model.py:585-592, 721-747) and the
-        # decoder treats every frame separately, so a TRAINING step (a backward pass follows) gathers those rows, runs the decoder on half
-        # the rows and scatters the input gradient back - exact.  Forward-only calls (eval, no_grad) and `_full_pred_once` (the learner sets
-        # it for the batch whose vis it returns) keep the full decoder; otherwise vis["pred"] is formed on request from the decoder input.
-        full_once = net.__dict__.pop("_full_pred_once", False)
-        compact = engine._DEC_MASKED and not full_once and not RT.inference and RT.dtype in engine._16 and RT.replay is None
         net.__dict__["_last_ecat"] = None
         if compact:
-            ecat_c = hip.gather_rows(ecat, idx_i32, B, T)
+            ecat_c = ecat if tail else hip.gather_rows(ecat, idx_i32, B, T)
             pred = engine.decoder_fwd(ecat_c, net.decoder, saved)                                   # [B * nm, F * 4]
             if net.__dict__.get("_loss_grad_with_forward"):
                 out, ctx.dpred = hip.masked_mse_compact(pred, x, idx_i32, ch_i32, sink=sink, with_grad=True)
             else:
                 out = hip.masked_mse_compact(pred, x, idx_i32, ch_i32, sink=sink)
-            net.__dict__["_last_ecat"] = ecat
+            # what a full prediction would start from: the decoder input of every frame - or (compact tails) the inputs of the two tails
+            net.__dict__["_last_ecat"] = ecat if not tail else ("tails", tails_x[0], tails_x[1], ds, dt_, net.training)
         else:
             pred = engine.decoder_fwd(ecat, net.decoder, saved)
             if net.__dict__.get("_loss_grad_with_forward"):  # graph.py: backward follows at once with an incoming gradient of exactly 1
                 out, ctx.dpred = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink, with_grad=True)
             else:
                 out = hip.masked_mse_fwd(pred, x, idx_i32, ch_i32, sink=sink)
-        ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds, idx_i32 if compact else None)
+        ctx.net, ctx.saved, ctx.aux = net, saved, (pred, x, mp_u8, ch_i32, idx_i32.shape[1], ds, (idx_i32, tail) if compact else None)
         ctx.nparams = len(params)
         ctx.mark_non_differentiable(out, pred)
         return (out[0] if sink is not None else out[0].clone()), out, pred
@@ -230,9 +236,12 @@ class _PretrainFn(torch.autograd.Function):
         dpred = getattr(ctx, "dpred", None)
         hip.stamp("bwd.decoder.begin")
         if idx_c is not None:           # compact decoder (forward): gradient rows of the masked frames, scattered back behind the decoder
+            idx_c, tail = idx_c
             if dpred is None:
                 dpred = hip.masked_mse_bwd_compact(pred, x, idx_c, ch_i32, 1.0, dloss.contiguous().float())
-            decat = hip.scatter_rows(engine.decoder_bwd(dpred, net.decoder, saved), idx_c, x.shape[0], x.shape[3])
+            decat = engine.decoder_bwd(dpred, net.decoder, saved)
+            if not tail:            # (compact tails: the encoders' last blocks take the compact gradient and scatter behind their own tails)
+                decat = hip.scatter_rows(decat, idx_c, x.shape[0], x.shape[3])
         else:
             if dpred is None:
                 dpred = hip.masked_mse_bwd(pred, x, mp_u8, ch_i32, nm, 1.0, dloss.contiguous().float())
@@ -421,7 +430,7 @@ class SARSSL(nn.Module):
                     RT.inference = False
             ecat = self.__dict__.pop("_last_ecat", None)
             if ecat is not None:        # compact training step: vis["pred"] = the decoder on every frame of this step's decoder input, on request
-                pred = _full_pred_fn(ecat, self.decoder)
+                pred = _full_pred_fn(ecat, self.decoder, self)
             return loss, out[1], LazyVis(pred, x, mp, ch)
         # ---- downstream branch (code/model.py:667-719): both encoders on the unmasked input, mean over frames, MLP head
         B, T, F = nbatch, nt, nf
@@ -442,8 +451,11 @@ class SARSSL(nn.Module):
         return head(pooled), pooled
 
 
-def _full_pred_fn(ecat, dec):
-    """The decoder on every frame of a step's decoder input, in the numeric mode of that step (the caller may have switched modes since)."""
+def _full_pred_fn(ecat, dec, net=None):
+    """The decoder on every frame of a step's decoder input, in the numeric mode of that step (the caller may have switched modes since).
+    ecat = ("tails", x_spec, x_spat, ds, dt, train): the step also ran the tails of the encoders' last blocks on the masked frames only -
+    they are run on every row first (train mode with dropout: fresh masks - a training step's vis is for plotting; the learner runs the
+    batch whose vis it returns without any of this)."""
     from . import runtime
     prec = runtime.get_precision()
 
@@ -453,6 +465,12 @@ def _full_pred_fn(ecat, dec):
         RT.inference = True
         try:
             with torch.no_grad():
+                if isinstance(ecat, tuple):
+                    _, xs, xt, ds, dt_, train = ecat
+                    full = torch.empty((xs.shape[0], ds + dt_), dtype=xs.dtype, device=xs.device)
+                    engine.block_tail_full(xs, net.spec_encoder.embed.layers[-1], train, out=full[:, :ds])
+                    engine.block_tail_full(xt, net.spat_encoder.embed.layers[-1], train, out=full[:, ds:])
+                    return engine.decoder_fwd(full, dec, [])
                 return engine.decoder_fwd(ecat, dec, [])
         finally:
             RT.inference = keep

@@ -396,8 +396,9 @@ def test_nonfinite_loss_skips_the_optimizer_step(form):
 
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_decoder_on_the_masked_frames_only_equals_the_full_decoder(prec, monkeypatch):
-    """Training steps run EmbedDecoder (code/model.py:321-334) on the masked frames only - gen_loss (code/model.py:721-747) reads nothing
-    else and the decoder treats frames separately.  Against the full-frame decoder (SARSSL_DEC_MASKED=0) on the same inputs, weights and
+    """Training steps run EmbedDecoder (code/model.py:321-334) - and the row-wise tail of each encoder's last Conformer block: second
+    feed-forward module + closing LayerNorm (code/common/Conformer.py:84-90) - on the masked frames only: gen_loss (code/model.py:721-747)
+    reads nothing else and these layers treat frames separately.  Against the full-frame decoder (SARSSL_DEC_MASKED=0) on the same inputs, weights and
     masks: the loss bit for bit (same rows, same arithmetic), every parameter's gradient to summation-order noise (the decoder's weight
     gradients contract over half the rows - the other half were exact zeros), and vis["pred"] - formed on request from the step's decoder
     input - equal to the full decoder's prediction."""
@@ -412,8 +413,9 @@ def test_decoder_on_the_masked_frames_only_equals_the_full_decoder(prec, monkeyp
         idx = np.stack([g.choice(T, T // 2, replace=False) for _ in range(B)])        # unsorted on purpose: the model sorts
         ch = g.integers(0, 2, size=B)
         res = {}
-        for masked in (True, False):
-            monkeypatch.setattr(engine, "_DEC_MASKED", masked)
+        for masked in (True, "decoder_only", False):
+            monkeypatch.setattr(engine, "_DEC_MASKED", bool(masked))
+            monkeypatch.setattr(engine, "_TAIL_MASKED", masked is True)      # True: decoder + the row-wise tails of the encoders' last blocks
             torch.manual_seed(9)
             net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev)
             _set_dropout(net, 0.0)
@@ -423,10 +425,12 @@ def test_decoder_on_the_masked_frames_only_equals_the_full_decoder(prec, monkeyp
             loss, diff, vis = net(hip.stft_frontend(sig))
             loss.backward()
             res[masked] = (float(loss), float(diff), flat.grad.clone(), vis["pred"].clone(), vis["mask"].clone())
-        a, b = res[True], res[False]
-        assert a[0] == b[0] and a[1] == b[1]
-        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
-        check("dec_masked.%s.grad_rel_l2" % prec, float((a[2] - b[2]).norm() / b[2].norm()), 2e-3)
-        check("dec_masked.%s.grad_max_over_max" % prec, float((a[2] - b[2]).abs().max() / b[2].abs().max()), 5e-3)
+        b = res[False]
+        for key in (True, "decoder_only"):
+            a = res[key]
+            assert a[0] == b[0] and a[1] == b[1]
+            assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+            check("dec_masked.%s.%s.grad_rel_l2" % (prec, key), float((a[2] - b[2]).norm() / b[2].norm()), 2e-3)
+            check("dec_masked.%s.%s.grad_max_over_max" % (prec, key), float((a[2] - b[2]).abs().max() / b[2].abs().max()), 5e-3)
     finally:
         runtime.set_precision("bf16")
