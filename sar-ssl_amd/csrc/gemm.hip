@@ -111,7 +111,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     // congruent to x and each XCD's L2 reads ITS eighth of both operands once.  With the row-panel order below every XCD streams the
     // whole B operand: the round-2 counters show 203 MB fetched for 84 MB of operands on the FFN weight gradient and 862 MB for
     // 134 MB on the decoder's - those launches were HBM-bound at 4.4-5.8 TB/s of mostly repeated reads.
-    const bool slice_major = g.split_k > 0 && (nsplit & 7) == 0 && grid_z == nsplit;
+    const bool slice_major = g.split_k > 0 && ((nsplit & 7) == 0 || nsplit == 4 || nsplit == 2) && grid_z == nsplit;   // (2, 4: two / four XCDs share a slice)
     const int lin_all = (bid_z * grid_y + bid_y) * grid_x + bid_x;
     const int z = slice_major ? 0 : bid_z / nsplit, ks = slice_major ? lin_all % nsplit : bid_z % nsplit;
     const int z0 = z / g.batch_inner, z1 = z % g.batch_inner;

@@ -73,6 +73,8 @@ def mm_nn(dy, W, fp8=True, **kw):
 _WGRAD_GROUP = os.environ.get("SARSSL_WGRAD_GROUP", "1") != "0"
 _WGRAD_CSUM = os.environ.get("SARSSL_WGRAD_CSUM", "1") != "0"   # bias gradients from the grouped weight-gradient launch (0: separate column-sum launch)
 _STEM_LAST_ALL_CUS = os.environ.get("SARSSL_STEM_LAST_ALL_CUS", "1") != "0"   # gradient convolutions of the stem that runs last (spat) on every CU (model.py)
+_WGRAD_SPLIT_BIG = int(os.environ.get("SARSSL_WGRAD_SPLIT_BIG", "4"))            # K-slices of a grouped launch with >= .._TILES output tiles
+_WGRAD_SPLIT_BIG_TILES = int(os.environ.get("SARSSL_WGRAD_SPLIT_BIG_TILES", "128"))
 _wg_blocks = []              # stack of pending-product lists (wgrad_block)
 
 
@@ -94,6 +96,12 @@ class wgrad_block:
         # cannot join the grouped launch (it has no ragged instantiation) - they must not keep the block's other products out of it
         ragged = [it for it in items if it[0].shape[0] % 64 != 0]
         items = [it for it in items if it[0].shape[0] % 64 == 0]
+        if _WGRAD_SPLIT_BIG != 8:
+            # a group whose products already have plenty of 256 x 128 output tiles needs fewer K-slices to fill the chip: half the
+            # partial-sum traffic of the products and of the fold launch
+            tiles = sum(((it[0].shape[1] + 255) // 256) * ((it[1].shape[1] + 127) // 128) for it in items)
+            if tiles >= _WGRAD_SPLIT_BIG_TILES:
+                items = [(dy, x, g2, _WGRAD_SPLIT_BIG if (split == 8 and dy.shape[0] >= 4096) else split, bias) for dy, x, g2, split, bias in items]
         for dy, x, g2, split, bias in ragged:
             _wgrad_gemm(dy, x, g2, split)
             if bias is not None:
@@ -258,7 +266,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_WGRAD_SPLIT_BIG": [_WGRAD_SPLIT_BIG, _WGRAD_SPLIT_BIG_TILES], "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
