@@ -152,9 +152,12 @@ struct AttnDrop {
 // bias tile.  Per wave and position tile only the part that can be valid for its 32 rows is computed.  What this removes per layer: the
 // batched positional-score GEMM launch (K = d_head: 53 us for a 33 MB output written element by element in the shifted layout) and
 // the kernel's own 33 MB bias read.
-template <int DH, typename TA, bool POS = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 && !POS) ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
-    constexpr int TQ = 128, TK = 64;
+// NW = 8 (d_head 64, POS): ONE workgroup of eight waves takes all 256 query rows of a (batch, head) - the [256][T] slab + one K / V tile
+// are 157 KB of LDS, two waves share a SIMD (one on the matrix cores while the other is in its softmax / scatter / hash stretch) and
+// every K / V tile is staged once per (batch, head) instead of once per 128 rows.
+template <int DH, typename TA, bool POS = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <= 64 && !POS) || NW == 8) ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
+    constexpr int TQ = 32 * NW, TK = 64, NT = 64 * NW;
 #ifdef ATTN_EXP_1WG
     constexpr int PK = DH + 8, PV = DH + 32, PB = 256 + 8;
 #else
@@ -197,12 +200,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
 
     // K, V (64 keys x DH) and the bias tile (128 rows x 64 keys) go through registers: the next tile's loads are in flight while
     // this one is on the matrix cores
-    constexpr int NKV = TK * CPR / 256, NBI = TQ * (TK / 8) / 256;
+    constexpr int NKV = TK * CPR / NT, NBI = TQ * (TK / 8) / NT, NRP = 256 * CPR / NT;
+    static_assert(NKV >= 1 && NRP >= 2, "tile loads per thread");
     uint4 rk[NKV], rv[NKV], rbi[NBI];
     auto load_tile = [&](int j0) {
 #pragma unroll
         for (int c = 0; c < NKV; ++c) {
-            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            const int cid = tid + NT * c, row = cid / CPR, c8 = cid % CPR;
             rk[c] = make_uint4(0, 0, 0, 0); rv[c] = rk[c];
             if (j0 + row < T) {
                 rk[c] = *(const uint4*)(K + (long)(j0 + row) * a.ldk + c8 * 8);
@@ -212,18 +216,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
         if constexpr (!POS) {
 #pragma unroll
             for (int c = 0; c < NBI; ++c) {
-                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+                const int cid = tid + NT * c, row = cid >> 3, c8 = cid & 7;
                 rbi[c] = make_uint4(0, 0, 0, 0);
                 if (i0 + row < T && j0 + c8 * 8 < T) rbi[c] = *(const uint4*)(Bi + (long)(i0 + row) * T + j0 + c8 * 8);
             }
         }
     };
-    uint4 rp[POS ? CPR : 1];                                  // POS: the head's whole positional projection (T <= 256 rows), one request burst
+    uint4 rp[POS ? NRP : 1];                                  // POS: the head's whole positional projection (T <= 256 rows), one request burst
     if constexpr (POS) {
         const h16* Pm = a.pos + h * DH;
 #pragma unroll
-        for (int c = 0; c < CPR; ++c) {
-            const int row = tid / CPR + c * (256 / CPR);
+        for (int c = 0; c < NRP; ++c) {
+            const int row = tid / CPR + c * (NT / CPR);
             rp[c] = row < T ? *(const uint4*)(Pm + (long)row * a.ldp + (tid % CPR) * 8) : make_uint4(0, 0, 0, 0);
         }
     }
@@ -257,9 +261,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
         for (int stage = 0; stage < 2; ++stage) {
             if (stage * 128 < T) {
 #pragma unroll
-                for (int c = 0; c < CPR / 2; ++c) {
-                    const int row = tid / CPR + c * (256 / CPR);
-                    *(uint4*)&sP[row * PK + (tid % CPR) * 8] = rp[stage * (CPR / 2) + c];
+                for (int c = 0; c < NRP / 2; ++c) {
+                    const int row = tid / CPR + c * (NT / CPR);
+                    *(uint4*)&sP[row * PK + (tid % CPR) * 8] = rp[stage * (NRP / 2) + c];
                 }
                 __syncthreads();
 #pragma unroll
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
         if (a.bias_out) {                                                       // (T % 8 == 0, T <= 256)
             h16* Bo = a.bias_out + (long)bh * T * T;
             const int cpr = T >> 3;
-            for (int cid = tid; cid < TQ * cpr; cid += 256) {
+            for (int cid = tid; cid < TQ * cpr; cid += NT) {
                 const int row = cid / cpr, c8 = cid - row * cpr;
                 if (i0 + row < T) *(uint4*)(Bo + (long)(i0 + row) * T + c8 * 8) = *(const uint4*)&sB[row * PB + c8 * 8];
             }
@@ -311,14 +315,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DH <= 64 &
     for (int j0 = 0; j0 < T; j0 += TK) {
 #pragma unroll
         for (int c = 0; c < NKV; ++c) {
-            const int cid = tid + 256 * c, row = cid / CPR, c8 = cid % CPR;
+            const int cid = tid + NT * c, row = cid / CPR, c8 = cid % CPR;
             *(uint4*)&sK[row * PK + c8 * 8] = rk[c];
             *(uint4*)&sV[row * PV + c8 * 8] = rv[c];
         }
         if constexpr (!POS) {
 #pragma unroll
             for (int c = 0; c < NBI; ++c) {
-                const int cid = tid + 256 * c, row = cid >> 3, c8 = cid & 7;
+                const int cid = tid + NT * c, row = cid >> 3, c8 = cid & 7;
                 *(uint4*)&sB[row * PB + c8 * 8] = rbi[c];
             }
         }
@@ -990,6 +994,11 @@ extern "C" int sarssl_relpos_attn_fwd(const void* qu, long ldq, const void* k, c
 // The same forward with the shifted positional score formed inside the kernel (attention.py:87-89 + 105-113 fused): qv = q + v_bias
 // [B*T][ldq], pos = positional projection [T][ldp] (head h at column h*dh).  bias_out (optional, (B,H,T,T)) receives the shifted score
 // for backward kernels that read it.  T <= 256, T % 8 == 0 (sarssl_relpos_attn_pos_supported).
+static int sarssl_attn_fwd_waves() {          // SARSSL_ATTN_FWD_WAVES=4: the four-wave forward for d_head 64 as well (A/B runs)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SARSSL_ATTN_FWD_WAVES"); v = (e && atoi(e) == 4) ? 4 : 8; }
+    return v;
+}
 extern "C" int sarssl_relpos_attn_pos_supported(int T, int dh) { return (T > 0 && T <= 256 && T % 8 == 0 && (dh == 32 || dh == 64 || dh == 128)) ? 1 : 0; }
 // u_bias / v_bias (both or neither; f32 [H*dh]): qu and qv are then the SAME plain query projection q and the kernels form q + u / q + v
 // while loading (the values sarssl_bias2 would have stored).
@@ -1007,6 +1016,13 @@ extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long l
     a.ctx = (h16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     dim3 grid((T + 127) / 128, B * H);
     hipStream_t st = (hipStream_t)stream;
+    if (dh == 64 && T > 128 && sarssl_attn_fwd_waves() == 8) {        // all 256 query rows of a (batch, head) in one eight-wave workgroup
+        dim3 grid8(1, B * H);
+        if (dtype == SARSSL_F16) relpos_attn_fwd_kernel<64, f16, true, 8><<<grid8, 512, 0, st>>>(a);
+        else relpos_attn_fwd_kernel<64, bf16, true, 8><<<grid8, 512, 0, st>>>(a);
+        SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel<pos, 8 waves>");
+        return 0;
+    }
     if (dtype == SARSSL_F16) {
         if (dh == 128) relpos_attn_fwd_kernel<128, f16, true><<<grid, 256, 0, st>>>(a);
         else if (dh == 64) relpos_attn_fwd_kernel<64, f16, true><<<grid, 256, 0, st>>>(a);
