@@ -136,8 +136,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     constexpr int CPRA = BM / 8, CPRB = BN / 8;
     const TA* pa = (const TA*)g.A + z0 * g.sA0 + z1 * g.sA1 +
                    (AKC ? (long)(m0 + (tid >> 3)) * g.lda + k_begin + (tid & 7) * 8 : (long)(k_begin + tid / CPRA) * g.lda + m0 + (tid % CPRA) * 8);
-    const int bsel = g.bsel ? g.bsel[z] : 0;
-    const TB* pb = (const TB*)g.B + z0 * g.sB0 + z1 * g.sB1 + (long)bsel * g.bsel_stride +
+    const TB* pb = (const TB*)g.B + z0 * g.sB0 + z1 * g.sB1 +
                    (BKC ? (long)(n0 + (tid >> 3)) * g.ldb + k_begin + (tid & 7) * 8 : (long)(k_begin + tid / CPRB) * g.ldb + n0 + (tid % CPRB) * 8);
     const long stepA = AKC ? BK : (long)BK * g.lda, stepB = BKC ? BK : (long)BK * g.ldb;
 
@@ -167,10 +166,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     // every epilogue slice, so its 8 bias values are loaded here, behind the whole K loop
     const int ch = tid & 15, n = n0 + ch * 8;
     float bias8[8];
-    if (g.bias && g.bsel) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias8[e] = (n + e < g.N) ? g.bias[(long)(n + e) * g.bias_stride + bsel] : 0.f;
-    } else if (g.bias && (!EDGE || n + 8 <= g.N)) {
+    if (g.bias && (!EDGE || n + 8 <= g.N)) {
         const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
         bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
     } else {
@@ -493,16 +489,14 @@ static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, int nbatch, hipS
 // C ABI ------------------------------------------------------------------------------------
 // dtypes: 0 = f32, 1 = bf16.  Supported (A,B,C) combinations: (1,1,1) (1,1,0) (0,0,0).
 // precise != 0 (f32 operands only) runs the 3-pass split and needs ws (f32, nbatch*M*N).
-static int gemm_entry(const void* A, const void* B, void* C, int dtA, int dtB, int dtC,
-                      int a_kc, int b_kc, int M, int N, int K, long lda, long ldb, long ldc,
-                      int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
-                      float alpha, float out_scale, const float* bias, int act,
-                      const void* resid, long ldr, long sR0, long sR1, float res_scale,
-                      void* preact, const void* aux, int aux_act, int aux_dtype, float p_drop, unsigned long long seed,
-                      int precise, float* ws, int split_k, int c_row_shift, void* stream,
-                      const int* bsel, long bsel_stride, int bias_stride) {
+extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC,
+                           int a_kc, int b_kc, int M, int N, int K, long lda, long ldb, long ldc,
+                           int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
+                           float alpha, float out_scale, const float* bias, int act,
+                           const void* resid, long ldr, long sR0, long sR1, float res_scale,
+                           void* preact, const void* aux, int aux_act, int aux_dtype, float p_drop, unsigned long long seed,
+                           int precise, float* ws, int split_k, int c_row_shift, void* stream) {
     SARSSL_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0 && batch_inner > 0, "sarssl_gemm");
-    SARSSL_REQUIRE(!bsel || (split_k <= 0 && !precise && !c_row_shift && bsel_stride % 8 == 0 && bias_stride >= 1), "sarssl_gemm_bsel");
     SARSSL_REQUIRE(a_kc ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0), "sarssl_gemm(A alignment)");
     SARSSL_REQUIRE(b_kc ? (K % 8 == 0 && ldb % 8 == 0) : (N % 8 == 0 && ldb % 8 == 0), "sarssl_gemm(B alignment)");
     GemmArgs g;
@@ -517,7 +511,6 @@ static int gemm_entry(const void* A, const void* B, void* C, int dtA, int dtB, i
     g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K;
     g.row_shift = 0; g.csum_ws = nullptr;
-    g.bsel = bsel; g.bsel_stride = bsel_stride; g.bias_stride = bias_stride;
 #ifdef GEMM_STAMPS
     g.stamps = g_gemm_stamps_host;
 #endif
@@ -602,28 +595,6 @@ static int gemm_entry(const void* A, const void* B, void* C, int dtA, int dtB, i
     return -1;
 }
 
-extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC,
-                           int a_kc, int b_kc, int M, int N, int K, long lda, long ldb, long ldc,
-                           int nbatch, int batch_inner, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1,
-                           float alpha, float out_scale, const float* bias, int act,
-                           const void* resid, long ldr, long sR0, long sR1, float res_scale,
-                           void* preact, const void* aux, int aux_act, int aux_dtype, float p_drop, unsigned long long seed,
-                           int precise, float* ws, int split_k, int c_row_shift, void* stream) {
-    return gemm_entry(A, B, C, dtA, dtB, dtC, a_kc, b_kc, M, N, K, lda, ldb, ldc, nbatch, batch_inner, sA0, sA1, sB0, sB1, sC0, sC1, alpha,
-                      out_scale, bias, act, resid, ldr, sR0, sR1, res_scale, preact, aux, aux_act, aux_dtype, p_drop, seed, precise, ws, split_k,
-                      c_row_shift, stream, nullptr, 0, 1);
-}
-// The same product with the B operand (and the bias) of every batch matrix chosen on the device: batch z reads B + bsel[z] * bsel_stride
-// and bias[n * bias_stride + bsel[z]] (GemmArgs::bsel).  16-bit operands; no split-K / precise / row-shift epilogues.
-extern "C" int sarssl_gemm_bsel(const void* A, const void* B, void* C, int dtA, int dtB, int dtC,
-                                int a_kc, int b_kc, int M, int N, int K, long lda, long ldb, long ldc,
-                                int nbatch, long sA, long sC, const int* bsel, long bsel_stride,
-                                const float* bias, int bias_stride, int act, const void* aux, int aux_act, int aux_dtype, void* stream) {
-    SARSSL_REQUIRE(bsel != nullptr, "sarssl_gemm_bsel");
-    return gemm_entry(A, B, C, dtA, dtB, dtC, a_kc, b_kc, M, N, K, lda, ldb, ldc, nbatch, 1, sA, 0, 0, 0, sC, 0, 1.f, 1.f, bias, act,
-                      nullptr, 0, 0, 0, 1.f, nullptr, aux, aux_act, aux_dtype, 0.f, 0ull, 0, nullptr, 0, 0, stream, bsel, bsel_stride, bias_stride);
-}
-
 // Grouped split-K weight-gradient products: ws[q] (f32, split_q * M_q * N_q, see `split_out`) receives the partial sums of
 // dY_q^T X_q with A_q = dY [K_q][M_q] (row stride lda), B_q = X [K_q][N_q] (row stride ldb), bf16; fold with
 // sarssl_splitk_reduce_multi.  split_k[q] is the requested split; the effective number of partial slices (ceil(K / per), per a
@@ -645,7 +616,7 @@ extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, 
         GemmArgs& g = a.p[q];
         g.A = A[q]; g.B = B[q]; g.C = nullptr; g.M = M[q]; g.N = N[q]; g.K = K[q]; g.lda = lda[q]; g.ldb = ldb[q]; g.ldc = N[q];
         g.batch_inner = 1; g.sA0 = g.sA1 = g.sB0 = g.sB1 = g.sC0 = g.sC1 = 0;
-        g.alpha = 1.f; g.out_scale = 1.f; g.bias = nullptr; g.act = 0; g.bsel = nullptr; g.bsel_stride = 0; g.bias_stride = 1;
+        g.alpha = 1.f; g.out_scale = 1.f; g.bias = nullptr; g.act = 0;
         g.resid = nullptr; g.ldr = 0; g.sR0 = g.sR1 = 0; g.res_scale = 0.f;
         g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.aux_f16 = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
         g.p_drop = 0.f; g.seed = 0; g.salt = nullptr; g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);

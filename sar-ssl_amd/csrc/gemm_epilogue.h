@@ -22,11 +22,6 @@ struct GemmArgs {
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
     float* csum_ws;             // grouped weight-gradient launch only: f32 [split_k][M] partial column sums of the A operand (= the bias
                                 // gradient of the layer whose weight gradient this product is), written by the workgroups of column tile 0
-    const int* bsel; long bsel_stride; int bias_stride;
-                                // bsel != null (device, one int per batch matrix): batch z reads its B operand bsel[z] * bsel_stride elements
-                                // further on and bias entry n * bias_stride + bsel[z] - the rows of a weight matrix interleaved in groups
-                                // (ldb = groups * row length), one group per batch item, chosen on the device (the decoder's output
-                                // Linear on the masked channel's rows only: model.py, SARSSL_DEC_HALF)
     int row_shift;              // != 0 (= T, with M = N = ldc = T): row m of every batch matrix is stored m + 1 - T elements further
                                 // (elements falling before the matrix are dropped): the relative-position shift of the reference
                                 // (attention.py:105-113: pad one zero column, reinterpret (T, T+1) as (T+1, T), drop the first row)
