@@ -266,7 +266,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_WGRAD_SPLIT_BIG": [_WGRAD_SPLIT_BIG, _WGRAD_SPLIT_BIG_TILES], "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_PREP_ASYNC": int(_PREP_ASYNC), "SARSSL_WGRAD_SPLIT_BIG": [_WGRAD_SPLIT_BIG, _WGRAD_SPLIT_BIG_TILES], "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
@@ -343,6 +343,7 @@ def _replaying(train):
 
 
 _DEC_MASKED = os.environ.get("SARSSL_DEC_MASKED", "1") != "0"   # training steps run the decoder on the masked frames only (model._PretrainFn; 0: every frame)
+_PREP_ASYNC = os.environ.get("SARSSL_PREP_ASYNC", "1") != "0"    # weight-only launches of a step on the side stream, next to the front-end (model.py)
 _TAIL_MASKED = os.environ.get("SARSSL_TAIL_MASKED", "1") != "0"  # ... and the row-wise tail of each encoder's last block (second feed-forward module + closing LayerNorm)
 _FFN2 = os.environ.get("SARSSL_FFN2", "1") != "0"             # 0: the feed-forward module as two GEMM launches (A/B runs)
 # Model widths that take the fused forward / backward launch.  Default: d = 256 only (the spat encoder - the step's critical chain).  The
@@ -576,6 +577,34 @@ def _pe(mod, T):
     return c[key]
 
 
+def _pos_proj(mod, T):
+    """The module's positional projection linear_pos(PE[:T]) [T, d] (attention.py:84): batch-invariant and a function of the weights only,
+    so it is cached per weight version like the re-laid-out taps - prepare_step_weights forms it off the encoders' chains."""
+    lin = mod.attention.pos_proj.linear
+    return _cached(lin, "pos%d" % T, lambda: mm_nt(_pe(mod, T), wt(lin.weight), fp8=False))
+
+
+def prepare_step_weights(net, F, T, need_bwd=True):
+    """Everything a step derives from the PARAMETERS ALONE - re-laid-out 3x3 taps, patch-conv matrices, fragment-order feed-forward
+    packs, the positional projections - in one place, so that model._PretrainFn can issue it on the side stream while the front-end /
+    masking launches run (a dozen 5-20 us launches that otherwise sit in the two encoders' chains).  The point-of-use helpers
+    (_taps, _patch_w, _pos_proj, _ffn_packs) then hit their caches."""
+    encs = (net.spec_encoder, net.spat_encoder)
+    if _FFN2 and RT.dtype in _16 and not RT.fp8 and RT.replay is None:
+        # fragment-order packs of every feed-forward module's weights for the fused kernel: one launch per step
+        prepare_ffn_packs(block_ffns(encs[0].embed) + block_ffns(encs[1].embed), need_bwd=need_bwd)
+        if _LIN256:
+            prepare_lin256_packs(block_lin256_mods(encs[0].embed) + block_lin256_mods(encs[1].embed), need_bwd=need_bwd)
+    for enc in encs:
+        pe = enc.patch_embed
+        _taps(pe[3]); _taps(pe[6])
+        _patch_w(pe[12], F)
+        if need_bwd:
+            _patch_w(pe[12], F, grad=True)
+        for blk in enc.embed.layers:
+            _pos_proj(blk.sequential[1].module, T)
+
+
 def _adjacent(ts):
     """Back-to-back views of ONE storage (as laid out by runtime.FlatParams)."""
     base = ts[0].untyped_storage().data_ptr()
@@ -629,7 +658,7 @@ def mhsa_fwd(x, mod, B, T, train, saved):
         v = mm_nt(ln, wt(att.value_proj.linear.weight), bias=att.value_proj.linear.bias.data)
     ldk = k.stride(0)
     pe = _pe(mod, T)
-    pos = mm_nt(pe, wt(att.pos_proj.linear.weight), fp8=False)                               # [T, d]
+    pos = _pos_proj(mod, T)                                                                  # [T, d]
     nbh = B * H
     pa = _p(att.dropout, train)
     sa = RT.next_seed() if pa > 0 else 0

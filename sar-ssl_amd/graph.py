@@ -112,6 +112,10 @@ class PretrainStepGraph:
         net = self.net
         if with_adam:
             hip.step_tick(self.state)
+        # weight-only launches of the step (taps, patch matrices, feed-forward packs, positional projections): on the side stream, under
+        # the front-end launch (the callers have validated the 16-bit shadows)
+        F_, T_ = (256, (src.shape[1] - 512) // 256 + 1) if from_pcm else (src.shape[2], src.shape[3])
+        net.__dict__["_prep_event"] = net.prepare_weights(F_, T_)
         if from_pcm:        # front-end and input masks in one pass over the spectrum; the forward below picks the masked inputs up
             x, spec_in, spat_in = hip.stft_frontend(src, masks=(mp, ch), dtype=RT.dtype)
             net.__dict__["_premasked"] = (x, spec_in, spat_in)
@@ -128,6 +132,7 @@ class PretrainStepGraph:
             net.__dict__.pop("_loss_sink", None)
             net.__dict__.pop("_loss_grad_with_forward", None)
             net.__dict__.pop("_premasked", None)
+            net.__dict__.pop("_prep_event", None)
         self.pred, self.xin, self.vis_masks = pred, x, (mp, ch)
         self.ecat = net.__dict__.pop("_last_ecat", None)      # compact decoder path: the decoder's input of every frame (for vis)
         _PretrainFn.backward(ctx, self.one, None, None)

@@ -139,12 +139,9 @@ class _PretrainFn(torch.autograd.Function):
         B, _, F, T, _ = x.shape
         saved = []
         runtime_begin_forward(net.parameters() if not params else params)
-        if engine._FFN2 and RT.dtype in engine._16 and not RT.fp8 and RT.replay is None:
-            # fragment-order packs of every feed-forward module's weights for the fused kernel: one launch per step, on the main stream
-            engine.prepare_ffn_packs(engine.block_ffns(net.spec_encoder.embed) + engine.block_ffns(net.spat_encoder.embed), need_bwd=not RT.inference)
-            if engine._LIN256:
-                engine.prepare_lin256_packs(engine.block_lin256_mods(net.spec_encoder.embed) + engine.block_lin256_mods(net.spat_encoder.embed),
-                                            need_bwd=not RT.inference)
+        # weight-only launches (taps, patch matrices, feed-forward packs, positional projections): already under way on the side stream
+        # when the caller issued them in front of its front-end launches (graph.py), otherwise started here, next to the masking pass
+        prep = net.__dict__.pop("_prep_event", None) or net.prepare_weights(F, T)
         pre = net.__dict__.pop("_premasked", None)          # (graph.py: the front-end launch already applied the masks to this very x)
         if pre is not None and pre[0] is x and pre[1].dtype == RT.dtype:
             spec_in, spat_in = pre[1], pre[2]
@@ -166,6 +163,8 @@ class _PretrainFn(torch.autograd.Function):
         saved_spat = []
         side = net._side_stream(x.device)
         main = torch.cuda.current_stream()
+        if prep is not True:
+            main.wait_event(prep)                          # (the side stream runs the weight-only launches in order anyway)
         if side is not None:
             pass                                           # (the lazy weight refresh already happened in begin_forward, on the main stream)
             side.wait_stream(main)
@@ -369,6 +368,23 @@ class SARSSL(nn.Module):
         if self.pretrain:
             groups.append(("decoder", list(self.decoder.parameters())))
         return groups
+
+    def prepare_weights(self, F, T):
+        """Issues engine.prepare_step_weights: on the side stream (-> the event the main stream has to wait for before it uses any of the
+        results) or, single-stream, in place (-> True).  graph.py calls it in front of the front-end launch and leaves the event in
+        ``_prep_event`` for the forward pass."""
+        dev = next(self.parameters()).device
+        side = self._side_stream(dev) if (engine._PREP_ASYNC and dev.type == "cuda") else None
+        if side is None:
+            engine.prepare_step_weights(self, F, T, need_bwd=not RT.inference)
+            return True
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                             # (the previous step's optimizer launch wrote the 16-bit shadows on the main stream)
+        with torch.cuda.stream(side):
+            engine.prepare_step_weights(self, F, T, need_bwd=not RT.inference)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
 
     def _side_stream(self, device):
         """Second HIP stream for the spat encoder (None disables the two-stream schedule: SARSSL_TWO_STREAMS=0)."""
