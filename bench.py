@@ -391,6 +391,8 @@ def main():
         if dp:
             torch.distributed.barrier()
 
+    if state["graph"] is not None:
+        step()                  # set-up, not a warm-up step: the first call captures the graph(s) - also with --warmup 0 the timed region replays
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
