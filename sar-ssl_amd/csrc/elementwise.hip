@@ -68,6 +68,94 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
+// The same arithmetic with SEVERAL rows per wave (d = 256: four rows of 16 lanes, d = 512: two rows of 32 lanes).  The kernel above keeps
+// one 512-byte row per wave in flight, so a [16384, 256] pass is bound by request round trips (2 TB/s); here a wave has 2 KB in flight and
+// the four rows' reductions are ONE set of lane exchanges.  Bit-identical by construction: a lane holds the float4 columns of the virtual
+// lanes v = l + LPR * j of the 64-lane layout (column c4 = v + 64 i), forms each virtual lane's partial exactly as above, combines them in
+// the order of wave_sum's butterfly (exchange distances 32 .. LPR are additions of its own partials - a + b == b + a - the rest are lane
+// exchanges inside the row's LPR lanes).  (Round 4 measured a 16-lane layout with 32-byte requests 9.0 -> 6.8 us but with another summation
+// order, which moved the model-level per-bin maxima - noise, but not kept; this one changes no bit.)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void layernorm_fwd_rows_kernel(const T* __restrict__ x, long ldx, long M, int d /* == D: a run-time
+                                                                 divisor keeps the divisions of the one-row kernel (no reciprocal / FMA folding) */,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, T* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd) {
+    constexpr int NI = D / 256;                             // float4 columns per virtual lane (c4 = v + 64 i)
+    constexpr int RPW = 4 / NI;                             // rows per wave: 4 (d = 256), 2 (d = 512)
+    constexpr int LPR = 64 / RPW;                           // lanes per row
+    constexpr int J = RPW;                                  // virtual lanes per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane % LPR, slot = lane / LPR;
+    float4 g[J][NI], bb[J][NI];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c4 = lr + LPR * j + 64 * i;
+            g[j][i] = *(const float4*)(gamma + c4 * 4); bb[j][i] = *(const float4*)(beta + c4 * 4);
+        }
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * RPW; row0 < M; row0 += (long)gridDim.x * 4 * RPW) {
+        const long row = row0 + slot;
+        const bool ok = row < M;
+        float4 v[J][NI];
+        float p[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c4 = lr + LPR * j + 64 * i;
+                v[j][i] = ok ? ld4(x + row * ldx + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s += v[j][i].x + v[j][i].y + v[j][i].z + v[j][i].w;
+            }
+            p[j] = s;
+        }
+        // wave_sum's butterfly: distances 32 .. LPR among the lane's own partials, LPR/2 .. 1 between lanes
+        auto fold = [&](float (&q)[J]) -> float {
+#pragma unroll
+            for (int m = J / 2; m > 0; m >>= 1) {
+                float t[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) t[j] = q[j] + q[j ^ m];
+#pragma unroll
+                for (int j = 0; j < J; ++j) q[j] = t[j];
+            }
+            float r = q[0];
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+            return r;
+        };
+        const float mu = fold(p) / (float)d;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float a = v[j][i].x - mu, b = v[j][i].y - mu, c = v[j][i].z - mu, e = v[j][i].w - mu;
+                // four products, three additions, no fused multiply-add: what hipcc makes of the one-row kernel's `a * a + b * b + c * c + e * e`
+                // (packed multiplies); left to -ffp-contract=fast it picks FMAs here and rstd moves by an ulp on 6 % of the rows
+                float a2 = a * a, b2 = b * b, c2 = c * c, e2 = e * e;
+                asm volatile("" : "+v"(a2), "+v"(b2), "+v"(c2), "+v"(e2));       // (the products as values: nothing to contract with)
+                q = q + (((a2 + b2) + c2) + e2);
+            }
+            p[j] = q;
+        }
+        const float rs = rsqrtf(fold(p) / (float)d + eps);
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int c4 = lr + LPR * j + 64 * i;
+                    st4(y + row * ldy + c4 * 4, make_float4((v[j][i].x - mu) * rs * g[j][i].x + bb[j][i].x, (v[j][i].y - mu) * rs * g[j][i].y + bb[j][i].y,
+                                                            (v[j][i].z - mu) * rs * g[j][i].z + bb[j][i].z, (v[j][i].w - mu) * rs * g[j][i].w + bb[j][i].w));
+                }
+            if (lr == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+        }
+    }
+}
+
 // Two LayerNorms in a row on the same data - a Conformer block's closing LayerNorm and the first one of the next block's feed-forward
 // module (Conformer.py:88-90, feed_forward.py:48): y = LN_a(x) is stored (rounded to T), z = LN_b(y as stored) - the arithmetic of two
 // launches of the kernel above, bit for bit, in one pass over the row.
@@ -878,6 +966,14 @@ __global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, fl
 extern "C" int sarssl_layernorm_fwd(const void* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps,
                                     void* y, long ldy, float* mean, float* rstd, int dtype, void* stream) {
     SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0, "sarssl_layernorm_fwd");
+    static const int rows_kernel = [] { const char* e = getenv("SARSSL_LN_ROWS"); return (e && atoi(e) == 0) ? 0 : 1; }();   // 0: one row per wave (A/B runs)
+    if (rows_kernel && (d == 256 || d == 512) && M >= 4096) {
+        const int nblk = nblocks_for(M, d == 256 ? 16 : 8, 4096);
+        if (d == 256) { DISPATCH_T(dtype, (layernorm_fwd_rows_kernel<T, 256><<<nblk, 256, 0, ST>>>((const T*)x, ldx, M, d, gamma, beta, eps, (T*)y, ldy, mean, rstd))); }
+        else { DISPATCH_T(dtype, (layernorm_fwd_rows_kernel<T, 512><<<nblk, 256, 0, ST>>>((const T*)x, ldx, M, d, gamma, beta, eps, (T*)y, ldy, mean, rstd))); }
+        SARSSL_CHECK_LAUNCH("layernorm_fwd_rows_kernel");
+        return 0;
+    }
     const int nblk = nblocks_for(M, 4, 4096);
     DISPATCH_T(dtype, (layernorm_fwd_kernel<T><<<nblk, 256, 0, ST>>>((const T*)x, ldx, M, d, gamma, beta, eps, (T*)y, ldy, mean, rstd)));
     SARSSL_CHECK_LAUNCH("layernorm_fwd_kernel");

@@ -673,6 +673,28 @@ def test_layernorm(dtp, d):
     assert _relerr(wide[:, 64:].float(), yref.detach()) < tol and float(wide[:, :64].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtp", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("d", [256, 512])
+def test_layernorm_several_rows_per_wave_is_bit_identical(dtp, d):
+    """Large row counts take layernorm_fwd_rows_kernel (four / two rows per wave, a row's reductions inside 16 / 32 lanes): the same
+    summation order as the one-row-per-wave kernel that shorter inputs take - outputs and saved statistics equal bit for bit, also for a
+    row count that is no multiple of the rows per wave, strided input and output; and against the f64 LayerNorm."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(d + 1)
+    M = 8191
+    xw = (torch.randn((M, d + 64), generator=g) * 1.7 + 0.4).to(dtp).to(dev)
+    x = xw[:, 32:32 + d]                                          # row stride d + 64
+    gamma, beta = (torch.rand(d, generator=g) + 0.5).to(dev), torch.randn(d, generator=g).to(dev)
+    wide = torch.zeros((M, d + 8), dtype=dtp, device=dev)
+    y, st = hip.layernorm_fwd(x, gamma, beta, out=wide[:, 8:])
+    parts = [hip.layernorm_fwd(x[a:b], gamma, beta) for a, b in ((0, 3000), (3000, 6000), (6000, M))]       # < 4096 rows: one row per wave
+    assert torch.equal(y, torch.cat([p[0] for p in parts])) and torch.equal(st, torch.cat([p[1] for p in parts], dim=1))
+    assert float(wide[:, :8].abs().max()) == 0.0
+    ref = torch.nn.functional.layer_norm(x.double(), (d,), gamma.double(), beta.double(), 1e-5)
+    assert _relerr(y.float(), ref) < (2e-5 if dtp == torch.float32 else 2e-2)
+
+
 @pytest.mark.parametrize("dtp", [torch.float32, torch.bfloat16])
 def test_glu_dwconv_misc(dtp):
     from sar_ssl_amd import hip
