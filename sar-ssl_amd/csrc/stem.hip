@@ -831,7 +831,22 @@ __global__ void cl_affine_act_kernel(const T* __restrict__ x, long rows, int L, 
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const int ch = (col + e) % C; sc[e] = scale[ch]; sh[e] = shift[ch]; }
-    for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
+    // four rows in flight per thread (the launch gives every thread four rows: one 16-byte request per thread at a time made these passes
+    // request-latency bound at ~1 TB/s)
+    const long stride = (long)gridDim.x * rpb;
+    long n = (long)blockIdx.x * rpb + rslot;
+    for (; n + 3 * stride < rows; n += 4 * stride) {
+        f8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld8(x + (n + u * stride) * L + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[u].v[e] = act_fwd(fmaf(v[u].v[e], sc[e], sh[e]), act);
+            st8(z + (n + u * stride) * L + col, v[u]);
+        }
+    }
+    for (; n < rows; n += stride) {
         f8 v = ld8(x + n * L + col);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v.v[e] = act_fwd(fmaf(v.v[e], sc[e], sh[e]), act);
@@ -871,7 +886,20 @@ __global__ void cl_bn_train_act_kernel(const T* __restrict__ x, long rows, int C
             }
         }
     }
-    for (long n = (long)blockIdx.x * rpb + rslot; n < rows; n += (long)gridDim.x * rpb) {
+    const long stride = (long)gridDim.x * rpb;          // four rows in flight per thread, as in cl_affine_act_kernel
+    long n = (long)blockIdx.x * rpb + rslot;
+    for (; n + 3 * stride < rows; n += 4 * stride) {
+        f8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld8(x + (n + u * stride) * C + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[u].v[e] = act_fwd(fmaf(v[u].v[e], sc[e], sh[e]), act);
+            st8(z + (n + u * stride) * C + col, v[u]);
+        }
+    }
+    for (; n < rows; n += stride) {
         f8 v = ld8(x + n * C + col);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v.v[e] = act_fwd(fmaf(v.v[e], sc[e], sh[e]), act);

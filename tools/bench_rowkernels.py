@@ -12,10 +12,11 @@ M = B * T
 F16, BF = torch.float16, torch.bfloat16
 
 
-def timeit(fn, n=40):
+def timeit(fn, n=100):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
+    hip.gpu_runway(3.0)                 # the GPU is kept busy while the host enqueues the loop: launches of a few us are host-bound otherwise
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):
