@@ -51,6 +51,15 @@ for d in (256, 512):
     c = torch.randn((M, d), device=dev).to(F16)
     aff = torch.randn((4, d), device=dev)
     row("cl_affine_act d=%d (BatchNorm + Swish)" % d, timeit(lambda: hip.cl_affine_act(c, d, aff, 2)), 2 * 2 * M * d)
+    hip.sums_arena_reset(dev)
+    red = hip.cl_bn_bwd_reduce(dc, c, d, aff, 2)
+
+    def bn_reduce():
+        hip.sums_arena_reset(dev)                               # (the arena hands out one slice per call; a launch of its own, ~2 us)
+        hip.cl_bn_bwd_reduce(dc, c, d, aff, 2)
+    row("cl_bn_bwd_reduce d=%d (Swish; + arena reset + memset launches)" % d, timeit(bn_reduce), 2 * 2 * M * d)
+    outb = torch.empty_like(dc)
+    row("cl_bn_bwd_apply d=%d (Swish)" % d, timeit(lambda: hip.cl_bn_bwd_apply(dc, c, d, aff, 2, False, True, red, out=outb)), 3 * 2 * M * d)
     q = torch.randn((M, d), device=dev).to(F16)
     u, v = torch.randn(d, device=dev), torch.randn(d, device=dev)
     row("bias2 d=%d (q+u, q+v)" % d, timeit(lambda: hip.bias2(q, u, v)), 3 * 2 * M * d)
