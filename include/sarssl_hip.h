@@ -9,6 +9,7 @@
  * tensors SAVED BY THE FORWARD PASS it reads are fp16 - the fp16-forward / bf16-backward numeric mode (abi version 2: fp16 has 3 more
  * mantissa bits than bf16 at the same MFMA rate, which is what puts the forward pass inside the reference's 1e-3 per-bin tolerance;
  * gradients keep bf16's exponent range, so no loss scaling - the reference's own AMP is fp16 with a GradScaler, code/learner.py:46-50).
+ * 5 = "mixed f32" (hybrid mode): bf16 gradient tensors next to an f32 tensor saved by the forward pass.
  * "precise" != 0 (f32 storage only) runs every MFMA contraction as three split-bf16 passes (hi*hi + hi*lo + lo*hi).
  */
 #ifndef SARSSL_HIP_H
@@ -90,6 +91,34 @@ int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC
 /*      operand dtypes: (bf16,bf16) and (fp16,fp16) contract on the matrix cores as stored, (f32,f32) as split-bf16 parts; a bf16 / fp16
  *      pair (gradient x saved activation) contracts in bf16, the fp16 operand re-encoded while staged.  aux_dtype: dtype of `aux`
  *      (= dtC, or fp16 next to a bf16 C). */
+
+/* ---- "hybrid" numeric mode (round 6): fp16 CNN stem + f32 residual stream in the Conformer blocks / decoder - the mode that meets the
+ *      1e-3 per-bin tolerance against the reference's f32 path (code/learner.py:100-103 runs the model in f32 by default) at 16-bit
+ *      matrix-core speed.  An f32 tensor enters a product as an fp16 PAIR hi = fp16(x), lo = fp16(x - hi), a weight likewise.
+ *      sarssl_gemm_split: nn.Linear forward (code/common/conformer/modules.py:35-48 and every use of it: feed_forward.py:47-54,
+ *      attention.py:82-85, :113, convolution.py:138, :143, code/model.py:63, 296-301): C = epilogue(A B^T [+ A_lo B^T] [+ A B_lo^T]), f32
+ *      accumulation across the segments, epilogue of sarssl_gemm (bias, act 1 relu | 2 swish, saved pre-activation, dropout, scaled
+ *      residual).  A, A_lo [M][K] fp16 (row stride lda), B, B_lo [N][K] fp16 (row stride ldb); A_lo needs B_lo; C / resid / preact of
+ *      dtC (fp16 | f32). */
+int sarssl_gemm_split(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, int dtC, int M, int N, int K, long lda,
+                      long ldb, long ldc, float out_scale, const float* bias, int act, const void* resid, long ldr, float res_scale,
+                      void* preact, float p_drop, unsigned long long seed, void* stream);
+/*      LayerNorm on f32 rows with the result written as an fp16 pair (and, y32 != NULL, in f32): the operand of the Linear layer behind it. */
+int sarssl_layernorm_fwd_pair(const float* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps, void* y_hi,
+                              void* y_lo, long ldy, float* y32, long ldy32, float* mean, float* rstd, void* stream);
+/*      y = LN_a(x) in f32 (a Conformer block's closing LayerNorm, code/common/Conformer.py:88-90), z = LN_b(y) as a pair (the next
+ *      block's feed_forward.py:48) in one launch. */
+int sarssl_layernorm_fwd2_pair(const float* x, long ldx, long M, int d, const float* gamma_a, const float* beta_a, float eps_a, float* y,
+                               long ldy, float* mean_a, float* rstd_a, const float* gamma_b, const float* beta_b, float eps_b, void* z_hi,
+                               void* z_lo, long ldz, float* mean_b, float* rstd_b, void* stream);
+/*      LayerNorm backward on the f32 stream: x / resid / dx f32, dy (the branch gradient) bf16 | f32 (dy_dtype); dx2 (optional, [M][d]
+ *      bf16) = dx * dropmask(p_drop, seed) * gscale, the matrix-core operand of the next module of the backward chain.  partial /
+ *      dgamma / dbeta as sarssl_layernorm_bwd. */
+int sarssl_layernorm_bwd_stream(const void* dy, int dy_dtype, long lddy, const float* x, long ldx, long M, int d, const float* gamma,
+                                const float* mean, const float* rstd, const float* resid, long ldr, float* dx, long lddx, float* dgamma,
+                                float* dbeta, float* partial, void* dx2, float p_drop, unsigned long long seed, float gscale, void* stream);
+/*      src (f32 | fp16 | bf16; n % 4 == 0) -> hi = fp16(src) (may be NULL), lo = fp16(src - hi): the weights' lo shadow, stem outputs. */
+int sarssl_split_pair(const void* src, int src_dtype, long n, void* hi, void* lo, void* stream);
 
 /* several split-K products reduced in one launch: C_q[m][n] += sum_s ws_q[s][m][n].  Pair with sarssl_gemm(split_k > 0, C = NULL,
  * bf16 operands), which then only writes the partials (split count = ceil(K / (ceil(ceil(K / split_k) / 64) * 64))). */

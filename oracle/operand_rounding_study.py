@@ -16,9 +16,10 @@ Modes (applied to both operands unless noted):
   bf16x2w    weights hi+lo, activations one bf16
   bf16x3     hi*hi + hi*lo + lo*hi  (the repo's `fp32` mode)
   fp16x2a / fp16x2w   fp16 with the activations / the weights split hi+lo (two passes)
+  fp16x3     fp16 hi*hi + hi*lo + lo*hi
 `--store` additionally rounds every contraction OUTPUT to the mode's storage type (what bf16 / fp16 activation storage adds).
 `--family NAME=MODE,...` overrides the mode per family: stem1 (4->64 1x1), conv3 (3x3), stem4 (64->4), patch, lin (Conformer
-Linear / pointwise), attn (score / PV products), dec (decoder).
+Linear / pointwise; or one of its layers: ffn1, ffn2, q, k, v, pos, out, pw1, pw2), attn (score / PV products), dec (decoder; dec1, dec2).  `NAME=MODE:n` keeps that family's outputs in f32 under --store.
 """
 import argparse
 import json
@@ -60,8 +61,23 @@ class Policy:
     def __init__(self, default, store, overrides):
         self.default, self.store, self.over = default, store, overrides
 
+    GROUP = {"ffn1": "lin", "ffn2": "lin", "q": "lin", "k": "lin", "v": "lin", "pos": "lin", "out": "lin", "pw1": "lin", "pw2": "lin",
+             "dec1": "dec", "dec2": "dec"}
+
+    def _spec(self, fam):
+        """a layer name (ffn1, ffn2, q, k, v, pos, out, pw1, pw2, dec1, dec2) falls back to its group (lin / dec), then to the default"""
+        if fam in self.over:
+            return self.over[fam]
+        return self.over.get(self.GROUP.get(fam, fam), self.default)
+
     def mode(self, fam):
-        return self.over.get(fam, self.default)
+        return self._spec(fam).split(":")[0]
+
+    def stores(self, fam):
+        """`fam=mode:n` keeps that family's outputs in f32 under --store (the hybrid mode: f32 activation storage behind the stem);
+        `fam=mode:s` stores them in the mode's 16-bit type even without --store."""
+        o = self._spec(fam)
+        return o.endswith(":s") or (self.store and not o.endswith(":n"))
 
     def contract(self, fam, fn, a, w):
         """fn(a, w) is the f32 contraction; a = activation-side operand, w = weight-side operand."""
@@ -86,21 +102,39 @@ class Policy:
             wh, wl = _split16(w)
             ab = _r(a, "fp16")
             y = fn(ab, wh) + fn(ab, wl)
+        elif m == "fp16x3":
+            ah, al = _split16(a)
+            wh, wl = _split16(w)
+            y = fn(ah, wh) + fn(ah, wl) + fn(al, wh)
         elif m == "bf16x3":
             ah, al = _split(a)
             wh, wl = _split(w)
             y = fn(ah, wh) + fn(ah, wl) + fn(al, wh)
         else:
             raise ValueError(m)
-        if self.store and m != "f32":
+        if self.stores(fam) and m != "f32":
             y = _r(y, "fp16" if m.startswith("fp16") else "bf16")
         return y
 
 
+_attn_calls = [0]
+
+
 def family_of_linear(x, w):
     out_f, in_f = w.shape
-    if (out_f, in_f) in ((3072, 768), (1024, 3072)):
-        return "dec"
+    if (out_f, in_f) == (3072, 768):
+        return "dec1"
+    if (out_f, in_f) == (1024, 3072):
+        return "dec2"
+    if out_f == 4 * in_f:
+        return "ffn1"
+    if in_f == 4 * out_f:
+        return "ffn2"
+    if out_f == 2 * in_f:
+        return "pw1"
+    if out_f == in_f:                          # oracle mhsa(): query, key, value, pos, out - in that order
+        _attn_calls[0] += 1
+        return ("q", "k", "v", "pos", "out")[(_attn_calls[0] - 1) % 5]
     return "lin"
 
 
@@ -131,7 +165,7 @@ class FProxy:
     def conv1d(self, x, w, b=None, **kw):
         if kw.get("groups", 1) != 1:                                     # depthwise: VALU kernel, f32 arithmetic
             return F.conv1d(x, w, b, **kw)
-        y = self.pol.contract("lin", lambda a, ww: F.conv1d(a, ww, None, **kw), x, w)
+        y = self.pol.contract("pw2", lambda a, ww: F.conv1d(a, ww, None, **kw), x, w)
         return y if b is None else y + b[None, :, None]
 
 
@@ -148,6 +182,7 @@ class TorchProxy:
 
 def run(pol, train, z, sd, x):
     orc.F, orc.torch = FProxy(pol), TorchProxy(pol)
+    _attn_calls[0] = 0
     try:
         sd = {k: v.clone() for k, v in sd.items()}
         with torch.no_grad():

@@ -16,7 +16,8 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 // saved-activation-side 16-bit tensors): gradients in / out are bf16, tensors SAVED BY THE FORWARD PASS are fp16 - the "fp16 forward /
 // bf16 backward" numeric mode (fp16 carries 3 more mantissa bits than bf16 at the same MFMA rate: per-bin deviation from the
 // reference's f32 path 8e-3 -> 1e-3 of range; gradients keep bf16's exponent range, so there is no loss scaling)
-enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2, SARSSL_F16 = 3, SARSSL_MIX16 = 4 };
+// SARSSL_MIXF32 (hybrid mode): bf16 gradients next to an f32 tensor saved by the forward pass (the f32 prediction / residual stream)
+enum { SARSSL_F32 = 0, SARSSL_BF16 = 1, SARSSL_I16 = 2, SARSSL_F16 = 3, SARSSL_MIX16 = 4, SARSSL_MIXF32 = 5 };
 
 // error plumbing (api.cpp owns the storage)
 extern "C" const char* sarssl_last_error();

@@ -20,6 +20,7 @@
     if (dtype == SARSSL_BF16) { typedef bf16 T; typedef bf16 TA; CALL; }                    \
     else if (dtype == SARSSL_F32) { typedef float T; typedef float TA; CALL; }              \
     else if (dtype == SARSSL_MIX16) { typedef bf16 T; typedef f16 TA; CALL; }               \
+    else if (dtype == SARSSL_MIXF32) { typedef bf16 T; typedef float TA; CALL; }            \
     else { sarssl_set_error("unsupported dtype %d", dtype); return -1; }
 static inline int nblocks_for(long work, int per_block, int cap = 4096) {
     long b = (work + per_block - 1) / per_block;

@@ -86,11 +86,12 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
     return u.b;
 }
 
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool CSUM = false>
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool CSUM = false, bool SEG = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, const int bid_y, const int bid_z, const int grid_x,
                                           const int grid_y, const int grid_z) {
     typedef typename MfmaT<TA, TB>::type TM;
     static_assert(sizeof(TA) == 2 || (sizeof(TA) == 4 && sizeof(TB) == 4), "f32 operands come in pairs (split-bf16 passes)");
+    static_assert(!SEG || (AKC && BKC && sizeof(TA) == 2 && sizeof(TB) == 2), "K-segment products: NT layout, 16-bit operands");
     constexpr int BM = 64 * FM;
     constexpr int PTA = BM + 32, PTB = BN + 32;
     constexpr int A_ELEMS = AKC ? BM * PITCH : BK * PTA;
@@ -234,6 +235,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
 #else
 #define GSTAMP(k) do {} while (0)
 #endif
+        // SEG: the K loop runs once per segment; the per-thread offsets into A / B are the same in every segment, only the base moves
+        // (segment 1 of 3 reads A2, the last segment of 2 or 3 reads B2) - the prefetch crosses segment boundaries like any K-tile
+        const int nseg = SEG ? g.nseg : 1;
+        const long offA = SEG ? (long)(pa - (const TA*)g.A) : 0, offB = SEG ? (long)(pb - (const TB*)g.B) : 0;
+        for (int seg = 0; seg < nseg; ++seg)
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
             GSTAMP(0);
             tile_store<AKC, BM>(sA, tid, ra);
@@ -245,6 +251,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
                 pa += stepA; pb += stepB;
                 tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
                 tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
+            } else if (SEG && seg + 1 < nseg) {              // first K-tile of the next segment
+                pa = (const TA*)((seg + 1 == 1 && nseg == 3) ? g.A2 : g.A) + offA;
+                pb = (const TB*)((seg + 1 == nseg - 1) ? g.B2 : g.B) + offB;
+                tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
+                tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
             }
             GSTAMP(3);
             mfma_phase(sA, sB);
@@ -333,6 +344,11 @@ extern "C" int sarssl_gemm_stamp_buffer(void* p) { g_gemm_stamps_host = (unsigne
 template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_kernel(GemmArgs g) {
     gemm_body<TA, TB, TC, AKC, BKC, FM, EDGE>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+}
+// K-segment products (sarssl_gemm_split): fp16 operands, NT layout
+template <typename TC, int FM, bool EDGE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_seg_kernel(GemmArgs g) {
+    gemm_body<f16, f16, TC, true, true, FM, EDGE, false, true>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
 }
 
 // ---- grouped launch: up to GROUP_MAXP independent split-K weight-gradient products (A = dY [K][M], B = X [K][N], both with the
@@ -510,7 +526,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     g.aux_f16 = (aux && aux_dtype == SARSSL_F16 && dtC == SARSSL_BF16) ? 1 : 0;
     g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K;
-    g.row_shift = 0; g.csum_ws = nullptr;
+    g.row_shift = 0; g.csum_ws = nullptr; g.A2 = nullptr; g.B2 = nullptr; g.nseg = 0;
 #ifdef GEMM_STAMPS
     g.stamps = g_gemm_stamps_host;
 #endif
@@ -595,6 +611,54 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     return -1;
 }
 
+// K-segment NT product on fp16 operands (the "hybrid" numeric mode's forward Linear layers): C = epilogue(A B^T [+ A_lo B^T] [+ A B_lo^T])
+// with f32 accumulation across the segments - an f32 activation given as its fp16 pair (hi = fp16(x), lo = fp16(x - hi): 22 significant
+// bits) against a weight given as its pair contracts to ~2^-21 relative per product (the lo lo term is dropped), on the fp16 matrix
+// cores.  The segments are a longer K loop of the plain kernel: same tiles, same epilogue, the prologue / epilogue of a short-K product
+// amortised over 2-3 times the MFMAs.  A, A_lo: [M][K] (row stride lda), B, B_lo: [N][K] (row stride ldb); A_lo / B_lo may be null.
+// C / resid / preact: dtC (fp16 | f32).
+template <typename TC>
+static int launch_seg(const GemmArgs& g, hipStream_t st) {
+    GemmArgs h = g;                      // tile height from the effective contraction length
+    h.K = g.K * (g.nseg > 0 ? g.nseg : 1); h.k_per_split = h.K;
+    const int fm = pick_fm(h, 1, true);
+    const int bm = 64 * fm;
+    const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
+    const bool edge = (g.M % bm) != 0 || (g.N % BN) != 0 || (g.K % BK) != 0 || !vec_ok;
+    dim3 grid((g.N + BN - 1) / BN, (g.M + bm - 1) / bm, 1);
+    if (fm == 4) { if (edge) gemm_seg_kernel<TC, 4, true><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 4, false><<<grid, 256, 0, st>>>(g); }
+    else if (fm == 1) { if (edge) gemm_seg_kernel<TC, 1, true><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 1, false><<<grid, 256, 0, st>>>(g); }
+    else { if (edge) gemm_seg_kernel<TC, 2, true><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 2, false><<<grid, 256, 0, st>>>(g); }
+    SARSSL_CHECK_LAUNCH("sarssl_gemm_split");
+    return 0;
+}
+extern "C" int sarssl_gemm_split(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, int dtC, int M, int N, int K,
+                                 long lda, long ldb, long ldc, float out_scale, const float* bias, int act, const void* resid, long ldr,
+                                 float res_scale, void* preact, float p_drop, unsigned long long seed, void* stream) {
+    SARSSL_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "sarssl_gemm_split");
+    SARSSL_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sarssl_gemm_split(alignment)");
+    SARSSL_REQUIRE(dtC == SARSSL_F16 || dtC == SARSSL_F32, "sarssl_gemm_split(dtC)");
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.batch_inner = 1; g.sA0 = g.sA1 = g.sB0 = g.sB1 = g.sC0 = g.sC1 = 0;
+    g.alpha = 1.f; g.out_scale = out_scale; g.bias = bias; g.act = act;
+    g.resid = resid; g.ldr = ldr; g.sR0 = g.sR1 = 0; g.res_scale = res_scale;
+    g.preact = preact; g.aux = nullptr; g.aux_act = 0; g.aux_f16 = 0; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
+    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
+    g.split_k = 0; g.k_per_split = K; g.row_shift = 0; g.csum_ws = nullptr;
+    // segments: (A, B) [, (A_lo, B)] [, (A, B_lo)] - the kernel reads A2 in segment 1 of 3 and B2 in the last of 2 or 3
+    SARSSL_REQUIRE(!A_lo || B_lo, "sarssl_gemm_split(A_lo needs B_lo)");
+    if (A_lo && B_lo) { g.A2 = A_lo; g.B2 = B_lo; g.nseg = 3; }
+    else if (B_lo) { g.A2 = nullptr; g.B2 = B_lo; g.nseg = 2; }
+    else { g.A2 = nullptr; g.B2 = nullptr; g.nseg = 1; }
+#ifdef GEMM_STAMPS
+    g.stamps = nullptr;
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    if (dtC == SARSSL_F16) return launch_seg<f16>(g, st);
+    return launch_seg<float>(g, st);
+}
+
 // Grouped split-K weight-gradient products: ws[q] (f32, split_q * M_q * N_q, see `split_out`) receives the partial sums of
 // dY_q^T X_q with A_q = dY [K_q][M_q] (row stride lda), B_q = X [K_q][N_q] (row stride ldb), bf16; fold with
 // sarssl_splitk_reduce_multi.  split_k[q] is the requested split; the effective number of partial slices (ceil(K / per), per a
@@ -620,7 +684,7 @@ extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, 
         g.resid = nullptr; g.ldr = 0; g.sR0 = g.sR1 = 0; g.res_scale = 0.f;
         g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.aux_f16 = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
         g.p_drop = 0.f; g.seed = 0; g.salt = nullptr; g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
-        g.split_k = ns; g.k_per_split = per; g.row_shift = 0;
+        g.split_k = ns; g.k_per_split = per; g.row_shift = 0; g.A2 = nullptr; g.B2 = nullptr; g.nseg = 0;
         g.csum_ws = csum_ws ? csum_ws[q] : nullptr;
         a.gx[q] = (N[q] + BN - 1) / BN; a.gy[q] = (M[q] + 127) / 128;
         a.first[q] = total; total += (a.gx[q] * a.gy[q] * ns + 7) / 8 * 8;

@@ -22,6 +22,9 @@ struct GemmArgs {
     int split_k, k_per_split;   // split_k > 0: blockIdx.z = z * split_k + s; raw alpha*acc partial -> acc_ws[z][s][M][N], reduced into C afterwards
     float* csum_ws;             // grouped weight-gradient launch only: f32 [split_k][M] partial column sums of the A operand (= the bias
                                 // gradient of the layer whose weight gradient this product is), written by the workgroups of column tile 0
+    const void* A2; const void* B2; int nseg;     // K-segment products (sarssl_gemm_split, NT layout, same strides as A / B): the contraction
+                                // runs over nseg segments of K - nseg = 2: A B^T + A B2^T; nseg = 3: A B^T + A2 B^T + A B2^T (x = hi + lo
+                                // splits of an f32 operand in fp16 pairs: hi hi + lo hi + hi lo); 0 / 1: the plain product
     int row_shift;              // != 0 (= T, with M = N = ldc = T): row m of every batch matrix is stored m + 1 - T elements further
                                 // (elements falling before the matrix are dropped): the relative-position shift of the reference
                                 // (attention.py:105-113: pad one zero column, reinterpret (T, T+1) as (T+1, T), drop the first row)

@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import hip
-from .runtime import RT, wt, wtg, gbuf, weights_version
+from .runtime import RT, wt, wt_lo, wtg, gbuf, weights_version
 
 _16 = (torch.bfloat16, torch.float16)          # 16-bit activation storage: the fused kernels' domain
 
@@ -158,6 +158,59 @@ def mm_tn_acc(dy, x, gW, group=True, bias=None):
             hip.colsum(dy, bias)
 
 
+# ------------------------------------------------------------------------------------------------ hybrid mode (runtime.set_precision)
+# fp16 stem and module-internal tensors, f32 residual stream: an f32 activation is handed to a Linear layer as an fp16 pair (hip.Pair,
+# written by the LayerNorm in front of it), a weight as its (hi, lo) fp16 shadows; hip.gemm_split contracts hi hi + lo hi + hi lo.
+_F32 = torch.float32
+_H_DLN32 = os.environ.get("SARSSL_HYBRID_DLN32", "1") != "0"    # branch gradients entering the LayerNorm backward in f32 (0: bf16)
+
+
+def wpair(p, view=None):
+    """(hi, lo) fp16 shadows of parameter ``p`` (optionally viewed as ``view``)."""
+    hi, lo = wt(p), wt_lo(p)
+    return (hi.view(view), lo.view(view)) if view is not None else (hi, lo)
+
+
+def mm_nt_h(x, w, out_dtype, **kw):
+    """x [M,K] (hip.Pair or an fp16 tensor) @ (w_hi + w_lo)[N,K]^T -> [M,N] of ``out_dtype`` (fp16 | f32): nn.Linear forward, hybrid mode."""
+    M, K = x.shape
+    return hip.gemm_split(x, w[0], w[1], M=M, N=w[0].shape[0], K=K, out_dtype=out_dtype, **kw)
+
+
+def _as_stream(x):
+    """x as an f32 stream tensor (module-level entry points hand over whatever dtype their caller used)."""
+    return x if x.dtype == _F32 else hip.cast(x.contiguous(), _F32)
+
+
+def _ln_bwd_hd(dln, x, ln_mod, stats, dy, drop, want16):
+    """LayerNorm backward of the hybrid mode: f32 stream gradient out; with ``want16`` also the bf16 operand of the next module of the
+    backward chain - with its dropout backward applied when ``drop`` = (p, seed, gscale) is given, else the plain copy (the module
+    multiplies a replayed tensor mask itself) -> (dx, dx16), or dx alone without ``want16``."""
+    r = hip.layernorm_bwd_stream(dln, x, ln_mod.weight.data, stats, resid=dy, dgamma=gbuf(ln_mod.weight), dbeta=gbuf(ln_mod.bias),
+                                 drop=drop if want16 else None, copy16=want16 and drop is None)
+    if isinstance(r, tuple):
+        r[1]._dropped = drop is not None
+    return r
+
+
+def _ln_bwd_h(dln, x, ln_mod, stats, dy, saved, next_kind, want16):
+    return _ln_bwd_hd(dln, x, ln_mod, stats, dy, _next_drop(next_kind, saved) if want16 else None, want16)
+
+
+def _grad16(dy, dy16, p, seed, gscale=1.0):
+    """bf16 matrix-core operand of a module's backward pass from its incoming stream gradient: ``dy16`` when the previous LayerNorm backward
+    already wrote it (with this module's dropout backward applied when dy16._dropped), else formed here."""
+    if dy16 is not None:
+        if getattr(dy16, "_dropped", False) or torch.is_tensor(seed) or (p <= 0 and gscale == 1.0):
+            return dy16
+        return hip.act_bwd(dy16, None, 0, p_drop=p, seed=seed, gscale=gscale)
+    own = dy.dtype != torch.bfloat16              # (module-level entry points hand the gradient over in bf16 already)
+    d16 = hip.cast(dy.contiguous(), torch.bfloat16) if own else dy.contiguous()
+    if torch.is_tensor(seed) or (p <= 0 and gscale == 1.0):
+        return d16
+    return hip.act_bwd(d16, None, 0, p_drop=p, seed=seed, gscale=gscale, out=d16 if own else None)
+
+
 def to_rt(x):
     return x if x.dtype == RT.dtype else hip.cast(x.contiguous(), RT.dtype)
 
@@ -214,6 +267,14 @@ def _patch_w(conv, F, grad=False):
     return _cached(conv, "patchw_g" if (grad and dtype != RT.dtype) else "patchw", build)
 
 
+def _patch_w_pair(conv, F):
+    """(hi, lo) fp16 pair of the [d][f*4+c] patch matrix (hybrid mode)."""
+    def build():
+        p = hip.split_pair(hip.patch_w(conv.weight.data.contiguous(), _F32))
+        return p.hi, p.lo
+    return _cached(conv, "patchw_pair", build)
+
+
 def stem_fwd(a0, pe, train, saved):
     """``patch_embed`` (code/model.py:50-64) on channels-last a0 (B,F,T,4) -> [B*T, d]."""
     B, F, T, _ = a0.shape
@@ -244,7 +305,10 @@ def stem_fwd(a0, pe, train, saved):
         y4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])
         aff4 = bn_affine(y4, 4, pe[10], train)
     z4 = hip.cl_affine_act(y4, 4, aff4, RELU).view(B * T, F * 4)
-    e = mm_nt(z4, _patch_w(pe[12], F), fp8=False)
+    if RT.hybrid:          # the stream starts here: f32 result, the weight as its fp16 pair
+        e = mm_nt_h(z4, _patch_w_pair(pe[12], F), _F32)
+    else:
+        e = mm_nt(z4, _patch_w(pe[12], F), fp8=False)
     saved.append((a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
     return e
 
@@ -282,6 +346,8 @@ def patch_bwd(de, pe, saved):
     a0, z4 = saved[-1][0], saved[-1][9]
     B, F, T, _ = a0.shape
     d = de.shape[1]
+    if RT.hybrid and de.dtype == _F32:        # the stream's gradient leaves f32 here: bf16 operand of the two products below
+        de = getattr(de, "_g16", None) if getattr(de, "_g16", None) is not None else hip.cast(de.contiguous(), torch.bfloat16)
     if RT.dtype in _16 and RT.replay is None:   # split-K partials folded and re-laid-out in one pass (nothing zeroed)
         ws, nslice = hip.gemm_tn_partials(de, z4, _wgrad_split(de.shape[0], d, F * 4, False))
         hip.patch_wgrad_accum(ws, gbuf(pe[12].weight), nslice)
@@ -460,8 +526,61 @@ def block_ffns(enc):
     return [blk.sequential[i].module for blk in enc.layers for i in (0, 3)]
 
 
+def _ffn_fwd_h(x, ff, factor, train, saved, out=None):
+    """ffn_fwd in the hybrid mode: x / result f32, LayerNorm output as an fp16 pair, hidden activation and saved pre-activation fp16."""
+    seq = ff.sequential
+    x = _as_stream(x)
+    pre = x.__dict__.pop("_pre_ln", None)
+    p1, p2 = _p(seq[3], train), _p(seq[5], train)
+    if pre is not None and pre[0] is seq[0]:
+        ln, stats = pre[1], pre[2]
+    else:
+        ln, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+    l1, l2 = seq[1].linear, seq[4].linear
+    hpre = torch.empty((x.shape[0], l1.weight.shape[0]), dtype=torch.float16, device=x.device)
+    if _replaying(train) and (p1 > 0 or p2 > 0):          # host-drawn masks in the reference's order: hidden, then output
+        a = mm_nt_h(ln, wpair(l1.weight), torch.float16, bias=l1.bias.data, act=SWISH, preact=hpre)
+        s1 = RT.replay.mask(tuple(a.shape), p1, x.device, a.dtype) if p1 > 0 else 0
+        if p1 > 0:
+            a = a * s1
+        y = mm_nt_h(a, wpair(l2.weight), _F32, bias=l2.bias.data)
+        s2 = RT.replay.mask(tuple(y.shape), p2, x.device, _F32) if p2 > 0 else 0
+        y = torch.add(x, y * s2 if p2 > 0 else y, alpha=factor)
+        if out is not None:
+            out.copy_(y)
+            y = out
+    else:
+        s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
+        a = mm_nt_h(ln, wpair(l1.weight), torch.float16, bias=l1.bias.data, act=SWISH, preact=hpre, p_drop=p1, seed=s1)
+        y = mm_nt_h(a, wpair(l2.weight), _F32, bias=l2.bias.data, p_drop=p2, seed=s2, out_scale=factor, resid=x, ldr=x.stride(0),
+                    res_scale=1.0, out=out, ldc=(out.stride(0) if out is not None else None))
+    saved.append((x, ln.hi, stats, hpre, a, p1, s1, p2, s2, factor))
+    return y
+
+
+def _ffn_bwd_h(dy, ff, saved, dy16=None, next_kind=None, want16=True):
+    """-> (dx f32, dx16) - the stream gradient and its bf16 copy for the next module of the backward chain - or dx alone (want16 False)."""
+    x, ln, stats, hpre, a, p1, s1, p2, s2, factor = saved.pop()
+    seq = ff.sequential
+    l1, l2 = seq[1].linear, seq[4].linear
+    dz2 = _grad16(dy, dy16, p2, s2, factor)
+    if torch.is_tensor(s2):
+        dz2 = dz2 * (s2 * factor).to(dz2.dtype)
+    mm_tn_acc(dz2, a, gbuf(l2.weight), bias=gbuf(l2.bias))
+    if torch.is_tensor(s1):
+        dh = mm_nn(dz2, wtg(l2.weight), aux=hpre, aux_act=SWISH)
+        dh = dh * s1.to(dh.dtype)
+    else:
+        dh = mm_nn(dz2, wtg(l2.weight), aux=hpre, aux_act=SWISH, p_drop=p1, seed=s1)
+    mm_tn_acc(dh, ln, gbuf(l1.weight), bias=gbuf(l1.bias))
+    dln = mm_nn(dh, wtg(l1.weight), out_dtype=_F32 if _H_DLN32 else None)
+    return _ln_bwd_h(dln, x, seq[0], stats, _as_stream(dy), saved, next_kind, want16)
+
+
 def ffn_fwd(x, ff, factor, train, saved, out=None):
     """x + factor * FeedForwardModule(x)  (conformer/feed_forward.py:47-57, Conformer.py:60-67)."""
+    if RT.hybrid:
+        return _ffn_fwd_h(x, ff, factor, train, saved, out=out)
     seq = ff.sequential
     pre = x.__dict__.pop("_pre_ln", None)            # (block_fwd of the previous block already normalised this very tensor for us)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
@@ -530,6 +649,8 @@ def _next_drop(kind, saved):
 
 
 def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
+    if RT.hybrid:
+        return _ffn_bwd_h(dy, ff, saved, dy16=dy_dropped, next_kind=next_kind, want16=next_kind is not None)
     x, ln, stats, hpre, a, p1, s1, p2, s2, factor = saved.pop()
     seq = ff.sequential
     if torch.is_tensor(s1) or torch.is_tensor(s2):        # replayed masks (see ffn_fwd)
@@ -627,6 +748,93 @@ def _qkv_views(att, grad=False):
             torch.as_strided(gw[0], (3 * d, d), (d, 1)), torch.as_strided(gb[0], (3 * d,), (1,)))
 
 
+def _pos_proj_h(mod, T):
+    """_pos_proj in the hybrid mode: the sinusoid table and the weight as fp16 pairs, result fp16 (an attention operand)."""
+    lin = mod.attention.pos_proj.linear
+
+    def build():
+        pe = hip.split_pair(mod.positional_encoding.pe[0, :T].contiguous().float())
+        return mm_nt_h(pe, wpair(lin.weight), torch.float16)
+    return _cached(lin, "posh%d" % T, build)
+
+
+def _qkv_views_lo(att):
+    """[3d, d] view of the q / k / v weights' lo shadows (laid out like the hi shadows, see _qkv_views)."""
+    ws = [wt_lo(l.weight) for l in (att.query_proj.linear, att.key_proj.linear, att.value_proj.linear)]
+    if not _adjacent(ws):
+        return None
+    d = att.d_model
+    return torch.as_strided(ws[0], (3 * d, d), (d, 1))
+
+
+def _mhsa_fwd_h(x, mod, B, T, train, saved):
+    """mhsa_fwd in the hybrid mode: x / result f32; q, k, v, the attention core and its context are the fp16 kernels of the fp16 mode."""
+    att = mod.attention
+    H, dh, d = att.num_heads, att.d_head, att.d_model
+    M = B * T
+    x = _as_stream(x)
+    ln, stats = hip.layernorm_fwd_pair(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps)
+    fused = _qkv_views(att)
+    fused_lo = _qkv_views_lo(att) if fused is not None else None
+    if fused is not None and fused_lo is not None:
+        qkv = mm_nt_h(ln, (fused[0], fused_lo), torch.float16, bias=fused[1])
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    else:
+        q = mm_nt_h(ln, wpair(att.query_proj.linear.weight), torch.float16, bias=att.query_proj.linear.bias.data)
+        k = mm_nt_h(ln, wpair(att.key_proj.linear.weight), torch.float16, bias=att.key_proj.linear.bias.data)
+        v = mm_nt_h(ln, wpair(att.value_proj.linear.weight), torch.float16, bias=att.value_proj.linear.bias.data)
+    ldk = k.stride(0)
+    pe = _pe(mod, T)
+    pos = _pos_proj_h(mod, T)
+    nbh = B * H
+    pa = _p(att.dropout, train)
+    sa = RT.next_seed() if pa > 0 else 0
+    scale = 1.0 / math.sqrt(d)
+    replay = _replaying(train) and (pa > 0 or _p(mod.dropout, train) > 0)
+    fused_attn = _FUSED_ATTN and not replay and hip.relpos_attn_supported(T, dh, RT.dtype)
+    in_kernel = fused_attn and _ATTN_POS and hip.relpos_attn_pos_supported(T, dh, RT.dtype)
+    ub, vb = att.u_bias.data.view(-1), att.v_bias.data.view(-1)
+    qu, qv = (q, None) if in_kernel else hip.bias2(q, ub, vb)
+    po = _p(mod.dropout, train)
+    wo = wpair(att.out_proj.linear.weight)
+    if fused_attn:
+        if in_kernel:
+            ctx, lse, bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, biases=(ub, vb))
+        else:
+            bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
+            hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
+                     sC=(H * T * T, T * T), c_row_shift=True)
+            ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)
+        so = RT.next_seed() if po > 0 else 0
+        y = mm_nt_h(ctx, wo, _F32, bias=att.out_proj.linear.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
+        saved.append((x, ln.hi, stats, qu, qv, k, v, pos, pe, bias, lse, pa, sa, ctx, po, so, B, T))
+        return y
+    content = hip.gemm(qu, k, M=T, N=T, K=dh, lda=d, ldb=ldk, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * ldk, dh),
+                       out_dtype=torch.float32, out_shape=(B, H, T, T))
+    pscore = hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh),
+                      out_dtype=torch.float32, out_shape=(B, H, T, T))
+    if replay:
+        p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, 0.0, 0)
+        if pa > 0:
+            sa = RT.replay.mask((B, H, T, T), pa, x.device, RT.dtype)
+            pd = p * sa
+    else:
+        p, pd = hip.softmax_relshift_fwd(content, pscore, scale, RT.dtype, pa, sa)
+    del content, pscore
+    ctx = torch.empty((M, d), dtype=RT.dtype, device=x.device)
+    hip.gemm(pd, v, a_kc=True, b_kc=False, M=T, N=dh, K=T, lda=T, ldb=ldk, nbatch=nbh, batch_inner=H,
+             sA=(H * T * T, T * T), sB=(T * ldk, dh), out=ctx, ldc=d, sC=(T * d, dh))
+    if replay:
+        y = mm_nt_h(ctx, wo, _F32, bias=att.out_proj.linear.bias.data)
+        so = RT.replay.mask(tuple(y.shape), po, x.device, _F32) if po > 0 else 0
+        y = x + (y * so if po > 0 else y)
+    else:
+        so = RT.next_seed() if po > 0 else 0
+        y = mm_nt_h(ctx, wo, _F32, bias=att.out_proj.linear.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
+    saved.append((x, ln.hi, stats, qu, qv, k, v, pos, pe, p, pd, pa, sa, ctx, po, so, B, T))
+    return y
+
+
 def mhsa_fwd(x, mod, B, T, train, saved):
     """x + MultiHeadedSelfAttentionModule(x)  (conformer/attention.py:143-151, 72-113).
 
@@ -638,6 +846,8 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     att = mod.attention
     H, dh, d = att.num_heads, att.d_head, att.d_model
     M = B * T
+    if RT.hybrid:
+        return _mhsa_fwd_h(x, mod, B, T, train, saved)
     fused = _qkv_views(att)
     lin = (_LIN256 and fused is not None and d == 256 and not RT.fp8 and not _replaying(train) and x.stride(1) == 1
            and hip.lin256_supported(M, 3 * d, d, x.dtype))
@@ -722,7 +932,11 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
     M, nbh = B * T, B * H
     dev = x.device
     fused_attn = isinstance(pd, tuple)                                # fused forward saved (bias, (ctx32, lse)) in place of (p, pd)
-    if torch.is_tensor(so):
+    if RT.hybrid:                                          # dy: f32 stream gradient, dy_dropped: its bf16 operand copy
+        dout = _grad16(dy, dy_dropped, po, so)
+        if torch.is_tensor(so):
+            dout = dout * so.to(dout.dtype)
+    elif torch.is_tensor(so):
         dout = dy * so.to(dy.dtype)                        # replayed mask
     elif dy_dropped is not None:
         dout = dy_dropped
@@ -752,7 +966,7 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
                                         biases=(att.u_bias.data.view(-1), att.v_bias.data.view(-1)) if plain_q else None, dq_sum=dq_out)
         return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d,
                               dev, drop=_next_drop(next_kind, saved), dq_out=dq_out if dq_out is not None else dqu,
-                              dq_done=dq_out is not None)
+                              dq_done=dq_out is not None, want16=next_kind is not None)
     if fused_attn:
         dbias = hip.relpos_attn_bwd(qu, k, v, p, pd, dctx, dqu, dk, dv, B, H, T, dh, scale, pa, sa)      # p = bias, pd = (ctx32, lse) here
         dps = hip.relshift_bwd(dbias)                                                        # d (unshifted) pos score
@@ -769,7 +983,7 @@ def mhsa_bwd(dy, mod, saved, dy_dropped=None, next_kind=None):
              sA=(H * T * T, T * T), sB=(T * d, dh), out=dposb, ldc=d, sC=(T * d, dh), precise=RT.precise)
     del dps
     return _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv if fused is not None else None, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev,
-                          drop=_next_drop(next_kind, saved), dq_out=dqkv[:, :d] if fused is not None else dqu)
+                          drop=_next_drop(next_kind, saved), dq_out=dqkv[:, :d] if fused is not None else dqu, want16=next_kind is not None)
 
 
 def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ldg, scale, pa, sa):
@@ -795,7 +1009,7 @@ def _mhsa_bwd_scores(dctx, qu, k, v, p, pd, dqu, dk, dv, B, T, H, dh, d, ldk, ld
 
 
 def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb, fused, B, T, d, dev, drop=None, dq_out=None,
-                   dq_done=False):
+                   dq_done=False, want16=False):
     """Positional-projection, bias and q/k/v-projection gradients + LayerNorm backward (shared by both attention cores)."""
     if dposb.dtype == RT.gdtype:                                     # batch sum straight into the GEMM operand's dtype: one launch
         dpos_rt = hip.colsum_store(dposb.view(dposb.shape[0], T * d)).view(T, d)      # (B rows, or B * ntile partials of the fused backward)
@@ -818,13 +1032,15 @@ def _mhsa_bwd_tail(dy, mod, att, x, ln, stats, pe, dqkv, dqu, dk, dv, dqv, dposb
             # data gradient of the projection + the LayerNorm backward in one tile-resident launch
             return hip.lin256_bwd(dqkv, pk[1][1], d, 3 * d, ln_bwd=(x, mod.layer_norm.weight.data, stats, dy, gbuf(mod.layer_norm.weight),
                                                                      gbuf(mod.layer_norm.bias), drop))
-        dln = mm_nn(dqkv, fused[0])
+        dln = mm_nn(dqkv, fused[0], out_dtype=_F32 if (RT.hybrid and _H_DLN32) else None)
     else:
         for proj, g in ((att.query_proj, dq), (att.key_proj, dk), (att.value_proj, dv)):
             mm_tn_acc(g, ln, gbuf(proj.linear.weight), bias=gbuf(proj.linear.bias))
         dln = mm_nn(dq, wtg(att.query_proj.linear.weight))
         dln = mm_nn(dk, wtg(att.key_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
         dln = mm_nn(dv, wtg(att.value_proj.linear.weight), out=dln, ldc=d, resid=dln, ldr=d, res_scale=1.0)
+    if RT.hybrid:
+        return _ln_bwd_hd(dln, x, mod.layer_norm, stats, _as_stream(dy), drop, want16)
     return hip.layernorm_bwd(dln, x, mod.layer_norm.weight.data, stats, resid=dy, dgamma=gbuf(mod.layer_norm.weight),
                              dbeta=gbuf(mod.layer_norm.bias), drop=drop)
 
@@ -834,9 +1050,16 @@ def convmod_fwd(x, cm, B, T, train, saved):
     seq = cm.sequential
     d = x.shape[1]
     pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
-    lin = (_LIN256 and d == 256 and not RT.fp8 and not _replaying(train) and x.stride(1) == 1 and hip.lin256_supported(x.shape[0], 2 * d, d, x.dtype))
+    hyb = RT.hybrid
+    if hyb:
+        x = _as_stream(x)
+    lin = (_LIN256 and not hyb and d == 256 and not RT.fp8 and not _replaying(train) and x.stride(1) == 1 and hip.lin256_supported(x.shape[0], 2 * d, d, x.dtype))
     pk = _lin256_pack(cm, "pw1", need_bwd=not RT.inference) if lin else None
-    if pk is not None:      # LayerNorm + first pointwise convolution in one tile-resident launch (csrc/lin256.hip)
+    if hyb:                 # f32 stream in / out; the module's inner tensors (h, c, s) are the fp16 tensors of the fp16 mode
+        lnp, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+        ln = lnp.hi
+        h = mm_nt_h(lnp, wpair(pw1.weight, (2 * d, d)), torch.float16, bias=pw1.bias.data)
+    elif pk is not None:      # LayerNorm + first pointwise convolution in one tile-resident launch (csrc/lin256.hip)
         h, ln, stats = hip.lin256_fwd(None, pk[0], pw1.bias.data, 2 * d, d, ln_in=(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps))
     else:
         ln, stats = hip.layernorm_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
@@ -857,9 +1080,12 @@ def convmod_fwd(x, cm, B, T, train, saved):
     s = (s_act if s_act is not None else hip.cl_affine_act(c, d, aff, SWISH)).view(B * T, d)
     po = _p(seq[8], train)
     if _replaying(train) and po > 0:                       # the reference draws this mask on the (B, d, T) conv output
-        y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data)
-        so = RT.replay.mask((B, d, T), po, x.device, RT.dtype, to_layout=lambda m: m.permute(0, 2, 1).reshape(B * T, d))
+        y = mm_nt_h(s, wpair(pw2.weight, (d, d)), _F32, bias=pw2.bias.data) if hyb else mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data)
+        so = RT.replay.mask((B, d, T), po, x.device, y.dtype, to_layout=lambda m: m.permute(0, 2, 1).reshape(B * T, d))
         y = x + y * so
+    elif hyb:
+        so = RT.next_seed() if po > 0 else 0
+        y = mm_nt_h(s, wpair(pw2.weight, (d, d)), _F32, bias=pw2.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
     else:
         so = RT.next_seed() if po > 0 else 0
         y = mm_nt(s, wt(pw2.weight).view(d, d), bias=pw2.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
@@ -872,7 +1098,11 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
     seq = cm.sequential
     d = x.shape[1]
     pw1, dw, bn, pw2 = seq[2].conv, seq[4].conv, seq[5], seq[7].conv
-    if torch.is_tensor(so):
+    if RT.hybrid:
+        dout = _grad16(dy, dy_dropped, po, so)
+        if torch.is_tensor(so):
+            dout = dout * so.to(dout.dtype)
+    elif torch.is_tensor(so):
         dout = dy * so.to(dy.dtype)
     elif dy_dropped is not None:
         dout = dy_dropped
@@ -895,6 +1125,9 @@ def convmod_bwd(dy, cm, saved, dy_dropped=None, next_kind=None):
             and x.stride(1) == 1 and dy.stride(1) == 1 and dh.stride(1) == 1 and hip.lin256_supported(dh.shape[0], d, 2 * d, dh.dtype)):
         return hip.lin256_bwd(dh, pk[1][1], d, 2 * d, ln_bwd=(x, seq[0].weight.data, stats, dy, gbuf(seq[0].weight), gbuf(seq[0].bias),
                                                                _next_drop(next_kind, saved)))
+    if RT.hybrid:
+        dln = mm_nn(dh, wtg(pw1.weight).view(2 * d, d), out_dtype=_F32 if _H_DLN32 else None)
+        return _ln_bwd_h(dln, x, seq[0], stats, _as_stream(dy), saved, next_kind, next_kind is not None)
     dln = mm_nn(dh, wtg(pw1.weight).view(2 * d, d))
     return hip.layernorm_bwd(dln, x, seq[0].weight.data, stats, resid=dy, dgamma=gbuf(seq[0].weight), dbeta=gbuf(seq[0].bias),
                              drop=_next_drop(next_kind, saved))
@@ -923,7 +1156,8 @@ def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None, rows=None):
     x = ffn_fwd(x, seq[3].module, seq[3].module_factor, train, saved)
     if next_blk is not None and out is None and _LN_PAIR:
         nln = next_blk.sequential[0].module.sequential[0]
-        y, stats, z, zstats = hip.layernorm_fwd2(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps)
+        y, stats, z, zstats = (hip.layernorm_fwd2_pair if RT.hybrid else hip.layernorm_fwd2)(
+            x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps)
         # the paired LayerNorm's result travels ON the tensor object it belongs to (round 4 kept it in a process-global dict keyed by the
         # tensor's address: a stale entry could outlive its tensor and match a recycled address - advisor): whoever consumes y as the next
         # block's input finds it, anything else never sees it, and it dies with y
@@ -944,16 +1178,19 @@ def block_bwd(dy, blk, saved):
         # each module's backward starts with the dropout backward of its incoming gradient: the LayerNorm backward that produces
         # that gradient writes the dropped copy as a second output (d = (gradient, dropped gradient) where a mask applies)
         pair = lambda r: r if isinstance(r, tuple) else (r, None)
-        d, dd = pair(hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias),
-                                       drop=_next_drop("ffn", saved)))
+        if RT.hybrid:       # f32 stream gradient (d) + the bf16 operand copy of the module that consumes it next (dd)
+            d, dd = _ln_bwd_h(_as_stream(dy), x, seq[4], stats, None, saved, "ffn", True)
+        else:
+            d, dd = pair(hip.layernorm_bwd(dy, x, seq[4].weight.data, stats, dgamma=gbuf(seq[4].weight), dbeta=gbuf(seq[4].bias),
+                                           drop=_next_drop("ffn", saved)))
         if rows is not None:    # the tail ran on the gathered rows: its input gradient goes back to its frames, zeros elsewhere
-            d = ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind=None)
+            d = pair(ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind=None))[0]
             d, dd = hip.scatter_rows(d, rows[0], rows[1], rows[2]), None
         else:
             d, dd = pair(ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind="conv"))
         d, dd = pair(convmod_bwd(d, seq[2].module, saved, dy_dropped=dd, next_kind="mhsa"))
         d, dd = pair(mhsa_bwd(d, seq[1].module, saved, dy_dropped=dd, next_kind="ffn"))
-        d = ffn_bwd(d, seq[0].module, saved, dy_dropped=dd)
+        d = pair(ffn_bwd(d, seq[0].module, saved, dy_dropped=dd))[0]
     return d
 
 
@@ -984,6 +1221,12 @@ def decoder_fwd(e, dec, saved):
     """EmbedDecoder ['','fc'] (code/model.py:295-301, 321-334): Linear -> ReLU -> Linear.  Stays in bf16 in 'fp8' mode: it produces
     the predicted spectrogram itself, and config 5 names the attention / FFN GEMMs only."""
     l1, l2 = dec.proj[0], dec.proj[2]
+    if RT.hybrid:           # f32 decoder input as an fp16 pair, fp16 hidden layer, f32 prediction
+        ep = e if isinstance(e, hip.Pair) else hip.split_pair(_as_stream(e).contiguous())
+        h = mm_nt_h(ep, wpair(l1.weight), torch.float16, bias=l1.bias.data, act=RELU)
+        pred = mm_nt_h(h, wpair(l2.weight), _F32, bias=l2.bias.data)
+        saved.append((ep.hi, h))
+        return pred
     h = mm_nt(e, wt(l1.weight), fp8=False, bias=l1.bias.data, act=RELU)
     pred = mm_nt(h, wt(l2.weight), fp8=False, bias=l2.bias.data)
     saved.append((e, h))
@@ -997,4 +1240,4 @@ def decoder_bwd(dpred, dec, saved):
         mm_tn_acc(dpred, h, gbuf(l2.weight), bias=gbuf(l2.bias))
         dh = mm_nn(dpred, wtg(l2.weight), fp8=False, aux=h, aux_act=RELU)
         mm_tn_acc(dh, e, gbuf(l1.weight), bias=gbuf(l1.bias))
-        return mm_nn(dh, wtg(l1.weight), fp8=False)
+        return mm_nn(dh, wtg(l1.weight), fp8=False, out_dtype=_F32 if RT.hybrid else None)      # hybrid: the stream's gradient is f32

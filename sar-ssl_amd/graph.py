@@ -149,6 +149,7 @@ class PretrainStepGraph:
         # GradScaler skips such a step too (code/learner.py:105-108); decided on the device, counted in the step state
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
                           zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16, guard=self.out)
+        self.flat.refresh_lo()            # hybrid mode: the weights' fp16 lo shadow follows (a launch of the captured step)
 
     def _exchange_in_graph(self):
         """True when the bucket all-reduces are captured INSIDE the step graph: the library's own exchange (sarssl_allreduce_bucket,
@@ -244,12 +245,12 @@ class PretrainStepGraph:
         cur.wait_stream(cap)
         torch.cuda.synchronize()
         self._plan = seg.plan
-        self._key = (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, net.training)
+        self._key = (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, RT.hybrid, net.training)
 
     # ------------------------------------------------------------------------------------------------ replay
     def matches(self, x=None, pcm=None):
         src = pcm if pcm is not None else x
-        return self._key is None or self._key == (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, self.net.training)
+        return self._key is None or self._key == (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, RT.hybrid, self.net.training)
 
     def step(self, x=None, pcm=None, static=False):
         assert (x is None) != (pcm is None)

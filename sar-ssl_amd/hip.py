@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import c_void_p, c_int, c_long, c_float, c_ulonglong
 
-F32, BF16, I16, F16, MIX16 = 0, 1, 2, 3, 4
+F32, BF16, I16, F16, MIX16, MIXF32 = 0, 1, 2, 3, 4, 5
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.int16: I16, torch.float16: F16}
 _16 = (torch.bfloat16, torch.float16)
 
@@ -28,11 +28,19 @@ def dt_ga(g, a):
         return _DT[g.dtype]
     if g.dtype == torch.bfloat16 and a.dtype == torch.float16:
         return MIX16
+    if g.dtype == torch.bfloat16 and a.dtype == torch.float32:      # hybrid mode: bf16 gradient next to the f32 prediction / stream
+        return MIXF32
     raise _lib.SarsslHipError("unsupported gradient / saved-activation dtype pair (%s, %s)" % (g.dtype, a.dtype))
 
 
+_hybrid = False        # runtime.set_precision('hybrid'): branch gradients are bf16 also next to an f32 tensor (the f32 prediction)
+
+
 def gdtype_of(a_dtype):
-    """Gradient dtype that goes with activations of ``a_dtype``: bf16 for fp16 activations (no loss scaling needed), else the same."""
+    """Gradient dtype that goes with activations of ``a_dtype``: bf16 for fp16 activations (no loss scaling needed), else the same
+    (hybrid mode: bf16 next to the f32 prediction as well - the loss gradient is a matrix-core operand)."""
+    if _hybrid and a_dtype == torch.float32:
+        return torch.bfloat16
     return torch.bfloat16 if a_dtype == torch.float16 else a_dtype
 
 
@@ -209,6 +217,112 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
         if len(_splitk_batch) == 32:
             splitk_flush()
     return out
+
+
+# ---- hybrid numeric mode (csrc/hybrid.hip, sarssl_gemm_split): f32 tensors as fp16 pairs ------------------------------------------------
+class Pair:
+    """An f32 tensor [M, d] given as two fp16 tensors, hi = fp16(x) and lo = fp16(x - hi) (22 significant bits): the form in which the
+    hybrid mode's f32 activations enter the matrix cores (gemm_split).  ``hi`` alone is the fp16 rounding of x - what the backward pass
+    keeps as the weight-gradient operand."""
+    __slots__ = ("hi", "lo", "__dict__")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    shape = property(lambda self: self.hi.shape)
+    device = property(lambda self: self.hi.device)
+    dtype = torch.float32
+
+    def float(self):
+        return self.hi.float() + self.lo.float()
+
+
+def gemm_split(A, B, B_lo, *, M, N, K, out=None, out_dtype=None, ldc=None, out_scale=1.0, bias=None, act=0, resid=None, ldr=0, res_scale=1.0,
+               preact=None, p_drop=0.0, seed=0):
+    """C = epilogue(A B^T + A B_lo^T [+ A_lo B^T]) - nn.Linear forward of the hybrid mode.  A: Pair (f32 activation) or an fp16 tensor
+    [M, K]; B, B_lo: fp16 [N, K] (the weight's hi / lo shadows); C / resid / preact: fp16 or f32."""
+    pair = isinstance(A, Pair)
+    Ah, Al = (A.hi, A.lo) if pair else (A, None)
+    _need_cuda(Ah, Al, B, B_lo, out, bias, resid, preact)
+    assert Ah.dtype == torch.float16 and B.dtype == torch.float16 and (B_lo is None or (B_lo.dtype == torch.float16 and B_lo.stride(0) == B.stride(0)))
+    assert Ah.stride(1) == 1 and B.stride(1) == 1 and (Al is None or Al.stride(0) == Ah.stride(0))
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=Ah.device)
+    if ldc is None:
+        ldc = out.stride(0)
+    assert out.dtype in (torch.float16, torch.float32) and (resid is None or resid.dtype == out.dtype) and (preact is None or preact.dtype == out.dtype)
+    with _Timed("gemm_split[%d,%d,%d x%d %s]" % (M, N, K, 1 + (Al is not None) + (B_lo is not None), str(out.dtype)[6:]) if _prof_shapes and _prof is not None else None):
+        _lib.call("sarssl_gemm_split", _p(Ah), _p(Al), _p(B), _p(B_lo), _p(out), c_int(dt(out)), c_int(M), c_int(N), c_int(K),
+                  c_long(Ah.stride(0)), c_long(B.stride(0)), c_long(ldc), c_float(out_scale), _p(bias), c_int(act), _p(resid), c_long(ldr),
+                  c_float(res_scale), _p(preact), c_float(p_drop), c_ulonglong(seed), _stream())
+    return out
+
+
+def split_pair(src, want_hi=True, hi=None, lo=None):
+    """src (f32 | fp16 | bf16, contiguous) -> Pair(hi = fp16(src), lo = fp16(src - hi)); want_hi False: the lo part only (-> tensor)."""
+    _need_cuda(src, hi, lo)
+    assert src.is_contiguous() and src.numel() % 4 == 0
+    if lo is None:
+        lo = torch.empty(src.shape, dtype=torch.float16, device=src.device)
+    if want_hi and hi is None:
+        hi = torch.empty(src.shape, dtype=torch.float16, device=src.device)
+    _lib.call("sarssl_split_pair", _p(src), c_int(dt(src)), c_long(src.numel()), _p(hi) if want_hi else c_void_p(0), _p(lo), _stream())
+    return Pair(hi, lo) if want_hi else lo
+
+
+def layernorm_fwd_pair(x2d, gamma, beta, eps=1e-5, save=True, want32=False):
+    """LayerNorm of f32 rows -> (Pair, stats[, y32])."""
+    M, d = x2d.shape
+    assert x2d.dtype == torch.float32
+    hi = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+    lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+    y32 = torch.empty((M, d), dtype=torch.float32, device=x2d.device) if want32 else None
+    stats = torch.empty((2, M), dtype=torch.float32, device=x2d.device) if save else None
+    _lib.call("sarssl_layernorm_fwd_pair", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d), _p(gamma), _p(beta), c_float(eps), _p(hi), _p(lo),
+              c_long(d), _p(y32), c_long(d), _p(stats[0]) if save else c_void_p(0), _p(stats[1]) if save else c_void_p(0), _stream())
+    return (Pair(hi, lo), stats, y32) if want32 else (Pair(hi, lo), stats)
+
+
+def layernorm_fwd2_pair(x2d, ga, ba, epsa, gb, bb, epsb, out=None):
+    """y = LN_a(x) (f32), z = LN_b(y) (Pair) in one launch -> (y, stats_a, z, stats_b)."""
+    M, d = x2d.shape
+    assert x2d.dtype == torch.float32
+    if out is None:
+        out = torch.empty((M, d), dtype=torch.float32, device=x2d.device)
+    hi = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+    lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+    sa = torch.empty((2, M), dtype=torch.float32, device=x2d.device)
+    sb = torch.empty((2, M), dtype=torch.float32, device=x2d.device)
+    _lib.call("sarssl_layernorm_fwd2_pair", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d), _p(ga), _p(ba), c_float(epsa), _p(out),
+              c_long(out.stride(0)), _p(sa[0]), _p(sa[1]), _p(gb), _p(bb), c_float(epsb), _p(hi), _p(lo), c_long(d), _p(sb[0]), _p(sb[1]), _stream())
+    return out, sa, Pair(hi, lo), sb
+
+
+def layernorm_bwd_stream(dy2d, x2d, gamma, stats, resid=None, dgamma=None, dbeta=None, out=None, drop=None, copy16=False):
+    """LayerNorm backward on the f32 stream (x, resid, result f32; dy bf16 or f32).  drop = (p, seed, gscale) / copy16: also returns the
+    bf16 tensor out * dropout_mask * gscale (copy16: p = 0, gscale = 1 - the plain bf16 copy) -> (out, out16)."""
+    M, d = x2d.shape
+    assert x2d.dtype == torch.float32 and dy2d.dtype in (torch.bfloat16, torch.float32) and (resid is None or resid.dtype == torch.float32)
+    if out is None:
+        out = torch.empty((M, d), dtype=torch.float32, device=x2d.device)
+    part = None
+    if dgamma is not None:
+        fn = _lib.lib().sarssl_layernorm_bwd_workspace_bytes
+        fn.restype = c_long
+        if _ln_batch is not None:
+            part = torch.empty((fn(c_long(M), c_int(d)) // 4,), dtype=torch.float32, device=x2d.device)
+            _ln_batch.append((part, int(_lib.lib().sarssl_layernorm_bwd_nparts(c_long(M))), d, dgamma, dbeta))
+            dgamma = dbeta = None
+        else:
+            part = workspace(fn(c_long(M), c_int(d)), x2d.device, "ln_part")
+    out2 = None
+    p, seed, gscale = drop if drop is not None else (0.0, 0, 1.0)
+    if drop is not None or copy16:
+        out2 = torch.empty((M, d), dtype=torch.bfloat16, device=x2d.device)
+    _lib.call("sarssl_layernorm_bwd_stream", _p(dy2d), c_int(dt(dy2d)), c_long(dy2d.stride(0)), _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d),
+              _p(gamma), _p(stats[0]), _p(stats[1]), _p(resid), c_long(resid.stride(0) if resid is not None else 0), _p(out), c_long(out.stride(0)),
+              _p(dgamma), _p(dbeta), _p(part), _p(out2), c_float(p), c_ulonglong(seed), c_float(gscale), _stream())
+    return (out, out2) if out2 is not None else out
 
 
 # ---- fused feed-forward module (csrc/ffn2.hip) ------------------------------------------------------------------------------------

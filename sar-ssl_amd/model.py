@@ -157,7 +157,7 @@ class _PretrainFn(torch.autograd.Function):
         compact = engine._DEC_MASKED and not full_once and not RT.inference and RT.dtype in engine._16 and RT.replay is None
         tail = compact and engine._TAIL_MASKED and net._side_stream(x.device) is not None
         nrow = B * idx_i32.shape[1] if tail else B * T
-        ecat = torch.empty((nrow, ds + dt_), dtype=RT.dtype, device=x.device)
+        ecat = torch.empty((nrow, ds + dt_), dtype=torch.float32 if RT.hybrid else RT.dtype, device=x.device)   # (hybrid: the f32 stream)
         # The two encoders are independent until the decoder: run them on two HIP streams so one encoder's HBM-bound passes
         # (BatchNorm statistics / backward, LayerNorm, ...) overlap the other's MFMA-bound convolutions and GEMMs.
         saved_spat = []

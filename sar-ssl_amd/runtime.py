@@ -29,6 +29,7 @@ class _RT:
         return hip.gdtype_of(self.dtype)
 
     fp8 = False
+    hybrid = False         # 'hybrid' mode: dtype = fp16 (CNN stem, module-internal tensors), f32 residual stream in the Conformer / decoder
     inference = False      # set while a forward runs that no backward will follow (no_grad / frozen): skips backward-only outputs
     replay = None          # DropoutReplay: masks drawn on the host in the reference's order (parity tests only)
     _seed = 0x5A25_5151_0000_0000
@@ -72,7 +73,14 @@ def set_precision(mode):
     """'bf16' (fast path), 'fp32' (split-bf16 precise path) or 'fp8' (bf16 storage; the Linear / pointwise-conv forward and
     input-gradient GEMMs of the Conformer blocks - FFN, q/k/v and output projections, conv-module pointwise convs - on the OCP-e4m3
     block-scaled MFMA with per-tensor scales chosen on the device: BASELINE.json config 5; everything else as 'bf16')."""
-    if mode in ("fp16", torch.float16):
+    RT.hybrid = hip._hybrid = False
+    if mode == "hybrid":
+        # fp16 stem / fp16 module-internal tensors and bf16 gradients as in 'fp16'; the tensors that carry values from layer to layer in
+        # the Conformer blocks and the decoder (residual stream, LayerNorm outputs, prediction) and the stream's gradient are f32; f32
+        # activations and the weights enter the forward products as fp16 pairs (hi hi + lo hi + hi lo: hip.gemm_split)
+        RT.dtype, RT.precise, RT.fp8, RT.hybrid = torch.float16, False, False, True
+        hip._hybrid = True
+    elif mode in ("fp16", torch.float16):
         RT.dtype, RT.precise, RT.fp8 = torch.float16, False, False
     elif mode in ("bf16", torch.bfloat16):
         RT.dtype, RT.precise, RT.fp8 = torch.bfloat16, False, False
@@ -86,10 +94,12 @@ def set_precision(mode):
         # of the three split passes of 'fp32'
         RT.dtype, RT.precise, RT.fp8 = torch.float32, False, False
     else:
-        raise ValueError("precision must be 'fp16', 'bf16', 'fp32', 'fp32_1pass' or 'fp8'")
+        raise ValueError("precision must be 'hybrid', 'fp16', 'bf16', 'fp32', 'fp32_1pass' or 'fp8'")
 
 
 def get_precision():
+    if RT.hybrid:
+        return "hybrid"
     if RT.dtype == torch.float16:
         return "fp16"
     return "fp8" if RT.fp8 else ("bf16" if RT.dtype == torch.bfloat16 else ("fp32" if RT.precise else "fp32_1pass"))
@@ -125,6 +135,21 @@ def wt(p):
     if RT.dtype == torch.float32:
         return p.data
     return _wt16(p, RT.dtype)
+
+
+def wt_lo(p):
+    """fp16 lo part of parameter ``p`` (fp16(p - fp16(p))): with ``wt(p)`` the pair a hybrid-mode forward product contracts against."""
+    flat = getattr(p, "_flat", None)
+    if flat is not None:
+        if not flat._fresh:
+            flat.ensure_shadow()
+        flat.ensure_lo()
+        return p._wl16
+    cache = getattr(p, "_wl16_cache", None)
+    if cache is None or cache[0] != p._version:
+        p._wl16_cache = (p._version, hip.split_pair(p.data.contiguous(), want_hi=False))
+        bump_version()
+    return p._wl16_cache[1]
 
 
 def wtg(p):
@@ -231,7 +256,24 @@ class FlatParams:
                 self.group_spans[g] = (min(a[0], o), max(a[1], end)) if a else (o, end)
         self._synced = None
         self._fresh = False
+        self.wl16 = None                       # fp16 lo shadow (hybrid mode): allocated on first use (ensure_lo)
+        self._lo_synced = None
         self.ensure_shadow()
+
+    def ensure_lo(self):
+        """The weights' fp16 lo parts (hybrid mode): allocated on first use; rewritten by ``refresh_lo`` behind every optimiser step and
+        here whenever a parameter was modified through torch."""
+        if self.wl16 is None:
+            self.wl16 = torch.zeros(self.numel, dtype=torch.float16, device=self.flat.device)
+            for p, o in zip(self.params, self.offsets):
+                p._wl16 = self.wl16[o:o + p.numel()].view(p.shape)
+        if self._lo_synced != self._synced:
+            self.refresh_lo()
+
+    def refresh_lo(self):
+        if self.wl16 is not None and self.on_gpu:
+            hip.split_pair(self.flat, want_hi=False, lo=self.wl16)
+        self._lo_synced = self._synced
 
     def _sig(self):
         return tuple(p._version for p in self.params)
@@ -244,6 +286,8 @@ class FlatParams:
                 hip.cast(self.flat, torch.bfloat16, out=self.w16)
                 hip.cast(self.flat, torch.float16, out=self.wh16)
             self._synced = sig
+            if self.wl16 is not None:
+                self.refresh_lo()
             bump_version()
         self._fresh = True
 
@@ -308,4 +352,5 @@ class FusedAdam:
         hip.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.lr, self.step_count,
                       gscale=grad_scale, betas=self.betas, eps=self.eps, ph16=self.flat.wh16,
                       guard=guard.detach().reshape(-1) if guard is not None else None, nskipped=self.nskipped if guard is not None else None)
+        self.flat.refresh_lo()                 # (hybrid mode: the lo shadow follows the parameters; nothing to do otherwise)
         bump_version()

@@ -43,7 +43,9 @@ def _set_dropout(m, p):
 # batch means of bf16-rounded tensors; the full-size bf16 test below is the meaningful fast-path gate.
 TOL = {"fp32": dict(y=2e-4, dx=5e-4, g=1e-3), "bf16": dict(y=3e-2, dx=1.2e-1, g=6e-1, gall=1e-1),
        # fp16 forward / bf16 backward: outputs 8x closer than bf16's, gradients bf16-class
-       "fp16": dict(y=4e-3, dx=1.2e-1, g=6e-1, gall=1e-1)}
+       "fp16": dict(y=4e-3, dx=1.2e-1, g=6e-1, gall=1e-1),
+       # hybrid: f32 stream, fp16-pair products - outputs in the f32 class behind the fp16 stem, gradients between the two
+       "hybrid": dict(y=4e-3, dx=1.2e-1, g=6e-1, gall=1e-1)}
 
 
 def _run_block(name, build, seed, prec, call=None, check_dx=True, residual=False):
@@ -87,7 +89,7 @@ def _run_block(name, build, seed, prec, call=None, check_dx=True, residual=False
         runtime.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_ffn_module(prec):
     from sar_ssl_amd.common.conformer.feed_forward import FeedForwardModule
     _run_block("ffn", lambda: FeedForwardModule(encoder_dim=32, expansion_factor=4, dropout_p=0.1), 21, prec,
@@ -96,7 +98,7 @@ def test_ffn_module(prec):
         _run_block("ffn", lambda: FeedForwardModule(encoder_dim=32, expansion_factor=4, dropout_p=0.1), 21, prec)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_mhsa_module(prec):
     from sar_ssl_amd.common.conformer.attention import MultiHeadedSelfAttentionModule
     _run_block("mhsa", lambda: MultiHeadedSelfAttentionModule(d_model=32, num_heads=4, dropout_p=0.1), 22, prec,
@@ -105,7 +107,7 @@ def test_mhsa_module(prec):
         _run_block("mhsa", lambda: MultiHeadedSelfAttentionModule(d_model=32, num_heads=4, dropout_p=0.1), 22, prec)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_conv_module(prec):
     from sar_ssl_amd.common.conformer.convolution import ConformerConvModule
     mk = lambda: ConformerConvModule(in_channels=32, kernel_size=31, expansion_factor=2, dropout_p=0.1)
@@ -114,7 +116,7 @@ def test_conv_module(prec):
         _run_block("convmod", mk, 23, prec)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_conformer_block_and_encoder(prec):
     from sar_ssl_amd.common.Conformer import ConformerBlock, ConformerEncoder
     _run_block("block", lambda: ConformerBlock(encoder_dim=32, num_attention_heads=4), 24, prec)
@@ -123,7 +125,7 @@ def test_conformer_block_and_encoder(prec):
                call=lambda m, x: m(x, False))
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_embed_encoder_decoder(prec):
     from sar_ssl_amd import model
     _run_block("embed_encoder", lambda: model.EmbedEncoder(sig_shape=[16, 8, 2, 2], patch_shape=(16, 1), dembed=32,
@@ -181,7 +183,7 @@ def _full_tol(prec):
     return dict(loss=g["loss"], pred=g["per_bin_max"], pred_rms=g["per_bin_rms"], grad=g["grad_norm"], bn=g["bn_running"])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_1pass", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_1pass", "fp16", "hybrid"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_fullsize_forward_backward(mode, prec):
     """north_star gate: loss and per-bin outputs within 1e-3 relative of the reference CPU path (fp32 mode); the bf16 fast path is
