@@ -219,7 +219,7 @@ def product_loop(dev, batch, precision, nseg=2048, epochs=2):
         net = model.SARSSL(sig_shape=(256, 256, 2, 2), pretrain=True, device=dev)
         lrn = L.STFTLearner(net, win_len=512, win_shift_ratio=0.5, nfft=512, fre_used_ratio=1, fs=16000, task=None, ch_mode="M")
         lrn.cuda()
-        if precision in ("fp16", "bf16", "fp8"):
+        if precision in ("fp16", "hybrid", "bf16", "fp8"):
             lrn.amp()
         runtime.set_precision(precision)
         random.seed(99)
@@ -277,7 +277,7 @@ def main():
     # (round 5: "fp8" is no longer a bench choice - the e4m3 Linear GEMMs are 1.2-1.65x faster than the bf16 kernels, the just-in-time
     #  quantisation makes the step 7-12 % SLOWER and the ceiling with fused quantisation is +4-6 % (NOTES.md 4.5): the mode stays in
     #  runtime.set_precision as a parity-tested experiment, tests/test_gpu_fp8.py, and is not advertised as a configuration to time)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "fp32_1pass"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "hybrid", "bf16", "fp32", "fp32_1pass"])
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-product-loop", action="store_true")
@@ -522,7 +522,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"fp16": "fp16 forward / bf16 backward (16-bit MFMA operands, f32 accumulate)", "bf16": "bf16", "fp32": "f32(split-bf16 MFMA)", "fp32_1pass": "f32 storage, single-pass bf16 MFMA",
+            "dtype": {"fp16": "fp16 forward / bf16 backward (16-bit MFMA operands, f32 accumulate)",
+                      "hybrid": "fp16 stem + f32 residual stream (fp16-pair MFMA operands: hi hi + lo hi + hi lo), bf16 backward", "bf16": "bf16", "fp32": "f32(split-bf16 MFMA)", "fp32_1pass": "f32 storage, single-pass bf16 MFMA",
                       "fp8": "bf16 storage, fp8(e4m3) Linear GEMMs"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "SAR-SSL MC-Conformer cross-channel-reconstruction pretrain step (STFT+mask+fwd+bwd+Adam), "

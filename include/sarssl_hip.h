@@ -117,6 +117,13 @@ int sarssl_layernorm_fwd2_pair(const float* x, long ldx, long M, int d, const fl
 int sarssl_layernorm_bwd_stream(const void* dy, int dy_dtype, long lddy, const float* x, long ldx, long M, int d, const float* gamma,
                                 const float* mean, const float* rstd, const float* resid, long ldr, float* dx, long lddx, float* dgamma,
                                 float* dbeta, float* partial, void* dx2, float p_drop, unsigned long long seed, float gscale, void* stream);
+/*      the stem's 64 -> 4 convolution with its f32 result as a pair (y4_hi = what sarssl_stem_c4_fwd stores, y4_lo the remainder;
+ *      stats8 = BatchNorm(4) sums of the pair's value, may be NULL), and BatchNorm(4) affine + ReLU on the pair -> pair: the f32 operand
+ *      of the frame-patch product (code/model.py:60-63). */
+int sarssl_stem_c4_fwd_pair(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4_hi,
+                            void* y4_lo, double* stats8, int dtype, void* stream);
+int sarssl_cl_affine_act_pair(const void* x_hi, const void* x_lo, long n, int C, const float* scale, const float* shift, int act, void* z_hi,
+                              void* z_lo, void* stream);
 /*      src (f32 | fp16 | bf16; n % 4 == 0) -> hi = fp16(src) (may be NULL), lo = fp16(src - hi): the weights' lo shadow, stem outputs. */
 int sarssl_split_pair(const void* src, int src_dtype, long n, void* hi, void* lo, void* stream);
 

@@ -320,7 +320,31 @@ __global__ void split_pair_kernel(const TS* __restrict__ s, long n4, f16* __rest
     }
 }
 
+// ---- channels-last per-channel affine + activation on a pair: z = act(scale[c] * (hi + lo) + shift[c]) -> pair (the stem's BatchNorm(4)
+// + ReLU in front of the frame-patch product, code/model.py:60-62; act 1 = relu, 2 = swish).  C % 4 == 0 or C == 4.
+__global__ void cl_affine_act_pair_kernel(const f16* __restrict__ xhi, const f16* __restrict__ xlo, long n4, int C,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                          f16* __restrict__ zhi, f16* __restrict__ zlo) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 a = ld4(xhi + i * 4), b = ld4(xlo + i * 4);
+        const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+        float4 z = make_float4(fmaf(a.x + b.x, sc.x, sh.x), fmaf(a.y + b.y, sc.y, sh.y), fmaf(a.z + b.z, sc.z, sh.z), fmaf(a.w + b.w, sc.w, sh.w));
+        if (act == 1) z = make_float4(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f));
+        else if (act == 2) z = make_float4(z.x * sigmoidf_(z.x), z.y * sigmoidf_(z.y), z.z * sigmoidf_(z.z), z.w * sigmoidf_(z.w));
+        st4_pair(zhi + i * 4, zlo + i * 4, z);
+    }
+}
+
 // ================================================================================================ C ABI
+extern "C" int sarssl_cl_affine_act_pair(const void* x_hi, const void* x_lo, long n, int C, const float* scale, const float* shift, int act,
+                                         void* z_hi, void* z_lo, void* stream) {
+    SARSSL_REQUIRE(n > 0 && C > 0 && (C & 3) == 0 && n % C == 0 && x_hi && x_lo && z_hi && z_lo, "sarssl_cl_affine_act_pair");
+    cl_affine_act_pair_kernel<<<nblocks_for(n / 4, 256, 8192), 256, 0, ST>>>((const f16*)x_hi, (const f16*)x_lo, n / 4, C, scale, shift, act,
+                                                                             (f16*)z_hi, (f16*)z_lo);
+    SARSSL_CHECK_LAUNCH("cl_affine_act_pair_kernel");
+    return 0;
+}
 extern "C" int sarssl_layernorm_fwd_pair(const float* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps,
                                          void* y_hi, void* y_lo, long ldy, float* y32, long ldy32, float* mean, float* rstd, void* stream) {
     SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy32 & 3) == 0 && y_hi && y_lo,

@@ -380,7 +380,9 @@ __global__ void stem_c1_bwd_finalize_kernel(const double* __restrict__ red, long
 template <typename T, int U>
 __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __restrict__ W4, const float* __restrict__ scale,
                                    const float* __restrict__ shift, int nb, int F, int Tn, T* __restrict__ y4,
-                                   double* __restrict__ stats = nullptr) {
+                                   double* __restrict__ stats = nullptr, T* __restrict__ y4lo = nullptr) {
+    // y4lo (hybrid mode, sarssl_stem_c4_fwd_pair): the f32 result leaves as a pair - y4 = T(o), y4lo = T(o - y4); the statistics are
+    // those of the pair's value
     const int cg = threadIdx.x & 7;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};      // stats: sum / sum of squares of the STORED y4 (BatchNorm(4) statistics)
     float w[4][8], sc[8], sh[8];
@@ -414,10 +416,16 @@ __global__ void stem_c4_fwd_kernel(const T* __restrict__ y3, const float* __rest
         }
         if (cg == 0) {
             st4(y4 + ((((long)b * Tn + t) * F + f) * 4), make_float4(o[0], o[1], o[2], o[3]));
+            float lo[4] = {0.f, 0.f, 0.f, 0.f};
+            if (y4lo) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lo[c] = o[c] - round_as<T>(o[c]);
+                st4(y4lo + ((((long)b * Tn + t) * F + f) * 4), make_float4(lo[0], lo[1], lo[2], lo[3]));
+            }
             if (stats) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float r = round_as<T>(o[c]);
+                    const float r = y4lo ? round_as<T>(o[c]) + round_as<T>(lo[c]) : round_as<T>(o[c]);
                     ssum[c] += r; ssq[c] = fmaf(r, r, ssq[c]);
                 }
             }
@@ -1281,17 +1289,17 @@ extern "C" int sarssl_stem_c1_stats_affine(const void* a0, long npix, const floa
 // (8 bins x 4U frames) items, U loads in flight per thread; 2048 workgroups = one resident round at B = 64 (sweep 1024 / 2048 / 4096 /
 // 8192 with U = 8: 125 / 121 / 126 / 141 us); frame counts that are no multiple of 16 (or bin counts of 8) take the pixel-order loop
 static int stem_c4_fwd_launch(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn, void* y4,
-                              double* stats8, int dtype, void* stream) {
+                              double* stats8, int dtype, void* stream, void* y4lo = nullptr) {
     SARSSL_REQUIRE(nb > 0 && F > 0 && Tn > 0 && (long)nb * F * Tn < (1L << 31), "sarssl_stem_c4_fwd");
     static const int cap = grid_cap("SARSSL_GRID_C4F", 2048);
     const int u = (F % 8 == 0) ? (Tn % 32 == 0 ? 8 : (Tn % 16 == 0 ? 4 : 0)) : 0;
     if (u == 0) {
         const int nblk = nblocks_for((long)nb * F * Tn * 8, 256, 8192);
-        DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 0><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8)));
+        DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 0><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8, (T*)y4lo)));
     } else {
         const int nblk = nblocks_for((long)nb * (F / 8) * (Tn / (4 * u)), 1, cap);
-        if (u == 8) { DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 8><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8))); }
-        else { DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 4><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8))); }
+        if (u == 8) { DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 8><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8, (T*)y4lo))); }
+        else { DISPATCH_T(dtype, (stem_c4_fwd_kernel<T, 4><<<nblk, 256, 0, ST>>>((const T*)y3, W4, scale, shift, nb, F, Tn, (T*)y4, stats8, (T*)y4lo))); }
     }
     SARSSL_CHECK_LAUNCH("stem_c4_fwd_kernel");
     return 0;
@@ -1307,6 +1315,15 @@ extern "C" int sarssl_stem_c4_fwd_stats(const void* y3, const float* W4, const f
     SARSSL_REQUIRE(stats8 != nullptr, "sarssl_stem_c4_fwd_stats");
     if (SARSSL_ZERO(stats8, 8 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
     return stem_c4_fwd_launch(y3, W4, scale, shift, nb, F, Tn, y4, stats8, dtype, stream);
+}
+
+// Hybrid mode: the f32 result as a pair of `dtype` tensors (y4_hi = T(o), y4_lo = T(o - y4_hi)); stats8 (may be null) = the sums of the
+// pair's value.  y4_hi is exactly what sarssl_stem_c4_fwd stores - the backward kernels read it unchanged.
+extern "C" int sarssl_stem_c4_fwd_pair(const void* y3, const float* W4, const float* scale, const float* shift, int nb, int F, int Tn,
+                                       void* y4_hi, void* y4_lo, double* stats8, int dtype, void* stream) {
+    SARSSL_REQUIRE(y4_lo != nullptr && (dtype == SARSSL_F16 || dtype == SARSSL_BF16), "sarssl_stem_c4_fwd_pair");
+    if (stats8 && SARSSL_ZERO(stats8, 8 * sizeof(double), ST) != hipSuccess) { sarssl_set_error("memset"); return -2; }
+    return stem_c4_fwd_launch(y3, W4, scale, shift, nb, F, Tn, y4_hi, stats8, dtype, stream, y4_lo);
 }
 
 // red: f64[384] (zeroed here): [0,256) dW4[c][ci], [256,320) s1, [320,384) s2

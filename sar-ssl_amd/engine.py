@@ -162,6 +162,9 @@ def mm_tn_acc(dy, x, gW, group=True, bias=None):
 # fp16 stem and module-internal tensors, f32 residual stream: an f32 activation is handed to a Linear layer as an fp16 pair (hip.Pair,
 # written by the LayerNorm in front of it), a weight as its (hi, lo) fp16 shadows; hip.gemm_split contracts hi hi + lo hi + hi lo.
 _F32 = torch.float32
+_H_STEM4 = os.environ.get("SARSSL_HYBRID_STEM4", "1") != "0"    # the stem's 4-channel tensors (64 -> 4 result, BatchNorm(4) + ReLU of it) as pairs (0: fp16)
+_H_CTX = os.environ.get("SARSSL_HYBRID_CTX", "1") != "0"        # the attention context enters the output projection as a pair (0: fp16)
+_H_FFN2_BWD = os.environ.get("SARSSL_HYBRID_FFN2_BWD", "1") != "0"   # the feed-forward module's data gradients in the fused launch (d = 256; 0: two GEMMs)
 _H_DLN32 = os.environ.get("SARSSL_HYBRID_DLN32", "1") != "0"    # branch gradients entering the LayerNorm backward in f32 (0: bf16)
 
 
@@ -298,6 +301,20 @@ def stem_fwd(a0, pe, train, saved):
     y3, s3 = hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], want_stats=True) if fuse else \
         (hip.conv3x3_fwd(y2, _taps(pe[6])[0], aff2[0], aff2[1], precise=RT.precise), None)
     aff3 = bn_affine(y3, 64, pe[7], train, sums=s3)
+    if RT.hybrid and _H_STEM4 and RT.dtype == torch.float16:
+        # the f32 stream starts at the 4-channel tensors (0.5 MB per segment): the 64 -> 4 result and BatchNorm(4) + ReLU of it travel as
+        # fp16 pairs into a three-segment frame-patch product; the hi halves are exactly the fp16 mode's y4 / z4 (what backward reads)
+        if train:
+            y4p, s4 = hip.stem_c4_fwd_pair(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1], want_stats=True)
+            aff4 = bn_affine(y4p.hi, 4, pe[10], train, sums=s4)
+        else:
+            y4p = hip.stem_c4_fwd_pair(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1])
+            aff4 = bn_affine(y4p.hi, 4, pe[10], train)
+        z4p = hip.cl_affine_act_pair(y4p, 4, aff4, RELU)
+        y4, z4 = y4p.hi, z4p.hi.view(B * T, F * 4)
+        e = mm_nt_h(hip.Pair(z4, z4p.lo.view(B * T, F * 4)), _patch_w_pair(pe[12], F), _F32)
+        saved.append((a0, (y1, mom1), aff1, y2, aff2, y3, aff3, y4, aff4, z4, train))
+        return e
     if train:                       # BatchNorm(4) sums ride in the 64->4 pass (no statistics pass over y4)
         y4, s4 = hip.stem_c4_fwd(y3, pe[9].weight.data.view(4, 64), aff3[0], aff3[1], want_stats=True)        # (B,T,F,4)
         aff4 = bn_affine(y4, 4, pe[10], train, sums=s4)
@@ -567,6 +584,15 @@ def _ffn_bwd_h(dy, ff, saved, dy16=None, next_kind=None, want16=True):
     if torch.is_tensor(s2):
         dz2 = dz2 * (s2 * factor).to(dz2.dtype)
     mm_tn_acc(dz2, a, gbuf(l2.weight), bias=gbuf(l2.bias))
+    d = x.shape[1]
+    if (_FFN2 and _H_FFN2_BWD and d in _FFN2_BWD and not torch.is_tensor(s1) and dz2.stride(1) == 1 and hip.ffn2_supported(x.shape[0], d, dz2.dtype)
+            and hpre.shape[1] == 4 * d and ff.__dict__.get("_ffn2_packs") is not None and ff.__dict__["_ffn2_packs"][0][5]
+            and ff.__dict__["_ffn2_packs"][0][0] == weights_version()):
+        # both data-gradient products in the fused launch of the fp16 mode (csrc/ffn2.hip; bf16 gradients, fp16 saved pre-activation):
+        # the branch gradient dln reaches the stream's LayerNorm backward in bf16
+        dln, dh = hip.ffn2_bwd(dz2, _ffn_packs(ff)[2], _ffn_packs(ff)[3], hpre, d, p1=p1, s1=s1)
+        mm_tn_acc(dh, ln, gbuf(l1.weight), bias=gbuf(l1.bias))
+        return _ln_bwd_h(dln, x, seq[0], stats, _as_stream(dy), saved, next_kind, want16)
     if torch.is_tensor(s1):
         dh = mm_nn(dz2, wtg(l2.weight), aux=hpre, aux_act=SWISH)
         dh = dh * s1.to(dh.dtype)
@@ -799,14 +825,17 @@ def _mhsa_fwd_h(x, mod, B, T, train, saved):
     wo = wpair(att.out_proj.linear.weight)
     if fused_attn:
         if in_kernel:
-            ctx, lse, bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, biases=(ub, vb))
+            ctx, lse, bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, biases=(ub, vb),
+                                                     want_ctx32=_H_CTX)
         else:
             bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
             hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
                      sC=(H * T * T, T * T), c_row_shift=True)
-            ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)
+            ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, want_ctx32=_H_CTX)
         so = RT.next_seed() if po > 0 else 0
-        y = mm_nt_h(ctx, wo, _F32, bias=att.out_proj.linear.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
+        # the kernel's unrounded f32 context (it keeps it for the backward pass anyway) enters the output projection as a pair
+        cin = hip.Pair(ctx, hip.split_pair(lse[0], want_hi=False)) if (_H_CTX and lse[0] is not None) else ctx
+        y = mm_nt_h(cin, wo, _F32, bias=att.out_proj.linear.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
         saved.append((x, ln.hi, stats, qu, qv, k, v, pos, pe, bias, lse, pa, sa, ctx, po, so, B, T))
         return y
     content = hip.gemm(qu, k, M=T, N=T, K=dh, lda=d, ldb=ldk, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(T * ldk, dh),

@@ -797,6 +797,25 @@ def stem_c4_fwd(y3, W4, scale, shift, want_stats=False):
     return y4
 
 
+def stem_c4_fwd_pair(y3, W4, scale, shift, want_stats=False):
+    """Hybrid mode: the 64 -> 4 convolution's f32 result as a Pair (hi = what stem_c4_fwd stores) -> Pair or (Pair, sums f64[8])."""
+    B, F, T, _ = y3.shape
+    hi = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)
+    lo = torch.empty((B, T, F, 4), dtype=y3.dtype, device=y3.device)
+    sums = _sums(8, y3.device) if want_stats else None
+    _lib.call("sarssl_stem_c4_fwd_pair", _p(y3), _p(W4), _p(scale), _p(shift), c_int(B), c_int(F), c_int(T), _p(hi), _p(lo), _p(sums),
+              c_int(dt(y3)), _stream())
+    return (Pair(hi, lo), sums) if want_stats else Pair(hi, lo)
+
+
+def cl_affine_act_pair(x, C, aff, act):
+    """act(aff[0][c] * x + aff[1][c]) on a channels-last Pair -> Pair."""
+    zh, zl = torch.empty_like(x.hi), torch.empty_like(x.lo)
+    _lib.call("sarssl_cl_affine_act_pair", _p(x.hi), _p(x.lo), c_long(x.hi.numel()), c_int(C), _p(aff[0]), _p(aff[1]), c_int(act), _p(zh), _p(zl),
+              _stream())
+    return Pair(zh, zl)
+
+
 def stem_c4_bwd(y3, dy4, W4, aff):
     """-> g3 (B,F,T,64), red f64[384] = [dW4 (4x64) | s1 (64) | s2 (64)]."""
     B, F, T, _ = y3.shape
@@ -1247,14 +1266,14 @@ def relpos_attn_supported(T, dh, dtype):
     return dtype in _16 and bool(_lib.lib().sarssl_relpos_attn_supported(c_int(T), c_int(dh)))
 
 
-def relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True):
+def relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True, want_ctx32=False):
     """qu [B*T, d], k / v [B*T, d] (row-strided views), bias (B,H,T,T) shifted positional score -> ctx [B*T, d] bf16,
     (ctx32 [B*T, d] f32 unrounded, lse (B,H,T)) for backward."""
     _need_cuda(qu, k, v, bias)
     assert k.stride(0) == v.stride(0) and bias.is_contiguous() and qu.dtype in _16 and k.dtype == qu.dtype and v.dtype == qu.dtype and \
         bias.dtype == qu.dtype
     ctx = torch.empty((B * T, H * dh), dtype=qu.dtype, device=qu.device)
-    ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if need_bwd else None
+    ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if (need_bwd or want_ctx32) else None
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
     _lib.call("sarssl_relpos_attn_fwd", _p(qu), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(bias), _p(ctx),
               c_long(ctx.stride(0)), _p(ctx32), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh), c_float(scale), c_float(p_drop),
@@ -1267,7 +1286,7 @@ def relpos_attn_pos_supported(T, dh, dtype):
     return dtype in _16 and bool(_lib.lib().sarssl_relpos_attn_pos_supported(c_int(T), c_int(dh)))
 
 
-def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True, biases=None):
+def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True, biases=None, want_ctx32=False):
     """relpos_attn_fwd with the shifted positional score (qv pos^T, relative shift) formed inside the kernel.  Returns
     ctx, (ctx32, lse), bias ((B,H,T,T) as the kernel used it; None when need_bwd is False).
     biases = (u, v) f32 [H*dh]: qu and qv are then the same plain query projection q, the kernel adds the biases while loading."""
@@ -1278,7 +1297,7 @@ def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=
     assert k.stride(0) == v.stride(0) and qu.stride(0) == qv.stride(0) and qu.dtype in _16 and \
         all(t.dtype == qu.dtype for t in (qv, k, v, pos)) and pos.stride(1) == 1
     ctx = torch.empty((B * T, H * dh), dtype=qu.dtype, device=qu.device)
-    ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if need_bwd else None
+    ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if (need_bwd or want_ctx32) else None
     bias = torch.empty((B, H, T, T), dtype=qu.dtype, device=qu.device) if need_bwd else None
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
     _lib.call("sarssl_relpos_attn_fwd_pos", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),

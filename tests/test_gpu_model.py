@@ -294,7 +294,7 @@ def _f15(prec, case):
     return net, loss, diff, vis, z, x
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "hybrid", "bf16"])
 @pytest.mark.parametrize("case", F15_CASES)
 def test_edge_case_inputs_vs_the_reference(case, prec):
     """Round-4 verdict: every fixture used well-scaled input.  F15 = the reference's own forward + backward (train mode, fp32 CPU) on a
@@ -310,7 +310,7 @@ def test_edge_case_inputs_vs_the_reference(case, prec):
         tag = "f15.%s.%s." % (case, prec)
         assert abs(float(x.abs().max()) / float(z[case + ".input_absmax"]) - 1) < 1e-4           # the f32 front-end itself is exact on every case
         check(tag + "diff", abs(diff.item() / float(z[case + ".diff"]) - 1), 1e-4)
-        if prec == "fp16" and case == "ref_mic_all_zero":
+        if prec in ("fp16", "hybrid") and case == "ref_mic_all_zero":          # (hybrid: the stem - and the network input - are fp16)
             assert float(z[case + ".input_absmax"]) > 65504.0 and not np.isfinite(loss.item()), loss.item()
             return
         check(tag + "loss", abs(loss.item() / float(z[case + ".loss"]) - 1), tol["loss"])
@@ -396,7 +396,7 @@ def test_nonfinite_loss_skips_the_optimizer_step(form):
         runtime.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16", "hybrid", "bf16"])
 def test_decoder_on_the_masked_frames_only_equals_the_full_decoder(prec, monkeypatch):
     """Training steps run EmbedDecoder (code/model.py:321-334) - and the row-wise tail of each encoder's last Conformer block: second
     feed-forward module + closing LayerNorm (code/common/Conformer.py:84-90) - on the masked frames only: gen_loss (code/model.py:721-747)

@@ -63,7 +63,7 @@ def test_loss_curve_100_steps_vs_reference_fp32():
     check("curve100.fp32.max", rel.max(), 1e-3)
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16", "hybrid", "bf16"])
 def test_loss_curve_100_steps_16bit_modes_track_reference(prec):
     """Fast paths (fp16 forward / bf16 backward = what bench.py times; bf16 throughout): all 100 steps of the same curve at the
     north_star's 1e-3 (bf16 measured on MI355X: max relative deviation 1.6e-4)."""
@@ -78,7 +78,7 @@ def _update_norms(net, init):
     return {k: float((p.detach().float().cpu().double() - init[k].double()).norm()) for k, p in net.named_parameters()}
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_pretrain_epoch_vs_reference_pretrain_epoch(prec):
     """``STFTLearner.pretrain_epoch`` against fixture F12, produced by the reference's OWN ``pretrain_epoch``
     (code/learner.py:76-131): two epochs x four batches, returned (loss, diff, vis) per epoch, a new learning rate and a fresh Adam
@@ -88,7 +88,7 @@ def test_pretrain_epoch_vs_reference_pretrain_epoch(prec):
     dev = torch.device("cuda:0")
     z = np.load(os.path.join(GOLD, "f12_pretrain_epoch.npz"))
     tol = {"fp32": dict(loss=1e-3, rms=1.5e-1, upd=1e-2, upd1=2e-1), "bf16": dict(loss=2e-3, rms=1.5e-1, upd=2e-2, upd1=3e-1),
-           "fp16": dict(loss=1e-3, rms=1.5e-1, upd=5e-3, upd1=2e-1)}[prec]      # measured: 1.4e-4, 3.9e-3 / 2.4e-2, 6.1e-4, 4.9e-2
+           "fp16": dict(loss=1e-3, rms=1.5e-1, upd=5e-3, upd1=2e-1), "hybrid": dict(loss=1e-3, rms=1.5e-1, upd=5e-3, upd1=2e-1)}[prec]      # measured: 1.4e-4, 3.9e-3 / 2.4e-2, 6.1e-4, 4.9e-2
     # (rms = output ENERGY after 4 / 8 Adam steps, a SANITY bound and not a parity quantity - see below: the second epoch's value moved from
     #  3.5e-4 to 2.4e-2 when the positional-projection gradient changed its summation order in round 4 (same 2.9e-3 error against f64 either
     #  way, tools/attn_diag.py) and to 5.1e-2 in round 5 when all-zero STFT frames became exact zeros; the reference and its own f32
@@ -165,7 +165,7 @@ def test_checkpoint_written_by_reference_resumes(tmp_path):
         runtime.set_precision("bf16")
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_dropout_on_curve_with_replayed_masks_vs_reference(prec):
     """SURVEY fixture F5(ii) / Q17: the reference's dropout-ON training run (p = 0.1, 40 Adam steps, batch 8).  The build draws the
     step's 28 dropout masks on the host with torch's CPU generator in the reference's order and layouts (runtime.DropoutReplay,

@@ -50,7 +50,7 @@ for _ in range(a.steps):
 p = hip.profile_stop()
 rows = []
 for k, (n, ms) in p.items():
-    m = re.match(r"gemm\[(\d+),(\d+),(\d+) x(\d+)", k)
+    m = re.match(r"gemm(?:_split)?\[(\d+),(\d+),(\d+) x(\d+)", k)       # gemm_split: x = K segments (FLOPs executed = segments x 2 M N K)
     if m:
         M, N, K, nb = (int(v) for v in m.groups())
         flop = 2.0 * M * N * K * nb
@@ -60,6 +60,10 @@ print("%9s %6s %9s %8s  %s" % ("ms/step", "n/step", "us/launch", "TFLOP/s", "sha
 for r in rows:
     print("%9.4f %6.1f %9.1f %8.1f  %s" % r)
 print("total gemm ms/step: %.3f" % sum(r[0] for r in rows))
+other = sorted(((ms / a.steps, n / a.steps, k) for k, (n, ms) in p.items() if k.startswith("call:")), reverse=True)
+print("--- every other entry point, ms/step (launches)")
+for ms, n, k in other[:40]:
+    print("%9.4f %6.1f  %s" % (ms, n, k))
 for k in ("call:sarssl_gemm_group_tn", "call:sarssl_splitk_reduce_multi", "call:sarssl_colsum_multi_partials", "call:sarssl_colsum_store"):
     if k in p:
         print("%-40s %.4f ms/step (%d launches)" % (k, p[k][1] / a.steps, p[k][0] / a.steps))
