@@ -117,6 +117,15 @@ int sarssl_layernorm_fwd2_pair(const float* x, long ldx, long M, int d, const fl
 int sarssl_layernorm_bwd_stream(const void* dy, int dy_dtype, long lddy, const float* x, long ldx, long M, int d, const float* gamma,
                                 const float* mean, const float* rstd, const float* resid, long ldr, float* dx, long lddx, float* dgamma,
                                 float* dbeta, float* partial, void* dx2, float p_drop, unsigned long long seed, float gscale, void* stream);
+/*      fused feed-forward module on the f32 stream (d = 256; csrc/ffn2h.hip): FeedForwardModule.forward (feed_forward.py:47-54) under
+ *      the half-step residual (Conformer.py:60-67) with its LayerNorm in the prologue - y = x + out_scale * drop2((W2h + W2l) drop1(
+ *      swish((W1h + W1l) LN(x) + b1)) + b2), LN(x) held on the CU as an fp16 pair; written for the backward pass: ln_hi [M][d] fp16,
+ *      ln_mean / ln_rstd [M], preact / hidden [M][4d] fp16.  w1h / w1l / w2h / w2l: sarssl_ffn_pack of the weights' hi / lo shadows. */
+int sarssl_ffn2h_supported(long M, int d);
+int sarssl_ffn2h_fwd(const float* x, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_hi, float* ln_mean,
+                     float* ln_rstd, const void* w1h, const void* w1l, const void* w2h, const void* w2l, const float* b1, const float* b2,
+                     void* preact, void* hidden, float* y, long ldy, long M, int d, float p1, unsigned long long s1, float p2,
+                     unsigned long long s2, float out_scale, void* stream);
 /*      the stem's 64 -> 4 convolution with its f32 result as a pair (y4_hi = what sarssl_stem_c4_fwd stores, y4_lo the remainder;
  *      stats8 = BatchNorm(4) sums of the pair's value, may be NULL), and BatchNorm(4) affine + ReLU on the pair -> pair: the f32 operand
  *      of the frame-patch product (code/model.py:60-63). */

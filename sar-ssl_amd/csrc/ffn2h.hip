@@ -1,0 +1,285 @@
+// Fused feed-forward module of the HYBRID numeric mode (d = 256): the forward launch of csrc/ffn2.hip on an f32 residual stream.
+//
+//   y = x + f * drop2( W2 . drop1( swish( W1 . LN(x) + b1 ) ) + b2 )        (feed_forward.py:47-54, Conformer.py:60-67)
+//
+// x, y: f32 [M][256].  The LayerNorm runs in the prologue (arithmetic of layernorm_fwd_kernel, csrc/elementwise.hip); its f32 result stays
+// on the CU as an fp16 PAIR (two LDS tiles, hi = fp16(ln), lo = fp16(ln - hi)) and only the hi half is written out (the weight-gradient
+// operand of the backward pass).  Weights arrive as fragment-order packs (sarssl_ffn_pack) of their hi and lo fp16 shadows.  First product:
+// hi hi + lo hi + hi lo (three MFMAs per fragment pair); the hidden tile is fp16 in LDS as in ffn2.hip, so the second product is
+// h W2_hi + h W2_lo (two).  What leaves the chip: the fp16 pre-activation and dropped hidden tensors [M][1024] (saved for the backward
+// pass, bit-identical to what the unfused hybrid sequence stores), LN hi, the LayerNorm statistics and the f32 result.
+//
+// Against the unfused sequence (LayerNorm -> pair, sarssl_gemm_split x 2) this removes the pair's round trip through HBM (2 x 16 MB
+// written + read), the hidden tensor's read-back (33 MB) and two prologue / epilogue phases; the weight stream per workgroup doubles
+// (hi + lo packs: 2 MB from L2).  Same dropout masks (pure functions of (seed, row * N + column)).
+#include "common.h"
+#include "ffn_common.h"
+
+#define FFN_NT 512
+#define FFN_HC 256
+#define FFN_PH (FFN_HC + 8)
+
+struct Ffn2hArgs {
+    const float* X; long ldx;                  // [M][D] f32: LayerNorm input and residual
+    const float* ln_g; const float* ln_b; float ln_eps;
+    f16* LNout; float* ln_mean; float* ln_rstd;
+    const void* W1h; const void* W1l; const void* W2h; const void* W2l;     // packs of [4D x D] / [D x 4D], hi and lo shadows
+    const float* b1; const float* b2;
+    f16* P; f16* Hs;                           // [M][4D] pre-activation / dropped hidden activations
+    float* Y; long ldy;
+    float p1, p2; unsigned long long s1, s2; const unsigned long long* salt;
+    float out_scale;
+    int M;
+};
+
+template <int D>
+__global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
+    constexpr int H = 4 * D, NCH = H / FFN_HC, PA = D + 8, KS1 = D / 16, DB = D / 256;
+    constexpr int SA_ELEMS = 64 * PA, ST_ELEMS = 64 * FFN_PH, PY = D + 4;
+    constexpr int TILE_ELEMS = 2 * SA_ELEMS + 2 * ST_ELEMS, YST_ELEMS = 64 * PY * 2;
+    constexpr int LDS_ELEMS = TILE_ELEMS > YST_ELEMS ? TILE_ELEMS : YST_ELEMS;
+    constexpr int NP1 = 2 * KS1, NP2 = 2 * 16 * DB, NPOS = NP1 + NP2;      // positions of a chunk in the wave's weight stream
+    static_assert(NPOS % 16 == 0 && NP1 >= 16, "weight queue: 16 fragments in flight");
+    __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];
+    uint16_t* sAh = smem;
+    uint16_t* sAl = smem + SA_ELEMS;
+    uint16_t* sH = smem + 2 * SA_ELEMS;
+    uint16_t* sP = sH + ST_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long m0 = (long)blockIdx.x * 64;
+    const uint4* W1h = (const uint4*)g.W1h + lane;
+    const uint4* W1l = (const uint4*)g.W1l + lane;
+    const uint4* W2h = (const uint4*)g.W2h + lane;
+    const uint4* W2l = (const uint4*)g.W2l + lane;
+    // position P of chunk c in the wave's stream: first product ks = P / 2 (even: hi pack, odd: lo pack), then the second product
+    // (k-step ksl, column block dbi) = (P - NP1) / 2, same parity rule
+    auto piece = [&](int c, int P) -> const uint4* {
+        if (P < NP1) return ((P & 1) ? W1l : W1h) + ((long)((c * 8 + w) * KS1 + (P >> 1)) << 6);
+        const int i2 = (P - NP1) >> 1;
+        return (((P - NP1) & 1) ? W2l : W2h) + ((long)((w * DB + i2 % DB) * (H / 16) + c * 16 + i2 / DB) << 6);
+    };
+    uint4 q[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) q[j] = *piece(0, j);
+
+    // ---- LayerNorm of the tile's rows (one wave per row, rows w * 8 .. w * 8 + 7) -> hi / lo tiles in LDS, hi to HBM
+    {
+        constexpr int NVL = D / 256;
+        float4 v[8][NVL];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) v[j][i] = *(const float4*)(g.X + (m0 + w * 8 + j) * g.ldx + (lane + i * 64) * 4);
+        float4 gam[NVL], bet[NVL];
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) { gam[i] = *(const float4*)(g.ln_g + (lane + i * 64) * 4); bet[i] = *(const float4*)(g.ln_b + (lane + i * 64) * 4); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = w * 8 + j;
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) sm += v[j][i].x + v[j][i].y + v[j][i].z + v[j][i].w;
+            const float mu = wave_sum(sm) / (float)D;
+            float qv = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const float a = v[j][i].x - mu, b = v[j][i].y - mu, c = v[j][i].z - mu, e = v[j][i].w - mu;
+                qv += a * a + b * b + c * c + e * e;
+            }
+            const float rs = rsqrtf(wave_sum(qv) / (float)D + g.ln_eps);
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const int c4 = lane + i * 64;
+                const float ov[4] = {(v[j][i].x - mu) * rs * gam[i].x + bet[i].x, (v[j][i].y - mu) * rs * gam[i].y + bet[i].y,
+                                     (v[j][i].z - mu) * rs * gam[i].z + bet[i].z, (v[j][i].w - mu) * rs * gam[i].w + bet[i].w};
+                const uint2 hi = pack4<f16>(ov);
+                const sarssl_f32x2 h0 = unpack2_f16(hi.x), h1 = unpack2_f16(hi.y);
+                const float lv[4] = {ov[0] - h0.x, ov[1] - h0.y, ov[2] - h1.x, ov[3] - h1.y};
+                *(uint2*)(g.LNout + (m0 + row) * (long)D + c4 * 4) = hi;
+                *(uint2*)&sAh[row * PA + c4 * 4] = hi;
+                *(uint2*)&sAl[row * PA + c4 * 4] = pack4<f16>(lv);
+            }
+            if (lane == 0) { g.ln_mean[m0 + row] = mu; g.ln_rstd[m0 + row] = rs; }
+        }
+    }
+    FfnDrop d1;
+    d1.init(g.p1, g.s1, g.salt);
+
+    f32x16 Y[DB][2];
+#pragma unroll
+    for (int a = 0; a < DB; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[a][i][r] = 0.f;
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int hl0 = w * 32 + 4 * (lane >> 5);
+    const int trow = tid >> 5, tch = tid & 31;
+    __syncthreads();
+
+    for (int c = 0; c < NCH; ++c) {
+        const int cn = c + 1 < NCH ? c + 1 : c;
+        auto refill = [&](int P) {                          // queue slot of position P <- the fragment 16 positions further down the stream
+            const int nxt = P + 16;
+            q[P & 15] = nxt < NPOS ? *piece(c, nxt) : *piece(cn, nxt - NPOS);       // (last chunk: a harmless re-read of its own fragments)
+        };
+        // ---- first product: S^T[h][m] = sum_k (W1_hi + W1_lo)[h][k] (A_hi + A_lo)[m][k] without the lo lo term
+        f32x16 S[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[i][r] = 0.f;
+        {
+            bf16x8 fh_[2][2], fl_[2][2];
+            fh_[0][0] = *(const bf16x8*)&sAh[frow * PA + fk];
+            fh_[0][1] = *(const bf16x8*)&sAh[(32 + frow) * PA + fk];
+            fl_[0][0] = *(const bf16x8*)&sAl[frow * PA + fk];
+            fl_[0][1] = *(const bf16x8*)&sAl[(32 + frow) * PA + fk];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int cur = ks & 1, nx = cur ^ 1;
+                if (ks + 1 < KS1) {
+                    fh_[nx][0] = *(const bf16x8*)&sAh[frow * PA + (ks + 1) * 16 + fk];
+                    fh_[nx][1] = *(const bf16x8*)&sAh[(32 + frow) * PA + (ks + 1) * 16 + fk];
+                    fl_[nx][0] = *(const bf16x8*)&sAl[frow * PA + (ks + 1) * 16 + fk];
+                    fl_[nx][1] = *(const bf16x8*)&sAl[(32 + frow) * PA + (ks + 1) * 16 + fk];
+                }
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, q[(2 * ks) & 15]);
+                S[0] = mfma16<f16>(wh, fh_[cur][0], S[0]);
+                S[1] = mfma16<f16>(wh, fh_[cur][1], S[1]);
+                S[0] = mfma16<f16>(wh, fl_[cur][0], S[0]);
+                S[1] = mfma16<f16>(wh, fl_[cur][1], S[1]);
+                refill(2 * ks);
+                const bf16x8 wl = __builtin_bit_cast(bf16x8, q[(2 * ks + 1) & 15]);
+                S[0] = mfma16<f16>(wl, fh_[cur][0], S[0]);
+                S[1] = mfma16<f16>(wl, fh_[cur][1], S[1]);
+                refill(2 * ks + 1);
+            }
+        }
+        // ---- epilogue of the first product in the accumulators' own layout (lane = row m, registers = 4 x 4 consecutive hidden units)
+        {
+            float4 bq[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(g.b1 + c * FFN_HC + hl0 + 8 * gq);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = i * 32 + frow;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int hl = hl0 + 8 * gq;
+                    float v[4] = {S[i][4 * gq + 0] + bq[gq].x, S[i][4 * gq + 1] + bq[gq].y, S[i][4 * gq + 2] + bq[gq].z, S[i][4 * gq + 3] + bq[gq].w};
+                    *(uint2*)&sP[m * FFN_PH + hl] = pack4<f16>(v);                 // pre-activation as saved for backward
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sigmoidf_(v[e]);
+                    if (d1.p > 0.f) {
+                        float k[4];
+                        d1.scale4((unsigned long long)(m0 + m) * H + (unsigned long long)(c * FFN_HC + hl), k);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= k[e];
+                    }
+                    *(uint2*)&sH[m * FFN_PH + hl] = pack4<f16>(v);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the tiles leave for HBM row by row ...
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = trow + 16 * j;
+            *(uint4*)(g.Hs + (m0 + row) * H + c * FFN_HC + tch * 8) = *(const uint4*)&sH[row * FFN_PH + tch * 8];
+            *(uint4*)(g.P + (m0 + row) * H + c * FFN_HC + tch * 8) = *(const uint4*)&sP[row * FFN_PH + tch * 8];
+        }
+        // ---- ... while the second product contracts the hidden tile against W2_hi and W2_lo
+        {
+            bf16x8 fh[2][2];
+            fh[0][0] = *(const bf16x8*)&sH[frow * FFN_PH + fk];
+            fh[0][1] = *(const bf16x8*)&sH[(32 + frow) * FFN_PH + fk];
+#pragma unroll
+            for (int ksl = 0; ksl < 16; ++ksl) {
+                const int cur = ksl & 1, nx = cur ^ 1;
+                if (ksl + 1 < 16) {
+                    fh[nx][0] = *(const bf16x8*)&sH[frow * FFN_PH + (ksl + 1) * 16 + fk];
+                    fh[nx][1] = *(const bf16x8*)&sH[(32 + frow) * FFN_PH + (ksl + 1) * 16 + fk];
+                }
+#pragma unroll
+                for (int dbi = 0; dbi < DB; ++dbi) {
+                    const int P = NP1 + 2 * (ksl * DB + dbi);
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, q[P & 15]);
+                    Y[dbi][0] = mfma16<f16>(wh, fh[cur][0], Y[dbi][0]);
+                    Y[dbi][1] = mfma16<f16>(wh, fh[cur][1], Y[dbi][1]);
+                    refill(P);
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, q[(P + 1) & 15]);
+                    Y[dbi][0] = mfma16<f16>(wl, fh[cur][0], Y[dbi][0]);
+                    Y[dbi][1] = mfma16<f16>(wl, fh[cur][1], Y[dbi][1]);
+                    refill(P + 1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- result: accumulators -> f32 LDS staging -> 8-wide row pieces: bias, dropout, scale, f32 residual
+    float* sY = (float*)smem;
+#pragma unroll
+    for (int dbi = 0; dbi < DB; ++dbi)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *(float4*)&sY[(i * 32 + frow) * PY + (w * DB + dbi) * 32 + 8 * gq + 4 * (lane >> 5)] =
+                    make_float4(Y[dbi][i][4 * gq + 0], Y[dbi][i][4 * gq + 1], Y[dbi][i][4 * gq + 2], Y[dbi][i][4 * gq + 3]);
+    __syncthreads();
+    {
+        constexpr int CPRW = D / 8, RPI = FFN_NT / CPRW;
+        const int r = tid / CPRW, ch = tid % CPRW, n = ch * 8;
+        FfnDrop d2;
+        d2.init(g.p2, g.s2, g.salt);
+        const float4 b0 = *(const float4*)(g.b2 + n), b1v = *(const float4*)(g.b2 + n + 4);
+        const float bias8[8] = {b0.x, b0.y, b0.z, b0.w, b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+        for (int j = 0; j < 64 / RPI; ++j) {
+            const int row = r + RPI * j;
+            const long m = m0 + row;
+            const float4 a0 = *(const float4*)&sY[row * PY + n], a1 = *(const float4*)&sY[row * PY + n + 4];
+            f8 v;
+            v.v[0] = a0.x; v.v[1] = a0.y; v.v[2] = a0.z; v.v[3] = a0.w; v.v[4] = a1.x; v.v[5] = a1.y; v.v[6] = a1.z; v.v[7] = a1.w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] += bias8[e];
+            if (d2.p > 0.f) {
+                float k0[4], k1[4];
+                const unsigned long long base = (unsigned long long)m * D + n;
+                d2.scale4(base, k0);
+                d2.scale4(base + 4, k1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v.v[e] *= k0[e]; v.v[4 + e] *= k1[e]; }
+            }
+            const f8 rr = ld8(g.X + m * g.ldx + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * g.out_scale + rr.v[e];
+            st8(g.Y + m * g.ldy + n, v);
+        }
+    }
+}
+
+extern "C" int sarssl_ffn2h_supported(long M, int d) { return (M > 0 && M % 64 == 0 && d == 256) ? 1 : 0; }
+
+// y [M][d] f32 = x + out_scale * drop(p2, s2)( (W2h + W2l) drop(p1, s1)( swish((W1h + W1l) LN(x) + b1) ) + b2 ) with LN(x) as an fp16 pair;
+// ln_hi [M][d] fp16, ln_mean / ln_rstd [M], preact / hidden [M][4d] fp16 are written for the backward pass.  Packs: sarssl_ffn_pack of
+// the weights' hi / lo fp16 shadows ([4d x d] and [d x 4d]).
+extern "C" int sarssl_ffn2h_fwd(const float* x, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_hi, float* ln_mean,
+                                float* ln_rstd, const void* w1h, const void* w1l, const void* w2h, const void* w2l, const float* b1,
+                                const float* b2, void* preact, void* hidden, float* y, long ldy, long M, int d, float p1,
+                                unsigned long long s1, float p2, unsigned long long s2, float out_scale, void* stream) {
+    SARSSL_REQUIRE(sarssl_ffn2h_supported(M, d) && ldx % 4 == 0 && ldy % 4 == 0 && x && y && ln_gamma && ln_beta && ln_hi && ln_mean && ln_rstd &&
+                   w1h && w1l && w2h && w2l && b1 && b2 && preact && hidden, "sarssl_ffn2h_fwd");
+    Ffn2hArgs g;
+    g.X = x; g.ldx = ldx; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps; g.LNout = (f16*)ln_hi; g.ln_mean = ln_mean; g.ln_rstd = ln_rstd;
+    g.W1h = w1h; g.W1l = w1l; g.W2h = w2h; g.W2l = w2l; g.b1 = b1; g.b2 = b2; g.P = (f16*)preact; g.Hs = (f16*)hidden; g.Y = y; g.ldy = ldy;
+    g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt(); g.out_scale = out_scale; g.M = (int)M;
+    ffn2h_kernel<256><<<(int)(M / 64), FFN_NT, 0, (hipStream_t)stream>>>(g);
+    SARSSL_CHECK_LAUNCH("ffn2h_kernel");
+    return 0;
+}

@@ -86,17 +86,19 @@ __device__ __forceinline__ bf16x8 frag_tr(const uint16_t* s, int kbase, int r0, 
     return u.b;
 }
 
-template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool CSUM = false, bool SEG = false>
+// NSEG (sarssl_gemm_split; NT layout, fp16 operands): 2 = A B^T + A B2^T, 3 = A B^T + A2 B^T + A B2^T - the lo tiles (A2, B2) are staged
+// next to the hi tiles and every fragment read feeds two MFMAs (fp16 pairs of an f32 activation / weight: hi hi + lo hi + hi lo)
+template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, bool EDGE, bool CSUM = false, int NSEG = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, const int bid_y, const int bid_z, const int grid_x,
                                           const int grid_y, const int grid_z) {
     typedef typename MfmaT<TA, TB>::type TM;
     static_assert(sizeof(TA) == 2 || (sizeof(TA) == 4 && sizeof(TB) == 4), "f32 operands come in pairs (split-bf16 passes)");
-    static_assert(!SEG || (AKC && BKC && sizeof(TA) == 2 && sizeof(TB) == 2), "K-segment products: NT layout, 16-bit operands");
+    static_assert(NSEG == 0 || ((NSEG == 2 || NSEG == 3) && AKC && BKC && sizeof(TA) == 2 && sizeof(TB) == 2 && FM <= 2), "pair products: NT layout, 16-bit operands");
     constexpr int BM = 64 * FM;
     constexpr int PTA = BM + 32, PTB = BN + 32;
     constexpr int A_ELEMS = AKC ? BM * PITCH : BK * PTA;
     constexpr int B_ELEMS = BKC ? BN * PITCH : BK * PTB;
-    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    constexpr int STAGE = A_ELEMS + B_ELEMS + (NSEG >= 2 ? B_ELEMS : 0) + (NSEG == 3 ? A_ELEMS : 0);
     constexpr int PC = BN + 4;                                  // f32 staging pitch of the epilogue (conflict-free 16-byte LDS writes)
     constexpr int EPI_ELEMS = 64 * PC * 2;                      // 64 x 132 f32, in 16-bit units
     constexpr int LDS_ELEMS = STAGE > EPI_ELEMS ? STAGE : EPI_ELEMS;      // (a double-buffered variant - two LDS stages, two register
@@ -104,6 +106,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];    // FM = 2: 2 x 32-37 KiB (2 workgroups / CU), FM = 4: 56 KiB (2 / CU)
     uint16_t* sA = smem;
     uint16_t* sB = smem + A_ELEMS;
+    uint16_t* sB2 = sB + B_ELEMS;                 // NSEG >= 2: the lo tile of B
+    uint16_t* sA2 = sB2 + B_ELEMS;                // NSEG == 3: the lo tile of A
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nsplit = g.split_k > 0 ? g.split_k : 1;
@@ -225,7 +229,83 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
         if (g.prio) __builtin_amdgcn_s_setprio(0);
     };
 
-    {
+    if constexpr (NSEG >= 2) {
+        // pair products: per K-tile the hi and lo tiles of both operands are staged once; a k-step reads FM (+ FM) A fragments and 2 + 2
+        // B fragments for 2 FM x NSEG MFMAs (hi hi, hi lo_B, lo_A hi) - two thirds of the fragment reads, one third of the barriers and
+        // tile stores per MFMA of a plain product
+        const TA* pa2 = (const TA*)g.A2 + (pa - (const TA*)g.A);
+        const TB* pb2 = (const TB*)g.B2 + (pb - (const TB*)g.B);
+        uint4 ra[BM / 32], rb[BN / 32], rb2[BN / 32], ra2[NSEG == 3 ? BM / 32 : 1];
+        auto load_all = [&](int k0) {
+            tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k0, g.M, k_end, 0, tid, ra);
+            tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k0, g.N, k_end, 0, tid, rb);
+            tile_load<TB, TM, BKC, BN, EDGE>(pb2, g.ldb, n0, k0, g.N, k_end, 0, tid, rb2);
+            if constexpr (NSEG == 3) tile_load<TA, TM, AKC, BM, EDGE>(pa2, g.lda, m0, k0, g.M, k_end, 0, tid, ra2);
+        };
+        auto phase = [&]() {
+            auto load_frags = [&](int kk, bf16x8 (&fa)[FM], bf16x8 (&fa2)[FM], bf16x8 (&fb)[2], bf16x8 (&fb2)[2]) {
+                const int koff = kk * 16 + (lane >> 5) * 8;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int o = (wm * (FM * 32) + i * 32 + (lane & 31)) * PITCH + koff;
+                    fa[i] = *(const bf16x8*)&sA[o];
+                    if constexpr (NSEG == 3) fa2[i] = *(const bf16x8*)&sA2[o];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int o = (wn * 64 + j * 32 + (lane & 31)) * PITCH + koff;
+                    fb[j] = *(const bf16x8*)&sB[o];
+                    fb2[j] = *(const bf16x8*)&sB2[o];
+                }
+            };
+            auto mfmas = [&](const bf16x8 (&fa)[FM], const bf16x8 (&fa2)[FM], const bf16x8 (&fb)[2], const bf16x8 (&fb2)[2]) {
+                // (one pass over the accumulators per product type: consecutive MFMAs never wait on each other's result)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<TM>(fb[j], fa[i], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<TM>(fb2[j], fa[i], acc[i][j]);
+                if constexpr (NSEG == 3) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<TM>(fb[j], fa2[i], acc[i][j]);
+                }
+            };
+            bf16x8 fa0[FM], fa20[FM], fb0[2], fb20[2], fa1[FM], fa21[FM], fb1[2], fb21[2];
+            if (g.prio) __builtin_amdgcn_s_setprio(2);
+            load_frags(0, fa0, fa20, fb0, fb20);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; kk += 2) {
+                load_frags(kk + 1, fa1, fa21, fb1, fb21);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(fa0, fa20, fb0, fb20);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < BK / 16) load_frags(kk + 2, fa0, fa20, fb0, fb20);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(fa1, fa21, fb1, fb21);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g.prio) __builtin_amdgcn_s_setprio(0);
+        };
+        load_all(k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            tile_store<AKC, BM>(sA, tid, ra);
+            tile_store<BKC, BN>(sB, tid, rb);
+            tile_store<BKC, BN>(sB2, tid, rb2);
+            if constexpr (NSEG == 3) tile_store<AKC, BM>(sA2, tid, ra2);
+            __syncthreads();
+            if (k0 + BK < k_end) {
+                pa += stepA; pb += stepB; pa2 += stepA; pb2 += stepB;
+                load_all(k0 + BK);
+            }
+            phase();
+            __syncthreads();
+        }
+    } else {
         uint4 ra[BM / 32], rb[BN / 32];
         tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
         tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
@@ -235,11 +315,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
 #else
 #define GSTAMP(k) do {} while (0)
 #endif
-        // SEG: the K loop runs once per segment; the per-thread offsets into A / B are the same in every segment, only the base moves
-        // (segment 1 of 3 reads A2, the last segment of 2 or 3 reads B2) - the prefetch crosses segment boundaries like any K-tile
-        const int nseg = SEG ? g.nseg : 1;
-        const long offA = SEG ? (long)(pa - (const TA*)g.A) : 0, offB = SEG ? (long)(pb - (const TB*)g.B) : 0;
-        for (int seg = 0; seg < nseg; ++seg)
         for (int k0 = k_begin; k0 < k_end; k0 += BK) {
             GSTAMP(0);
             tile_store<AKC, BM>(sA, tid, ra);
@@ -251,11 +326,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
                 pa += stepA; pb += stepB;
                 tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
                 tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
-            } else if (SEG && seg + 1 < nseg) {              // first K-tile of the next segment
-                pa = (const TA*)((seg + 1 == 1 && nseg == 3) ? g.A2 : g.A) + offA;
-                pb = (const TB*)((seg + 1 == nseg - 1) ? g.B2 : g.B) + offB;
-                tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
-                tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
             }
             GSTAMP(3);
             mfma_phase(sA, sB);
@@ -345,10 +415,10 @@ template <typename TA, typename TB, typename TC, bool AKC, bool BKC, int FM, boo
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_kernel(GemmArgs g) {
     gemm_body<TA, TB, TC, AKC, BKC, FM, EDGE>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
 }
-// K-segment products (sarssl_gemm_split): fp16 operands, NT layout
-template <typename TC, int FM, bool EDGE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FM == 4 ? 2 : 3))) void gemm_seg_kernel(GemmArgs g) {
-    gemm_body<f16, f16, TC, true, true, FM, EDGE, false, true>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
+// pair products (sarssl_gemm_split): fp16 operands, NT layout, NSEG = 2 | 3 (see gemm_body); two workgroups per CU (55-74 KB of LDS)
+template <typename TC, int FM, bool EDGE, int NSEG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_seg_kernel(GemmArgs g) {
+    gemm_body<f16, f16, TC, true, true, FM, EDGE, false, NSEG>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z);
 }
 
 // ---- grouped launch: up to GROUP_MAXP independent split-K weight-gradient products (A = dY [K][M], B = X [K][N], both with the
@@ -617,18 +687,21 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
 // cores.  The segments are a longer K loop of the plain kernel: same tiles, same epilogue, the prologue / epilogue of a short-K product
 // amortised over 2-3 times the MFMAs.  A, A_lo: [M][K] (row stride lda), B, B_lo: [N][K] (row stride ldb); A_lo / B_lo may be null.
 // C / resid / preact: dtC (fp16 | f32).
-template <typename TC>
+template <typename TC, int NSEG>
 static int launch_seg(const GemmArgs& g, hipStream_t st) {
-    GemmArgs h = g;                      // tile height from the effective contraction length
-    h.K = g.K * (g.nseg > 0 ? g.nseg : 1); h.k_per_split = h.K;
-    const int fm = pick_fm(h, 1, true);
+    // 64-row tiles when 128-row tiles would leave CUs without a second workgroup (the rule of pick_fm), else 128 x 128
+    const long wg2 = (long)((g.M + 127) / 128) * ((g.N + BN - 1) / BN);
+    // measured on MI355X (tools/hybrid_fm_ab.sh, M = 16384 / 8192): with at most one 128 x 128 tile per CU (N = 256) the 64-row tile wins at
+    // any K (50.6 vs 59.1 us at K = 1024); with up to two per CU only at K <= 256 (four K-tiles: 34 vs 42 us) - at K = 512 .. 3072 the larger
+    // tile's operand reuse wins (N = 512: 64 vs 68 us at K = 512, 106 vs 143 us at K = 2048; the decoder's second layer 127 vs 190 us)
+    const long cus = sarssl_cu_count();
+    const int fm = (g.M >= 128 && (wg2 <= cus || (wg2 <= 2 * cus && g.K <= 256))) ? 1 : 2;
     const int bm = 64 * fm;
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
     const bool edge = (g.M % bm) != 0 || (g.N % BN) != 0 || (g.K % BK) != 0 || !vec_ok;
     dim3 grid((g.N + BN - 1) / BN, (g.M + bm - 1) / bm, 1);
-    if (fm == 4) { if (edge) gemm_seg_kernel<TC, 4, true><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 4, false><<<grid, 256, 0, st>>>(g); }
-    else if (fm == 1) { if (edge) gemm_seg_kernel<TC, 1, true><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 1, false><<<grid, 256, 0, st>>>(g); }
-    else { if (edge) gemm_seg_kernel<TC, 2, true><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 2, false><<<grid, 256, 0, st>>>(g); }
+    if (fm == 1) { if (edge) gemm_seg_kernel<TC, 1, true, NSEG><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 1, false, NSEG><<<grid, 256, 0, st>>>(g); }
+    else { if (edge) gemm_seg_kernel<TC, 2, true, NSEG><<<grid, 256, 0, st>>>(g); else gemm_seg_kernel<TC, 2, false, NSEG><<<grid, 256, 0, st>>>(g); }
     SARSSL_CHECK_LAUNCH("sarssl_gemm_split");
     return 0;
 }
@@ -655,8 +728,12 @@ extern "C" int sarssl_gemm_split(const void* A, const void* A_lo, const void* B,
     g.stamps = nullptr;
 #endif
     hipStream_t st = (hipStream_t)stream;
-    if (dtC == SARSSL_F16) return launch_seg<f16>(g, st);
-    return launch_seg<float>(g, st);
+    if (g.nseg == 1) {                   // no lo parts: the plain fp16 product
+        if (dtC == SARSSL_F16) return launch_layout<f16, f16, f16, true>(g, 1, 1, 1, st);
+        return launch_layout<f16, f16, float, false>(g, 1, 1, 1, st);
+    }
+    if (g.nseg == 2) return dtC == SARSSL_F16 ? launch_seg<f16, 2>(g, st) : launch_seg<float, 2>(g, st);
+    return dtC == SARSSL_F16 ? launch_seg<f16, 3>(g, st) : launch_seg<float, 3>(g, st);
 }
 
 // Grouped split-K weight-gradient products: ws[q] (f32, split_q * M_q * N_q, see `split_out`) receives the partial sums of

@@ -164,6 +164,7 @@ def mm_tn_acc(dy, x, gW, group=True, bias=None):
 _F32 = torch.float32
 _H_STEM4 = os.environ.get("SARSSL_HYBRID_STEM4", "1") != "0"    # the stem's 4-channel tensors (64 -> 4 result, BatchNorm(4) + ReLU of it) as pairs (0: fp16)
 _H_CTX = os.environ.get("SARSSL_HYBRID_CTX", "1") != "0"        # the attention context enters the output projection as a pair (0: fp16)
+_H_FFN2_FWD = os.environ.get("SARSSL_HYBRID_FFN2_FWD", "1") != "0"   # the feed-forward module's forward on the f32 stream in one launch (d = 256, csrc/ffn2h.hip; 0: LayerNorm + two GEMMs)
 _H_FFN2_BWD = os.environ.get("SARSSL_HYBRID_FFN2_BWD", "1") != "0"   # the feed-forward module's data gradients in the fused launch (d = 256; 0: two GEMMs)
 _H_DLN32 = os.environ.get("SARSSL_HYBRID_DLN32", "1") != "0"    # branch gradients entering the LayerNorm backward in f32 (0: bf16)
 
@@ -450,16 +451,21 @@ def prepare_ffn_packs(ffs, need_bwd=True):
         w1, w2 = wt(l1.weight), wt(l2.weight)
         if w1.dtype not in _16 or not w1.is_cuda:
             continue
-        key = (weights_version(), w1.dtype, l1.weight._version, l2.weight._version, w1.data_ptr(), bool(need_bwd))
+        hyb = RT.hybrid and _H_FFN2_FWD                    # hybrid mode: packs of the lo shadows as well (csrc/ffn2h.hip)
+        key = (weights_version(), w1.dtype, l1.weight._version, l2.weight._version, w1.data_ptr(), bool(need_bwd), hyb)
         c = ff.__dict__.get("_ffn2_packs")
-        if c is not None and (c[0] == key or (c[0][:5] == key[:5] and c[0][5])):
+        if c is not None and (c[0] == key or (c[0][:5] == key[:5] and c[0][5] and c[0][6] == hyb)):
             continue
         bufs = ff.__dict__.get("_ffn2_bufs")
-        if bufs is None or bufs[0].dtype != w1.dtype or bufs[0].device != w1.device:
+        if bufs is None or bufs[0].dtype != w1.dtype or bufs[0].device != w1.device or (hyb and len(bufs) < 6):
             gd = RT.gdtype
             bufs = ff.__dict__["_ffn2_bufs"] = (torch.empty(w1.numel(), dtype=w1.dtype, device=w1.device), torch.empty(w2.numel(), dtype=w1.dtype, device=w1.device),
                                                 torch.empty(w2.numel(), dtype=gd, device=w1.device), torch.empty(w1.numel(), dtype=gd, device=w1.device))
+            if hyb:
+                bufs = ff.__dict__["_ffn2_bufs"] = bufs + (torch.empty(w1.numel(), dtype=w1.dtype, device=w1.device), torch.empty(w2.numel(), dtype=w1.dtype, device=w1.device))
         jobs += [(w1, bufs[0]), (w2, bufs[1])]
+        if hyb:
+            jobs += [(wt_lo(l1.weight), bufs[4]), (wt_lo(l2.weight), bufs[5])]
         if need_bwd:
             jobs += [(wtg(l2.weight).t(), bufs[2]), (wtg(l1.weight).t(), bufs[3])]
         fresh.append((ff, key, bufs))
@@ -549,11 +555,21 @@ def _ffn_fwd_h(x, ff, factor, train, saved, out=None):
     x = _as_stream(x)
     pre = x.__dict__.pop("_pre_ln", None)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
+    l1, l2 = seq[1].linear, seq[4].linear
+    d = x.shape[1]
+    if (_FFN2 and _H_FFN2_FWD and d in _FFN2_FWD and pre is None and not _replaying(train) and x.stride(1) == 1 and hip.ffn2h_supported(x.shape[0], d)
+            and l1.weight.shape[0] == 4 * d and wt(l1.weight).is_cuda):
+        # LayerNorm + Linear + Swish + Dropout + Linear + Dropout + scaled residual on the f32 stream in one launch (csrc/ffn2h.hip)
+        packs = _ffn_packs(ff, need_bwd=not RT.inference)
+        s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
+        y, hpre, a, lnh, stats = hip.ffn2h_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps, packs[0], packs[4], packs[1], packs[5],
+                                               l1.bias.data, l2.bias.data, d, p1=p1, s1=s1, p2=p2, s2=s2, out_scale=factor, out=out)
+        saved.append((x, lnh, stats, hpre, a, p1, s1, p2, s2, factor))
+        return y
     if pre is not None and pre[0] is seq[0]:
         ln, stats = pre[1], pre[2]
     else:
         ln, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
-    l1, l2 = seq[1].linear, seq[4].linear
     hpre = torch.empty((x.shape[0], l1.weight.shape[0]), dtype=torch.float16, device=x.device)
     if _replaying(train) and (p1 > 0 or p2 > 0):          # host-drawn masks in the reference's order: hidden, then output
         a = mm_nt_h(ln, wpair(l1.weight), torch.float16, bias=l1.bias.data, act=SWISH, preact=hpre)
@@ -1183,7 +1199,9 @@ def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None, rows=None):
         saved.append((xc, stats, (rows, B, T), x))          # (x: the full-row input of the tail, for a full prediction on request - vis)
         return y
     x = ffn_fwd(x, seq[3].module, seq[3].module_factor, train, saved)
-    if next_blk is not None and out is None and _LN_PAIR:
+    if next_blk is not None and out is None and _LN_PAIR and not (RT.hybrid and _FFN2 and _H_FFN2_FWD and x.shape[1] in _FFN2_FWD and not _replaying(train)
+                                                               and hip.ffn2h_supported(x.shape[0], x.shape[1])):
+        # (hybrid, d = 256: the next block's fused feed-forward launch normalises its rows in its own prologue)
         nln = next_blk.sequential[0].module.sequential[0]
         y, stats, z, zstats = (hip.layernorm_fwd2_pair if RT.hybrid else hip.layernorm_fwd2)(
             x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps)

@@ -373,6 +373,29 @@ def ffn2_fwd(ln, w1p, w2p, b1, b2, resid, d, p1=0.0, s1=0, p2=0.0, s2=0, out_sca
     return out, pre, hid
 
 
+def ffn2h_supported(M, d):
+    return bool(_lib.lib().sarssl_ffn2h_supported(c_long(M), c_int(d)))
+
+
+def ffn2h_fwd(x, gamma, beta, eps, w1h, w1l, w2h, w2l, b1, b2, d, p1=0.0, s1=0, p2=0.0, s2=0, out_scale=1.0, out=None):
+    """Hybrid mode, d = 256: y = x + out_scale * drop2(W2 drop1(swish(W1 LN(x) + b1)) + b2) on the f32 stream in one launch
+    -> (y f32, preact fp16 [M, 4d], hidden fp16 [M, 4d], ln_hi fp16 [M, d], stats f32 [2, M])."""
+    _need_cuda(x, w1h, w1l, w2h, w2l, b1, b2, out)
+    M = x.shape[0]
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    pre = torch.empty((M, 4 * d), dtype=torch.float16, device=x.device)
+    hid = torch.empty((M, 4 * d), dtype=torch.float16, device=x.device)
+    lno = torch.empty((M, d), dtype=torch.float16, device=x.device)
+    stats = torch.empty((2, M), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((M, d), dtype=torch.float32, device=x.device)
+    with _Timed("ffn2h_fwd[d%d]" % d if _prof_shapes and _prof is not None else None):
+        _lib.call("sarssl_ffn2h_fwd", _p(x), c_long(x.stride(0)), _p(gamma), _p(beta), c_float(eps), _p(lno), _p(stats[0]), _p(stats[1]),
+                  _p(w1h), _p(w1l), _p(w2h), _p(w2l), _p(b1), _p(b2), _p(pre), _p(hid), _p(out), c_long(out.stride(0)), c_long(M), c_int(d),
+                  c_float(p1), c_ulonglong(s1), c_float(p2), c_ulonglong(s2), c_float(out_scale), _stream())
+    return out, pre, hid, lno, stats
+
+
 def ffn2_bwd(dz2, w2tp, w1tp, preact, d, p1=0.0, s1=0, ln_bwd=None):
     """-> (dln [M, d], dh [M, 4d]) in the gradient dtype of dz2.
     ln_bwd = (x, gamma, stats, resid, dgamma, dbeta, drop): the LayerNorm backward of the module's first layer runs in the launch's

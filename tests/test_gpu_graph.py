@@ -285,7 +285,7 @@ def test_full_batch_gradient_vs_the_reference_at_batch_64(prec):
         names, offs = json.loads(str(z["names_json"])), z["sample_offsets"]
         params = dict(net.named_parameters())
         top = max(gn.values())
-        worst, got_all, want_all = (0.0, ""), [], []
+        worst, worst_body, got_all, want_all = (0.0, ""), (0.0, ""), [], []
         for i, k in enumerate(names):
             g = params[k].grad.detach().double().reshape(-1).cpu()
             si = torch.from_numpy(z["sample_idx"][offs[i]:offs[i + 1]])
@@ -294,7 +294,13 @@ def test_full_batch_gradient_vs_the_reference_at_batch_64(prec):
                 assert float(g.norm()) < 1e-4 * top, (k, float(g.norm()), gn[k])
             else:
                 worst = max(worst, (abs(float(g.norm()) - gn[k]) / gn[k], k))
+                import re
+                mstem = re.search(r"patch_embed\.(\d+)\.", k)
+                if not (mstem and int(mstem.group(1)) < 12) and not k.endswith(("attention.u_bias", "attention.v_bias")):
+                    worst_body = max(worst_body, (abs(float(g.norm()) - gn[k]) / gn[k], k))
         check(tag + "gradnorm[worst=%s]" % worst[1], worst[0], gate["grad_norm"])
+        if gate.get("grad_norm_body") is not None:     # hybrid: the parameters whose gradient flows along the f32 stream (sar_ssl_amd/parity.py)
+            check(tag + "gradnorm_body[worst=%s]" % worst_body[1], worst_body[0], gate["grad_norm_body"])
         tot_ref = sum(v * v for v in gn.values()) ** 0.5
         tot = sum(float(p.grad.double().norm()) ** 2 for p in params.values()) ** 0.5
         check(tag + "gradnorm_total", abs(tot / tot_ref - 1), 0.25 * gate["grad_norm"])

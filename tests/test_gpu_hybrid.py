@@ -130,3 +130,50 @@ def test_layernorm_pair_and_stream_backward(shape):
         assert torch.equal(dx16, want)
         dx_b, c16 = hip.layernorm_bwd_stream(dy, x, gamma, stats, resid=res, copy16=True)
         assert torch.equal(dx_b, dx) and torch.equal(c16, dx.bfloat16())
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_feed_forward_on_the_f32_stream_equals_the_unfused_sequence(train, monkeypatch):
+    """csrc/ffn2h.hip (LayerNorm + both Linear layers in one launch, d = 256) against the hybrid mode's unfused sequence (LayerNorm -> pair,
+    two sarssl_gemm_split launches): the tensors saved for the backward pass bit for bit (same MFMA products in the same order, same
+    dropout masks), the f32 result to an ulp (one fused multiply-add in the residual), and the result against an f64 reference."""
+    from sar_ssl_amd import engine, runtime
+    from sar_ssl_amd.common.conformer.feed_forward import FeedForwardModule
+    dev = _dev()
+    runtime.set_precision("hybrid")
+    try:
+        torch.manual_seed(5)
+        ff = FeedForwardModule(encoder_dim=256, expansion_factor=4, dropout_p=0.1).to(dev).train(train)
+        with torch.no_grad():
+            ff.sequential[0].weight.add_(0.1 * torch.randn(256, device=dev)); ff.sequential[0].bias.add_(0.1 * torch.randn(256, device=dev))
+        x = (torch.randn(2048, 256, device=dev) * 1.5 + 0.2)
+        res = {}
+        for fused in (True, False):
+            monkeypatch.setattr(engine, "_H_FFN2_FWD", fused)
+            runtime.RT.manual_seed(99)
+            saved = []
+            y = engine.ffn_fwd(x.clone(), ff, 0.5, train, saved)
+            res[fused] = (y, saved[0])
+        (yf, sf), (yu, su) = res[True], res[False]
+        for i, name in ((1, "ln_hi"), (2, "stats")):
+            assert torch.equal(sf[i], su[i]), name
+        # pre-activation / hidden tensor: the same products accumulated in another order (k-step-major here, segment-major there) - equal
+        # up to the f32 summation order, i.e. an fp16 ulp on a fraction of the entries
+        for i, name in ((3, "preact"), (4, "hidden")):
+            a, b = sf[i].float(), su[i].float()
+            check("hybrid.ffn2h.%s.%s_vs_unfused" % ("train" if train else "eval", name), ((a - b).abs().max() / b.abs().max()).item(), 1e-3)
+            assert (a != b).float().mean().item() < 0.02, name
+            if train and name == "hidden":
+                assert torch.equal(a == 0, b == 0)            # the same dropout mask
+        assert sf[5:] == su[5:]
+        check("hybrid.ffn2h.%s.y_vs_unfused" % ("train" if train else "eval"), _rel(yf, yu), 2e-4)
+        if not train:
+            seq = ff.sequential
+            xd = x.double()
+            ln = torch.nn.functional.layer_norm(xd, (256,), seq[0].weight.double(), seq[0].bias.double(), seq[0].eps)
+            h = torch.nn.functional.silu(ln @ seq[1].linear.weight.double().t() + seq[1].linear.bias.double())
+            ref = xd + 0.5 * (h @ seq[4].linear.weight.double().t() + seq[4].linear.bias.double())
+            # the hidden activation is an fp16 tensor (2^-12 per element): the module's contribution carries that, the stream itself is f32
+            check("hybrid.ffn2h.eval.y_vs_f64", _rel(yf, ref), 2e-4)
+    finally:
+        runtime.set_precision("bf16")

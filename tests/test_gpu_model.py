@@ -135,7 +135,18 @@ def test_embed_encoder_decoder(prec):
                                                            model=["", "fc"]), 28, prec, call=lambda m, x: m.forward(x))
 
 
-def _check_gradnorms(net, gn, rtol, tag="gradnorm"):
+def _is_stem_param(name):
+    """Parameters of the CNN stem below the frame-patch product (patch_embed.0 ... patch_embed.10: 1x1 / 3x3 convolutions and BatchNorms)."""
+    import re
+    m = re.search(r"patch_embed\.(\d+)\.", name)
+    return m is not None and int(m.group(1)) < 12
+
+
+def _is_cancelling_bias(name):
+    return name.endswith(("attention.u_bias", "attention.v_bias"))
+
+
+def _check_gradnorms(net, gn, rtol, tag="gradnorm", body_rtol=None):
     """Per-parameter gradient L2 norms vs the reference.  Gradients that are analytically zero (e.g. the key-projection
     bias: softmax is invariant to it) are round-off in the reference too, so they get an absolute bound instead."""
     top = max(gn.values())
@@ -147,7 +158,14 @@ def _check_gradnorms(net, gn, rtol, tag="gradnorm"):
         else:
             report.append((abs(got - gn[k]) / gn[k], k))
     worst = max(report)
+    print("GRADNORM top5 %s: %s" % (tag, ", ".join("%s=%.2e" % (k, e) for e, k in sorted(report, reverse=True)[:5])))
+    body = [r for r in report if not _is_stem_param(r[1]) and not _is_cancelling_bias(r[1])]
+    if body:
+        print("GRADNORM top3 of the f32-stream parameters %s: %s" % (tag, ", ".join("%s=%.2e" % (k, e) for e, k in sorted(body, reverse=True)[:3])))
     check("%s[worst=%s]" % (tag, worst[1]), worst[0], rtol)
+    if body_rtol is not None and body:      # hybrid mode: parameters whose gradient flows along the f32 stream (outside the bf16 stem backward
+        wb = max(body)                      # and the attention biases' near-cancelling column sums) at their own, tighter gate
+        check("%s_body[worst=%s]" % (tag, wb[1]), wb[0], body_rtol)
     return worst
 
 
@@ -180,7 +198,7 @@ def _fullsize(prec, mode):
 def _full_tol(prec):
     from sar_ssl_amd.parity import GATES
     g = GATES[prec]
-    return dict(loss=g["loss"], pred=g["per_bin_max"], pred_rms=g["per_bin_rms"], grad=g["grad_norm"], bn=g["bn_running"])
+    return dict(loss=g["loss"], pred=g["per_bin_max"], pred_rms=g["per_bin_rms"], grad=g["grad_norm"], bn=g["bn_running"], grad_body=g.get("grad_norm_body"))
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp32_1pass", "fp16", "hybrid"])
@@ -199,7 +217,7 @@ def test_fullsize_forward_backward(mode, prec):
     check(tag + "pred", ((got - want).abs().max() / float(z[mode + ".pred_absmax"])).item(), tol["pred"])
     check(tag + "pred_rms", ((got - want).pow(2).mean().sqrt() / float(z[mode + ".pred_absmax"])).item(), tol["pred_rms"])
     gn = json.loads(str(z[mode + ".gradnorm_json"]))
-    _check_gradnorms(net, gn, tol["grad"], tag + "gradnorm")
+    _check_gradnorms(net, gn, tol["grad"], tag + "gradnorm", body_rtol=tol["grad_body"])
     if mode == "train":
         sd = net.state_dict()
         for k in ("spec_encoder.patch_embed.4.running_mean", "spec_encoder.patch_embed.4.running_var",
@@ -322,7 +340,7 @@ def test_edge_case_inputs_vs_the_reference(case, prec):
         # 1e7x louder second channel - measured fp16 3.9-4.9e-2 (-40 dB), 1.8e-2 (-60 dB), bf16 5.1e-2 / 4.6e-2 / 8.8e-2 (all-zero reference);
         # gated at 2.5x the mode's usual class there, at the usual class on the clipped recording
         gtol = tol["grad"] * (2.5 if case.startswith("ref_mic") and prec != "fp32" else 1.0)
-        _check_gradnorms(net, json.loads(str(z[case + ".gradnorm_json"])), gtol, tag + "gradnorm")
+        _check_gradnorms(net, json.loads(str(z[case + ".gradnorm_json"])), gtol, tag + "gradnorm", body_rtol=tol["grad_body"])
     finally:
         runtime.set_precision("bf16")
 
