@@ -695,7 +695,8 @@ static int launch_seg(const GemmArgs& g, hipStream_t st) {
     // any K (50.6 vs 59.1 us at K = 1024); with up to two per CU only at K <= 256 (four K-tiles: 34 vs 42 us) - at K = 512 .. 3072 the larger
     // tile's operand reuse wins (N = 512: 64 vs 68 us at K = 512, 106 vs 143 us at K = 2048; the decoder's second layer 127 vs 190 us)
     const long cus = sarssl_cu_count();
-    const int fm = (g.M >= 128 && (wg2 <= cus || (wg2 <= 2 * cus && g.K <= 256))) ? 1 : 2;
+    static const int force_fm = [] { const char* e = getenv("SARSSL_SPLIT_FM"); return e ? atoi(e) : 0; }();      // A/B runs: 1 | 2
+    const int fm = force_fm ? force_fm : ((g.M >= 128 && (wg2 <= cus || (wg2 <= 2 * cus && g.K <= 256))) ? 1 : 2);
     const int bm = 64 * fm;
     const bool vec_ok = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (!g.resid || (g.ldr & 7) == 0);
     const bool edge = (g.M % bm) != 0 || (g.N % BN) != 0 || (g.K % BK) != 0 || !vec_ok;

@@ -159,9 +159,16 @@ class FlatGradAllReduce:
         else:
             self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
-    def finish(self):
+    def finish(self, guard=None):
         """Wait for all outstanding buckets (also reduces every span no stage hook fired for in this step, e.g. 'other' parameters
-        not owned by a stage).  Returns the gradient scale (1/world) to fold into the optimizer step."""
+        not owned by a stage).  Returns the gradient scale (1/world) to fold into the optimizer step.
+
+        guard (optional, f32 device tensor of one element holding this rank's loss): summed over the ranks IN PLACE next to the buckets,
+        so that every rank's guarded optimizer launch sees the same value - a non-finite loss on ANY rank (its fp16 forward overflowed)
+        makes the sum non-finite everywhere and all replicas skip the step together.  Deciding on the local loss would let the ranks
+        disagree: the one that overflowed skips, the others apply an update averaged over a gradient that contains its garbage, and the
+        replicas drift apart for good (parameters are broadcast only once).  The reference's GradScaler decides once, on the gradients
+        of its single process (code/learner.py:105-108)."""
         bad = {}
         if self.strict and not self._closed:
             bad = {n: self._calls.get(n, 0) for n in self.spans if n in STAGES and self._calls.get(n, 0) != 1}
@@ -171,6 +178,9 @@ class FlatGradAllReduce:
                 for name, (s, e) in sorted(self.spans.items(), key=lambda kv: kv[1]):
                     if name not in self._fired:
                         self._reduce(self.flat.grad[s:e])
+                if guard is not None and self.world > 1:
+                    assert guard.numel() == 1 and guard.dtype == torch.float32
+                    self._reduce(guard)
             for h in self.handles:
                 h.wait()
             if self.native is not None:

@@ -57,6 +57,7 @@ class PretrainStepGraph:
         self._pool = None
         self._stage = []          # ring of (pinned staging buffer, event) for the masks
         self._stage_i = 0
+        self.guard = torch.zeros(1, dtype=torch.float32, device=self.dev)      # data parallel: the ranks' summed loss = the optimizer launch's guard
         self.zero_grad_in_adam = True     # optimizer.zero_grad() folded into the Adam pass (tests switch it off to read the gradient)
 
     # ------------------------------------------------------------------------------------------------ optimizer interface
@@ -133,6 +134,10 @@ class PretrainStepGraph:
             net.__dict__.pop("_loss_grad_with_forward", None)
             net.__dict__.pop("_premasked", None)
             net.__dict__.pop("_prep_event", None)
+        if with_adam and self.reducer is not None and self.reducer.world > 1:
+            # data parallel: this rank's loss goes into the guard word that dist.FlatGradAllReduce.finish sums over the ranks in front of
+            # the optimizer launch (copied HERE, in the step's first graph segment - the exchange runs between the later segments)
+            self.guard.copy_(self.out[:1])
         self.pred, self.xin, self.vis_masks = pred, x, (mp, ch)
         self.ecat = net.__dict__.pop("_last_ecat", None)      # compact decoder path: the decoder's input of every frame (for vis)
         _PretrainFn.backward(ctx, self.one, None, None)
@@ -140,15 +145,18 @@ class PretrainStepGraph:
             return
         world = self.reducer.world if self.reducer is not None else 1
         in_graph = self._exchange_in_graph()
+        # more than one rank: the guard of the optimizer launch is the SUM of the ranks' losses (exchanged next to the buckets), so that all
+        # replicas skip a step together when any rank's forward overflowed (dist.FlatGradAllReduce.finish)
+        guard = self.guard if world > 1 else self.out      # (self.guard: copied from the loss right behind the forward pass, see above)
         if seg is not None and not in_graph:
             if self.reducer is not None and (self.reducer.exchange or getattr(self.reducer, "native", None) is not None):
                 seg.cut(("finish", None))
         elif self.reducer is not None:                     # (native exchange under capture: the join with the communication stream becomes a graph edge)
-            self.reducer.finish()                          # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
+            self.reducer.finish(guard=self.guard if world > 1 else None)      # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
         # guard = the step's loss: a forward that overflowed fp16 (non-finite loss) leaves parameters and moments alone - the reference's
         # GradScaler skips such a step too (code/learner.py:105-108); decided on the device, counted in the step state
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
-                          zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16, guard=self.out)
+                          zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16, guard=guard)
         self.flat.refresh_lo()            # hybrid mode: the weights' fp16 lo shadow follows (a launch of the captured step)
 
     def _exchange_in_graph(self):
@@ -272,8 +280,8 @@ class PretrainStepGraph:
                 item.replay()
             elif kind == "reduce":
                 self.reducer._on_stage(item)
-            else:                                           # "finish": wait for the buckets (stream-side for RCCL)
-                self.reducer.finish()
+            else:                                           # "finish": wait for the buckets (stream-side for RCCL) + the collective guard
+                self.reducer.finish(guard=self.guard if self.reducer.world > 1 else None)
         runtime.bump_version()                             # weights moved: eager users of the re-laid-out caches must rebuild
         self.nsteps += 1
         return self.out

@@ -91,12 +91,14 @@ class Learner(ABC):
                 self.model.__dict__["_full_pred_once"] = True
             loss_batch, diff_batch, vis_batch = self.model(in_batch)
             loss_batch.backward()
-            gscale = self._reducer.finish() if self._reducer is not None else 1.0
-            # (16-bit modes: a non-finite loss - an fp16 forward that overflowed - skips the update on the device, like GradScaler.step)
-            optimizer.step(grad_scale=gscale, guard=loss_batch.detach() if (self.use_amp and loss_batch.dtype == torch.float32) else None)
+            # (16-bit modes: a non-finite loss - an fp16 forward that overflowed - skips the update on the device, like GradScaler.step;
+            #  data parallel: the guard is the sum of the ranks' losses, exchanged with the buckets - every replica takes the same decision)
+            guard = loss_batch.detach().clone().reshape(1) if (self.use_amp and loss_batch.dtype == torch.float32) else None
+            gscale = self._reducer.finish(guard=guard) if self._reducer is not None else 1.0
+            optimizer.step(grad_scale=gscale, guard=guard)
             optimizer.zero_grad()
             if self.use_amp:                                                                # a skipped step is not part of the epoch mean
-                ok = torch.isfinite(loss_batch.detach())
+                ok = torch.isfinite(guard[0]) if guard is not None else torch.isfinite(loss_batch.detach())
                 acc[0] += torch.where(ok, loss_batch.detach().double(), acc.new_zeros(()))
                 acc[1] += torch.where(ok, diff_batch.detach().double(), acc.new_zeros(()))
             else:

@@ -65,6 +65,15 @@ def _worker(rank, world, port, q):
         red2.finish()
         ok2 = ok2 and float(flat2.grad.min()) == float(flat2.grad.max()) == 3.0
     ok2 = ok2 and red2.order == ["decoder", "spat_encoder", "spec_encoder"] and red2.nsteps == 2      # (order: the last step's)
+    # the optimizer launch's guard is a collective decision (round-5 advisor finding): finish(guard=...) sums the ranks' losses in place -
+    # a non-finite loss on ONE rank makes the guard non-finite on EVERY rank, finite losses give the same finite value everywhere
+    for step, mine in enumerate((float(rank + 1), float("nan") if rank == 1 else 2.0, float("inf") if rank == 0 else 1.0)):
+        flat2.grad.fill_(1.0)
+        for stage in ("decoder", "spat_encoder", "spec_encoder", "stem_bwd_begin"):
+            net2._hook(stage)
+        guard = torch.tensor([mine], dtype=torch.float32)
+        red2.finish(guard=guard)
+        ok2 = ok2 and ((float(guard[0]) == 3.0) if step == 0 else (not bool(torch.isfinite(guard[0]))))
     # BatchNorm buffers / validation scalars follow rank 0 (run_pretrain.py)
     bn = torch.nn.BatchNorm1d(3)
     bn.running_mean.fill_(float(rank + 1)); bn.num_batches_tracked.fill_(rank + 5)

@@ -360,6 +360,27 @@ def test_two_rank_overlapped_allreduce_equals_full_batch_gradient(two_streams):
     check("dp2.grad_vs_full_batch.streams%s" % two_streams, out["max_rel_err"], 2e-5)
 
 
+@pytest.mark.parametrize("form", ["captured", "eager"])
+def test_two_rank_overflow_on_one_rank_skips_the_step_on_every_rank(form):
+    """Advisor finding (round 5): the skip-on-non-finite-loss guard of the optimizer launch read each rank's LOCAL loss - with more than one
+    rank the replicas could disagree about skipping a step and drift apart for good.  The guard is now exchanged next to the gradient
+    buckets (dist.FlatGradAllReduce.finish(guard=...)): tests/dp_guard_check.py runs three steps on 2 ranks, the second with an input
+    that overflows fp16 on rank 1 only, and reports whether every rank skipped it and the replicas stayed bit-identical."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SARSSL_DIST_BACKEND="gloo", DPGUARD_FORM=form)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dp_guard_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["world"] == 2 and out["form"] == form
+    assert out["losses_per_rank"][1][1] is None and out["losses_per_rank"][0][1] is not None      # only rank 1's forward overflowed
+    assert out["skipped_per_rank"] == [1, 1], out
+    assert out["replicas_identical_after_each_step"] == [True, True, True], out
+    assert out["step2_left_parameters_and_moments_untouched_on_rank0"] and out["step3_moved_parameters"], out
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_two_rank_training_mode_batchnorm_step_vs_per_replica_oracle(prec):
     """Round-3 verdict 6a: the data-parallel step in TRAIN mode (per-rank BatchNorm statistics, like the reference's DataParallel
