@@ -301,7 +301,7 @@ class PretrainStepGraph:
             from .model import _full_pred_fn
             e = self.ecat
             e = tuple(t.clone() if torch.is_tensor(t) else t for t in e) if isinstance(e, tuple) else e.clone()
-            pred = _full_pred_fn(e, self.net.decoder, self.net)
+            pred = _full_pred_fn(e, self.net.decoder, self.net, step_rows=(pred, self.idx.clone(), self.B, self.T))     # the step's own rows at the masked frames
         return LazyVis(pred, self.xin.clone(), self.vis_masks[0].clone(), self.vis_masks[1].clone())
 
 

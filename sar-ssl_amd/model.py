@@ -445,8 +445,8 @@ class SARSSL(nn.Module):
                 finally:
                     RT.inference = False
             ecat = self.__dict__.pop("_last_ecat", None)
-            if ecat is not None:        # compact training step: vis["pred"] = the decoder on every frame of this step's decoder input, on request
-                pred = _full_pred_fn(ecat, self.decoder, self)
+            if ecat is not None:        # compact training step: vis["pred"] = the decoder on every frame of this step's decoder input, on request,
+                pred = _full_pred_fn(ecat, self.decoder, self, step_rows=(pred.detach(), idx, nbatch, nt))      # with the step's own rows at the masked frames
             return loss, out[1], LazyVis(pred, x, mp, ch)
         # ---- downstream branch (code/model.py:667-719): both encoders on the unmasked input, mean over frames, MLP head
         B, T, F = nbatch, nt, nf
@@ -467,11 +467,13 @@ class SARSSL(nn.Module):
         return head(pooled), pooled
 
 
-def _full_pred_fn(ecat, dec, net=None):
+def _full_pred_fn(ecat, dec, net=None, step_rows=None):
     """The decoder on every frame of a step's decoder input, in the numeric mode of that step (the caller may have switched modes since).
     ecat = ("tails", x_spec, x_spat, ds, dt, train): the step also ran the tails of the encoders' last blocks on the masked frames only -
-    they are run on every row first (train mode with dropout: fresh masks - a training step's vis is for plotting; the learner runs the
-    batch whose vis it returns without any of this)."""
+    they are run on every row first.  step_rows = (pred_c [B * nm, F * 4], idx [B, nm], B, T): the step's OWN prediction at the masked
+    frames (the rows its decoder did run on) is written over the re-formed rows, so vis["pred"] at every frame that entered the loss is
+    the step's prediction bit for bit - with dropout on as well (code/model.py:595-599 clones the step's pred); the unmasked frames,
+    which no loss ever reads, are a second draw of the row-wise layers' dropout masks (the compact step never computed them)."""
     from . import runtime
     prec = runtime.get_precision()
 
@@ -486,8 +488,15 @@ def _full_pred_fn(ecat, dec, net=None):
                     full = torch.empty((xs.shape[0], ds + dt_), dtype=xs.dtype, device=xs.device)
                     engine.block_tail_full(xs, net.spec_encoder.embed.layers[-1], train, out=full[:, :ds])
                     engine.block_tail_full(xt, net.spat_encoder.embed.layers[-1], train, out=full[:, ds:])
-                    return engine.decoder_fwd(full, dec, [])
-                return engine.decoder_fwd(ecat, dec, [])
+                    pred = engine.decoder_fwd(full, dec, [])
+                else:
+                    pred = engine.decoder_fwd(ecat, dec, [])
+                if step_rows is not None:          # (pure data movement on a plotting path: torch indexing)
+                    pc, idx, B, T = step_rows
+                    pred = pred.clone()
+                    rows = (torch.arange(B, device=idx.device, dtype=torch.long)[:, None] * T + idx.long()).reshape(-1)
+                    pred.view(B * T, -1).index_copy_(0, rows, pc.reshape(rows.numel(), -1).to(pred.dtype))
+                return pred
         finally:
             RT.inference = keep
             runtime.set_precision(now)

@@ -21,7 +21,7 @@ class opt_pretrain():
         p.add_argument("--bs", type=int, nargs="+", default=[128, 128, 128], metavar="TrainValTestBatch",
                        help="batch size for training, validation and test (default: [128, 128, 128])")
         p.add_argument("--no-cuda", action="store_true", default=False, help="disables CUDA training (default: False)")
-        p.add_argument("--use-amp", action="store_true", default=False, help="Use mixed precision (bf16 on MI355X)")
+        p.add_argument("--use-amp", action="store_true", default=False, help="Use mixed precision (MI355X: the 'hybrid' mode - fp16 stem, f32 residual stream; SARSSL_AMP_DTYPE=fp16|bf16 selects the others)")
         p.add_argument("--seed", type=int, default=1, metavar="Seed", help="random seed (default: 1)")
         p.add_argument("--checkpoint-start", action="store_true", default=False, help="train model from saved latest checkpoints")
         p.add_argument("--checkpoint-from-best-epoch", action="store_true", default=False, help="train model from saved best checkpoints")
@@ -74,7 +74,7 @@ class opt_downstream():
         p.add_argument("--gpu-id", type=str, default="6,", metavar="GPU", help="GPU ID")
         p.add_argument("--workers", type=int, default=4, metavar="Worker", help="number of workers (default: 4)")
         p.add_argument("--no-cuda", action="store_true", default=False)
-        p.add_argument("--use-amp", action="store_true", default=False, help="bf16 storage / MFMA inputs")
+        p.add_argument("--use-amp", action="store_true", default=False, help="mixed precision (the 'hybrid' mode; SARSSL_AMP_DTYPE=fp16|bf16 selects the others)")
         p.add_argument("--seed", type=int, default=1, metavar="Seed")
         p.add_argument("--checkpoint-start", action="store_true", default=False)
         p.add_argument("--time", type=str, default=self.time, metavar="Time")

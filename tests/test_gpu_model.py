@@ -452,5 +452,28 @@ def test_decoder_on_the_masked_frames_only_equals_the_full_decoder(prec, monkeyp
             assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
             check("dec_masked.%s.%s.grad_rel_l2" % (prec, key), float((a[2] - b[2]).norm() / b[2].norm()), 2e-3)
             check("dec_masked.%s.%s.grad_max_over_max" % (prec, key), float((a[2] - b[2]).abs().max() / b[2].abs().max()), 5e-3)
+        # dropout ON (round-5 verdict): vis["pred"] of a compact training step at the frames that entered the loss is the step's OWN
+        # prediction - the rows its decoder ran on - bit for bit (the reference clones the step's pred, code/model.py:595-599); the loss of
+        # those very rows is the returned loss
+        for masked in (True, "decoder_only"):
+            monkeypatch.setattr(engine, "_DEC_MASKED", True)
+            monkeypatch.setattr(engine, "_TAIL_MASKED", masked is True)
+            torch.manual_seed(9)
+            net = model.SARSSL(sig_shape=(256, T, 2, 2), pretrain=True, device=dev)
+            net.to(dev).train()                                        # dropout 0.1 everywhere
+            runtime.FlatParams(net)
+            runtime.RT.manual_seed(77)
+            net.set_masks(idx, ch)
+            x = hip.stft_frontend(sig)
+            loss, diff, vis = net(x)
+            pv = vis["pred"]                                           # (B, F, T, reim, mic), formed now
+            sidx = torch.from_numpy(np.sort(idx, axis=1)).to(dev)
+            mch = torch.from_numpy(ch).to(dev)
+            got = pv.permute(0, 2, 1, 3, 4)[torch.arange(B, device=dev)[:, None], sidx]           # (B, nm, F, reim, mic)
+            got = got[torch.arange(B, device=dev), :, :, :, mch]                                   # masked channel: (B, nm, F, reim)
+            tar = x.permute(0, 3, 2, 4, 1)[torch.arange(B, device=dev)[:, None], sidx]            # x (B,mic,F,T,reim) -> (B, nm, F, reim, mic)
+            tar = tar[torch.arange(B, device=dev), :, :, :, mch]
+            relo = abs(float(((got.float() - tar.float()) ** 2).mean()) / float(loss) - 1)
+            check("dec_masked.%s.%s.dropout_on.loss_of_vis_rows_vs_step_loss" % (prec, masked), relo, 1e-5 if prec != "bf16" else 1e-4)
     finally:
         runtime.set_precision("bf16")

@@ -31,12 +31,12 @@ def test_frontend_all_pairs_mode_mm():
     assert _relerr(out_i, hip.stft_frontend(pcm.float() / 32768.0, ch_mode="MM").cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "hybrid"])
 def test_config5_ten_second_four_mic_segment(prec):
     """T = 624 is not a multiple of the conv tile (64) or the GEMM tile: ragged tiles everywhere."""
     from sar_ssl_amd import hip, model, runtime
     z = _z()
-    tol = {"fp32": (1e-3, 1e-3, 5e-3), "bf16": (1e-3, 3e-2, 6e-2), "fp16": (1e-3, 4e-3, 4e-2)}[prec]       # bf16: 3-5x measured (5.3e-5, 1.0e-2, 1.9e-2)
+    tol = {"fp32": (1e-3, 1e-3, 5e-3), "bf16": (1e-3, 3e-2, 6e-2), "fp16": (1e-3, 4e-3, 4e-2), "hybrid": (1e-3, 4e-3, 4e-2)}[prec]       # bf16: 3-5x measured (5.3e-5, 1.0e-2, 1.9e-2)
     runtime.set_precision(prec)
     try:
         man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
