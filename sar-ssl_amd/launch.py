@@ -67,11 +67,25 @@ def spawn_ranks(script, argv, nproc, gpu_ids=None, poll_s=0.2, grace_s=10.0):
     assert nproc >= 1
     envs = rank_envs(nproc, gpu_ids)
     procs = []
-    for r, e in enumerate(envs):
-        out = None if r == 0 else sys.stderr                     # rank 0 owns stdout
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e, stdout=out, stdin=subprocess.DEVNULL))
+    # a SIGTERM / SIGHUP to the parent (scheduler kill, timeout(1), closed terminal) must reach the ranks: they hold GPUs and may sit in a
+    # collective for ever (advisor, round 5) - the handlers turn the signal into an exception the finally block below acts on
+    class _Stop(Exception):
+        pass
+
+    def _on_signal(signum, frame):
+        raise _Stop(signum)
+    old_handlers = {}
+    for sg in (signal.SIGTERM, getattr(signal, "SIGHUP", None)):
+        if sg is not None:
+            try:
+                old_handlers[sg] = signal.signal(sg, _on_signal)
+            except (ValueError, OSError):                        # (not the main thread: leave the default disposition)
+                pass
     worst = 0
     try:
+        for r, e in enumerate(envs):
+            out = None if r == 0 else sys.stderr                 # rank 0 owns stdout
+            procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e, stdout=out, stdin=subprocess.DEVNULL))
         alive = set(range(nproc))
         while alive:
             for r in sorted(alive):
@@ -95,14 +109,25 @@ def spawn_ranks(script, argv, nproc, gpu_ids=None, poll_s=0.2, grace_s=10.0):
                     break
             if alive:
                 time.sleep(poll_s)
-    except KeyboardInterrupt:
+    except (KeyboardInterrupt, _Stop) as stop:
+        sig = signal.SIGINT if isinstance(stop, KeyboardInterrupt) else signal.SIGTERM
         for p in procs:
             if p.poll() is None:
-                p.send_signal(signal.SIGINT)
+                p.send_signal(sig)
+        worst = worst or (130 if sig == signal.SIGINT else 143)
+    finally:
+        # whatever ends the parent - normal return, a signal, an exception - no rank survives it
+        deadline = time.time() + grace_s
         for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        for sg, h in old_handlers.items():
             try:
-                p.wait(timeout=grace_s)
-            except subprocess.TimeoutExpired:
-                p.kill()
-        worst = worst or 130
+                signal.signal(sg, h)
+            except (ValueError, OSError):
+                pass
     return worst

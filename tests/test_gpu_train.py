@@ -295,14 +295,24 @@ def test_run_pretrain_with_two_gpu_ids_trains_with_two_ranks(tmp_path):
     assert (logd / "latest_model.tar").exists() and r.stdout.count("Pre-Training finished") == 1          # rank 0 only
 
 
-def test_two_rank_bench_path_over_gloo():
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_two_rank_bench_path_over_gloo(launcher):
     """The data-parallel step (stage hooks, bucketed all-reduce, max-over-ranks timing) with 2 ranks sharing this GPU over gloo -
-    a functional check of the code path the 8-GPU RCCL run uses (RCCL itself needs one GPU per rank)."""
+    a functional check of the code path the 8-GPU RCCL run uses (RCCL itself needs one GPU per rank).  launcher 'self': plain
+    `python bench.py --gpus 2`, which starts its own two ranks (sar_ssl_amd/launch.py) and forwards rank 0's single line - the form the
+    first multi-GPU run will take; the line documents that run: four buckets, their all-reduce times, the overlap check."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SARSSL_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    else:
+        env["MASTER_PORT"] = str(port)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -314,6 +324,9 @@ def test_two_rank_bench_path_over_gloo():
     assert d["world"] == 2 and d["backend"] == "gloo" and [b["name"] for b in d["buckets"]] == ["decoder", "spat_encoder", "spec_encoder", "stems"]
     assert sum(b["bytes"] for b in d["buckets"]) > 70e6 and all(b["allreduce_ms_alone"] > 0 for b in d["buckets"])
     assert d["steps_seen_by_reducer"] >= 3 and out["knobs"]["SARSSL_C1IN"] == 1
+    oc = d["overlap_check"]
+    assert "error" not in oc and oc["stem_backward_window_ms_min_over_ranks"] > 0 and oc["allreduce_ms_alone_of_the_buckets_issued_before_it"] > 0
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1          # exactly one JSON line on stdout
 
 
 @pytest.mark.parametrize("mode", ["eager", "graph"])

@@ -79,3 +79,31 @@ def test_run_pretrain_with_several_gpu_ids_spawns_one_rank_per_id(monkeypatch):
     except SystemExit as e:
         assert "needs an MI355X GPU" in str(e.code)
     assert len(calls) == 1
+
+
+def test_sigterm_to_the_parent_stops_every_rank(tmp_path):
+    """Advisor (round 5): a SIGTERM / SIGHUP to the parent (scheduler kill, timeout(1)) left the ranks running - holding GPUs, possibly
+    inside a collective.  The parent now forwards the signal and reaps its children whatever ends it."""
+    import signal
+    import time
+    child = tmp_path / "rank.py"
+    child.write_text("import os, sys, time\nopen(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(120)\n" % str(tmp_path))
+    parent = tmp_path / "parent.py"
+    parent.write_text("import sys\nsys.path.insert(0, %r)\nimport sarssl_boot\nfrom sar_ssl_amd import launch\nsys.exit(launch.spawn_ranks(%r, [], 2, grace_s=5.0))\n"
+                      % (ROOT, str(child)))
+    p = subprocess.Popen([sys.executable, str(parent)], env=_clean_env(), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / ("pid%d" % r)).exists() and (tmp_path / ("pid%d" % r)).read_text() for r in (0, 1)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid%d" % r)).read_text()) for r in (0, 1)]
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=30)
+    assert rc == 143, rc
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except OSError:
+            alive = False
+        assert not alive, "rank process %d survived its parent" % pid

@@ -192,6 +192,47 @@ def main():
               0, 2.0 * 4 * Mr * d)
         group(tag + 4, "layernorm_bwd d=%d (+resid, dgamma/dbeta, dropout output)" % d,
               lambda: hip.layernorm_bwd(dyy, xx, gam, st, resid=rr, dgamma=gg, dbeta=gb, drop=(0.1, 3, 0.5)), 0, 2.0 * 5 * Mr * d)
+    # ---- hybrid numeric mode (round 6): fp16-pair products, LayerNorm -> pair, LayerNorm backward on the f32 stream, fused feed-forward
+    if AD == torch.float16:
+        f32 = torch.float32
+        for tag, (M_, N_, K_, nseg, odt, lbl) in ((80, (Mr, 1024, 256, 3, AD, "ffn1 d=256 (3 products; +bias,swish,preact,dropout -> fp16)")),
+                                                  (81, (Mr, 256, 1024, 2, f32, "ffn2 d=256 (2 products; +bias,dropout,f32 resid -> f32)")),
+                                                  (82, (Mr, 2048, 512, 3, AD, "ffn1 d=512 (3 products -> fp16)")),
+                                                  (83, (Mr, 512, 2048, 2, f32, "ffn2 d=512 (2 products, f32 resid -> f32)")),
+                                                  (84, (Mr // 2, 3072, 768, 3, AD, "decoder layer 1 on the masked rows (3 products, relu -> fp16)")),
+                                                  (85, (Mr // 2, 1024, 3072, 2, f32, "decoder layer 2 on the masked rows (2 products -> f32)"))):
+            xa = hip.split_pair(torch.randn((M_, K_), device=dev))
+            wp = hip.split_pair(torch.randn((N_, K_), device=dev) * K_ ** -0.5)
+            A_ = xa if nseg == 3 else xa.hi
+            o_ = torch.empty((M_, N_), dtype=odt, device=dev)
+            kw = dict(bias=bias[:N_])
+            if odt == f32:
+                kw.update(resid=torch.randn((M_, N_), device=dev), ldr=N_, p_drop=0.1, seed=9, out_scale=0.5)
+            elif tag in (80, 82):
+                kw.update(act=2, preact=torch.empty((M_, N_), dtype=AD, device=dev), p_drop=0.1, seed=7)
+            else:
+                kw.update(act=1)
+            osz = 4 if odt == f32 else 2
+            group(tag, "gemm_split " + lbl, lambda: hip.gemm_split(A_, wp.hi, wp.lo, M=M_, N=N_, K=K_, out=o_, **kw),
+                  2.0 * M_ * N_ * K_ * nseg, 2.0 * ((nseg - 1) * M_ * K_ + 2 * N_ * K_) + osz * M_ * N_ * (2 if (odt == f32 or tag in (80, 82)) else 1))
+        dd, Hh = 256, 1024
+        W1 = hip.split_pair(torch.randn((Hh, dd), device=dev) * dd ** -0.5); W2 = hip.split_pair(torch.randn((dd, Hh), device=dev) * Hh ** -0.5)
+        pk = [torch.empty(Hh * dd, dtype=AD, device=dev) for _ in range(4)]
+        hip.ffn_pack([(W1.hi, pk[0]), (W1.lo, pk[1]), (W2.hi, pk[2]), (W2.lo, pk[3])])
+        xs = torch.randn((Mr, dd), device=dev)
+        gam, bet = torch.ones(dd, device=dev), torch.zeros(dd, device=dev)
+        group(86, "ffn2h fused forward d=256 on the f32 stream (LayerNorm + 3 / 2 products; pre-activation + hidden + LN hi saved)",
+              lambda: hip.ffn2h_fwd(xs, gam, bet, 1e-5, pk[0], pk[1], pk[2], pk[3], bias[:Hh], bias[:dd], dd, p1=0.1, s1=7, p2=0.1, s2=9, out_scale=0.5),
+              2.0 * Mr * dd * Hh * 5, 4.0 * 2 * Mr * dd + 2.0 * (Mr * dd + 2 * Mr * Hh))
+        for tag, d in ((90, 256), (92, 512)):
+            xx = torch.randn((Mr, d), device=dev)
+            gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+            gg, gb = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+            _, st = hip.layernorm_fwd_pair(xx, gam, bet)
+            dyb, rr = rnd(Mr, d, dtype=GD), torch.randn((Mr, d), device=dev)
+            group(tag, "layernorm_fwd_pair d=%d (f32 rows -> fp16 hi + lo)" % d, lambda: hip.layernorm_fwd_pair(xx, gam, bet), 0, (4.0 + 4.0) * Mr * d)
+            group(tag + 1, "layernorm_bwd_stream d=%d (bf16 branch gradient, f32 x / resid / dx, bf16 dropped copy)" % d,
+                  lambda: hip.layernorm_bwd_stream(dyb, xx, gam, st, resid=rr, dgamma=gg, dbeta=gb, drop=(0.1, 3, 0.5)), 0, (2.0 + 4 + 4 + 4 + 2) * Mr * d)
     # ---- fp8 GEMM (csrc/gemm_fp8.hip)
     for tag, (M_, N_, K_) in ((60, (Mr, 2048, 512)), (61, (Mr, 1024, 3072))):
         A = rnd(M_, K_, dtype=GD); Bm = rnd(N_, K_, scale=0.05, dtype=GD)
