@@ -21,47 +21,17 @@ RELU, SWISH = 1, 2
 
 
 # ------------------------------------------------------------------------------------------------ GEMM helpers
-_FP8_KW = {"out", "ldc", "bias", "act", "preact", "aux", "aux_act", "p_drop", "seed", "out_scale", "resid", "ldr", "res_scale", "alpha"}
-_fp8_wcache = {}
-
-
-def _fp8_weight(W, transposed):
-    """fp8 copy (+ device-resident dequantisation scale) of a bf16 weight view [N, K] - as is for the forward GEMM, transposed
-    ([K, N]) for the input-gradient GEMM; cached until the weights change."""
-    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transposed)
-    ver = weights_version()
-    hit = _fp8_wcache.get(key)
-    if hit is None or hit[0] != ver:
-        if len(_fp8_wcache) > 512:
-            _fp8_wcache.clear()
-        hit = (ver,) + hip.fp8_quantize(W, transpose=transposed)
-        _fp8_wcache[key] = hit
-    return hit[1], hit[2]
-
-
-def _fp8_ok(x, W, kw):
-    return (RT.fp8 and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.dim() == 2 and W.dim() == 2 and x.stride(1) == 1
-            and W.stride(1) == 1 and x.stride(0) % 8 == 0 and W.stride(0) % 8 == 0 and x.shape[1] % 16 == 0 and W.shape[0] % 16 == 0
-            and set(kw) <= _FP8_KW)
-
-
-def mm_nt(x, W, fp8=True, **kw):
-    """x [M,K] @ W[N,K]^T -> [M,N]   (nn.Linear forward)."""
+def mm_nt(x, W, fp8=False, **kw):
+    """x [M,K] @ W[N,K]^T -> [M,N]   (nn.Linear forward).  (``fp8``: accepted and ignored - the whole-step fp8 mode of rounds 2-5 was removed
+    in round 6: its just-in-time quantisation made the step 7-12 % slower than bf16; the e4m3 GEMM kernels remain library entry points,
+    hip.gemm_fp8 / tests/test_gpu_fp8.py.)"""
     M, K = x.shape
-    if fp8 and _fp8_ok(x, W, kw):
-        xq, sx = hip.fp8_quantize(x)
-        wq, sw = _fp8_weight(W, False)
-        return hip.gemm_fp8(xq, sx, wq, sw, M=M, N=W.shape[0], K=K, **kw)
     return hip.gemm(x, W, M=M, N=W.shape[0], K=K, lda=x.stride(0), ldb=W.stride(0), precise=RT.precise, **kw)
 
 
-def mm_nn(dy, W, fp8=True, **kw):
+def mm_nn(dy, W, fp8=False, **kw):
     """dy [M,N] @ W[N,K] -> [M,K]   (input gradient of nn.Linear)."""
     M, N = dy.shape
-    if fp8 and _fp8_ok(dy, W, kw) and W.shape[1] % 8 == 0:
-        dq, sd = hip.fp8_quantize(dy)
-        wtq, swt = _fp8_weight(W, True)                                       # [K, N]: contraction index contiguous
-        return hip.gemm_fp8(dq, sd, wtq, swt, M=M, N=W.shape[1], K=N, **kw)
     return hip.gemm(dy, W, a_kc=True, b_kc=False, M=M, N=W.shape[1], K=N, lda=dy.stride(0), ldb=W.stride(0),
                     precise=RT.precise, **kw)
 
@@ -627,7 +597,7 @@ def ffn_fwd(x, ff, factor, train, saved, out=None):
     pre = x.__dict__.pop("_pre_ln", None)            # (block_fwd of the previous block already normalised this very tensor for us)
     p1, p2 = _p(seq[3], train), _p(seq[5], train)
     d = x.shape[1]
-    fused = (_FFN2 and d in _FFN2_FWD and not _replaying(train) and not RT.fp8 and hip.ffn2_supported(x.shape[0], d, x.dtype)
+    fused = (_FFN2 and d in _FFN2_FWD and not _replaying(train) and hip.ffn2_supported(x.shape[0], d, x.dtype)
              and seq[1].linear.weight.shape[0] == 4 * d)
     if pre is not None and pre[0] is seq[0]:
         ln, stats = pre[1], pre[2]
@@ -708,7 +678,7 @@ def ffn_bwd(dy, ff, saved, dy_dropped=None, next_kind=None):
             dz2 = hip.act_bwd(dy, None, 0, p_drop=p2, seed=s2, gscale=factor) if (p2 > 0 or factor != 1.0) else dy
         mm_tn_acc(dz2, a, gbuf(seq[4].linear.weight), bias=gbuf(seq[4].linear.bias))
         d = x.shape[1]
-        if (_FFN2 and d in _FFN2_BWD and not RT.fp8 and dz2.dtype in _16 and dz2.stride(1) == 1 and hip.ffn2_supported(x.shape[0], d, dz2.dtype)
+        if (_FFN2 and d in _FFN2_BWD and dz2.dtype in _16 and dz2.stride(1) == 1 and hip.ffn2_supported(x.shape[0], d, dz2.dtype)
                 and hpre.shape[1] == 4 * d and ff.__dict__.get("_ffn2_packs") is not None and ff.__dict__["_ffn2_packs"][0][5]):
             # both data-gradient products in one launch: dh = (dz2 W2) * mask * swish'(hpre) leaves the chip once (the two weight-gradient
             # products read it), dln = dh W1 is formed from the LDS-resident tile (csrc/ffn2.hip, packs of the transposed weights)
@@ -753,7 +723,7 @@ def prepare_step_weights(net, F, T, need_bwd=True):
     masking launches run (a dozen 5-20 us launches that otherwise sit in the two encoders' chains).  The point-of-use helpers
     (_taps, _patch_w, _pos_proj, _ffn_packs) then hit their caches."""
     encs = (net.spec_encoder, net.spat_encoder)
-    if _FFN2 and RT.dtype in _16 and not RT.fp8 and RT.replay is None:
+    if _FFN2 and RT.dtype in _16 and RT.replay is None:
         # fragment-order packs of every feed-forward module's weights for the fused kernel: one launch per step
         prepare_ffn_packs(block_ffns(encs[0].embed) + block_ffns(encs[1].embed), need_bwd=need_bwd)
         if _LIN256:
@@ -894,7 +864,7 @@ def mhsa_fwd(x, mod, B, T, train, saved):
     if RT.hybrid:
         return _mhsa_fwd_h(x, mod, B, T, train, saved)
     fused = _qkv_views(att)
-    lin = (_LIN256 and fused is not None and d == 256 and not RT.fp8 and not _replaying(train) and x.stride(1) == 1
+    lin = (_LIN256 and fused is not None and d == 256 and not _replaying(train) and x.stride(1) == 1
            and hip.lin256_supported(M, 3 * d, d, x.dtype))
     pk = _lin256_pack(mod, "qkv", need_bwd=not RT.inference) if lin else None
     if pk is not None:      # LayerNorm + the [M, 3d] projection in one tile-resident launch (csrc/lin256.hip)
@@ -1098,7 +1068,7 @@ def convmod_fwd(x, cm, B, T, train, saved):
     hyb = RT.hybrid
     if hyb:
         x = _as_stream(x)
-    lin = (_LIN256 and not hyb and d == 256 and not RT.fp8 and not _replaying(train) and x.stride(1) == 1 and hip.lin256_supported(x.shape[0], 2 * d, d, x.dtype))
+    lin = (_LIN256 and not hyb and d == 256 and not _replaying(train) and x.stride(1) == 1 and hip.lin256_supported(x.shape[0], 2 * d, d, x.dtype))
     pk = _lin256_pack(cm, "pw1", need_bwd=not RT.inference) if lin else None
     if hyb:                 # f32 stream in / out; the module's inner tensors (h, c, s) are the fp16 tensors of the fp16 mode
         lnp, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
@@ -1265,8 +1235,7 @@ def encoder_bwd(dy, enc, saved):
 
 # ------------------------------------------------------------------------------------------------ decoder + loss
 def decoder_fwd(e, dec, saved):
-    """EmbedDecoder ['','fc'] (code/model.py:295-301, 321-334): Linear -> ReLU -> Linear.  Stays in bf16 in 'fp8' mode: it produces
-    the predicted spectrogram itself, and config 5 names the attention / FFN GEMMs only."""
+    """EmbedDecoder ['','fc'] (code/model.py:295-301, 321-334): Linear -> ReLU -> Linear."""
     l1, l2 = dec.proj[0], dec.proj[2]
     if RT.hybrid:           # f32 decoder input as an fp16 pair, fp16 hidden layer, f32 prediction
         ep = e if isinstance(e, hip.Pair) else hip.split_pair(_as_stream(e).contiguous())

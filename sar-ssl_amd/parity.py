@@ -48,9 +48,6 @@ GATES = {
 
 def parity_class(precision):
     """What bench.py prints for the timed mode."""
-    if precision == "fp8":
-        return {"loss_vs_bf16_path": 2e-3, "per_bin_pred_of_range": 0.15, "status": "parity only (slower than bf16 on this model, NOTES.md 4.5)",
-                "pinned_by": "tests/test_gpu_fp8.py (against the bf16 path)"}
     g = GATES[precision]
     return {"loss_vs_reference": g["loss"], "loss_curve_100_steps": g["curve100"], "per_bin_pred_of_range_max": g["per_bin_max"],
             "per_bin_pred_of_range_rms": g["per_bin_rms"], "per_parameter_grad_norm": g["grad_norm"], "measured_eval_train": g["measured"],

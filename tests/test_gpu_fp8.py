@@ -1,7 +1,7 @@
 """GPU: the OCP-fp8 (e4m3fn) GEMM path of BASELINE.json config 5 (csrc/gemm_fp8.hip).  The reference has no fp8 arithmetic
 (fp32 / fp16-AMP, code/learner.py:46-50), so the path is pinned (a) kernel by kernel against torch's own float8_e4m3fn conversion
-and an f64 product of the quantised operands, (b) end to end against this build's bf16 path - itself pinned to the reference - on
-the 4-microphone 10-second segment of fixture F10, with the tolerances stated here."""
+and an f64 product of the quantised operands.  (Rounds 2-5 also ran them end to end as a whole-step 'fp8' mode against the bf16 path on
+fixture F10; that mode was slower than bf16 on this model and was removed in round 6 - the kernels remain library entry points.)"""
 import json
 import os
 
@@ -62,77 +62,10 @@ def test_fp8_gemm_vs_exact_product_of_the_quantised_operands(M, N, K):
     assert _relerr(pre, h) < 1e-2 and _relerr(y2, R.double() + 0.5 * h * torch.sigmoid(h)) < 1e-2
 
 
-def _set_dropout(m, p):
-    for mod in m.modules():
-        if isinstance(mod, torch.nn.Dropout):
-            mod.p = p
-
-
-def _config5(prec):
-    from sar_ssl_amd import hip, model, runtime
-    z = np.load(os.path.join(GOLD, "f10_multich.npz"), allow_pickle=False)
-    runtime.set_precision(prec)
-    try:
-        man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))["pretrain"]
-        net = model.SARSSL(sig_shape=(256, 624, 2, 2), pretrain=True, device="cuda:0")
-        net.load_state_dict(recipes.recipe_state_dict(man, 0))
-        _set_dropout(net, 0.0)
-        net.cuda().train()
-        x = hip.stft_frontend(recipes.recipe_signal(1, 160000, 4, seed=21).cuda())
-        net.set_masks(z["c5.mask_idx"], z["c5.mask_ch"])
-        loss, diff, vis = net(x)
-        loss.backward()
-        grads = {k: p.grad.double().norm().item() for k, p in net.named_parameters()}
-        return float(loss), vis["pred"].float().clone(), grads, z
-    finally:
-        runtime.set_precision("bf16")
-
-
-def test_config5_fp8_path_tracks_the_bf16_path_and_the_reference():
-    """BASELINE.json config 5: 4 microphones x 10 s (3 pairs, T = 624) through forward + backward with the fp8 GEMM path, against
-    the bf16 path on identical inputs / weights / masks, and against the reference's own loss (fixture F10).  Stated tolerances:
-    loss 5e-3 of the bf16 / reference loss; individual outputs 2e-1 of the output range (with the recipe weights the prediction is
-    ~10x smaller than the data it regresses, so e4m3 noise of the block outputs is large relative to it while the loss moves by
-    1e-3); per-parameter gradient norms 25 %."""
-    l8, p8, g8, z = _config5("fp8")
-    l16, p16, g16, _ = _config5("bf16")
-    check("fp8.config5.loss_vs_bf16", abs(l8 / l16 - 1), 5e-3)
-    check("fp8.config5.loss_vs_reference", abs(l8 / float(z["c5.loss"]) - 1), 5e-3)
-    check("fp8.config5.pred_vs_bf16", ((p8 - p16).abs().max() / p16.abs().max()).item(), 2e-1)
-    top = max(g16.values())
-    worst = max((abs(g8[k] - g16[k]) / g16[k], k) for k in g16 if g16[k] > 1e-6 * top)
-    check("fp8.config5.gradnorm_vs_bf16[worst=%s]" % worst[1], worst[0], 0.25)
-    assert l8 != l16                                                    # the fp8 kernels really ran
-
-
-def test_fp8_mode_trains():
-    """A few optimiser steps in fp8 mode (dropout on, fused Adam): finite, and step by step within 2 % of the bf16 run on the same
-    data, masks and dropout seeds."""
-    from sar_ssl_amd import hip, model, runtime, synth
-    import random
-    losses = {}
-    for prec in ("bf16", "fp8"):
-        runtime.set_precision(prec)
-        try:
-            torch.manual_seed(3)
-            net = model.SARSSL(sig_shape=(256, 64, 2, 2), pretrain=True, device="cuda:0").cuda().train()
-            man = {k: list(v.shape) for k, v in net.state_dict().items()}
-            net.load_state_dict(recipes.recipe_state_dict(man, 4))
-            flat = runtime.FlatParams(net)
-            opt = runtime.FusedAdam(flat, lr=1e-3)
-            opt.zero_grad()
-            sig = torch.from_numpy(synth.make_batch(0, 8, nsample=512 + 256 * 63)).cuda()
-            runtime.RT.manual_seed(11)
-            random.seed(5)
-            cur = []
-            for _ in range(6):
-                loss, _, _ = net(hip.stft_frontend(sig))
-                loss.backward()
-                opt.step()
-                opt.zero_grad()
-                cur.append(float(loss))
-            losses[prec] = cur
-        finally:
-            runtime.set_precision("bf16")
-    assert all(np.isfinite(losses["fp8"]))
-    check("fp8.train6.loss_vs_bf16", max(abs(a / b - 1) for a, b in zip(losses["fp8"], losses["bf16"])), 2e-2)
+def test_whole_step_fp8_mode_is_gone_and_says_why():
+    """Round 6: the model-level 'fp8' mode (e4m3 Linear GEMMs inside the Conformer blocks) was removed - it was 7-12 % slower than bf16 on
+    this model (just-in-time quantisation); config 5 is timed in 'hybrid' / 'fp16'.  The kernels above stay library entry points."""
+    from sar_ssl_amd import runtime
+    with pytest.raises(ValueError, match="removed in round 6"):
+        runtime.set_precision("fp8")
+    assert runtime.RT.fp8 is False
