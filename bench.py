@@ -6,8 +6,11 @@
 
 One step = one pass of the whole hot path over one batch of synthetic input that is already resident in HBM (int16 PCM,
 64 two-channel 4.112 s @ 16 kHz segments per GPU): fused STFT front-end -> masks -> two MC-Conformer encoders -> decoder ->
-masked MSE -> hand-written backward -> (bucketed RCCL all-reduce overlapped with backward) -> fused Adam.  bf16 storage/MFMA,
-f32 accumulation; dropout active (training mode), nothing cached or skipped.
+masked MSE -> hand-written backward -> (bucketed RCCL all-reduce overlapped with backward) -> fused Adam.  Numeric mode (--precision):
+'hybrid' by default since round 6 - fp16 CNN stem, f32 residual stream through the Conformer blocks / decoder with f32 activations and
+weights contracted as fp16 pairs on the matrix cores, bf16 backward - the mode that meets the 1e-3 per-bin tolerance against the
+reference; 'fp16' (fp16 forward / bf16 backward) is timed next to it in the same line (`fast_mode`).  f32 accumulation; dropout active
+(training mode), nothing cached or skipped.
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   * `roofline`: measured live with events on the launch stream around every BN-prologue launch of the dominant kernel
@@ -19,7 +22,9 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   * `parity_class`: what the timed numeric mode is pinned to against the reference (tests/, DESIGN.md section 2);
   * `product_loop` (N = 1): the same step driven the way run_pretrain.py drives it - PCM-16 WAV files -> dataset.PcmSegmentLoader
     (native reader thread + pinned upload) -> STFTLearner.pretrain_epoch (captured step, STFT inside the replay);
-  * `dist` (N > 1): backend, RCCL version, ranks, bytes per gradient bucket and the event-timed all-reduce of each bucket.
+  * `dist` (N > 1): backend, RCCL version, ranks, bytes per gradient bucket, the event-timed all-reduce of each bucket and `overlap_check`
+    (the CNN-stem backward window the exchange hides under against the sum of the buckets issued in front of it);
+  * `fast_mode` / `tolerance_mode` (N = 1): a short timed run of the other 16-bit mode on the same box and batches.
 `--via-learner` makes the product loop the line's primary value; `--workload config5` times BASELINE config 5 (4-microphone 10 s
 segments: 3 microphone pairs per segment, T = 624 frames).
 """
@@ -611,7 +616,7 @@ def main():
         # rocprofv3 --pmc runs, FETCH_SIZE x 2 on gfx950).  tag -> variant of the 3x3 family
         PMC_TAGS = {20: "fwd_bn_prologue", 24: "fwd_from_4ch_input", 22: "dgrad_bnred", 26: "dgrad_consumed_in_epilogue", 23: "wgrad", 25: "wgrad_from_4ch_input"}
         traffic, mfma_busy, pmc_file, pmc_var = None, None, None, {}
-        for name in ("r05_kernel_counters.json", "r04_kernel_counters.json", "r03_kernel_counters.json", "r02_kernel_counters.json"):
+        for name in ("r06_kernel_counters.json", "r05_kernel_counters.json", "r04_kernel_counters.json", "r03_kernel_counters.json", "r02_kernel_counters.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if traffic is None and args.workload == "config2" and batch == 64 and os.path.exists(pmc):
                 for e in json.load(open(pmc)).get("kernels", []):

@@ -92,6 +92,18 @@ int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int dtB, int dtC
  *      pair (gradient x saved activation) contracts in bf16, the fp16 operand re-encoded while staged.  aux_dtype: dtype of `aux`
  *      (= dtC, or fp16 next to a bf16 C). */
 
+/* ---- downstream heads (round 6): SARSSL.forward's downstream branch (code/model.py:667-719: mean over the frames, then
+ *      nn.Sequential(LayerNorm, Linear) or (LayerNorm, Linear, ReLU, Linear)) and SARSSL_MultiCH.head_mch (code/model.py:793-821).  f32 tensors
+ *      of a few hundred rows at most; LayerNorm = sarssl_layernorm_fwd / _bwd.  sarssl_mean_rows: x (B, Tn, d) of `dtype` -> out f32 (B, d);
+ *      _bwd: dx (B, Tn, d) of `dtype` (f32 | bf16) = dy / Tn.  sarssl_small_linear_fwd: y [M][N] = act(x [M][K] W[N][K]^T + bias), act 0 | 1 (relu),
+ *      any N >= 1.  _bwd: dx (may be NULL) = dz W, dW += dz^T x, db (may be NULL) += column sums of dz, dz = dy (act 0) or dy * [y > 0] (act 1,
+ *      written to dz_ws [M][N]). */
+int sarssl_mean_rows(const void* x, int B, int Tn, int d, float* out, int dtype, void* stream);
+int sarssl_mean_rows_bwd(const float* dy, int B, int Tn, int d, void* dx, int dtype, void* stream);
+int sarssl_small_linear_fwd(const float* x, const float* W, const float* bias, int M, int N, int K, int act, float* y, void* stream);
+int sarssl_small_linear_bwd(const float* dy, const float* y, const float* x, const float* W, int M, int N, int K, int act, float* dz_ws, float* dx,
+                            float* dW, float* db, void* stream);
+
 /* ---- "hybrid" numeric mode (round 6): fp16 CNN stem + f32 residual stream in the Conformer blocks / decoder - the mode that meets the
  *      1e-3 per-bin tolerance against the reference's f32 path (code/learner.py:100-103 runs the model in f32 by default) at 16-bit
  *      matrix-core speed.  An f32 tensor enters a product as an fp16 PAIR hi = fp16(x), lo = fp16(x - hi), a weight likewise.

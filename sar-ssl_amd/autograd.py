@@ -55,3 +55,45 @@ def tape_apply(module, fwd, bwd, x):
         return fwd(_to_rt(x.detach().contiguous()), [])
     finally:
         RT.inference = False
+
+
+class _F32Tape(torch.autograd.Function):
+    """Node of the downstream heads (engine.head_fwd / hip.mean_rows): f32 in, f32 out in every numeric mode."""
+
+    @staticmethod
+    def forward(ctx, fwd, bwd, x, *params):
+        if not x.is_cuda:
+            raise hip._lib.SarsslHipError("sar_ssl_amd modules run on the GPU only (no CPU fallback); got a CPU tensor")
+        saved = []
+        y = fwd(x.detach().contiguous(), saved)
+        ctx.bwd, ctx.saved, ctx.in_dtype, ctx.nparams = bwd, saved, x.dtype, len(params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ctx.bwd(dy.contiguous().float(), ctx.saved)
+        if dx is not None and dx.dtype != ctx.in_dtype:
+            dx = hip.cast(dx.contiguous(), ctx.in_dtype)
+        return (None, None, dx) + (None,) * ctx.nparams
+
+
+def pool_mean(embed):
+    """embed (B, T, d) -> f32 (B, d), mean over the frames (code/model.py:700-708: ``embed.mean(dim=1)``) through csrc/head.hip."""
+    T = embed.shape[1]
+    fwd = lambda x, saved: hip.mean_rows(x)
+    bwd = lambda dy, saved: hip.mean_rows_bwd(dy, T, torch.float32)
+    if torch.is_grad_enabled() and embed.requires_grad:
+        return _F32Tape.apply(fwd, bwd, embed.float())
+    return fwd(embed.detach(), [])
+
+
+def head_apply(seq, pooled):
+    """nn.Sequential(LayerNorm, Linear[, ReLU, Linear]) on pooled f32 embeddings through the library (engine.head_fwd / head_bwd)."""
+    from . import engine
+    from .runtime import gbuf                                                # noqa: F401  (engine accumulates into p.grad)
+    params = [p for p in seq.parameters() if p.requires_grad]
+    fwd = lambda x, saved: engine.head_fwd(x.float().contiguous(), seq, saved)
+    bwd = lambda dy, saved: engine.head_bwd(dy, seq, saved)
+    if torch.is_grad_enabled() and (pooled.requires_grad or params):
+        return _F32Tape.apply(fwd, bwd, pooled, *params)
+    return fwd(pooled.detach(), [])

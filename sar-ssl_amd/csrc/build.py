@@ -6,7 +6,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "hybrid.hip", "ffn2h.hip", "ffn2.hip", "lin256.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip", "comm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "hybrid.hip", "ffn2h.hip", "head.hip", "ffn2.hip", "lin256.hip", "gemm_fp8.hip", "attention.hip", "stft.hip", "conv3x3.hip", "stem.hip", "elementwise.hip", "dwconv.hip", "wavio.hip", "comm.hip"]
 LIB = os.path.join(HERE, "libsarssl_hip.so")
 # -munsafe-fp-atomics: the only floating-point atomics left are the f64 `atomicAdd`s of the statistics reductions (BatchNorm sums, loss
 # sums, STFT magnitude sums, first-layer moments: one per (workgroup, channel) after an LDS fold - csrc/stem.hip, conv3x3.hip, dwconv.hip,

@@ -1257,3 +1257,33 @@ def decoder_bwd(dpred, dec, saved):
         dh = mm_nn(dpred, wtg(l2.weight), fp8=False, aux=h, aux_act=RELU)
         mm_tn_acc(dh, e, gbuf(l1.weight), bias=gbuf(l1.bias))
         return mm_nn(dh, wtg(l1.weight), fp8=False, out_dtype=_F32 if RT.hybrid else None)      # hybrid: the stream's gradient is f32
+
+
+# ------------------------------------------------------------------------------------------------ downstream heads
+def _head_layers(seq):
+    """nn.Sequential(LayerNorm, Linear) or (LayerNorm, Linear, ReLU, Linear) (code/model.py:411-419, 806-808) -> (LayerNorm, [Linear, ..])."""
+    mods = list(seq)
+    assert isinstance(mods[0], torch.nn.LayerNorm) and all(isinstance(m, (torch.nn.Linear, torch.nn.ReLU)) for m in mods[1:]), "unsupported head"
+    return mods[0], [m for m in mods[1:] if isinstance(m, torch.nn.Linear)]
+
+
+def head_fwd(x, seq, saved):
+    """Downstream head on pooled embeddings x f32 [B, d]: LayerNorm + Linear (+ ReLU + Linear), f32 through csrc/head.hip."""
+    ln_mod, lins = _head_layers(seq)
+    h, stats = hip.layernorm_fwd(x, ln_mod.weight.data, ln_mod.bias.data, ln_mod.eps)
+    acts = []
+    for i, lin in enumerate(lins):
+        act = 1 if i + 1 < len(lins) else 0
+        y = hip.small_linear_fwd(h, lin.weight.data.contiguous(), lin.bias.data if lin.bias is not None else None, act)
+        acts.append((h, y, act))
+        h = y
+    saved.append((x, stats, acts))
+    return h
+
+
+def head_bwd(dy, seq, saved):
+    ln_mod, lins = _head_layers(seq)
+    x, stats, acts = saved.pop()
+    for lin, (h, y, act) in reversed(list(zip(lins, acts))):
+        dy = hip.small_linear_bwd(dy, y, h, lin.weight.data.contiguous(), act, gbuf(lin.weight), gbuf(lin.bias) if lin.bias is not None else None)
+    return hip.layernorm_bwd(dy, x, ln_mod.weight.data, stats, dgamma=gbuf(ln_mod.weight), dbeta=gbuf(ln_mod.bias))

@@ -219,6 +219,47 @@ def gemm(A, B, *, a_kc=True, b_kc=True, M, N, K, lda, ldb, out=None, out_dtype=N
     return out
 
 
+# ---- downstream heads (csrc/head.hip): mean over frames, small f32 Linear layers ----------------------------------------------------
+def mean_rows(x3d):
+    """(B, T, d) of any storage dtype -> f32 (B, d): mean over the frames."""
+    _need_cuda(x3d)
+    B, T, d = x3d.shape
+    x3d = x3d.contiguous()
+    out = torch.empty((B, d), dtype=torch.float32, device=x3d.device)
+    _lib.call("sarssl_mean_rows", _p(x3d), c_int(B), c_int(T), c_int(d), _p(out), c_int(dt(x3d)), _stream())
+    return out
+
+
+def mean_rows_bwd(dy2d, T, dtype=torch.float32):
+    B, d = dy2d.shape
+    dx = torch.empty((B, T, d), dtype=dtype, device=dy2d.device)
+    _lib.call("sarssl_mean_rows_bwd", _p(dy2d.contiguous().float()), c_int(B), c_int(T), c_int(d), _p(dx), c_int(_DT[dtype]), _stream())
+    return dx
+
+
+def small_linear_fwd(x2d, W, bias, act=0):
+    """act(x [M, K] @ W[N, K]^T + bias) in f32, any N >= 1 (act 1 = relu)."""
+    _need_cuda(x2d, W, bias)
+    M, K = x2d.shape
+    N = W.shape[0]
+    assert x2d.dtype == torch.float32 and W.dtype == torch.float32 and x2d.is_contiguous() and W.is_contiguous()
+    y = torch.empty((M, N), dtype=torch.float32, device=x2d.device)
+    _lib.call("sarssl_small_linear_fwd", _p(x2d), _p(W), _p(bias), c_int(M), c_int(N), c_int(K), c_int(act), _p(y), _stream())
+    return y
+
+
+def small_linear_bwd(dy2d, y2d, x2d, W, act, dW, db, need_dx=True):
+    """-> dx [M, K] (or None); dW += dz^T x, db += column sums of dz, dz = dy (act 0) / dy * [y > 0] (act 1)."""
+    M, K = x2d.shape
+    N = W.shape[0]
+    dy2d = dy2d.contiguous().float()
+    dz = torch.empty((M, N), dtype=torch.float32, device=x2d.device) if act == 1 else None
+    dx = torch.empty((M, K), dtype=torch.float32, device=x2d.device) if need_dx else None
+    _lib.call("sarssl_small_linear_bwd", _p(dy2d), _p(y2d), _p(x2d), _p(W), c_int(M), c_int(N), c_int(K), c_int(act), _p(dz), _p(dx), _p(dW), _p(db),
+              _stream())
+    return dx
+
+
 # ---- hybrid numeric mode (csrc/hybrid.hip, sarssl_gemm_split): f32 tensors as fp16 pairs ------------------------------------------------
 class Pair:
     """An f32 tensor [M, d] given as two fp16 tensors, hi = fp16(x) and lo = fp16(x - hi) (22 significant bits): the form in which the

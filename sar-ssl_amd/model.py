@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import engine, hip
-from .autograd import tape_apply
+from .autograd import tape_apply, pool_mean, head_apply
 from .runtime import RT, begin_forward as runtime_begin_forward
 from .common import utils_module as at_module
 from .common.Conformer import ConformerEncoder
@@ -461,10 +461,11 @@ class SARSSL(nn.Module):
             embed = embed_spat
         else:
             embed = torch.zeros_like(embed_spec)
-        # tiny (B x d) pooling + head: torch ops (a "next" row; not on the pretraining hot path)
-        pooled = embed.float().mean(dim=1)
+        # pooling + head (a "next" row): mean over the frames, LayerNorm, one or two small Linear layers - through the
+        # library like everything else (csrc/head.hip; round 6)
+        pooled = pool_mean(embed)
         head = self.mlp_head if self.downstream_dlabel == 1 else self.joint_head
-        return head(pooled), pooled
+        return head_apply(head, pooled), pooled
 
 
 def _full_pred_fn(ecat, dec, net=None, step_rows=None):
@@ -551,6 +552,6 @@ class SARSSL_MultiCH(nn.Module):
 
     def forward(self, x):
         v = x.permute(0, 3, 2, 4, 1).reshape(x.shape[0], x.shape[3], -1)
-        embed_sch = self.model_sch.spat_encoder(v).float().mean(dim=1)
+        embed_sch = pool_mean(self.model_sch.spat_encoder(v))
         embed_sch = embed_sch.reshape(-1, self.nmic_pair * embed_sch.shape[-1])
-        return self.head_mch(embed_sch), embed_sch
+        return head_apply(self.head_mch, embed_sch), embed_sch
