@@ -17,6 +17,7 @@ Modes (applied to both operands unless noted):
   bf16x3     hi*hi + hi*lo + lo*hi  (the repo's `fp32` mode)
   fp16x2a / fp16x2w   fp16 with the activations / the weights split hi+lo (two passes)
   fp16x3     fp16 hi*hi + hi*lo + lo*hi
+  fp16a      activation operand rounded to fp16, weights exact
 `--store` additionally rounds every contraction OUTPUT to the mode's storage type (what bf16 / fp16 activation storage adds).
 `--family NAME=MODE,...` overrides the mode per family: stem1 (4->64 1x1), conv3 (3x3), stem4 (64->4), patch, lin (Conformer
 Linear / pointwise; or one of its layers: ffn1, ffn2, q, k, v, pos, out, pw1, pw2), attn (score / PV products), dec (decoder; dec1, dec2).  `NAME=MODE:n` keeps that family's outputs in f32 under --store.
@@ -94,6 +95,8 @@ class Policy:
             wh, wl = _split(w)
             ab = _r(a, "bf16")
             y = fn(ab, wh) + fn(ab, wl)
+        elif m == "fp16a":                   # activation operand rounded to fp16, weights exact (a VALU layer on an fp16-stored input)
+            y = fn(_r(a, "fp16"), w)
         elif m == "fp16x2a":                 # activations hi+lo fp16 (two passes), weights one fp16
             ah, al = _split16(a)
             wb = _r(w, "fp16")
