@@ -145,6 +145,11 @@ int sarssl_stem_c4_fwd_pair(const void* y3, const float* W4, const float* scale,
                             void* y4_lo, double* stats8, int dtype, void* stream);
 int sarssl_cl_affine_act_pair(const void* x_hi, const void* x_lo, long n, int C, const float* scale, const float* shift, int act, void* z_hi,
                               void* z_lo, void* stream);
+/*      the guarded Adam launches with a third shadow: pl16 = fp16(p - fp16(p)), the weights' lo halves, rewritten in the same pass */
+int sarssl_adam_step_guard_lo(float* p, const float* g, float* m, float* v, void* p16, void* ph16, void* pl16, long n, float gscale, float lr,
+                              float beta1, float beta2, float eps, int step, const float* guard, int* nskipped, void* stream);
+int sarssl_adam_step_dev_guard_lo(float* p, float* g, float* m, float* v, void* p16, void* ph16, void* pl16, long n, float gscale, void* state,
+                                  float eps, int zero_grad, const float* guard, void* stream);
 /*      src (f32 | fp16 | bf16; n % 4 == 0) -> hi = fp16(src) (may be NULL), lo = fp16(src - hi): the weights' lo shadow, stem outputs. */
 int sarssl_split_pair(const void* src, int src_dtype, long n, void* hi, void* lo, void* stream);
 

@@ -917,7 +917,8 @@ __global__ void masked_mse_bwd_kernel(const TA* __restrict__ pred, const float* 
 // forward overflowed (code/learner.py:105-108) - decided on the device, no host synchronisation.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             bf16* __restrict__ p16, f16* __restrict__ ph16, long n, float gscale, float beta1, float beta2, float step_size,
-                            float inv_bc2_sqrt, float eps, const float* __restrict__ guard, int* __restrict__ nskipped) {
+                            float inv_bc2_sqrt, float eps, const float* __restrict__ guard, int* __restrict__ nskipped,
+                            f16* __restrict__ pl16 = nullptr /* hybrid mode: fp16(p - fp16(p)), the lo shadow */) {
     if (guard && !isfinite(guard[0])) {
         if (nskipped && blockIdx.x == 0 && threadIdx.x == 0) nskipped[0] += 1;
         return;
@@ -932,6 +933,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] = pi;
         if (p16) st_f(p16 + i, pi);
         if (ph16) st_f(ph16 + i, pi);
+        if (pl16) st_f(pl16 + i, pi - (float)(f16)pi);
     }
 }
 
@@ -939,7 +941,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // gradient buffer in the same pass (the reference's optimizer.zero_grad() right after optimizer.step(), code/learner.py:113-115).
 __global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                 bf16* __restrict__ p16, f16* __restrict__ ph16, long n, float gscale, SarsslStepState* __restrict__ st, float eps,
-                                int zero_g, const float* __restrict__ guard) {
+                                int zero_g, const float* __restrict__ guard, f16* __restrict__ pl16 = nullptr) {
     const float beta1 = st->beta1, beta2 = st->beta2, step_size = st->step_size, inv_bc2_sqrt = st->inv_bc2_sqrt;
     if (guard && !isfinite(guard[0])) {
         // skipped step: nothing moves, the gradient buffer is still cleared (zero_grad follows the step), the Adam step count is taken
@@ -959,6 +961,7 @@ __global__ void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, fl
         p[i] = pi;
         if (p16) st_f(p16 + i, pi);
         if (ph16) st_f(ph16 + i, pi);
+        if (pl16) st_f(pl16 + i, pi - (float)(f16)pi);
         if (zero_g) g[i] = 0.f;
     }
 }
@@ -1343,6 +1346,24 @@ extern "C" int sarssl_adam_step_guard(float* p, const float* g, float* m, float*
     adam_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, beta1, beta2, (float)(lr / bc1),
                                                            (float)(1.0 / sqrt(bc2)), eps, guard, nskipped);
     SARSSL_CHECK_LAUNCH("adam_kernel");
+    return 0;
+}
+// hybrid mode: the same pass also rewrites the fp16 lo shadow pl16 = fp16(p - fp16(p)) (with ph16 the pair a forward product contracts against)
+extern "C" int sarssl_adam_step_guard_lo(float* p, const float* g, float* m, float* v, void* p16, void* ph16, void* pl16, long n, float gscale,
+                                         float lr, float beta1, float beta2, float eps, int step, const float* guard, int* nskipped, void* stream) {
+    SARSSL_REQUIRE(n > 0 && step >= 1, "sarssl_adam_step");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    adam_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, beta1, beta2, (float)(lr / bc1),
+                                                           (float)(1.0 / sqrt(bc2)), eps, guard, nskipped, (f16*)pl16);
+    SARSSL_CHECK_LAUNCH("adam_kernel");
+    return 0;
+}
+extern "C" int sarssl_adam_step_dev_guard_lo(float* p, float* g, float* m, float* v, void* p16, void* ph16, void* pl16, long n, float gscale,
+                                             void* state, float eps, int zero_grad, const float* guard, void* stream) {
+    SARSSL_REQUIRE(n > 0 && state, "sarssl_adam_step_dev");
+    adam_dev_kernel<<<nblocks_for(n, 256, 8192), 256, 0, ST>>>(p, g, m, v, (bf16*)p16, (f16*)ph16, n, gscale, (SarsslStepState*)state, eps,
+                                                               zero_grad, guard, (f16*)pl16);
+    SARSSL_CHECK_LAUNCH("adam_dev_kernel");
     return 0;
 }
 extern "C" int sarssl_adam_step(float* p, const float* g, float* m, float* v, void* p16, void* ph16, long n, float gscale, float lr,

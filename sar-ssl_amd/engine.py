@@ -1165,7 +1165,10 @@ def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None, rows=None):
     if rows is not None:
         xc = hip.gather_rows(x, rows, B, T)
         xc = ffn_fwd(xc, seq[3].module, seq[3].module_factor, train, saved)
-        y, stats = hip.layernorm_fwd(xc, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
+        if isinstance(out, tuple):         # hybrid mode: the decoder's input leaves the closing LayerNorm as the fp16 pair its first product reads
+            y, stats = hip.layernorm_fwd_pair(_as_stream(xc), seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
+        else:
+            y, stats = hip.layernorm_fwd(xc, seq[4].weight.data, seq[4].bias.data, seq[4].eps, out=out)
         saved.append((xc, stats, (rows, B, T), x))          # (x: the full-row input of the tail, for a full prediction on request - vis)
         return y
     x = ffn_fwd(x, seq[3].module, seq[3].module_factor, train, saved)

@@ -85,9 +85,12 @@ class PretrainStepGraph:
             idx, ch = net.patch_mask.sample(B, 2)
         else:                                               # capture warm-up: must not advance the python RNG the reference shares
             nm = net.patch_mask.nmasked_patch
-            idx = np.tile(np.arange(nm, dtype=np.int64)[None, :] * 2 % T, (B, 1))
+            idx = np.tile((np.arange(nm, dtype=np.int64) * max(T // max(nm, 1), 1))[None, :] % T, (B, 1))       # distinct frames (nm <= T)
             ch = np.zeros((B,), dtype=np.int64)
-        return np.sort(np.asarray(idx), axis=1), np.asarray(ch).reshape(-1)      # ascending per item (row order of the compact decoder path)
+        idx = np.sort(np.asarray(idx), axis=1)                                   # ascending per item (row order of the compact decoder path)
+        if idx.shape[1] > 1 and not (np.diff(idx, axis=1) > 0).all():
+            raise ValueError("masked-frame indices must be distinct per item (got a repeated frame index)")
+        return idx, np.asarray(ch).reshape(-1)
 
     def _upload_masks(self, idx, ch, B, T):
         nm = idx.shape[1]
@@ -154,10 +157,14 @@ class PretrainStepGraph:
         elif self.reducer is not None:                     # (native exchange under capture: the join with the communication stream becomes a graph edge)
             self.reducer.finish(guard=self.guard if world > 1 else None)      # (world 1: closes the step's hook record, see FlatGradAllReduce.strict)
         # guard = the step's loss: a forward that overflowed fp16 (non-finite loss) leaves parameters and moments alone - the reference's
-        # GradScaler skips such a step too (code/learner.py:105-108); decided on the device, counted in the step state
+        # GradScaler skips such a step too (code/learner.py:105-108); decided on the device, counted in the step state.  Deliberately
+        # stricter than the reference in the modes without a GradScaler counterpart (fp32 / bf16, where the reference would let a NaN
+        # propagate into the parameters): the captured step never applies an update computed from a non-finite loss, in any mode; the
+        # launch-by-launch learner path guards under --use-amp only, like the reference (advisor, round 5: documented, not aligned)
         hip.adam_step_dev(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.state, gscale=1.0 / world, eps=self.eps,
-                          zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16, guard=guard)
-        self.flat.refresh_lo()            # hybrid mode: the weights' fp16 lo shadow follows (a launch of the captured step)
+                          zero_grad=self.zero_grad_in_adam, ph16=self.flat.wh16, guard=guard,
+                          pl16=self.flat.wl16)      # hybrid mode: the weights' fp16 lo shadow is rewritten by the same pass (None otherwise)
+        self.flat._lo_synced = self.flat._synced
 
     def _exchange_in_graph(self):
         """True when the bucket all-reduces are captured INSIDE the step graph: the library's own exchange (sarssl_allreduce_bucket,

@@ -311,16 +311,20 @@ def split_pair(src, want_hi=True, hi=None, lo=None):
     return Pair(hi, lo) if want_hi else lo
 
 
-def layernorm_fwd_pair(x2d, gamma, beta, eps=1e-5, save=True, want32=False):
-    """LayerNorm of f32 rows -> (Pair, stats[, y32])."""
+def layernorm_fwd_pair(x2d, gamma, beta, eps=1e-5, save=True, want32=False, out=None):
+    """LayerNorm of f32 rows -> (Pair, stats[, y32]).  out = (hi, lo): fp16 [M, d] views with a common row stride to write into."""
     M, d = x2d.shape
     assert x2d.dtype == torch.float32
-    hi = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
-    lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+    if out is not None:
+        hi, lo = out
+        assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.stride(0) == lo.stride(0) and hi.stride(1) == 1 and lo.stride(1) == 1
+    else:
+        hi = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+        lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
     y32 = torch.empty((M, d), dtype=torch.float32, device=x2d.device) if want32 else None
     stats = torch.empty((2, M), dtype=torch.float32, device=x2d.device) if save else None
     _lib.call("sarssl_layernorm_fwd_pair", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d), _p(gamma), _p(beta), c_float(eps), _p(hi), _p(lo),
-              c_long(d), _p(y32), c_long(d), _p(stats[0]) if save else c_void_p(0), _p(stats[1]) if save else c_void_p(0), _stream())
+              c_long(hi.stride(0)), _p(y32), c_long(d), _p(stats[0]) if save else c_void_p(0), _p(stats[1]) if save else c_void_p(0), _stream())
     return (Pair(hi, lo), stats, y32) if want32 else (Pair(hi, lo), stats)
 
 
@@ -1617,11 +1621,16 @@ def masked_mse_bwd(pred, x, mp_u8, mch_i32, nm, gscale=1.0, gscale_dev=None):
     return dpred
 
 
-def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8, ph16=None, guard=None, nskipped=None):
+def adam_step(p, g, m, v, p16, lr, step, gscale=1.0, betas=(0.9, 0.999), eps=1e-8, ph16=None, guard=None, nskipped=None, pl16=None):
     """p16 / ph16: bf16 / fp16 shadow copies of the parameters rewritten by the same pass (either may be None).  guard: f32 device
     tensor holding the step's loss - not finite -> the update is skipped on the device (nskipped: int32 device counter, += 1)."""
     assert (p16 is None or p16.dtype == torch.bfloat16) and (ph16 is None or ph16.dtype == torch.float16)
     assert guard is None or (guard.dtype == torch.float32 and guard.is_cuda)
+    if pl16 is not None:              # hybrid mode: the lo shadow (fp16(p - fp16(p))) in the same pass
+        assert pl16.dtype == torch.float16
+        _lib.call("sarssl_adam_step_guard_lo", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), _p(pl16), c_long(p.numel()), c_float(gscale), c_float(lr),
+                  c_float(betas[0]), c_float(betas[1]), c_float(eps), c_int(step), _p(guard), _p(nskipped), _stream())
+        return
     _lib.call("sarssl_adam_step_guard", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), c_float(lr),
               c_float(betas[0]), c_float(betas[1]), c_float(eps), c_int(step), _p(guard), _p(nskipped), _stream())
 
@@ -1696,9 +1705,14 @@ def step_tick(st):
     _lib.call("sarssl_step_tick", _p(st), _stream())
 
 
-def adam_step_dev(p, g, m, v, p16, st, gscale=1.0, eps=1e-8, zero_grad=False, ph16=None, guard=None):
+def adam_step_dev(p, g, m, v, p16, st, gscale=1.0, eps=1e-8, zero_grad=False, ph16=None, guard=None, pl16=None):
     assert (p16 is None or p16.dtype == torch.bfloat16) and (ph16 is None or ph16.dtype == torch.float16)
     assert guard is None or (guard.dtype == torch.float32 and guard.is_cuda)
+    if pl16 is not None:
+        assert pl16.dtype == torch.float16
+        _lib.call("sarssl_adam_step_dev_guard_lo", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), _p(pl16), c_long(p.numel()), c_float(gscale), _p(st),
+                  c_float(eps), c_int(1 if zero_grad else 0), _p(guard), _stream())
+        return
     _lib.call("sarssl_adam_step_dev_guard", _p(p), _p(g), _p(m), _p(v), _p(p16), _p(ph16), c_long(p.numel()), c_float(gscale), _p(st), c_float(eps),
               c_int(1 if zero_grad else 0), _p(guard), _stream())
 

@@ -157,7 +157,14 @@ class _PretrainFn(torch.autograd.Function):
         compact = engine._DEC_MASKED and not full_once and not RT.inference and RT.dtype in engine._16 and RT.replay is None
         tail = compact and engine._TAIL_MASKED and net._side_stream(x.device) is not None
         nrow = B * idx_i32.shape[1] if tail else B * T
-        ecat = torch.empty((nrow, ds + dt_), dtype=torch.float32 if RT.hybrid else RT.dtype, device=x.device)   # (hybrid: the f32 stream)
+        # (hybrid: the f32 stream - or, with the compact tails, directly the fp16 pair the decoder's first product contracts: hi | lo halves)
+        pair_out = RT.hybrid and tail
+        ecat = torch.empty((2 * nrow if pair_out else nrow, ds + dt_), dtype=(torch.float16 if pair_out else torch.float32) if RT.hybrid else RT.dtype,
+                           device=x.device)
+        ecat_lo = ecat[nrow:] if pair_out else None
+        if pair_out:
+            ecat = ecat[:nrow]
+        osl = (lambda a, b: (ecat[:, a:b], ecat_lo[:, a:b])) if pair_out else (lambda a, b: ecat[:, a:b])
         # The two encoders are independent until the decoder: run them on two HIP streams so one encoder's HBM-bound passes
         # (BatchNorm statistics / backward, LayerNorm, ...) overlap the other's MFMA-bound convolutions and GEMMs.
         saved_spat = []
@@ -185,15 +192,15 @@ class _PretrainFn(torch.autograd.Function):
             hip.stamp("fwd.spec.stem.end")
             nl = len(spa.embed.layers)
             with torch.cuda.stream(side):
-                e_spat = engine.block_fwd(e_spat, spa.embed.layers[0], B, T, train, saved_spat, out=ecat[:, ds:] if nl == 1 else None,
+                e_spat = engine.block_fwd(e_spat, spa.embed.layers[0], B, T, train, saved_spat, out=osl(ds, ds + dt_) if nl == 1 else None,
                                           next_blk=spa.embed.layers[1] if nl > 1 else None, rows=idx_i32 if (tail and nl == 1) else None)
             assert len(spe.embed.layers) == 1
-            engine.block_fwd(e_spec, spe.embed.layers[0], B, T, train, saved, out=ecat[:, :ds], rows=idx_i32 if tail else None)
+            engine.block_fwd(e_spec, spe.embed.layers[0], B, T, train, saved, out=osl(0, ds), rows=idx_i32 if tail else None)
             hip.stamp("fwd.spec.block.end")
             with torch.cuda.stream(side):
                 for li in range(1, nl):
                     e_spat = engine.block_fwd(e_spat, spa.embed.layers[li], B, T, train, saved_spat,
-                                              out=ecat[:, ds:] if li == nl - 1 else None,
+                                              out=osl(ds, ds + dt_) if li == nl - 1 else None,
                                               next_blk=spa.embed.layers[li + 1] if li + 1 < nl else None,
                                               rows=idx_i32 if (tail and li == nl - 1) else None)
                 hip.stamp("fwd.spat.blocks.end")
@@ -208,7 +215,7 @@ class _PretrainFn(torch.autograd.Function):
         ctx.dpred = None
         net.__dict__["_last_ecat"] = None
         if compact:
-            ecat_c = ecat if tail else hip.gather_rows(ecat, idx_i32, B, T)
+            ecat_c = (hip.Pair(ecat, ecat_lo) if pair_out else ecat) if tail else hip.gather_rows(ecat, idx_i32, B, T)
             pred = engine.decoder_fwd(ecat_c, net.decoder, saved)                                   # [B * nm, F * 4]
             if net.__dict__.get("_loss_grad_with_forward"):
                 out, ctx.dpred = hip.masked_mse_compact(pred, x, idx_i32, ch_i32, sink=sink, with_grad=True)
@@ -415,6 +422,10 @@ class SARSSL(nn.Module):
         else:
             idx, ch = self.patch_mask.sample(B, 2)
         idx = np.sort(np.asarray(idx), axis=1)            # ascending per item: the row order of the compact decoder path (the mask is a set)
+        if idx.shape[1] > 1 and not (np.diff(idx, axis=1) > 0).all():
+            # the compact loss maps a frame to its row by counting the masked frames below it: a repeated index would silently shift the rows
+            # (advisor, round 5) - the reference's PatchMask draws without replacement (utils_module.py:265-267), so this is a caller error
+            raise ValueError("masked-frame indices must be distinct per item (got a repeated frame index)")
         mp = np.ones((B, T), dtype=np.uint8)
         np.put_along_axis(mp, idx, 0, axis=1)
         # pinned staging: an H2D copy from pageable memory first drains the stream (the host could never run ahead of the GPU

@@ -355,6 +355,7 @@ class FusedAdam:
             self.nskipped = torch.zeros(1, dtype=torch.int32, device=self.flat.flat.device)
         hip.adam_step(self.flat.flat, self.flat.grad, self.m, self.v, self.flat.w16, self.lr, self.step_count,
                       gscale=grad_scale, betas=self.betas, eps=self.eps, ph16=self.flat.wh16,
-                      guard=guard.detach().reshape(-1) if guard is not None else None, nskipped=self.nskipped if guard is not None else None)
-        self.flat.refresh_lo()                 # (hybrid mode: the lo shadow follows the parameters; nothing to do otherwise)
+                      guard=guard.detach().reshape(-1) if guard is not None else None, nskipped=self.nskipped if guard is not None else None,
+                      pl16=self.flat.wl16)     # (hybrid mode: the lo shadow is rewritten by the same pass; None otherwise)
+        self.flat._lo_synced = self.flat._synced
         bump_version()

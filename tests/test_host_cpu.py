@@ -257,3 +257,19 @@ def test_dropout_replay_draws_the_reference_masks():
     m2 = rp.mask((2, 6, 7), 0.1, "cpu", torch.float32, to_layout=lambda m: m.permute(0, 2, 1).reshape(14, 6))
     assert rp.draws == 2
     assert torch.allclose(y1.detach(), x1.detach() * m1) and torch.allclose(y2.permute(0, 2, 1).reshape(14, 6), x2.permute(0, 2, 1).reshape(14, 6) * m2)
+
+
+def test_repeated_mask_indices_are_refused():
+    """Advisor (round 5): the compact loss maps a masked frame to its row by counting the masked frames below it - a repeated index would
+    silently shift rows.  PatchMask draws without replacement; forced masks with a repeat are refused on the host."""
+    import numpy as np
+    import pytest
+    import torch
+    from sar_ssl_amd import model
+    net = model.SARSSL(sig_shape=(256, 8, 2, 2), pretrain=True, device="cpu")
+    net.set_masks(np.array([[0, 2, 2, 5]]), np.array([0]))
+    with pytest.raises(ValueError, match="distinct"):
+        net._masks(1, 8, torch.device("cpu"))
+    net.set_masks(np.array([[5, 0, 2, 7]]), np.array([1]))
+    idx, ch, mp = net._masks(1, 8, torch.device("cpu"))
+    assert idx.tolist() == [[0, 2, 5, 7]] and mp.tolist() == [[0, 1, 0, 1, 1, 0, 1, 0]]
