@@ -740,7 +740,7 @@ def main():
         # hybrid headline, `tolerance_mode` (hybrid) next to an fp16 one - so that one line carries the price of the per-bin tolerance
         other = "fp16" if args.precision == "hybrid" else "hybrid"
         try:
-            out["fast_mode" if other == "fp16" else "tolerance_mode"] = other_mode_line(other, dev, T, pcms, pcm, batch, nsteps=max(20, min(60, args.steps)))
+            out["fast_mode" if other == "fp16" else "tolerance_mode"] = other_mode_line(other, dev, T, pcms, pcm, batch, nsteps=max(40, min(60, args.steps)))
         except Exception as e:                           # (must not cost the run its headline)
             out["fast_mode" if other == "fp16" else "tolerance_mode"] = {"error": repr(e)}
         runtime.set_precision(args.precision)
