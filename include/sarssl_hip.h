@@ -241,6 +241,14 @@ int sarssl_relpos_attn_pos_supported(int T, int dh);
 int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos, long ldp,
                                void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh, float scale,
                                float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias, int dtype, void* stream);
+/*      round 6: the same for T > 256 (T % 8 == 0, d_head 64 | 128; BASELINE config 5: T = 624) - the slab of the shifted score covers one
+ *      256-key block at a time, the position tiles that can reach it stream from memory.  qu / qv: the biased projections (q + u_bias,
+ *      q + v_bias as sarssl_bias2 stores them); bias_out (may be NULL) = the (B,H,T,T) shifted score sarssl_relpos_attn_bwd reads.
+ *      Replaces the positional-score sarssl_gemm(c_row_shift) launch and the attention kernel's read of its result. */
+int sarssl_relpos_attn_pos_long_supported(int T, int dh);
+int sarssl_relpos_attn_fwd_pos_long(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos, long ldp,
+                                    void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh, float scale,
+                                    float p_drop, unsigned long long seed, int dtype, void* stream);
 /* u_bias / v_bias (both or neither, f32 [H*dh]; attention.py:54-55): qu == qv == the plain query projection q and the kernels form
  * q + u / q + v while loading their rows (the values sarssl_bias2 would have stored); same for sarssl_relpos_attn_bwd_pos */
 /* Backward with the positional-score gradients formed in the dQ kernel - no d(bias) tensor, no sarssl_relshift_bwd pass, no batched

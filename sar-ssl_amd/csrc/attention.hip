@@ -155,8 +155,13 @@ struct AttnDrop {
 // NW = 8 (d_head 64, POS): ONE workgroup of eight waves takes all 256 query rows of a (batch, head) - the [256][T] slab + one K / V tile
 // are 157 KB of LDS, two waves share a SIMD (one on the matrix cores while the other is in its softmax / scatter / hash stretch) and
 // every K / V tile is staged once per (batch, head) instead of once per 128 rows.
-template <int DH, typename TA, bool POS = false, int NW = 4>
+// LONGT (round 6; POS, T > 256, four waves): the slab holds the shifted score of ONE 256-key block at a time - per block the position
+// tiles that can contribute to it (a diagonal band of the (row, position) plane) stream from memory through the K / V buffers, the block
+// is written out for the backward kernels (bias_out) and its four key tiles run; the online softmax carries across blocks.  Replaces the
+// batched positional-score GEMM (150 MB written in the shifted layout at B' = 48, T = 624) and this kernel's read of it.
+template <int DH, typename TA, bool POS = false, int NW = 4, bool LONGT = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <= 64 && !POS) || NW == 8) ? 2 : 1))) void relpos_attn_fwd_kernel(AttnArgs a) {
+    static_assert(!LONGT || (POS && NW == 4), "long-sequence form: in-kernel positional score, four waves");
     constexpr int TQ = 32 * NW, TK = 64, NT = 64 * NW;
 #ifdef ATTN_EXP_1WG
     constexpr int PK = DH + 8, PV = DH + 32, PB = 256 + 8;
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <=
             }
         }
     };
-    uint4 rp[POS ? NRP : 1];                                  // POS: the head's whole positional projection (T <= 256 rows), one request burst
-    if constexpr (POS) {
+    uint4 rp[(POS && !LONGT) ? NRP : 1];                      // POS: the head's whole positional projection (T <= 256 rows), one request burst
+    if constexpr (POS && !LONGT) {
         const h16* Pm = a.pos + h * DH;
 #pragma unroll
         for (int c = 0; c < NRP; ++c) {
@@ -232,24 +237,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <=
         }
     }
     load_tile(0);
+    bf16x8 fqv[POS ? DH / 16 : 1], fqvn[POS ? DH / 16 : 1];
     if constexpr (POS) {
-        const int il = wave * 32 + (lane & 31), r0 = i0 + wave * 32;
-        bf16x8 fqv[DH / 16], fqvn[DH / 16];
-        {
-            const bool nx = row_ok && (i + 1 < T);
-            const h16* q0 = a.qv + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
+        const bool nx = row_ok && (i + 1 < T);
+        const h16* q0 = a.qv + ((long)b * T + (row_ok ? i : 0)) * a.ldq + h * DH + half * 8;
 #pragma unroll
-            for (int s = 0; s < DH / 16; ++s) {
-                uint4 w0 = row_ok ? *(const uint4*)(q0 + s * 16) : make_uint4(0, 0, 0, 0);
-                uint4 w1 = nx ? *(const uint4*)(q0 + a.ldq + s * 16) : make_uint4(0, 0, 0, 0);
-                if (a.vb) {
-                    if (row_ok) w0 = addb8<TA>(w0, a.vb + h * DH + s * 16 + half * 8);
-                    if (nx) w1 = addb8<TA>(w1, a.vb + h * DH + s * 16 + half * 8);
-                }
-                fqv[s] = __builtin_bit_cast(bf16x8, w0);
-                fqvn[s] = __builtin_bit_cast(bf16x8, w1);
+        for (int s = 0; s < DH / 16; ++s) {
+            uint4 w0 = row_ok ? *(const uint4*)(q0 + s * 16) : make_uint4(0, 0, 0, 0);
+            uint4 w1 = nx ? *(const uint4*)(q0 + a.ldq + s * 16) : make_uint4(0, 0, 0, 0);
+            if (a.vb) {
+                if (row_ok) w0 = addb8<TA>(w0, a.vb + h * DH + s * 16 + half * 8);
+                if (nx) w1 = addb8<TA>(w1, a.vb + h * DH + s * 16 + half * 8);
             }
+            fqv[s] = __builtin_bit_cast(bf16x8, w0);
+            fqvn[s] = __builtin_bit_cast(bf16x8, w1);
         }
+    }
+    if constexpr (POS && !LONGT) {
+        const int il = wave * 32 + (lane & 31), r0 = i0 + wave * 32;
         if (half == 0 && row_ok && i + 1 < T) sB[il * PB + i + 1] = 0;          // the zero of the padding column (masked in the key loop anyway)
         // lane-constant parts of the shifted columns: low  R[i][m]   -> column m - (T-1) + i   (valid when >= 0)
         //                                             up   R[i+1][m] -> column m + i + 2       (valid when <= T-1)
@@ -312,7 +317,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <=
             }
         }
     }
-    for (int j0 = 0; j0 < T; j0 += TK) {
+    // one 64-key tile: jc = column of key j0 in the slab (POS: j0, LONGT: j0 - first key of the block; staged bias tile: 0)
+    auto key_tile = [&](const int j0, const int jc) {
 #pragma unroll
         for (int c = 0; c < NKV; ++c) {
             const int cid = tid + NT * c, row = cid / CPR, c8 = cid % CPR;
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <=
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int jl = f * 32 + 8 * g + 4 * half;
-                const uint2 bu = *(const uint2*)&sB[(wave * 32 + (lane & 31)) * PB + (POS ? j0 : 0) + jl];
+                const uint2 bu = *(const uint2*)&sB[(wave * 32 + (lane & 31)) * PB + jc + jl];
                 const float bv[4] = {H16<TA>::lo(bu.x), H16<TA>::hi(bu.x), H16<TA>::lo(bu.y), H16<TA>::hi(bu.y)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -402,6 +408,80 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <=
                 }
         }
         __syncthreads();
+    };
+    if constexpr (!LONGT) {
+        for (int j0 = 0; j0 < T; j0 += TK) key_tile(j0, POS ? j0 : 0);
+    } else {
+        const int il = wave * 32 + (lane & 31), r0 = i0 + wave * 32;
+        uint16_t* rowp = sB + il * PB;
+        uint16_t* sP = sK;                                                      // [128 positions][PK]: the K and V buffers together
+        static_assert(TK * PK + TK * PV >= 128 * PK, "position stage must fit the K + V buffers");
+        const h16* Pm = a.pos + h * DH;
+        for (int jb = 0; jb < T; jb += 256) {
+            const int jend = min(jb + 256, T);                                  // keys jb .. jend - 1
+            // shifted columns relative to the block: low  R[i][m] -> column m - (T-1) + i - jb,   up  R[i+1][m] -> column m + i + 2 - jb
+            const int cl = i - (T - 1) - jb, cu = i + 2 - jb;
+            if (half == 0 && row_ok && i + 1 >= jb && i + 1 < jend) rowp[i + 1 - jb] = 0;     // the zero of the padding column
+            for (int ms = 0; ms < T; ms += 128) {
+                // workgroup-uniform: can positions ms .. ms+127 reach columns of this block for any of the tile's rows i0 .. i0+TQ-1 ?
+                //   low: m + i in [jb + T-1, jend-1 + T-1];   up: m + i + 2 in [jb, jend-1]
+                const int slo = ms + i0, shi = ms + 127 + i0 + TQ - 1;
+                const bool wl_ = shi >= jb + T - 1 && slo <= jend - 1 + T - 1, wu_ = shi + 2 >= jb && slo + 2 <= jend - 1;
+                if (!(wl_ || wu_)) continue;
+#pragma unroll
+                for (int c = 0; c < NRP / 2; ++c) {
+                    const int row = tid / CPR + c * (NT / CPR);
+                    *(uint4*)&sP[row * PK + (tid % CPR) * 8] = (ms + row < T) ? *(const uint4*)(Pm + (long)(ms + row) * a.ldp + (tid % CPR) * 8)
+                                                                               : make_uint4(0, 0, 0, 0);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int m0 = ms + f * 32;
+                    const int wlo = m0 + r0, whi = m0 + 31 + r0 + 31;             // range of m + i over the wave's rows and this sub-tile
+                    const bool need[2] = {m0 < T && whi >= jb + T - 1 && wlo <= jend - 1 + T - 1, m0 < T && whi + 2 >= jb && wlo + 2 <= jend - 1};
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        if (!need[part]) continue;
+                        f32x16 s;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                        for (int st = 0; st < DH / 16; ++st) {
+                            const bf16x8 pf = *(const bf16x8*)&sP[(f * 32 + (lane & 31)) * PK + st * 16 + half * 8];
+                            s = mfma16<TA>(pf, part == 0 ? fqv[st] : fqvn[st], s);
+                        }
+                        if (row_ok) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; e += 2) {
+                                    const int m = m0 + 8 * g + 4 * half + e;
+                                    const uint32_t w = H16<TA>::pack(s[4 * g + e], s[4 * g + e + 1]);
+                                    const int c0 = m + (part == 0 ? cl : cu), c1 = c0 + 1;
+                                    if (part == 0) {          // valid: m <= T-1 (then j <= i) and j = c + jb >= 0
+                                        if (c0 >= 0 && c0 + jb < jend && m < T) rowp[c0] = (uint16_t)w;
+                                        if (c1 >= 0 && c1 + jb < jend && m + 1 < T) rowp[c1] = (uint16_t)(w >> 16);
+                                    } else {                  // valid: j = c + jb <= T-1 (j >= i + 2 > 0)
+                                        if (c0 >= 0 && c0 + jb < jend) rowp[c0] = (uint16_t)w;
+                                        if (c1 >= 0 && c1 + jb < jend) rowp[c1] = (uint16_t)(w >> 16);
+                                    }
+                                }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (a.bias_out) {                                                   // (T % 8 == 0)
+                h16* Bo = a.bias_out + (long)bh * T * T;
+                const int cpr = (jend - jb) >> 3;
+                for (int cid = tid; cid < TQ * cpr; cid += NT) {
+                    const int row = cid / cpr, c8 = cid - row * cpr;
+                    if (i0 + row < T) *(uint4*)(Bo + (long)(i0 + row) * T + jb + c8 * 8) = *(const uint4*)&sB[row * PB + c8 * 8];
+                }
+            }
+            for (int j0 = jb; j0 < jend; j0 += TK) key_tile(j0, j0 - jb);
+        }
     }
     const float l_tot = l_run + half_swap_f(l_run);
     const float inv_l = 1.0f / l_tot;
@@ -1033,6 +1113,32 @@ extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long l
         else relpos_attn_fwd_kernel<32, bf16, true><<<grid, 256, 0, st>>>(a);
     }
     SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel<pos>");
+    return 0;
+}
+
+// The same for T > 256 (T % 8 == 0; the slab covers one 256-key block at a time): qu / qv must be the biased projections (no u_bias /
+// v_bias); bias_out (may be null) receives the (B,H,T,T) shifted score block by block - what sarssl_relpos_attn_bwd reads.
+extern "C" int sarssl_relpos_attn_pos_long_supported(int T, int dh) { return (T > 256 && T <= 4096 && T % 8 == 0 && (dh == 64 || dh == 128)) ? 1 : 0; }
+extern "C" int sarssl_relpos_attn_fwd_pos_long(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
+                                               long ldp, void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh,
+                                               float scale, float p_drop, unsigned long long seed, int dtype, void* stream) {
+    if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_fwd_pos_long")) return -1;
+    SARSSL_REQUIRE(sarssl_relpos_attn_pos_long_supported(T, dh) && ldp % 8 == 0 && qv && pos, "sarssl_relpos_attn_fwd_pos_long(T > 256)");
+    SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr && (dtype == SARSSL_BF16 || dtype == SARSSL_F16), "sarssl_relpos_attn_fwd_pos_long");
+    AttnArgs a = {};
+    a.qu = (const h16*)qu; a.qv = (const h16*)qv; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk;
+    a.pos = (const h16*)pos; a.ldp = ldp; a.bias_out = (h16*)bias_out; a.ub = nullptr; a.vb = nullptr;
+    a.ctx = (h16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
+    dim3 grid((T + 127) / 128, B * H);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SARSSL_F16) {
+        if (dh == 128) relpos_attn_fwd_kernel<128, f16, true, 4, true><<<grid, 256, 0, st>>>(a);
+        else relpos_attn_fwd_kernel<64, f16, true, 4, true><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (dh == 128) relpos_attn_fwd_kernel<128, bf16, true, 4, true><<<grid, 256, 0, st>>>(a);
+        else relpos_attn_fwd_kernel<64, bf16, true, 4, true><<<grid, 256, 0, st>>>(a);
+    }
+    SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel<pos, long>");
     return 0;
 }
 

@@ -308,6 +308,11 @@ _DGRAD_BNRED = os.environ.get("SARSSL_DGRAD_BNRED", "1") != "0"
 _DWGLU = os.environ.get("SARSSL_DWGLU", "1") != "0"             # 0: separate glu / dwconv / cl_stats kernels (A/B runs)
 _FUSED_ATTN = os.environ.get("SARSSL_FUSED_ATTN", "1") != "0"   # 0: GEMM + softmax-kernel attention core also in bf16 mode (A/B runs)
 _ATTN_POS = os.environ.get("SARSSL_ATTN_POS", "1") != "0"       # 0: positional score by its own GEMM launch instead of inside the attention kernel (A/B runs)
+# T > 256 (config 5): the forward kernel forms the shifted score itself, one 256-key block of its slab at a time (round 6; bit-identical to
+# the score-GEMM sequence).  OFF by default: measured SLOWER on config 5 (same box, two interleaved rounds: 20.65 vs 20.33 ms fp16, 22.46 vs
+# 22.16 ms hybrid) - per (query tile, key block) the band of position tiles is re-staged through LDS behind two barriers each at one wave
+# per SIMD, which costs more than the chip-filling score GEMM it replaces plus the read of its 150 MB result
+_ATTN_POS_LONG = os.environ.get("SARSSL_ATTN_POS_LONG", "0") != "0"
 _C1IN = os.environ.get("SARSSL_C1IN", "1") != "0"             # 0: store the first layer's 64-channel output (A/B runs)
 _C1RED = os.environ.get("SARSSL_C1RED", "1") != "0"           # 0: store the gradient w.r.t. that output and reduce it in a pass of its own
 
@@ -317,7 +322,7 @@ def knobs():
     comparable with another one under the same knobs)."""
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
-            "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
+            "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_ATTN_POS": int(_ATTN_POS), "SARSSL_ATTN_POS_LONG": int(_ATTN_POS_LONG), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
             "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_PREP_ASYNC": int(_PREP_ASYNC), "SARSSL_WGRAD_SPLIT_BIG": [_WGRAD_SPLIT_BIG, _WGRAD_SPLIT_BIG_TILES], "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
@@ -813,6 +818,8 @@ def _mhsa_fwd_h(x, mod, B, T, train, saved):
         if in_kernel:
             ctx, lse, bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, biases=(ub, vb),
                                                      want_ctx32=_H_CTX)
+        elif _ATTN_POS_LONG and hip.relpos_attn_pos_long_supported(T, dh, RT.dtype):
+            ctx, lse, bias = hip.relpos_attn_fwd_pos_long(qu, qv, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, want_ctx32=_H_CTX)
         else:
             bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
             hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,
@@ -901,6 +908,10 @@ def mhsa_fwd(x, mod, B, T, train, saved):
             # T <= 256: the kernel forms the shifted positional score itself (position tiles stream through its K buffer)
             ctx, lse, bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference,
                                                      biases=(ub, vb))
+        elif _ATTN_POS_LONG and hip.relpos_attn_pos_long_supported(T, dh, RT.dtype):
+            # T > 256 (config 5): the forward kernel forms the shifted score itself, one 256-key block of the slab at a time, and writes
+            # it out for the backward kernels - no positional-score GEMM launch, no read of its result
+            ctx, lse, bias = hip.relpos_attn_fwd_pos_long(qu, qv, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference)
         else:
             bias = torch.empty((B, H, T, T), dtype=RT.dtype, device=x.device)
             hip.gemm(qv, pos, M=T, N=T, K=dh, lda=d, ldb=d, nbatch=nbh, batch_inner=H, sA=(T * d, dh), sB=(0, dh), out=bias, ldc=T,

@@ -1374,6 +1374,27 @@ def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=
     return ctx, (ctx32, lse), bias
 
 
+def relpos_attn_pos_long_supported(T, dh, dtype):
+    """Shapes the long-sequence forward with the in-kernel positional score takes (T > 256, one 256-key block of the slab at a time)."""
+    return dtype in _16 and bool(_lib.lib().sarssl_relpos_attn_pos_long_supported(c_int(T), c_int(dh)))
+
+
+def relpos_attn_fwd_pos_long(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True, want_ctx32=False):
+    """relpos_attn_fwd_pos for T > 256 (biased projections qu / qv; no u / v bias form).  Returns ctx, (ctx32, lse), bias - the (B,H,T,T)
+    shifted score as relpos_attn_bwd reads it (None when need_bwd is False)."""
+    _need_cuda(qu, qv, k, v, pos)
+    assert k.stride(0) == v.stride(0) and qu.stride(0) == qv.stride(0) and qu.dtype in _16 and \
+        all(t.dtype == qu.dtype for t in (qv, k, v, pos)) and pos.stride(1) == 1
+    ctx = torch.empty((B * T, H * dh), dtype=qu.dtype, device=qu.device)
+    ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if (need_bwd or want_ctx32) else None
+    bias = torch.empty((B, H, T, T), dtype=qu.dtype, device=qu.device) if need_bwd else None
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
+    _lib.call("sarssl_relpos_attn_fwd_pos_long", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),
+              c_long(pos.stride(0)), _p(bias), _p(ctx), c_long(ctx.stride(0)), _p(ctx32), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh),
+              c_float(scale), c_float(p_drop), c_ulonglong(seed), c_int(dt(qu)), _stream())
+    return ctx, (ctx32, lse), bias
+
+
 def relpos_attn_bwd(qu, k, v, bias, aux, dctx, dqu, dk, dv, B, H, T, dh, scale, p_drop=0.0, seed=0):
     """aux = (ctx32, lse) from relpos_attn_fwd.  Writes dqu / dk / dv (row-strided [B*T, d] views, dk and dv with the same row
     stride) and returns dbias (B,H,T,T)."""

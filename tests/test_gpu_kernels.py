@@ -901,7 +901,8 @@ def _attn_mask(B, H, T, dh, p_drop, seed, dev):
 @pytest.mark.parametrize("adt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 @pytest.mark.parametrize("B,H,T,dh", [(2, 4, 256, 128), (3, 4, 40, 64), (1, 2, 624, 64), (2, 4, 64, 32), (1, 4, 136, 128),
-                                      (2, 2, 8, 32), (1, 2, 128, 64), (2, 1, 248, 64), (1, 3, 200, 32), (2, 4, 256, 64)])
+                                      (2, 2, 8, 32), (1, 2, 128, 64), (2, 1, 248, 64), (1, 3, 200, 32), (2, 4, 256, 64),
+                                      (1, 2, 624, 128), (2, 2, 264, 64), (1, 1, 1000, 64), (1, 2, 512, 128)])
 def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
     """Positional-score GEMM written in the relative-shift layout + fused attention forward / backward against an f64 torch
     restatement of attention.py:87-113 on the same 16-bit operands (dropout mask read back from the kernel's own hash).  adt = dtype
@@ -947,6 +948,16 @@ def test_fused_relpos_attention_fwd_bwd(B, H, T, dh, p_drop, adt):
         assert none_bias is None and torch.equal(ctx_i, ctx)
     else:
         assert T > 256
+    if hip.relpos_attn_pos_long_supported(T, dh, adt):
+        # round 6, T > 256: the forward forms the shifted score per 256-key block of its slab - the GEMM's MFMA products in the GEMM's order:
+        # score tensor, output and log-sum-exp bit for bit those of the two-launch path
+        ctx_l, aux_l, bias_l = hip.relpos_attn_fwd_pos_long(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop, seed)
+        bl = bias_l.double()
+        bl[:, :, ii, ii + 1] = 0.0
+        assert torch.equal(bl, got_bias), (bl - got_bias).abs().max().item()
+        assert torch.equal(ctx_l, ctx) and torch.equal(aux_l[0], aux[0]) and torch.equal(aux_l[1], aux[1])
+        ctx_li, _, none_bias = hip.relpos_attn_fwd_pos_long(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop, seed, need_bwd=False)
+        assert none_bias is None and torch.equal(ctx_li, ctx)
     keep = torch.ones((B, H, T, T), dtype=torch.float64, device=dev)
     if p_drop > 0:
         mask = _attn_mask(B, H, T, dh, p_drop, seed, dev)
