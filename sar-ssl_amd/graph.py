@@ -52,7 +52,9 @@ class PretrainStepGraph:
         self.state = hip.step_state_new(self.dev, RT._seed ^ 0x6A09E667F3BCC909, self.lr, betas)
         self.acc = torch.zeros(2, dtype=torch.float64, device=self.dev)        # running sum of (loss, diff) since reset_epoch()
         self.nsteps = 0
-        self._plan = None
+        self._plan = None         # the first captured plan (kept under this name for tests / tools)
+        self._plans = {}          # full_pred (bool) -> (plan, pred, xin, vis_masks, ecat): the compact step and, captured on first use, the
+                                  # step with the decoder / block tails on EVERY frame (the batch whose vis an epoch returns)
         self._key = None
         self._pool = None
         self._stage = []          # ring of (pinned staging buffer, event) for the masks
@@ -197,25 +199,36 @@ class PretrainStepGraph:
         self.nsteps += 1
         return self.out
 
-    def _capture(self, x, pcm, static=False):
+    def _capture(self, x, pcm, static=False, full=False):
+        """Captures the step for this input shape.  full: the variant whose decoder and block tails run on EVERY frame (vis of the batch an
+        epoch returns, code/learner.py:131) - a second set of graphs sharing every buffer of the first (input, masks, loss word, moments,
+        step state), captured the first time it is asked for."""
         net, dev = self.net, self.dev
         src = pcm if pcm is not None else x
-        self.src = src if static else src.clone()          # input buffer of the graph (static: the caller's tensor is persistent and refilled in place)
         if pcm is not None:
             nb, nsample, nch = pcm.shape
             assert nch == 2, "graph step: 2-channel segments ('M' pairing of two mics)"
             B, T = nb, (nsample - 512) // 256 + 1
         else:
             B, T = x.shape[0], x.shape[3]
-        nm = net.patch_mask.nmasked_patch
-        o_idx, o_ch, o_mp, total = self._mask_layout(B, T, nm)
-        self.mbuf = torch.zeros(total, dtype=torch.uint8, device=dev)
-        self.idx = self.mbuf[o_idx:o_ch].view(torch.int32).view(B, nm)
-        self.ch = self.mbuf[o_ch:o_mp].view(torch.int32)
-        self.mp = self.mbuf[o_mp:total].view(B, T)
-        self.out = torch.zeros(2, dtype=torch.float32, device=dev)
-        self.one = torch.ones((), dtype=torch.float32, device=dev)
-        self.B, self.T = B, T
+        if not self._plans:                                 # buffers shared by every captured variant
+            self.src = src if static else src.clone()      # input buffer of the graph (static: the caller's tensor is persistent and refilled in place)
+            nm = net.patch_mask.nmasked_patch
+            o_idx, o_ch, o_mp, total = self._mask_layout(B, T, nm)
+            self.mbuf = torch.zeros(total, dtype=torch.uint8, device=dev)
+            self.idx = self.mbuf[o_idx:o_ch].view(torch.int32).view(B, nm)
+            self.ch = self.mbuf[o_ch:o_mp].view(torch.int32)
+            self.mp = self.mbuf[o_mp:total].view(B, T)
+            self.out = torch.zeros(2, dtype=torch.float32, device=dev)
+            self.one = torch.ones((), dtype=torch.float32, device=dev)
+            self.B, self.T = B, T
+        elif self.src.data_ptr() != src.data_ptr():
+            self.src.copy_(src, non_blocking=True)
+
+        def body(seg, with_adam):
+            if full:
+                net.__dict__["_full_pred_once"] = True      # (popped by the forward pass: decoder and block tails on every frame)
+            self._body(seg, self.src, self.idx, self.ch, self.mp, pcm is not None, with_adam=with_adam)
 
         # ---- warm-up: one eager pass without side effects (lazy kernel loading, workspaces, allocator) - buffers restored, no Adam
         bufs = [b for b in net.buffers()]
@@ -230,7 +243,7 @@ class PretrainStepGraph:
         cap.wait_stream(cur)
         try:
             with torch.cuda.stream(cap):
-                self._body(None, self.src, self.idx, self.ch, self.mp, pcm is not None, with_adam=False)
+                body(None, False)
                 cap.synchronize()
                 self.flat.grad.zero_()
                 for b, k in zip(bufs, keep):
@@ -250,7 +263,7 @@ class PretrainStepGraph:
                 try:
                     self._seed_ctr0 = RT._ctr               # (tests: the static dropout seeds of the captured launches)
                     seg.begin()
-                    self._body(seg, self.src, self.idx, self.ch, self.mp, pcm is not None, with_adam=True)
+                    body(seg, True)
                     seg.end()
                 finally:
                     hip.step_state_attach(None)
@@ -259,30 +272,36 @@ class PretrainStepGraph:
             net._stage_hook = hook
         cur.wait_stream(cap)
         torch.cuda.synchronize()
-        self._plan = seg.plan
-        self._key = (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, RT.hybrid, net.training)
+        self._plans[bool(full)] = (seg.plan, self.pred, self.xin, self.vis_masks, self.ecat)
+        if self._plan is None:
+            self._plan = seg.plan
+            self._key = (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, RT.hybrid, net.training)
 
     # ------------------------------------------------------------------------------------------------ replay
     def matches(self, x=None, pcm=None):
         src = pcm if pcm is not None else x
         return self._key is None or self._key == (tuple(src.shape), src.dtype, RT.dtype, RT.fp8, RT.hybrid, self.net.training)
 
-    def step(self, x=None, pcm=None, static=False):
+    def step(self, x=None, pcm=None, static=False, full_pred=False):
+        """full_pred: run the decoder and the encoders' last row-wise layers on every frame in this step (the full-prediction variant of
+        the captured step) - vis() then returns this very step's prediction at every frame, as the reference does for the batch an epoch
+        returns; the default (compact) step computes what the loss reads and forms the rest of vis["pred"] on request."""
         assert (x is None) != (pcm is None)
         assert RT.replay is None, "replayed dropout masks (parity tests) need the eager step"
         src = pcm if pcm is not None else x
-        if self._plan is None:
-            self._capture(x, pcm, static)
-        elif not self.matches(x, pcm):
+        full_pred = bool(full_pred)
+        if self._plan is not None and not self.matches(x, pcm):
             raise ValueError("PretrainStepGraph was captured for %r, got %r" % (self._key[0], tuple(src.shape)))
-        else:
-            if self.src.data_ptr() != src.data_ptr():
-                self.src.copy_(src, non_blocking=True)
+        if full_pred not in self._plans:
+            self._capture(x, pcm, static, full=full_pred)
+        elif self.src.data_ptr() != src.data_ptr():
+            self.src.copy_(src, non_blocking=True)
+        plan, self.pred, self.xin, self.vis_masks, self.ecat = self._plans[full_pred]
         self.flat._fresh = False
         self.flat.ensure_shadow()                          # parameters changed through torch since the last step (load_state_dict, ...)
         idx, ch = self._draw_masks(self.B, self.T)
         self._upload_masks(idx, ch, self.B, self.T)
-        for kind, item in self._plan:
+        for kind, item in plan:
             if kind == "graph":
                 item.replay()
             elif kind == "reduce":

@@ -167,20 +167,25 @@ class Learner(ABC):
             mic_sig_batch = batch[0] if isinstance(batch, (list, tuple)) else batch
             if not torch.is_tensor(mic_sig_batch):
                 mic_sig_batch = torch.as_tensor(mic_sig_batch)
-            if last:        # the batch whose vis is returned (code/learner.py:131) takes the step launch by launch with the FULL decoder (the
-                self.model.__dict__["_full_pred_once"] = True      # captured step runs it on the masked frames only): vis["pred"] = this step's prediction
+            # the batch whose vis is returned (code/learner.py:131) runs the FULL-prediction variant of the captured step (decoder and block
+            # tails on every frame: vis["pred"] = this very step's prediction) - a second set of graphs captured at its first use (round 6;
+            # round 5 took this batch launch by launch: ~450 host launches once per epoch); a batch of another shape takes the step eagerly
             if self._graph_takes_raw_batch(mic_sig_batch):                                  # STFT front-end inside the replay
                 sig = mic_sig_batch.to(self.device, non_blocking=True).contiguous()
-                if g.matches(pcm=sig) and not last:
-                    g.step(pcm=sig)
+                if g.matches(pcm=sig):
+                    g.step(pcm=sig, full_pred=last)
                 else:
+                    if last:
+                        self.model.__dict__["_full_pred_once"] = True
                     g.step_eager(pcm=sig)
                 continue
             in_batch, = self.data_preprocess(mic_sig_batch, None)
             in_batch = in_batch.contiguous().float()
-            if g.matches(x=in_batch) and not last:
-                g.step(x=in_batch)
+            if g.matches(x=in_batch):
+                g.step(x=in_batch, full_pred=last)
             else:
+                if last:
+                    self.model.__dict__["_full_pred_once"] = True
                 g.step_eager(x=in_batch)
         vis_batch = g.vis() if g.nsteps else None
         nskip = g.skipped_steps() - skipped0

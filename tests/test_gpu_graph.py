@@ -97,6 +97,47 @@ def test_graph_step_equals_eager_step(prec):
         runtime.set_precision("bf16")
 
 
+@pytest.mark.parametrize("prec", ["hybrid", "fp16"])
+def test_full_prediction_variant_of_the_captured_step(prec):
+    """Round 6 (advisor, round 5): the batch whose vis an epoch returns no longer takes the step launch by launch - `step(full_pred=True)`
+    replays a second set of graphs (decoder and block tails on EVERY frame) that shares every buffer of the compact one.  Six steps, dropout
+    off, the third and the sixth with the full prediction: captured == the same sequence with those two steps enqueued launch by launch
+    (bit for bit: parameters, moments, losses), and vis()["pred"] of a full-prediction step equals the launch-by-launch step's."""
+    from sar_ssl_amd import runtime
+    from sar_ssl_amd.graph import PretrainStepGraph
+    runtime.set_precision(prec)
+    try:
+        T, B, n = 16, 4, 6
+        xs = _batches(T, n, B)
+        res = {}
+        for form in ("captured", "eager_for_full"):
+            net, flat = _make(T, 11, 0.0)
+            g = PretrainStepGraph(net, flat, lr=1e-3)
+            random.seed(77)
+            losses, vis_pred = [], None
+            for k, x in enumerate(xs):
+                full = k in (2, 5)
+                if full and form == "eager_for_full":
+                    net.__dict__["_full_pred_once"] = True
+                    out = g.step_eager(x=x)
+                else:
+                    out = g.step(x=x, full_pred=full)
+                losses.append(float(out[0]))
+                if k == 5:
+                    v = g.vis()
+                    assert getattr(g, "ecat", None) is None              # a full-prediction step: vis["pred"] is the step's own tensor
+                    vis_pred = v["pred"].clone()
+            torch.cuda.synchronize()
+            res[form] = (losses, flat.flat.clone(), g.m.clone(), g.v.clone(), vis_pred, sorted(g._plans))
+        a, b = res["captured"], res["eager_for_full"]
+        assert a[5] == [False, True] and b[5] == [False]
+        assert a[0] == b[0], (a[0], b[0])
+        for i in (1, 2, 3, 4):
+            assert torch.equal(a[i], b[i]), i
+    finally:
+        runtime.set_precision("bf16")
+
+
 @pytest.mark.parametrize("form", ["captured", "between_graphs"])
 def test_step_with_the_native_rccl_exchange_equals_the_eager_step(form, monkeypatch):
     """Advisor (round 4): the library's own exchange (sarssl_allreduce_bucket, SARSSL_NATIVE_RCCL) inside the captured step had no test.
