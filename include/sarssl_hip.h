@@ -115,7 +115,8 @@ int sarssl_small_linear_bwd(const float* dy, const float* y, const float* x, con
 int sarssl_gemm_split(const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, int dtC, int M, int N, int K, long lda,
                       long ldb, long ldc, float out_scale, const float* bias, int act, const void* resid, long ldr, float res_scale,
                       void* preact, float p_drop, unsigned long long seed, void* stream);
-/*      LayerNorm on f32 rows with the result written as an fp16 pair (and, y32 != NULL, in f32): the operand of the Linear layer behind it. */
+/*      LayerNorm on f32 rows with the result written as an fp16 pair (and, y32 != NULL, in f32): the operand of the Linear layer behind it.
+ *      y_lo (z_lo below) may be NULL: the hi half only. */
 int sarssl_layernorm_fwd_pair(const float* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps, void* y_hi,
                               void* y_lo, long ldy, float* y32, long ldy32, float* mean, float* rstd, void* stream);
 /*      y = LN_a(x) in f32 (a Conformer block's closing LayerNorm, code/common/Conformer.py:88-90), z = LN_b(y) as a pair (the next
@@ -137,7 +138,9 @@ int sarssl_ffn2h_supported(long M, int d);
 int sarssl_ffn2h_fwd(const float* x, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_hi, float* ln_mean,
                      float* ln_rstd, const void* w1h, const void* w1l, const void* w2h, const void* w2l, const float* b1, const float* b2,
                      void* preact, void* hidden, float* y, long ldy, long M, int d, float p1, unsigned long long s1, float p2,
-                     unsigned long long s2, float out_scale, void* stream);
+                     unsigned long long s2, float out_scale, int act_pair, void* stream);
+/*      act_pair != 0: LN(x) enters the first product as a pair (hi hi + lo hi + hi lo), else as its hi half (hi hi + hi lo) - its output is
+ *      an fp16 tensor either way, whose own rounding is of the size of what the lo half adds. */
 /*      the stem's 64 -> 4 convolution with its f32 result as a pair (y4_hi = what sarssl_stem_c4_fwd stores, y4_lo the remainder;
  *      stats8 = BatchNorm(4) sums of the pair's value, may be NULL), and BatchNorm(4) affine + ReLU on the pair -> pair: the f32 operand
  *      of the frame-patch product (code/model.py:60-63). */

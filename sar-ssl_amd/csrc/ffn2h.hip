@@ -32,18 +32,21 @@ struct Ffn2hArgs {
     int M;
 };
 
-template <int D>
+// ALO: the LayerNorm result enters the first product as a pair (hi hi + lo hi + hi lo; the engine's default); !ALO: its hi half only
+// (hi hi + hi lo) - the first product's OUTPUT is an fp16 tensor, whose own rounding is of the size of what the lo half adds to the
+// per-bin result; the gradients of the f32-stream parameters do see it (engine.py, SARSSL_HYBRID_ALO)
+template <int D, bool ALO>
 __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
     constexpr int H = 4 * D, NCH = H / FFN_HC, PA = D + 8, KS1 = D / 16, DB = D / 256;
     constexpr int SA_ELEMS = 64 * PA, ST_ELEMS = 64 * FFN_PH, PY = D + 4;
-    constexpr int TILE_ELEMS = 2 * SA_ELEMS + 2 * ST_ELEMS, YST_ELEMS = 64 * PY * 2;
+    constexpr int TILE_ELEMS = (ALO ? 2 : 1) * SA_ELEMS + 2 * ST_ELEMS, YST_ELEMS = 64 * PY * 2;
     constexpr int LDS_ELEMS = TILE_ELEMS > YST_ELEMS ? TILE_ELEMS : YST_ELEMS;
     constexpr int NP1 = 2 * KS1, NP2 = 2 * 16 * DB, NPOS = NP1 + NP2;      // positions of a chunk in the wave's weight stream
     static_assert(NPOS % 16 == 0 && NP1 >= 16, "weight queue: 16 fragments in flight");
     __shared__ __attribute__((aligned(16))) uint16_t smem[LDS_ELEMS];
     uint16_t* sAh = smem;
-    uint16_t* sAl = smem + SA_ELEMS;
-    uint16_t* sH = smem + 2 * SA_ELEMS;
+    uint16_t* sAl = smem + SA_ELEMS;                    // (ALO only)
+    uint16_t* sH = smem + (ALO ? 2 : 1) * SA_ELEMS;
     uint16_t* sP = sH + ST_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
                 const float lv[4] = {ov[0] - h0.x, ov[1] - h0.y, ov[2] - h1.x, ov[3] - h1.y};
                 *(uint2*)(g.LNout + (m0 + row) * (long)D + c4 * 4) = hi;
                 *(uint2*)&sAh[row * PA + c4 * 4] = hi;
-                *(uint2*)&sAl[row * PA + c4 * 4] = pack4<f16>(lv);
+                if constexpr (ALO) *(uint2*)&sAl[row * PA + c4 * 4] = pack4<f16>(lv);
             }
             if (lane == 0) { g.ln_mean[m0 + row] = mu; g.ln_rstd[m0 + row] = rs; }
         }
@@ -133,25 +136,31 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[i][r] = 0.f;
         {
-            bf16x8 fh_[2][2], fl_[2][2];
+            bf16x8 fh_[2][2], fl_[2][ALO ? 2 : 1];
             fh_[0][0] = *(const bf16x8*)&sAh[frow * PA + fk];
             fh_[0][1] = *(const bf16x8*)&sAh[(32 + frow) * PA + fk];
-            fl_[0][0] = *(const bf16x8*)&sAl[frow * PA + fk];
-            fl_[0][1] = *(const bf16x8*)&sAl[(32 + frow) * PA + fk];
+            if constexpr (ALO) {
+                fl_[0][0] = *(const bf16x8*)&sAl[frow * PA + fk];
+                fl_[0][1] = *(const bf16x8*)&sAl[(32 + frow) * PA + fk];
+            }
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const int cur = ks & 1, nx = cur ^ 1;
                 if (ks + 1 < KS1) {
                     fh_[nx][0] = *(const bf16x8*)&sAh[frow * PA + (ks + 1) * 16 + fk];
                     fh_[nx][1] = *(const bf16x8*)&sAh[(32 + frow) * PA + (ks + 1) * 16 + fk];
-                    fl_[nx][0] = *(const bf16x8*)&sAl[frow * PA + (ks + 1) * 16 + fk];
-                    fl_[nx][1] = *(const bf16x8*)&sAl[(32 + frow) * PA + (ks + 1) * 16 + fk];
+                    if constexpr (ALO) {
+                        fl_[nx][0] = *(const bf16x8*)&sAl[frow * PA + (ks + 1) * 16 + fk];
+                        fl_[nx][1] = *(const bf16x8*)&sAl[(32 + frow) * PA + (ks + 1) * 16 + fk];
+                    }
                 }
                 const bf16x8 wh = __builtin_bit_cast(bf16x8, q[(2 * ks) & 15]);
                 S[0] = mfma16<f16>(wh, fh_[cur][0], S[0]);
                 S[1] = mfma16<f16>(wh, fh_[cur][1], S[1]);
-                S[0] = mfma16<f16>(wh, fl_[cur][0], S[0]);
-                S[1] = mfma16<f16>(wh, fl_[cur][1], S[1]);
+                if constexpr (ALO) {
+                    S[0] = mfma16<f16>(wh, fl_[cur][0], S[0]);
+                    S[1] = mfma16<f16>(wh, fl_[cur][1], S[1]);
+                }
                 refill(2 * ks);
                 const bf16x8 wl = __builtin_bit_cast(bf16x8, q[(2 * ks + 1) & 15]);
                 S[0] = mfma16<f16>(wl, fh_[cur][0], S[0]);
@@ -268,18 +277,20 @@ extern "C" int sarssl_ffn2h_supported(long M, int d) { return (M > 0 && M % 64 =
 
 // y [M][d] f32 = x + out_scale * drop(p2, s2)( (W2h + W2l) drop(p1, s1)( swish((W1h + W1l) LN(x) + b1) ) + b2 ) with LN(x) as an fp16 pair;
 // ln_hi [M][d] fp16, ln_mean / ln_rstd [M], preact / hidden [M][4d] fp16 are written for the backward pass.  Packs: sarssl_ffn_pack of
-// the weights' hi / lo fp16 shadows ([4d x d] and [d x 4d]).
+// the weights' hi / lo fp16 shadows ([4d x d] and [d x 4d]).  act_pair: LN(x) enters the first product as a pair (3 products) or as its
+// hi half (2 products).
 extern "C" int sarssl_ffn2h_fwd(const float* x, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_hi, float* ln_mean,
                                 float* ln_rstd, const void* w1h, const void* w1l, const void* w2h, const void* w2l, const float* b1,
                                 const float* b2, void* preact, void* hidden, float* y, long ldy, long M, int d, float p1,
-                                unsigned long long s1, float p2, unsigned long long s2, float out_scale, void* stream) {
+                                unsigned long long s1, float p2, unsigned long long s2, float out_scale, int act_pair, void* stream) {
     SARSSL_REQUIRE(sarssl_ffn2h_supported(M, d) && ldx % 4 == 0 && ldy % 4 == 0 && x && y && ln_gamma && ln_beta && ln_hi && ln_mean && ln_rstd &&
                    w1h && w1l && w2h && w2l && b1 && b2 && preact && hidden, "sarssl_ffn2h_fwd");
     Ffn2hArgs g;
     g.X = x; g.ldx = ldx; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps; g.LNout = (f16*)ln_hi; g.ln_mean = ln_mean; g.ln_rstd = ln_rstd;
     g.W1h = w1h; g.W1l = w1l; g.W2h = w2h; g.W2l = w2l; g.b1 = b1; g.b2 = b2; g.P = (f16*)preact; g.Hs = (f16*)hidden; g.Y = y; g.ldy = ldy;
     g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt(); g.out_scale = out_scale; g.M = (int)M;
-    ffn2h_kernel<256><<<(int)(M / 64), FFN_NT, 0, (hipStream_t)stream>>>(g);
+    if (act_pair) ffn2h_kernel<256, true><<<(int)(M / 64), FFN_NT, 0, (hipStream_t)stream>>>(g);
+    else ffn2h_kernel<256, false><<<(int)(M / 64), FFN_NT, 0, (hipStream_t)stream>>>(g);
     SARSSL_CHECK_LAUNCH("ffn2h_kernel");
     return 0;
 }

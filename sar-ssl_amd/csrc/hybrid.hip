@@ -29,7 +29,7 @@ __device__ __forceinline__ void st4_pair(f16* __restrict__ hi, f16* __restrict__
     const sarssl_f32x2 a = unpack2_f16(h.x), b = unpack2_f16(h.y);
     l.x = pack2_f16(o.x - a.x, o.y - a.y); l.y = pack2_f16(o.z - b.x, o.w - b.y);
     *(uint2*)hi = h;
-    *(uint2*)lo = l;
+    if (lo) *(uint2*)lo = l;                // (lo == null: the consumer contracts the hi half only - a Linear layer whose OUTPUT is an fp16 tensor)
 }
 
 // ---- LayerNorm forward, f32 rows -> fp16 pair (the arithmetic of layernorm_fwd_kernel<float>, csrc/elementwise.hip; the f32 result is
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pair_kernel(const float* __
                 const float4 g = *(const float4*)(gamma + c4 * 4), bb = *(const float4*)(beta + c4 * 4);
                 const float4 o = make_float4((v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y,
                                              (v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w);
-                st4_pair(yhi + row * ldy + c4 * 4, ylo + row * ldy + c4 * 4, o);
+                st4_pair(yhi + row * ldy + c4 * 4, ylo ? ylo + row * ldy + c4 * 4 : nullptr, o);
                 if (y32) *(float4*)(y32 + row * ldy32 + c4 * 4) = o;
             }
         }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pair_rows_kernel(const floa
                 for (int i = 0; i < NI; ++i) {
                     const int c4 = lr + LPR * j + 64 * i;
                     const float4 g = *(const float4*)(gamma + c4 * 4), bb = *(const float4*)(beta + c4 * 4);
-                    st4_pair(yhi + row * ldy + c4 * 4, ylo + row * ldy + c4 * 4,
+                    st4_pair(yhi + row * ldy + c4 * 4, ylo ? ylo + row * ldy + c4 * 4 : nullptr,
                              make_float4((v[j][i].x - mu) * rs * g.x + bb.x, (v[j][i].y - mu) * rs * g.y + bb.y,
                                          (v[j][i].z - mu) * rs * g.z + bb.z, (v[j][i].w - mu) * rs * g.w + bb.w));
                 }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd2_pair_kernel(const float* _
                     const float4 o = make_float4((v[i].x - mu) * rs * g.x + be.x, (v[i].y - mu) * rs * g.y + be.y,
                                                  (v[i].z - mu) * rs * g.z + be.z, (v[i].w - mu) * rs * g.w + be.w);
                     if (stage == 0) { *(float4*)(y + row * ldy + c4 * 4) = o; v[i] = o; }
-                    else st4_pair(zhi + row * ldz + c4 * 4, zlo + row * ldz + c4 * 4, o);
+                    else st4_pair(zhi + row * ldz + c4 * 4, zlo ? zlo + row * ldz + c4 * 4 : nullptr, o);
                 }
             }
             float* mean = stage ? meanb : meana; float* rstd = stage ? rstdb : rstda;
@@ -347,8 +347,8 @@ extern "C" int sarssl_cl_affine_act_pair(const void* x_hi, const void* x_lo, lon
 }
 extern "C" int sarssl_layernorm_fwd_pair(const float* x, long ldx, long M, int d, const float* gamma, const float* beta, float eps,
                                          void* y_hi, void* y_lo, long ldy, float* y32, long ldy32, float* mean, float* rstd, void* stream) {
-    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy32 & 3) == 0 && y_hi && y_lo,
-                   "sarssl_layernorm_fwd_pair");
+    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldy32 & 3) == 0 && y_hi,
+                   "sarssl_layernorm_fwd_pair");          // y_lo may be null: the hi half only
     if (!y32 && (d == 256 || d == 512) && M >= 4096) {
         const int nblk = nblocks_for(M, d == 256 ? 16 : 8, 4096);
         if (d == 256) layernorm_fwd_pair_rows_kernel<256><<<nblk, 256, 0, ST>>>(x, ldx, M, d, gamma, beta, eps, (f16*)y_hi, (f16*)y_lo, ldy, mean, rstd);
@@ -363,8 +363,8 @@ extern "C" int sarssl_layernorm_fwd_pair(const float* x, long ldx, long M, int d
 extern "C" int sarssl_layernorm_fwd2_pair(const float* x, long ldx, long M, int d, const float* gamma_a, const float* beta_a, float eps_a,
                                           float* y, long ldy, float* mean_a, float* rstd_a, const float* gamma_b, const float* beta_b,
                                           float eps_b, void* z_hi, void* z_lo, long ldz, float* mean_b, float* rstd_b, void* stream) {
-    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldz & 3) == 0 && y && z_hi && z_lo,
-                   "sarssl_layernorm_fwd2_pair");
+    SARSSL_REQUIRE(M > 0 && d > 0 && (d & 3) == 0 && d <= 1024 && (ldx & 3) == 0 && (ldy & 3) == 0 && (ldz & 3) == 0 && y && z_hi,
+                   "sarssl_layernorm_fwd2_pair");         // z_lo may be null
     layernorm_fwd2_pair_kernel<<<nblocks_for(M, 4, 4096), 256, 0, ST>>>(x, ldx, M, d, gamma_a, beta_a, eps_a, y, ldy, mean_a, rstd_a, gamma_b, beta_b,
                                                                      eps_b, (f16*)z_hi, (f16*)z_lo, ldz, mean_b, rstd_b);
     SARSSL_CHECK_LAUNCH("layernorm_fwd2_pair_kernel");

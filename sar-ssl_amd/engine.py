@@ -134,6 +134,13 @@ def mm_tn_acc(dy, x, gW, group=True, bias=None):
 _F32 = torch.float32
 _H_STEM4 = os.environ.get("SARSSL_HYBRID_STEM4", "1") != "0"    # the stem's 4-channel tensors (64 -> 4 result, BatchNorm(4) + ReLU of it) as pairs (0: fp16)
 _H_CTX = os.environ.get("SARSSL_HYBRID_CTX", "1") != "0"        # the attention context enters the output projection as a pair (0: fp16)
+# Which Linear layers fed by a LayerNorm contract the ACTIVATION as a pair (three products) instead of its fp16 rounding (two).  The CPU
+# study (profiles/r06_operand_rounding_study.txt) says the pair buys no per-bin accuracy where the layer's OUTPUT is an fp16 tensor (q / k /
+# v, the feed-forward hidden layer: rms 1.02e-4 -> 1.06e-4 eval, 2.02e-4 -> 2.05e-4 train) - measured on the GPU (profiles/
+# r06_hybrid_alo_ab.txt) the per-bin figures hold (F13 train max 5.6e-4 -> 7.3e-4, inside the 1e-3 gate) but the GRADIENT deviation of the
+# f32-stream parameters grows 2.1e-3 -> 5.7e-3 / 6.9e-3 (the positional projection's weight, the convolution module's LayerNorm bias) for
+# 0.05 ms per family of an 11.1 ms step.  Not worth it: every family keeps the pair by default; "pw1,dec1" is the 0.1 ms faster setting.
+_H_ALO = set(v for v in os.environ.get("SARSSL_HYBRID_ALO", "ffn1,qkv,pw1,dec1").split(",") if v != "none" and v)
 _H_FFN2_FWD = os.environ.get("SARSSL_HYBRID_FFN2_FWD", "1") != "0"   # the feed-forward module's forward on the f32 stream in one launch (d = 256, csrc/ffn2h.hip; 0: LayerNorm + two GEMMs)
 _H_FFN2_BWD = os.environ.get("SARSSL_HYBRID_FFN2_BWD", "1") != "0"   # the feed-forward module's data gradients in the fused launch (d = 256; 0: two GEMMs)
 _H_DLN32 = os.environ.get("SARSSL_HYBRID_DLN32", "1") != "0"    # branch gradients entering the LayerNorm backward in f32 (0: bf16)
@@ -323,7 +330,7 @@ def knobs():
     from . import runtime
     return {"SARSSL_WGRAD_GROUP": int(_WGRAD_GROUP), "SARSSL_WGRAD_CSUM": int(_WGRAD_CSUM), "SARSSL_DGRAD_BNRED": int(_DGRAD_BNRED), "SARSSL_DWGLU": int(_DWGLU),
             "SARSSL_FUSED_ATTN": int(_FUSED_ATTN), "SARSSL_ATTN_POS": int(_ATTN_POS), "SARSSL_ATTN_POS_LONG": int(_ATTN_POS_LONG), "SARSSL_C1IN": int(_C1IN), "SARSSL_C1RED": int(_C1RED),
-            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_PREP_ASYNC": int(_PREP_ASYNC), "SARSSL_WGRAD_SPLIT_BIG": [_WGRAD_SPLIT_BIG, _WGRAD_SPLIT_BIG_TILES], "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
+            "SARSSL_FUSE_DROP_BWD": int(_FUSE_DROP_BWD), "SARSSL_FFN2": int(_FFN2), "SARSSL_FFN2_FWD": sorted(_FFN2_FWD), "SARSSL_FFN2_BWD": sorted(_FFN2_BWD), "SARSSL_FFN2_LN": int(_FFN2_LN), "SARSSL_HYBRID_ALO": sorted(_H_ALO), "SARSSL_LIN256": int(_LIN256), "SARSSL_DEC_MASKED": int(_DEC_MASKED), "SARSSL_TAIL_MASKED": int(_TAIL_MASKED), "SARSSL_PREP_ASYNC": int(_PREP_ASYNC), "SARSSL_WGRAD_SPLIT_BIG": [_WGRAD_SPLIT_BIG, _WGRAD_SPLIT_BIG_TILES], "SARSSL_TWO_STREAMS": os.environ.get("SARSSL_TWO_STREAMS", "1"),
             "SARSSL_STEM_LAST_ALL_CUS": int(_STEM_LAST_ALL_CUS), "SARSSL_WGRAD_WS": os.environ.get("SARSSL_WGRAD_WS", "1"),
             "SARSSL_CONV_WS": os.environ.get("SARSSL_CONV_WS", "4"),
             "SARSSL_CONV_CUS_FWD": os.environ.get("SARSSL_CONV_CUS_FWD", os.environ.get("SARSSL_CONV_CUS", "default(256)")),
@@ -538,13 +545,14 @@ def _ffn_fwd_h(x, ff, factor, train, saved, out=None):
         packs = _ffn_packs(ff, need_bwd=not RT.inference)
         s1, s2 = (RT.next_seed() if p1 > 0 else 0), (RT.next_seed() if p2 > 0 else 0)
         y, hpre, a, lnh, stats = hip.ffn2h_fwd(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps, packs[0], packs[4], packs[1], packs[5],
-                                               l1.bias.data, l2.bias.data, d, p1=p1, s1=s1, p2=p2, s2=s2, out_scale=factor, out=out)
+                                               l1.bias.data, l2.bias.data, d, p1=p1, s1=s1, p2=p2, s2=s2, out_scale=factor, out=out,
+                                               act_pair="ffn1" in _H_ALO)
         saved.append((x, lnh, stats, hpre, a, p1, s1, p2, s2, factor))
         return y
     if pre is not None and pre[0] is seq[0]:
         ln, stats = pre[1], pre[2]
     else:
-        ln, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+        ln, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps, want_lo="ffn1" in _H_ALO)
     hpre = torch.empty((x.shape[0], l1.weight.shape[0]), dtype=torch.float16, device=x.device)
     if _replaying(train) and (p1 > 0 or p2 > 0):          # host-drawn masks in the reference's order: hidden, then output
         a = mm_nt_h(ln, wpair(l1.weight), torch.float16, bias=l1.bias.data, act=SWISH, preact=hpre)
@@ -790,7 +798,7 @@ def _mhsa_fwd_h(x, mod, B, T, train, saved):
     H, dh, d = att.num_heads, att.d_head, att.d_model
     M = B * T
     x = _as_stream(x)
-    ln, stats = hip.layernorm_fwd_pair(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps)
+    ln, stats = hip.layernorm_fwd_pair(x, mod.layer_norm.weight.data, mod.layer_norm.bias.data, mod.layer_norm.eps, want_lo="qkv" in _H_ALO)
     fused = _qkv_views(att)
     fused_lo = _qkv_views_lo(att) if fused is not None else None
     if fused is not None and fused_lo is not None:
@@ -1082,7 +1090,7 @@ def convmod_fwd(x, cm, B, T, train, saved):
     lin = (_LIN256 and not hyb and d == 256 and not _replaying(train) and x.stride(1) == 1 and hip.lin256_supported(x.shape[0], 2 * d, d, x.dtype))
     pk = _lin256_pack(cm, "pw1", need_bwd=not RT.inference) if lin else None
     if hyb:                 # f32 stream in / out; the module's inner tensors (h, c, s) are the fp16 tensors of the fp16 mode
-        lnp, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps)
+        lnp, stats = hip.layernorm_fwd_pair(x, seq[0].weight.data, seq[0].bias.data, seq[0].eps, want_lo="pw1" in _H_ALO)
         ln = lnp.hi
         h = mm_nt_h(lnp, wpair(pw1.weight, (2 * d, d)), torch.float16, bias=pw1.bias.data)
     elif pk is not None:      # LayerNorm + first pointwise convolution in one tile-resident launch (csrc/lin256.hip)
@@ -1187,8 +1195,11 @@ def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None, rows=None):
                                                                and hip.ffn2h_supported(x.shape[0], x.shape[1])):
         # (hybrid, d = 256: the next block's fused feed-forward launch normalises its rows in its own prologue)
         nln = next_blk.sequential[0].module.sequential[0]
-        y, stats, z, zstats = (hip.layernorm_fwd2_pair if RT.hybrid else hip.layernorm_fwd2)(
-            x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps)
+        if RT.hybrid:
+            y, stats, z, zstats = hip.layernorm_fwd2_pair(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps,
+                                                          want_lo="ffn1" in _H_ALO)
+        else:
+            y, stats, z, zstats = hip.layernorm_fwd2(x, seq[4].weight.data, seq[4].bias.data, seq[4].eps, nln.weight.data, nln.bias.data, nln.eps)
         # the paired LayerNorm's result travels ON the tensor object it belongs to (round 4 kept it in a process-global dict keyed by the
         # tensor's address: a stale entry could outlive its tensor and match a recycled address - advisor): whoever consumes y as the next
         # block's input finds it, anything else never sees it, and it dies with y
@@ -1253,7 +1264,7 @@ def decoder_fwd(e, dec, saved):
     l1, l2 = dec.proj[0], dec.proj[2]
     if RT.hybrid:           # f32 decoder input as an fp16 pair, fp16 hidden layer, f32 prediction
         ep = e if isinstance(e, hip.Pair) else hip.split_pair(_as_stream(e).contiguous())
-        h = mm_nt_h(ep, wpair(l1.weight), torch.float16, bias=l1.bias.data, act=RELU)
+        h = mm_nt_h(ep if "dec1" in _H_ALO else ep.hi, wpair(l1.weight), torch.float16, bias=l1.bias.data, act=RELU)
         pred = mm_nt_h(h, wpair(l2.weight), _F32, bias=l2.bias.data)
         saved.append((ep.hi, h))
         return pred

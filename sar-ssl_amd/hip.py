@@ -275,7 +275,7 @@ class Pair:
     dtype = torch.float32
 
     def float(self):
-        return self.hi.float() + self.lo.float()
+        return self.hi.float() + self.lo.float() if self.lo is not None else self.hi.float()
 
 
 def gemm_split(A, B, B_lo, *, M, N, K, out=None, out_dtype=None, ldc=None, out_scale=1.0, bias=None, act=0, resid=None, ldr=0, res_scale=1.0,
@@ -283,7 +283,7 @@ def gemm_split(A, B, B_lo, *, M, N, K, out=None, out_dtype=None, ldc=None, out_s
     """C = epilogue(A B^T + A B_lo^T [+ A_lo B^T]) - nn.Linear forward of the hybrid mode.  A: Pair (f32 activation) or an fp16 tensor
     [M, K]; B, B_lo: fp16 [N, K] (the weight's hi / lo shadows); C / resid / preact: fp16 or f32."""
     pair = isinstance(A, Pair)
-    Ah, Al = (A.hi, A.lo) if pair else (A, None)
+    Ah, Al = (A.hi, A.lo) if pair else (A, None)                 # (a Pair without its lo half contracts as the fp16 tensor hi)
     _need_cuda(Ah, Al, B, B_lo, out, bias, resid, preact)
     assert Ah.dtype == torch.float16 and B.dtype == torch.float16 and (B_lo is None or (B_lo.dtype == torch.float16 and B_lo.stride(0) == B.stride(0)))
     assert Ah.stride(1) == 1 and B.stride(1) == 1 and (Al is None or Al.stride(0) == Ah.stride(0))
@@ -311,8 +311,9 @@ def split_pair(src, want_hi=True, hi=None, lo=None):
     return Pair(hi, lo) if want_hi else lo
 
 
-def layernorm_fwd_pair(x2d, gamma, beta, eps=1e-5, save=True, want32=False, out=None):
-    """LayerNorm of f32 rows -> (Pair, stats[, y32]).  out = (hi, lo): fp16 [M, d] views with a common row stride to write into."""
+def layernorm_fwd_pair(x2d, gamma, beta, eps=1e-5, save=True, want32=False, out=None, want_lo=True):
+    """LayerNorm of f32 rows -> (Pair, stats[, y32]).  out = (hi, lo): fp16 [M, d] views with a common row stride to write into.
+    want_lo False: the hi half only (Pair.lo is None) - for a consumer that contracts the fp16 rounding of the result."""
     M, d = x2d.shape
     assert x2d.dtype == torch.float32
     if out is not None:
@@ -320,7 +321,7 @@ def layernorm_fwd_pair(x2d, gamma, beta, eps=1e-5, save=True, want32=False, out=
         assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.stride(0) == lo.stride(0) and hi.stride(1) == 1 and lo.stride(1) == 1
     else:
         hi = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
-        lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+        lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device) if want_lo else None
     y32 = torch.empty((M, d), dtype=torch.float32, device=x2d.device) if want32 else None
     stats = torch.empty((2, M), dtype=torch.float32, device=x2d.device) if save else None
     _lib.call("sarssl_layernorm_fwd_pair", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d), _p(gamma), _p(beta), c_float(eps), _p(hi), _p(lo),
@@ -328,14 +329,14 @@ def layernorm_fwd_pair(x2d, gamma, beta, eps=1e-5, save=True, want32=False, out=
     return (Pair(hi, lo), stats, y32) if want32 else (Pair(hi, lo), stats)
 
 
-def layernorm_fwd2_pair(x2d, ga, ba, epsa, gb, bb, epsb, out=None):
-    """y = LN_a(x) (f32), z = LN_b(y) (Pair) in one launch -> (y, stats_a, z, stats_b)."""
+def layernorm_fwd2_pair(x2d, ga, ba, epsa, gb, bb, epsb, out=None, want_lo=True):
+    """y = LN_a(x) (f32), z = LN_b(y) (Pair; want_lo False: hi half only) in one launch -> (y, stats_a, z, stats_b)."""
     M, d = x2d.shape
     assert x2d.dtype == torch.float32
     if out is None:
         out = torch.empty((M, d), dtype=torch.float32, device=x2d.device)
     hi = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
-    lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device)
+    lo = torch.empty((M, d), dtype=torch.float16, device=x2d.device) if want_lo else None
     sa = torch.empty((2, M), dtype=torch.float32, device=x2d.device)
     sb = torch.empty((2, M), dtype=torch.float32, device=x2d.device)
     _lib.call("sarssl_layernorm_fwd2_pair", _p(x2d), c_long(x2d.stride(0)), c_long(M), c_int(d), _p(ga), _p(ba), c_float(epsa), _p(out),
@@ -422,7 +423,7 @@ def ffn2h_supported(M, d):
     return bool(_lib.lib().sarssl_ffn2h_supported(c_long(M), c_int(d)))
 
 
-def ffn2h_fwd(x, gamma, beta, eps, w1h, w1l, w2h, w2l, b1, b2, d, p1=0.0, s1=0, p2=0.0, s2=0, out_scale=1.0, out=None):
+def ffn2h_fwd(x, gamma, beta, eps, w1h, w1l, w2h, w2l, b1, b2, d, p1=0.0, s1=0, p2=0.0, s2=0, out_scale=1.0, out=None, act_pair=False):
     """Hybrid mode, d = 256: y = x + out_scale * drop2(W2 drop1(swish(W1 LN(x) + b1)) + b2) on the f32 stream in one launch
     -> (y f32, preact fp16 [M, 4d], hidden fp16 [M, 4d], ln_hi fp16 [M, d], stats f32 [2, M])."""
     _need_cuda(x, w1h, w1l, w2h, w2l, b1, b2, out)
@@ -437,7 +438,7 @@ def ffn2h_fwd(x, gamma, beta, eps, w1h, w1l, w2h, w2l, b1, b2, d, p1=0.0, s1=0, 
     with _Timed("ffn2h_fwd[d%d]" % d if _prof_shapes and _prof is not None else None):
         _lib.call("sarssl_ffn2h_fwd", _p(x), c_long(x.stride(0)), _p(gamma), _p(beta), c_float(eps), _p(lno), _p(stats[0]), _p(stats[1]),
                   _p(w1h), _p(w1l), _p(w2h), _p(w2l), _p(b1), _p(b2), _p(pre), _p(hid), _p(out), c_long(out.stride(0)), c_long(M), c_int(d),
-                  c_float(p1), c_ulonglong(s1), c_float(p2), c_ulonglong(s2), c_float(out_scale), _stream())
+                  c_float(p1), c_ulonglong(s1), c_float(p2), c_ulonglong(s2), c_float(out_scale), c_int(1 if act_pair else 0), _stream())
     return out, pre, hid, lno, stats
 
 

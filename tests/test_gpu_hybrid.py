@@ -101,6 +101,8 @@ def test_layernorm_pair_and_stream_backward(shape):
     assert torch.equal(p.lo, (y32 - y32.half().float()).half())
     p2, _, y2 = hip.layernorm_fwd_pair(x, gamma, beta, 1e-5, want32=True)
     assert torch.equal(y2, y32) and torch.equal(p2.hi, p.hi)
+    p3, st3 = hip.layernorm_fwd_pair(x, gamma, beta, 1e-5, want_lo=False)            # hi half only
+    assert p3.lo is None and torch.equal(p3.hi, p.hi) and torch.equal(st3, stats)
     # two LayerNorms in a row
     gb = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
     bb = (0.1 * torch.randn(d, generator=g)).to(dev)
@@ -108,6 +110,8 @@ def test_layernorm_pair_and_stream_backward(shape):
     assert torch.equal(ya, y32) and torch.equal(sa, st32)
     zp, zs = hip.layernorm_fwd_pair(ya, gb, bb, 1e-5)
     assert torch.equal(z.hi, zp.hi) and torch.equal(z.lo, zp.lo) and torch.equal(sb, zs)
+    ya3, _, z3, sb3 = hip.layernorm_fwd2_pair(x, gamma, beta, 1e-5, gb, bb, 1e-5, want_lo=False)
+    assert z3.lo is None and torch.equal(ya3, ya) and torch.equal(z3.hi, z.hi) and torch.equal(sb3, sb)
     # backward on the stream: f32 and bf16 branch gradients, with and without the dropped bf16 copy
     xr = x.double().requires_grad_(True)
     dyf = torch.randn(M, d, generator=g).to(dev)
@@ -132,11 +136,13 @@ def test_layernorm_pair_and_stream_backward(shape):
         assert torch.equal(dx_b, dx) and torch.equal(c16, dx.bfloat16())
 
 
+@pytest.mark.parametrize("act_pair", [False, True])
 @pytest.mark.parametrize("train", [False, True])
-def test_fused_feed_forward_on_the_f32_stream_equals_the_unfused_sequence(train, monkeypatch):
+def test_fused_feed_forward_on_the_f32_stream_equals_the_unfused_sequence(train, act_pair, monkeypatch):
     """csrc/ffn2h.hip (LayerNorm + both Linear layers in one launch, d = 256) against the hybrid mode's unfused sequence (LayerNorm -> pair,
     two sarssl_gemm_split launches): the tensors saved for the backward pass bit for bit (same MFMA products in the same order, same
-    dropout masks), the f32 result to an ulp (one fused multiply-add in the residual), and the result against an f64 reference."""
+    dropout masks), the f32 result to an ulp (one fused multiply-add in the residual), and the result against an f64 reference.
+    act_pair: LN(x) enters the first product as a pair (three products) or as its fp16 rounding (two; engine._H_ALO)."""
     from sar_ssl_amd import engine, runtime
     from sar_ssl_amd.common.conformer.feed_forward import FeedForwardModule
     dev = _dev()
@@ -148,6 +154,8 @@ def test_fused_feed_forward_on_the_f32_stream_equals_the_unfused_sequence(train,
             ff.sequential[0].weight.add_(0.1 * torch.randn(256, device=dev)); ff.sequential[0].bias.add_(0.1 * torch.randn(256, device=dev))
         x = (torch.randn(2048, 256, device=dev) * 1.5 + 0.2)
         res = {}
+        monkeypatch.setattr(engine, "_H_ALO", {"ffn1"} if act_pair else set())
+        tag = "hybrid.ffn2h.%s.%s" % ("pair" if act_pair else "hi", "train" if train else "eval")
         for fused in (True, False):
             monkeypatch.setattr(engine, "_H_FFN2_FWD", fused)
             runtime.RT.manual_seed(99)
@@ -161,12 +169,12 @@ def test_fused_feed_forward_on_the_f32_stream_equals_the_unfused_sequence(train,
         # up to the f32 summation order, i.e. an fp16 ulp on a fraction of the entries
         for i, name in ((3, "preact"), (4, "hidden")):
             a, b = sf[i].float(), su[i].float()
-            check("hybrid.ffn2h.%s.%s_vs_unfused" % ("train" if train else "eval", name), ((a - b).abs().max() / b.abs().max()).item(), 1e-3)
+            check("%s.%s_vs_unfused" % (tag, name), ((a - b).abs().max() / b.abs().max()).item(), 1e-3)
             assert (a != b).float().mean().item() < 0.02, name
             if train and name == "hidden":
                 assert torch.equal(a == 0, b == 0)            # the same dropout mask
         assert sf[5:] == su[5:]
-        check("hybrid.ffn2h.%s.y_vs_unfused" % ("train" if train else "eval"), _rel(yf, yu), 2e-4)
+        check(tag + ".y_vs_unfused", _rel(yf, yu), 2e-4)
         if not train:
             seq = ff.sequential
             xd = x.double()
@@ -174,6 +182,6 @@ def test_fused_feed_forward_on_the_f32_stream_equals_the_unfused_sequence(train,
             h = torch.nn.functional.silu(ln @ seq[1].linear.weight.double().t() + seq[1].linear.bias.double())
             ref = xd + 0.5 * (h @ seq[4].linear.weight.double().t() + seq[4].linear.bias.double())
             # the hidden activation is an fp16 tensor (2^-12 per element): the module's contribution carries that, the stream itself is f32
-            check("hybrid.ffn2h.eval.y_vs_f64", _rel(yf, ref), 2e-4)
+            check(tag + ".y_vs_f64", _rel(yf, ref), 2e-4)
     finally:
         runtime.set_precision("bf16")
