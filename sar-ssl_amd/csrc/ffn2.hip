@@ -53,6 +53,7 @@ struct Ffn2Args {
     const float* ln_g; const float* ln_b; float ln_eps;
     void* LNout; float* ln_mean; float* ln_rstd;
     void* Y2; float* ln_partial;
+    int rot;                                   // chunk rotation per workgroup (see the weight queue)
 };
 
 #include "ffn_common.h"
@@ -81,9 +82,14 @@ __global__ __launch_bounds__(FFN_NT) void ffn2_kernel(Ffn2Args g) {
 
     // weight queue: 16 fragments (16 KiB per wave) in flight; position p of a product uses q[p % 16] and refills it with the fragment
     // 16 positions further down the wave's stream (first product of chunk c, second product of chunk c, first product of chunk c + 1, ...)
+    // Every workgroup streams the same weight packs: started on the same chunk, the 32 CUs of an XCD (workgroups b, b + 8, ...) ask its L2
+    // for the same lines at the same time.  Workgroup b walks the chunks from (b / 8) % NCH instead - the second product's sum over the
+    // chunks has a fixed order per workgroup either way.  -5 % on the launch (tools/bench_ffn2.py, SARSSL_FFN_ROT=0 for the old order).
+    static_assert((NCH & (NCH - 1)) == 0, "chunk rotation");
+    const int c0 = g.rot ? (int)((blockIdx.x >> 3) & (NCH - 1)) : 0;
     uint4 q[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) q[j] = *w1_piece(0, j);
+    for (int j = 0; j < 16; ++j) q[j] = *w1_piece(c0, j);
 
     // ---- input tile -> LDS (padded pitch: conflict-free ds_read_b128 fragment reads)
     if (!BWD && g.X) {
@@ -152,8 +158,9 @@ __global__ __launch_bounds__(FFN_NT) void ffn2_kernel(Ffn2Args g) {
     const int trow = tid >> 5, tch = tid & 31;
     __syncthreads();
 
-    for (int c = 0; c < NCH; ++c) {
-        const int cn = c + 1 < NCH ? c + 1 : c;
+    for (int it = 0; it < NCH; ++it) {
+        const int c = (it + c0) & (NCH - 1);
+        const int cn = it + 1 < NCH ? ((c + 1) & (NCH - 1)) : c;
         uint4 hp_regs[4];
         if constexpr (BWD) {        // the chunk's saved pre-activation tile: requested now, parked in LDS behind the first product
             const TP* P = (const TP*)g.P;
@@ -481,7 +488,7 @@ extern "C" int sarssl_ffn2_fwd(const void* ln, long ldln, const void* w1p, const
     g.X = x_ln; g.ldx = ldx; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps; g.LNout = ln_out; g.ln_mean = ln_mean; g.ln_rstd = ln_rstd;
     g.Y2 = nullptr; g.ln_partial = nullptr;
     g.A = ln; g.lda = ldln; g.W1p = w1p; g.W2p = w2p; g.b1 = b1; g.b2 = b2; g.P = preact; g.Hs = hidden; g.Y = y; g.ldy = ldy;
-    g.R = resid; g.ldr = ldr; g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt(); g.out_scale = out_scale; g.M = (int)M;
+    g.R = resid; g.ldr = ldr; g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt(); g.rot = ffn_rot(); g.out_scale = out_scale; g.M = (int)M;
     if (dtype == SARSSL_F16) return ffn2_launch<f16, f16, false>(g, d, (hipStream_t)stream);
     if (dtype == SARSSL_BF16) return ffn2_launch<bf16, bf16, false>(g, d, (hipStream_t)stream);
     sarssl_set_error("sarssl_ffn2_fwd: dtype %d", dtype);
@@ -500,7 +507,7 @@ extern "C" int sarssl_ffn2_bwd(const void* dz2, long lddz, const void* w2tp, con
     SARSSL_REQUIRE(!x_ln || (ldx % 8 == 0 && ln_gamma && ln_mean && ln_rstd && (!resid || ldr % 8 == 0)), "sarssl_ffn2_bwd(layernorm)");
     Ffn2Args g;
     g.A = dz2; g.lda = lddz; g.W1p = w2tp; g.W2p = w1tp; g.b1 = nullptr; g.b2 = nullptr; g.P = const_cast<void*>(preact); g.Hs = dh; g.Y = dln;
-    g.ldy = lddln; g.R = x_ln ? resid : nullptr; g.ldr = ldr; g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt();
+    g.ldy = lddln; g.R = x_ln ? resid : nullptr; g.ldr = ldr; g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt(); g.rot = ffn_rot();
     g.out_scale = x_ln ? gscale2 : 1.f;
     g.M = (int)M;
     g.X = x_ln; g.ldx = ldx; g.ln_g = ln_gamma; g.ln_b = nullptr; g.ln_eps = 0.f; g.LNout = nullptr; g.ln_mean = const_cast<float*>(ln_mean);

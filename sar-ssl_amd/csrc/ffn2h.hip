@@ -30,13 +30,18 @@ struct Ffn2hArgs {
     float p1, p2; unsigned long long s1, s2; const unsigned long long* salt;
     float out_scale;
     int M;
+    int rot;                                   // chunk rotation per workgroup (see the chunk loop)
+    unsigned long long* stamps;                // tools/bench_ffn2.py --hybrid-stamps: s_memtime at the phase boundaries of workgroup 0
 };
+#define FSTAMP(k) do { if (g.stamps && blockIdx.x == 0 && lane == 0) g.stamps[w * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // ALO: the LayerNorm result enters the first product as a pair (hi hi + lo hi + hi lo; the engine's default); !ALO: its hi half only
 // (hi hi + hi lo) - the first product's OUTPUT is an fp16 tensor, whose own rounding is of the size of what the lo half adds to the
 // per-bin result; the gradients of the f32-stream parameters do see it (engine.py, SARSSL_HYBRID_ALO)
-template <int D, bool ALO>
+template <int D, bool ALO, int ABL = 0>
 __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
+    // ABL (tools/bench_ffn2.py --hybrid, SARSSL_FFN_ABL): ablation builds for timing only - 1: no stores of the saved tensors, 2: no MFMAs,
+    // 4: no weight refills, 8: no activation arithmetic, 16: no LayerNorm arithmetic
     constexpr int H = 4 * D, NCH = H / FFN_HC, PA = D + 8, KS1 = D / 16, DB = D / 256;
     constexpr int SA_ELEMS = 64 * PA, ST_ELEMS = 64 * FFN_PH, PY = D + 4;
     constexpr int TILE_ELEMS = (ALO ? 2 : 1) * SA_ELEMS + 2 * ST_ELEMS, YST_ELEMS = 64 * PY * 2;
@@ -58,15 +63,27 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
     const uint4* W2l = (const uint4*)g.W2l + lane;
     // position P of chunk c in the wave's stream: first product ks = P / 2 (even: hi pack, odd: lo pack), then the second product
     // (k-step ksl, column block dbi) = (P - NP1) / 2, same parity rule
+    // k rotation (g.rot == 2): workgroup b contracts both products' k-steps from k0 on (k0, k0 + 1, ..., wrapping at 16).  The operand tiles
+    // are STORED in LDS with their columns rotated by 16 k0, so the fragment reads keep their compile-time offsets; only the weight
+    // stream's piece index (scalar arithmetic) carries k0
+    const int k0 = __builtin_amdgcn_readfirstlane(g.rot == 2 ? (int)((blockIdx.x >> 5) & 7) * 2 : 0);
+    static_assert(KS1 == 16, "k rotation");
     auto piece = [&](int c, int P) -> const uint4* {
-        if (P < NP1) return ((P & 1) ? W1l : W1h) + ((long)((c * 8 + w) * KS1 + (P >> 1)) << 6);
+        if (P < NP1) return ((P & 1) ? W1l : W1h) + ((long)__builtin_amdgcn_readfirstlane((c * 8 + w) * KS1 + (((P >> 1) + k0) & 15)) << 6);
         const int i2 = (P - NP1) >> 1;
-        return (((P - NP1) & 1) ? W2l : W2h) + ((long)((w * DB + i2 % DB) * (H / 16) + c * 16 + i2 / DB) << 6);
+        return (((P - NP1) & 1) ? W2l : W2h) + ((long)__builtin_amdgcn_readfirstlane((w * DB + i2 % DB) * (H / 16) + c * 16 + ((i2 / DB + k0) & 15)) << 6);
+    };
+    auto mm = [&](const bf16x8& a, const bf16x8& b, const f32x16& acc) -> f32x16 {
+        if constexpr (ABL & 2) { f32x16 r = acc; r[0] += __builtin_bit_cast(float, (uint32_t)a[0] | ((uint32_t)b[0] << 16)); return r; }
+        else return mfma16<f16>(a, b, acc);
     };
     uint4 q[16];
+    // chunk rotation per workgroup as in ffn2_kernel (csrc/ffn2.hip): the CUs of an XCD do not ask its L2 for the same lines at the same time
+    const int c0 = g.rot ? (int)((blockIdx.x >> 3) & (NCH - 1)) : 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) q[j] = *piece(0, j);
+    for (int j = 0; j < 16; ++j) q[j] = *piece(c0, j);
 
+    FSTAMP(0);
     // ---- LayerNorm of the tile's rows (one wave per row, rows w * 8 .. w * 8 + 7) -> hi / lo tiles in LDS, hi to HBM
     {
         constexpr int NVL = D / 256;
@@ -101,12 +118,14 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
                 const sarssl_f32x2 h0 = unpack2_f16(hi.x), h1 = unpack2_f16(hi.y);
                 const float lv[4] = {ov[0] - h0.x, ov[1] - h0.y, ov[2] - h1.x, ov[3] - h1.y};
                 *(uint2*)(g.LNout + (m0 + row) * (long)D + c4 * 4) = hi;
-                *(uint2*)&sAh[row * PA + c4 * 4] = hi;
-                if constexpr (ALO) *(uint2*)&sAl[row * PA + c4 * 4] = pack4<f16>(lv);
+                const int cr = (c4 * 4 - 16 * k0) & (D - 1);                        // (rotated column, see k0)
+                *(uint2*)&sAh[row * PA + cr] = hi;
+                if constexpr (ALO) *(uint2*)&sAl[row * PA + cr] = pack4<f16>(lv);
             }
             if (lane == 0) { g.ln_mean[m0 + row] = mu; g.ln_rstd[m0 + row] = rs; }
         }
     }
+    FSTAMP(1);
     FfnDrop d1;
     d1.init(g.p1, g.s1, g.salt);
 
@@ -120,13 +139,19 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     const int hl0 = w * 32 + 4 * (lane >> 5);
+    const int hr0 = (hl0 - 16 * k0) & (FFN_HC - 1);                // the same columns in the rotated hidden tile (k0 even: whole 32-column blocks move)
     const int trow = tid >> 5, tch = tid & 31;
+    const int tcr = (tch * 8 - 16 * k0) & (FFN_HC - 1);
     __syncthreads();
+    FSTAMP(2);
 
-    for (int c = 0; c < NCH; ++c) {
-        const int cn = c + 1 < NCH ? c + 1 : c;
+    static_assert((NCH & (NCH - 1)) == 0, "chunk rotation");
+    for (int it = 0; it < NCH; ++it) {
+        const int c = (it + c0) & (NCH - 1);
+        const int cn = it + 1 < NCH ? ((c + 1) & (NCH - 1)) : c;
         auto refill = [&](int P) {                          // queue slot of position P <- the fragment 16 positions further down the stream
             const int nxt = P + 16;
+            if constexpr (ABL & 4) return;
             q[P & 15] = nxt < NPOS ? *piece(c, nxt) : *piece(cn, nxt - NPOS);       // (last chunk: a harmless re-read of its own fragments)
         };
         // ---- first product: S^T[h][m] = sum_k (W1_hi + W1_lo)[h][k] (A_hi + A_lo)[m][k] without the lo lo term
@@ -155,19 +180,20 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
                     }
                 }
                 const bf16x8 wh = __builtin_bit_cast(bf16x8, q[(2 * ks) & 15]);
-                S[0] = mfma16<f16>(wh, fh_[cur][0], S[0]);
-                S[1] = mfma16<f16>(wh, fh_[cur][1], S[1]);
+                S[0] = mm(wh, fh_[cur][0], S[0]);
+                S[1] = mm(wh, fh_[cur][1], S[1]);
                 if constexpr (ALO) {
-                    S[0] = mfma16<f16>(wh, fl_[cur][0], S[0]);
-                    S[1] = mfma16<f16>(wh, fl_[cur][1], S[1]);
+                    S[0] = mm(wh, fl_[cur][0], S[0]);
+                    S[1] = mm(wh, fl_[cur][1], S[1]);
                 }
                 refill(2 * ks);
                 const bf16x8 wl = __builtin_bit_cast(bf16x8, q[(2 * ks + 1) & 15]);
-                S[0] = mfma16<f16>(wl, fh_[cur][0], S[0]);
-                S[1] = mfma16<f16>(wl, fh_[cur][1], S[1]);
+                S[0] = mm(wl, fh_[cur][0], S[0]);
+                S[1] = mm(wl, fh_[cur][1], S[1]);
                 refill(2 * ks + 1);
             }
         }
+        FSTAMP(3 + it * 6);
         // ---- epilogue of the first product in the accumulators' own layout (lane = row m, registers = 4 x 4 consecutive hidden units)
         {
             float4 bq[4];
@@ -182,25 +208,29 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
                     float v[4] = {S[i][4 * gq + 0] + bq[gq].x, S[i][4 * gq + 1] + bq[gq].y, S[i][4 * gq + 2] + bq[gq].z, S[i][4 * gq + 3] + bq[gq].w};
                     *(uint2*)&sP[m * FFN_PH + hl] = pack4<f16>(v);                 // pre-activation as saved for backward
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sigmoidf_(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = (ABL & 8) ? v[e] : v[e] * sigmoidf_(v[e]);
                     if (d1.p > 0.f) {
                         float k[4];
                         d1.scale4((unsigned long long)(m0 + m) * H + (unsigned long long)(c * FFN_HC + hl), k);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= k[e];
                     }
-                    *(uint2*)&sH[m * FFN_PH + hl] = pack4<f16>(v);
+                    *(uint2*)&sH[m * FFN_PH + hr0 + 8 * gq] = pack4<f16>(v);
                 }
             }
         }
+        FSTAMP(4 + it * 6);
         __syncthreads();
+        FSTAMP(5 + it * 6);
         // ---- the tiles leave for HBM row by row ...
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if constexpr (ABL & 1) break;
             const int row = trow + 16 * j;
-            *(uint4*)(g.Hs + (m0 + row) * H + c * FFN_HC + tch * 8) = *(const uint4*)&sH[row * FFN_PH + tch * 8];
+            *(uint4*)(g.Hs + (m0 + row) * H + c * FFN_HC + tch * 8) = *(const uint4*)&sH[row * FFN_PH + tcr];
             *(uint4*)(g.P + (m0 + row) * H + c * FFN_HC + tch * 8) = *(const uint4*)&sP[row * FFN_PH + tch * 8];
         }
+        FSTAMP(6 + it * 6);
         // ---- ... while the second product contracts the hidden tile against W2_hi and W2_lo
         {
             bf16x8 fh[2][2];
@@ -217,17 +247,19 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
                 for (int dbi = 0; dbi < DB; ++dbi) {
                     const int P = NP1 + 2 * (ksl * DB + dbi);
                     const bf16x8 wh = __builtin_bit_cast(bf16x8, q[P & 15]);
-                    Y[dbi][0] = mfma16<f16>(wh, fh[cur][0], Y[dbi][0]);
-                    Y[dbi][1] = mfma16<f16>(wh, fh[cur][1], Y[dbi][1]);
+                    Y[dbi][0] = mm(wh, fh[cur][0], Y[dbi][0]);
+                    Y[dbi][1] = mm(wh, fh[cur][1], Y[dbi][1]);
                     refill(P);
                     const bf16x8 wl = __builtin_bit_cast(bf16x8, q[(P + 1) & 15]);
-                    Y[dbi][0] = mfma16<f16>(wl, fh[cur][0], Y[dbi][0]);
-                    Y[dbi][1] = mfma16<f16>(wl, fh[cur][1], Y[dbi][1]);
+                    Y[dbi][0] = mm(wl, fh[cur][0], Y[dbi][0]);
+                    Y[dbi][1] = mm(wl, fh[cur][1], Y[dbi][1]);
                     refill(P + 1);
                 }
             }
         }
+        FSTAMP(7 + it * 6);
         __syncthreads();
+        FSTAMP(8 + it * 6);
     }
 
     // ---- result: accumulators -> f32 LDS staging -> 8-wide row pieces: bias, dropout, scale, f32 residual
@@ -240,7 +272,9 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
             for (int gq = 0; gq < 4; ++gq)
                 *(float4*)&sY[(i * 32 + frow) * PY + (w * DB + dbi) * 32 + 8 * gq + 4 * (lane >> 5)] =
                     make_float4(Y[dbi][i][4 * gq + 0], Y[dbi][i][4 * gq + 1], Y[dbi][i][4 * gq + 2], Y[dbi][i][4 * gq + 3]);
+    FSTAMP(27);
     __syncthreads();
+    FSTAMP(28);
     {
         constexpr int CPRW = D / 8, RPI = FFN_NT / CPRW;
         const int r = tid / CPRW, ch = tid % CPRW, n = ch * 8;
@@ -271,7 +305,11 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
             st8(g.Y + m * g.ldy + n, v);
         }
     }
+    FSTAMP(29);
 }
+
+static unsigned long long* g_ffn_stamps = nullptr;
+extern "C" int sarssl_ffn_stamp_buffer(void* p) { g_ffn_stamps = (unsigned long long*)p; return 0; }      // (timing tool hook, not part of the ABI)
 
 extern "C" int sarssl_ffn2h_supported(long M, int d) { return (M > 0 && M % 64 == 0 && d == 256) ? 1 : 0; }
 
@@ -289,6 +327,24 @@ extern "C" int sarssl_ffn2h_fwd(const float* x, long ldx, const float* ln_gamma,
     g.X = x; g.ldx = ldx; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = ln_eps; g.LNout = (f16*)ln_hi; g.ln_mean = ln_mean; g.ln_rstd = ln_rstd;
     g.W1h = w1h; g.W1l = w1l; g.W2h = w2h; g.W2l = w2l; g.b1 = b1; g.b2 = b2; g.P = (f16*)preact; g.Hs = (f16*)hidden; g.Y = y; g.ldy = ldy;
     g.p1 = p1; g.p2 = p2; g.s1 = s1; g.s2 = s2; g.salt = sarssl_dropout_salt(); g.out_scale = out_scale; g.M = (int)M;
+    g.rot = ffn_rot();
+    g.stamps = g_ffn_stamps;
+    static const int abl = [] { const char* e = getenv("SARSSL_FFN_ABL"); return e ? atoi(e) : 0; }();
+    if (abl && act_pair) {
+        const int nb = (int)(M / 64);
+        hipStream_t st = (hipStream_t)stream;
+        switch (abl) {
+            case 1: ffn2h_kernel<256, true, 1><<<nb, FFN_NT, 0, st>>>(g); break;
+            case 2: ffn2h_kernel<256, true, 2><<<nb, FFN_NT, 0, st>>>(g); break;
+            case 4: ffn2h_kernel<256, true, 4><<<nb, FFN_NT, 0, st>>>(g); break;
+            case 6: ffn2h_kernel<256, true, 6><<<nb, FFN_NT, 0, st>>>(g); break;
+            case 8: ffn2h_kernel<256, true, 8><<<nb, FFN_NT, 0, st>>>(g); break;
+            case 9: ffn2h_kernel<256, true, 9><<<nb, FFN_NT, 0, st>>>(g); break;
+            case 15: ffn2h_kernel<256, true, 15><<<nb, FFN_NT, 0, st>>>(g); break;
+            default: SARSSL_REQUIRE(false, "SARSSL_FFN_ABL");
+        }
+        return 0;
+    }
     if (act_pair) ffn2h_kernel<256, true><<<(int)(M / 64), FFN_NT, 0, (hipStream_t)stream>>>(g);
     else ffn2h_kernel<256, false><<<(int)(M / 64), FFN_NT, 0, (hipStream_t)stream>>>(g);
     SARSSL_CHECK_LAUNCH("ffn2h_kernel");

@@ -1,6 +1,13 @@
 // Helpers shared by the row-tile-resident fused launches (ffn2.hip, lin256.hip).
 #pragma once
+#include <stdlib.h>
 #include "common.h"
+
+// SARSSL_FFN_ROT=0: every workgroup of the fused feed-forward launches walks the hidden chunks from chunk 0 (the order up to round 6)
+static inline int ffn_rot() {
+    static const int rot = [] { const char* e = getenv("SARSSL_FFN_ROT"); return e ? atoi(e) : 1; }();
+    return rot;
+}
 
 struct FfnDrop {
     unsigned long long seed; uint32_t key0, thr; float inv_keep; float p;

@@ -1328,7 +1328,16 @@ def test_fused_feed_forward_module_fwd_bwd(M, d, p_drop, dtp):
     y_r = hip.gemm(a_r, W2, M=M, N=d, K=H, lda=H, ldb=H, bias=b2, p_drop=p_drop, seed=s2, out_scale=factor, resid=x, ldr=d, res_scale=1.0)
     assert torch.equal(hpre, hpre_r)
     assert torch.equal(a, a_r)
-    assert _relerr(y, y_r) < 1e-6
+    # workgroups 8, 9, ... walk the hidden chunks from another start (csrc/ffn2.hip, chunk rotation): their sum over the hidden dimension
+    # has another order than the GEMM's K loop - the 16-bit result may differ by a rounding on a few entries
+    rotated = M > 8 * 64
+
+    def same(u, v):
+        if not rotated:
+            return _relerr(u, v) < 1e-6
+        ulp = 2.0 ** (-10 if u.dtype == torch.float16 else -7)
+        return _relerr(u, v) <= ulp and (u != v).float().mean().item() < 0.05
+    assert same(y, y_r)
     # (2) f64, with the kernel's own masks (read back from its outputs: hidden == 0 where dropped; second mask from the unfused twin at p = 1 - 1)
     h64 = ln.double() @ W1.double().t() + b1.double()
     act = h64 * torch.sigmoid(h64)
@@ -1353,7 +1362,7 @@ def test_fused_feed_forward_module_fwd_bwd(M, d, p_drop, dtp):
     dln_r = hip.gemm(dh_r, W1g, a_kc=True, b_kc=False, M=M, N=d, K=H, lda=H, ldb=d)
     assert dh.dtype == gdt and dln.dtype == gdt
     assert torch.equal(dh, dh_r)
-    assert _relerr(dln, dln_r) < 1e-6
+    assert same(dln, dln_r)
     hp = hpre.double()
     sg = torch.sigmoid(hp)
     dh64 = (dz2.double() @ W2g.double()) * (sg * (1 + hp * (1 - sg)))
