@@ -63,10 +63,10 @@ __global__ __launch_bounds__(FFN_NT) void ffn2h_kernel(Ffn2hArgs g) {
     const uint4* W2l = (const uint4*)g.W2l + lane;
     // position P of chunk c in the wave's stream: first product ks = P / 2 (even: hi pack, odd: lo pack), then the second product
     // (k-step ksl, column block dbi) = (P - NP1) / 2, same parity rule
-    // k rotation (g.rot == 2): workgroup b contracts both products' k-steps from k0 on (k0, k0 + 1, ..., wrapping at 16).  The operand tiles
+    // k rotation (with the chunk rotation, g.rot != 0): workgroup b contracts both products' k-steps from k0 on (k0, k0 + 1, ..., wrapping at 16).  The operand tiles
     // are STORED in LDS with their columns rotated by 16 k0, so the fragment reads keep their compile-time offsets; only the weight
     // stream's piece index (scalar arithmetic) carries k0
-    const int k0 = __builtin_amdgcn_readfirstlane(g.rot == 2 ? (int)((blockIdx.x >> 5) & 7) * 2 : 0);
+    const int k0 = __builtin_amdgcn_readfirstlane(g.rot ? (int)((blockIdx.x >> 5) & 7) * 2 : 0);
     static_assert(KS1 == 16, "k rotation");
     auto piece = [&](int c, int P) -> const uint4* {
         if (P < NP1) return ((P & 1) ? W1l : W1h) + ((long)__builtin_amdgcn_readfirstlane((c * 8 + w) * KS1 + (((P >> 1) + k0) & 15)) << 6);

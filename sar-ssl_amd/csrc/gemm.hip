@@ -28,11 +28,6 @@
 // m; the epilogue transposes the accumulators through LDS so every thread stores 16-byte pieces of contiguous rows.
 #include "gemm_epilogue.h"
 #include <stdlib.h>
-static int gemm_krot() {
-    static const int v = [] { const char* e = getenv("SARSSL_GEMM_KROT"); return (e && atoi(e)) ? 2 : 0; }();
-    return v;
-}
-#include <stdlib.h>
 
 #define BN 128
 #define BK 64
@@ -149,10 +144,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
     const TB* pb = (const TB*)g.B + z0 * g.sB0 + z1 * g.sB1 +
                    (BKC ? (long)(n0 + (tid >> 3)) * g.ldb + k_begin + (tid & 7) * 8 : (long)(k_begin + tid / CPRB) * g.ldb + n0 + (tid % CPRB) * 8);
     const long stepA = AKC ? BK : (long)BK * g.lda, stepB = BKC ? BK : (long)BK * g.ldb;
-    // K-tile rotation (g.prio & 2, experiment): the workgroups that share an operand panel start their walk over K at different tiles, so
-    // they do not ask the XCD's L2 for the same lines at the same time (whole K-tiles only; the sum over K keeps a fixed order per tile)
-    const int nkt = (k_end - k_begin + BK - 1) / BK;
-    const int krot = ((g.prio & 2) && nkt > 1 && (k_end - k_begin) % BK == 0) ? (bx + by) % nkt : 0;
 
     f32x16 acc[FM][2];
 #pragma unroll
@@ -222,7 +213,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             }
         };
         bf16x8 fa0[FM], fb0[2], fa1[FM], fb1[2];
-        if (g.prio & 1) __builtin_amdgcn_s_setprio(2);      // over the co-resident workgroups' waves that are staging / storing
+        if (g.prio) __builtin_amdgcn_s_setprio(2);      // over the co-resident workgroups' waves that are staging / storing
         load_frags(0, fa0, fb0);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; kk += 2) {
@@ -235,7 +226,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
             mfmas(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (g.prio & 1) __builtin_amdgcn_s_setprio(0);
+        if (g.prio) __builtin_amdgcn_s_setprio(0);
     };
 
     if constexpr (NSEG >= 2) {
@@ -285,7 +276,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
                 }
             };
             bf16x8 fa0[FM], fa20[FM], fb0[2], fb20[2], fa1[FM], fa21[FM], fb1[2], fb21[2];
-            if (g.prio & 1) __builtin_amdgcn_s_setprio(2);
+            if (g.prio) __builtin_amdgcn_s_setprio(2);
             load_frags(0, fa0, fa20, fb0, fb20);
 #pragma unroll
             for (int kk = 0; kk < BK / 16; kk += 2) {
@@ -298,50 +289,43 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bid_x, co
                 mfmas(fa1, fa21, fb1, fb21);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (g.prio & 1) __builtin_amdgcn_s_setprio(0);
+            if (g.prio) __builtin_amdgcn_s_setprio(0);
         };
-        pa += krot * stepA; pb += krot * stepB; pa2 += krot * stepA; pb2 += krot * stepB;
-        load_all(k_begin + krot * BK);
-        for (int it = 0; it < nkt; ++it) {
+        load_all(k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
             tile_store<AKC, BM>(sA, tid, ra);
             tile_store<BKC, BN>(sB, tid, rb);
             tile_store<BKC, BN>(sB2, tid, rb2);
             if constexpr (NSEG == 3) tile_store<AKC, BM>(sA2, tid, ra2);
             __syncthreads();
-            if (it + 1 < nkt) {
-                const int nx = it + 1 + krot;
-                const long wa = nx == nkt ? -(long)(nkt - 1) : 1;          // (the rotated walk wraps to the first K-tile once)
-                pa += wa * stepA; pb += wa * stepB; pa2 += wa * stepA; pb2 += wa * stepB;
-                load_all(k_begin + (nx >= nkt ? nx - nkt : nx) * BK);
+            if (k0 + BK < k_end) {
+                pa += stepA; pb += stepB; pa2 += stepA; pb2 += stepB;
+                load_all(k0 + BK);
             }
             phase();
             __syncthreads();
         }
     } else {
         uint4 ra[BM / 32], rb[BN / 32];
-        pa += krot * stepA; pb += krot * stepB;
-        tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k_begin + krot * BK, g.M, k_end, g.partA, tid, ra);
-        tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin + krot * BK, g.N, k_end, g.partB, tid, rb);
+        tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k_begin, g.M, k_end, g.partA, tid, ra);
+        tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k_begin, g.N, k_end, g.partB, tid, rb);
 #ifdef GEMM_STAMPS
 #define GSTAMP(k) do { if (g.stamps && bid_x == 0 && bid_y == 0 && bid_z == 0 && lane == 0 && kt < 16) g.stamps[((tid >> 6) * 16 + kt) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
         int kt = 0;
 #else
 #define GSTAMP(k) do {} while (0)
 #endif
-        for (int it = 0; it < nkt; ++it) {
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
             GSTAMP(0);
             tile_store<AKC, BM>(sA, tid, ra);
             tile_store<BKC, BN>(sB, tid, rb);
             GSTAMP(1);
             __syncthreads();
             GSTAMP(2);
-            if (it + 1 < nkt) {                              // next K-tile in flight behind the MFMAs
-                const int nx = it + 1 + krot;
-                const long wa = nx == nkt ? -(long)(nkt - 1) : 1;
-                const int kn = k_begin + (nx >= nkt ? nx - nkt : nx) * BK;
-                pa += wa * stepA; pb += wa * stepB;
-                tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, kn, g.M, k_end, g.partA, tid, ra);
-                tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, kn, g.N, k_end, g.partB, tid, rb);
+            if (k0 + BK < k_end) {                           // next K-tile in flight behind the MFMAs
+                pa += stepA; pb += stepB;
+                tile_load<TA, TM, AKC, BM, EDGE>(pa, g.lda, m0, k0 + BK, g.M, k_end, g.partA, tid, ra);
+                tile_load<TB, TM, BKC, BN, EDGE>(pb, g.ldb, n0, k0 + BK, g.N, k_end, g.partB, tid, rb);
             }
             GSTAMP(3);
             mfma_phase(sA, sB);
@@ -610,7 +594,7 @@ extern "C" int sarssl_gemm(const void* A, const void* B, void* C, int dtA, int d
     // aux (the saved pre-activation of a fused activation backward) has C's dtype, or fp16 next to a bf16 C (fp16-forward mode)
     SARSSL_REQUIRE(!aux || aux_dtype == dtC || (aux_dtype == SARSSL_F16 && dtC == SARSSL_BF16), "sarssl_gemm(aux dtype)");
     g.aux_f16 = (aux && aux_dtype == SARSSL_F16 && dtC == SARSSL_BF16) ? 1 : 0;
-    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3) | gemm_krot();
+    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K;
     g.row_shift = 0; g.csum_ws = nullptr; g.A2 = nullptr; g.B2 = nullptr; g.nseg = 0;
 #ifdef GEMM_STAMPS
@@ -734,7 +718,7 @@ extern "C" int sarssl_gemm_split(const void* A, const void* A_lo, const void* B,
     g.alpha = 1.f; g.out_scale = out_scale; g.bias = bias; g.act = act;
     g.resid = resid; g.ldr = ldr; g.sR0 = g.sR1 = 0; g.res_scale = res_scale;
     g.preact = preact; g.aux = nullptr; g.aux_act = 0; g.aux_f16 = 0; g.acc_ws = nullptr; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
-    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3) | gemm_krot();
+    g.p_drop = p_drop; g.seed = seed; g.salt = sarssl_dropout_salt(); g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
     g.split_k = 0; g.k_per_split = K; g.row_shift = 0; g.csum_ws = nullptr;
     // segments: (A, B) [, (A_lo, B)] [, (A, B_lo)] - the kernel reads A2 in segment 1 of 3 and B2 in the last of 2 or 3
     SARSSL_REQUIRE(!A_lo || B_lo, "sarssl_gemm_split(A_lo needs B_lo)");
@@ -777,7 +761,7 @@ extern "C" int sarssl_gemm_group_tn(const void* const* A, const void* const* B, 
         g.alpha = 1.f; g.out_scale = 1.f; g.bias = nullptr; g.act = 0;
         g.resid = nullptr; g.ldr = 0; g.sR0 = g.sR1 = 0; g.res_scale = 0.f;
         g.preact = nullptr; g.aux = nullptr; g.aux_act = 0; g.aux_f16 = 0; g.acc_ws = ws[q]; g.acc_in = 0; g.acc_out = 0; g.partA = 0; g.partB = 0;
-        g.p_drop = 0.f; g.seed = 0; g.salt = nullptr; g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3) | gemm_krot();
+        g.p_drop = 0.f; g.seed = 0; g.salt = nullptr; g.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 3);
         g.split_k = ns; g.k_per_split = per; g.row_shift = 0; g.A2 = nullptr; g.B2 = nullptr; g.nseg = 0;
         g.csum_ws = csum_ws ? csum_ws[q] : nullptr;
         a.gx[q] = (N[q] + BN - 1) / BN; a.gy[q] = (M[q] + 127) / 128;
