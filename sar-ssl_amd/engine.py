@@ -137,7 +137,7 @@ _H_CTX = os.environ.get("SARSSL_HYBRID_CTX", "1") != "0"        # the attention 
 # Which Linear layers fed by a LayerNorm contract the ACTIVATION as a pair (three products) instead of its fp16 rounding (two).  The CPU
 # study (profiles/r06_operand_rounding_study.txt) says the pair buys no per-bin accuracy where the layer's OUTPUT is an fp16 tensor (q / k /
 # v, the feed-forward hidden layer: rms 1.02e-4 -> 1.06e-4 eval, 2.02e-4 -> 2.05e-4 train) - measured on the GPU (profiles/
-# r06_hybrid_alo_ab.txt) the per-bin figures hold (F13 train max 5.6e-4 -> 7.3e-4, inside the 1e-3 gate) but the GRADIENT deviation of the
+# r06_hybrid_alo_ab.txt) the per-bin figures hold (F13 train max 5.6e-4 -> 7.3e-4 on that build, inside the 1e-3 gate) but the GRADIENT deviation of the
 # f32-stream parameters grows 2.1e-3 -> 5.7e-3 / 6.9e-3 (the positional projection's weight, the convolution module's LayerNorm bias) for
 # 0.05 ms per family of an 11.1 ms step.  Not worth it: every family keeps the pair by default; "pw1,dec1" is the 0.1 ms faster setting.
 _H_ALO = set(v for v in os.environ.get("SARSSL_HYBRID_ALO", "ffn1,qkv,pw1,dec1").split(",") if v != "none" and v)

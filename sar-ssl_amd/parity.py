@@ -27,11 +27,11 @@ GATES = {
     # matrix cores): the mode that meets north_star's 1e-3 per bin at 16-bit matrix-core speed
     # grad_norm: worst parameter overall - always one whose gradient is a near-cancelling sum formed by the bf16 backward pass (BatchNorm
     # betas of the stem, the attention module's u / v biases: measured 0.7-1.1e-2 on F3 / F14, same as the fp16 mode's); grad_norm_body: the
-    # parameters outside the stem and those biases, whose gradients flow along the f32 stream (measured <= 2.1e-3; fp16 mode: 1.7e-2)
+    # parameters outside the stem and those biases, whose gradients flow along the f32 stream (measured 2.1e-3 on F14 / F3 eval, 3.4e-3 F3 train, <= 4.5e-3 on F15; fp16 mode: 1.7e-2)
     "hybrid": dict(loss=1e-3, per_bin_max=1e-3, per_bin_rms=3e-4, grad_norm=1.5e-2, grad_norm_body=5e-3, bn_running=5e-4, curve100=1e-3,
-                   measured=dict(loss=(1.5e-6, 3.5e-6), per_bin_max=(3.3e-4, 9.0e-4), per_bin_rms=(7.6e-5, 2.2e-4), grad_norm=(7.0e-3, 9.6e-3),
-                                 grad_norm_body=(1.6e-3, 2.1e-3), curve100=1.9e-4,
-                                 b64_f13=dict(per_bin_max=(2.5e-4, 5.6e-4), per_bin_rms=(7.0e-5, 1.6e-4)))),
+                   measured=dict(loss=(1.1e-6, 1.0e-6), per_bin_max=(3.3e-4, 8.5e-4), per_bin_rms=(7.6e-5, 2.2e-4), grad_norm=(1.03e-2, 9.6e-3),
+                                 grad_norm_body=(2.1e-3, 3.4e-3), curve100=1.9e-4,
+                                 b64_f13=dict(per_bin_max=(2.6e-4, 6.5e-4), per_bin_rms=(7.0e-5, 1.6e-4)))),
     # fp16 forward / bf16 backward - the mode bench.py times since round 4
     "fp16": dict(loss=1e-3, per_bin_max=1.5e-3, per_bin_rms=5e-4, grad_norm=2.5e-2, bn_running=5e-4, curve100=1e-3,
                  measured=dict(loss=(6.1e-6, 9.6e-7), per_bin_max=(9.1e-4, 1.21e-3), grad_norm=(1.5e-2, 7.9e-3), curve100=1.9e-4)),
