@@ -141,6 +141,7 @@ _H_CTX = os.environ.get("SARSSL_HYBRID_CTX", "1") != "0"        # the attention 
 # f32-stream parameters grows 2.1e-3 -> 5.7e-3 / 6.9e-3 (the positional projection's weight, the convolution module's LayerNorm bias) for
 # 0.05 ms per family of an 11.1 ms step.  Not worth it: every family keeps the pair by default; "pw1,dec1" is the 0.1 ms faster setting.
 _H_ALO = set(v for v in os.environ.get("SARSSL_HYBRID_ALO", "ffn1,qkv,pw1,dec1").split(",") if v != "none" and v)
+_H_PREP = os.environ.get("SARSSL_HYBRID_PREP", "1") != "0"      # 0: the hybrid mode's positional projections / patch pair formed at their point of use
 _H_FFN2_FWD = os.environ.get("SARSSL_HYBRID_FFN2_FWD", "1") != "0"   # the feed-forward module's forward on the f32 stream in one launch (d = 256, csrc/ffn2h.hip; 0: LayerNorm + two GEMMs)
 _H_FFN2_BWD = os.environ.get("SARSSL_HYBRID_FFN2_BWD", "1") != "0"   # the feed-forward module's data gradients in the fused launch (d = 256; 0: two GEMMs)
 _H_DLN32 = os.environ.get("SARSSL_HYBRID_DLN32", "1") != "0"    # branch gradients entering the LayerNorm backward in f32 (0: bf16)
@@ -744,11 +745,16 @@ def prepare_step_weights(net, F, T, need_bwd=True):
     for enc in encs:
         pe = enc.patch_embed
         _taps(pe[3]); _taps(pe[6])
-        _patch_w(pe[12], F)
+        if RT.hybrid and _H_PREP:
+            _patch_w_pair(pe[12], F)                         # (the forward's operand; the backward takes the gradient-side matrix below)
+        else:
+            _patch_w(pe[12], F)
         if need_bwd:
             _patch_w(pe[12], F, grad=True)
         for blk in enc.embed.layers:
-            _pos_proj(blk.sequential[1].module, T)
+            # hybrid: the pair-accurate projection is what both passes use (round 6: it used to be formed inside the blocks' chains - four
+            # 12-19 us launches - while the fp16 mode's projection was still formed here, unused)
+            (_pos_proj_h if (RT.hybrid and _H_PREP) else _pos_proj)(blk.sequential[1].module, T)
 
 
 def _adjacent(ts):
