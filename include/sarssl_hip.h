@@ -244,6 +244,11 @@ int sarssl_relpos_attn_pos_supported(int T, int dh);
 int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos, long ldp,
                                void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh, float scale,
                                float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias, int dtype, void* stream);
+/*      hybrid mode: the context also leaves as an fp16 pair - ctx_lo [B*T][ldc] = fp16(c - fp16(c)) of the unrounded f32 context c, the
+ *      lo operand of the output projection (attention.py:101) - instead of a sarssl_split_pair pass over ctx32.  fp16 tensors. */
+int sarssl_relpos_attn_fwd_pos_pair(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos, long ldp,
+                                    void* bias_out, void* ctx, void* ctx_lo, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh,
+                                    float scale, float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias, void* stream);
 /*      round 6: the same for T > 256 (T % 8 == 0, d_head 64 | 128; BASELINE config 5: T = 624) - the slab of the shifted score covers one
  *      256-key block at a time, the position tiles that can reach it stream from memory.  qu / qv: the biased projections (q + u_bias,
  *      q + v_bias as sarssl_bias2 stores them); bias_out (may be NULL) = the (B,H,T,T) shifted score sarssl_relpos_attn_bwd reads.

@@ -24,6 +24,8 @@ struct AttnArgs {
     const h16* k; const h16* v; long ldk;
     const h16* bias;                   // (B,H,T,T) shifted positional score (unscaled)
     h16* ctx; long ldc;                // [B*T][ldc]
+    h16* ctx_lo;                       // (hybrid mode, optional; rows as ctx) fp16(ctx_f32 - fp16(ctx_f32)): ctx + ctx_lo is the pair operand of the
+                                       // output projection - written here instead of a separate pass over ctx32
     float* ctx32;                      // [B*T][H*DH] f32 copy of ctx before rounding (forward out, backward in): D_i = dctx_i . ctx_i
                                        // enters dS as a small difference (flat softmax: 1/sqrt(d_model) scaling), so it must not
                                        // carry the bf16 rounding of ctx
@@ -499,6 +501,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(((DH <=
                 u.y = H16<TA>::pack(v.z, v.w);
                 *(uint2*)(out + c * 32 + 8 * g + 4 * half) = u;
                 if (out32) *(float4*)(out32 + c * 32 + 8 * g + 4 * half) = v;
+                if (a.ctx_lo) {
+                    uint2 l;
+                    l.x = H16<TA>::pack(v.x - H16<TA>::lo(u.x), v.y - H16<TA>::hi(u.x));
+                    l.y = H16<TA>::pack(v.z - H16<TA>::lo(u.y), v.w - H16<TA>::hi(u.y));
+                    *(uint2*)(a.ctx_lo + ((long)b * T + i) * a.ldc + h * DH + c * 32 + 8 * g + 4 * half) = l;
+                }
             }
     }
 }
@@ -1082,17 +1090,17 @@ static int sarssl_attn_fwd_waves() {          // SARSSL_ATTN_FWD_WAVES=4: the fo
 extern "C" int sarssl_relpos_attn_pos_supported(int T, int dh) { return (T > 0 && T <= 256 && T % 8 == 0 && (dh == 32 || dh == 64 || dh == 128)) ? 1 : 0; }
 // u_bias / v_bias (both or neither; f32 [H*dh]): qu and qv are then the SAME plain query projection q and the kernels form q + u / q + v
 // while loading (the values sarssl_bias2 would have stored).
-extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
-                                          long ldp, void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh,
-                                          float scale, float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias,
-                                          int dtype, void* stream) {
+static int attn_fwd_pos_impl(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
+                             long ldp, void* bias_out, void* ctx, void* ctx_lo, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh,
+                             float scale, float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias,
+                             int dtype, void* stream) {
     SARSSL_REQUIRE((u_bias == nullptr) == (v_bias == nullptr) && (!u_bias || qu == qv), "sarssl_relpos_attn_fwd_pos(u_bias / v_bias)");
     if (attn_check(B, H, T, dh, ldq, ldk, "sarssl_relpos_attn_fwd_pos")) return -1;
     SARSSL_REQUIRE(sarssl_relpos_attn_pos_supported(T, dh) && ldp % 8 == 0 && qv && pos, "sarssl_relpos_attn_fwd_pos(T <= 256)");
     SARSSL_REQUIRE(ldc % 4 == 0 && lse != nullptr && (dtype == SARSSL_BF16 || dtype == SARSSL_F16), "sarssl_relpos_attn_fwd_pos");
     AttnArgs a = {};
     a.qu = (const h16*)qu; a.qv = (const h16*)qv; a.ldq = ldq; a.k = (const h16*)k; a.v = (const h16*)v; a.ldk = ldk;
-    a.pos = (const h16*)pos; a.ldp = ldp; a.bias_out = (h16*)bias_out; a.ub = u_bias; a.vb = v_bias;
+    a.pos = (const h16*)pos; a.ldp = ldp; a.bias_out = (h16*)bias_out; a.ub = u_bias; a.vb = v_bias; a.ctx_lo = (h16*)ctx_lo;
     a.ctx = (h16*)ctx; a.ldc = ldc; a.ctx32 = ctx32; a.lse = lse; a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.salt = sarssl_dropout_salt();
     dim3 grid((T + 127) / 128, B * H);
     hipStream_t st = (hipStream_t)stream;
@@ -1114,6 +1122,23 @@ extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long l
     }
     SARSSL_CHECK_LAUNCH("relpos_attn_fwd_kernel<pos>");
     return 0;
+}
+
+extern "C" int sarssl_relpos_attn_fwd_pos(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
+                                          long ldp, void* bias_out, void* ctx, long ldc, float* ctx32, float* lse, int B, int H, int T, int dh,
+                                          float scale, float p_drop, unsigned long long seed, const float* u_bias, const float* v_bias,
+                                          int dtype, void* stream) {
+    return attn_fwd_pos_impl(qu, qv, ldq, k, v, ldk, pos, ldp, bias_out, ctx, nullptr, ldc, ctx32, lse, B, H, T, dh, scale, p_drop, seed, u_bias, v_bias,
+                             dtype, stream);
+}
+// ... with the context also written as an fp16 PAIR (hybrid mode): ctx_lo [B*T][ldc] = fp16(c - fp16(c)) of the unrounded f32 context c
+extern "C" int sarssl_relpos_attn_fwd_pos_pair(const void* qu, const void* qv, long ldq, const void* k, const void* v, long ldk, const void* pos,
+                                               long ldp, void* bias_out, void* ctx, void* ctx_lo, long ldc, float* ctx32, float* lse, int B, int H,
+                                               int T, int dh, float scale, float p_drop, unsigned long long seed, const float* u_bias,
+                                               const float* v_bias, void* stream) {
+    SARSSL_REQUIRE(ctx_lo != nullptr, "sarssl_relpos_attn_fwd_pos_pair");
+    return attn_fwd_pos_impl(qu, qv, ldq, k, v, ldk, pos, ldp, bias_out, ctx, ctx_lo, ldc, ctx32, lse, B, H, T, dh, scale, p_drop, seed, u_bias, v_bias,
+                             SARSSL_F16, stream);
 }
 
 // The same for T > 256 (T % 8 == 0; the slab covers one 256-key block at a time): qu / qv must be the biased projections (no u_bias /

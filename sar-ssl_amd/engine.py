@@ -831,7 +831,7 @@ def _mhsa_fwd_h(x, mod, B, T, train, saved):
     if fused_attn:
         if in_kernel:
             ctx, lse, bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, biases=(ub, vb),
-                                                     want_ctx32=_H_CTX)
+                                                     pair=_H_CTX)            # (the kernel writes the context's lo half itself)
         elif _ATTN_POS_LONG and hip.relpos_attn_pos_long_supported(T, dh, RT.dtype):
             ctx, lse, bias = hip.relpos_attn_fwd_pos_long(qu, qv, k, v, pos, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, want_ctx32=_H_CTX)
         else:
@@ -841,7 +841,10 @@ def _mhsa_fwd_h(x, mod, B, T, train, saved):
             ctx, lse = hip.relpos_attn_fwd(qu, k, v, bias, B, H, T, dh, scale, pa, sa, need_bwd=not RT.inference, want_ctx32=_H_CTX)
         so = RT.next_seed() if po > 0 else 0
         # the kernel's unrounded f32 context (it keeps it for the backward pass anyway) enters the output projection as a pair
-        cin = hip.Pair(ctx, hip.split_pair(lse[0], want_hi=False)) if (_H_CTX and lse[0] is not None) else ctx
+        if isinstance(ctx, hip.Pair):
+            cin, ctx = ctx, ctx.hi
+        else:
+            cin = hip.Pair(ctx, hip.split_pair(lse[0], want_hi=False)) if (_H_CTX and lse[0] is not None) else ctx
         y = mm_nt_h(cin, wo, _F32, bias=att.out_proj.linear.bias.data, p_drop=po, seed=so, resid=x, ldr=x.stride(0), res_scale=1.0)
         saved.append((x, ln.hi, stats, qu, qv, k, v, pos, pe, bias, lse, pa, sa, ctx, po, so, B, T))
         return y

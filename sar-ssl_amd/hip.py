@@ -1355,10 +1355,11 @@ def relpos_attn_pos_supported(T, dh, dtype):
     return dtype in _16 and bool(_lib.lib().sarssl_relpos_attn_pos_supported(c_int(T), c_int(dh)))
 
 
-def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True, biases=None, want_ctx32=False):
+def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=0, need_bwd=True, biases=None, want_ctx32=False, pair=False):
     """relpos_attn_fwd with the shifted positional score (qv pos^T, relative shift) formed inside the kernel.  Returns
     ctx, (ctx32, lse), bias ((B,H,T,T) as the kernel used it; None when need_bwd is False).
-    biases = (u, v) f32 [H*dh]: qu and qv are then the same plain query projection q, the kernel adds the biases while loading."""
+    biases = (u, v) f32 [H*dh]: qu and qv are then the same plain query projection q, the kernel adds the biases while loading.
+    pair (fp16 tensors): the context as a Pair - the kernel also writes fp16(c - fp16(c)) of its unrounded f32 context."""
     _need_cuda(qu, qv, k, v, pos)
     ub, vb = biases if biases is not None else (None, None)
     assert biases is None or (qu.data_ptr() == qv.data_ptr() and ub.dtype == torch.float32 and vb.dtype == torch.float32 and
@@ -1369,6 +1370,13 @@ def relpos_attn_fwd_pos(qu, qv, k, v, pos, B, H, T, dh, scale, p_drop=0.0, seed=
     ctx32 = torch.empty((B * T, H * dh), dtype=torch.float32, device=qu.device) if (need_bwd or want_ctx32) else None
     bias = torch.empty((B, H, T, T), dtype=qu.dtype, device=qu.device) if need_bwd else None
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qu.device)
+    if pair:
+        assert qu.dtype == torch.float16
+        lo = torch.empty_like(ctx)
+        _lib.call("sarssl_relpos_attn_fwd_pos_pair", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),
+                  c_long(pos.stride(0)), _p(bias), _p(ctx), _p(lo), c_long(ctx.stride(0)), _p(ctx32), _p(lse), c_int(B), c_int(H), c_int(T),
+                  c_int(dh), c_float(scale), c_float(p_drop), c_ulonglong(seed), _p(ub), _p(vb), _stream())
+        return Pair(ctx, lo), (ctx32, lse), bias
     _lib.call("sarssl_relpos_attn_fwd_pos", _p(qu), _p(qv), c_long(qu.stride(0)), _p(k), _p(v), c_long(k.stride(0)), _p(pos),
               c_long(pos.stride(0)), _p(bias), _p(ctx), c_long(ctx.stride(0)), _p(ctx32), _p(lse), c_int(B), c_int(H), c_int(T), c_int(dh),
               c_float(scale), c_float(p_drop), c_ulonglong(seed), _p(ub), _p(vb), c_int(dt(qu)), _stream())

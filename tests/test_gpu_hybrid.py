@@ -185,3 +185,28 @@ def test_fused_feed_forward_on_the_f32_stream_equals_the_unfused_sequence(train,
             check(tag + ".y_vs_f64", _rel(yf, ref), 2e-4)
     finally:
         runtime.set_precision("bf16")
+
+
+@pytest.mark.parametrize("T,dh,H", [(256, 64, 4), (256, 128, 4), (128, 64, 4)])
+def test_attention_forward_writes_the_context_pair(T, dh, H):
+    """sarssl_relpos_attn_fwd_pos_pair: the same launch as sarssl_relpos_attn_fwd_pos, plus the lo half of its unrounded f32 context -
+    bit for bit what sarssl_split_pair makes of ctx32 (the separate pass it replaces in the hybrid mode's attention module)."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    B, d = 3, H * dh
+    g = torch.Generator().manual_seed(11)
+    q, k, v = [(torch.randn(B * T, d, generator=g) * 0.7).half().to(dev) for _ in range(3)]
+    pos = (torch.randn(T, d, generator=g) * 0.7).half().to(dev)
+    ub, vb = (torch.randn(d, generator=g) * 0.1).to(dev), (torch.randn(d, generator=g) * 0.1).to(dev)
+    scale = d ** -0.5
+    for p_drop in (0.0, 0.1):
+        ctx, (c32, lse), bias = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, p_drop, 77, biases=(ub, vb), want_ctx32=True)
+        pr, (c32p, lsep), biasp = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, p_drop, 77, biases=(ub, vb), pair=True)
+        assert isinstance(pr, hip.Pair) and torch.equal(pr.hi, ctx) and torch.equal(c32p, c32) and torch.equal(lsep, lse) and torch.equal(biasp, bias)
+        ref = hip.split_pair(c32)
+        assert torch.equal(ref.hi, ctx) and torch.equal(pr.lo, ref.lo)
+        # inference: no f32 copy is kept next to the pair
+        pi, (c32i, _), bi = hip.relpos_attn_fwd_pos(q, q, k, v, pos, B, H, T, dh, scale, 0.0, 0, need_bwd=False, biases=(ub, vb), pair=True)
+        assert c32i is None and bi is None
+        if p_drop == 0.0:
+            assert torch.equal(pi.hi, ctx) and torch.equal(pi.lo, pr.lo)
