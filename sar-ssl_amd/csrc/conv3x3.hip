@@ -32,10 +32,6 @@
 #define X_ELEMS (NPIX_H * 64)
 #define Y_ELEMS (TR * TCOL * 64)
 
-static int conv_wrot() {
-    static const int v = [] { const char* e = getenv("SARSSL_CONV_WROT"); return e ? atoi(e) : 1; }();
-    return v;
-}
 struct ConvArgs {
     const void* in; const void* w; void* out;
     float* acc_ws; int acc_in, acc_out;
@@ -48,7 +44,6 @@ struct ConvArgs {
     const void* bn_y;   // (B,F,T,64) pre-BN activations of the layer whose input gradient this launch produces
     const float* bn_aff;    // [4][64]: scale, shift, mean, rstd
     int prio;           // != 0: raise the wave's issue priority for its MFMA phase (s_setprio), see sarssl_mfma_prio()
-    int wrot;           // != 0: rotated start of the weight-table copy per workgroup (SARSSL_CONV_WROT)
     // first-layer INPUT mode of the ping-pong kernel (C1IN): `in` is the stem's 4-channel input a0 (B,F,T,4) and the convolution runs
     // on relu(bn1(W1 a0)) formed while staging (c1_w = W1 f32[64][4], scale / shift = bn1's affine) - the 64-channel output of the
     // first 1x1 layer is never stored or read (2 x 537 MB per encoder and pass at B = 64)
@@ -478,11 +473,7 @@ __global__ __launch_bounds__(512) void conv3x3_fwd_pp_kernel(ConvArgs a) {
     const int cch = tid & 7;
     {
         const T* w = (const T*)a.w;
-        // (every workgroup copies the same 72 KB: the CUs of an XCD - workgroups b, b + 8, ... - start at different eighths of the table so
-        //  that they do not ask the L2 for the same lines at the same time)
-        const int q0 = a.wrot ? (int)((blockIdx.x >> 3) & 7) * (9 * 64) : 0;
-        for (int qq = tid; qq < 9 * 64 * 8; qq += 512) {
-            const int q = qq + q0 < 9 * 64 * 8 ? qq + q0 : qq + q0 - 9 * 64 * 8;
+        for (int q = tid; q < 9 * 64 * 8; q += 512) {
             const int p = q >> 3, c = q & 7;
             *(uint4*)&sW[swz(p, c)] = *(const uint4*)(w + (long)p * 64 + c * 8);
         }
@@ -900,9 +891,7 @@ __global__ __launch_bounds__(768) void conv3x3_fwd_ws_kernel(ConvArgs a) {
     const int cch = tid & 7;
     {
         const T* w = (const T*)a.w;
-        const int q0 = a.wrot ? (int)((blockIdx.x >> 3) & 7) * (9 * 64) : 0;
-        for (int qq = tid; qq < 9 * 64 * 8; qq += 768) {
-            const int q = qq + q0 < 9 * 64 * 8 ? qq + q0 : qq + q0 - 9 * 64 * 8;
+        for (int q = tid; q < 9 * 64 * 8; q += 768) {
             const int p = q >> 3, c = q & 7;
             *(uint4*)&sW[swz(p, c)] = *(const uint4*)(w + (long)p * 64 + c * 8);
         }
@@ -1937,7 +1926,6 @@ extern "C" int sarssl_conv3x3_fwd_c1(const void* a0, const float* W1, const floa
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
-    a.wrot = conv_wrot();
     a.clk = conv_clk() ? conv_clk() + 4 * 3 : nullptr;
     a.stats = stats;
     a.in = a0; a.w = w; a.out = out; a.scale = scale; a.shift = shift; a.prologue = 1; a.c1_w = W1;
@@ -1967,7 +1955,6 @@ extern "C" int sarssl_conv3x3_dgrad_c1red(const void* dy, const void* w, const v
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
-    a.wrot = conv_wrot();
     a.clk = conv_clk() ? conv_clk() + 4 * 4 : nullptr;
     a.in = dy; a.w = w; a.out = nullptr; a.scale = scale; a.shift = shift; a.prologue = 0; a.c1_w = W1; a.c1_a0 = a0; a.c1_red = red;
     a.nb = nb; a.F = F; a.T = T;
@@ -1992,7 +1979,6 @@ static int conv3x3_launch(const void* in, const void* w, void* out, int dtype, i
     a.stamps = g_conv_stamps_host;
 #endif
     a.prio = (sarssl_mfma_prio() == 1 || sarssl_mfma_prio() == 2);
-    a.wrot = conv_wrot();
     a.clk = conv_clk() ? conv_clk() + 4 * (bn_y ? 2 : (scale != nullptr ? 0 : 1)) : nullptr;
     a.bn_y = bn_y; a.bn_aff = bn_aff;
     a.stats = stats;
