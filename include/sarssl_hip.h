@@ -480,6 +480,11 @@ int sarssl_masked_mse_bwd(const void* pred, const float* x, const unsigned char*
  *      sarssl_masked_mse_bwd_compact: the stand-alone gradient, scaled by gscale * (*gscale_dev). */
 int sarssl_gather_rows(const void* src, long ld_src, const int* idx, int nb, int Tn, int nm, int d, void* dst, int dtype, void* stream);
 int sarssl_scatter_rows(const void* src, const int* idx, int nb, int Tn, int nm, int d, void* dst, long ld_dst, int dtype, void* stream);
+/*      hybrid mode: scatter of an f32 gradient [nb * nm][d] that also writes the bf16 operand of the next module of the backward chain with
+ *      its dropout backward applied - dst16 = bf16(bf16(v) * gscale * keep(seed, index in the FULL tensor)), zeros elsewhere (both
+ *      destinations [nb * Tn][d] contiguous, zeroed first); replaces sarssl_scatter_rows + sarssl_cast + sarssl_act_bwd over the full tensor */
+int sarssl_scatter_rows_drop16(const float* src, const int* idx, int nb, int Tn, int nm, int d, float* dst32, void* dst16, float p_drop,
+                               unsigned long long seed, float gscale, void* stream);
 int sarssl_masked_mse_compact(const void* pred_c, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm, double* sums,
                               float* out, float* out_keep, double* acc, void* dpred_c, int dtype, void* stream);
 int sarssl_masked_mse_bwd_compact(const void* pred_c, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,

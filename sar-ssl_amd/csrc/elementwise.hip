@@ -1297,6 +1297,42 @@ extern "C" int sarssl_scatter_rows(const void* src, const int* idx, int nb, int 
     SARSSL_CHECK_LAUNCH("scatter_rows_kernel");
     return 0;
 }
+// Hybrid mode, block tails on the gathered rows: the f32 stream gradient src [nb * nm][d] goes back to its frames (dst32, zeros elsewhere)
+// AND leaves as the bf16 operand of the next module of the backward chain with that module's dropout backward applied (dst16 =
+// bf16(bf16(v) * gscale * keep(seed, full-tensor index)), zeros elsewhere) - what sarssl_scatter_rows + sarssl_cast + sarssl_act_bwd
+// computed in three passes over the FULL tensor (bit-identical: same roundings in the same order).
+__global__ void scatter_rows_drop16_kernel(const float* __restrict__ src, const int* __restrict__ idx, int nb, int Tn, int nm, int d,
+                                           float* __restrict__ dst32, bf16* __restrict__ dst16, float p_drop, unsigned long long seed0,
+                                           float gscale, const unsigned long long* __restrict__ salt) {
+    const unsigned long long seed = salted_seed(seed0, salt);
+    const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    const int cpr = d >> 2;
+    const long total = (long)nb * nm * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr);
+        const long r = i / cpr;
+        const int b = (int)(r / nm);
+        const long o = ((long)b * Tn + idx[r]) * d + c * 4;
+        const float4 v = *(const float4*)(src + r * d + c * 4);
+        *(float4*)(dst32 + o) = v;
+        float kp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p_drop > 0.f) dropout_scale4(seed, (unsigned long long)o, p_drop, inv_keep, kp);
+        st4(dst16 + o, make_float4(round_as<bf16>(v.x) * gscale * kp[0], round_as<bf16>(v.y) * gscale * kp[1],
+                                   round_as<bf16>(v.z) * gscale * kp[2], round_as<bf16>(v.w) * gscale * kp[3]));
+    }
+}
+extern "C" int sarssl_scatter_rows_drop16(const float* src, const int* idx, int nb, int Tn, int nm, int d, float* dst32, void* dst16,
+                                          float p_drop, unsigned long long seed, float gscale, void* stream) {
+    SARSSL_REQUIRE(nb > 0 && nm > 0 && d > 0 && d % 8 == 0 && src && dst32 && dst16, "sarssl_scatter_rows_drop16");
+    if (hipMemsetAsync(dst32, 0, (size_t)nb * Tn * d * 4, ST) != hipSuccess || hipMemsetAsync(dst16, 0, (size_t)nb * Tn * d * 2, ST) != hipSuccess) {
+        sarssl_set_error("memset");
+        return -2;
+    }
+    scatter_rows_drop16_kernel<<<nblocks_for((long)nb * nm * (d / 4), 256, 8192), 256, 0, ST>>>(src, idx, nb, Tn, nm, d, dst32, (bf16*)dst16, p_drop, seed,
+                                                                                            gscale, sarssl_dropout_salt());
+    SARSSL_CHECK_LAUNCH("scatter_rows_drop16_kernel");
+    return 0;
+}
 // loss (and, dpred != null, its gradient for an incoming gradient of 1) on the compact prediction pred_c [nb][nm][F * 4]; idx must be
 // ascending per item.  dtype as sarssl_masked_mse_fwd (dpred == null) / sarssl_masked_mse_fwd_bwd (dpred != null).
 extern "C" int sarssl_masked_mse_compact(const void* pred_c, const float* x, const int* idx, const int* mch, int nb, int F, int Tn, int nm,

@@ -660,7 +660,7 @@ def _next_drop(kind, saved):
     is on top of ``saved``) applies to its incoming gradient, or None when there is nothing to apply (or the masks are replayed host
     tensors).  The LayerNorm backward that produces that gradient then writes the dropped copy as a second output
     (hip.layernorm_bwd(drop=...)) instead of a separate act_bwd pass."""
-    if not _FUSE_DROP_BWD or kind is None or not saved:
+    if not _FUSE_DROP_BWD or kind is None or kind == "copy" or not saved:
         return None
     e = saved[-1]
     if kind == "ffn":
@@ -1219,7 +1219,9 @@ def block_fwd(x, blk, B, T, train, saved, out=None, next_blk=None, rows=None):
     return y
 
 
-def block_bwd(dy, blk, saved):
+def block_bwd(dy, blk, saved, first=False):
+    """first (hybrid mode): ``blk`` is the encoder's first block - its input gradient goes to the frame-patch GEMMs, which take it in bf16;
+    the block's last LayerNorm backward writes that copy next to the f32 gradient (attribute ``_g16``) instead of a cast pass."""
     seq = blk.sequential
     top = saved.pop()
     x, stats = top[0], top[1]
@@ -1236,12 +1238,22 @@ def block_bwd(dy, blk, saved):
                                            drop=_next_drop("ffn", saved)))
         if rows is not None:    # the tail ran on the gathered rows: its input gradient goes back to its frames, zeros elsewhere
             d = pair(ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind=None))[0]
-            d, dd = hip.scatter_rows(d, rows[0], rows[1], rows[2]), None
+            drop = _next_drop("conv", saved) if (RT.hybrid and d.dtype == _F32) else None
+            if drop is not None:       # the scatter also writes the convolution module's bf16 operand (its dropout backward applied)
+                d, dd = hip.scatter_rows_drop16(d.contiguous(), rows[0], rows[1], rows[2], *drop)
+                dd._dropped = True
+            else:
+                d, dd = hip.scatter_rows(d, rows[0], rows[1], rows[2]), None
         else:
             d, dd = pair(ffn_bwd(d, seq[3].module, saved, dy_dropped=dd, next_kind="conv"))
         d, dd = pair(convmod_bwd(d, seq[2].module, saved, dy_dropped=dd, next_kind="mhsa"))
         d, dd = pair(mhsa_bwd(d, seq[1].module, saved, dy_dropped=dd, next_kind="ffn"))
-        d = pair(ffn_bwd(d, seq[0].module, saved, dy_dropped=dd))[0]
+        if first and RT.hybrid:
+            d, d16 = pair(ffn_bwd(d, seq[0].module, saved, dy_dropped=dd, next_kind="copy"))
+            if d16 is not None:
+                d._g16 = d16
+        else:
+            d = pair(ffn_bwd(d, seq[0].module, saved, dy_dropped=dd))[0]
     return d
 
 
@@ -1263,7 +1275,7 @@ def encoder_fwd(x, enc, B, T, train, saved, out=None):
 
 def encoder_bwd(dy, enc, saved):
     for blk in reversed(enc.layers):
-        dy = block_bwd(dy, blk, saved)
+        dy = block_bwd(dy, blk, saved, first=blk is enc.layers[0])
     return dy
 
 

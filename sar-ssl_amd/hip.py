@@ -1620,6 +1620,18 @@ def scatter_rows(src2d, idx_i32, B, T):
     return dst
 
 
+def scatter_rows_drop16(src2d, idx_i32, B, T, p_drop, seed, gscale=1.0):
+    """scatter_rows of an f32 [B*nm, d] gradient -> (dst f32 [B*T, d], dst16 bf16 [B*T, d]): dst16 = the bf16 copy with the dropout backward
+    (p_drop, seed, gscale; mask of the FULL tensor's element indices) applied - bit-identical to act_bwd(cast(scatter_rows(src)))."""
+    assert src2d.dtype == torch.float32 and src2d.is_contiguous()
+    nm, d = idx_i32.shape[1], src2d.shape[1]
+    dst = torch.empty((B * T, d), dtype=torch.float32, device=src2d.device)
+    dst16 = torch.empty((B * T, d), dtype=torch.bfloat16, device=src2d.device)
+    _lib.call("sarssl_scatter_rows_drop16", _p(src2d), _p(idx_i32), c_int(B), c_int(T), c_int(nm), c_int(d), _p(dst), _p(dst16), c_float(p_drop),
+              c_ulonglong(seed), c_float(gscale), _stream())
+    return dst, dst16
+
+
 def masked_mse_compact(pred_c, x, idx_i32, mch_i32, sink=None, with_grad=False):
     """masked_mse_fwd on the compact prediction pred_c (B*nm, F*4) (rows in ascending frame order) -> out f32[2] or (out, dpred_c)."""
     B, _, F, T, _ = x.shape

@@ -274,11 +274,11 @@ class _PretrainFn(torch.autograd.Function):
         d_spec = decat[:, :ds]
         hip.stamp("bwd.spec.block.begin")
         for blk in reversed(spe.embed.layers):
-            d_spec = engine.block_bwd(d_spec, blk, saved)
+            d_spec = engine.block_bwd(d_spec, blk, saved, first=blk is spe.embed.layers[0])
         hip.stamp("bwd.spec.block.end")
         cut = side is not None and getattr(net, "_cut_mode", False)   # graph capture cut at the bucket boundaries (graph.py): a cut
         with on_side():                                               # needs both streams joined, so the two hooks fire after the join
-            d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat)
+            d_spat = engine.block_bwd(d_spat, spa.embed.layers[0], saved_spat, first=True)
             dz_spat = engine.patch_bwd(d_spat, spa.patch_embed, saved_spat)
             hip.stamp("bwd.spat.blocks.end")
             if not cut:

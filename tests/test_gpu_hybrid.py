@@ -210,3 +210,19 @@ def test_attention_forward_writes_the_context_pair(T, dh, H):
         assert c32i is None and bi is None
         if p_drop == 0.0:
             assert torch.equal(pi.hi, ctx) and torch.equal(pi.lo, pr.lo)
+
+
+def test_scatter_with_the_dropped_bf16_copy_equals_the_three_passes():
+    """sarssl_scatter_rows_drop16 (block tails on the gathered rows, hybrid mode) = sarssl_scatter_rows + sarssl_cast + sarssl_act_bwd, bit for bit."""
+    from sar_ssl_amd import hip
+    dev = _dev()
+    B, T, nm, d = 5, 64, 23, 256
+    g = torch.Generator().manual_seed(3)
+    idx = torch.stack([torch.randperm(T, generator=g)[:nm].sort().values for _ in range(B)]).to(torch.int32).to(dev)
+    src = torch.randn(B * nm, d, generator=g).to(dev)
+    for p, gs in ((0.1, 0.5), (0.25, 1.0)):
+        full = hip.scatter_rows(src, idx, B, T)
+        want16 = hip.act_bwd(hip.cast(full, torch.bfloat16), None, 0, p_drop=p, seed=4242, gscale=gs)
+        d32, d16 = hip.scatter_rows_drop16(src, idx, B, T, p, 4242, gs)
+        assert torch.equal(d32, full) and d16.dtype == torch.bfloat16 and torch.equal(d16, want16)
+        assert (d16 == 0).float().mean().item() > 1.0 - nm / T - 1e-6          # (rows nobody scattered to stay zero)
