@@ -182,7 +182,7 @@ def test_backward_stage_hooks_fire_before_the_stem_backward(monkeypatch):
     off = (pw.grad.data_ptr() - flat.grad.data_ptr()) // 4
     assert spans["spec_encoder"][0] <= off < spans["spec_encoder"][1]
     log = []
-    monkeypatch.setattr(engine, "block_bwd", lambda d, blk, saved: (log.append("block"), d)[1])
+    monkeypatch.setattr(engine, "block_bwd", lambda d, blk, saved, first=False: (log.append("block"), d)[1])
     monkeypatch.setattr(engine, "patch_bwd", lambda d, pe, saved: (log.append("patch"), d)[1])
     monkeypatch.setattr(engine, "stem_bwd", lambda d, pe, saved: log.append("stem"))
     monkeypatch.setattr(engine, "decoder_bwd", lambda d, dec, saved, after_dx=None: (log.append("decoder"), torch.zeros(16, 768))[1])
